@@ -1,0 +1,79 @@
+"""Pins oracle/asr_oracle.py against the golden vectors produced by executing the real reference
+(oracle/gen_golden.py, run in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import asr_oracle as O
+
+CASES = ["vgg_tiny", "emb_tiny", "raw_tiny"]
+
+
+def load(golden_dir, name):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    w0 = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}
+    return z, w0
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_matches_reference_two_steps(golden_dir, name):
+    torch.set_num_threads(4)
+    z, w = load(golden_dir, name)
+    cfg = O.Cfg.from_flags(str(z["flags"]))
+    src, src_len, tgt = torch.from_numpy(z["src"]), torch.from_numpy(z["src_len"]), torch.from_numpy(z["tgt"])
+    sm = float(z["smoothing"])
+    names = O.trainable_names(w, cfg)
+    params = {k: w[k] for k in names}
+    opt = O.NoamAdam(params, model_size=int(z["dim_input"]))
+    bn = {}
+    r = O.train_step(w, cfg, src, src_len, tgt, sm, opt=opt, bn_state=bn)
+    np.testing.assert_allclose(r["pred"].numpy(), z["pred"], rtol=0, atol=2e-5)
+    assert np.array_equal(r["gold"].numpy(), z["gold"])
+    # Rows whose decoder input is EOS are zeroed (transformer.py:282,536) -> all V logits are exactly 0.
+    # torch.topk(pred, 1) (transformer.py:80) breaks that exact tie in a kernel-specific way (index 22 for
+    # V=35 on this CPU build); utils/metrics.py:89 (`pred.max(1)[1]`) and the oracle/product return the
+    # LOWEST index.  hyp is therefore compared on non-degenerate rows, and tied rows must give index 0.
+    tied = (z["pred"].max(-1) == z["pred"].min(-1))
+    assert np.array_equal(r["hyp"].numpy()[~tied], z["hyp_seq"][~tied])
+    assert (r["hyp"].numpy()[tied] == 0).all()
+    assert r["num_correct"] == int(z["num_correct"])
+    assert abs(r["loss"] - float(z["loss"])) < 2e-6
+    for k in names:
+        ref = z["g0/" + k]
+        tol = 1e-6 + 2e-5 * np.abs(ref).max()
+        np.testing.assert_allclose(r["grads"][k].numpy(), ref, rtol=0, atol=tol, err_msg=k)
+    assert abs(opt.rate - float(z["lr1"])) < 1e-12
+    if cfg.emb_trg_sharing:
+        w["decoder.output_linear.weight"] = w["decoder.trg_embedding.weight"]
+    r2 = O.train_step(w, cfg, src, src_len, tgt, sm, opt=opt, bn_state=bn)
+    assert abs(r2["loss"] - float(z["loss2"])) < 5e-6
+    assert abs(opt.rate - float(z["lr2"])) < 1e-12
+    for k in names:
+        # key_linear.bias gradients are mathematically zero (softmax is shift invariant); what autograd returns is
+        # ~1e-9 rounding noise that Adam normalises to a full +-lr update, so each side moves by up to lr per step: only |delta| <= 2*(lr1+lr2) is pinned.
+        atol = 2.1 * (float(z["lr1"]) + float(z["lr2"])) if k.endswith("key_linear.bias") else 5e-6
+        np.testing.assert_allclose(w[k].numpy(), z["w2/" + k], rtol=0, atol=atol, err_msg=k)
+    for k, v in bn.items():
+        np.testing.assert_allclose(np.asarray(v, dtype=np.float64), z["w2/" + k].astype(np.float64), rtol=1e-5, atol=1e-6)
+    # eval-mode forward with the updated weights (BatchNorm running stats for emb_cnn)
+    wl = dict(w); wl.update(bn)
+    pred, _, _ = O.transformer_forward(wl, cfg, src, src_len, tgt, training=False, bn_state=dict(bn))
+    np.testing.assert_allclose(pred.detach().numpy(), z["pred_eval"], rtol=0, atol=5e-5)
+
+
+def test_preprocess_strips_interior_pad(golden_dir):
+    z, _ = load(golden_dir, "raw_tiny")
+    tgt = torch.from_numpy(z["tgt"])
+    assert (tgt[1, 2] == 0) and (tgt[1, 3] != 0)
+    seq_in, seq_out = O.decoder_preprocess(tgt, 16)
+    assert np.array_equal(seq_out.numpy(), z["gold"])
+    assert seq_in[1, 0] == O.SOS and (seq_in[1] == O.EOS).sum() == 16 - 1 - 8
+
+
+def test_edit_distance_known_answers():
+    assert O.edit_distance("kitten", "sitting") == 3
+    assert O.edit_distance("", "abc") == 3
+    assert O.edit_distance("flaw", "lawn") == 2
+    assert O.edit_distance("abc", "abc") == 0
