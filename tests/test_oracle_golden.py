@@ -62,7 +62,7 @@ def test_oracle_matches_reference_two_steps(golden_dir, name):
         atol = 2.1 * (float(z["lr1"]) + float(z["lr2"])) if noise_driven(k, cfg) else 5e-6
         np.testing.assert_allclose(w[k].numpy(), z["w2/" + k], rtol=0, atol=atol, err_msg=k)
     for k, v in bn.items():
-        np.testing.assert_allclose(np.asarray(v, dtype=np.float64), z["w2/" + k].astype(np.float64), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(np.asarray(v, dtype=np.float64), z["w2/" + k].astype(np.float64), rtol=1e-5, atol=1e-5)  # running_mean carries the noise-driven conv bias
     # eval-mode forward with the updated weights (BatchNorm running stats for emb_cnn)
     wl = dict(w); wl.update(bn)
     pred, _, _ = O.transformer_forward(wl, cfg, src, src_len, tgt, training=False, bn_state=dict(bn))
