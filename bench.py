@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Throughput of the Transformer-ASR TRAINING STEP on MI355X (BASELINE.json metric: input spectrogram frames/s).
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): 4-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Transformer,
+synthetic spectrogram batch (B=32 per GPU, 1, 161, T_src=800) fp32, targets (B, 99) int64 padded to T_tgt=100,
+V=4364, label smoothing 0.1, dropout 0.1, bf16 kernels with fp32 accumulation; a step = zero_grad + forward +
+label-smoothed CE + backward (+ gradient all-reduce over RCCL when N > 1) + Noam/Adam update.  Inputs are resident in
+HBM before the timed region.  One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "end2end-asr-pytorch_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+V = 4364
+T_SRC, T_TGT, F_BINS = 800, 100, 161
+MODEL_FLAGS = ["--num-layers", "4", "--num-heads", "8", "--dim-model", "512", "--dim-key", "64", "--dim-value", "64",
+               "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "vgg_cnn", "--tgt-max-len", str(T_TGT),
+               "--src-max-len", str(T_SRC), "--label-smoothing", "0.1"]
+MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm/bmm) per input frame, SURVEY.md 8(d)
+PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+def conv_igemm_flops(B):
+    """Algorithmic FLOPs of all asr_conv3x3_igemm launches in ONE step: 3 forward convs + 3 dgrads (2*9*Cin*Cout/pixel)."""
+    px1, px2 = B * 161 * 800, B * 80 * 400
+    fwd = 2 * 9 * (64 * 64 * px1 + 64 * 128 * px2 + 128 * 128 * px2)
+    return 2 * fwd, 6
+
+
+def labels():
+    from utils import constant
+    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(V - 3)]
+    l2i = {c: i for i, c in enumerate(chars)}
+    return l2i, {i: c for c, i in l2i.items()}
+
+
+def synthetic_batch(B, torch):
+    g = torch.Generator().manual_seed(1234)
+    src = torch.randn(B, 1, F_BINS, T_SRC, generator=g)
+    tgt = torch.randint(3, V, (B, T_TGT - 1), generator=g)
+    src_len = torch.full((B,), T_SRC, dtype=torch.int32)
+    return src, src_len, tgt
+
+
+def cpu_baseline(state_dict, dropout_free_flags, seconds_budget=25.0):
+    """The CPU oracle (port of the reference step, oracle/asr_oracle.py) timed on this box's host cores on a bounded
+    sample of the same workload: same model, same T_src/T_tgt/V, batch 8 instead of 32."""
+    import torch
+    from oracle import asr_oracle as O
+    Bc = 8
+    cfg = O.Cfg.from_flags(dropout_free_flags)
+    w = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+    src, src_len, tgt = synthetic_batch(Bc, torch)
+    names = O.trainable_names(w, cfg)
+    opt = O.NoamAdam({k: w[k] for k in names}, model_size=5120)
+    times = []
+    t_start = time.time()
+    for i in range(3):
+        t0 = time.time()
+        O.train_step(w, cfg, src, src_len, tgt, 0.1, opt=opt)
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget:
+            break
+    best = min(times[1:]) if len(times) > 1 else times[0]
+    return {"value": Bc * T_SRC / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle/asr_oracle.py train_step (fwd+CE+bwd+Noam/Adam, fp32, dropout off), same 4-layer d512 vgg_cnn "
+                      "model and shapes at batch %d, best of %d timed steps after 1 warm-up; data loading and CER "
+                      "bookkeeping excluded" % (Bc, max(1, len(times) - 1))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from asr_hip import lib as L
+    from asr_hip import ops
+    from utils import constant
+    from utils.functions import init_optimizer, init_transformer_model
+    from utils.metrics import calculate_loss
+
+    flags = MODEL_FLAGS + ["--dropout", str(a.dropout), "--precision", a.precision, "--cuda", "--batch-size", str(a.batch)]
+    if world > 1:
+        flags.append("--parallel")
+    args = constant.parse(flags)
+    l2i, i2l = labels()
+    torch.manual_seed(123456)
+    model = init_transformer_model(args, l2i, i2l).cuda()
+    model.train()
+    opt = init_optimizer(args, model, "noam")
+    src, src_len, tgt = synthetic_batch(a.batch, torch)
+    src, tgt = src.cuda(), tgt.cuda()
+    sd_cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        core = model.module if hasattr(model, "module") else model
+        sd_cpu = {k: v.detach().cpu().clone() for k, v in core.state_dict().items()}
+
+    def step():
+        opt.zero_grad()
+        pred, gold, hyp, _ = model(src, src_len, tgt)
+        loss = calculate_loss(pred, gold, smoothing=0.1, loss_type="ce")
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    if not a.no_roofline:
+        ops.prof_enable(L.OP_CONV_IGEMM, True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        frames = a.batch * world * T_SRC * a.steps
+        value = frames / dt
+        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
+               "config": {"workload": "configs[1]: 4-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Transformer ASR training "
+                                      "step, synthetic (B=%d/GPU,1,161,T_src=800) -> T_tgt=100, V=4364, label smoothing 0.1, "
+                                      "dropout %.2f, random init" % (a.batch, a.dropout),
+                          "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                          "step_tflops_whole_model": value * MFLOP_PER_FRAME * 1e6 / 1e12,
+                          "frac_of_mfma_peak_whole_step": value * MFLOP_PER_FRAME * 1e6 / 1e12 / (peak * world),
+                          "final_loss": final_loss}}
+        if not a.no_roofline:
+            tot_ms, n = ops.prof_collect(L.OP_CONV_IGEMM)
+            ops.prof_enable(L.OP_CONV_IGEMM, False)
+            fl, per_step = conv_igemm_flops(a.batch)
+            if n > 0 and tot_ms > 0:
+                ach = fl * a.steps / (tot_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (3 fwd + 3 dgrad launches per step)",
+                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                   "launches": n, "avg_launch_ms": tot_ms / n,
+                                   "algorithmic_flop_per_launch_avg": fl / per_step}
+        if sd_cpu is not None:
+            try:
+                out["cpu_baseline"] = cpu_baseline(sd_cpu, " ".join(MODEL_FLAGS))
+            except Exception as e:           # the baseline is a report, never a reason to lose the measurement
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

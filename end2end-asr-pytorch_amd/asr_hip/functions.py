@@ -1,0 +1,344 @@
+"""torch.autograd glue: one Function per fused sub-layer of the reference model.  Each forward/backward is a fixed
+sequence of launches into libasr_hip.so; parameter gradients are ACCUMULATED in place into the fp32 buffers returned
+by params.grad_of() (so the Functions return None for them) and reported to the DDP reducer with params.grad_ready().
+
+Sub-layer -> reference code
+  MHAFn      models/common_layers.py:170-200 (+ :211-225) and the `*= non_pad_mask` that follows every call
+  FFNFn      models/common_layers.py:135-142 (+ mask)
+  EncInFn    models/asr/transformer.py:172-173
+  EmbedFn    models/asr/transformer.py:292-293
+  LinearFn   models/asr/transformer.py:302 (output_linear) and any plain nn.Linear
+  VGGFn      models/asr/transformer.py:42-53, :70-76
+  CEFn       utils/metrics.py:102-132
+"""
+import torch
+from torch.autograd import Function
+
+from . import ops
+from . import params as P
+
+
+def _splits_for(n_out, k_out, red):
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    s = max(1, 512 // max(tiles, 1))
+    return max(1, min(s, red // 256))
+
+
+def _wgrad(dy_t, x_t, wparam):
+    """dW (N,K) += dy_t (N, Mp) . x_t (K, Mp)^T over the (zero padded) reduction axis Mp."""
+    g = P.grad_of(wparam).view(wparam.shape[0], -1)
+    ops.gemm_nt(dy_t, x_t, out=g, accumulate=True, splits=_splits_for(g.shape[0], g.shape[1], dy_t.shape[1]))
+
+
+def _as_compute(dy2d):
+    """(M,N) gradient in any float dtype -> (dy (M,Np) zero padded, dy^T (N,Mp) zero padded) in the compute dtype."""
+    cd = ops.compute_dtype()
+    if dy2d.dtype == torch.float32 and cd != torch.float32:
+        return ops.cast_and_transpose(dy2d, cd)
+    if dy2d.dtype != cd:
+        dy2d = dy2d.to(cd)
+    N = dy2d.shape[1]
+    if not dy2d.is_contiguous() or N % 8 != 0:
+        pad = torch.zeros((dy2d.shape[0], ops._pad8(N)), device=dy2d.device, dtype=cd)
+        pad[:, :N].copy_(dy2d)
+        dy_c = pad
+    else:
+        dy_c = dy2d
+    return dy_c, ops.transpose_padded(dy_c[:, :N])
+
+
+def _pad_cols(x2d):
+    """(M,K) contiguous -> itself if K % 8 == 0 else zero padded copy (M, pad8(K))."""
+    K = x2d.shape[1]
+    if K % 8 == 0 and x2d.is_contiguous():
+        return x2d
+    out = torch.zeros((x2d.shape[0], ops._pad8(K)), device=x2d.device, dtype=x2d.dtype)
+    out[:, :K].copy_(x2d)
+    return out
+
+
+def _linear_fwd(x2d, wparam, bparam, relu=False, out_dtype=None):
+    W, _ = P.linear_shadow(wparam)
+    xp = _pad_cols(x2d)
+    return ops.gemm_nt(xp, W, bias=bparam.data if bparam is not None else None, relu=relu, out_dtype=out_dtype)
+
+
+def _linear_bwd(dy_c, dy_t, x_t, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
+    """dy_c (M,Np), dy_t (N,Mp), x_t (K,Mp) (all zero padded).  Returns dx (M,K) or None."""
+    N = wparam.shape[0]
+    _wgrad(dy_t, x_t, wparam)
+    if bparam is not None:
+        ops.colsum_acc(dy_c[:, :N], P.grad_of(bparam))
+    dx = None
+    if need_dx:
+        _, Wt = P.linear_shadow(wparam)
+        dx = ops.gemm_nt(dy_c, Wt, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
+    return dx
+
+
+def _t(x2d):
+    return ops.transpose_padded(x2d)
+
+
+# ================================================================================================ plain linear
+class LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_fp32, mark_ready):
+        cd = ops.compute_dtype()
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        y = _linear_fwd(x2, weight, bias, out_dtype=torch.float32 if out_fp32 else None)
+        ctx.x2 = x2
+        ctx.weight, ctx.bias, ctx.mark_ready = weight, bias, mark_ready
+        ctx.in_shape = x.shape
+        ctx.need_dx = x.requires_grad
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        N = ctx.weight.shape[0]
+        dy_c, dy_t = _as_compute(dy.reshape(-1, N))
+        x_t = _t(ctx.x2)
+        dx = _linear_bwd(dy_c, dy_t, x_t, ctx.weight, ctx.bias, need_dx=ctx.need_dx)
+        if ctx.mark_ready:
+            P.grad_ready(*[p for p in (ctx.weight, ctx.bias) if p is not None])
+        if dx is not None:
+            dx = dx.view(ctx.in_shape)
+        return dx, None, None, None, None
+
+
+# ================================================================================================ attention sub-layer
+class MHAFn(Function):
+    @staticmethod
+    def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta, cfg):
+        H, dk = cfg["H"], cfg["dk"]
+        B, Tq, D = q_in.shape
+        self_attn = kv_in is None
+        kv = q_in if self_attn else kv_in
+        Tk = kv.shape[1]
+        q2, kv2 = q_in.reshape(B * Tq, D), kv.reshape(B * Tk, D)
+        Q = _linear_fwd(q2, Wq, bq).view(B, Tq, H * dk)
+        K = _linear_fwd(kv2, Wk, bk).view(B, Tk, H * dk)
+        V = _linear_fwd(kv2, Wv, bv).view(B, Tk, H * dk)
+        p_att = cfg["p"]
+        seed_a, seed_o = P.next_seed(), P.next_seed()
+        scale = 1.0 / (dk ** 0.5)
+        O, lse, attn = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
+                                    causal=cfg.get("causal", False), scale=scale, p=p_att, seed=seed_a,
+                                    want_attn=cfg.get("want_attn", False))
+        Y = _linear_fwd(O.view(B * Tq, H * dk), Wo, bo)
+        out, mean, rstd = ops.add_ln_fwd(Y, q2.contiguous(), gamma.data, beta.data, row_keep=cfg.get("row_keep"),
+                                         p=p_att, seed=seed_o)
+        ctx.cfg, ctx.self_attn = cfg, self_attn
+        ctx.seeds = (seed_a, seed_o)
+        ctx.scale = scale
+        ctx.t = (q2, kv2, Q, K, V, O, lse, Y, mean, rstd)      # Y now holds z
+        ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta)
+        ctx.shape = (B, Tq, Tk, D)
+        ctx.need_dkv = (not self_attn) and kv_in.requires_grad
+        out = out.view(B, Tq, D)
+        if attn is not None:
+            ctx.mark_non_differentiable(attn)
+            return out, attn
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        cfg = ctx.cfg
+        H, dk = cfg["H"], cfg["dk"]
+        B, Tq, Tk, D = ctx.shape
+        q2, kv2, Q, K, V, O, lse, Z, mean, rstd = ctx.t
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta = ctx.params
+        seed_a, seed_o = ctx.seeds
+        dout2 = dout.reshape(B * Tq, D).contiguous()
+        d_res, d_y = ops.add_ln_bwd(dout2, Z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
+                                    P.grad_of(beta), p=cfg["p"], seed=seed_o)
+        # output projection
+        dy_c = _pad_cols(d_y)
+        dO = _linear_bwd(dy_c, _t(d_y), _t(O.view(B * Tq, H * dk)), Wo, bo)
+        dQ, dK, dV = ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, H * dk), lse, H, dk, key_len=cfg.get("key_len"),
+                                  key_pad=cfg.get("key_pad"), causal=cfg.get("causal", False), scale=ctx.scale,
+                                  p=cfg["p"], seed=seed_a)
+        dQ2, dK2, dV2 = dQ.view(B * Tq, H * dk), dK.view(B * Tk, H * dk), dV.view(B * Tk, H * dk)
+        q_t = _t(q2)
+        kv_t = q_t if ctx.self_attn else _t(kv2)
+        # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulate straight into d_res
+        _linear_bwd(_pad_cols(dQ2), _t(dQ2), q_t, Wq, bq, dx_out=d_res, accumulate=True)
+        d_kv = None
+        if ctx.self_attn:
+            _linear_bwd(_pad_cols(dK2), _t(dK2), kv_t, Wk, bk, dx_out=d_res, accumulate=True)
+            _linear_bwd(_pad_cols(dV2), _t(dV2), kv_t, Wv, bv, dx_out=d_res, accumulate=True)
+        else:
+            d_kv = _linear_bwd(_pad_cols(dK2), _t(dK2), kv_t, Wk, bk, need_dx=ctx.need_dkv)
+            _linear_bwd(_pad_cols(dV2), _t(dV2), kv_t, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
+            if d_kv is not None:
+                d_kv = d_kv.view(B, Tk, D)
+        P.grad_ready(*ctx.params)
+        return (d_res.view(B, Tq, D), d_kv) + (None,) * 11
+
+
+# ================================================================================================ feed-forward sub-layer
+class FFNFn(Function):
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, gamma, beta, cfg):
+        B, T, D = x.shape
+        x2 = x.reshape(B * T, D).contiguous()
+        h = _linear_fwd(x2, W1, b1, relu=True)
+        y = _linear_fwd(h, W2, b2)
+        seed = P.next_seed()
+        out, mean, rstd = ops.add_ln_fwd(y, x2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=cfg["p"], seed=seed)
+        ctx.t = (x2, h, y, mean, rstd)
+        ctx.params = (W1, b1, W2, b2, gamma, beta)
+        ctx.cfg, ctx.seed, ctx.shape = cfg, seed, (B, T, D)
+        return out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, D = ctx.shape
+        x2, h, z, mean, rstd = ctx.t
+        W1, b1, W2, b2, gamma, beta = ctx.params
+        cfg = ctx.cfg
+        dout2 = dout.reshape(B * T, D).contiguous()
+        d_res, d_y = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
+                                    P.grad_of(beta), p=cfg["p"], seed=ctx.seed)
+        # dh = (d_y . W2) * (h > 0)   -- ReLU mask fused into the dgrad epilogue
+        dh = _linear_bwd(_pad_cols(d_y), _t(d_y), _t(h), W2, b2, relu_mask=h)
+        _linear_bwd(_pad_cols(dh), _t(dh), _t(x2), W1, b1, dx_out=d_res, accumulate=True)
+        P.grad_ready(*ctx.params)
+        return (d_res.view(B, T, D),) + (None,) * 7
+
+
+# ================================================================================================ encoder input
+class EncInFn(Function):
+    @staticmethod
+    def forward(ctx, x, Win, bin_, gamma, beta, pe):
+        cd = ops.compute_dtype()
+        B, T, Din = x.shape
+        x2 = x.reshape(B * T, Din)
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        x2 = x2.contiguous()
+        y = _linear_fwd(x2, Win, bin_)
+        out, mean, rstd = ops.add_ln_fwd(y, None, gamma.data, beta.data, post_add=pe[:T].contiguous())
+        ctx.t = (x2, y, mean, rstd)
+        ctx.params = (Win, bin_, gamma, beta)
+        ctx.shape = (B, T, Din)
+        ctx.need_dx = x.requires_grad
+        ctx.in_dtype = x.dtype
+        return out.view(B, T, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, T, Din = ctx.shape
+        x2, z, mean, rstd = ctx.t
+        Win, bin_, gamma, beta = ctx.params
+        dout2 = dout.reshape(B * T, -1).contiguous()
+        dz, _ = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, None, P.grad_of(gamma), P.grad_of(beta))
+        dx = _linear_bwd(_pad_cols(dz), _t(dz), _t(x2), Win, bin_, need_dx=ctx.need_dx)
+        P.grad_ready(*ctx.params)
+        if dx is not None:
+            dx = dx.view(B, T, Din).to(ctx.in_dtype)
+        return dx, None, None, None, None, None
+
+
+# ================================================================================================ target embedding
+class EmbedFn(Function):
+    @staticmethod
+    def forward(ctx, tok, table, pe, scale, p, pad_id, mark_ready):
+        seed = P.next_seed()
+        T = tok.shape[1]
+        out = ops.embed_fwd(tok, table.data, pe[:T].contiguous(), scale, p, seed, ops.compute_dtype())
+        ctx.tok, ctx.table, ctx.scale, ctx.p, ctx.seed, ctx.pad_id = tok, table, scale, p, seed, pad_id
+        ctx.mark_ready = mark_ready
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops.embed_bwd(ctx.tok, dout.contiguous(), P.grad_of(ctx.table), ctx.scale, ctx.p, ctx.seed, ctx.pad_id)
+        if ctx.mark_ready:
+            P.grad_ready(ctx.table)
+        return (None,) * 7
+
+
+# ================================================================================================ vgg front end
+class VGGFn(Function):
+    @staticmethod
+    def forward(ctx, src, w0, b0, w2, b2, w5, b5, w7, b7):
+        cd = ops.compute_dtype()
+        src = src.contiguous().float()
+        y1 = ops.conv1_fwd(src, w0.data, b0.data, cd)
+        wk2, _ = P.conv_shadow(w2)
+        y2 = ops.conv3x3(y1, wk2, b2.data, w2.shape[0], relu=True)
+        p1 = ops.maxpool_fwd(y2)
+        wk5, _ = P.conv_shadow(w5)
+        y3 = ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True)
+        wk7, _ = P.conv_shadow(w7)
+        y4 = ops.conv3x3(y3, wk7, b7.data, w7.shape[0], relu=True)
+        out = ops.maxpool_fwd(y4, tcf=True)
+        ctx.t = (src, y1, y2, p1, y3, y4)
+        ctx.params = (w0, b0, w2, b2, w5, b5, w7, b7)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        src, y1, y2, p1, y3, y4 = ctx.t
+        w0, b0, w2, b2, w5, b5, w7, b7 = ctx.params
+
+        def wgrad(x, dy, w, b, tag):
+            B, H, W, Cin = x.shape
+            Cout = dy.shape[3]
+            xp = ops.nhwc_to_planar(x, tag + "x")
+            dyp = ops.nhwc_to_planar(dy, tag + "dy")
+            ops.conv3x3_wgrad(xp, dyp, P.grad_of(w), B, H, W, Cin, Cout)
+            ops.colsum_acc(dy.view(-1, Cout), P.grad_of(b))
+
+        dy4 = ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
+        wgrad(y3, dy4, w7, b7, "c7")
+        P.grad_ready(w7, b7)
+        _, wd7 = P.conv_shadow(w7)
+        dy3 = ops.conv3x3(dy4, wd7, None, w7.shape[1], relu=False, mask_src=y3)
+        wgrad(p1, dy3, w5, b5, "c5")
+        P.grad_ready(w5, b5)
+        _, wd5 = P.conv_shadow(w5)
+        dp1 = ops.conv3x3(dy3, wd5, None, w5.shape[1], relu=False)
+        dy2 = ops.maxpool_bwd(y2, dp1)
+        wgrad(y1, dy2, w2, b2, "c2")
+        P.grad_ready(w2, b2)
+        _, wd2 = P.conv_shadow(w2)
+        dy1 = ops.conv3x3(dy2, wd2, None, w2.shape[1], relu=False, mask_src=y1)
+        ops.conv1_wgrad(src, dy1, P.grad_of(w0), P.grad_of(b0))
+        P.grad_ready(w0, b0)
+        return (None,) * 9
+
+
+# ================================================================================================ loss
+class CEFn(Function):
+    """loss = sum over non-PAD rows of the (label smoothed) row loss / count.  `count` is this rank's non-PAD count
+    unless `global_count` (a device scalar, e.g. all-reduced over data-parallel ranks) is given (SURVEY.md section 5:
+    exact DP -> DDP equivalence needs local_sum / global_count with SUMMED gradients)."""
+
+    @staticmethod
+    def forward(ctx, pred, gold, smoothing, pad_id, global_count):
+        V = pred.shape[-1]
+        logits = pred.reshape(-1, V)
+        if logits.dtype != torch.float32:
+            logits = logits.float()
+        logits = logits.contiguous()
+        g = gold.reshape(-1).contiguous()
+        lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id)
+        red = P._state["reducer"]
+        if global_count is None and red is not None and red.world > 1:
+            global_count = red.all_reduce_scalar_(sums[1:2].clone())      # one scalar all-reduce per step
+        count = global_count if global_count is not None else sums[1:2]
+        ctx.t = (logits, g, lse, count)
+        ctx.smoothing, ctx.pad_id, ctx.shape = smoothing, pad_id, pred.shape
+        ctx.mark_non_differentiable(sums, am)
+        loss = sums[0] / count.reshape(())
+        return loss, sums, am
+
+    @staticmethod
+    def backward(ctx, dloss, *unused):
+        logits, g, lse, count = ctx.t
+        dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, dloss.reshape(1).float().contiguous(), count)
+        return dl.view(ctx.shape), None, None, None, None

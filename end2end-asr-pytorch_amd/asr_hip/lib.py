@@ -1,0 +1,120 @@
+"""ctypes binding of libasr_hip.so (include/asr_hip.h).  Plumbing only: tensors in, error codes checked.
+
+The library is REQUIRED: there is no CPU or eager-PyTorch fallback for any op on the hot path.  `load()` raises if
+the shared object is missing, and every wrapper raises if a tensor is not on a HIP device.
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libasr_hip.so")
+HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "asr_hip.h")
+
+F32, BF16 = 0, 1
+GEMM_RELU, GEMM_ACCUMULATE = 1, 2
+OP_GEMM, OP_CONV_IGEMM, OP_CONV_WGRAD, OP_ATTN_FWD, OP_ATTN_BWD, OP_ADD_LN, OP_CE, OP_ADAM, OP_CONV1, OP_POOL, \
+    OP_LAYOUT = range(11)
+
+_lib = None
+
+_P, _I, _L, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint64
+
+_SIGS = {
+    "asr_strerror": (ctypes.c_char_p, [_I]),
+    "asr_abi_version": (_I, []),
+    "asr_prof_enable": (_I, [_I, _I]),
+    "asr_prof_collect": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
+    "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
+    "asr_transpose": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
+    "asr_cast_weight": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
+    "asr_colsum_acc": (_I, [_P, _L, _I, _I, _P, _I, _P]),
+    "asr_add_ln_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _I, _P]),
+    "asr_add_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _I, _P]),
+    "asr_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _P, _L, _L,
+                          _I, _F, _F, _U64, _I, _P]),
+    "asr_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,
+                          _P, _P, _L, _L, _I, _F, _F, _U64, _I, _P]),
+    "asr_decoder_preprocess": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "asr_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _P]),
+    "asr_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I, _P]),
+    "asr_ce_fwd": (_I, [_P, _L, _P, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "asr_argmax_rows": (_I, [_P, _L, _I, _I, _P, _P]),
+    "asr_ce_bwd": (_I, [_P, _L, _P, _P, _I, _I, _F, _I, _P, _P, _P, _L, _I, _P]),
+    "asr_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "asr_sumsq_acc": (_I, [_P, _L, _P, _P]),
+    "asr_clip_coef": (_I, [_P, _F, _P, _P]),
+    "asr_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "asr_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "asr_conv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "asr_conv3x3_igemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_planar_pitch": (_L, [_I, _I]),
+    "asr_planar_size": (_L, [_I, _I, _I, _I]),
+    "asr_nhwc_to_planar": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "asr_conv3x3_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+}
+
+
+def header_symbols():
+    """Every function name declared in include/asr_hip.h."""
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(asr_[a-z0-9_]+)\s*\(", src)))
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libasr_hip.so is missing (%s): run `python __graft_entry__.py build` -- there is no "
+                           "fallback path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class AsrHipError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AsrHipError("%s failed: %s (%d)" % (what, load().asr_strerror(rc).decode(), rc))
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise AsrHipError("unsupported dtype %s" % t.dtype)
+
+
+def dt_of(dtype):
+    return {torch.float32: F32, torch.bfloat16: BF16}[dtype]
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses host tensors: the HIP path is the only path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AsrHipError("asr_hip ops need tensors on a HIP device (got %s); there is no CPU path" % t.device)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,327 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point, no arithmetic in Python).
+
+Everything here launches HIP kernels from libasr_hip.so on torch's current stream.  torch is used for device
+memory (torch.empty / zeros) and nothing else.
+"""
+import torch
+
+from . import lib as L
+
+_cfg = {"dtype": torch.bfloat16}
+
+
+def set_compute_dtype(dtype):
+    """torch.float32 = parity mode (fp32 storage, fp32 MFMA); torch.bfloat16 = perf mode (bf16 in / fp32 accumulate)."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _cfg["dtype"] = dtype
+
+
+def compute_dtype():
+    return _cfg["dtype"]
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ------------------------------------------------------------------------------------------------ dense
+def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, splits=1, out_dtype=None, K=None,
+            relu_mask=None):
+    """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T (+bias) ; A, B 2-D with unit inner stride (row stride arbitrary)."""
+    assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
+    M, N = A.shape[0], B.shape[0]
+    K = A.shape[1] if K is None else K
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
+        assert not accumulate
+    assert out.stride(1) == 1 and out.shape == (M, N)
+    if relu_mask is not None:
+        assert relu_mask.dtype == A.dtype and relu_mask.stride(0) == out.stride(0) and relu_mask.stride(1) == 1
+    flags = (L.GEMM_RELU if relu else 0) | (L.GEMM_ACCUMULATE if accumulate else 0)
+    L.call("asr_gemm_nt", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out), out.stride(0), L.ptr(bias),
+           L.ptr(relu_mask), M, N, K, float(alpha), flags, int(splits), L.dt(A), L.dt(out), L.stream())
+    return out
+
+
+def transpose_padded(x):
+    """(rows, cols) -> (cols, pad8(rows)) with zero pad columns (so a contraction may run over the padded axis)."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    rows, cols = x.shape
+    ld = _pad8(rows)
+    out = torch.zeros((cols, ld), device=x.device, dtype=x.dtype) if ld != rows else \
+        torch.empty((cols, ld), device=x.device, dtype=x.dtype)
+    L.call("asr_transpose", L.ptr(x), x.stride(0), L.ptr(out), ld, rows, cols, L.dt(x), L.stream())
+    return out
+
+
+def transpose(x):
+    return transpose_padded(x)[:, :x.shape[0]]
+
+
+def cast_and_transpose(src, dtype, want_same=True, want_t=True):
+    """fp32 (rows, cols) -> (copy in dtype with ld padded to 8, transpose in dtype with ld padded to 8).
+    Pad columns are zero so a contraction may run over the padded K."""
+    assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
+    rows, cols = src.shape
+    same = t = None
+    if want_same:
+        same = torch.zeros((rows, _pad8(cols)), device=src.device, dtype=dtype)
+    if want_t:
+        t = torch.zeros((cols, _pad8(rows)), device=src.device, dtype=dtype)
+    L.call("asr_cast_weight", L.ptr(src), src.stride(0), L.ptr(same), same.stride(0) if same is not None else 0,
+           L.ptr(t), t.stride(0) if t is not None else 0, rows, cols, L.dt_of(dtype), L.stream())
+    return same, t
+
+
+def cast_into(src, same, t):
+    """Refresh persistent shadow buffers (same: (rows, ld), t: (cols, ld_t)) from the fp32 master `src`."""
+    rows, cols = src.shape
+    dtype = (same if same is not None else t).dtype
+    L.call("asr_cast_weight", L.ptr(src), src.stride(0), L.ptr(same), same.stride(0) if same is not None else 0,
+           L.ptr(t), t.stride(0) if t is not None else 0, rows, cols, L.dt_of(dtype), L.stream())
+
+
+def colsum_acc(x, out):
+    assert x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.float32
+    L.call("asr_colsum_acc", L.ptr(x), x.stride(0), x.shape[0], x.shape[1], L.ptr(out), L.dt(x), L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ layer norm
+def add_ln_fwd(y, residual, gamma, beta, post_add=None, row_keep=None, eps=1e-5, p=0.0, seed=0):
+    """y (M,D) contiguous is overwritten with z = dropout(y)+residual.  Returns (out, mean, rstd)."""
+    M, D = y.shape
+    assert y.is_contiguous() and (residual is None or residual.is_contiguous())
+    out = torch.empty_like(y)
+    mean = torch.empty(M, device=y.device, dtype=torch.float32)
+    rstd = torch.empty(M, device=y.device, dtype=torch.float32)
+    period = post_add.shape[0] if post_add is not None else 0
+    L.call("asr_add_ln_fwd", L.ptr(y), L.ptr(residual), L.ptr(gamma), L.ptr(beta), L.ptr(post_add), period,
+           L.ptr(row_keep), L.ptr(out), L.ptr(mean), L.ptr(rstd), M, D, float(eps), float(p), int(seed), L.dt(y),
+           L.stream())
+    return out, mean, rstd
+
+
+def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=0):
+    """Returns (d_res, d_y); d_y is d_res itself when p == 0."""
+    M, D = z.shape
+    assert dout.is_contiguous() and z.is_contiguous()
+    d_res = torch.empty_like(z)
+    d_y = torch.empty_like(z) if p > 0 else d_res
+    L.call("asr_add_ln_bwd", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
+           L.ptr(d_res), L.ptr(d_y), L.ptr(dgamma), L.ptr(dbeta), M, D, float(p), int(seed), L.dt(z), L.stream())
+    return d_res, d_y
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _bt_strides(x, H, d):
+    assert x.dim() == 3 and x.stride(2) == 1 and x.shape[2] == H * d
+    return x.stride(0), x.stride(1)
+
+
+def _mask_strides(mask, B, Tq, Tk):
+    """uint8 mask: (B,Tk) per-key or (B,Tq,Tk) full -> (batch stride, query stride)."""
+    if mask is None:
+        return 0, 0
+    assert mask.dtype == torch.uint8 and mask.is_contiguous()
+    if mask.dim() == 2:
+        assert mask.shape == (B, Tk)
+        return Tk, 0
+    assert mask.shape == (B, Tq, Tk)
+    return Tq * Tk, Tk
+
+
+def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, want_attn=False):
+    """q (B,Tq,H*d), k/v (B,Tk,H*d) -> (o (B,Tq,H*d), lse (B,H,Tq), attn (H*B,Tq,Tk) or None)."""
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    msb, msq = _mask_strides(key_pad, B, Tq, Tk)
+    o = torch.empty((B, Tq, H * d), device=q.device, dtype=q.dtype)
+    lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    attn = torch.empty((H * B, Tq, Tk), device=q.device, dtype=torch.float32) if want_attn else None
+    qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
+    L.call("asr_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(attn), B, H, Tq, Tk, d, qs[0], qs[1],
+           ks[0], ks[1], vs[0], vs[1], os_[0], os_[1], L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal),
+           float(scale), float(p), int(seed), L.dt(q), L.stream())
+    return o, lse, attn
+
+
+def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    assert do.is_contiguous() and o.is_contiguous()
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
+    delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    msb, msq = _mask_strides(key_pad, B, Tq, Tk)
+    qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
+    L.call("asr_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dq),
+           L.ptr(dk), L.ptr(dv), B, H, Tq, Tk, d, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],
+           L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), L.dt(q),
+           L.stream())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------ decoder input
+def decoder_preprocess(tgt, Td):
+    B, Lw = tgt.shape
+    tgt = tgt.contiguous()
+    dev = tgt.device
+    seq_in = torch.empty((B, Td), device=dev, dtype=torch.int64)
+    seq_out = torch.empty((B, Td), device=dev, dtype=torch.int64)
+    key_pad = torch.empty((B, Td), device=dev, dtype=torch.uint8)
+    row_keep = torch.empty((B, Td), device=dev, dtype=torch.uint8)
+    overflow = torch.zeros(1, device=dev, dtype=torch.int32)
+    L.call("asr_decoder_preprocess", L.ptr(tgt), B, Lw, Td, L.ptr(seq_in), L.ptr(seq_out), L.ptr(key_pad),
+           L.ptr(row_keep), L.ptr(overflow), L.stream())
+    return seq_in, seq_out, key_pad, row_keep, overflow
+
+
+def embed_fwd(tok, table, pe, scale, p, seed, dtype):
+    B, T = tok.shape
+    D = table.shape[1]
+    out = torch.empty((B, T, D), device=tok.device, dtype=dtype)
+    L.call("asr_embed_fwd", L.ptr(tok), L.ptr(table), L.ptr(pe), L.ptr(out), B, T, D, float(scale), float(p), int(seed),
+           L.dt_of(dtype), L.stream())
+    return out
+
+
+def embed_bwd(tok, dout, dtable, scale, p, seed, pad_id):
+    B, T = tok.shape
+    D = dtable.shape[1]
+    assert dout.is_contiguous()
+    L.call("asr_embed_bwd", L.ptr(tok), L.ptr(dout), L.ptr(dtable), B, T, D, float(scale), float(p), int(seed),
+           int(pad_id), L.dt(dout), L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ loss
+def ce_fwd(logits, gold, smoothing, pad_id):
+    """logits (M,V) fp32 -> (row_lse (M), argmax (M) int64, sums (3) fp32 = [loss_sum, count, num_correct])."""
+    M, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and gold.is_contiguous()
+    lse = torch.empty(M, device=logits.device, dtype=torch.float32)
+    am = torch.empty(M, device=logits.device, dtype=torch.int64)
+    sums = torch.zeros(3, device=logits.device, dtype=torch.float32)
+    L.call("asr_ce_fwd", L.ptr(logits), logits.stride(0), L.ptr(gold), M, V, float(smoothing), int(pad_id), L.ptr(lse),
+           L.ptr(am), L.ptr(sums), L.stream())
+    return lse, am, sums
+
+
+def argmax_rows(logits):
+    M, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    out = torch.empty(M, device=logits.device, dtype=torch.int64)
+    L.call("asr_argmax_rows", L.ptr(logits), logits.stride(0), M, V, L.ptr(out), L.stream())
+    return out
+
+
+def ce_bwd(logits, gold, lse, smoothing, pad_id, grad_out, count):
+    """Returns fp32 dlogits as an (M,V) view of an (M, pad8(V)) buffer whose pad columns are zero."""
+    M, V = logits.shape
+    ld = _pad8(V)
+    dl = torch.empty((M, ld), device=logits.device, dtype=torch.float32)
+    L.call("asr_ce_bwd", L.ptr(logits), logits.stride(0), L.ptr(gold), L.ptr(lse), M, V, float(smoothing), int(pad_id),
+           L.ptr(grad_out), L.ptr(count), L.ptr(dl), ld, L.F32, L.stream())
+    return dl[:, :V]
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=None):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    L.call("asr_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
+           float(eps), float(bc1), float(bc2), L.ptr(grad_scale), L.stream())
+
+
+def sumsq_acc(g, acc):
+    L.call("asr_sumsq_acc", L.ptr(g), g.numel(), L.ptr(acc), L.stream())
+
+
+def clip_coef(sumsq, max_norm, coef):
+    L.call("asr_clip_coef", L.ptr(sumsq), float(max_norm), L.ptr(coef), L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ conv front end
+def conv1_fwd(x, w, bias, dtype):
+    B, _, H, W = x.shape
+    C0 = w.shape[0]
+    assert x.is_contiguous() and x.dtype == torch.float32
+    y = torch.empty((B, H, W, C0), device=x.device, dtype=dtype)
+    L.call("asr_conv1_fwd", L.ptr(x), L.ptr(w), L.ptr(bias), L.ptr(y), B, H, W, C0, L.dt_of(dtype), L.stream())
+    return y
+
+
+def conv1_wgrad(x, dy, dw, db):
+    B, H, W, C0 = dy.shape
+    L.call("asr_conv1_wgrad", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, H, W, C0, L.dt(dy), L.stream())
+
+
+def conv_pack_weight(w, wk, wd):
+    Cout, Cin = w.shape[0], w.shape[1]
+    t = wk if wk is not None else wd
+    L.call("asr_conv_pack_weight", L.ptr(w), L.ptr(wk), L.ptr(wd), Cout, Cin, L.dt(t), L.stream())
+
+
+def conv3x3(x, wk, bias, Cout, relu, mask_src=None):
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, H, W, Cout), device=x.device, dtype=x.dtype)
+    L.call("asr_conv3x3_igemm", L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(mask_src), L.ptr(y), B, H, W, Cin, Cout,
+           int(relu), L.dt(x), L.stream())
+    return y
+
+
+def maxpool_fwd(x, tcf=False):
+    B, H, W, C = x.shape
+    if tcf:
+        y = torch.empty((B, W // 2, C * (H // 2)), device=x.device, dtype=x.dtype)
+    else:
+        y = torch.empty((B, H // 2, W // 2, C), device=x.device, dtype=x.dtype)
+    L.call("asr_maxpool_fwd", L.ptr(x), L.ptr(y), B, H, W, C, int(tcf), L.dt(x), L.stream())
+    return y
+
+
+def maxpool_bwd(x, dy, tcf=False):
+    B, H, W, C = x.shape
+    assert dy.is_contiguous()
+    dx = torch.empty_like(x)
+    L.call("asr_maxpool_bwd", L.ptr(x), L.ptr(dy), L.ptr(dx), B, H, W, C, int(tcf), L.dt(x), L.stream())
+    return dx
+
+
+_planar_ws = {}
+
+
+def planar_workspace(tag, C, B, H, W, dtype, device):
+    """Persistent zero-initialised planar buffer (pads must stay zero between uses; only real pixels are rewritten)."""
+    key = (tag, C, B, H, W, dtype, str(device))
+    buf = _planar_ws.get(key)
+    if buf is None:
+        Np = L.load().asr_planar_size(B, H, W, L.dt_of(dtype))
+        buf = torch.zeros((C, Np), device=device, dtype=dtype)
+        _planar_ws[key] = buf
+    return buf
+
+
+def nhwc_to_planar(x, tag):
+    B, H, W, C = x.shape
+    xp = planar_workspace(tag, C, B, H, W, x.dtype, x.device)
+    L.call("asr_nhwc_to_planar", L.ptr(x), L.ptr(xp), B, H, W, C, L.dt(x), L.stream())
+    return xp
+
+
+def conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout):
+    L.call("asr_conv3x3_wgrad", L.ptr(xp), L.ptr(dyp), L.ptr(dw), B, H, W, Cin, Cout, L.dt(xp), L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ profiling
+def prof_enable(op, on=True):
+    L.call("asr_prof_enable", int(op), int(on))
+
+
+def prof_collect(op):
+    import ctypes
+    ms = ctypes.c_double(0.0)
+    n = ctypes.c_int64(0)
+    L.check(L.load().asr_prof_collect(int(op), ctypes.byref(ms), ctypes.byref(n)), "asr_prof_collect")
+    return ms.value, n.value

@@ -1,0 +1,140 @@
+"""Parameter-side state of the HIP path: compute-dtype weight shadows, fp32 gradient buffers, flat storage and the
+hooks a data-parallel gradient reducer attaches to.
+
+Masters stay fp32 `nn.Parameter`s with the reference's names and shapes (checkpoint compatibility).
+Kernels never read them directly in bf16 mode: they read shadows in kernel-friendly layouts
+  linear  W (N,K)          -> W  (N, pad8(K)) and W^T (K, pad8(N))       (forward / dgrad are both NT contractions)
+  conv3x3 W (Co,Ci,3,3)    -> wk (Co,9,Ci)   and wd  (Ci,9 flipped,Co)   (forward / dgrad implicit GEMM)
+refreshed lazily whenever the master changed (torch version counter, or `bump_generation()` from the fused
+optimiser which rewrites masters through the C ABI).
+"""
+import torch
+
+from . import ops
+
+_state = {"generation": 0, "reducer": None, "seed_ctr": 0, "base_seed": None}
+
+
+def bump_generation():
+    _state["generation"] += 1
+
+
+def next_seed():
+    """Distinct 64-bit seed per dropout site and per step, derived from torch's global seed."""
+    if _state["base_seed"] is None:
+        _state["base_seed"] = int(torch.initial_seed()) & 0xFFFFFFFF
+    _state["seed_ctr"] += 1
+    return ((_state["base_seed"] << 32) ^ (_state["seed_ctr"] * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
+
+def _key(p, dtype):
+    return (p._version, _state["generation"], dtype, p.data_ptr())
+
+
+def linear_shadow(p, dtype=None):
+    """p: (N,K) or (N,K,1) fp32 master -> (W (N,Kp) , Wt (K,Np)) in compute dtype, zero-padded to multiples of 8."""
+    dtype = dtype or ops.compute_dtype()
+    sh = p.__dict__.get("_asr_shadow")
+    key = _key(p, dtype)
+    if sh is not None and sh["key"] == key:
+        return sh["w"], sh["wt"]
+    w2 = p.data.view(p.shape[0], -1)
+    N, K = w2.shape
+    if sh is None or sh["w"].dtype != dtype or sh["w"].device != p.device:
+        sh = {"w": torch.zeros((N, ops._pad8(K)), device=p.device, dtype=dtype),
+              "wt": torch.zeros((K, ops._pad8(N)), device=p.device, dtype=dtype)}
+        p.__dict__["_asr_shadow"] = sh
+    ops.cast_into(w2, sh["w"], sh["wt"])
+    sh["key"] = key
+    return sh["w"], sh["wt"]
+
+
+def conv_shadow(p, dtype=None):
+    """p: (Cout,Cin,3,3) fp32 master -> (wk (Cout,9,Cin), wd (Cin,9,Cout)) in compute dtype."""
+    dtype = dtype or ops.compute_dtype()
+    sh = p.__dict__.get("_asr_shadow")
+    key = _key(p, dtype)
+    if sh is not None and sh["key"] == key:
+        return sh["wk"], sh["wd"]
+    Cout, Cin = p.shape[0], p.shape[1]
+    if sh is None or sh["wk"].dtype != dtype or sh["wk"].device != p.device:
+        sh = {"wk": torch.empty((Cout, 9, Cin), device=p.device, dtype=dtype),
+              "wd": torch.empty((Cin, 9, Cout), device=p.device, dtype=dtype)}
+        p.__dict__["_asr_shadow"] = sh
+    ops.conv_pack_weight(p.data, sh["wk"], sh["wd"])
+    sh["key"] = key
+    return sh["wk"], sh["wd"]
+
+
+def grad_of(p):
+    """fp32 gradient buffer of a parameter (kernels ACCUMULATE into it; `zero_grad` must zero, not drop, it)."""
+    if p.grad is None:
+        p.grad = torch.zeros_like(p.data)
+    return p.grad
+
+
+def set_reducer(r):
+    _state["reducer"] = r
+
+
+def grad_ready(*params):
+    """Called by a backward as soon as the LAST contribution to each parameter's gradient has been enqueued."""
+    r = _state["reducer"]
+    if r is not None:
+        for p in params:
+            r.mark_ready(p)
+
+
+# ------------------------------------------------------------------------------------------------ flat storage
+class FlatParams:
+    """Re-homes every parameter of a module into ONE fp32 buffer (and its gradient into another), each parameter at a
+    64-element aligned offset, so that the optimiser is a single kernel launch and DDP buckets are plain slices.
+    `p.data` / `p.grad` become views; names, shapes and values are unchanged."""
+
+    ALIGN = 64
+
+    def __init__(self, module_or_params):
+        params = []
+        seen = set()
+        it = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
+        for p in it:
+            if id(p) not in seen:
+                seen.add(id(p))
+                params.append(p)
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        off = 0
+        self.offsets = []
+        for p in params:
+            self.offsets.append(off)
+            off += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.total = off
+        self.params = params
+        self.data = torch.zeros(off, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        for p, o in zip(params, self.offsets):
+            n = p.numel()
+            self.data[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + n].view(p.shape)
+            if p.grad is not None:
+                self.grad[o:o + n].copy_(p.grad.reshape(-1))
+            p.grad = self.grad[o:o + n].view(p.shape)
+        self.index = {id(p): i for i, p in enumerate(params)}
+
+    def range_of(self, p):
+        i = self.index[id(p)]
+        return self.offsets[i], self.offsets[i] + p.numel()
+
+    def rebind(self):
+        """Re-attach views after something replaced p.data / p.grad (e.g. .to(), load_state_dict on another device)."""
+        for p, o in zip(self.params, self.offsets):
+            n = p.numel()
+            if p.data.data_ptr() != self.data[o:o + n].data_ptr():
+                self.data[o:o + n].copy_(p.data.reshape(-1))
+                p.data = self.data[o:o + n].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != self.grad[o:o + n].data_ptr():
+                p.grad = self.grad[o:o + n].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()

@@ -1,0 +1,151 @@
+// Label-smoothed cross entropy + argmax + num_correct (reference: utils/metrics.py:78-132; topk at
+// models/asr/transformer.py:80).  One 256-thread block per token row; wave-first reductions.
+// HBM-bound: forward reads M*V*4 bytes once (second pass is L2-resident), backward reads M*V*4 and writes
+// M*ldd*sizeof(T).
+#include "common.h"
+
+namespace {
+
+struct MaxIdx { float v; int i; };
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {     // greater value, lowest index on ties
+  if (b.v > a.v || (b.v == a.v && b.i < a.i)) return b;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                     const int64_t* __restrict__ gold, int V, float eps, int pad_id,
+                                                     float* __restrict__ row_lse, int64_t* __restrict__ argmax, float* sums) {
+  __shared__ float s_v[4]; __shared__ int s_i[4]; __shared__ float s_s[4]; __shared__ float s_e[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* l = logits + (int64_t)row * ld;
+  MaxIdx mi{-INFINITY, 0x7fffffff};
+  float sum = 0.f;
+  for (int v = tid; v < V; v += 256) {
+    const float x = l[v];
+    sum += x;
+    if (x > mi.v) { mi.v = x; mi.i = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxIdx t{__shfl_xor(mi.v, o, 64), __shfl_xor(mi.i, o, 64)};
+    mi = better(mi, t);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) { s_v[wave] = mi.v; s_i[wave] = mi.i; s_s[wave] = sum; }
+  __syncthreads();
+  MaxIdx m{s_v[0], s_i[0]};
+#pragma unroll
+  for (int w = 1; w < 4; ++w) m = better(m, MaxIdx{s_v[w], s_i[w]});
+  sum = s_s[0] + s_s[1] + s_s[2] + s_s[3];
+  float e = 0.f;
+  for (int v = tid; v < V; v += 256) e += expf(l[v] - m.v);
+  e = wave_sum(e);
+  if (lane == 0) s_e[wave] = e;
+  __syncthreads();
+  if (tid == 0) {
+    const float lse = m.v + logf(s_e[0] + s_e[1] + s_e[2] + s_e[3]);
+    row_lse[row] = lse;
+    argmax[row] = m.i;
+    const int64_t g = gold[row];
+    if (g != pad_id) {
+      const float lpg = l[g] - lse;
+      float loss;
+      if (eps > 0.f) {
+        const float sum_lp = sum - (float)V * lse;
+        loss = -((1.f - eps) * lpg + (eps / (float)V) * (sum_lp - lpg));
+      } else {
+        loss = -lpg;
+      }
+      atomicAdd(sums + 0, loss);
+      atomicAdd(sums + 1, 1.f);
+      if (m.i == g) atomicAdd(sums + 2, 1.f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int64_t ld, int V,
+                                                          int64_t* __restrict__ out) {
+  __shared__ float s_v[4]; __shared__ int s_i[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* l = logits + (int64_t)row * ld;
+  MaxIdx mi{-INFINITY, 0x7fffffff};
+  for (int v = tid; v < V; v += 256) {
+    const float x = l[v];
+    if (x > mi.v) { mi.v = x; mi.i = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    MaxIdx t{__shfl_xor(mi.v, o, 64), __shfl_xor(mi.i, o, 64)};
+    mi = better(mi, t);
+  }
+  if (lane == 0) { s_v[wave] = mi.v; s_i[wave] = mi.i; }
+  __syncthreads();
+  if (tid == 0) {
+    MaxIdx m{s_v[0], s_i[0]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) m = better(m, MaxIdx{s_v[w], s_i[w]});
+    out[row] = m.i == 0x7fffffff ? 0 : m.i;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                     const int64_t* __restrict__ gold, const float* __restrict__ row_lse,
+                                                     int V, float eps, int pad_id, const float* __restrict__ grad_out,
+                                                     const float* __restrict__ count, T* __restrict__ dl, int64_t ldd) {
+  const int row = blockIdx.x;
+  const int64_t g = gold[row];
+  T* d = dl + (int64_t)row * ldd;
+  if (g == pad_id) {
+    for (int v = threadIdx.x; v < ldd; v += 256) DT<T>::st(d + v, 0.f);
+    return;
+  }
+  const float coef = (*grad_out) / (*count);
+  const float* l = logits + (int64_t)row * ld;
+  const float lse = row_lse[row];
+  const float q_other = eps > 0.f ? eps / (float)V : 0.f;
+  const float q_gold = eps > 0.f ? 1.f - eps : 1.f;
+  const float sum_q = q_gold + (float)(V - 1) * q_other;
+  for (int v = threadIdx.x; v < ldd; v += 256) {
+    float o = 0.f;
+    if (v < V) o = coef * (expf(l[v] - lse) * sum_q - (v == g ? q_gold : q_other));
+    DT<T>::st(d + v, o);
+  }
+}
+
+}  // namespace
+
+extern "C" int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, int M, int V, float smoothing, int pad_id,
+                          float* row_lse, int64_t* argmax, float* sums, hipStream_t s) {
+  ASR_CHECK_ARG(logits && gold && row_lse && argmax && sums && M >= 0 && V > 0 && ld >= V && smoothing >= 0.f);
+  if (M == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_CE, s);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(256), 0, s, logits, ld, gold, V, smoothing, pad_id, row_lse, argmax, sums);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_ce_bwd(const float* logits, int64_t ld, const int64_t* gold, const float* row_lse, int M, int V,
+                          float smoothing, int pad_id, const float* grad_out, const float* count, void* dlogits, int64_t ldd,
+                          int out_dtype, hipStream_t s) {
+  ASR_CHECK_ARG(logits && gold && row_lse && grad_out && count && dlogits && M >= 0 && V > 0 && ld >= V && ldd >= V);
+  if (M == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_CE, s);
+  if (out_dtype == ASR_F32)
+    hipLaunchKernelGGL((ce_bwd_kernel<float>), dim3(M), dim3(256), 0, s, logits, ld, gold, row_lse, V, smoothing, pad_id,
+                       grad_out, count, (float*)dlogits, ldd);
+  else if (out_dtype == ASR_BF16)
+    hipLaunchKernelGGL((ce_bwd_kernel<bf16_t>), dim3(M), dim3(256), 0, s, logits, ld, gold, row_lse, V, smoothing, pad_id,
+                       grad_out, count, (bf16_t*)dlogits, ldd);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_argmax_rows(const float* logits, int64_t ld, int M, int V, int64_t* out, hipStream_t s) {
+  ASR_CHECK_ARG(logits && out && M >= 0 && V > 0 && ld >= V);
+  if (M == 0) return ASR_OK;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, s, logits, ld, V, out);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

@@ -1,0 +1,121 @@
+// Shared device helpers for libasr_hip.so (gfx950 / MI355X only).
+//
+// Conventions used by every kernel in this directory
+//   * storage dtype T is `float` (parity mode) or `bf16_t` (= unsigned short, perf mode); accumulation is fp32.
+//   * MFMA "pack": one lane holds KPACK consecutive k of one row/col of a 16x16 fragment:
+//       bf16: KPACK = 8  -> one v_mfma_f32_16x16x32_bf16 per pack  (k-range of a macro step = 32)
+//       f32 : KPACK = 4  -> four v_mfma_f32_16x16x4_f32 per pack   (k-range of a macro step = 16)
+//     lane l: row/col = l & 15, k-block g = l >> 4, so a pack is always one aligned 16-byte read.
+//     Both operands use the same k <-> (g, j) map, so the contraction is exact whatever the map is.
+//   * C/D fragment (both dtypes): col = l & 15, row = 4 * (l >> 4) + reg   (reg = 0..3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/asr_hip.h"
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+#define ASR_WAVE 64
+
+// ---------------------------------------------------------------------------------------------- conversions
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;   // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int kDtype = ASR_F32;
+  static constexpr int EPC = 4;          // elements per 16-byte chunk (= KPACK)
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+  __device__ static __forceinline__ float to(float v) { return v; }
+  __device__ static __forceinline__ float from(float v) { return v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int kDtype = ASR_BF16;
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+  __device__ static __forceinline__ bf16_t to(float v) { return f32_to_bf16(v); }
+  __device__ static __forceinline__ float from(bf16_t v) { return bf16_to_f32(v); }
+};
+
+// 16-byte chunk viewed as elements
+template <typename T> union Chunk {
+  uint4 v;
+  T e[16 / sizeof(T)];
+};
+
+// ---------------------------------------------------------------------------------------------- MFMA wrapper
+// acc += A_pack (x) B_pack for one 16x16 fragment over one macro step.
+template <typename T> __device__ __forceinline__ void mma16(f32x4_t& acc, const uint4& a, const uint4& b);
+template <> __device__ __forceinline__ void mma16<bf16_t>(f32x4_t& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uint4& a, const uint4& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+}
+
+// ---------------------------------------------------------------------------------------------- reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------- dropout RNG
+// Counter based: keep(seed, idx) is a pure function so backward regenerates the forward mask exactly.
+// (The reference uses torch's Philox stream; RNG streams cannot match across implementations, SURVEY.md 4.3 --
+//  parity is checked with dropout = 0, dropout itself by its statistics and fwd/bwd mask consistency.)
+__device__ __forceinline__ uint32_t asr_hash32(uint64_t seed, uint64_t idx) {
+  uint64_t z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z ^= z >> 32; z *= 0xD6E8FEB86659FD93ull;
+  z ^= z >> 32; z *= 0xD6E8FEB86659FD93ull;
+  z ^= z >> 32;
+  return (uint32_t)z;
+}
+// threshold = (uint32)(p * 2^32); keep iff hash >= threshold
+__device__ __forceinline__ bool asr_keep(uint64_t seed, uint64_t idx, uint32_t thr) { return asr_hash32(seed, idx) >= thr; }
+static inline uint32_t asr_drop_threshold(float p) {
+  if (p <= 0.f) return 0u;
+  double t = (double)p * 4294967296.0;
+  if (t > 4294967295.0) t = 4294967295.0;
+  return (uint32_t)t;
+}
+
+// ---------------------------------------------------------------------------------------------- host helpers
+#define ASR_CHECK_ARG(cond)                 \
+  do {                                      \
+    if (!(cond)) return ASR_EINVAL;         \
+  } while (0)
+#define ASR_LAUNCH_CHECK()                                     \
+  do {                                                         \
+    if (hipGetLastError() != hipSuccess) return ASR_ELAUNCH;   \
+  } while (0)
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// profiling hook (prof.hip): brackets one launch with hipEvents when profiling of `op` is enabled.
+struct AsrProfScope {
+  int op;
+  hipStream_t s;
+  void* slot;
+  AsrProfScope(int op, hipStream_t s);
+  ~AsrProfScope();
+};

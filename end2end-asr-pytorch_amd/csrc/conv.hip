@@ -1,0 +1,659 @@
+// vgg_cnn front end (reference: models/asr/transformer.py:42-53 applied at :70-71, reshape :74-76).
+// Activations are NHWC (B, H=F, W=T, C): the contraction axis of every 3x3 convolution (taps x channels) is then
+// made of 9 shifted, channel-contiguous rows, i.e. an implicit GEMM whose A operand is read from ONE halo patch
+// staged in LDS per workgroup.
+//
+//   asr_conv3x3_igemm : forward (+bias+ReLU) and dgrad (tap-flipped weights, ReLU mask of the consumer's input).
+//                       MFMA-bound: 2*9*Cin*Cout flop per output pixel; HBM bytes per pixel = (Cin + Cout)*sizeof(T)
+//                       (+ halo overlap 1.4x on the read side, served by L2).
+//   asr_conv3x3_wgrad : dW = dY^T . shift(X) over ~B*H*W pixels, split-K with fp32 atomics; operands are planar
+//                       zero-padded copies so every tap is a pure pointer shift (no boundary logic in the loop).
+//   conv1 / pooling / layout kernels are HBM-bound streaming kernels.
+#include "common.h"
+
+namespace {
+
+// ================================================================================================ conv1 (Cin = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int H,
+                                                        int W, int C0) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float sw[];       // [C0*9] weights + [C0] bias
+  for (int i = threadIdx.x; i < C0 * 10; i += 256) sw[i] = i < C0 * 9 ? w[i] : bias[i - C0 * 9];
+  __syncthreads();
+  const int groups = C0 / EPC;
+  const int64_t total = (int64_t)B * H * W * groups;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % groups);
+    const int64_t pix = i / groups;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = yh + ky - 1, xx = xw + kx - 1;
+        in[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(b * H + yy) * W + xx] : 0.f;
+      }
+    Chunk<T> o;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const int c = cg * EPC + j;
+      float a = sw[C0 * 9 + c];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) a += sw[c * 9 + t] * in[t];
+      o.e[j] = DT<T>::to(fmaxf(a, 0.f));
+    }
+    *reinterpret_cast<uint4*>(y + pix * C0 + cg * EPC) = o.v;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
+                                                          float* dw, float* db, int B, int H, int W, int C0) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float sacc[];     // [C0*10]
+  for (int i = threadIdx.x; i < C0 * 10; i += 256) sacc[i] = 0.f;
+  __syncthreads();
+  const int groups = C0 / EPC;        // 256 % groups == 0 -> a thread keeps its channel group across the loop
+  const int cg = threadIdx.x % groups;
+  float aw[EPC][9], ab[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) { ab[j] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) aw[j][t] = 0.f; }
+  const int64_t npix = (int64_t)B * H * W;
+  const int ppb = 256 / groups;
+  for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / groups; pix < npix; pix += (int64_t)gridDim.x * ppb) {
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+    const int64_t b = pix / ((int64_t)W * H);
+    Chunk<T> d;
+    d.v = *reinterpret_cast<const uint4*>(dy + pix * C0 + cg * EPC);
+    float in[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int yy = yh + ky - 1, xx = xw + kx - 1;
+        in[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(b * H + yy) * W + xx] : 0.f;
+      }
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const float g = DT<T>::from(d.e[j]);
+      ab[j] += g;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) aw[j][t] += g * in[t];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    const int c = cg * EPC + j;
+    atomicAdd(&sacc[C0 * 9 + c], ab[j]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(&sacc[c * 9 + t], aw[j][t]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C0 * 10; i += 256) {
+    if (i < C0 * 9) atomicAdd(dw + i, sacc[i]);
+    else atomicAdd(db + (i - C0 * 9), sacc[i]);
+  }
+}
+
+// ================================================================================================ weight packing
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wk, T* __restrict__ wd, int Cout, int Cin) {
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(i % 9);
+    const int ci = (int)((i / 9) % Cin);
+    const int co = (int)(i / (9 * (int64_t)Cin));
+    const float v = w[i];
+    if (wk) DT<T>::st(wk + ((int64_t)co * 9 + tap) * Cin + ci, v);
+    if (wd) DT<T>::st(wd + ((int64_t)ci * 9 + (8 - tap)) * Cout + co, v);   // tap flip: (2-ky)*3+(2-kx) = 8 - tap
+  }
+}
+
+// ================================================================================================ implicit GEMM 3x3
+struct ConvArgs {
+  const void* x; const void* wk; const float* bias; const void* mask_src; void* y;
+  int B, H, W, Cin, Cout, relu, tiles_h, tiles_w;
+};
+
+template <typename T, int NCO>
+__global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
+  constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
+  constexpr int CPP = 64 / EPC;            // 16-B chunks per 64-channel pixel slice
+  constexpr int PP = 64 * ESZ + 16;        // LDS pitch of a pixel slice / weight row
+  constexpr int NMS = 64 / (4 * EPC);      // macro steps per 64 channels
+  constexpr int FN = NCO / 32;             // cout fragments per wave
+  constexpr int WCH = NCO * CPP / 256;     // weight chunks per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sP = smem;                       // 180 halo pixels
+  unsigned char* sW0 = smem + 180 * PP;           // weight tile, buffer 0
+  unsigned char* sW1 = sW0 + NCO * PP;            // buffer 1
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  int t = blockIdx.x;
+  const int tw = t % p.tiles_w; t /= p.tiles_w;
+  const int th = t % p.tiles_h;
+  const int b = t / p.tiles_h;
+  const int h0 = th * 8, w0 = tw * 16;
+  const T* X = static_cast<const T*>(p.x);
+  const T* Wk = static_cast<const T*>(p.wk);
+  const int nchunk = p.Cin / 64;
+  const int nsteps = nchunk * 9;
+
+  f32x4_t acc[4][FN];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // weight tile (tap, 64-channel slice) : global -> registers -> LDS; the register copy lives for one iteration only
+#define ASR_WLOAD(RW, STEP)                                                                                   \
+  {                                                                                                           \
+    const int cc_ = (STEP) / 9, tap_ = (STEP) % 9;                                                            \
+    _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                         \
+      const int c = tid + i * 256, co = c / CPP, ch = c % CPP;                                                \
+      RW[i] = *reinterpret_cast<const u32x4_t*>(Wk + ((int64_t)co * 9 + tap_) * p.Cin + cc_ * 64 + ch * EPC); \
+    }                                                                                                         \
+  }
+#define ASR_WWRITE(RW, DST)                                                                                   \
+  {                                                                                                           \
+    _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                         \
+      const int c = tid + i * 256, co = c / CPP, ch = c % CPP;                                                \
+      *reinterpret_cast<u32x4_t*>((DST) + co * PP + ch * 16) = RW[i];                                         \
+    }                                                                                                         \
+  }
+  auto pstage = [&](int cc) __attribute__((always_inline)) {
+    for (int c = tid; c < 180 * CPP; c += 256) {
+      const int hp = c / CPP, ch = c % CPP;
+      const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        v = *reinterpret_cast<const uint4*>(X + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cin + cc * 64 + ch * EPC);
+      *reinterpret_cast<uint4*>(sP + hp * PP + ch * 16) = v;
+    }
+  };
+
+  {
+    u32x4_t rw0[WCH];
+    ASR_WLOAD(rw0, 0)
+    ASR_WWRITE(rw0, sW0)
+  }
+#pragma unroll 1
+  for (int step = 0; step < nsteps; ++step) {
+    const int tap = step % 9;
+    if (tap == 0) {
+      if (step > 0) __syncthreads();      // everybody is done with the previous channel slice of the patch
+      pstage(step / 9);
+      __syncthreads();                     // patch + weight buffer (step&1) visible
+    }
+    const bool has_next = step + 1 < nsteps;
+    u32x4_t rw[WCH];
+    if (has_next) ASR_WLOAD(rw, step + 1)
+    const unsigned char* sW = (step & 1) ? sW1 : sW0;
+    const int dy = tap / 3, dx = tap % 3;
+#pragma unroll
+    for (int ms = 0; ms < NMS; ++ms) {
+      uint4 a[4], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        a[i] = *reinterpret_cast<const uint4*>(sP + ((wm * 4 + i + dy) * 18 + lr + dx) * PP + (ms * 4 + g) * 16);
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+        bfr[j] = *reinterpret_cast<const uint4*>(sW + (wn * (NCO / 2) + j * 16 + lr) * PP + (ms * 4 + g) * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], bfr[j]);
+    }
+    if (has_next) {
+      unsigned char* dst = (step & 1) ? sW0 : sW1;
+      ASR_WWRITE(rw, dst)
+      // the next step either re-stages the patch (tap 8 -> barrier pair above) or needs this barrier
+      if (tap != 8) __syncthreads();
+    }
+  }
+
+#undef ASR_WLOAD
+#undef ASR_WWRITE
+
+  T* Y = static_cast<T*>(p.y);
+  const T* Msk = static_cast<const T*>(p.mask_src);
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int co = wn * (NCO / 2) + j * 16 + lr;
+    const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = h0 + wm * 4 + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gx = w0 + g * 4 + r;
+        if (gy < p.H && gx < p.W) {
+          const int64_t off = (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + co;
+          float v = acc[i][j][r] + bv;
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (Msk && !(DT<T>::ld(Msk + off) > 0.f)) v = 0.f;
+          DT<T>::st(Y + off, v);
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================ max pooling
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
+  const int64_t total = (int64_t)B * H2 * W2 * groups;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int cg = (int)(i % groups);
+    const int64_t op = i / groups;
+    const int ow = (int)(op % W2), oh = (int)((op / W2) % H2);
+    const int64_t b = op / ((int64_t)W2 * H2);
+    const T* base = x + (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+    Chunk<T> a, bq, c, d, o;
+    a.v = *reinterpret_cast<const uint4*>(base);
+    bq.v = *reinterpret_cast<const uint4*>(base + C);
+    c.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C);
+    d.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C + C);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const float m = fmaxf(fmaxf(DT<T>::from(a.e[j]), DT<T>::from(bq.e[j])), fmaxf(DT<T>::from(c.e[j]), DT<T>::from(d.e[j])));
+      o.e[j] = DT<T>::to(m);
+    }
+    *reinterpret_cast<uint4*>(y + op * C + cg * EPC) = o.v;
+  }
+}
+// block per (b, ow): pooled (H2, C) slab -> LDS -> written as (C, H2) i.e. feature index c*H2 + oh (transformer.py:74-76)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_tcf_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  extern __shared__ float sp[];     // [H2][C+1]
+  const int H2 = H / 2, W2 = W / 2;
+  const int ow = blockIdx.x % W2, b = blockIdx.x / W2;
+  for (int i = threadIdx.x; i < H2 * C; i += 256) {
+    const int c = i % C, oh = i / C;
+    const T* base = x + ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + c;
+    const float m = fmaxf(fmaxf(DT<T>::ld(base), DT<T>::ld(base + C)),
+                          fmaxf(DT<T>::ld(base + (int64_t)W * C), DT<T>::ld(base + (int64_t)W * C + C)));
+    sp[oh * (C + 1) + c] = m;
+  }
+  __syncthreads();
+  T* out = y + ((int64_t)b * W2 + ow) * (int64_t)C * H2;
+  for (int i = threadIdx.x; i < H2 * C; i += 256) {
+    const int oh = i % H2, c = i / H2;
+    DT<T>::st(out + i, sp[oh * (C + 1) + c]);
+  }
+}
+// dx for one 2x2 window: gradient goes to the FIRST maximum in scan order (PyTorch max_pool2d), times ReLU'(x)
+template <typename T>
+__device__ __forceinline__ void pool_bwd_window(const T* __restrict__ x, T* __restrict__ dx, int64_t base, int C, int W, float gy) {
+  const float v0 = DT<T>::ld(x + base), v1 = DT<T>::ld(x + base + C);
+  const float v2 = DT<T>::ld(x + base + (int64_t)W * C), v3 = DT<T>::ld(x + base + (int64_t)W * C + C);
+  int arg = 0; float m = v0;
+  if (v1 > m) { m = v1; arg = 1; }
+  if (v2 > m) { m = v2; arg = 2; }
+  if (v3 > m) { m = v3; arg = 3; }
+  const float gr = m > 0.f ? gy : 0.f;
+  DT<T>::st(dx + base, arg == 0 ? gr : 0.f);
+  DT<T>::st(dx + base + C, arg == 1 ? gr : 0.f);
+  DT<T>::st(dx + base + (int64_t)W * C, arg == 2 ? gr : 0.f);
+  DT<T>::st(dx + base + (int64_t)W * C + C, arg == 3 ? gr : 0.f);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                            int B, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2;
+  const int64_t total = (int64_t)B * H2 * W2 * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t op = i / C;
+    const int ow = (int)(op % W2), oh = (int)((op / W2) % H2);
+    const int64_t b = op / ((int64_t)W2 * H2);
+    pool_bwd_window<T>(x, dx, (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + c, C, W, DT<T>::ld(dy + i));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_tcf_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                           int B, int H, int W, int C) {
+  extern __shared__ float sp[];     // [H2][C+1]
+  const int H2 = H / 2, W2 = W / 2;
+  const int ow = blockIdx.x % W2, b = blockIdx.x / W2;
+  const T* in = dy + ((int64_t)b * W2 + ow) * (int64_t)C * H2;
+  for (int i = threadIdx.x; i < H2 * C; i += 256) {
+    const int oh = i % H2, c = i / H2;
+    sp[oh * (C + 1) + c] = DT<T>::ld(in + i);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < H2 * C; i += 256) {
+    const int c = i % C, oh = i / C;
+    pool_bwd_window<T>(x, dx, ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + c, C, W, sp[oh * (C + 1) + c]);
+  }
+}
+// rows/cols that floor-mode pooling drops (odd H or W) get zero gradient
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_edges_kernel(T* __restrict__ dx, int B, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2;
+  const int64_t total = (int64_t)B * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t pix = i / C;
+    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
+    if (yh >= 2 * H2 || xw >= 2 * W2) DT<T>::st(dx + i, 0.f);
+  }
+}
+
+// ================================================================================================ NHWC -> planar
+// block per (b, y, 64-wide x tile): (64 px, C) -> LDS -> C rows of 64 contiguous px
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const T* __restrict__ x, T* __restrict__ xp, int B, int H, int W, int C,
+                                                             int64_t WP, int64_t Np, int tiles_w) {
+  extern __shared__ float sp[];     // [64][C+1]
+  int t = blockIdx.x;
+  const int tw = t % tiles_w; t /= tiles_w;
+  const int yh = t % H;
+  const int b = t / H;
+  const int x0 = tw * 64;
+  const int npx = min(64, W - x0);
+  const T* in = x + (((int64_t)b * H + yh) * W + x0) * (int64_t)C;
+  for (int i = threadIdx.x; i < npx * C; i += 256) sp[(i / C) * (C + 1) + (i % C)] = DT<T>::ld(in + i);
+  __syncthreads();
+  const int64_t pbase = ((int64_t)b * (H + 1) + yh + 2) * WP + x0;
+  for (int i = threadIdx.x; i < C * 64; i += 256) {
+    const int px = i & 63, c = i >> 6;
+    if (px < npx) DT<T>::st(xp + (int64_t)c * Np + pbase + px, sp[px * (C + 1) + c]);
+  }
+}
+
+// ================================================================================================ wgrad
+struct WgradArgs {
+  const void* xp; const void* dyp; float* dw;
+  int Cin, Cout;
+  int64_t WP, Np, k_beg, k_end, k_per_slice;
+  int nci;     // Cin / 64
+};
+
+// workgroup: 64 output channels x (3x3 taps x 64 input channels) over one slice of the padded pixel axis.
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
+  constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
+  constexpr int BKP = 64 / ESZ;            // pixels per stage: 64 data bytes per row
+  constexpr int NMS = BKP / (4 * EPC);     // macro steps per stage (bf16: 1, f32: 1)
+  constexpr int PW = 80;                   // LDS row pitch (64 data + 16 pad)
+  static_assert(NMS == 1, "one macro step per stage");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;                // 64 rows  (co)
+  unsigned char* sB = smem + 64 * PW;      // 576 rows (tap, ci)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int co0 = (blockIdx.y / p.nci) * 64, ci0 = (blockIdx.y % p.nci) * 64;
+  const T* Xp = static_cast<const T*>(p.xp);
+  const T* Dp = static_cast<const T*>(p.dyp);
+  const int64_t kb = p.k_beg + (int64_t)blockIdx.x * p.k_per_slice;
+  const int64_t ke = min(p.k_end, kb + p.k_per_slice);
+
+  f32x4_t acc[4][9];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 9; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // loader assignment: A: thread -> (row = tid/4, chunk = tid%4); B: 3 units per thread, unit u = tid + i*256 ->
+  // (dyi = u / 256, ci = (u % 256) / 4, chunk = u % 4)
+  uint4 ra; Chunk<T> rb[3]; T rprev[3], rnext[3];
+  auto gload = [&](int64_t k0) __attribute__((always_inline)) {
+    {
+      const int row = tid >> 2, ch = tid & 3;
+      const int64_t k = k0 + ch * EPC;
+      ra = k < ke ? *reinterpret_cast<const uint4*>(Dp + (int64_t)(co0 + row) * p.Np + k) : make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ci = tid >> 2, ch = tid & 3;
+      const int64_t k = k0 + ch * EPC;
+      const T* a = Xp + (int64_t)(ci0 + ci) * p.Np + k + (int64_t)(i - 1) * p.WP;
+      if (k < ke) {
+        rb[i].v = *reinterpret_cast<const uint4*>(a);
+        rprev[i] = a[-1];
+        rnext[i] = a[EPC];
+      } else {
+        rb[i].v = make_uint4(0u, 0u, 0u, 0u);
+        rprev[i] = T(0); rnext[i] = T(0);
+      }
+    }
+  };
+  auto swrite = [&]() __attribute__((always_inline)) {
+    {
+      const int row = tid >> 2, ch = tid & 3;
+      *reinterpret_cast<uint4*>(sA + row * PW + ch * 16) = ra;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ci = tid >> 2, ch = tid & 3;
+      Chunk<T> lo, hi;
+      lo.e[0] = rprev[i];
+#pragma unroll
+      for (int j = 1; j < EPC; ++j) lo.e[j] = rb[i].e[j - 1];
+#pragma unroll
+      for (int j = 0; j < EPC - 1; ++j) hi.e[j] = rb[i].e[j + 1];
+      hi.e[EPC - 1] = rnext[i];
+      *reinterpret_cast<uint4*>(sB + ((i * 3 + 0) * 64 + ci) * PW + ch * 16) = lo.v;     // dx = -1 : x[p-1]
+      *reinterpret_cast<uint4*>(sB + ((i * 3 + 1) * 64 + ci) * PW + ch * 16) = rb[i].v;  // dx =  0
+      *reinterpret_cast<uint4*>(sB + ((i * 3 + 2) * 64 + ci) * PW + ch * 16) = hi.v;     // dx = +1 : x[p+1]
+    }
+  };
+
+  if (kb < ke) gload(kb);
+  for (int64_t k0 = kb; k0 < ke; k0 += BKP) {
+    swrite();
+    __syncthreads();
+    if (k0 + BKP < ke) gload(k0 + BKP);
+    uint4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(sA + (i * 16 + lr) * PW + g * 16);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+      const uint4 bfr = *reinterpret_cast<const uint4*>(sB + (wave * 144 + j * 16 + lr) * PW + g * 16);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mma16<T>(acc[i][j], a[i], bfr);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const int n = wave * 144 + j * 16 + lr;
+    const int tap = n >> 6, ci = ci0 + (n & 63);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + i * 16 + g * 4 + r;
+        atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + tap, acc[i][j][r]);
+      }
+  }
+}
+
+template <typename K> void allow_big_lds(K kernel, size_t lds) {
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+template <typename T, int NCO>
+int launch_igemm(const ConvArgs& a, hipStream_t s) {
+  ConvArgs p = a;
+  p.tiles_h = (p.H + 7) / 8;
+  p.tiles_w = (p.W + 15) / 16;
+  const size_t lds = (size_t)(180 + 2 * NCO) * (64 * sizeof(T) + 16);
+  allow_big_lds(conv3x3_igemm_kernel<T, NCO>, lds);
+  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+inline unsigned stream_grid(int64_t total_threads) {
+  int64_t blocks = ceil_div64(total_threads, 256);
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+}  // namespace
+
+extern "C" int64_t asr_planar_pitch(int W, int dtype) { (void)dtype; return ((int64_t)W + 1 + 7) / 8 * 8; }
+extern "C" int64_t asr_planar_size(int B, int H, int W, int dtype) { return ((int64_t)B * (H + 1) + 4) * asr_planar_pitch(W, dtype); }
+
+extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0, int dtype,
+                             hipStream_t s) {
+  ASR_CHECK_ARG(x && w && bias && y && B >= 0 && H > 0 && W > 0 && C0 > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  if (C0 % epc != 0 || !aligned16(y)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  const int64_t total = (int64_t)B * H * W * (C0 / epc);
+  const size_t lds = (size_t)C0 * 10 * sizeof(float);
+  AsrProfScope prof(ASR_OP_CONV1, s);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float>), dim3(stream_grid(total)), dim3(256), lds, s, x, w, bias, (float*)y, B, H, W, C0);
+  else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), lds, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_conv1_wgrad(const float* x, const void* dy, float* dw, float* db, int B, int H, int W, int C0, int dtype,
+                               hipStream_t s) {
+  ASR_CHECK_ARG(x && dy && dw && db && B >= 0 && H > 0 && W > 0 && C0 > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  if (C0 % epc != 0 || 256 % (C0 / epc) != 0 || !aligned16(dy)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  const int64_t npix = (int64_t)B * H * W;
+  const int ppb = 256 / (C0 / epc);
+  int64_t blocks = ceil_div64(npix, (int64_t)ppb * 64);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  const size_t lds = (size_t)C0 * 10 * sizeof(float);
+  AsrProfScope prof(ASR_OP_CONV1, s);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_wgrad_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, s, x, (const float*)dy, dw, db, B, H, W, C0);
+  else hipLaunchKernelGGL((conv1_wgrad_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, s, x, (const bf16_t*)dy, dw, db, B, H, W, C0);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_conv_pack_weight(const float* w, void* wk, void* wd, int Cout, int Cin, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(w && (wk || wd) && Cout > 0 && Cin > 0);
+  const int64_t total = (int64_t)Cout * Cin * 9;
+  if (dtype == ASR_F32) hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, w, (float*)wk, (float*)wd, Cout, Cin);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, w, (bf16_t*)wk, (bf16_t*)wd, Cout, Cin);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bias, const void* mask_src, void* y, int B, int H,
+                                 int W, int Cin, int Cout, int relu, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && wk && y && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (Cin % 64 != 0 || (Cout != 64 && Cout != 128) || !aligned16(x) || !aligned16(wk)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  ConvArgs p{};
+  p.x = x; p.wk = wk; p.bias = bias; p.mask_src = mask_src; p.y = y;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
+  return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);
+}
+
+extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && y && B >= 0 && H >= 2 && W >= 2 && C > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (B == 0) return ASR_OK;
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  const int H2 = H / 2, W2 = W / 2;
+  AsrProfScope prof(ASR_OP_POOL, s);
+  if (out_tcf) {
+    const size_t lds = (size_t)H2 * (C + 1) * sizeof(float);
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    if (dtype == ASR_F32) { allow_big_lds(pool_fwd_tcf_kernel<float>, lds); hipLaunchKernelGGL((pool_fwd_tcf_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (float*)y, B, H, W, C); }
+    else { allow_big_lds(pool_fwd_tcf_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_fwd_tcf_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C); }
+  } else {
+    if (C % epc != 0 || !aligned16(x) || !aligned16(y)) return ASR_EUNSUPPORTED;
+    const int64_t total = (int64_t)B * H2 * W2 * (C / epc);
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_fwd_nhwc_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
+    else hipLaunchKernelGGL((pool_fwd_nhwc_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
+                               hipStream_t s) {
+  ASR_CHECK_ARG(x && dy && dx && B >= 0 && H >= 2 && W >= 2 && C > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (B == 0) return ASR_OK;
+  const int H2 = H / 2, W2 = W / 2;
+  AsrProfScope prof(ASR_OP_POOL, s);
+  if ((H & 1) || (W & 1)) {
+    const int64_t total = (int64_t)B * H * W * C;
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_edges_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (float*)dx, B, H, W, C);
+    else hipLaunchKernelGGL((pool_bwd_edges_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (bf16_t*)dx, B, H, W, C);
+    ASR_LAUNCH_CHECK();
+  }
+  if (in_tcf) {
+    const size_t lds = (size_t)H2 * (C + 1) * sizeof(float);
+    if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    if (dtype == ASR_F32) { allow_big_lds(pool_bwd_tcf_kernel<float>, lds); hipLaunchKernelGGL((pool_bwd_tcf_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C); }
+    else { allow_big_lds(pool_bwd_tcf_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_bwd_tcf_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C); }
+  } else {
+    const int64_t total = (int64_t)B * H2 * W2 * C;
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_nhwc_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
+    else hipLaunchKernelGGL((pool_bwd_nhwc_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && xp && B >= 0 && H > 0 && W > 0 && C > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (B == 0) return ASR_OK;
+  const int64_t WP = asr_planar_pitch(W, dtype), Np = asr_planar_size(B, H, W, dtype);
+  const int tiles_w = (W + 63) / 64;
+  const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
+  AsrProfScope prof(ASR_OP_LAYOUT, s);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const float*)x, (float*)xp, B, H, W, C, WP, Np, tiles_w);
+  else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)xp, B, H, W, C, WP, Np, tiles_w);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw, int B, int H, int W, int Cin, int Cout, int dtype,
+                                 hipStream_t s) {
+  ASR_CHECK_ARG(xp && dyp && dw && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (Cin % 64 != 0 || Cout % 64 != 0 || !aligned16(xp) || !aligned16(dyp)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  WgradArgs p{};
+  p.xp = xp; p.dyp = dyp; p.dw = dw; p.Cin = Cin; p.Cout = Cout;
+  p.WP = asr_planar_pitch(W, dtype); p.Np = asr_planar_size(B, H, W, dtype);
+  p.k_beg = 2 * p.WP;                                  // rows 0,1 are guard / zero rows (tap reads reach row-1, elem-1)
+  p.k_end = ((int64_t)B * (H + 1) + 2) * p.WP;          // two more guard rows follow
+  p.nci = Cin / 64;
+  const int bkp = dtype == ASR_F32 ? 16 : 32;
+  const int tiles = (Cout / 64) * p.nci;
+  int64_t slices = 768 / tiles;
+  if (slices < 1) slices = 1;
+  const int64_t klen = p.k_end - p.k_beg;
+  int64_t kps = ceil_div64(ceil_div64(klen, slices), bkp) * bkp;
+  if (kps < 4 * bkp) kps = 4 * bkp;
+  slices = ceil_div64(klen, kps);
+  p.k_per_slice = kps;
+  const size_t lds = (size_t)(64 + 576) * 80;
+  AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
+  if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_kernel<float>), dim3((unsigned)slices, (unsigned)tiles), dim3(256), lds, s, p); }
+  else { allow_big_lds(conv3x3_wgrad_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_kernel<bf16_t>), dim3((unsigned)slices, (unsigned)tiles), dim3(256), lds, s, p); }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

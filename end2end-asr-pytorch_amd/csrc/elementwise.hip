@@ -1,0 +1,281 @@
+// HBM-bound helpers: transposes, weight shadows, bias-gradient column sums, embedding, decoder framing,
+// fused Adam, gradient-norm.  All are coalesced along the contiguous axis; reductions are wave-first.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ transpose
+// 64x64 tile through LDS (+1 pad).  in (rows, cols) -> out (cols, rows).  TI -> TO conversion on the way.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, int64_t ld_in, TO* __restrict__ out,
+                                                        int64_t ld_out, TO* __restrict__ out_same, int64_t ld_same, int rows, int cols) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int i = ty; i < 64; i += 4) {
+    int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < rows && c < cols) {
+      v = DT<TI>::ld(in + (int64_t)r * ld_in + c);
+      if (out_same) DT<TO>::st(out_same + (int64_t)r * ld_same + c, v);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (out) {
+    for (int i = ty; i < 64; i += 4) {
+      int c = c0 + i, r = r0 + tx;
+      if (r < rows && c < cols) DT<TO>::st(out + (int64_t)c * ld_out + r, tile[tx][i]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ colsum
+// out[n] += sum_m X[m, n].  Block = 256 threads = 64 columns x 4 row-lanes; grid.y strides over row slabs.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, int64_t ld, int M, int N, float* out,
+                                                     int rows_per_block) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int m_beg = blockIdx.y * rows_per_block, m_end = min(M, m_beg + rows_per_block);
+  float s = 0.f;
+  if (n < N)
+    for (int m = m_beg + ty; m < m_end; m += 4) s += DT<T>::ld(X + (int64_t)m * ld + n);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && n < N) atomicAdd(out + n, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+template <typename T>
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ table,
+                                                        const float* __restrict__ pe, T* __restrict__ out, int T_len,
+                                                        int D, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+  const int row = blockIdx.x;                 // b*T + t
+  const int t = row % T_len;
+  const int64_t id = tok[row];
+  const float* e = table + id * (int64_t)D;
+  const float* pr = pe + (int64_t)t * D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float v = e[c] * scale + pr[c];
+    if (thr) v = asr_keep(seed, (uint64_t)row * D + c, thr) ? v * inv_keep : 0.f;
+    DT<T>::st(out + (int64_t)row * D + c, v);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const T* __restrict__ dout,
+                                                        float* dtable, int D, float scale, uint32_t thr, float inv_keep,
+                                                        uint64_t seed, int pad_id) {
+  const int row = blockIdx.x;
+  const int64_t id = tok[row];
+  if (id == pad_id) return;                   // nn.Embedding(padding_idx=PAD): no gradient for the PAD row
+  float* d = dtable + id * (int64_t)D;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float g = DT<T>::ld(dout + (int64_t)row * D + c) * scale;
+    if (thr) g = asr_keep(seed, (uint64_t)row * D + c, thr) ? g * inv_keep : 0.f;
+    atomicAdd(d + c, g);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ preprocess
+// one wave per target row; stable compaction of non-PAD tokens with ballot prefix counts.
+__global__ __launch_bounds__(64) void preprocess_kernel(const int64_t* __restrict__ tgt, int L, int Td, int64_t* seq_in,
+                                                        int64_t* seq_out, uint8_t* key_pad, uint8_t* row_keep,
+                                                        int32_t* overflow) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t* y = tgt + (int64_t)b * L;
+  int64_t* si = seq_in + (int64_t)b * Td;
+  int64_t* so = seq_out + (int64_t)b * Td;
+  for (int t = lane; t < Td; t += 64) { si[t] = 2; so[t] = 0; }          // EOS / PAD fill (transformer.py:263-264)
+  __syncthreads();
+  int n = 0;
+  for (int base = 0; base < L; base += 64) {
+    const int i = base + lane;
+    const int64_t v = i < L ? y[i] : 0;
+    const bool keep = v != 0;
+    const unsigned long long m = __ballot(keep);
+    const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) {
+      if (pos + 1 < Td) si[pos + 1] = v;
+      if (pos < Td) so[pos] = v;
+    }
+    n += __popcll(m);
+  }
+  if (lane == 0) {
+    si[0] = 1;                                                             // SOS
+    if (n < Td) so[n] = 2;                                                 // EOS
+    if (n + 1 > Td) *overflow = 1;
+  }
+  __syncthreads();
+  for (int t = lane; t < Td; t += 64) {
+    const bool is_eos = si[t] == 2;
+    key_pad[(int64_t)b * Td + t] = is_eos ? 1 : 0;
+    row_keep[(int64_t)b * Td + t] = is_eos ? 0 : 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n4, int64_t n, float lr, float b1,
+                                                   float b2, float eps, float bc1, float bc2_sqrt,
+                                                   const float* __restrict__ gscale) {
+  const float gs = gscale ? *gscale : 1.f;
+  const float step = lr / bc1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; float* G = &gg.x; float* Mo = &mm.x; float* Vo = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = G[j] * gs;
+      Mo[j] = b1 * Mo[j] + (1.f - b1) * gj;
+      Vo[j] = b2 * Vo[j] + (1.f - b2) * gj * gj;
+      const float denom = sqrtf(Vo[j]) / bc2_sqrt + eps;
+      P[j] -= step * (Mo[j] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  // scalar tail
+  const int64_t tail = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tail < n) {
+    const float gj = g[tail] * gs;
+    const float mo = b1 * m[tail] + (1.f - b1) * gj;
+    const float vo = b2 * v[tail] + (1.f - b2) * gj * gj;
+    m[tail] = mo; v[tail] = vo;
+    p[tail] -= step * (mo / (sqrtf(vo) / bc2_sqrt + eps));
+  }
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* acc) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += g[i] * g[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
+}
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef) {
+  const float nrm = sqrtf(*sumsq);
+  const float c = max_norm / (nrm + 1e-6f);     // torch.nn.utils.clip_grad_norm_
+  *coef = c < 1.f ? c : 1.f;
+}
+
+}  // namespace
+
+extern "C" int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
+                             hipStream_t s) {
+  ASR_CHECK_ARG(in && out && rows >= 0 && cols >= 0);
+  if (rows == 0 || cols == 0) return ASR_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  AsrProfScope prof(ASR_OP_LAYOUT, s);
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, ld_in, (float*)out, ld_out,
+                       (float*)nullptr, (int64_t)0, rows, cols);
+  else if (dtype == ASR_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out,
+                       ld_out, (bf16_t*)nullptr, (int64_t)0, rows, cols);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_cast_weight(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t,
+                               int rows, int cols, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(src && rows >= 0 && cols >= 0 && (dst || dst_t) && ld_src >= cols);
+  ASR_CHECK_ARG((!dst || ld_dst >= cols) && (!dst_t || ld_dst_t >= rows));
+  if (rows == 0 || cols == 0) return ASR_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  AsrProfScope prof(ASR_OP_LAYOUT, s);
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, src, ld_src, (float*)dst_t, ld_dst_t,
+                       (float*)dst, ld_dst, rows, cols);
+  else if (dtype == ASR_BF16)
+    hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, s, src, ld_src, (bf16_t*)dst_t, ld_dst_t,
+                       (bf16_t*)dst, ld_dst, rows, cols);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_colsum_acc(const void* X, int64_t ld, int M, int N, float* out, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(X && out && M >= 0 && N >= 0);
+  if (M == 0 || N == 0) return ASR_OK;
+  const int rpb = 256;
+  dim3 grid((N + 63) / 64, (M + rpb - 1) / rpb);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)X, ld, M, N, out, rpb);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, ld, M, N, out, rpb);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void* out, int B, int T, int D,
+                             float scale, float p, uint64_t seed, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(tok && table && pe && out && B >= 0 && T > 0 && D > 0 && p >= 0.f && p < 1.f);
+  if (B == 0) return ASR_OK;
+  const uint32_t thr = asr_drop_threshold(p);
+  const float inv = 1.f / (1.f - p);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3(B * T), dim3(256), 0, s, tok, table, pe, (float*)out, T, D, scale, thr, inv, seed);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), dim3(B * T), dim3(256), 0, s, tok, table, pe, (bf16_t*)out, T, D, scale, thr, inv, seed);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+extern "C" int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable, int B, int T, int D, float scale,
+                             float p, uint64_t seed, int pad_id, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(tok && dout && dtable && B >= 0 && T > 0 && D > 0 && p >= 0.f && p < 1.f);
+  if (B == 0) return ASR_OK;
+  const uint32_t thr = asr_drop_threshold(p);
+  const float inv = 1.f / (1.f - p);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(B * T), dim3(256), 0, s, tok, (const float*)dout, dtable, D, scale, thr, inv, seed, pad_id);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(B * T), dim3(256), 0, s, tok, (const bf16_t*)dout, dtable, D, scale, thr, inv, seed, pad_id);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_decoder_preprocess(const int64_t* tgt, int B, int L, int Td, int64_t* seq_in, int64_t* seq_out,
+                                      uint8_t* key_pad, uint8_t* row_keep, int32_t* overflow, hipStream_t s) {
+  ASR_CHECK_ARG(tgt && seq_in && seq_out && key_pad && row_keep && overflow && B >= 0 && L >= 0 && Td >= 1);
+  if (B == 0) return ASR_OK;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(B), dim3(64), 0, s, tgt, L, Td, seq_in, seq_out, key_pad, row_keep, overflow);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                             float eps, float bc1, float bc2, const float* gscale, hipStream_t s) {
+  ASR_CHECK_ARG(p && g && m && v && n >= 0 && bc1 > 0.f && bc2 > 0.f);
+  if (n == 0) return ASR_OK;
+  ASR_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v));
+  const int64_t n4 = n / 4;
+  int64_t blocks = ceil_div64(n4 > 0 ? n4 : 1, 256);
+  if (blocks > 4096) blocks = 4096;
+  AsrProfScope prof(ASR_OP_ADAM, s);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, n, lr, beta1, beta2, eps, bc1,
+                     sqrtf(bc2), gscale);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_sumsq_acc(const float* g, int64_t n, float* acc, hipStream_t s) {
+  ASR_CHECK_ARG(g && acc && n >= 0);
+  if (n == 0) return ASR_OK;
+  int64_t blocks = ceil_div64(n, 256 * 8);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, acc);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+extern "C" int asr_clip_coef(const float* sumsq, float max_norm, float* coef, hipStream_t s) {
+  ASR_CHECK_ARG(sumsq && coef);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, coef);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

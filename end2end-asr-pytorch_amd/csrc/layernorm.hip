@@ -1,0 +1,223 @@
+// Fused sub-layer epilogue:  z = dropout(y) + residual ; out = (LN(z)*gamma + beta + post_add) * row_keep
+// (reference: models/common_layers.py:140-141 and :197-198; models/asr/transformer.py:172-173, :198, :201,
+//  :536-543).  One wave per row, row kept in registers, fp32 statistics (biased variance, eps inside sqrt).
+// HBM-bound: algorithmic bytes per row = (2 reads + 2 writes) * D * sizeof(T).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxPerLane = 32;   // D <= 64 * 32 = 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, const T* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ post, int post_period,
+                                                         const uint8_t* __restrict__ keep, T* __restrict__ out,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
+                                                         float eps, uint32_t thr, float inv_keep, uint64_t seed) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int NCH = kMaxPerLane / EPC;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  T* yr = y_z + (int64_t)row * D;
+  float z[kMaxPerLane];
+  float s = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = (ch * 64 + lane) * EPC;
+    if (c0 < D) {
+      Chunk<T> cy, cr;
+      cy.v = *reinterpret_cast<const uint4*>(yr + c0);
+      if (res) cr.v = *reinterpret_cast<const uint4*>(res + (int64_t)row * D + c0);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        float v = DT<T>::from(cy.e[j]);
+        if (thr) v = asr_keep(seed, (uint64_t)row * D + c0 + j, thr) ? v * inv_keep : 0.f;
+        if (res) v += DT<T>::from(cr.e[j]);
+        // z is what backward sees: round it to the storage type first so fwd and bwd agree bit for bit
+        cy.e[j] = DT<T>::to(v);
+        v = DT<T>::from(cy.e[j]);
+        z[ch * EPC + j] = v;
+        s += v;
+      }
+      *reinterpret_cast<uint4*>(yr + c0) = cy.v;
+    } else {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) z[ch * EPC + j] = 0.f;
+    }
+  }
+  const float mu = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = (ch * 64 + lane) * EPC;
+    if (c0 < D) {
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) { const float d = z[ch * EPC + j] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  const float kp = keep ? (keep[row] ? 1.f : 0.f) : 1.f;
+  const float* pr = post ? post + (int64_t)(row % post_period) * D : nullptr;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = (ch * 64 + lane) * EPC;
+    if (c0 < D) {
+      Chunk<T> co;
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) {
+        float v = (z[ch * EPC + j] - mu) * rs * gamma[c0 + j] + beta[c0 + j];
+        if (pr) v += pr[c0 + j];
+        co.e[j] = DT<T>::to(v * kp);
+      }
+      *reinterpret_cast<uint4*>(out + (int64_t)row * D + c0) = co.v;
+    }
+  }
+}
+
+// Backward.  Each block owns `rows_per_block` consecutive rows; lane l of every wave owns the same columns, so
+// dgamma/dbeta partials live in registers across rows and are reduced across the block's 4 waves through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ z,
+                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, const uint8_t* __restrict__ keep,
+                                                         T* __restrict__ d_res, T* __restrict__ d_y, float* dgamma,
+                                                         float* dbeta, int M, int D, int rows_per_block, uint32_t thr,
+                                                         float inv_keep, uint64_t seed) {
+  constexpr int EPC = DT<T>::EPC;
+  constexpr int NCH = kMaxPerLane / EPC;
+  extern __shared__ float red[];   // [4][2*D] -> only waves 1..3 write
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[kMaxPerLane], ab[kMaxPerLane];
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
+  for (int row = r_beg + wave; row < r_end; row += 4) {
+    const float kp = keep ? (keep[row] ? 1.f : 0.f) : 1.f;
+    const float mu = mean[row], rs = rstd[row];
+    float xh[kMaxPerLane], dyh[kMaxPerLane];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = (ch * 64 + lane) * EPC;
+      if (c0 < D) {
+        Chunk<T> cd, cz;
+        cd.v = *reinterpret_cast<const uint4*>(dout + (int64_t)row * D + c0);
+        cz.v = *reinterpret_cast<const uint4*>(z + (int64_t)row * D + c0);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const float go = DT<T>::from(cd.e[j]) * kp;
+          const float x = (DT<T>::from(cz.e[j]) - mu) * rs;
+          const float gy = go * gamma[c0 + j];
+          xh[ch * EPC + j] = x; dyh[ch * EPC + j] = gy;
+          s1 += gy; s2 += gy * x;
+          ag[ch * EPC + j] += go * x; ab[ch * EPC + j] += go;
+        }
+      }
+    }
+    s1 = wave_sum(s1) / (float)D;
+    s2 = wave_sum(s2) / (float)D;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = (ch * 64 + lane) * EPC;
+      if (c0 < D) {
+        Chunk<T> cr, cy;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          const float dz = rs * (dyh[ch * EPC + j] - s1 - xh[ch * EPC + j] * s2);
+          cr.e[j] = DT<T>::to(dz);
+          float dy = dz;
+          if (thr) dy = asr_keep(seed, (uint64_t)row * D + c0 + j, thr) ? dz * inv_keep : 0.f;
+          cy.e[j] = DT<T>::to(dy);
+        }
+        *reinterpret_cast<uint4*>(d_res + (int64_t)row * D + c0) = cr.v;
+        if (d_y && d_y != d_res) *reinterpret_cast<uint4*>(d_y + (int64_t)row * D + c0) = cy.v;
+      }
+    }
+  }
+  // block reduction of the column partials
+  if (wave > 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = (ch * 64 + lane) * EPC;
+      if (c0 < D) {
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          red[(wave - 1) * 2 * D + c0 + j] = ag[ch * EPC + j];
+          red[(wave - 1) * 2 * D + D + c0 + j] = ab[ch * EPC + j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = (ch * 64 + lane) * EPC;
+      if (c0 < D) {
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+          float g = ag[ch * EPC + j], b = ab[ch * EPC + j];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) { g += red[w * 2 * D + c0 + j]; b += red[w * 2 * D + D + c0 + j]; }
+          atomicAdd(dgamma + c0 + j, g);
+          atomicAdd(dbeta + c0 + j, b);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamma, const float* beta, const float* post_add,
+                              int post_period, const uint8_t* row_keep, void* out, float* mean, float* rstd, int M, int D,
+                              float eps, float p, uint64_t seed, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(y_z && gamma && beta && out && mean && rstd && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  if (D % epc != 0 || D > 64 * kMaxPerLane) return ASR_EUNSUPPORTED;
+  ASR_CHECK_ARG(aligned16(y_z) && aligned16(out) && (!residual || aligned16(residual)));
+  ASR_CHECK_ARG(!post_add || post_period > 0);
+  if (M == 0) return ASR_OK;
+  const uint32_t thr = asr_drop_threshold(p);
+  const float inv = 1.f / (1.f - p);
+  dim3 grid((M + 3) / 4);
+  AsrProfScope prof(ASR_OP_ADD_LN, s);
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((add_ln_fwd_kernel<float>), grid, dim3(256), 0, s, (float*)y_z, (const float*)residual, gamma, beta,
+                       post_add, post_period, row_keep, (float*)out, mean, rstd, M, D, eps, thr, inv, seed);
+  else
+    hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (bf16_t*)y_z, (const bf16_t*)residual, gamma, beta,
+                       post_add, post_period, row_keep, (bf16_t*)out, mean, rstd, M, D, eps, thr, inv, seed);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
+                              const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma, float* dbeta, int M, int D,
+                              float p, uint64_t seed, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(dout && z && mean && rstd && gamma && d_res && dgamma && dbeta && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  if (D % epc != 0 || D > 64 * kMaxPerLane) return ASR_EUNSUPPORTED;
+  ASR_CHECK_ARG(aligned16(dout) && aligned16(z) && aligned16(d_res) && (!d_y || aligned16(d_y)));
+  if (p > 0.f) ASR_CHECK_ARG(d_y && d_y != d_res);
+  if (M == 0) return ASR_OK;
+  const uint32_t thr = asr_drop_threshold(p);
+  const float inv = 1.f / (1.f - p);
+  const int rpb = 32;
+  dim3 grid((M + rpb - 1) / rpb);
+  const size_t lds = (size_t)3 * 2 * D * sizeof(float);
+  AsrProfScope prof(ASR_OP_ADD_LN, s);
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), lds, s, (const float*)dout, (const float*)z, mean, rstd,
+                       gamma, row_keep, (float*)d_res, (float*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed);
+  else
+    hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)z, mean,
+                       rstd, gamma, row_keep, (bf16_t*)d_res, (bf16_t*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

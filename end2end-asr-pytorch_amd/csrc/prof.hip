@@ -1,0 +1,75 @@
+// Error strings, ABI version and the built-in HIP-event profiler used by bench.py's roofline leg:
+// every launch of ONE selected op id is bracketed by hipEvents on the stream it is launched on.
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+struct Pair { hipEvent_t a, b; };
+struct OpProf {
+  bool enabled = false;
+  std::vector<Pair> pool;   // created lazily, reused across captures
+  size_t used = 0;
+};
+OpProf g_prof[ASR_OP_COUNT];
+std::mutex g_mu;
+constexpr size_t kMaxPairs = 1 << 16;
+}  // namespace
+
+AsrProfScope::AsrProfScope(int op_, hipStream_t s_) : op(op_), s(s_), slot(nullptr) {
+  if (op < 0 || op >= ASR_OP_COUNT || !g_prof[op].enabled) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  OpProf& P = g_prof[op];
+  if (P.used >= kMaxPairs) return;
+  if (P.used == P.pool.size()) {
+    Pair pr;
+    if (hipEventCreate(&pr.a) != hipSuccess || hipEventCreate(&pr.b) != hipSuccess) return;
+    P.pool.push_back(pr);
+  }
+  Pair* pr = &P.pool[P.used++];
+  (void)hipEventRecord(pr->a, s);
+  slot = reinterpret_cast<void*>(P.used);   // index + 1
+}
+AsrProfScope::~AsrProfScope() {
+  if (!slot) return;
+  std::lock_guard<std::mutex> lk(g_mu);
+  OpProf& P = g_prof[op];
+  const size_t idx = reinterpret_cast<size_t>(slot) - 1;
+  if (idx < P.pool.size()) (void)hipEventRecord(P.pool[idx].b, s);
+}
+
+extern "C" const char* asr_strerror(int code) {
+  switch (code) {
+    case ASR_OK: return "ok";
+    case ASR_EINVAL: return "invalid argument";
+    case ASR_ELAUNCH: return "kernel launch failed";
+    case ASR_EUNSUPPORTED: return "unsupported shape/alignment for this kernel";
+    case ASR_ERUNTIME: return "HIP runtime error";
+    default: return "unknown error";
+  }
+}
+extern "C" int asr_abi_version(void) { return 1; }
+
+extern "C" int asr_prof_enable(int op, int enable) {
+  if (op < 0 || op >= ASR_OP_COUNT) return ASR_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_prof[op].enabled = enable != 0;
+  if (enable) g_prof[op].used = 0;
+  return ASR_OK;
+}
+extern "C" int asr_prof_collect(int op, double* total_ms, int64_t* launches) {
+  if (op < 0 || op >= ASR_OP_COUNT || !total_ms || !launches) return ASR_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  OpProf& P = g_prof[op];
+  double tot = 0.0;
+  for (size_t i = 0; i < P.used; ++i) {
+    if (hipEventSynchronize(P.pool[i].b) != hipSuccess) return ASR_ERUNTIME;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, P.pool[i].a, P.pool[i].b) != hipSuccess) return ASR_ERUNTIME;
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = (int64_t)P.used;
+  return ASR_OK;
+}

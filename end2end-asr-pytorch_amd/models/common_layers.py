@@ -1,0 +1,174 @@
+"""Transformer building blocks with the reference's constructor signatures and state_dict keys
+(reference: models/common_layers.py), executed by the hand-written HIP kernels in libasr_hip.so.
+
+The nn.Linear / nn.Conv1d / nn.LayerNorm children are PARAMETER CONTAINERS only (same names, shapes and default
+initialisation as the reference, so checkpoints interchange); their own forward() is never called on the hot path.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from asr_hip import functions as F_
+from asr_hip import ops
+from utils import constant
+
+
+def pad_list(xs, pad_value):
+    """reference: common_layers.py:14-22 -- pads to --tgt-max-len (a flag, not the batch maximum)."""
+    max_len = constant.args.tgt_max_len
+    out = xs[0].new_full((len(xs), max_len) + tuple(xs[0].shape[1:]), pad_value)
+    for i, x in enumerate(xs):
+        out[i, :x.size(0)] = x
+    return out
+
+
+# ---- mask helpers: kept for API compatibility (reference: common_layers.py:28-74).  The fused kernels take
+# ---- lengths / pad bytes / a causal flag instead and never materialise (B,T,T) masks.
+def get_non_pad_mask(padded_input, input_lengths=None, pad_idx=None):
+    assert input_lengths is not None or pad_idx is not None
+    if input_lengths is not None:
+        T = padded_input.size(1)
+        lens = torch.as_tensor(input_lengths, device=padded_input.device).to(torch.int64)
+        mask = (torch.arange(T, device=padded_input.device)[None, :] < lens[:, None]).to(padded_input.dtype)
+    if pad_idx is not None:
+        assert padded_input.dim() == 2
+        mask = padded_input.ne(pad_idx).float()
+    return mask.unsqueeze(-1)
+
+
+def get_attn_key_pad_mask(seq_k, seq_q, pad_idx):
+    return seq_k.eq(pad_idx).unsqueeze(1).expand(-1, seq_q.size(1), -1)
+
+
+def get_attn_pad_mask(padded_input, input_lengths, expand_length):
+    pad = get_non_pad_mask(padded_input, input_lengths=input_lengths).squeeze(-1).lt(1)
+    return pad.unsqueeze(1).expand(-1, expand_length, -1)
+
+
+def get_subsequent_mask(seq):
+    b, n = seq.size()
+    m = torch.triu(torch.ones((n, n), device=seq.device, dtype=torch.bool), diagonal=1)
+    return m.unsqueeze(0).expand(b, -1, -1)
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table kept as the buffer `pe` (1, max_length, dim_model) exactly like the reference
+    (common_layers.py:80-98) so that it round-trips through state_dict."""
+
+    def __init__(self, dim_model, max_length=2000):
+        super().__init__()
+        pos = torch.arange(0, max_length).unsqueeze(1).float()
+        freq = torch.exp(torch.arange(0, dim_model, 2).float() * -(math.log(10000.0) / dim_model))
+        pe = torch.zeros(max_length, dim_model)
+        pe[:, 0::2] = torch.sin(pos * freq)
+        pe[:, 1::2] = torch.cos(pos * freq)
+        self.register_buffer('pe', pe.unsqueeze(0))
+
+    def forward(self, input):
+        return self.pe[:, :input.size(1)]
+
+
+def _to_compute(x):
+    cd = ops.compute_dtype()
+    return x if x.dtype == cd else x.to(cd)
+
+
+def _mask_to_u8(mask):
+    if mask is None:
+        return None
+    return mask.to(torch.uint8).contiguous()
+
+
+class MultiHeadAttention(nn.Module):
+    """forward(query, key, value, mask=None) -> (output, attn)   (reference: common_layers.py:144-200).
+
+    Fast path arguments (used by Encoder/Decoder): key_len (B int32: keys >= len masked), key_pad ((B,Tk) uint8),
+    causal, row_keep ((B*Tq) uint8: the `*= non_pad_mask` that follows every call in the reference), need_attn.
+    A generic boolean `mask` (B,Tq,Tk) is also accepted, as in the reference."""
+
+    def __init__(self, num_heads, dim_model, dim_key, dim_value, dropout=0.1):
+        super().__init__()
+        if dim_key != dim_value:
+            raise NotImplementedError("the fused attention kernel needs dim_key == dim_value")
+        self.num_heads, self.dim_model, self.dim_key, self.dim_value = num_heads, dim_model, dim_key, dim_value
+        self.query_linear = nn.Linear(dim_model, num_heads * dim_key)
+        self.key_linear = nn.Linear(dim_model, num_heads * dim_key)
+        self.value_linear = nn.Linear(dim_model, num_heads * dim_value)
+        nn.init.normal_(self.query_linear.weight, mean=0, std=np.sqrt(2.0 / (dim_model + dim_key)))
+        nn.init.normal_(self.key_linear.weight, mean=0, std=np.sqrt(2.0 / (dim_model + dim_key)))
+        nn.init.normal_(self.value_linear.weight, mean=0, std=np.sqrt(2.0 / (dim_model + dim_value)))
+        self.attention = ScaledDotProductAttention(temperature=np.power(dim_key, 0.5), attn_dropout=dropout)
+        self.layer_norm = nn.LayerNorm(dim_model)
+        self.output_linear = nn.Linear(num_heads * dim_value, dim_model)
+        nn.init.xavier_normal_(self.output_linear.weight)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
+                need_attn=True):
+        if key is not value:
+            raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
+        cfg = dict(H=self.num_heads, dk=self.dim_key, p=self.dropout.p if self.training else 0.0, key_len=key_len,
+                   key_pad=key_pad if key_pad is not None else _mask_to_u8(mask), causal=causal, row_keep=row_keep,
+                   want_attn=need_attn)
+        q = _to_compute(query)
+        kv = None if key is query else _to_compute(key)
+        res = F_.MHAFn.apply(q, kv, self.query_linear.weight, self.query_linear.bias, self.key_linear.weight,
+                             self.key_linear.bias, self.value_linear.weight, self.value_linear.bias,
+                             self.output_linear.weight, self.output_linear.bias, self.layer_norm.weight,
+                             self.layer_norm.bias, cfg)
+        if need_attn:
+            return res[0], res[1]
+        return res, None
+
+
+class ScaledDotProductAttention(nn.Module):
+    """forward(q, k, v, mask=None) on head-major (H*B, T, d) tensors (reference: common_layers.py:202-225), run by the
+    fused attention kernel with H = 1 (no gradient path: the training graph goes through MultiHeadAttention)."""
+
+    def __init__(self, temperature, attn_dropout=0.1):
+        super().__init__()
+        self.temperature = temperature
+        self.dropout = nn.Dropout(attn_dropout)
+
+    def forward(self, q, k, v, mask=None):
+        d = q.shape[-1]
+        p = self.dropout.p if self.training else 0.0
+        from asr_hip import params as P
+        o, _, attn = ops.attn_fwd(_to_compute(q).contiguous(), _to_compute(k).contiguous(), _to_compute(v).contiguous(),
+                                  1, d, key_pad=_mask_to_u8(mask), scale=1.0 / float(self.temperature), p=p,
+                                  seed=P.next_seed(), want_attn=True)
+        return o, attn
+
+
+class PositionwiseFeedForwardWithConv(nn.Module):
+    """LN(dropout(W2 relu(W1 x)) + x) with the weights stored as Conv1d(k=1) (reference: common_layers.py:124-142)."""
+
+    def __init__(self, dim_model, dim_hidden, dropout=0.1):
+        super().__init__()
+        self.conv_1 = nn.Conv1d(dim_model, dim_hidden, 1)
+        self.conv_2 = nn.Conv1d(dim_hidden, dim_model, 1)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(dim_model)
+
+    def forward(self, x, row_keep=None):
+        cfg = dict(p=self.dropout.p if self.training else 0.0, row_keep=row_keep)
+        return F_.FFNFn.apply(_to_compute(x), self.conv_1.weight, self.conv_1.bias, self.conv_2.weight, self.conv_2.bias,
+                              self.layer_norm.weight, self.layer_norm.bias, cfg)
+
+
+class PositionwiseFeedForward(nn.Module):
+    """Linear variant (reference: common_layers.py:100-122; unused by the reference model, kept for the API)."""
+
+    def __init__(self, dim_model, dim_ff, dropout=0.1):
+        super().__init__()
+        self.linear_1 = nn.Linear(dim_model, dim_ff)
+        self.linear_2 = nn.Linear(dim_ff, dim_model)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(dim_model)
+
+    def forward(self, x, row_keep=None):
+        cfg = dict(p=self.dropout.p if self.training else 0.0, row_keep=row_keep)
+        return F_.FFNFn.apply(_to_compute(x), self.linear_1.weight, self.linear_1.bias, self.linear_2.weight,
+                              self.linear_2.bias, self.layer_norm.weight, self.layer_norm.bias, cfg)

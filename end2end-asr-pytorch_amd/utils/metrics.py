@@ -1,0 +1,61 @@
+"""Loss and error-rate metrics with the reference's call signatures (reference: utils/metrics.py).
+
+calculate_loss / calculate_metrics run the label-smoothed cross entropy + argmax + num_correct kernel
+(asr_ce_fwd / asr_ce_bwd).  CER / WER use our own Levenshtein distance (asr_hip.text) because python-Levenshtein
+(reference: metrics.py:3) is a third-party C extension that is not part of this build.
+"""
+import torch
+
+from asr_hip import functions as F_
+from asr_hip.text import edit_distance
+from utils import constant
+
+
+def calculate_cer(s1, s2):
+    """Character edit distance between hypothesis s1 and gold s2 (reference: metrics.py:48-56)."""
+    return edit_distance(s1, s2)
+
+
+def calculate_wer(s1, s2):
+    """Word edit distance (reference: metrics.py:58-76; the word->char remapping there only exists to satisfy
+    python-Levenshtein's string-only API)."""
+    return edit_distance(s1.split(), s2.split())
+
+
+def _is_chinese(ch):
+    return '一' <= ch <= '鿿'
+
+
+def calculate_cer_en_zh(s1, s2):
+    """Mixed English / Chinese CER (reference: metrics.py:9-46 with data/helper.py:43-98): words containing a CJK
+    character are scored per language.  Returns (en_dist, zh_dist, len_en_gold, len_zh_gold)."""
+    def split(s):
+        en, zh = [], []
+        for seg in s.split():
+            (zh if any(_is_chinese(c) for c in seg) else en).append(seg)
+        return " ".join(en), " ".join(zh)
+    en1, zh1 = split(s1)
+    en2, zh2 = split(s2)
+    return calculate_cer(en1, en2), calculate_cer(zh1, zh2), len(en2), len(zh2)
+
+
+def calculate_loss(pred, gold, input_lengths=None, target_lengths=None, smoothing=0.0, loss_type="ce", global_count=None):
+    """pred (B,T,V), gold (B,T) -> scalar loss (reference: metrics.py:102-132).
+    ce: mean over non-PAD tokens of the label-smoothed row loss, smoothing mass eps/V on every class (metrics.py:124).
+    global_count: optional device scalar replacing the local non-PAD count (exact loss under data parallelism)."""
+    if loss_type != "ce":
+        raise NotImplementedError("only loss_type='ce' is on the accelerated path (CTC: SURVEY.md 8(f) #4)")
+    loss, _, _ = F_.CEFn.apply(pred, gold, float(smoothing), constant.PAD_TOKEN, global_count)
+    return loss
+
+
+def calculate_metrics(pred, gold, input_lengths=None, target_lengths=None, smoothing=0.0, loss_type="ce", sync=True,
+                      global_count=None):
+    """-> (loss, num_correct)  (reference: metrics.py:78-100).  num_correct is a Python int as in the reference
+    (one device sync); pass sync=False to get the fp32 device tensor [loss_sum, count, num_correct] instead."""
+    if loss_type != "ce":
+        raise NotImplementedError("only loss_type='ce' is on the accelerated path (CTC: SURVEY.md 8(f) #4)")
+    loss, sums, _ = F_.CEFn.apply(pred, gold, float(smoothing), constant.PAD_TOKEN, global_count)
+    if sync:
+        return loss, int(sums[2].item())
+    return loss, sums

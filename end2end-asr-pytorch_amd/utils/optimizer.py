@@ -1,0 +1,169 @@
+"""Noam learning-rate schedule around a fused Adam (reference: utils/optimizer.py:3-32, utils/functions.py:107).
+
+NoamOpt keeps the reference's attributes (`optimizer`, `_step`, `_rate`, `warmup`, `factor`, `model_size`, `min_lr`) and
+methods (`step`, `zero_grad`, `rate`).  FusedAdam is a torch.optim.Adam whose step() is ONE asr_adam_step launch over the
+flat fp32 parameter / gradient / moment buffers, so `optimizer.state_dict()` keeps torch's Adam schema (checkpoints
+interchange with the reference).
+"""
+import torch
+
+from asr_hip import ops
+from asr_hip import params as P
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, ddp_bucket_bytes=None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps)
+        self.flat = None            # asr_hip.params.FlatParams, created once the parameters live on a GPU
+        self.reducer = None         # asr_hip.ddp.GradReducer (only under --parallel with world_size > 1)
+        self.ddp_bucket_bytes = ddp_bucket_bytes
+        self.grad_scale = None      # device scalar set by clip_grad_norm_()
+        self._t = 0
+        self._ensure_flat()
+
+    def _ensure_flat(self):
+        """Flatten lazily: the reference builds the optimiser BEFORE model.cuda() (train.py:101-110)."""
+        if self.flat is not None:
+            self.flat.rebind()
+            return
+        plist = [p for g in self.param_groups for p in g['params']]
+        if not plist or not plist[0].is_cuda:
+            return
+        old = {p: dict(self.state[p]) for p in plist if p in self.state and 'exp_avg' in self.state[p]}
+        self.flat = P.FlatParams(plist)
+        self._m = torch.zeros_like(self.flat.data)
+        self._v = torch.zeros_like(self.flat.data)
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            if p in old:
+                n = p.numel()
+                self._m[o:o + n].copy_(old[p]['exp_avg'].reshape(-1))
+                self._v[o:o + n].copy_(old[p]['exp_avg_sq'].reshape(-1))
+                self._t = max(self._t, int(float(old[p]['step'])))
+        self._bind_state()
+        if self.ddp_bucket_bytes is not None:
+            import torch.distributed as dist
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                from asr_hip.ddp import GradReducer
+                self.reducer = GradReducer(self.flat, bucket_bytes=self.ddp_bucket_bytes)
+                self.reducer.broadcast_parameters(0)
+        P.set_reducer(self.reducer)
+
+    def _bind_state(self):
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            n = p.numel()
+            st = self.state[p]
+            st['step'] = torch.tensor(float(self._t))
+            st['exp_avg'] = self._m[o:o + n].view(p.shape)
+            st['exp_avg_sq'] = self._v[o:o + n].view(p.shape)
+
+    def zero_grad(self, set_to_none=False):
+        """Gradients are accumulation targets of the kernels: zero them, never drop them."""
+        self._ensure_flat()
+        if self.flat is not None:
+            self.flat.zero_grad()
+            return
+        for g in self.param_groups:
+            for p in g['params']:
+                if p.grad is not None:
+                    p.grad.zero_()
+
+    def clip_grad_norm_(self, max_norm):
+        """torch.nn.utils.clip_grad_norm_ (reference: trainer.py:108-109) without a host sync: the coefficient stays on
+        the device and is folded into the next step()."""
+        if self.reducer is not None:
+            self.reducer.finish()
+        dev = self.param_groups[0]['params'][0].device
+        acc = torch.zeros(1, device=dev, dtype=torch.float32)
+        if self.flat is not None:
+            ops.sumsq_acc(self.flat.grad, acc)
+        else:
+            for g in self.param_groups:
+                for p in g['params']:
+                    if p.grad is not None:
+                        ops.sumsq_acc(p.grad.reshape(-1), acc)
+        self.grad_scale = torch.empty(1, device=dev, dtype=torch.float32)
+        ops.clip_coef(acc, max_norm, self.grad_scale)
+        return acc
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._ensure_flat()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self._t += 1
+        for group in self.param_groups:
+            b1, b2 = group['betas']
+            if self.flat is not None:
+                ops.adam_step(self.flat.data, self.flat.grad, self._m, self._v, group['lr'], b1, b2, group['eps'], self._t,
+                              self.grad_scale)
+                for p in self.flat.params:
+                    self.state[p]['step'] += 1
+                break
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if 'exp_avg' not in st:
+                    st['step'] = torch.tensor(0.0)
+                    st['exp_avg'] = torch.zeros_like(p.data)
+                    st['exp_avg_sq'] = torch.zeros_like(p.data)
+                st['step'] += 1
+                ops.adam_step(p.data.view(-1), p.grad.view(-1), st['exp_avg'].view(-1), st['exp_avg_sq'].view(-1),
+                              group['lr'], b1, b2, group['eps'], int(st['step'].item()), self.grad_scale)
+        self.grad_scale = None
+        P.bump_generation()          # masters were rewritten through the C ABI: weight shadows are stale
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self.flat is None:
+            self._ensure_flat()
+            return
+        t = 0
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            st = self.state.get(p, {})
+            if 'exp_avg' in st:
+                n = p.numel()
+                self._m[o:o + n].copy_(st['exp_avg'].reshape(-1))
+                self._v[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+                t = max(t, int(float(st['step'])))
+        self._t = t
+        self._bind_state()
+
+
+class NoamOpt:
+    "Optim wrapper that implements rate (reference: utils/optimizer.py:3-32)."
+
+    def __init__(self, model_size, factor, warmup, optimizer, min_lr=1e-5):
+        self.optimizer = optimizer
+        self._step = 0
+        self.warmup = warmup
+        self.factor = factor
+        self.model_size = model_size
+        self._rate = 0
+        self.min_lr = min_lr
+
+    def step(self):
+        self._step += 1
+        rate = self.rate()
+        for g in self.optimizer.param_groups:
+            g['lr'] = rate
+        self._rate = rate
+        self.optimizer.step()
+
+    def zero_grad(self):
+        self.optimizer.zero_grad()
+
+    def rate(self, step=None):
+        s = self._step if step is None else step
+        return max(self.min_lr, self.factor * (self.model_size ** (-0.5) * min(s ** (-0.5), s * self.warmup ** (-1.5))))
+
+
+class AnnealingOpt:
+    "lr / lr_anneal per step() call (reference: utils/optimizer.py:34-45; never selected by train.py:103)."
+
+    def __init__(self, lr, lr_anneal, optimizer):
+        self.optimizer, self.lr, self.lr_anneal = optimizer, lr, lr_anneal
+
+    def step(self):
+        for g in self.optimizer.param_groups:
+            g['lr'] = g['lr'] / self.lr_anneal

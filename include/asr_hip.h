@@ -1,0 +1,165 @@
+/* libasr_hip.so -- C ABI of the MI355X (gfx950) kernels behind the Transformer-ASR training step.
+ *
+ * The reference (gentaiscool/end2end-asr-pytorch) is pure Python: its "FFI" is the set of ATen calls its
+ * modules make.  Each entry point below replaces one such call site (cited as file:line relative to the
+ * reference tree) with a hand-written HIP kernel.  The host-side binding a maintainer would add is a
+ * ctypes stub; ours lives in end2end-asr-pytorch_amd/asr_hip/lib.py.
+ *
+ * Conventions (every entry point)
+ *   - returns ASR_OK (0) or a negative ASR_E* code; never throws, never allocates or frees device memory,
+ *     never synchronises; all buffers are caller-owned device pointers; work is enqueued on `stream`.
+ *   - `dtype` selects the storage type of activations / shadow weights: ASR_F32 (parity mode) or ASR_BF16
+ *     (perf mode, bf16 in / fp32 accumulate).  Parameters, gradients of parameters, LayerNorm statistics,
+ *     logits and losses are always fp32.  Token ids are int64, lengths int32, masks uint8 (1 = keep / 1 = masked
+ *     as documented per argument).
+ *   - leading dimensions / strides are in ELEMENTS.
+ */
+#ifndef ASR_HIP_H_
+#define ASR_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* asr_stream_t; /* == hipStream_t */
+
+enum { ASR_OK = 0, ASR_EINVAL = -1, ASR_ELAUNCH = -2, ASR_EUNSUPPORTED = -3, ASR_ERUNTIME = -4 };
+enum { ASR_F32 = 0, ASR_BF16 = 1 };
+enum { ASR_GEMM_RELU = 1, ASR_GEMM_ACCUMULATE = 2 };
+/* op ids for the built-in HIP-event profiler (asr_prof_*) */
+enum {
+  ASR_OP_GEMM = 0, ASR_OP_CONV_IGEMM = 1, ASR_OP_CONV_WGRAD = 2, ASR_OP_ATTN_FWD = 3, ASR_OP_ATTN_BWD = 4,
+  ASR_OP_ADD_LN = 5, ASR_OP_CE = 6, ASR_OP_ADAM = 7, ASR_OP_CONV1 = 8, ASR_OP_POOL = 9, ASR_OP_LAYOUT = 10,
+  ASR_OP_COUNT = 16
+};
+
+const char* asr_strerror(int code);
+int asr_abi_version(void);
+
+/* ---- profiling: bracket every launch of one op id with hipEvents on its own stream ------------------------- */
+int asr_prof_enable(int op_id, int enable);           /* enable=1 starts a fresh capture for op_id            */
+int asr_prof_collect(int op_id, double* total_ms, int64_t* launches); /* synchronises the recorded events      */
+
+/* ---- dense contraction: nn.Linear / Conv1d(k=1) forward, dgrad, wgrad ----------------------------------------
+ * C[M,N] (op)= alpha * sum_k A[m*lda+k] * B[n*ldb+k]  (+ bias[n]) (ReLU).  Both operands K-contiguous.
+ * flags: ASR_GEMM_RELU, ASR_GEMM_ACCUMULATE (C += ...).  splits>1: split-K with fp32 atomics, requires
+ * out_dtype F32 and ACCUMULATE.  Replaces common_layers.py:136-142 (FFN), :181-187 (Q/K/V), :197 (out proj),
+ * transformer.py:172 (input_linear), :302 (output_linear) and their autograd backward.                        */
+int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
+                const void* relu_mask /* optional (M,ldc) tensor of the input dtype: C = 0 where relu_mask <= 0 */,
+                int M, int N, int K, float alpha, int flags, int splits, int in_dtype, int out_dtype,
+                asr_stream_t stream);
+
+/* out[c*ld_out + r] = in[r*ld_in + c]   (operand preparation for dgrad / wgrad)                              */
+int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
+                  asr_stream_t stream);
+/* fp32 (rows,cols; ld_src) -> copy (rows,cols; ld_dst) and transpose (cols,rows; ld_dst_t) in `dtype`; either dst
+ * may be NULL.  Used for weight shadows and for fp32 gradients entering a bf16 backward.                        */
+int asr_cast_weight(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t,
+                    int rows, int cols, int dtype, asr_stream_t stream);
+/* column sums: out[n] += sum_m X[m*ld+n]  (bias gradients)                                                     */
+int asr_colsum_acc(const void* X, int64_t ld, int M, int N, float* out, int dtype, asr_stream_t stream);
+
+/* ---- residual + dropout + LayerNorm (+ positional add) (+ row mask) -----------------------------------------
+ * z = dropout(y) + residual ; out = (LN(z)*gamma+beta + post_add[row % post_period]) * row_keep[row]
+ * y is overwritten with z (saved for backward).  residual/post_add/row_keep may be NULL.
+ * Replaces common_layers.py:140-141, :197-198 (sub-layer epilogues), transformer.py:172-173 (input LN + PE)
+ * and the `*= non_pad_mask` at transformer.py:198,201,536,540,543.                                            */
+int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamma, const float* beta, const float* post_add,
+                   int post_period, const uint8_t* row_keep, void* out, float* mean, float* rstd, int M, int D,
+                   float eps, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+/* d_res = LN'(dout*row_keep) ; d_y = d_res * dropmask/(1-p) (d_y may alias d_res when p == 0, or be NULL);
+ * dgamma_acc/dbeta_acc (fp32, D) are accumulated into.                                                         */
+int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
+                   const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma_acc, float* dbeta_acc, int M,
+                   int D, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+
+/* ---- fused multi-head attention core: softmax(mask(Q K^T * scale)) (dropout) V -------------------------------
+ * Q (B,Tq,H,d) with element strides (q_sb, q_st) and head h at offset h*d; same for K,V (B,Tk,H,d), O (B,Tq,H,d).
+ * Masks (True = masked, as reference): key index >= key_len[b] (NULL = none); key_pad[b*mask_sb + q*mask_sq + k] != 0
+ * (NULL = none; mask_sb=Tk, mask_sq=0 for a per-key mask, mask_sb=Tq*Tk, mask_sq=Tk for a full (B,Tq,Tk) mask);
+ * causal: key > query.  lse (B,H,Tq) fp32 saved for backward.  attn_out (H*B,Tq,Tk) fp32 optional (index h*B+b,
+ * reference layout common_layers.py:185-190).  Replaces common_layers.py:211-225 and the permutes at :185-195. */
+int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, float* attn_out, int B, int H,
+                 int Tq, int Tk, int d, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
+                 int64_t v_st, int64_t o_sb, int64_t o_st, const int32_t* key_len, const uint8_t* key_pad,
+                 int64_t mask_sb, int64_t mask_sq, int causal, float scale, float dropout_p, uint64_t seed, int dtype,
+                 asr_stream_t stream);
+/* delta (B,H,Tq) fp32 workspace.  dQ/dK/dV use the strides of Q/K/V.                                           */
+int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                 float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
+                 int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
+                 const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,
+                 float scale, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+
+/* ---- decoder input side ---------------------------------------------------------------------------------------
+ * Decoder.preprocess (transformer.py:254-266) + masks (:282-286): strip PAD(0) anywhere, seq_in = [SOS]+y padded
+ * with EOS to Td, seq_out = y+[EOS] padded with PAD; key_pad = (seq_in==EOS), row_keep = (seq_in!=EOS).
+ * *overflow is set to 1 if any row needs more than Td slots (pad_list would raise, common_layers.py:21).       */
+int asr_decoder_preprocess(const int64_t* tgt, int B, int L, int Td, int64_t* seq_in, int64_t* seq_out,
+                           uint8_t* key_pad, uint8_t* row_keep, int32_t* overflow, asr_stream_t stream);
+/* out = dropout(table[tok]*scale + pe[t])   (transformer.py:292-293); table/pe fp32                            */
+int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void* out, int B, int T, int D,
+                  float scale, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable_acc, int B, int T, int D, float scale,
+                  float dropout_p, uint64_t seed, int pad_id, int dtype, asr_stream_t stream);
+
+/* ---- label-smoothed cross entropy + argmax + num_correct (utils/metrics.py:78-132, transformer.py:80) ---------
+ * logits (M, ld) fp32.  sums[0] += sum of row losses over non-PAD rows, sums[1] += #non-PAD rows,
+ * sums[2] += #(argmax == gold) over non-PAD rows.  argmax = lowest index among maxima.                        */
+int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, int M, int V, float smoothing, int pad_id,
+               float* row_lse, int64_t* argmax, float* sums, asr_stream_t stream);
+/* out[m] = lowest index of the row maximum (torch.topk(pred,1) at transformer.py:80, metrics.py:89)            */
+int asr_argmax_rows(const float* logits, int64_t ld, int M, int V, int64_t* out, asr_stream_t stream);
+/* dlogits[m,v] = coef * (softmax*sum_q - q), coef = *grad_out / *count (device scalars), 0 for PAD rows.
+ * dlogits has leading dimension ldd >= V and dtype `out_dtype`; columns V..ldd-1 are zero-filled.              */
+int asr_ce_bwd(const float* logits, int64_t ld, const int64_t* gold, const float* row_lse, int M, int V,
+               float smoothing, int pad_id, const float* grad_out, const float* count, void* dlogits, int64_t ldd,
+               int out_dtype, asr_stream_t stream);
+
+/* ---- optimiser: Adam(beta 0.9/0.98, eps 1e-9) under the Noam schedule (utils/optimizer.py:15-32,
+ * utils/functions.py:107).  One launch over the flat fp32 parameter/gradient/moment buffers.
+ * grad_scale_dev: optional device scalar multiplied into g (gradient clipping coefficient), may be NULL.        */
+int asr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float bias_corr1, float bias_corr2, const float* grad_scale_dev, asr_stream_t stream);
+/* acc[0] += sum(g^2)  (clip_grad_norm_, trainer.py:108-109)                                                     */
+int asr_sumsq_acc(const float* g, int64_t n, float* acc, asr_stream_t stream);
+/* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))                                                          */
+int asr_clip_coef(const float* sumsq, float max_norm, float* coef, asr_stream_t stream);
+
+/* ---- vgg_cnn front end (transformer.py:42-53, :70-76) -----------------------------------------------------------
+ * Activations are NHWC: (B, H=F, W=T, C), C contiguous, in `dtype`.                                             */
+/* conv.0: 1->C0 3x3 pad 1 + ReLU from the raw fp32 spectrogram (B,1,F,T); weight (C0,1,3,3), bias fp32          */
+int asr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0,
+                  int dtype, asr_stream_t stream);
+/* dw (C0*9) += , db (C0) += ; dy already masked by ReLU                                                          */
+int asr_conv1_wgrad(const float* x, const void* dy, float* dw_acc, float* db_acc, int B, int H, int W, int C0,
+                    int dtype, asr_stream_t stream);
+/* master (Cout,Cin,3,3) fp32 -> wk (Cout,9,Cin) for forward and wd (Cin,9,Cout) tap-flipped for dgrad            */
+int asr_conv_pack_weight(const float* w, void* wk, void* wd, int Cout, int Cin, int dtype, asr_stream_t stream);
+/* y = act(conv3x3_pad1(x; wk) + bias): relu=1 -> ReLU.  If mask_src != NULL: y *= (mask_src > 0) (dgrad through
+ * the ReLU that produced this conv's input).  Cin, Cout multiples of 64, Cout <= 128.                           */
+int asr_conv3x3_igemm(const void* x, const void* wk, const float* bias, const void* mask_src, void* y, int B,
+                      int H, int W, int Cin, int Cout, int relu, int dtype, asr_stream_t stream);
+/* 2x2/2 floor max-pool NHWC; if out_tcf != 0 writes (B, W/2, C, H/2) i.e. the encoder layout (B,T',C*F')        */
+int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, asr_stream_t stream);
+/* dx = scatter of dy to the first maximum of each window, times (x > 0); dy layout per in_tcf                   */
+int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
+                    asr_stream_t stream);
+/* NHWC (B,H,W,C) -> planar zero-padded (C, Np): pixel (b,y,x) at plane offset ((b*(H+1)+y+2)*WP + x), WP =
+ * asr_planar_pitch(W) >= W+1, one zero row between images, two guard rows at either end; Np = (B*(H+1)+4)*WP.
+ * Pads must be zero: the caller zero-initialises the buffer once, the kernel only writes real pixels.           */
+int64_t asr_planar_pitch(int W, int dtype);
+int64_t asr_planar_size(int B, int H, int W, int dtype); /* Np, elements per channel plane                        */
+int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int dtype, asr_stream_t stream);
+/* dW (Cout,Cin,3,3) += sum_p dy[p,co] * x[p+tap,ci] from planar operands (bias grad: asr_colsum_acc on NHWC dy)   */
+int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw_acc, int B, int H, int W, int Cin, int Cout,
+                      int dtype, asr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H_ */

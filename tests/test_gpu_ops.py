@@ -1,0 +1,443 @@
+"""Per-kernel parity: every C-ABI entry point against the torch-CPU fp32 expression it replaces (seeded inputs).
+Tolerances: fp32 mode = fp32 round-off of a different summation order; bf16 mode = bf16 storage (8 mantissa bits) of
+inputs/outputs with fp32 accumulation.  Runs on the MI355X (`-m gpu`)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def tol(dtype, scale=1.0):
+    return (2e-5 if dtype == torch.float32 else 1.6e-2) * scale
+
+
+def close(name, got, ref, dtype, scale=1.0, atol=0.0):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, "%s: shape %s vs %s" % (name, tuple(got.shape), tuple(ref.shape))
+    assert torch.isfinite(got).all(), "%s: non-finite output" % name
+    err = (got - ref).abs().max().item()
+    bound = atol + tol(dtype, scale) * max(ref.abs().max().item(), 1e-6)
+    assert err <= bound, "%s: max abs err %.3e > %.3e (ref max %.3e)" % (name, err, bound, ref.abs().max().item())
+
+
+def q(x, dtype):
+    """Round a CPU fp32 tensor to what the kernel will actually see."""
+    return x.to(dtype).float()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from asr_hip import ops as o
+    return o
+
+
+# ------------------------------------------------------------------------------------------------ MFMA layout probe
+def test_mfma_fragment_layout_asymmetric(ops):
+    """A = I (and a permutation) against an ASYMMETRIC B catches row/col swaps in the fragment maps."""
+    for dtype in DTYPES:
+        n = 48
+        A = torch.eye(n)
+        B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 / 16.0       # exactly representable in bf16
+        C = ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), out_dtype=torch.float32)
+        assert torch.equal(C.cpu(), B.t().contiguous()), "gemm_nt(I, B) != B^T for %s" % dtype
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+        C2 = ops.gemm_nt(A[perm].to(dev(), dtype), B.to(dev(), dtype), out_dtype=torch.float32)
+        assert torch.equal(C2.cpu(), B.t()[perm].contiguous())
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(200, 70, 96), (512, 384, 256), (130, 260, 40), (64, 4364, 512), (1000, 512, 5120),
+                                   (37, 35, 161)])
+def test_gemm_nt_bias_relu(ops, dtype, shape):
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = q(torch.randn(M, K, generator=g), dtype)
+    B = q(torch.randn(N, K, generator=g) / math.sqrt(K), dtype)
+    bias = torch.randn(N, generator=g)
+    ref = A @ B.t() + bias
+    out = ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), bias=bias.to(dev()))
+    close("gemm", out, ref, dtype)
+    out = ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), bias=bias.to(dev()), relu=True, out_dtype=torch.float32)
+    close("gemm+relu fp32 out", out, ref.relu(), torch.float32 if dtype == torch.float32 else dtype, scale=0.1 if dtype != torch.float32 else 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_splitk_accumulate_and_mask(ops, dtype):
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 96, 160, 4096
+    A = q(torch.randn(M, K, generator=g), dtype)
+    B = q(torch.randn(N, K, generator=g) / 64, dtype)
+    C0 = torch.randn(M, N, generator=g)
+    out = C0.clone().to(dev())
+    ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), out=out, accumulate=True, splits=8, alpha=0.5)
+    close("split-K", out, C0 + 0.5 * (A @ B.t()), torch.float32 if dtype == torch.float32 else dtype, scale=0.2 if dtype != torch.float32 else 4)
+    mask = q(torch.randn(M, N, generator=g), dtype)
+    out2 = ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), relu_mask=mask.to(dev(), dtype))
+    close("relu-mask epilogue", out2, (A @ B.t()) * (mask > 0), dtype)
+    acc = q(torch.randn(M, N, generator=g), dtype).to(dev(), dtype)
+    ref = acc.float().cpu() + A @ B.t()
+    ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), out=acc, accumulate=True)
+    close("accumulate in storage dtype", acc, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_cast_colsum(ops, dtype):
+    g = torch.Generator().manual_seed(3)
+    x = q(torch.randn(203, 77, generator=g), dtype)
+    t = ops.transpose(x.to(dev(), dtype))
+    assert torch.equal(t.float().cpu(), x.t())
+    tp = ops.transpose_padded(x.to(dev(), dtype))
+    assert tp.shape == (77, 208) and (tp[:, 203:] == 0).all()
+    src = torch.randn(131, 45, generator=g)
+    same, tr = ops.cast_and_transpose(src.to(dev()), dtype)
+    assert torch.equal(same[:, :45].float().cpu(), q(src, dtype)) and (same[:, 45:] == 0).all()
+    assert torch.equal(tr[:, :131].float().cpu(), q(src, dtype).t()) and (tr[:, 131:] == 0).all()
+    acc = torch.ones(77, device=dev())
+    ops.colsum_acc(x.to(dev(), dtype), acc)
+    close("colsum", acc, 1 + x.sum(0), torch.float32, scale=4)
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm epilogue
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D", [32, 512])
+def test_add_ln_fwd_bwd(ops, dtype, D):
+    g = torch.Generator().manual_seed(D)
+    M, T = 50, 10
+    y = q(torch.randn(M, D, generator=g), dtype)
+    res = q(torch.randn(M, D, generator=g), dtype)
+    gamma = 1 + 0.2 * torch.randn(D, generator=g)
+    beta = 0.1 * torch.randn(D, generator=g)
+    pe = torch.randn(T, D, generator=g)
+    keep = (torch.rand(M, generator=g) > 0.3)
+    dout = q(torch.randn(M, D, generator=g), dtype)
+
+    yr, rr, gr, br = y.clone().requires_grad_(), res.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    z = q((yr + rr).detach(), dtype) + (yr + rr) - (yr + rr).detach()        # kernel normalises the ROUNDED z
+    ref = (F.layer_norm(z, (D,), gr, br, 1e-5) + pe.repeat(M // T, 1)) * keep[:, None].float()
+    ref.backward(dout)
+
+    yz = y.to(dev(), dtype)
+    out, mean, rstd = ops.add_ln_fwd(yz, res.to(dev(), dtype), gamma.to(dev()), beta.to(dev()), post_add=pe.to(dev()),
+                                     row_keep=keep.to(torch.uint8).to(dev()))
+    close("ln out", out, ref, dtype, scale=2)
+    close("ln z (in place)", yz, q(y + res, dtype), dtype)
+    dg = torch.zeros(D, device=dev()); db = torch.zeros(D, device=dev())
+    d_res, d_y = ops.add_ln_bwd(dout.to(dev(), dtype), yz, mean, rstd, gamma.to(dev()), keep.to(torch.uint8).to(dev()), dg, db)
+    assert d_y is d_res
+    close("ln d_res", d_res, rr.grad, dtype, scale=4)
+    close("ln dgamma", dg, gr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=8 if dtype == torch.float32 else 2)
+    close("ln dbeta", db, br.grad, torch.float32, scale=8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_ln_dropout_consistency(ops, dtype):
+    """Dropout: keep-rate statistics, scaling, and the backward mask equals the forward mask."""
+    M, D, p = 256, 512, 0.25
+    y = torch.ones(M, D).to(dev(), dtype)
+    gamma, beta = torch.ones(D, device=dev()), torch.zeros(D, device=dev())
+    yz = y.clone()
+    out, mean, rstd = ops.add_ln_fwd(yz, None, gamma, beta, p=p, seed=1234)
+    zf = yz.float()
+    kept = zf != 0
+    rate = kept.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01, rate
+    assert torch.allclose(zf[kept], torch.full_like(zf[kept], 1 / (1 - p)), rtol=1e-2)
+    dg = torch.zeros(D, device=dev()); db = torch.zeros(D, device=dev())
+    dout = torch.randn(M, D, device=dev()).to(dtype)
+    d_res, d_y = ops.add_ln_bwd(dout, yz, mean, rstd, gamma, None, dg, db, p=p, seed=1234)
+    assert d_y is not d_res
+    dyf, drf = d_y.float(), d_res.float()
+    assert (dyf[~kept] == 0).all()
+    assert torch.allclose(dyf[kept], drf[kept] / (1 - p), rtol=2e-2, atol=1e-6)
+    yz2 = y.clone()
+    ops.add_ln_fwd(yz2, None, gamma, beta, p=p, seed=99)
+    assert not torch.equal(yz2, yz)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attn_ref(qx, kx, vx, H, d, key_len, key_pad, causal, scale):
+    B, Tq, _ = qx.shape
+    Tk = kx.shape[1]
+    qh = qx.view(B, Tq, H, d).permute(0, 2, 1, 3)
+    kh = kx.view(B, Tk, H, d).permute(0, 2, 1, 3)
+    vh = vx.view(B, Tk, H, d).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) * scale
+    mask = torch.zeros(B, 1, Tq, Tk, dtype=torch.bool)
+    if key_len is not None:
+        mask |= (torch.arange(Tk)[None, :] >= key_len[:, None].long())[:, None, None, :]
+    if key_pad is not None:
+        kp = key_pad.bool()
+        mask |= kp[:, None, None, :] if kp.dim() == 2 else kp[:, None]
+    if causal:
+        mask |= torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), diagonal=1)[None, None]
+    s = s.masked_fill(mask, float("-inf"))
+    a = torch.softmax(s, dim=-1)
+    o = (a @ vh).permute(0, 2, 1, 3).reshape(B, Tq, H * d)
+    return o, a
+
+
+CASES = [
+    dict(B=2, H=2, Tq=16, Tk=16, d=16, key_len=[16, 9], causal=False),
+    dict(B=3, H=4, Tq=100, Tk=100, d=16, pad=True, causal=True),
+    dict(B=2, H=8, Tq=100, Tk=200, d=64, key_len=[200, 37], causal=False),
+    dict(B=2, H=2, Tq=130, Tk=75, d=32, key_len=[75, 60], causal=False),
+    dict(B=1, H=2, Tq=70, Tk=70, d=64, full=True, causal=False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES)
+def test_attention_fwd_bwd(ops, dtype, case):
+    B, H, Tq, Tk, d = case["B"], case["H"], case["Tq"], case["Tk"], case["d"]
+    g = torch.Generator().manual_seed(Tq * 7 + Tk)
+    qx = q(torch.randn(B, Tq, H * d, generator=g), dtype)
+    kx = q(torch.randn(B, Tk, H * d, generator=g), dtype)
+    vx = q(torch.randn(B, Tk, H * d, generator=g), dtype)
+    do = q(torch.randn(B, Tq, H * d, generator=g), dtype)
+    key_len = torch.tensor(case["key_len"], dtype=torch.int32) if "key_len" in case else None
+    key_pad = None
+    if case.get("pad"):
+        key_pad = torch.zeros(B, Tk, dtype=torch.uint8)
+        for b in range(B):
+            key_pad[b, Tk - 7 * (b + 1):] = 1
+    if case.get("full"):
+        key_pad = (torch.rand(B, Tq, Tk, generator=g) > 0.7).to(torch.uint8)
+        key_pad[:, :, 0] = 0
+    scale = 1.0 / math.sqrt(d)
+    qr, kr, vr = qx.clone().requires_grad_(), kx.clone().requires_grad_(), vx.clone().requires_grad_()
+    oref, aref = attn_ref(qr, kr, vr, H, d, key_len, key_pad, case["causal"], scale)
+    oref.backward(do)
+    D = dev()
+    kl = key_len.to(D) if key_len is not None else None
+    kp = key_pad.to(D) if key_pad is not None else None
+    o, lse, attn = ops.attn_fwd(qx.to(D, dtype), kx.to(D, dtype), vx.to(D, dtype), H, d, key_len=kl, key_pad=kp,
+                                causal=case["causal"], scale=scale, want_attn=True)
+    close("attn out", o, oref, dtype, scale=2)
+    aref_hb = aref.permute(1, 0, 2, 3).reshape(H * B, Tq, Tk)
+    close("attn probs (H*B layout)", attn, aref_hb, dtype, scale=2, atol=1e-6)
+    dq, dk, dv = ops.attn_bwd(qx.to(D, dtype), kx.to(D, dtype), vx.to(D, dtype), o, do.to(D, dtype), lse, H, d, key_len=kl,
+                              key_pad=kp, causal=case["causal"], scale=scale)
+    close("attn dq", dq, qr.grad, dtype, scale=4)
+    close("attn dk", dk, kr.grad, dtype, scale=4)
+    close("attn dv", dv, vr.grad, dtype, scale=4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_dropout_consistency(ops, dtype):
+    """With dropout the returned attention matrix IS the dropped/scaled one; O must equal attn @ V and the backward
+    must use the same mask (checked through dV = attn^T dO)."""
+    B, H, T, d, p = 2, 2, 96, 32, 0.2
+    g = torch.Generator().manual_seed(5)
+    D = dev()
+    qx = torch.randn(B, T, H * d, generator=g).to(D, dtype)
+    kx = torch.randn(B, T, H * d, generator=g).to(D, dtype)
+    vx = torch.randn(B, T, H * d, generator=g).to(D, dtype)
+    do = torch.randn(B, T, H * d, generator=g).to(D, dtype)
+    o, lse, attn = ops.attn_fwd(qx, kx, vx, H, d, scale=0.2, p=p, seed=77, want_attn=True)
+    a = attn.view(H, B, T, T).permute(1, 0, 2, 3).float().cpu()
+    drop_rate = (a == 0).float().mean().item()
+    assert abs(drop_rate - p) < 0.02, drop_rate
+    vh = vx.float().cpu().view(B, T, H, d).permute(0, 2, 1, 3)
+    close("O == attn_dropped @ V", o, (a @ vh).permute(0, 2, 1, 3).reshape(B, T, H * d), dtype, scale=3)
+    _, _, dv = ops.attn_bwd(qx, kx, vx, o, do, lse, H, d, scale=0.2, p=p, seed=77)
+    doh = do.float().cpu().view(B, T, H, d).permute(0, 2, 1, 3)
+    close("dV == attn_dropped^T @ dO", dv, (a.transpose(-1, -2) @ doh).permute(0, 2, 1, 3).reshape(B, T, H * d), dtype, scale=4)
+
+
+# ------------------------------------------------------------------------------------------------ decoder input side
+def test_decoder_preprocess_matches_oracle(ops):
+    from oracle import asr_oracle as O
+    g = torch.Generator().manual_seed(11)
+    B, Lw, Td = 5, 14, 16
+    tgt = torch.randint(3, 30, (B, Lw), generator=g)
+    tgt[0, 10:] = 0
+    tgt[1, 3] = 0           # interior PAD
+    tgt[2, :] = 0           # empty target
+    tgt[3, 14:] = 0
+    si_ref, so_ref = O.decoder_preprocess(tgt, Td)
+    si, so, key_pad, row_keep, ovf = ops.decoder_preprocess(tgt.to(dev()), Td)
+    assert torch.equal(si.cpu(), si_ref) and torch.equal(so.cpu(), so_ref)
+    assert torch.equal(key_pad.cpu().bool(), si_ref == O.EOS) and torch.equal(row_keep.cpu().bool(), si_ref != O.EOS)
+    assert int(ovf.item()) == 0
+    _, _, _, _, ovf = ops.decoder_preprocess(torch.randint(3, 30, (2, 20), generator=g).to(dev()), Td)
+    assert int(ovf.item()) == 1
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_fwd_bwd(ops, dtype):
+    g = torch.Generator().manual_seed(2)
+    B, T, D, V = 3, 12, 64, 35
+    tok = torch.randint(0, V, (B, T), generator=g)
+    table = torch.randn(V, D, generator=g)
+    pe = torch.randn(T, D, generator=g)
+    out = ops.embed_fwd(tok.to(dev()), table.to(dev()), pe.to(dev()), 0.5, 0.0, 0, dtype)
+    close("embed", out, table[tok] * 0.5 + pe, dtype)
+    dout = q(torch.randn(B, T, D, generator=g), dtype)
+    dt = torch.zeros(V, D, device=dev())
+    ops.embed_bwd(tok.to(dev()), dout.to(dev(), dtype), dt, 0.5, 0.0, 0, 0)
+    ref = torch.zeros(V, D).index_add_(0, tok.reshape(-1), dout.reshape(-1, D) * 0.5)
+    ref[0] = 0                                      # padding_idx row gets no gradient
+    close("embed bwd", dt, ref, torch.float32, scale=4)
+
+
+# ------------------------------------------------------------------------------------------------ loss
+@pytest.mark.parametrize("smoothing", [0.0, 0.1])
+@pytest.mark.parametrize("V", [35, 4364])
+def test_ce_matches_oracle(ops, smoothing, V):
+    from oracle import asr_oracle as O
+    g = torch.Generator().manual_seed(V)
+    M = 60
+    logits = torch.randn(M, V, generator=g)
+    gold = torch.randint(1, V, (M,), generator=g)
+    gold[::5] = 0
+    logits[7] = 0.0                                  # exact tie over the whole row -> argmax must be 0
+    logits[8, 5] = logits[8, 20] = 9.0               # two-way tie -> lowest index
+    lr = logits.clone().requires_grad_()
+    loss_ref, ncorrect, nword = O.smoothed_ce(lr.view(1, M, V), gold.view(1, M), smoothing)
+    loss_ref.backward()
+    lse, am, sums = ops.ce_fwd(logits.to(dev()), gold.to(dev()), smoothing, 0)
+    s = sums.cpu()
+    assert int(s[1]) == nword and int(s[2]) == ncorrect
+    assert abs(s[0].item() / s[1].item() - loss_ref.item()) < 2e-5 * max(1.0, abs(loss_ref.item()))
+    assert torch.equal(am.cpu(), logits.argmax(1)) and am[7].item() == 0 and am[8].item() == 5
+    assert torch.equal(ops.argmax_rows(logits.to(dev())).cpu(), logits.argmax(1))
+    gout = torch.tensor([1.7], device=dev())
+    dl = ops.ce_bwd(logits.to(dev()), gold.to(dev()), lse, smoothing, 0, gout, sums[1:2])
+    close("dlogits", dl, 1.7 * lr.grad, torch.float32, scale=8, atol=1e-9)
+    assert dl.stride(0) % 8 == 0
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_adam_matches_oracle(ops):
+    from oracle import asr_oracle as O
+    g = torch.Generator().manual_seed(9)
+    n = 1003
+    p0 = torch.randn(n, generator=g)
+    params = {"w": p0.clone()}
+    opt = O.NoamAdam(params, model_size=5120)
+    p = torch.zeros(1008, device=dev()); p[:n] = p0.to(dev())
+    gbuf = torch.zeros(1008, device=dev()); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for t in range(1, 4):
+        grad = torch.randn(n, generator=g) * (10.0 ** (t - 2))
+        opt.step({"w": grad})
+        gbuf[:n] = grad.to(dev())
+        lr = O.noam_rate(t, 5120, 1.0, 4000, 1e-5)
+        ops.adam_step(p[:n + 1], gbuf[:n + 1], m[:n + 1], v[:n + 1], lr, 0.9, 0.98, 1e-9, t)    # odd length: scalar tail
+        assert torch.allclose(p[:n].cpu(), params["w"], rtol=0, atol=2e-7), t
+    acc = torch.zeros(1, device=dev())
+    ops.sumsq_acc(gbuf, acc)
+    coef = torch.zeros(1, device=dev())
+    ops.clip_coef(acc, 0.5, coef)
+    nrm = gbuf.norm().item()
+    assert abs(acc.sqrt().item() - nrm) < 1e-3 * nrm and abs(coef.item() - min(1.0, 0.5 / (nrm + 1e-6))) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ conv front end
+def nhwc(x):       # (B,C,H,W) -> (B,H,W,C)
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv1_fwd_wgrad(ops, dtype):
+    g = torch.Generator().manual_seed(4)
+    B, H, W, C0 = 2, 21, 37, 64
+    x = torch.randn(B, 1, H, W, generator=g)
+    w = torch.randn(C0, 1, 3, 3, generator=g) / 3
+    b = torch.randn(C0, generator=g) / 3
+    wr, br = w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.relu(F.conv2d(x, wr, br, padding=1))
+    y = ops.conv1_fwd(x.to(dev()), w.to(dev()), b.to(dev()), dtype)
+    close("conv1", y, nhwc(ref), dtype)
+    dy = q(torch.randn(B, H, W, C0, generator=g), dtype) * (nhwc(ref) > 0)
+    ref.backward(nchw(dy))
+    dw = torch.zeros_like(w, device=dev()); db = torch.zeros(C0, device=dev())
+    ops.conv1_wgrad(x.to(dev()), dy.to(dev(), dtype), dw, db)
+    close("conv1 dw", dw, wr.grad, torch.float32, scale=16)
+    close("conv1 db", db, br.grad, torch.float32, scale=16)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 21, 37, 64, 64), (1, 16, 32, 64, 128), (2, 9, 50, 128, 128), (1, 11, 19, 128, 64)])
+def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
+    B, H, W, Cin, Cout = cfg
+    g = torch.Generator().manual_seed(H * W + Cin)
+    x = q(torch.randn(B, Cin, H, W, generator=g).relu(), dtype)         # an upstream ReLU output
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = torch.randn(Cout, generator=g) / 3
+    D = dev()
+    wk = torch.empty(Cout, 9, Cin, device=D, dtype=dtype); wd = torch.empty(Cin, 9, Cout, device=D, dtype=dtype)
+    ops.conv_pack_weight(w.to(D), wk, wd)
+    wq = q(w, dtype)
+    xr, wr, br = x.clone().requires_grad_(), wq.clone().requires_grad_(), b.clone().requires_grad_()
+    pre = F.conv2d(xr, wr, br, padding=1)
+    ref = F.relu(pre)
+    y = ops.conv3x3(nhwc(x).to(D, dtype), wk, b.to(D), Cout, relu=True)
+    close("conv3x3 fwd", y, nhwc(ref), dtype)
+    dy = q(torch.randn(B, H, W, Cout, generator=g), dtype) * (nhwc(ref) > 0)
+    ref.backward(nchw(dy))
+    # dgrad, masked by the ReLU that produced x
+    dx = ops.conv3x3(dy.to(D, dtype), wd, None, Cin, relu=False, mask_src=nhwc(x).to(D, dtype))
+    close("conv3x3 dgrad", dx, nhwc(xr.grad * (x > 0)), dtype, scale=2)
+    # wgrad from planar operands
+    xp = ops.nhwc_to_planar(nhwc(x).to(D, dtype), "tx")
+    dyp = ops.nhwc_to_planar(dy.to(D, dtype), "tdy")
+    dw = torch.zeros(Cout, Cin, 3, 3, device=D)
+    ops.conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout)
+    close("conv3x3 wgrad", dw, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
+    db = torch.zeros(Cout, device=D)
+    ops.colsum_acc(dy.to(D, dtype).view(-1, Cout), db)
+    close("conv3x3 db", db, br.grad, torch.float32, scale=16)
+    # run it twice through the persistent planar workspace: pads must still be zero
+    xp2 = ops.nhwc_to_planar(nhwc(x).to(D, dtype), "tx")
+    assert xp2.data_ptr() == xp.data_ptr()
+    dw2 = torch.zeros_like(dw)
+    ops.conv3x3_wgrad(xp2, dyp, dw2, B, H, W, Cin, Cout)
+    close("conv3x3 wgrad (2nd use of workspace)", dw2, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 21, 38, 64), (1, 161, 16, 64), (2, 40, 16, 128)])
+def test_maxpool_fwd_bwd_both_layouts(ops, dtype, shape):
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(H + W)
+    x = q(torch.randn(B, C, H, W, generator=g).relu(), dtype)
+    xr = x.clone().requires_grad_()
+    ref = F.max_pool2d(xr, 2, stride=2)
+    D = dev()
+    xd = nhwc(x).to(D, dtype)
+    y = ops.maxpool_fwd(xd)
+    assert torch.equal(y.float().cpu(), nhwc(ref.detach()))
+    ytcf = ops.maxpool_fwd(xd, tcf=True)
+    Bq, Cq, H2, W2 = ref.shape
+    ref_tcf = ref.detach().reshape(Bq, Cq * H2, W2).transpose(1, 2).contiguous()      # transformer.py:74-76
+    assert torch.equal(ytcf.float().cpu(), ref_tcf)
+    dy = q(torch.randn(B, C, H2, W2, generator=g), dtype)
+    ref.backward(dy)
+    want = nhwc(xr.grad * (x > 0))
+    dx = ops.maxpool_bwd(xd, nhwc(dy).to(D, dtype))
+    assert torch.equal(dx.float().cpu(), want)
+    dy_tcf = dy.reshape(B, C * H2, W2).transpose(1, 2).contiguous()
+    dx2 = ops.maxpool_bwd(xd, dy_tcf.to(D, dtype), tcf=True)
+    assert torch.equal(dx2.float().cpu(), want)
+
+
+def test_ops_refuse_host_tensors(ops):
+    from asr_hip.lib import AsrHipError
+    with pytest.raises(AsrHipError):
+        ops.gemm_nt(torch.zeros(8, 8), torch.zeros(8, 8))
