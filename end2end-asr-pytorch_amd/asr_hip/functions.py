@@ -64,11 +64,9 @@ def _linear_fwd(x2d, wparam, bparam, relu=False, out_dtype=None):
 
 
 def _linear_bwd(dy_c, dy_t, x_t, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
-    """dy_c (M,Np), dy_t (N,Mp), x_t (K,Mp) (all zero padded).  Returns dx (M,K) or None."""
-    N = wparam.shape[0]
+    """dy_c (M,Np), dy_t (N,Mp), x_t (K,Mp) (all zero padded).  The bias gradient has already been accumulated by the
+    transpose that produced dy_t (_t(dy, bias)).  Returns dx (M,K) or None."""
     _wgrad(dy_t, x_t, wparam)
-    if bparam is not None:
-        ops.colsum_acc(dy_c[:, :N], P.grad_of(bparam))
     dx = None
     if need_dx:
         _, Wt = P.linear_shadow(wparam)
@@ -76,8 +74,9 @@ def _linear_bwd(dy_c, dy_t, x_t, wparam, bparam, dx_out=None, accumulate=False, 
     return dx
 
 
-def _t(x2d):
-    return ops.transpose_padded(x2d)
+def _t(x2d, bias_param=None):
+    """Zero padded transpose; with bias_param also accumulates the column sums (= bias gradient) into its .grad."""
+    return ops.transpose_padded(x2d, P.grad_of(bias_param) if bias_param is not None else None)
 
 
 # ================================================================================================ plain linear
@@ -99,6 +98,8 @@ class LinearFn(Function):
     def backward(ctx, dy):
         N = ctx.weight.shape[0]
         dy_c, dy_t = _as_compute(dy.reshape(-1, N))
+        if ctx.bias is not None:
+            ops.colsum_acc(dy_c[:, :N], P.grad_of(ctx.bias))
         x_t = _t(ctx.x2)
         dx = _linear_bwd(dy_c, dy_t, x_t, ctx.weight, ctx.bias, need_dx=ctx.need_dx)
         if ctx.mark_ready:
@@ -156,7 +157,7 @@ class MHAFn(Function):
                                     P.grad_of(beta), p=cfg["p"], seed=seed_o)
         # output projection
         dy_c = _pad_cols(d_y)
-        dO = _linear_bwd(dy_c, _t(d_y), _t(O.view(B * Tq, H * dk)), Wo, bo)
+        dO = _linear_bwd(dy_c, _t(d_y, bo), _t(O.view(B * Tq, H * dk)), Wo, bo)
         dQ, dK, dV = ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, H * dk), lse, H, dk, key_len=cfg.get("key_len"),
                                   key_pad=cfg.get("key_pad"), causal=cfg.get("causal", False), scale=ctx.scale,
                                   p=cfg["p"], seed=seed_a)
@@ -164,14 +165,14 @@ class MHAFn(Function):
         q_t = _t(q2)
         kv_t = q_t if ctx.self_attn else _t(kv2)
         # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulate straight into d_res
-        _linear_bwd(_pad_cols(dQ2), _t(dQ2), q_t, Wq, bq, dx_out=d_res, accumulate=True)
+        _linear_bwd(_pad_cols(dQ2), _t(dQ2, bq), q_t, Wq, bq, dx_out=d_res, accumulate=True)
         d_kv = None
         if ctx.self_attn:
-            _linear_bwd(_pad_cols(dK2), _t(dK2), kv_t, Wk, bk, dx_out=d_res, accumulate=True)
-            _linear_bwd(_pad_cols(dV2), _t(dV2), kv_t, Wv, bv, dx_out=d_res, accumulate=True)
+            _linear_bwd(_pad_cols(dK2), _t(dK2, bk), kv_t, Wk, bk, dx_out=d_res, accumulate=True)
+            _linear_bwd(_pad_cols(dV2), _t(dV2, bv), kv_t, Wv, bv, dx_out=d_res, accumulate=True)
         else:
-            d_kv = _linear_bwd(_pad_cols(dK2), _t(dK2), kv_t, Wk, bk, need_dx=ctx.need_dkv)
-            _linear_bwd(_pad_cols(dV2), _t(dV2), kv_t, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
+            d_kv = _linear_bwd(_pad_cols(dK2), _t(dK2, bk), kv_t, Wk, bk, need_dx=ctx.need_dkv)
+            _linear_bwd(_pad_cols(dV2), _t(dV2, bv), kv_t, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
             if d_kv is not None:
                 d_kv = d_kv.view(B, Tk, D)
         P.grad_ready(*ctx.params)
@@ -203,8 +204,8 @@ class FFNFn(Function):
         d_res, d_y = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
                                     P.grad_of(beta), p=cfg["p"], seed=ctx.seed)
         # dh = (d_y . W2) * (h > 0)   -- ReLU mask fused into the dgrad epilogue
-        dh = _linear_bwd(_pad_cols(d_y), _t(d_y), _t(h), W2, b2, relu_mask=h)
-        _linear_bwd(_pad_cols(dh), _t(dh), _t(x2), W1, b1, dx_out=d_res, accumulate=True)
+        dh = _linear_bwd(_pad_cols(d_y), _t(d_y, b2), _t(h), W2, b2, relu_mask=h)
+        _linear_bwd(_pad_cols(dh), _t(dh, b1), _t(x2), W1, b1, dx_out=d_res, accumulate=True)
         P.grad_ready(*ctx.params)
         return (d_res.view(B, T, D),) + (None,) * 7
 
@@ -235,7 +236,7 @@ class EncInFn(Function):
         Win, bin_, gamma, beta = ctx.params
         dout2 = dout.reshape(B * T, -1).contiguous()
         dz, _ = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, None, P.grad_of(gamma), P.grad_of(beta))
-        dx = _linear_bwd(_pad_cols(dz), _t(dz), _t(x2), Win, bin_, need_dx=ctx.need_dx)
+        dx = _linear_bwd(_pad_cols(dz), _t(dz, bin_), _t(x2), Win, bin_, need_dx=ctx.need_dx)
         P.grad_ready(*ctx.params)
         if dx is not None:
             dx = dx.view(B, T, Din).to(ctx.in_dtype)

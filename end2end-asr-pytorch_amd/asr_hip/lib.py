@@ -28,22 +28,24 @@ _SIGS = {
     "asr_prof_enable": (_I, [_I, _I]),
     "asr_prof_collect": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
-    "asr_transpose": (_I, [_P, _L, _P, _L, _I, _I, _I, _P]),
+    "asr_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "asr_cast_weight": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "asr_colsum_acc": (_I, [_P, _L, _I, _I, _P, _I, _P]),
-    "asr_add_ln_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _I, _P]),
-    "asr_add_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _I, _P]),
+    "asr_add_ln_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _P, _I, _P]),
+    "asr_add_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _U64, _P, _I, _P]),
     "asr_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _P, _L, _L,
-                          _I, _F, _F, _U64, _I, _P]),
+                          _I, _F, _F, _U64, _P, _I, _P]),
     "asr_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,
-                          _P, _P, _L, _L, _I, _F, _F, _U64, _I, _P]),
+                          _P, _P, _L, _L, _I, _F, _F, _U64, _P, _I, _P]),
     "asr_decoder_preprocess": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
-    "asr_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _P]),
-    "asr_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _U64, _I, _I, _P]),
+    "asr_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _P]),
+    "asr_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _I, _P]),
     "asr_ce_fwd": (_I, [_P, _L, _P, _I, _I, _F, _I, _P, _P, _P, _P]),
     "asr_argmax_rows": (_I, [_P, _L, _I, _I, _P, _P]),
     "asr_ce_bwd": (_I, [_P, _L, _P, _P, _I, _I, _F, _I, _P, _P, _P, _L, _I, _P]),
     "asr_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P]),
+    "asr_step_advance": (_I, [_P, _P]),
+    "asr_adam_noam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "asr_sumsq_acc": (_I, [_P, _L, _P, _P]),
     "asr_clip_coef": (_I, [_P, _F, _P, _P]),
     "asr_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -7,7 +7,26 @@ import torch
 
 from . import lib as L
 
-_cfg = {"dtype": torch.bfloat16}
+_cfg = {"dtype": torch.bfloat16, "state": None}
+
+
+def step_state(device=None):
+    """Device uint64[2] {dropout seed counter, optimiser step}: mixed into every dropout seed and read by the
+    graph-replayable optimiser kernel; advanced once per training step by step_advance()."""
+    st = _cfg["state"]
+    if st is None or (device is not None and st.device != torch.device(device)):
+        st = torch.zeros(2, dtype=torch.int64, device=device or "cuda")
+        _cfg["state"] = st
+    return st
+
+
+def step_advance():
+    L.call("asr_step_advance", L.ptr(step_state()), L.stream())
+
+
+def _seed_dev(t):
+    st = _cfg["state"]
+    return L.ptr(st) if st is not None and st.device == t.device else None
 
 
 def set_compute_dtype(dtype):
@@ -44,14 +63,15 @@ def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, 
     return out
 
 
-def transpose_padded(x):
-    """(rows, cols) -> (cols, pad8(rows)) with zero pad columns (so a contraction may run over the padded axis)."""
+def transpose_padded(x, colsum_acc=None):
+    """(rows, cols) -> (cols, pad8(rows)) with zero pad columns (so a contraction may run over the padded axis).
+    colsum_acc (fp32, cols): optionally accumulate the column sums of x (bias gradient) in the same pass."""
     assert x.dim() == 2 and x.stride(1) == 1
     rows, cols = x.shape
     ld = _pad8(rows)
     out = torch.zeros((cols, ld), device=x.device, dtype=x.dtype) if ld != rows else \
         torch.empty((cols, ld), device=x.device, dtype=x.dtype)
-    L.call("asr_transpose", L.ptr(x), x.stride(0), L.ptr(out), ld, rows, cols, L.dt(x), L.stream())
+    L.call("asr_transpose", L.ptr(x), x.stride(0), L.ptr(out), ld, rows, cols, L.ptr(colsum_acc), L.dt(x), L.stream())
     return out
 
 
@@ -97,8 +117,8 @@ def add_ln_fwd(y, residual, gamma, beta, post_add=None, row_keep=None, eps=1e-5,
     rstd = torch.empty(M, device=y.device, dtype=torch.float32)
     period = post_add.shape[0] if post_add is not None else 0
     L.call("asr_add_ln_fwd", L.ptr(y), L.ptr(residual), L.ptr(gamma), L.ptr(beta), L.ptr(post_add), period,
-           L.ptr(row_keep), L.ptr(out), L.ptr(mean), L.ptr(rstd), M, D, float(eps), float(p), int(seed), L.dt(y),
-           L.stream())
+           L.ptr(row_keep), L.ptr(out), L.ptr(mean), L.ptr(rstd), M, D, float(eps), float(p), int(seed), _seed_dev(y),
+           L.dt(y), L.stream())
     return out, mean, rstd
 
 
@@ -109,7 +129,8 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     d_res = torch.empty_like(z)
     d_y = torch.empty_like(z) if p > 0 else d_res
     L.call("asr_add_ln_bwd", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
-           L.ptr(d_res), L.ptr(d_y), L.ptr(dgamma), L.ptr(dbeta), M, D, float(p), int(seed), L.dt(z), L.stream())
+           L.ptr(d_res), L.ptr(d_y), L.ptr(dgamma), L.ptr(dbeta), M, D, float(p), int(seed), _seed_dev(z), L.dt(z),
+           L.stream())
     return d_res, d_y
 
 
@@ -142,7 +163,7 @@ def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0,
     qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
     L.call("asr_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(attn), B, H, Tq, Tk, d, qs[0], qs[1],
            ks[0], ks[1], vs[0], vs[1], os_[0], os_[1], L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal),
-           float(scale), float(p), int(seed), L.dt(q), L.stream())
+           float(scale), float(p), int(seed), _seed_dev(q), L.dt(q), L.stream())
     return o, lse, attn
 
 
@@ -157,8 +178,8 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
     qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
     L.call("asr_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dq),
            L.ptr(dk), L.ptr(dv), B, H, Tq, Tk, d, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],
-           L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), L.dt(q),
-           L.stream())
+           L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), _seed_dev(q),
+           L.dt(q), L.stream())
     return dq, dk, dv
 
 
@@ -182,7 +203,7 @@ def embed_fwd(tok, table, pe, scale, p, seed, dtype):
     D = table.shape[1]
     out = torch.empty((B, T, D), device=tok.device, dtype=dtype)
     L.call("asr_embed_fwd", L.ptr(tok), L.ptr(table), L.ptr(pe), L.ptr(out), B, T, D, float(scale), float(p), int(seed),
-           L.dt_of(dtype), L.stream())
+           _seed_dev(tok), L.dt_of(dtype), L.stream())
     return out
 
 
@@ -191,7 +212,7 @@ def embed_bwd(tok, dout, dtable, scale, p, seed, pad_id):
     D = dtable.shape[1]
     assert dout.is_contiguous()
     L.call("asr_embed_bwd", L.ptr(tok), L.ptr(dout), L.ptr(dtable), B, T, D, float(scale), float(p), int(seed),
-           int(pad_id), L.dt(dout), L.stream())
+           _seed_dev(tok), int(pad_id), L.dt(dout), L.stream())
 
 
 # ------------------------------------------------------------------------------------------------ loss
@@ -231,6 +252,13 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=None):
     bc2 = 1.0 - beta2 ** step
     L.call("asr_adam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), float(lr), float(beta1), float(beta2),
            float(eps), float(bc1), float(bc2), L.ptr(grad_scale), L.stream())
+
+
+def adam_noam_step(p, g, m, v, beta1, beta2, eps, factor_ms, warmup, min_lr, grad_scale=None, lr_out=None):
+    """Adam update whose step count / Noam lr / bias corrections come from step_state()[1] on the device."""
+    L.call("asr_adam_noam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(step_state(p.device)),
+           float(beta1), float(beta2), float(eps), float(factor_ms), float(warmup), float(min_lr), L.ptr(grad_scale),
+           L.ptr(lr_out), L.stream())
 
 
 def sumsq_acc(g, acc):

@@ -21,7 +21,7 @@ struct AttnArgs {
   int B, H, Tq, Tk;
   int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
   const int32_t* key_len; const uint8_t* key_pad; int64_t m_sb, m_sq;
-  int causal; float scale; uint32_t thr; float inv_keep; uint64_t seed;
+  int causal; float scale; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
   int vec;     // all pointers 16-B aligned and all strides multiples of EPC
 };
 
@@ -141,6 +141,7 @@ __device__ __forceinline__ uint64_t drop_index(const AttnArgs& p, int b, int h, 
 // ================================================================================================ forward
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   using A = AT<T, HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         psum += pv;
         if (p.thr) {
           const int kg = k0 + kf * 16 + g * 4 + r;
-          pv = asr_keep(p.seed, drop_index(p, b, h, q, kg), p.thr) ? pv * p.inv_keep : 0.f;
+          pv = asr_keep(seed, drop_index(p, b, h, q, kg), p.thr) ? pv * p.inv_keep : 0.f;
         }
         s[kf][r] = pv;
       }
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int HD) {
 // ================================================================================================ dQ
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   using A = AT<T, HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sK = smem;
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         float pv = 0.f;
         if (!key_masked(p, b, kg, q, kend)) pv = expf(s[r] * p.scale - lse);
         float da = dp[r];
-        if (p.thr) da = asr_keep(p.seed, drop_index(p, b, h, q, kg), p.thr) ? da * p.inv_keep : 0.f;
+        if (p.thr) da = asr_keep(seed, drop_index(p, b, h, q, kg), p.thr) ? da * p.inv_keep : 0.f;
         ds_[kf][r] = pv * (da - dlt);
       }
     }
@@ -333,6 +335,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
 //   dK^T[d][key] += Qt . dS    A = Q tile transposed,  B = dS from registers
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   using A = AT<T, HD>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sQ = smem;
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         float pv = 0.f;
         if (!key_dead && qq < p.Tq && !key_masked(p, b, key, qq, kend)) pv = expf(s[r] * p.scale - s_lse[ql]);
         float keepf = 1.f;
-        if (p.thr) keepf = asr_keep(p.seed, drop_index(p, b, h, qq, key), p.thr) ? p.inv_keep : 0.f;
+        if (p.thr) keepf = asr_keep(seed, drop_index(p, b, h, qq, key), p.thr) ? p.inv_keep : 0.f;
         ad[qf][r] = pv * keepf;
         dsv[qf][r] = pv * (dp[r] * keepf - s_dlt[ql]);
       }
@@ -425,6 +428,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
 // MultiHeadAttention.forward (common_layers.py:200).  Only used when a caller asks for it.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs p, int HD) {
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   const int64_t total = (int64_t)p.B * p.H * p.Tq * p.Tk;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs p, int HD) {
   for (int c = 0; c < HD; ++c) s += DT<T>::ld(qp + c) * DT<T>::ld(kp + c);
   float pv = 0.f;
   if (!key_masked(p, b, k, q, key_end(p, b))) pv = expf(s * p.scale - p.lse[((int64_t)b * p.H + h) * p.Tq + q]);
-  if (p.thr) pv = asr_keep(p.seed, drop_index(p, b, h, q, k), p.thr) ? pv * p.inv_keep : 0.f;
+  if (p.thr) pv = asr_keep(seed, drop_index(p, b, h, q, k), p.thr) ? pv * p.inv_keep : 0.f;
   p.attn_out[i] = pv;
 }
 
@@ -465,8 +469,11 @@ int run_bwd(const AttnArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, p, HD);
   ASR_LAUNCH_CHECK();
   const size_t l1 = lds_dq<T, HD>(), l2 = lds_dkv<T, HD>();
-  if (l2 > 48 * 1024)
+  static bool granted = false;
+  if (l2 > 48 * 1024 && !granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+    granted = true;
+  }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3((p.Tq + 63) / 64, p.B * p.H), dim3(256), l1, s, p);
   ASR_LAUNCH_CHECK();
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3((p.Tk + 63) / 64, p.B * p.H), dim3(256), l2, s, p);
@@ -486,13 +493,14 @@ int dispatch(const AttnArgs& p, int d, bool bwd, hipStream_t s) {
 
 int fill_common(AttnArgs& p, int B, int H, int Tq, int Tk, int d, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st,
                 int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st, const int32_t* key_len, const uint8_t* key_pad,
-                int64_t m_sb, int64_t m_sq, int causal, float scale, float dropout_p, uint64_t seed, int dtype) {
+                int64_t m_sb, int64_t m_sq, int causal, float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev,
+                int dtype) {
   ASR_CHECK_ARG(B >= 0 && H > 0 && Tq >= 0 && Tk >= 0 && d > 0 && dropout_p >= 0.f && dropout_p < 1.f);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
   p.q_sb = q_sb; p.q_st = q_st; p.k_sb = k_sb; p.k_st = k_st; p.v_sb = v_sb; p.v_st = v_st; p.o_sb = o_sb; p.o_st = o_st;
   p.key_len = key_len; p.key_pad = key_pad; p.m_sb = m_sb; p.m_sq = m_sq; p.causal = causal; p.scale = scale;
-  p.thr = asr_drop_threshold(dropout_p); p.inv_keep = 1.f / (1.f - dropout_p); p.seed = seed;
+  p.thr = asr_drop_threshold(dropout_p); p.inv_keep = 1.f / (1.f - dropout_p); p.seed = seed; p.seed_dev = seed_dev;
   const int epc = dtype == ASR_F32 ? 4 : 8;
   p.vec = (q_sb % epc == 0) && (q_st % epc == 0) && (k_sb % epc == 0) && (k_st % epc == 0) && (v_sb % epc == 0) &&
           (v_st % epc == 0) && (o_sb % epc == 0) && (o_st % epc == 0);
@@ -505,11 +513,11 @@ extern "C" int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O
                             int Tq, int Tk, int d, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
                             int64_t v_st, int64_t o_sb, int64_t o_st, const int32_t* key_len, const uint8_t* key_pad,
                             int64_t mask_sb, int64_t mask_sq, int causal, float scale, float dropout_p, uint64_t seed,
-                            int dtype, hipStream_t stream) {
+                            const uint64_t* seed_dev, int dtype, hipStream_t stream) {
   ASR_CHECK_ARG(Q && K && V && O && lse);
   AttnArgs p{};
   int rc = fill_common(p, B, H, Tq, Tk, d, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, key_len, key_pad, mask_sb, mask_sq, causal,
-                       scale, dropout_p, seed, dtype);
+                       scale, dropout_p, seed, seed_dev, dtype);
   if (rc != ASR_OK) return rc;
   if (B == 0 || Tq == 0) return ASR_OK;
   p.Q = Q; p.K = K; p.V = V; p.Out = O; p.lse = lse; p.attn_out = attn_out;
@@ -522,11 +530,12 @@ extern "C" int asr_attn_bwd(const void* Q, const void* K, const void* V, const v
                             float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
                             int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
                             const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,
-                            float scale, float dropout_p, uint64_t seed, int dtype, hipStream_t stream) {
+                            float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype,
+                            hipStream_t stream) {
   ASR_CHECK_ARG(Q && K && V && O && dO && lse && delta && dQ && dK && dV);
   AttnArgs p{};
   int rc = fill_common(p, B, H, Tq, Tk, d, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, key_len, key_pad, mask_sb, mask_sq, causal,
-                       scale, dropout_p, seed, dtype);
+                       scale, dropout_p, seed, seed_dev, dtype);
   if (rc != ASR_OK) return rc;
   if (B == 0 || Tq == 0 || Tk == 0) return ASR_OK;
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.dO = dO; p.lse = const_cast<float*>(lse); p.delta = delta;

@@ -89,6 +89,11 @@ __device__ __forceinline__ uint32_t asr_hash32(uint64_t seed, uint64_t idx) {
   z ^= z >> 32;
   return (uint32_t)z;
 }
+// Per-step seed: host part (distinct per dropout site) mixed with a DEVICE counter that a captured hipGraph advances
+// on every replay (asr_step_advance), so replays do not repeat their dropout masks.
+__device__ __forceinline__ uint64_t asr_mix_seed(uint64_t seed, const uint64_t* seed_dev) {
+  return seed_dev ? seed + seed_dev[0] * 0xD1B54A32D192ED03ull : seed;
+}
 // threshold = (uint32)(p * 2^32); keep iff hash >= threshold
 __device__ __forceinline__ bool asr_keep(uint64_t seed, uint64_t idx, uint32_t thr) { return asr_hash32(seed, idx) >= thr; }
 static inline uint32_t asr_drop_threshold(float p) {

@@ -336,15 +336,20 @@ __global__ __launch_bounds__(256) void pool_bwd_tcf_kernel(const T* __restrict__
     pool_bwd_window<T>(x, dx, ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + c, C, W, sp[oh * (C + 1) + c]);
   }
 }
-// rows/cols that floor-mode pooling drops (odd H or W) get zero gradient
+// rows/cols that floor-mode pooling drops (odd H or W) get zero gradient: touch only those pixels
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_edges_kernel(T* __restrict__ dx, int B, int H, int W, int C) {
-  const int H2 = H / 2, W2 = W / 2;
-  const int64_t total = (int64_t)B * H * W * C;
+  const int er = H & 1, ec = W & 1;
+  const int64_t per_img = (int64_t)er * W + (int64_t)ec * (H - er);       // dropped pixels per image
+  const int64_t total = (int64_t)B * per_img * C;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t pix = i / C;
-    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
-    if (yh >= 2 * H2 || xw >= 2 * W2) DT<T>::st(dx + i, 0.f);
+    const int c = (int)(i % C);
+    const int64_t e = (i / C) % per_img;
+    const int64_t b = i / (C * per_img);
+    int yh, xw;
+    if (e < (int64_t)er * W) { yh = H - 1; xw = (int)e; }
+    else { yh = (int)(e - (int64_t)er * W); xw = W - 1; }
+    DT<T>::st(dx + (((b * H + yh) * W + xw) * (int64_t)C) + c, 0.f);
   }
 }
 
@@ -478,8 +483,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
   }
 }
 
+// once per kernel instantiation (never during a stream capture: the first eager/warm-up launch does it)
 template <typename K> void allow_big_lds(K kernel, size_t lds) {
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static size_t granted = 0;      // one static per template instantiation = per kernel
+  if (lds > 48 * 1024 && lds > granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = lds;
+  }
 }
 
 template <typename T, int NCO>
@@ -596,7 +606,7 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
   const int H2 = H / 2, W2 = W / 2;
   AsrProfScope prof(ASR_OP_POOL, s);
   if ((H & 1) || (W & 1)) {
-    const int64_t total = (int64_t)B * H * W * C;
+    const int64_t total = (int64_t)B * ((int64_t)(H & 1) * W + (int64_t)(W & 1) * (H - (H & 1))) * C;
     if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_edges_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (float*)dx, B, H, W, C);
     else hipLaunchKernelGGL((pool_bwd_edges_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (bf16_t*)dx, B, H, W, C);
     ASR_LAUNCH_CHECK();

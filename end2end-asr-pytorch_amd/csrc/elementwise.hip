@@ -8,8 +8,10 @@ namespace {
 // 64x64 tile through LDS (+1 pad).  in (rows, cols) -> out (cols, rows).  TI -> TO conversion on the way.
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ in, int64_t ld_in, TO* __restrict__ out,
-                                                        int64_t ld_out, TO* __restrict__ out_same, int64_t ld_same, int rows, int cols) {
+                                                        int64_t ld_out, TO* __restrict__ out_same, int64_t ld_same, int rows, int cols,
+                                                        float* __restrict__ colsum) {
   __shared__ float tile[64][65];
+  __shared__ float csum[4][64];
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
   for (int i = ty; i < 64; i += 4) {
@@ -22,6 +24,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TI* __restrict__ i
     tile[i][tx] = v;
   }
   __syncthreads();
+  if (colsum) {      // bias gradient for free: column sums of the tile we already hold (rows beyond `rows` are zero)
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += tile[ty * 16 + i][tx];
+    csum[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && c0 + tx < cols) atomicAdd(colsum + c0 + tx, csum[0][tx] + csum[1][tx] + csum[2][tx] + csum[3][tx]);
+  }
   if (out) {
     for (int i = ty; i < 64; i += 4) {
       int c = c0 + i, r = r0 + tx;
@@ -51,7 +61,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, in
 template <typename T>
 __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ tok, const float* __restrict__ table,
                                                         const float* __restrict__ pe, T* __restrict__ out, int T_len,
-                                                        int D, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+                                                        int D, float scale, uint32_t thr, float inv_keep, uint64_t seed0,
+                                                        const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   const int row = blockIdx.x;                 // b*T + t
   const int t = row % T_len;
   const int64_t id = tok[row];
@@ -66,7 +78,8 @@ __global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ tok, const T* __restrict__ dout,
                                                         float* dtable, int D, float scale, uint32_t thr, float inv_keep,
-                                                        uint64_t seed, int pad_id) {
+                                                        uint64_t seed0, const uint64_t* __restrict__ seed_dev, int pad_id) {
+  const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   const int row = blockIdx.x;
   const int64_t id = tok[row];
   if (id == pad_id) return;                   // nn.Embedding(padding_idx=PAD): no gradient for the PAD row
@@ -150,6 +163,49 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// Same update with the step count (and therefore Noam's learning rate and Adam's bias corrections) read from DEVICE
+// memory, so that a captured hipGraph replays a correct optimiser step (reference: utils/optimizer.py:15-32).
+__global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n4, int64_t n,
+                                                        const uint64_t* __restrict__ state, float b1, float b2, float eps,
+                                                        float factor_ms, float warmup, float min_lr,
+                                                        const float* __restrict__ gscale, float* __restrict__ lr_out) {
+  const double t = (double)state[1];
+  const double w15 = pow((double)warmup, -1.5);
+  const double sched = fmin(pow(t, -0.5), t * w15);
+  const float lr = fmaxf(min_lr, (float)((double)factor_ms * sched));
+  const float bc1 = (float)(1.0 - pow((double)b1, t));
+  const float bc2_sqrt = sqrtf((float)(1.0 - pow((double)b2, t)));
+  if (lr_out && blockIdx.x == 0 && threadIdx.x == 0) *lr_out = lr;
+  const float gs = gscale ? *gscale : 1.f;
+  const float step = lr / bc1;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float* P = &pp.x; float* G = &gg.x; float* Mo = &mm.x; float* Vo = &vv.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float gj = G[j] * gs;
+      Mo[j] = b1 * Mo[j] + (1.f - b1) * gj;
+      Vo[j] = b2 * Vo[j] + (1.f - b2) * gj * gj;
+      P[j] -= step * (Mo[j] / (sqrtf(Vo[j]) / bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  const int64_t tail = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tail < n) {
+    const float gj = g[tail] * gs;
+    const float mo = b1 * m[tail] + (1.f - b1) * gj;
+    const float vo = b2 * v[tail] + (1.f - b2) * gj * gj;
+    m[tail] = mo; v[tail] = vo;
+    p[tail] -= step * (mo / (sqrtf(vo) / bc2_sqrt + eps));
+  }
+}
+__global__ void step_advance_kernel(uint64_t* state) { state[0] += 1; state[1] += 1; }
+
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* acc) {
   __shared__ float red[4];
   float s = 0.f;
@@ -168,18 +224,18 @@ __global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef
 
 }  // namespace
 
-extern "C" int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
-                             hipStream_t s) {
+extern "C" int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, float* colsum,
+                             int dtype, hipStream_t s) {
   ASR_CHECK_ARG(in && out && rows >= 0 && cols >= 0);
   if (rows == 0 || cols == 0) return ASR_OK;
   dim3 grid((cols + 63) / 64, (rows + 63) / 64);
   AsrProfScope prof(ASR_OP_LAYOUT, s);
   if (dtype == ASR_F32)
     hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)in, ld_in, (float*)out, ld_out,
-                       (float*)nullptr, (int64_t)0, rows, cols);
+                       (float*)nullptr, (int64_t)0, rows, cols, colsum);
   else if (dtype == ASR_BF16)
     hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)in, ld_in, (bf16_t*)out,
-                       ld_out, (bf16_t*)nullptr, (int64_t)0, rows, cols);
+                       ld_out, (bf16_t*)nullptr, (int64_t)0, rows, cols, colsum);
   else return ASR_EINVAL;
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -194,10 +250,10 @@ extern "C" int asr_cast_weight(const float* src, int64_t ld_src, void* dst, int6
   AsrProfScope prof(ASR_OP_LAYOUT, s);
   if (dtype == ASR_F32)
     hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, src, ld_src, (float*)dst_t, ld_dst_t,
-                       (float*)dst, ld_dst, rows, cols);
+                       (float*)dst, ld_dst, rows, cols, (float*)nullptr);
   else if (dtype == ASR_BF16)
     hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, s, src, ld_src, (bf16_t*)dst_t, ld_dst_t,
-                       (bf16_t*)dst, ld_dst, rows, cols);
+                       (bf16_t*)dst, ld_dst, rows, cols, (float*)nullptr);
   else return ASR_EINVAL;
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -216,25 +272,25 @@ extern "C" int asr_colsum_acc(const void* X, int64_t ld, int M, int N, float* ou
 }
 
 extern "C" int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void* out, int B, int T, int D,
-                             float scale, float p, uint64_t seed, int dtype, hipStream_t s) {
+                             float scale, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(tok && table && pe && out && B >= 0 && T > 0 && D > 0 && p >= 0.f && p < 1.f);
   if (B == 0) return ASR_OK;
   const uint32_t thr = asr_drop_threshold(p);
   const float inv = 1.f / (1.f - p);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3(B * T), dim3(256), 0, s, tok, table, pe, (float*)out, T, D, scale, thr, inv, seed);
-  else if (dtype == ASR_BF16) hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), dim3(B * T), dim3(256), 0, s, tok, table, pe, (bf16_t*)out, T, D, scale, thr, inv, seed);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((embed_fwd_kernel<float>), dim3(B * T), dim3(256), 0, s, tok, table, pe, (float*)out, T, D, scale, thr, inv, seed, seed_dev);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((embed_fwd_kernel<bf16_t>), dim3(B * T), dim3(256), 0, s, tok, table, pe, (bf16_t*)out, T, D, scale, thr, inv, seed, seed_dev);
   else return ASR_EINVAL;
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
 extern "C" int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable, int B, int T, int D, float scale,
-                             float p, uint64_t seed, int pad_id, int dtype, hipStream_t s) {
+                             float p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(tok && dout && dtable && B >= 0 && T > 0 && D > 0 && p >= 0.f && p < 1.f);
   if (B == 0) return ASR_OK;
   const uint32_t thr = asr_drop_threshold(p);
   const float inv = 1.f / (1.f - p);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(B * T), dim3(256), 0, s, tok, (const float*)dout, dtable, D, scale, thr, inv, seed, pad_id);
-  else if (dtype == ASR_BF16) hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(B * T), dim3(256), 0, s, tok, (const bf16_t*)dout, dtable, D, scale, thr, inv, seed, pad_id);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((embed_bwd_kernel<float>), dim3(B * T), dim3(256), 0, s, tok, (const float*)dout, dtable, D, scale, thr, inv, seed, seed_dev, pad_id);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((embed_bwd_kernel<bf16_t>), dim3(B * T), dim3(256), 0, s, tok, (const bf16_t*)dout, dtable, D, scale, thr, inv, seed, seed_dev, pad_id);
   else return ASR_EINVAL;
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -276,6 +332,29 @@ extern "C" int asr_sumsq_acc(const float* g, int64_t n, float* acc, hipStream_t 
 extern "C" int asr_clip_coef(const float* sumsq, float max_norm, float* coef, hipStream_t s) {
   ASR_CHECK_ARG(sumsq && coef);
   hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, coef);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_step_advance(uint64_t* state, hipStream_t s) {
+  ASR_CHECK_ARG(state);
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, state);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
+                                  float beta2, float eps, float factor_ms, float warmup, float min_lr, const float* gscale,
+                                  float* lr_out, hipStream_t s) {
+  ASR_CHECK_ARG(p && g && m && v && state && n >= 0 && warmup > 0.f);
+  if (n == 0) return ASR_OK;
+  ASR_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v));
+  const int64_t n4 = n / 4;
+  int64_t blocks = ceil_div64(n4 > 0 ? n4 : 1, 256);
+  if (blocks > 4096) blocks = 4096;
+  AsrProfScope prof(ASR_OP_ADAM, s);
+  hipLaunchKernelGGL(adam_noam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, n, state, beta1, beta2, eps,
+                     factor_ms, warmup, min_lr, gscale, lr_out);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -14,9 +14,11 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, co
                                                          const float* __restrict__ post, int post_period,
                                                          const uint8_t* __restrict__ keep, T* __restrict__ out,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int M, int D,
-                                                         float eps, uint32_t thr, float inv_keep, uint64_t seed) {
+                                                         float eps, uint32_t thr, float inv_keep, uint64_t seed0,
+                                                         const uint64_t* __restrict__ seed_dev) {
   constexpr int EPC = DT<T>::EPC;
   constexpr int NCH = kMaxPerLane / EPC;
+  const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ gamma, const uint8_t* __restrict__ keep,
                                                          T* __restrict__ d_res, T* __restrict__ d_y, float* dgamma,
                                                          float* dbeta, int M, int D, int rows_per_block, uint32_t thr,
-                                                         float inv_keep, uint64_t seed) {
+                                                         float inv_keep, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
+  const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   constexpr int EPC = DT<T>::EPC;
   constexpr int NCH = kMaxPerLane / EPC;
   extern __shared__ float red[];   // [4][2*D] -> only waves 1..3 write
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
 
 extern "C" int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamma, const float* beta, const float* post_add,
                               int post_period, const uint8_t* row_keep, void* out, float* mean, float* rstd, int M, int D,
-                              float eps, float p, uint64_t seed, int dtype, hipStream_t s) {
+                              float eps, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(y_z && gamma && beta && out && mean && rstd && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   const int epc = dtype == ASR_F32 ? 4 : 8;
@@ -188,17 +191,17 @@ extern "C" int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamm
   AsrProfScope prof(ASR_OP_ADD_LN, s);
   if (dtype == ASR_F32)
     hipLaunchKernelGGL((add_ln_fwd_kernel<float>), grid, dim3(256), 0, s, (float*)y_z, (const float*)residual, gamma, beta,
-                       post_add, post_period, row_keep, (float*)out, mean, rstd, M, D, eps, thr, inv, seed);
+                       post_add, post_period, row_keep, (float*)out, mean, rstd, M, D, eps, thr, inv, seed, seed_dev);
   else
     hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (bf16_t*)y_z, (const bf16_t*)residual, gamma, beta,
-                       post_add, post_period, row_keep, (bf16_t*)out, mean, rstd, M, D, eps, thr, inv, seed);
+                       post_add, post_period, row_keep, (bf16_t*)out, mean, rstd, M, D, eps, thr, inv, seed, seed_dev);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
 
 extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
                               const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma, float* dbeta, int M, int D,
-                              float p, uint64_t seed, int dtype, hipStream_t s) {
+                              float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(dout && z && mean && rstd && gamma && d_res && dgamma && dbeta && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   const int epc = dtype == ASR_F32 ? 4 : 8;
@@ -214,10 +217,10 @@ extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean
   AsrProfScope prof(ASR_OP_ADD_LN, s);
   if (dtype == ASR_F32)
     hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), lds, s, (const float*)dout, (const float*)z, mean, rstd,
-                       gamma, row_keep, (float*)d_res, (float*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed);
+                       gamma, row_keep, (float*)d_res, (float*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed, seed_dev);
   else
     hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)z, mean,
-                       rstd, gamma, row_keep, (bf16_t*)d_res, (bf16_t*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed);
+                       rstd, gamma, row_keep, (bf16_t*)d_res, (bf16_t*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed, seed_dev);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -113,6 +113,27 @@ class FusedAdam(torch.optim.Adam):
         self.grad_scale = None
         P.bump_generation()          # masters were rewritten through the C ABI: weight shadows are stale
 
+    @torch.no_grad()
+    def step_device(self, factor_ms, warmup, min_lr, lr_out=None):
+        """Graph-replayable step: step count, Noam lr and bias corrections are computed ON THE DEVICE from
+        ops.step_state()[1] (advanced by ops.step_advance() at the top of the step).  Needs flat storage."""
+        self._ensure_flat()
+        if self.flat is None:
+            raise RuntimeError("step_device needs the parameters on a GPU")
+        if self.reducer is not None:
+            self.reducer.finish()
+        b1, b2 = self.param_groups[0]['betas']
+        ops.adam_noam_step(self.flat.data, self.flat.grad, self._m, self._v, b1, b2, self.param_groups[0]['eps'], factor_ms,
+                           warmup, min_lr, self.grad_scale, lr_out)
+        self.grad_scale = None
+
+    def after_replay(self, n=1):
+        """Host-side bookkeeping for `n` device-side steps (state_dict 'step' fields, shadow invalidation)."""
+        self._t += n
+        for p in self.flat.params:
+            self.state[p]['step'] += n
+        P.bump_generation()
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         if self.flat is None:

@@ -53,9 +53,10 @@ int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                 int M, int N, int K, float alpha, int flags, int splits, int in_dtype, int out_dtype,
                 asr_stream_t stream);
 
-/* out[c*ld_out + r] = in[r*ld_in + c]   (operand preparation for dgrad / wgrad)                              */
-int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, int dtype,
-                  asr_stream_t stream);
+/* out[c*ld_out + r] = in[r*ld_in + c]   (operand preparation for dgrad / wgrad).  If colsum_acc != NULL also
+ * colsum_acc[c] += sum_r in[r,c]  (the bias gradient, from the tile that is in LDS anyway).                    */
+int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, float* colsum_acc,
+                  int dtype, asr_stream_t stream);
 /* fp32 (rows,cols; ld_src) -> copy (rows,cols; ld_dst) and transpose (cols,rows; ld_dst_t) in `dtype`; either dst
  * may be NULL.  Used for weight shadows and for fp32 gradients entering a bf16 backward.                        */
 int asr_cast_weight(const float* src, int64_t ld_src, void* dst, int64_t ld_dst, void* dst_t, int64_t ld_dst_t,
@@ -70,12 +71,12 @@ int asr_colsum_acc(const void* X, int64_t ld, int M, int N, float* out, int dtyp
  * and the `*= non_pad_mask` at transformer.py:198,201,536,540,543.                                            */
 int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamma, const float* beta, const float* post_add,
                    int post_period, const uint8_t* row_keep, void* out, float* mean, float* rstd, int M, int D,
-                   float eps, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+                   float eps, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 /* d_res = LN'(dout*row_keep) ; d_y = d_res * dropmask/(1-p) (d_y may alias d_res when p == 0, or be NULL);
  * dgamma_acc/dbeta_acc (fp32, D) are accumulated into.                                                         */
 int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
                    const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma_acc, float* dbeta_acc, int M,
-                   int D, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+                   int D, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 
 /* ---- fused multi-head attention core: softmax(mask(Q K^T * scale)) (dropout) V -------------------------------
  * Q (B,Tq,H,d) with element strides (q_sb, q_st) and head h at offset h*d; same for K,V (B,Tk,H,d), O (B,Tq,H,d).
@@ -86,14 +87,14 @@ int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const flo
 int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, float* attn_out, int B, int H,
                  int Tq, int Tk, int d, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
                  int64_t v_st, int64_t o_sb, int64_t o_st, const int32_t* key_len, const uint8_t* key_pad,
-                 int64_t mask_sb, int64_t mask_sq, int causal, float scale, float dropout_p, uint64_t seed, int dtype,
-                 asr_stream_t stream);
+                 int64_t mask_sb, int64_t mask_sq, int causal, float scale, float dropout_p, uint64_t seed,
+                 const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 /* delta (B,H,Tq) fp32 workspace.  dQ/dK/dV use the strides of Q/K/V.                                           */
 int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
                  float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
                  int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
                  const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,
-                 float scale, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+                 float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 
 /* ---- decoder input side ---------------------------------------------------------------------------------------
  * Decoder.preprocess (transformer.py:254-266) + masks (:282-286): strip PAD(0) anywhere, seq_in = [SOS]+y padded
@@ -103,9 +104,9 @@ int asr_decoder_preprocess(const int64_t* tgt, int B, int L, int Td, int64_t* se
                            uint8_t* key_pad, uint8_t* row_keep, int32_t* overflow, asr_stream_t stream);
 /* out = dropout(table[tok]*scale + pe[t])   (transformer.py:292-293); table/pe fp32                            */
 int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void* out, int B, int T, int D,
-                  float scale, float dropout_p, uint64_t seed, int dtype, asr_stream_t stream);
+                  float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable_acc, int B, int T, int D, float scale,
-                  float dropout_p, uint64_t seed, int pad_id, int dtype, asr_stream_t stream);
+                  float dropout_p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, asr_stream_t stream);
 
 /* ---- label-smoothed cross entropy + argmax + num_correct (utils/metrics.py:78-132, transformer.py:80) ---------
  * logits (M, ld) fp32.  sums[0] += sum of row losses over non-PAD rows, sums[1] += #non-PAD rows,
@@ -125,6 +126,15 @@ int asr_ce_bwd(const float* logits, int64_t ld, const int64_t* gold, const float
  * grad_scale_dev: optional device scalar multiplied into g (gradient clipping coefficient), may be NULL.        */
 int asr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float bias_corr1, float bias_corr2, const float* grad_scale_dev, asr_stream_t stream);
+/* Graph-replayable variant: state = device uint64[2] {dropout seed counter, optimiser step t}; asr_step_advance()
+ * increments both (one launch at the top of every step, captured or not).  asr_adam_noam_step reads t from state[1] and
+ * computes lr = max(min_lr, factor_ms * min(t^-0.5, t * warmup^-1.5)) (factor_ms = k_lr * model_size^-0.5) and Adam's
+ * bias corrections on the device; *lr_out (optional) receives lr.  Every dropout kernel mixes state[0] into its seed
+ * through its `seed_dev` argument (NULL = host seed only).                                                        */
+int asr_step_advance(uint64_t* state, asr_stream_t stream);
+int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
+                       float beta2, float eps, float factor_ms, float warmup, float min_lr,
+                       const float* grad_scale_dev, float* lr_out, asr_stream_t stream);
 /* acc[0] += sum(g^2)  (clip_grad_norm_, trainer.py:108-109)                                                     */
 int asr_sumsq_acc(const float* g, int64_t n, float* acc, asr_stream_t stream);
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))                                                          */

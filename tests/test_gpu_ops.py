@@ -98,8 +98,10 @@ def test_transpose_cast_colsum(ops, dtype):
     x = q(torch.randn(203, 77, generator=g), dtype)
     t = ops.transpose(x.to(dev(), dtype))
     assert torch.equal(t.float().cpu(), x.t())
-    tp = ops.transpose_padded(x.to(dev(), dtype))
-    assert tp.shape == (77, 208) and (tp[:, 203:] == 0).all()
+    cs = torch.full((77,), 2.0, device=dev())
+    tp = ops.transpose_padded(x.to(dev(), dtype), colsum_acc=cs)
+    assert tp.shape == (77, 208) and (tp[:, 203:] == 0).all() and torch.equal(tp[:, :203].float().cpu(), x.t())
+    close("transpose-fused colsum", cs, 2 + x.sum(0), torch.float32, scale=4)
     src = torch.randn(131, 45, generator=g)
     same, tr = ops.cast_and_transpose(src.to(dev()), dtype)
     assert torch.equal(same[:, :45].float().cpu(), q(src, dtype)) and (same[:, 45:] == 0).all()
