@@ -18,16 +18,10 @@ from . import ops
 from . import params as P
 
 
-def _splits_for(n_out, k_out, red):
-    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
-    s = max(1, 512 // max(tiles, 1))
-    return max(1, min(s, red // 256))
-
-
 def _wgrad(dy_t, x_t, wparam):
     """dW (N,K) += dy_t (N, Mp) . x_t (K, Mp)^T over the (zero padded) reduction axis Mp."""
     g = P.grad_of(wparam).view(wparam.shape[0], -1)
-    ops.gemm_nt(dy_t, x_t, out=g, accumulate=True, splits=_splits_for(g.shape[0], g.shape[1], dy_t.shape[1]))
+    ops.gemm_nt(dy_t, x_t, out=g, accumulate=True, splits=0)      # 0 = let the library choose split-K
 
 
 def _as_compute(dy2d):
@@ -287,11 +281,8 @@ class VGGFn(Function):
         w0, b0, w2, b2, w5, b5, w7, b7 = ctx.params
 
         def wgrad(x, dy, w, b, tag):
-            B, H, W, Cin = x.shape
             Cout = dy.shape[3]
-            xp = ops.nhwc_to_planar(x, tag + "x")
-            dyp = ops.nhwc_to_planar(dy, tag + "dy")
-            ops.conv3x3_wgrad(xp, dyp, P.grad_of(w), B, H, W, Cin, Cout)
+            ops.conv3x3_wgrad_gemm(x, dy, P.grad_of(w))
             ops.colsum_acc(dy.view(-1, Cout), P.grad_of(b))
 
         dy4 = ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)

@@ -27,7 +27,7 @@ _SIGS = {
     "asr_abi_version": (_I, []),
     "asr_prof_enable": (_I, [_I, _I]),
     "asr_prof_collect": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
-    "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
+    "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
     "asr_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "asr_cast_weight": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "asr_colsum_acc": (_I, [_P, _L, _I, _I, _P, _I, _P]),
@@ -56,7 +56,7 @@ _SIGS = {
     "asr_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_planar_pitch": (_L, [_I, _I]),
     "asr_planar_size": (_L, [_I, _I, _I, _I]),
-    "asr_nhwc_to_planar": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "asr_nhwc_to_planar": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 

@@ -41,15 +41,20 @@ def compute_dtype():
 
 
 def _pad8(n):
+    """Leading-dimension padding of contraction axes: 8 elements (one 16-byte bf16 chunk) for small axes, a whole 128-byte
+    K step (64 bf16) for large ones so that the LDS-DMA GEMM path applies (e.g. V = 4364 -> 4416)."""
+    if n >= 256:
+        return (n + 63) // 64 * 64
     return (n + 7) // 8 * 8
 
 
 # ------------------------------------------------------------------------------------------------ dense
 def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, splits=1, out_dtype=None, K=None,
-            relu_mask=None):
+            relu_mask=None, b_rowoff=None, N=None):
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T (+bias) ; A, B 2-D with unit inner stride (row stride arbitrary)."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
-    M, N = A.shape[0], B.shape[0]
+    M = A.shape[0]
+    N = (b_rowoff.numel() if b_rowoff is not None else B.shape[0]) if N is None else N
     K = A.shape[1] if K is None else K
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
@@ -59,7 +64,7 @@ def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, 
         assert relu_mask.dtype == A.dtype and relu_mask.stride(0) == out.stride(0) and relu_mask.stride(1) == 1
     flags = (L.GEMM_RELU if relu else 0) | (L.GEMM_ACCUMULATE if accumulate else 0)
     L.call("asr_gemm_nt", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out), out.stride(0), L.ptr(bias),
-           L.ptr(relu_mask), M, N, K, float(alpha), flags, int(splits), L.dt(A), L.dt(out), L.stream())
+           L.ptr(relu_mask), L.ptr(b_rowoff), M, N, K, float(alpha), flags, int(splits), L.dt(A), L.dt(out), L.stream())
     return out
 
 
@@ -318,24 +323,55 @@ def maxpool_bwd(x, dy, tcf=False):
 
 
 _planar_ws = {}
+_rowoff_cache = {}
 
 
-def planar_workspace(tag, C, B, H, W, dtype, device):
+def planar_workspace(tag, C, B, H, W, dtype, device, copies=1):
     """Persistent zero-initialised planar buffer (pads must stay zero between uses; only real pixels are rewritten)."""
-    key = (tag, C, B, H, W, dtype, str(device))
+    key = (tag, C, B, H, W, dtype, str(device), copies)
     buf = _planar_ws.get(key)
     if buf is None:
         Np = L.load().asr_planar_size(B, H, W, L.dt_of(dtype))
-        buf = torch.zeros((C, Np), device=device, dtype=dtype)
+        buf = torch.zeros((copies, C, Np) if copies > 1 else (C, Np), device=device, dtype=dtype)
         _planar_ws[key] = buf
     return buf
 
 
-def nhwc_to_planar(x, tag):
+def nhwc_to_planar(x, tag, shifted3=False):
     B, H, W, C = x.shape
-    xp = planar_workspace(tag, C, B, H, W, x.dtype, x.device)
-    L.call("asr_nhwc_to_planar", L.ptr(x), L.ptr(xp), B, H, W, C, L.dt(x), L.stream())
+    xp = planar_workspace(tag, C, B, H, W, x.dtype, x.device, copies=3 if shifted3 else 1)
+    L.call("asr_nhwc_to_planar", L.ptr(x), L.ptr(xp), B, H, W, C, int(shifted3), L.dt(x), L.stream())
     return xp
+
+
+def conv3x3_wgrad_gemm(x, dy, dw):
+    """dW (Cout,Cin,3,3) += sum_p dy[p,co] * x[p+tap,ci] as ONE split-K NT GEMM over the padded pixel axis:
+    A = planar dy (Cout, Np), B row (ci, tap) = shifted planar copy of x at an aligned offset (b_rowoff table)."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    lib = L.load()
+    dtc = L.dt(x)
+    WP, Np = lib.asr_planar_pitch(W, dtc), lib.asr_planar_size(B, H, W, dtc)
+    xp3 = nhwc_to_planar(x, "wg_x", shifted3=True)
+    dyp = nhwc_to_planar(dy, "wg_dy")
+    key = (Cin, Np, WP, str(x.device))
+    tab = _rowoff_cache.get(key)
+    if tab is None:
+        ci = torch.arange(Cin, dtype=torch.int64).repeat_interleave(9)
+        tap = torch.arange(9, dtype=torch.int64).repeat(Cin)
+        dyi, dxi = tap // 3, tap % 3
+        tab = (dxi * Cin * Np + ci * Np + (dyi - 1) * WP).to(x.device)
+        _rowoff_cache[key] = tab
+    k_beg = 2 * WP
+    K = B * (H + 1) * WP
+    bk = 32 if x.dtype == torch.float32 else 64
+    K = (K + bk - 1) // bk * bk                     # runs into the zero guard rows
+    tiles = ((Cout + 63) // 64) * ((9 * Cin + 63) // 64)
+    splits = max(1, min(512 // tiles, K // (8 * bk)))
+    a = dyp[:, k_beg:]
+    b = xp3.view(-1)[k_beg:]
+    L.call("asr_gemm_nt", L.ptr(a), Np, L.ptr(b), 0, L.ptr(dw), 9 * Cin, None, None, L.ptr(tab), Cout, 9 * Cin, K, 1.0,
+           L.GEMM_ACCUMULATE, splits, dtc, L.F32, L.stream())
 
 
 def conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout):

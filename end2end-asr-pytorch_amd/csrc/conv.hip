@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void pool_bwd_edges_kernel(T* __restrict__ dx,
 // block per (b, y, 64-wide x tile): (64 px, C) -> LDS -> C rows of 64 contiguous px
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const T* __restrict__ x, T* __restrict__ xp, int B, int H, int W, int C,
-                                                             int64_t WP, int64_t Np, int tiles_w) {
+                                                             int64_t WP, int64_t Np, int tiles_w, int shifted3) {
   extern __shared__ float sp[];     // [64][C+1]
   int t = blockIdx.x;
   const int tw = t % tiles_w; t /= tiles_w;
@@ -371,7 +371,20 @@ __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const T* __restrict
   const int64_t pbase = ((int64_t)b * (H + 1) + yh + 2) * WP + x0;
   for (int i = threadIdx.x; i < C * 64; i += 256) {
     const int px = i & 63, c = i >> 6;
-    if (px < npx) DT<T>::st(xp + (int64_t)c * Np + pbase + px, sp[px * (C + 1) + c]);
+    if (px < npx) {
+      const float v = sp[px * (C + 1) + c];
+      T* d = xp + (int64_t)c * Np + pbase + px;
+      if (!shifted3) {
+        DT<T>::st(d, v);
+      } else {
+        // three copies so that the +-1 pixel taps of the wgrad contraction are ALIGNED pointer shifts:
+        // copy0[p] = x[p-1], copy1[p] = x[p], copy2[p] = x[p+1]   (never-written neighbours stay zero = padding)
+        const int64_t CN = (int64_t)C * Np;
+        DT<T>::st(d + 1, v);
+        DT<T>::st(d + CN, v);
+        DT<T>::st(d + 2 * CN - 1, v);
+      }
+    }
   }
 }
 
@@ -514,7 +527,7 @@ inline unsigned stream_grid(int64_t total_threads) {
 }  // namespace
 
 extern "C" int64_t asr_planar_pitch(int W, int dtype) { (void)dtype; return ((int64_t)W + 1 + 7) / 8 * 8; }
-extern "C" int64_t asr_planar_size(int B, int H, int W, int dtype) { return ((int64_t)B * (H + 1) + 4) * asr_planar_pitch(W, dtype); }
+extern "C" int64_t asr_planar_size(int B, int H, int W, int dtype) { return ((int64_t)B * (H + 1) + 4) * asr_planar_pitch(W, dtype) + 128; }
 
 extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0, int dtype,
                              hipStream_t s) {
@@ -625,7 +638,7 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
   return ASR_OK;
 }
 
-extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int dtype, hipStream_t s) {
+extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && xp && B >= 0 && H > 0 && W > 0 && C > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   if (B == 0) return ASR_OK;
@@ -633,8 +646,8 @@ extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, 
   const int tiles_w = (W + 63) / 64;
   const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
   AsrProfScope prof(ASR_OP_LAYOUT, s);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const float*)x, (float*)xp, B, H, W, C, WP, Np, tiles_w);
-  else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)xp, B, H, W, C, WP, Np, tiles_w);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const float*)x, (float*)xp, B, H, W, C, WP, Np, tiles_w, shifted3);
+  else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)xp, B, H, W, C, WP, Np, tiles_w, shifted3);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

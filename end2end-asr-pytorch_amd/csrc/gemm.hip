@@ -6,17 +6,19 @@
 //
 // Structure: 256 threads = 4 waves (2x2), tile BMxBN, LDS row = 128 data bytes (+16 pad) per tile row,
 // register-staged global->LDS with the next tile's loads issued before the current tile's MFMAs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 struct GemmArgs {
-  const void* A; const void* B; void* C; const float* bias; const void* mask;
+  const void* A; const void* B; void* C; const float* bias; const void* mask; const int64_t* b_rowoff;
   int64_t lda, ldb, ldc;
   int M, N, K;
   int k_per_split;     // multiple of BK
   float alpha;
-  int relu, accumulate, atomic, vecA, vecB;
+  int relu, accumulate, atomic, vecA, vecB, vecC;
   int tiles_n;
 };
 
@@ -148,6 +150,181 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
+
+// ================================================================================================ fast path
+// Direct-to-LDS staging (global_load_lds_dwordx4: no VGPR round trip, one wave instruction = 8 tile rows = 1 KiB),
+// LDS image is lane-linear [row][8 x 16 B] with the 16-B slot XOR-swizzled by (row & 7) -- applied on the per-lane
+// SOURCE address and again on the fragment read (the destination of an LDS-DMA cannot be permuted), two LDS stages,
+// one barrier per K step, XCD-aware tile order, and an epilogue that goes through LDS so that bias / ReLU / mask /
+// accumulate / atomics and the global stores are 16-byte row-contiguous.
+// Requirements: 16-B aligned operands, lda/ldb multiples of a 16-B chunk, every K range a multiple of BK (128 bytes).
+template <int ROWS>
+__device__ __forceinline__ void stage_glds(unsigned char* lds_stage, const unsigned char* gbase, int64_t ld_bytes,
+                                           const int64_t* rowoff, int esz, int row0, int row_limit, int64_t kbyte0, int tid,
+                                           int wave) {
+#pragma unroll
+  for (int i = 0; i < ROWS * 8 / 256; ++i) {
+    const int c = i * 256 + tid, row = c >> 3, slot = (c & 7) ^ (row & 7);
+    int gr = row0 + row;
+    gr = gr < row_limit ? gr : row_limit - 1;                       // clamp: rows past the edge are never stored
+    const int64_t roff = rowoff ? rowoff[gr] * esz : (int64_t)gr * ld_bytes;
+    const unsigned char* src = gbase + roff + kbyte0 + slot * 16;
+    unsigned char* dst = lds_stage + (i * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+  }
+}
+
+template <typename T, typename TO, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int BKB = 128;                       // bytes of K per stage row
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int CPITCH = BN * 4 + 16;            // fp32 C tile staged in LDS for the epilogue
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, g = lane >> 4;
+  // XCD-aware order: blocks b, b+8, b+16 ... run on the same XCD (private L2) -> give them consecutive tiles
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kend = min((int64_t)p.K, kbeg + p.k_per_split);
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  const int nk = (int)((kend - kbeg) * ESZ / BKB);
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    unsigned char* s = smem + buf * STAGE;
+    const int64_t kb = (kbeg * ESZ) + (int64_t)kt * BKB;
+    stage_glds<BM>(s, A, p.lda * ESZ, nullptr, ESZ, m0, p.M, kb, tid, wave);
+    stage_glds<BN>(s + BM * BKB, B, p.ldb * ESZ, p.b_rowoff, ESZ, n0, p.N, kb, tid, wave);
+  };
+
+  if (nk > 0) stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const unsigned char* sA = smem + (kt & 1) * STAGE;
+    const unsigned char* sB = sA + BM * BKB;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      uint4 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm * WM + i * 16 + lr;
+        a[i] = *reinterpret_cast<const uint4*>(sA + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int r = wn * WN + j * 16 + lr;
+        b[j] = *reinterpret_cast<const uint4*>(sB + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> row-contiguous 16-byte global accesses
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float*>(smem + (wm * WM + i * 16 + g * 4 + r) * CPITCH + (wn * WN + j * 16 + lr) * 4) = acc[i][j][r] * p.alpha;
+  __syncthreads();
+  TO* C = static_cast<TO*>(p.C);
+  const T* Msk = static_cast<const T*>(p.mask);
+  const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
+  constexpr int CPR = BN / 4;                    // 4-column chunks per tile row
+  for (int c = tid; c < BM * CPR; c += 256) {
+    const int row = c / CPR, col = (c % CPR) * 4;
+    const int gr = m0 + row, gc = n0 + col;
+    if (gr >= p.M || gc >= p.N) continue;
+    const float4 v4 = *reinterpret_cast<const float4*>(smem + row * CPITCH + col * 4);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    TO* dst = C + (int64_t)gr * p.ldc + gc;
+    const int nvalid = min(4, p.N - gc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nvalid) {
+        if (add_bias) v[e] += p.bias[gc + e];
+        if (p.relu) v[e] = fmaxf(v[e], 0.f);
+        if (Msk && !(DT<T>::ld(Msk + (int64_t)gr * p.ldc + gc + e) > 0.f)) v[e] = 0.f;
+      }
+    }
+    if (p.vecC && nvalid == 4 && !p.atomic) {
+      if constexpr (sizeof(TO) == 4) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<float4*>(dst) = o;
+      } else {
+        if (p.accumulate) {
+          const uint2 old = *reinterpret_cast<const uint2*>(dst);
+          v[0] += bf16_to_f32((bf16_t)(old.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(old.x >> 16));
+          v[2] += bf16_to_f32((bf16_t)(old.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(old.y >> 16));
+        }
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nvalid) store_out<TO>(dst + e, v[e], p.accumulate, p.atomic);
+    }
+  }
+}
+
+template <typename T, typename TO, int BM, int BN>
+int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
+  GemmArgs p = a;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)splits);
+  size_t lds = (size_t)2 * (BM + BN) * 128;
+  const size_t cl = (size_t)BM * (BN * 4 + 16);
+  if (cl > lds) lds = cl;
+  static bool granted = false;
+  if (lds > 48 * 1024 && !granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<T, TO, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = true;
+  }
+  hipLaunchKernelGGL((gemm_glds_kernel<T, TO, BM, BN>), grid, dim3(256), lds, s, p);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+template <typename T, typename TO>
+int dispatch_fast(const GemmArgs& a, int splits, hipStream_t s) {
+  if (const char* force = getenv("ASR_GEMM_TILE")) {          // tuning hook (tools/microbench.py)
+    if (force[0] == '0') return launch_fast<T, TO, 128, 128>(a, splits, s);
+    if (force[0] == '1') return launch_fast<T, TO, 128, 64>(a, splits, s);
+    if (force[0] == '2') return launch_fast<T, TO, 64, 64>(a, splits, s);
+  }
+  // Measured on MI355X (tools/microbench.py): with this two-stage pipeline the kernel is latency bound, so occupancy
+  // (64x64: 8 workgroups per CU) beats tile size until the grid is very large.
+  const int64_t t64 = ceil_div64(a.M, 64) * ceil_div64(a.N, 64) * splits;
+  if (t64 >= 6000 && a.M > 64) return launch_fast<T, TO, 128, 64>(a, splits, s);
+  return launch_fast<T, TO, 64, 64>(a, splits, s);
+}
+
 template <typename T, typename TO, int BM, int BN>
 int launch(const GemmArgs& a, int splits, hipStream_t s) {
   GemmArgs p = a;
@@ -172,8 +349,8 @@ int dispatch_tile(const GemmArgs& a, int splits, hipStream_t s) {
 }  // namespace
 
 extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                           const float* bias, const void* relu_mask, int M, int N, int K, float alpha, int flags,
-                           int splits, int in_dtype, int out_dtype, hipStream_t stream) {
+                           const float* bias, const void* relu_mask, const int64_t* b_rowoff, int M, int N, int K,
+                           float alpha, int flags, int splits, int in_dtype, int out_dtype, hipStream_t stream) {
   ASR_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return ASR_OK;
   ASR_CHECK_ARG(in_dtype == ASR_F32 || in_dtype == ASR_BF16);
@@ -181,12 +358,23 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   ASR_CHECK_ARG(!(in_dtype == ASR_F32 && out_dtype == ASR_BF16));
   const int esz = in_dtype == ASR_F32 ? 4 : 2, epc = 16 / esz, bk = 128 / esz;
   GemmArgs p{};
-  p.A = A; p.B = B; p.C = C; p.bias = bias; p.mask = relu_mask;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.mask = relu_mask; p.b_rowoff = b_rowoff;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   p.alpha = alpha;
   p.relu = (flags & ASR_GEMM_RELU) != 0;
   p.accumulate = (flags & ASR_GEMM_ACCUMULATE) != 0;
+  if (splits == 0) {
+    // auto: fp32 atomics are expensive (~10 ns each), so split only while the 64x64 grid cannot fill the chip
+    splits = 1;
+    if (p.accumulate && out_dtype == ASR_F32 && !p.relu && !relu_mask) {
+      const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
+      int64_t sp = (256 + t64 / 2) / (t64 > 0 ? t64 : 1);
+      if (sp > 4) sp = 4;
+      if (sp > K / (4 * bk)) sp = K / (4 * bk);
+      if (sp >= 2) splits = (int)sp;
+    }
+  }
   if (splits < 1) splits = 1;
   int kps = (int)(ceil_div64(ceil_div64(K > 0 ? K : 1, splits), bk) * bk);
   splits = (int)ceil_div64(K > 0 ? K : 1, kps);
@@ -199,7 +387,18 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   }
   p.vecA = aligned16(A) && (lda % epc == 0) && (K % epc == 0);
   p.vecB = aligned16(B) && (ldb % epc == 0) && (K % epc == 0);
+  const int oesz = out_dtype == ASR_F32 ? 4 : 2;
+  p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0) && (oesz == 4 || ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
+  // fast path: LDS-DMA staging needs whole 16-B chunks everywhere and whole 128-byte K steps
+  const bool fast = p.vecA && (b_rowoff ? aligned16(B) : p.vecB) && K > 0 && (K % bk == 0) && (kps % bk == 0) &&
+                    getenv("ASR_GEMM_GENERIC") == nullptr;
+  if (fast) {
+    if (in_dtype == ASR_F32) return dispatch_fast<float, float>(p, splits, stream);
+    if (out_dtype == ASR_BF16) return dispatch_fast<bf16_t, bf16_t>(p, splits, stream);
+    return dispatch_fast<bf16_t, float>(p, splits, stream);
+  }
+  if (b_rowoff) return ASR_EUNSUPPORTED;
   if (in_dtype == ASR_F32) return dispatch_tile<float, float>(p, splits, stream);
   if (out_dtype == ASR_BF16) return dispatch_tile<bf16_t, bf16_t>(p, splits, stream);
   return dispatch_tile<bf16_t, float>(p, splits, stream);

@@ -45,11 +45,12 @@ int asr_prof_collect(int op_id, double* total_ms, int64_t* launches); /* synchro
 
 /* ---- dense contraction: nn.Linear / Conv1d(k=1) forward, dgrad, wgrad ----------------------------------------
  * C[M,N] (op)= alpha * sum_k A[m*lda+k] * B[n*ldb+k]  (+ bias[n]) (ReLU).  Both operands K-contiguous.
- * flags: ASR_GEMM_RELU, ASR_GEMM_ACCUMULATE (C += ...).  splits>1: split-K with fp32 atomics, requires
+ * flags: ASR_GEMM_RELU, ASR_GEMM_ACCUMULATE (C += ...).  splits>1: split-K with fp32 atomics (0 = auto), requires
  * out_dtype F32 and ACCUMULATE.  Replaces common_layers.py:136-142 (FFN), :181-187 (Q/K/V), :197 (out proj),
  * transformer.py:172 (input_linear), :302 (output_linear) and their autograd backward.                        */
 int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                 const void* relu_mask /* optional (M,ldc) tensor of the input dtype: C = 0 where relu_mask <= 0 */,
+                const int64_t* b_rowoff /* optional device table: row n of B starts at B + b_rowoff[n] elements */,
                 int M, int N, int K, float alpha, int flags, int splits, int in_dtype, int out_dtype,
                 asr_stream_t stream);
 
@@ -160,11 +161,14 @@ int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_
 int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
                     asr_stream_t stream);
 /* NHWC (B,H,W,C) -> planar zero-padded (C, Np): pixel (b,y,x) at plane offset ((b*(H+1)+y+2)*WP + x), WP =
- * asr_planar_pitch(W) >= W+1, one zero row between images, two guard rows at either end; Np = (B*(H+1)+4)*WP.
- * Pads must be zero: the caller zero-initialises the buffer once, the kernel only writes real pixels.           */
+ * asr_planar_pitch(W) >= W+1, one zero row between images, two guard rows at either end; Np = (B*(H+1)+4)*WP+128.
+ * Pads must be zero: the caller zero-initialises the buffer once, the kernel only writes real pixels.
+ * shifted3 != 0: xp is (3, C, Np) with copy0[p] = x[p-1], copy1[p] = x[p], copy2[p] = x[p+1], which turns the +-1
+ * pixel taps of the weight-gradient contraction into 16-byte aligned pointer shifts (asr_gemm_nt + b_rowoff).    */
 int64_t asr_planar_pitch(int W, int dtype);
 int64_t asr_planar_size(int B, int H, int W, int dtype); /* Np, elements per channel plane                        */
-int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int dtype, asr_stream_t stream);
+int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, int dtype,
+                       asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += sum_p dy[p,co] * x[p+tap,ci] from planar operands (bias grad: asr_colsum_acc on NHWC dy)   */
 int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw_acc, int B, int H, int W, int Cin, int Cout,
                       int dtype, asr_stream_t stream);

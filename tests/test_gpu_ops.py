@@ -45,8 +45,7 @@ def ops():
 # ------------------------------------------------------------------------------------------------ MFMA layout probe
 def test_mfma_fragment_layout_asymmetric(ops):
     """A = I (and a permutation) against an ASYMMETRIC B catches row/col swaps in the fragment maps."""
-    for dtype in DTYPES:
-        n = 48
+    for dtype, n in [(d, n) for d in DTYPES for n in (48, 128, 192)]:      # 48: generic kernel; 128/192: LDS-DMA kernel
         A = torch.eye(n)
         B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 / 16.0       # exactly representable in bf16
         C = ops.gemm_nt(A.to(dev(), dtype), B.to(dev(), dtype), out_dtype=torch.float32)
@@ -59,7 +58,7 @@ def test_mfma_fragment_layout_asymmetric(ops):
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(200, 70, 96), (512, 384, 256), (130, 260, 40), (64, 4364, 512), (1000, 512, 5120),
-                                   (37, 35, 161)])
+                                   (37, 35, 161), (200, 70, 128), (129, 257, 192), (6400, 512, 512), (333, 2048, 64)])
 def test_gemm_nt_bias_relu(ops, dtype, shape):
     M, N, K = shape
     g = torch.Generator().manual_seed(M + N + K)
@@ -405,6 +404,12 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     db = torch.zeros(Cout, device=D)
     ops.colsum_acc(dy.to(D, dtype).view(-1, Cout), db)
     close("conv3x3 db", db, br.grad, torch.float32, scale=16)
+    # the production path: shifted planar copies + one split-K GEMM with a B row-offset table
+    dwg = torch.zeros(Cout, Cin, 3, 3, device=D)
+    ops.conv3x3_wgrad_gemm(nhwc(x).to(D, dtype), dy.to(D, dtype), dwg)
+    close("conv3x3 wgrad (GEMM path)", dwg, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
+    ops.conv3x3_wgrad_gemm(nhwc(x).to(D, dtype), dy.to(D, dtype), dwg)
+    close("conv3x3 wgrad (GEMM path, accumulates)", dwg, 2 * wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
     # run it twice through the persistent planar workspace: pads must still be zero
     xp2 = ops.nhwc_to_planar(nhwc(x).to(D, dtype), "tx")
     assert xp2.data_ptr() == xp.data_ptr()

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_header_symbols():
     assert h.asr_strerror(-3).decode().startswith("unsupported")
     # pure host helpers of the ABI (no device needed)
     assert h.asr_planar_pitch(800, 1) == 808 and h.asr_planar_pitch(7, 0) == 8
-    assert h.asr_planar_size(32, 161, 800, 1) == (32 * 162 + 4) * 808
+    assert h.asr_planar_size(32, 161, 800, 1) == (32 * 162 + 4) * 808 + 128
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmarks on the shapes of BASELINE config 2 (B=32): TFLOP/s per launch, measured with HIP events over
+back-to-back launches.  Development tool (not part of the test suite):  python tools/microbench.py [gemm|conv|wgrad|attn|all]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "end2end-asr-pytorch_amd"))
+import torch
+
+from asr_hip import ops
+
+D = torch.device("cuda:0")
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3      # us
+
+
+def gemm():
+    print("== gemm_nt  (M, N, K)  bf16")
+    shapes = [(6400, 512, 512, torch.bfloat16), (6400, 1536, 512, torch.bfloat16), (6400, 2048, 512, torch.bfloat16),
+              (6400, 512, 2048, torch.bfloat16), (6400, 512, 5120, torch.bfloat16), (3200, 512, 512, torch.bfloat16),
+              (3200, 4364, 512, torch.float32), (3200, 512, 4368, torch.bfloat16), (6400, 5120, 512, torch.bfloat16)]
+    for M, N, K, od in shapes:
+        A = torch.randn(M, K, device=D).bfloat16()
+        B = torch.randn(N, K, device=D).bfloat16()
+        bias = torch.randn(N, device=D)
+        out = torch.empty(M, N, device=D, dtype=od)
+        res = []
+        for tile in "012":
+            os.environ["ASR_GEMM_TILE"] = tile
+            us = timeit(lambda: ops.gemm_nt(A, B, out=out, bias=bias))
+            res.append("%s %6.1fus %5.0fTF" % (["128x128", "128x64", "64x64"][int(tile)], us, 2 * M * N * K / us / 1e6))
+        os.environ.pop("ASR_GEMM_TILE", None)
+        print("  fwd   %5d %5d %5d -> %-8s %s" % (M, N, K, str(od)[6:], " | ".join(res)))
+    print("== wgrad (split-K, fp32 atomics)  dW(N,K) over M")
+    for N, K, M in [(512, 512, 6400), (2048, 512, 6400), (512, 2048, 6400), (512, 5120, 6400), (4364, 512, 3200), (1536, 512, 6400)]:
+        dyt = torch.randn(N, M, device=D).bfloat16()
+        xt = torch.randn(K, M, device=D).bfloat16()
+        g = torch.zeros(N, K, device=D)
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        for tile in "012":
+            os.environ["ASR_GEMM_TILE"] = tile
+            res = []
+            for sp in (1, 2, 4, 8):
+                us = timeit(lambda: ops.gemm_nt(dyt, xt, out=g, accumulate=True, splits=sp))
+                res.append("s%d %6.1fus %5.0fTF" % (sp, us, 2 * M * N * K / us / 1e6))
+            print("  wgrad %5d %5d %5d tile %s : %s" % (N, K, M, ["128x128", "128x64", "64x64"][int(tile)], " | ".join(res)))
+        os.environ.pop("ASR_GEMM_TILE", None)
+
+
+def conv():
+    print("== conv3x3 igemm (B,H,W,Cin,Cout) bf16")
+    for B, H, W, Ci, Co in [(32, 161, 800, 64, 64), (32, 80, 400, 64, 128), (32, 80, 400, 128, 128), (32, 80, 400, 128, 64)]:
+        x = torch.randn(B, H, W, Ci, device=D).bfloat16()
+        wk = torch.randn(Co, 9, Ci, device=D).bfloat16()
+        bias = torch.randn(Co, device=D)
+        us = timeit(lambda: ops.conv3x3(x, wk, bias, Co, relu=True), iters=10)
+        fl = 2 * 9 * Ci * Co * B * H * W
+        print("  igemm %s %8.1f us  %7.1f TF/s" % ((B, H, W, Ci, Co), us, fl / us / 1e6))
+        msk = torch.randn(B, H, W, Co, device=D).bfloat16()
+        us = timeit(lambda: ops.conv3x3(x, wk, None, Co, relu=False, mask_src=msk), iters=10)
+        print("  igemm+mask %s %8.1f us  %7.1f TF/s" % ((B, H, W, Ci, Co), us, fl / us / 1e6))
+
+
+def wgrad():
+    print("== conv3x3 wgrad (B,H,W,Cin,Cout) bf16  (+ nhwc_to_planar)")
+    for B, H, W, Ci, Co in [(32, 161, 800, 64, 64), (32, 80, 400, 64, 128), (32, 80, 400, 128, 128)]:
+        x = torch.randn(B, H, W, Ci, device=D).bfloat16()
+        dy = torch.randn(B, H, W, Co, device=D).bfloat16()
+        us_p = timeit(lambda: ops.nhwc_to_planar(x, "mbx"), iters=10)
+        xp = ops.nhwc_to_planar(x, "mbx")
+        dyp = ops.nhwc_to_planar(dy, "mbdy")
+        dw = torch.zeros(Co, Ci, 3, 3, device=D)
+        us = timeit(lambda: ops.conv3x3_wgrad(xp, dyp, dw, B, H, W, Ci, Co), iters=10)
+        fl = 2 * 9 * Ci * Co * B * H * W
+        us_g = timeit(lambda: ops.conv3x3_wgrad_gemm(x, dy, dw), iters=10)
+        us_p3 = timeit(lambda: ops.nhwc_to_planar(x, "wg_x", shifted3=True), iters=10)
+        print("  wgrad-gemm path total %8.1f us (%6.1f TF/s incl. layout)   planar3(x) %7.1f us" % (us_g, fl / us_g / 1e6, us_p3))
+        print("  wgrad %s %8.1f us  %7.1f TF/s   planar(x) %7.1f us (%.0f GB/s)" %
+              ((B, H, W, Ci, Co), us, fl / us / 1e6, us_p, 2 * x.numel() * 2 / us_p / 1e3))
+
+
+def attn():
+    print("== attention (B,H,Tq,Tk,d) bf16")
+    for B, H, Tq, Tk, d, causal in [(32, 8, 200, 200, 64, False), (32, 8, 100, 100, 64, True), (32, 8, 100, 200, 64, False),
+                                    (32, 8, 800, 800, 64, False)]:
+        q = torch.randn(B, Tq, H * d, device=D).bfloat16()
+        k = torch.randn(B, Tk, H * d, device=D).bfloat16()
+        v = torch.randn(B, Tk, H * d, device=D).bfloat16()
+        do = torch.randn(B, Tq, H * d, device=D).bfloat16()
+        us = timeit(lambda: ops.attn_fwd(q, k, v, H, d, causal=causal, scale=0.125))
+        o, lse, _ = ops.attn_fwd(q, k, v, H, d, causal=causal, scale=0.125)
+        fl = 4 * B * H * Tq * Tk * d * (0.5 if causal else 1.0)
+        usb = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, H, d, causal=causal, scale=0.125))
+        print("  attn %s fwd %8.1f us %7.1f TF/s | bwd %8.1f us %7.1f TF/s" %
+              ((B, H, Tq, Tk, d, causal), us, fl / us / 1e6, usb, 2.5 * fl / usb / 1e6))
+
+
+def misc():
+    print("== streaming kernels")
+    M, Dm = 6400, 512
+    y = torch.randn(M, Dm, device=D).bfloat16(); r = torch.randn(M, Dm, device=D).bfloat16()
+    g = torch.ones(Dm, device=D); b = torch.zeros(Dm, device=D)
+    us = timeit(lambda: ops.add_ln_fwd(y, r, g, b, p=0.1, seed=1))
+    print("  add_ln_fwd 6400x512 %7.1f us  %.0f GB/s" % (us, 4 * M * Dm * 2 / us / 1e3))
+    out, mean, rstd = ops.add_ln_fwd(y, r, g, b, p=0.1, seed=1)
+    dg = torch.zeros(Dm, device=D); db = torch.zeros(Dm, device=D)
+    us = timeit(lambda: ops.add_ln_bwd(out, y, mean, rstd, g, None, dg, db, p=0.1, seed=1))
+    print("  add_ln_bwd 6400x512 %7.1f us  %.0f GB/s" % (us, 4 * M * Dm * 2 / us / 1e3))
+    x = torch.randn(M, 2048, device=D).bfloat16()
+    us = timeit(lambda: ops.transpose_padded(x))
+    print("  transpose 6400x2048 %7.1f us  %.0f GB/s" % (us, 2 * x.numel() * 2 / us / 1e3))
+    x1 = torch.randn(32, 161, 800, 64, device=D).bfloat16()
+    us = timeit(lambda: ops.maxpool_fwd(x1), iters=10)
+    print("  maxpool_fwd (32,161,800,64) %7.1f us  %.0f GB/s" % (us, 1.25 * x1.numel() * 2 / us / 1e3))
+    src = torch.randn(32, 1, 161, 800, device=D); w = torch.randn(64, 1, 3, 3, device=D); bb = torch.randn(64, device=D)
+    us = timeit(lambda: ops.conv1_fwd(src, w, bb, torch.bfloat16), iters=10)
+    print("  conv1_fwd %7.1f us  %.0f GB/s" % (us, x1.numel() * 2 / us / 1e3))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    for name, fn in (("gemm", gemm), ("conv", conv), ("wgrad", wgrad), ("attn", attn), ("misc", misc)):
+        if which in (name, "all"):
+            fn()
