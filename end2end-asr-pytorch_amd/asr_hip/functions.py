@@ -281,9 +281,8 @@ class VGGFn(Function):
         w0, b0, w2, b2, w5, b5, w7, b7 = ctx.params
 
         def wgrad(x, dy, w, b, tag):
-            Cout = dy.shape[3]
-            ops.conv3x3_wgrad_gemm(x, dy, P.grad_of(w))
-            ops.colsum_acc(dy.view(-1, Cout), P.grad_of(b))
+            # dW and db straight from the NHWC tensors (transposing LDS reads; no planar copies)
+            ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
 
         dy4 = ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
         wgrad(y3, dy4, w7, b7, "c7")

@@ -56,7 +56,8 @@ _SIGS = {
     "asr_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_planar_pitch": (_L, [_I, _I]),
     "asr_planar_size": (_L, [_I, _I, _I, _I]),
-    "asr_nhwc_to_planar": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_nhwc_to_planar": (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    "asr_conv3x3_wgrad_nhwc": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_wgrad": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
 }
 

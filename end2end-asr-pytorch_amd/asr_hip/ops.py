@@ -337,10 +337,11 @@ def planar_workspace(tag, C, B, H, W, dtype, device, copies=1):
     return buf
 
 
-def nhwc_to_planar(x, tag, shifted3=False):
+def nhwc_to_planar(x, tag, shifted3=False, chan_sum_acc=None):
+    """NHWC -> zero padded planar workspace; chan_sum_acc (fp32, C) optionally accumulates per-channel sums of x."""
     B, H, W, C = x.shape
     xp = planar_workspace(tag, C, B, H, W, x.dtype, x.device, copies=3 if shifted3 else 1)
-    L.call("asr_nhwc_to_planar", L.ptr(x), L.ptr(xp), B, H, W, C, int(shifted3), L.dt(x), L.stream())
+    L.call("asr_nhwc_to_planar", L.ptr(x), L.ptr(xp), B, H, W, C, int(shifted3), L.ptr(chan_sum_acc), L.dt(x), L.stream())
     return xp
 
 
@@ -372,6 +373,14 @@ def conv3x3_wgrad_gemm(x, dy, dw):
     b = xp3.view(-1)[k_beg:]
     L.call("asr_gemm_nt", L.ptr(a), Np, L.ptr(b), 0, L.ptr(dw), 9 * Cin, None, None, L.ptr(tab), Cout, 9 * Cin, K, 1.0,
            L.GEMM_ACCUMULATE, splits, dtc, L.F32, L.stream())
+
+
+def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
+    """dW (Cout,Cin,3,3) += , db (Cout) += from NHWC activations x (B,H,W,Cin) and gradients dy (B,H,W,Cout)."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3]
+    L.call("asr_conv3x3_wgrad_nhwc", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, H, W, Cin, Cout, L.dt(x), L.stream())
 
 
 def conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout):

@@ -222,27 +222,42 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #undef ASR_WLOAD
 #undef ASR_WWRITE
 
+  // ---- epilogue through LDS: (128 px, NCO) fp32 tile -> per pixel 16-byte channel-contiguous chunks, so that the
+  // bias / ReLU / mask reads and the NHWC stores are all row-contiguous vector accesses
+  constexpr int CP = NCO * 4 + 16;
+  __syncthreads();                               // all waves are done reading the patch / weight tiles
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float*>(smem + ((wm * 4 + i) * 16 + g * 4 + r) * CP + (wn * (NCO / 2) + j * 16 + lr) * 4) = acc[i][j][r];
+  __syncthreads();
   T* Y = static_cast<T*>(p.y);
   const T* Msk = static_cast<const T*>(p.mask_src);
+  constexpr int CPX = NCO / EPC;                 // 16-byte output chunks per pixel
+  for (int c = tid; c < 128 * CPX; c += 256) {
+    const int px = c / CPX, ch0 = (c % CPX) * EPC;
+    const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
+    if (gy >= p.H || gx >= p.W) continue;
+    const int64_t off = (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0;
+    float v[EPC];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int co = wn * (NCO / 2) + j * 16 + lr;
-    const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int gy = h0 + wm * 4 + i;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int gx = w0 + g * 4 + r;
-        if (gy < p.H && gx < p.W) {
-          const int64_t off = (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + co;
-          float v = acc[i][j][r] + bv;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (Msk && !(DT<T>::ld(Msk + off) > 0.f)) v = 0.f;
-          DT<T>::st(Y + off, v);
-        }
-      }
+    for (int e = 0; e < EPC; e += 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(smem + px * CP + (ch0 + e) * 4);
+      v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
     }
+    Chunk<T> m, o;
+    if (Msk) m.v = *reinterpret_cast<const uint4*>(Msk + off);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      float x = v[e] + (p.bias ? p.bias[ch0 + e] : 0.f);
+      if (p.relu) x = fmaxf(x, 0.f);
+      if (Msk && !(DT<T>::from(m.e[e]) > 0.f)) x = 0.f;
+      o.e[e] = DT<T>::to(x);
+    }
+    *reinterpret_cast<uint4*>(Y + off) = o.v;
   }
 }
 
@@ -354,10 +369,13 @@ __global__ __launch_bounds__(256) void pool_bwd_edges_kernel(T* __restrict__ dx,
 }
 
 // ================================================================================================ NHWC -> planar
-// block per (b, y, 64-wide x tile): (64 px, C) -> LDS -> C rows of 64 contiguous px
+// block per (b, y, 64-wide x tile): (64 px, C) -> LDS -> C rows of 64 contiguous px.  Optionally also accumulates the
+// per-channel sums of the tile (= the conv bias gradient when x is dY) -- the tile is in LDS anyway.
+// shifted3: three copies copy0[p] = x[p-1], copy1[p] = x[p], copy2[p] = x[p+1] (positions never written stay zero).
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const T* __restrict__ x, T* __restrict__ xp, int B, int H, int W, int C,
-                                                             int64_t WP, int64_t Np, int tiles_w, int shifted3) {
+                                                             int64_t WP, int64_t Np, int tiles_w, int shifted3,
+                                                             float* __restrict__ chan_sum) {
   extern __shared__ float sp[];     // [64][C+1]
   int t = blockIdx.x;
   const int tw = t % tiles_w; t /= tiles_w;
@@ -366,24 +384,26 @@ __global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const T* __restrict
   const int x0 = tw * 64;
   const int npx = min(64, W - x0);
   const T* in = x + (((int64_t)b * H + yh) * W + x0) * (int64_t)C;
-  for (int i = threadIdx.x; i < npx * C; i += 256) sp[(i / C) * (C + 1) + (i % C)] = DT<T>::ld(in + i);
+  for (int i = threadIdx.x; i < 64 * C; i += 256) sp[(i / C) * (C + 1) + (i % C)] = i < npx * C ? DT<T>::ld(in + i) : 0.f;
   __syncthreads();
   const int64_t pbase = ((int64_t)b * (H + 1) + yh + 2) * WP + x0;
+  const int64_t CN = (int64_t)C * Np;
   for (int i = threadIdx.x; i < C * 64; i += 256) {
     const int px = i & 63, c = i >> 6;
+    const float v = sp[px * (C + 1) + c];
     if (px < npx) {
-      const float v = sp[px * (C + 1) + c];
       T* d = xp + (int64_t)c * Np + pbase + px;
       if (!shifted3) {
         DT<T>::st(d, v);
       } else {
-        // three copies so that the +-1 pixel taps of the wgrad contraction are ALIGNED pointer shifts:
-        // copy0[p] = x[p-1], copy1[p] = x[p], copy2[p] = x[p+1]   (never-written neighbours stay zero = padding)
-        const int64_t CN = (int64_t)C * Np;
         DT<T>::st(d + 1, v);
         DT<T>::st(d + CN, v);
         DT<T>::st(d + 2 * CN - 1, v);
       }
+    }
+    if (chan_sum) {                 // a wave = the 64 pixels of one channel
+      const float sum = wave_sum(v);
+      if (px == 0) atomicAdd(chan_sum + c, sum);
     }
   }
 }
@@ -496,6 +516,170 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
   }
 }
 
+// ================================================================================================ wgrad, NHWC native
+// dW[co][ci][tap] += sum_px dY[px][co] * X[px + tap][ci]   straight from the NHWC tensors (no planar copies):
+// a workgroup owns a 64(co) x 64(ci) x 9(tap) block of dW and walks 8x16-pixel patches; per patch it stages the halo
+// patch of X (180 px x 64 ci) and the dY tile (128 px x 64 co) in LDS in their natural pixel-major layout and builds the
+// MFMA operands (which need 8 CONSECUTIVE PIXELS per lane) with the transposing LDS read ds_read_b64_tr_b16:
+//   in each 16-lane group, lane i slot j receives element (i&3) of the 8-byte row supplied by lane 4j+(i>>2)
+//   (measured: tools/probes/tr_read_probe.hip), so lane i supplying &T[p0 + (i>>2)][c0 + 4*(i&3)] gets T[p0..p0+3][c0+i].
+// A tap is a row offset into the halo patch, so all 9 taps reuse one staged patch: 2*64*576*128 flop per 41 KB staged.
+// fp32 mode uses one 4-byte read per MFMA operand element instead (k <-> lane group, conflict free).
+struct WgradNArgs {
+  const void* x; const void* dy; float* dw; float* db;
+  int B, H, W, Cin, Cout, tiles_h, tiles_w, npatch, patches_per_wg, nci;
+};
+
+template <typename T> struct WgPack;
+template <> struct WgPack<bf16_t> {
+  // pack = 8 consecutive pixels (k = 8g .. 8g+7 of a 32-pixel macro step) of channel c0 + lr
+  // pixel (macro step ms, k) -> patch row 2*ms + (k >> 4), col k & 15
+  template <int PITCH>
+  static __device__ __forceinline__ uint4 load(const unsigned char* tile, int ms, int lr, int g, int c0, int row_pitch_px,
+                                               int dy, int dx) {
+    const int y = 2 * ms + (g >> 1), x = 8 * (g & 1) + (lr >> 2);
+    const unsigned char* p = tile + ((y + dy) * row_pitch_px + x + dx) * PITCH + (c0 + 4 * (lr & 3)) * 2;
+    uint2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"((uint32_t)(uintptr_t)p));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"((uint32_t)(uintptr_t)(p + 4 * PITCH)));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+  static constexpr int NMS = 4;      // 128 pixels / 32
+};
+template <> struct WgPack<float> {
+  // pack element s (the s-th 16x16x4 MFMA of the macro step) <-> pixel 4*s + g of patch row ms
+  template <int PITCH>
+  static __device__ __forceinline__ uint4 load(const unsigned char* tile, int ms, int lr, int g, int c0, int row_pitch_px,
+                                               int dy, int dx) {
+    const unsigned char* p = tile + ((ms + dy) * row_pitch_px + g + dx) * PITCH + (c0 + lr) * 4;
+    uint4 r;
+    r.x = *reinterpret_cast<const uint32_t*>(p);
+    r.y = *reinterpret_cast<const uint32_t*>(p + 4 * PITCH);
+    r.z = *reinterpret_cast<const uint32_t*>(p + 8 * PITCH);
+    r.w = *reinterpret_cast<const uint32_t*>(p + 12 * PITCH);
+    return r;
+  }
+  static constexpr int NMS = 8;      // 128 pixels / 16
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p) {
+  constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
+  constexpr int CPP = 64 / EPC;
+  constexpr int PP = 64 * ESZ + 16;          // LDS pitch of one pixel's 64-channel slice
+  constexpr int NX = 180 * CPP, NDY = 128 * CPP;
+  constexpr int RX = (NX + 255) / 256, RDY = NDY / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sX = smem;                  // halo patch 10 x 18 pixels
+  unsigned char* sD = smem + 180 * PP;       // dY tile 8 x 16 pixels
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int co0 = (blockIdx.y / p.nci) * 64, ci0 = (blockIdx.y % p.nci) * 64;
+  const T* X = static_cast<const T*>(p.x);
+  const T* DY = static_cast<const T*>(p.dy);
+  const int p_beg = blockIdx.x * p.patches_per_wg, p_end = min(p.npatch, p_beg + p.patches_per_wg);
+
+  f32x4_t acc[9][4];                         // [tap][co fragment]; this wave's ci fragment is `wave`
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.db != nullptr && ci0 == 0 && wave == 0;
+
+  u32x4_t rx[RX], rd[RDY];
+  auto gload = [&](int patch) __attribute__((always_inline)) {
+    int t = patch;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h;
+    const int b = t / p.tiles_h;
+    const int h0 = th * 8, w0 = tw * 16;
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+      const int c = tid + i * 256;
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (c < NX) {
+        const int hp = c / CPP, ch = c % CPP;
+        const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+          v = *reinterpret_cast<const u32x4_t*>(X + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cin + ci0 + ch * EPC);
+      }
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < RDY; ++i) {
+      const int c = tid + i * 256, px = c / CPP, ch = c % CPP;
+      const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
+      u32x4_t v = {0u, 0u, 0u, 0u};
+      if (gy < p.H && gx < p.W)
+        v = *reinterpret_cast<const u32x4_t*>(DY + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + co0 + ch * EPC);
+      rd[i] = v;
+    }
+  };
+  auto swrite = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
+      const int c = tid + i * 256;
+      if (c < NX) *reinterpret_cast<u32x4_t*>(sX + (c / CPP) * PP + (c % CPP) * 16) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < RDY; ++i) {
+      const int c = tid + i * 256;
+      *reinterpret_cast<u32x4_t*>(sD + (c / CPP) * PP + (c % CPP) * 16) = rd[i];
+    }
+  };
+
+  if (p_beg < p_end) gload(p_beg);
+  for (int patch = p_beg; patch < p_end; ++patch) {
+    swrite();
+    __syncthreads();
+    if (patch + 1 < p_end) gload(patch + 1);          // next patch's HBM latency hides under this patch's MFMAs
+#pragma unroll 1
+    for (int ms = 0; ms < WgPack<T>::NMS; ++ms) {
+      uint4 a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = WgPack<T>::template load<PP>(sD, ms, lr, g, i * 16, 16, 0, 0);
+      if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Chunk<T> c; c.v = a[i];
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) bsum[i] += DT<T>::from(c.e[e]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const uint4 bfr = WgPack<T>::template load<PP>(sX, ms, lr, g, wave * 16, 18, t / 3, t % 3);
+        if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mma16<T>(acc[t][i], a[i], bfr);
+      }
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + i * 16 + g * 4 + r, ci = ci0 + wave * 16 + lr;
+        atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + t, acc[t][i][r]);
+      }
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) atomicAdd(p.db + co0 + i * 16 + lr, v);
+    }
+  }
+}
+
 // once per kernel instantiation (never during a stream capture: the first eager/warm-up launch does it)
 template <typename K> void allow_big_lds(K kernel, size_t lds) {
   static size_t granted = 0;      // one static per template instantiation = per kernel
@@ -510,7 +694,9 @@ int launch_igemm(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.tiles_h = (p.H + 7) / 8;
   p.tiles_w = (p.W + 15) / 16;
-  const size_t lds = (size_t)(180 + 2 * NCO) * (64 * sizeof(T) + 16);
+  size_t lds = (size_t)(180 + 2 * NCO) * (64 * sizeof(T) + 16);
+  const size_t lds_epi = (size_t)128 * (NCO * 4 + 16);
+  if (lds_epi > lds) lds = lds_epi;
   allow_big_lds(conv3x3_igemm_kernel<T, NCO>, lds);
   hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
@@ -579,7 +765,8 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
                                  int W, int Cin, int Cout, int relu, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && wk && y && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
-  if (Cin % 64 != 0 || (Cout != 64 && Cout != 128) || !aligned16(x) || !aligned16(wk)) return ASR_EUNSUPPORTED;
+  if (Cin % 64 != 0 || (Cout != 64 && Cout != 128) || !aligned16(x) || !aligned16(wk) || !aligned16(y) ||
+      (mask_src && !aligned16(mask_src))) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
   ConvArgs p{};
   p.x = x; p.wk = wk; p.bias = bias; p.mask_src = mask_src; p.y = y;
@@ -638,7 +825,8 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
   return ASR_OK;
 }
 
-extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, int dtype, hipStream_t s) {
+extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, float* chan_sum_acc,
+                                  int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && xp && B >= 0 && H > 0 && W > 0 && C > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   if (B == 0) return ASR_OK;
@@ -646,8 +834,8 @@ extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, 
   const int tiles_w = (W + 63) / 64;
   const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
   AsrProfScope prof(ASR_OP_LAYOUT, s);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const float*)x, (float*)xp, B, H, W, C, WP, Np, tiles_w, shifted3);
-  else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)xp, B, H, W, C, WP, Np, tiles_w, shifted3);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const float*)x, (float*)xp, B, H, W, C, WP, Np, tiles_w, shifted3, chan_sum_acc);
+  else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)xp, B, H, W, C, WP, Np, tiles_w, shifted3, chan_sum_acc);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -677,6 +865,33 @@ extern "C" int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw, int
   AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
   if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_kernel<float>), dim3((unsigned)slices, (unsigned)tiles), dim3(256), lds, s, p); }
   else { allow_big_lds(conv3x3_wgrad_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_kernel<bf16_t>), dim3((unsigned)slices, (unsigned)tiles), dim3(256), lds, s, p); }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, float* db, int B, int H, int W, int Cin, int Cout,
+                                      int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && dy && dw && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (Cin % 64 != 0 || Cout % 64 != 0 || !aligned16(x) || !aligned16(dy)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  WgradNArgs p{};
+  p.x = x; p.dy = dy; p.dw = dw; p.db = db;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout;
+  p.tiles_h = (H + 7) / 8; p.tiles_w = (W + 15) / 16;
+  p.npatch = B * p.tiles_h * p.tiles_w;
+  p.nci = Cin / 64;
+  const int blocks_y = (Cout / 64) * p.nci;
+  int wgx = 512 / blocks_y;                         // ~2 workgroups per CU in flight
+  if (wgx < 1) wgx = 1;
+  p.patches_per_wg = (p.npatch + wgx - 1) / wgx;
+  if (p.patches_per_wg < 4) p.patches_per_wg = 4;
+  wgx = (p.npatch + p.patches_per_wg - 1) / p.patches_per_wg;
+  const int esz = dtype == ASR_F32 ? 4 : 2;
+  const size_t lds = (size_t)(180 + 128) * (64 * esz + 16);
+  AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
+  if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_nhwc_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<float>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
+  else { allow_big_lds(conv3x3_wgrad_nhwc_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<bf16_t>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -19,7 +19,7 @@ struct GemmArgs {
   int k_per_split;     // multiple of BK
   float alpha;
   int relu, accumulate, atomic, vecA, vecB, vecC;
-  int tiles_n;
+  int tiles_n, ntiles;
 };
 
 constexpr int kPitch = 144;   // bytes per LDS tile row: 128 data + 16 pad (keeps 16-B alignment, breaks the 128-B stride)
@@ -188,10 +188,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, g = lane >> 4;
   // XCD-aware order: blocks b, b+8, b+16 ... run on the same XCD (private L2) -> give them consecutive tiles
+  // The linear work id is (split, tile) with the tile index fastest, so all tiles of one K slice (which share their
+  // A and B panels) sit next to each other on one XCD's L2.
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
-  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int split = wid / p.ntiles, tile = wid % p.ntiles;
   const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
-  const int64_t kbeg = (int64_t)blockIdx.z * p.k_per_split;
+  const int64_t kbeg = (int64_t)split * p.k_per_split;
   const int64_t kend = min((int64_t)p.K, kbeg + p.k_per_split);
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   __syncthreads();
   TO* C = static_cast<TO*>(p.C);
   const T* Msk = static_cast<const T*>(p.mask);
-  const bool add_bias = p.bias != nullptr && blockIdx.z == 0;
+  const bool add_bias = p.bias != nullptr && split == 0;
   constexpr int CPR = BN / 4;                    // 4-column chunks per tile row
   for (int c = tid; c < BM * CPR; c += 256) {
     const int row = c / CPR, col = (c % CPR) * 4;
@@ -297,7 +300,8 @@ int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
   GemmArgs p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  dim3 grid((unsigned)(tiles_m * p.tiles_n), 1, (unsigned)splits);
+  p.ntiles = tiles_m * p.tiles_n;
+  dim3 grid((unsigned)(p.ntiles * splits), 1, 1);
   size_t lds = (size_t)2 * (BM + BN) * 128;
   const size_t cl = (size_t)BM * (BN * 4 + 16);
   if (cl > lds) lds = cl;

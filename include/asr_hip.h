@@ -167,11 +167,17 @@ int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W
  * pixel taps of the weight-gradient contraction into 16-byte aligned pointer shifts (asr_gemm_nt + b_rowoff).    */
 int64_t asr_planar_pitch(int W, int dtype);
 int64_t asr_planar_size(int B, int H, int W, int dtype); /* Np, elements per channel plane                        */
-int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, int dtype,
-                       asr_stream_t stream);
+/* chan_sum_acc (fp32, C; optional): += per-channel sums of x (the conv bias gradient when x is dY).                */
+int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, float* chan_sum_acc,
+                       int dtype, asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += sum_p dy[p,co] * x[p+tap,ci] from planar operands (bias grad: asr_colsum_acc on NHWC dy)   */
 int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw_acc, int B, int H, int W, int Cin, int Cout,
                       int dtype, asr_stream_t stream);
+
+/* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
+ * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip).                          */
+int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw_acc, float* db_acc, int B, int H, int W, int Cin,
+                           int Cout, int dtype, asr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -397,14 +397,21 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     close("conv3x3 dgrad", dx, nhwc(xr.grad * (x > 0)), dtype, scale=2)
     # wgrad from planar operands
     xp = ops.nhwc_to_planar(nhwc(x).to(D, dtype), "tx")
-    dyp = ops.nhwc_to_planar(dy.to(D, dtype), "tdy")
+    dbp = torch.zeros(Cout, device=D)
+    dyp = ops.nhwc_to_planar(dy.to(D, dtype), "tdy", chan_sum_acc=dbp)
+    close("conv3x3 db (fused into the planar pass)", dbp, br.grad, torch.float32, scale=16)
     dw = torch.zeros(Cout, Cin, 3, 3, device=D)
     ops.conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout)
     close("conv3x3 wgrad", dw, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
     db = torch.zeros(Cout, device=D)
     ops.colsum_acc(dy.to(D, dtype).view(-1, Cout), db)
     close("conv3x3 db", db, br.grad, torch.float32, scale=16)
-    # the production path: shifted planar copies + one split-K GEMM with a B row-offset table
+    # NHWC-native kernel (transposing LDS reads), with the bias gradient fused
+    dwn = torch.zeros(Cout, Cin, 3, 3, device=D); dbn = torch.zeros(Cout, device=D)
+    ops.conv3x3_wgrad_nhwc(nhwc(x).to(D, dtype), dy.to(D, dtype), dwn, dbn)
+    close("conv3x3 wgrad (NHWC native)", dwn, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
+    close("conv3x3 db (NHWC native)", dbn, br.grad, torch.float32, scale=16)
+    # shifted planar copies + one split-K GEMM with a B row-offset table
     dwg = torch.zeros(Cout, Cin, 3, 3, device=D)
     ops.conv3x3_wgrad_gemm(nhwc(x).to(D, dtype), dy.to(D, dtype), dwg)
     close("conv3x3 wgrad (GEMM path)", dwg, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)

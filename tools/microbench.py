@@ -84,6 +84,9 @@ def wgrad():
         dw = torch.zeros(Co, Ci, 3, 3, device=D)
         us = timeit(lambda: ops.conv3x3_wgrad(xp, dyp, dw, B, H, W, Ci, Co), iters=10)
         fl = 2 * 9 * Ci * Co * B * H * W
+        dbb = torch.zeros(Co, device=D)
+        us_n = timeit(lambda: ops.conv3x3_wgrad_nhwc(x, dy, dw, dbb), iters=10)
+        print("  wgrad-NHWC %s %8.1f us  %7.1f TF/s" % ((B, H, W, Ci, Co), us_n, 2 * 9 * Ci * Co * B * H * W / us_n / 1e6))
         us_g = timeit(lambda: ops.conv3x3_wgrad_gemm(x, dy, dw), iters=10)
         us_p3 = timeit(lambda: ops.nhwc_to_planar(x, "wg_x", shifted3=True), iters=10)
         print("  wgrad-gemm path total %8.1f us (%6.1f TF/s incl. layout)   planar3(x) %7.1f us" % (us_g, fl / us_g / 1e6, us_p3))

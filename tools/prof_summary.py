@@ -1,0 +1,18 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd database (kernel trace) into a per-kernel table:  python tools/prof_summary.py <db> [steps] [title]"""
+import re
+import sqlite3
+import sys
+
+db, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 1
+title = sys.argv[3] if len(sys.argv) > 3 else ""
+c = sqlite3.connect(db)
+rows = c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
+tot = sum(r[2] for r in rows)
+if title:
+    print("# " + title)
+print("# total kernel time %.1f ms over %d steps = %.2f ms/step" % (tot, steps, tot / steps))
+print("%10s %6s %8s %7s %11s  %s" % ("total_ms", "pct", "ms/step", "calls", "avg_us", "kernel"))
+for n, cnt, ms, avg in rows:
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    print("%10.3f %5.1f%% %8.3f %7d %11.1f  %s" % (ms, 100 * ms / tot, ms / steps, cnt, avg, n[:140]))
