@@ -18,33 +18,35 @@ from . import ops
 from . import params as P
 
 
-def _wgrad(dy_t, x_t, wparam):
-    """dW (N,K) += dy_t (N, Mp) . x_t (K, Mp)^T over the (zero padded) reduction axis Mp."""
-    g = P.grad_of(wparam).view(wparam.shape[0], -1)
+def _wgrad_bias(dy2d, x2d, wparam, bparam):
+    """dW (N,K) += dy^T x and db (N) += column sums of dy, both accumulated in place into the fp32 gradient buffers.
+    Fast path: transpose-free TN kernel (natural layouts, bias gradient fused).  Fallback (rows not a multiple of the
+    kernel's stage, odd strides): explicit zero padded transposes + the NT kernel."""
+    N, K = wparam.shape[0], wparam.numel() // wparam.shape[0]
+    g = P.grad_of(wparam).view(N, K)
+    gb = P.grad_of(bparam) if bparam is not None else None
+    if ops.gemm_tn_supported(dy2d, x2d):
+        ops.gemm_tn(dy2d, x2d, g, colsum_acc=gb, N=N, K=K)
+        return
+    dy_t = ops.transpose_padded(dy2d[:, :N], gb)
+    x_t = ops.transpose_padded(x2d[:, :K])
     ops.gemm_nt(dy_t, x_t, out=g, accumulate=True, splits=0)      # 0 = let the library choose split-K
 
 
 def _as_compute(dy2d):
-    """(M,N) gradient in any float dtype -> (dy (M,Np) zero padded, dy^T (N,Mp) zero padded) in the compute dtype."""
+    """(M,N) gradient in any float dtype -> (M,Np) zero padded copy in the compute dtype (contiguous rows)."""
     cd = ops.compute_dtype()
     if dy2d.dtype == torch.float32 and cd != torch.float32:
-        return ops.cast_and_transpose(dy2d, cd)
+        return ops.cast_and_transpose(dy2d, cd, want_t=False)[0]
     if dy2d.dtype != cd:
         dy2d = dy2d.to(cd)
-    N = dy2d.shape[1]
-    if not dy2d.is_contiguous() or N % 8 != 0:
-        pad = torch.zeros((dy2d.shape[0], ops._pad8(N)), device=dy2d.device, dtype=cd)
-        pad[:, :N].copy_(dy2d)
-        dy_c = pad
-    else:
-        dy_c = dy2d
-    return dy_c, ops.transpose_padded(dy_c[:, :N])
+    return _pad_cols(dy2d)
 
 
 def _pad_cols(x2d):
-    """(M,K) contiguous -> itself if K % 8 == 0 else zero padded copy (M, pad8(K))."""
+    """(M,K) -> itself if rows are contiguous and K is already padded, else a zero padded copy (M, pad(K))."""
     K = x2d.shape[1]
-    if K % 8 == 0 and x2d.is_contiguous():
+    if K == ops._pad8(K) and x2d.is_contiguous():
         return x2d
     out = torch.zeros((x2d.shape[0], ops._pad8(K)), device=x2d.device, dtype=x2d.dtype)
     out[:, :K].copy_(x2d)
@@ -57,20 +59,14 @@ def _linear_fwd(x2d, wparam, bparam, relu=False, out_dtype=None):
     return ops.gemm_nt(xp, W, bias=bparam.data if bparam is not None else None, relu=relu, out_dtype=out_dtype)
 
 
-def _linear_bwd(dy_c, dy_t, x_t, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
-    """dy_c (M,Np), dy_t (N,Mp), x_t (K,Mp) (all zero padded).  The bias gradient has already been accumulated by the
-    transpose that produced dy_t (_t(dy, bias)).  Returns dx (M,K) or None."""
-    _wgrad(dy_t, x_t, wparam)
+def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
+    """dy2d (M,N[p]) and x2d (M,K) in the compute dtype.  Accumulates dW / db, returns dx = dy W (M,K) or None."""
+    _wgrad_bias(dy2d, x2d, wparam, bparam)
     dx = None
     if need_dx:
         _, Wt = P.linear_shadow(wparam)
-        dx = ops.gemm_nt(dy_c, Wt, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
+        dx = ops.gemm_nt(_pad_cols(dy2d), Wt, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
     return dx
-
-
-def _t(x2d, bias_param=None):
-    """Zero padded transpose; with bias_param also accumulates the column sums (= bias gradient) into its .grad."""
-    return ops.transpose_padded(x2d, P.grad_of(bias_param) if bias_param is not None else None)
 
 
 # ================================================================================================ plain linear
@@ -91,11 +87,8 @@ class LinearFn(Function):
     @staticmethod
     def backward(ctx, dy):
         N = ctx.weight.shape[0]
-        dy_c, dy_t = _as_compute(dy.reshape(-1, N))
-        if ctx.bias is not None:
-            ops.colsum_acc(dy_c[:, :N], P.grad_of(ctx.bias))
-        x_t = _t(ctx.x2)
-        dx = _linear_bwd(dy_c, dy_t, x_t, ctx.weight, ctx.bias, need_dx=ctx.need_dx)
+        dy_c = _as_compute(dy.reshape(-1, N))
+        dx = _linear_bwd(dy_c, ctx.x2, ctx.weight, ctx.bias, need_dx=ctx.need_dx)
         if ctx.mark_ready:
             P.grad_ready(*[p for p in (ctx.weight, ctx.bias) if p is not None])
         if dx is not None:
@@ -150,23 +143,20 @@ class MHAFn(Function):
         d_res, d_y = ops.add_ln_bwd(dout2, Z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
                                     P.grad_of(beta), p=cfg["p"], seed=seed_o)
         # output projection
-        dy_c = _pad_cols(d_y)
-        dO = _linear_bwd(dy_c, _t(d_y, bo), _t(O.view(B * Tq, H * dk)), Wo, bo)
+        dO = _linear_bwd(d_y, O.view(B * Tq, H * dk), Wo, bo)
         dQ, dK, dV = ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, H * dk), lse, H, dk, key_len=cfg.get("key_len"),
                                   key_pad=cfg.get("key_pad"), causal=cfg.get("causal", False), scale=ctx.scale,
                                   p=cfg["p"], seed=seed_a)
         dQ2, dK2, dV2 = dQ.view(B * Tq, H * dk), dK.view(B * Tk, H * dk), dV.view(B * Tk, H * dk)
-        q_t = _t(q2)
-        kv_t = q_t if ctx.self_attn else _t(kv2)
         # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulate straight into d_res
-        _linear_bwd(_pad_cols(dQ2), _t(dQ2, bq), q_t, Wq, bq, dx_out=d_res, accumulate=True)
+        _linear_bwd(dQ2, q2, Wq, bq, dx_out=d_res, accumulate=True)
         d_kv = None
         if ctx.self_attn:
-            _linear_bwd(_pad_cols(dK2), _t(dK2, bk), kv_t, Wk, bk, dx_out=d_res, accumulate=True)
-            _linear_bwd(_pad_cols(dV2), _t(dV2, bv), kv_t, Wv, bv, dx_out=d_res, accumulate=True)
+            _linear_bwd(dK2, q2, Wk, bk, dx_out=d_res, accumulate=True)
+            _linear_bwd(dV2, q2, Wv, bv, dx_out=d_res, accumulate=True)
         else:
-            d_kv = _linear_bwd(_pad_cols(dK2), _t(dK2, bk), kv_t, Wk, bk, need_dx=ctx.need_dkv)
-            _linear_bwd(_pad_cols(dV2), _t(dV2, bv), kv_t, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
+            d_kv = _linear_bwd(dK2, kv2, Wk, bk, need_dx=ctx.need_dkv)
+            _linear_bwd(dV2, kv2, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
             if d_kv is not None:
                 d_kv = d_kv.view(B, Tk, D)
         P.grad_ready(*ctx.params)
@@ -198,8 +188,8 @@ class FFNFn(Function):
         d_res, d_y = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
                                     P.grad_of(beta), p=cfg["p"], seed=ctx.seed)
         # dh = (d_y . W2) * (h > 0)   -- ReLU mask fused into the dgrad epilogue
-        dh = _linear_bwd(_pad_cols(d_y), _t(d_y, b2), _t(h), W2, b2, relu_mask=h)
-        _linear_bwd(_pad_cols(dh), _t(dh, b1), _t(x2), W1, b1, dx_out=d_res, accumulate=True)
+        dh = _linear_bwd(d_y, h, W2, b2, relu_mask=h)
+        _linear_bwd(dh, x2, W1, b1, dx_out=d_res, accumulate=True)
         P.grad_ready(*ctx.params)
         return (d_res.view(B, T, D),) + (None,) * 7
 
@@ -230,7 +220,7 @@ class EncInFn(Function):
         Win, bin_, gamma, beta = ctx.params
         dout2 = dout.reshape(B * T, -1).contiguous()
         dz, _ = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, None, P.grad_of(gamma), P.grad_of(beta))
-        dx = _linear_bwd(_pad_cols(dz), _t(dz, bin_), _t(x2), Win, bin_, need_dx=ctx.need_dx)
+        dx = _linear_bwd(dz, x2, Win, bin_, need_dx=ctx.need_dx)
         P.grad_ready(*ctx.params)
         if dx is not None:
             dx = dx.view(B, T, Din).to(ctx.in_dtype)

@@ -68,6 +68,24 @@ def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, 
     return out
 
 
+def gemm_tn_supported(dy, x):
+    """True when the transpose-free weight-gradient kernel applies to dy (M,N) / x (M,K)."""
+    rm = 64 if dy.dtype == torch.float32 else 128
+    epc = 4 if dy.dtype == torch.float32 else 8
+    return (dy.shape[0] % rm == 0 and dy.shape[0] > 0 and dy.stride(1) == 1 and x.stride(1) == 1 and
+            dy.stride(0) % epc == 0 and x.stride(0) % epc == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0):
+    """dw (N,K) fp32 += dy[:, :N]^T @ x[:, :K]; colsum_acc (N) += column sums of dy.  dy, x row-major (M, ld)."""
+    M = dy.shape[0]
+    N = dy.shape[1] if N is None else N
+    K = x.shape[1] if K is None else K
+    assert dw.dtype == torch.float32 and dw.stride(1) == 1 and dy.dtype == x.dtype
+    L.call("asr_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(dw), dw.stride(0), L.ptr(colsum_acc), M, N, K,
+           int(splits), L.dt(dy), L.stream())
+
+
 def transpose_padded(x, colsum_acc=None):
     """(rows, cols) -> (cols, pad8(rows)) with zero pad columns (so a contraction may run over the padded axis).
     colsum_acc (fp32, cols): optionally accumulate the column sums of x (bias gradient) in the same pass."""

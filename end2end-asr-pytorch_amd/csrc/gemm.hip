@@ -329,6 +329,175 @@ int dispatch_fast(const GemmArgs& a, int splits, hipStream_t s) {
   return launch_fast<T, TO, 64, 64>(a, splits, s);
 }
 
+
+// ================================================================================================ TN (weight gradient)
+// C[N,K] += sum_m A[m,n] * B[m,k]  (+ colsum[n] += sum_m A[m,n])  with A = dY (M,N) and B = X (M,K) in their NATURAL
+// row-major layouts: the contraction index m is the slow axis of both, so the MFMA operands (8 consecutive m per lane)
+// are built with the transposing LDS read ds_read_b64_tr_b16 (bf16) / one 4-byte read per element (fp32) -- no
+// transposed copies of the activations are ever written (reference: autograd of every nn.Linear / Conv1d(k=1) weight).
+// Workgroup: 64x64 tile of C; a stage holds RM = 4 macro steps of m; wave w contracts macro step w of every stage against
+// the full 64x64 tile (16 operand reads feed 16 MFMAs), the four partial tiles are summed through LDS at the end.
+struct TnArgs {
+  const void* A; const void* B; float* C; float* colsum;
+  int64_t lda, ldb, ldc;
+  int M, N, K, m_per_split, tiles_k, ntiles;
+};
+
+template <typename T> struct TnPack;
+template <> struct TnPack<bf16_t> {
+  static constexpr int RM = 128, ROWB = 128, CPR = 8;
+  // 8 consecutive rows m = m0 + 8g .. +7 of column c0 + lr  (m0 = first row of this wave's macro step)
+  static __device__ __forceinline__ uint4 load(const unsigned char* tile, int m0, int lr, int g, int c0) {
+    const int row = m0 + 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);          // this lane SUPPLIES 4 columns of one row
+    const int chunk = col >> 3, half = (col >> 2) & 1;
+    uint2 lo, hi;
+    const uint32_t a0 = (uint32_t)(uintptr_t)(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
+    const uint32_t a1 = (uint32_t)(uintptr_t)(tile + (row + 4) * ROWB + ((chunk ^ ((row + 4) & 7)) << 4) + half * 8);
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  }
+};
+template <> struct TnPack<float> {
+  static constexpr int RM = 64, ROWB = 256, CPR = 16;
+  static __device__ __forceinline__ uint4 load(const unsigned char* tile, int m0, int lr, int g, int c0) {
+    const int col = c0 + lr, chunk = col >> 2, sub = (col & 3) * 4;
+    uint4 r;
+    uint32_t* rr = &r.x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int row = m0 + 4 * s + g;
+      rr[s] = *reinterpret_cast<const uint32_t*>(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + sub);
+    }
+    return r;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
+  using P = TnPack<T>;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int STAGE = 2 * P::RM * P::ROWB;            // A tile + B tile
+  constexpr int MS_ROWS = P::RM / 4;                    // rows of one macro step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int split = wid / p.ntiles, tile = wid % p.ntiles;
+  const int n0 = (tile / p.tiles_k) * 64, k0 = (tile % p.tiles_k) * 64;
+  const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+  const int nstage = (m_end - m_beg) / P::RM;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  // column chunk (16 B) this tile may read: clamp to the operand's last whole chunk (columns past N / K are never stored)
+  const int a_chunks = (int)(p.lda * ESZ / 16), b_chunks = (int)(p.ldb * ESZ / 16);
+
+  auto stage = [&](int st, int buf) __attribute__((always_inline)) {
+    unsigned char* s = smem + buf * STAGE;
+    const int64_t mrow = m_beg + (int64_t)st * P::RM;
+#pragma unroll
+    for (int i = 0; i < P::RM * P::CPR / 256; ++i) {
+      const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
+      int ca = n0 * ESZ / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;
+      int cb = k0 * ESZ / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+      const unsigned char* sa = A + (mrow + row) * p.lda * ESZ + (int64_t)ca * 16;
+      const unsigned char* sb = B + (mrow + row) * p.ldb * ESZ + (int64_t)cb * 16;
+      unsigned char* d = s + (i * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(d + P::RM * P::ROWB), 16, 0, 0);
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = p.colsum != nullptr && k0 == 0;
+
+  if (nstage > 0) stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int st = 0; st < nstage; ++st) {
+    if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
+    const unsigned char* sA = smem + (st & 1) * STAGE;
+    const unsigned char* sB = sA + P::RM * P::ROWB;
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = P::load(sA, wave * MS_ROWS, lr, g, i * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = P::load(sB, wave * MS_ROWS, lr, g, j * 16);
+    if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Chunk<T> c; c.v = a[i];
+#pragma unroll
+        for (int e = 0; e < DT<T>::EPC; ++e) bsum[i] += DT<T>::from(c.e[e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- sum the four waves' partial tiles through LDS, then row-contiguous fp32 accumulation into C
+  constexpr int CP = 64 * 4 + 16;
+  float* part = reinterpret_cast<float*>(smem + wave * 64 * CP);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(part) + (i * 16 + g * 4 + r) * CP + (j * 16 + lr) * 4) = acc[i][j][r];
+  float (*s_col)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * CP);     // (all LDS in the one dynamic array)
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) s_col[wave][i * 16 + lr] = v;
+    }
+  }
+  __syncthreads();
+  const bool single = gridDim.x == (unsigned)p.ntiles;       // no split over m: plain read-modify-write
+  for (int c = tid; c < 64 * 16; c += 256) {
+    const int row = c >> 4, col = (c & 15) * 4;
+    const int gn = n0 + row, gk = k0 + col;
+    if (gn >= p.N || gk >= p.K) continue;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float4 t = *reinterpret_cast<const float4*>(smem + w * 64 * CP + row * CP + col * 4);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    float* dst = p.C + (int64_t)gn * p.ldc + gk;
+    const int nv = min(4, p.K - gk);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (single && nv == 4 && ((((uintptr_t)dst) & 15) == 0)) {
+      float4 o = *reinterpret_cast<float4*>(dst);
+      o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+      *reinterpret_cast<float4*>(dst) = o;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nv) { if (single) dst[e] += vv[e]; else atomicAdd(dst + e, vv[e]); }
+    }
+  }
+  if (do_colsum && tid < 64 && n0 + tid < p.N)
+    atomicAdd(p.colsum + n0 + tid, s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid]);
+}
+
 template <typename T, typename TO, int BM, int BN>
 int launch(const GemmArgs& a, int splits, hipStream_t s) {
   GemmArgs p = a;
@@ -406,4 +575,47 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   if (in_dtype == ASR_F32) return dispatch_tile<float, float>(p, splits, stream);
   if (out_dtype == ASR_BF16) return dispatch_tile<bf16_t, bf16_t>(p, splits, stream);
   return dispatch_tile<bf16_t, float>(p, splits, stream);
+}
+
+extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc,
+                           int M, int N, int K, int splits, int dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (N == 0 || K == 0 || M == 0) return ASR_OK;
+  const int esz = dtype == ASR_F32 ? 4 : 2, epc = 16 / esz;
+  const int rm = dtype == ASR_F32 ? 64 : 128;
+  // whole stages of m only (rows cannot be zero-filled by the LDS-DMA), 16-byte aligned rows
+  if (M % rm != 0 || lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K)
+    return ASR_EUNSUPPORTED;
+  TnArgs p{};
+  p.A = A; p.B = B; p.C = C; p.colsum = colsum_acc;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K;
+  const int tiles_n = (N + 63) / 64;
+  p.tiles_k = (K + 63) / 64;
+  p.ntiles = tiles_n * p.tiles_k;
+  const int stages = M / rm;
+  if (splits <= 0) {                                  // auto: fill ~256-512 workgroups, atomics are the price
+    splits = (160 + p.ntiles - 1) / p.ntiles;        // measured optimum: ~128-256 workgroups, at most 4 slices
+    if (splits > 4) splits = 4;
+  }
+  if (splits > stages) splits = stages;
+  if (splits < 1) splits = 1;
+  const int sps = (stages + splits - 1) / splits;
+  splits = (stages + sps - 1) / sps;
+  p.m_per_split = sps * rm;
+  const size_t lds_stage = (size_t)2 * 2 * rm * (64 * esz);
+  const size_t lds_epi = (size_t)4 * 64 * (64 * 4 + 16) + 4 * 64 * sizeof(float);
+  const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+  AsrProfScope prof(ASR_OP_GEMM, stream);
+  static bool granted[2] = {false, false};
+  if (dtype == ASR_F32) {
+    if (!granted[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted[0] = true; }
+    hipLaunchKernelGGL((gemm_tn_kernel<float>), dim3((unsigned)(p.ntiles * splits)), dim3(256), lds, stream, p);
+  } else {
+    if (!granted[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted[1] = true; }
+    hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), dim3((unsigned)(p.ntiles * splits)), dim3(256), lds, stream, p);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
 }

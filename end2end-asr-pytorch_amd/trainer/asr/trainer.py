@@ -1,0 +1,131 @@
+"""Training / validation loop with the reference's Trainer().train(...) signature (reference: trainer/asr/trainer.py).
+
+Differences that keep the semantics: token ids reach the host in ONE copy per step (the reference calls int() on every
+element of two (B,T) device tensors, trainer.py:62-75); the loss value is read once; under data parallelism the loss is
+local_sum / global token count with summed gradients (= the reference's loss over the gathered batch) and the decision
+to skip a batch with an infinite loss is taken collectively so that ranks never diverge.
+"""
+import logging
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+from tqdm import tqdm
+
+from utils import constant
+from utils.functions import save_model
+from utils.metrics import calculate_cer, calculate_metrics, calculate_wer
+
+
+def _strings(id_rows, id2label):
+    out = []
+    for row in id_rows:
+        s = []
+        for x in row:
+            if x == constant.PAD_TOKEN:
+                break
+            s.append(id2label[x])
+        out.append("".join(s))
+    return out
+
+
+def _strip(s):
+    return s.replace(constant.SOS_CHAR, '').replace(constant.EOS_CHAR, '')
+
+
+class Trainer():
+    def __init__(self):
+        logging.info("Trainer is initialized")
+
+    def _run_batch(self, model, data, smoothing, loss_type, id2label, opt=None):
+        src, tgt, src_percentages, src_lengths, tgt_lengths = data
+        if constant.USE_CUDA:
+            src, tgt = src.cuda(non_blocking=True), tgt.cuda(non_blocking=True)
+        if opt is not None:
+            opt.zero_grad()
+        pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)
+        loss, sums = calculate_metrics(pred, gold, smoothing=smoothing, loss_type=loss_type, sync=False)
+        finite = torch.isfinite(loss.detach()).float()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(finite, op=dist.ReduceOp.MIN)        # skip on every rank or on none
+        if finite.item() == 0:
+            logging.info("Found infinity loss, masking")
+            return None
+        if opt is not None:
+            loss.backward()
+            if constant.args.clip:
+                opt.optimizer.clip_grad_norm_(constant.args.max_norm)
+            opt.step()
+        ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()   # one D2H copy
+        strs_gold, strs_hyps = _strings(ids[0], id2label), _strings(ids[1], id2label)
+        cer = wer = chars = words = 0
+        for g, h in zip(strs_gold, strs_hyps):
+            g, h = _strip(g), _strip(h)
+            cer += calculate_cer(h.replace(' ', ''), g.replace(' ', ''))
+            wer += calculate_wer(h, g)
+            chars += len(g.replace(' ', ''))
+            words += len(g.split(" "))
+        return loss.item(), cer, wer, chars, words
+
+    def train(self, model, train_loader, train_sampler, valid_loader_list, opt, loss_type, start_epoch, num_epochs, label2id,
+              id2label, last_metrics=None):
+        history = []
+        best_valid_loss = 1000000000 if last_metrics is None else last_metrics['valid_loss']
+        smoothing = constant.args.label_smoothing
+        logging.info("name " + constant.args.name)
+        rank0 = not dist.is_initialized() or dist.get_rank() == 0
+        for epoch in range(start_epoch, num_epochs):
+            sys.stdout.flush()
+            total_loss = total_cer = total_wer = total_char = total_word = 0
+            n_batches = frames = 0
+            t0 = time.time()
+            logging.info("TRAIN")
+            model.train()
+            pbar = tqdm(iter(train_loader), leave=True, total=len(train_loader), disable=not rank0)
+            for i, data in enumerate(pbar):
+                r = self._run_batch(model, data, smoothing, loss_type, id2label, opt)
+                if r is None:
+                    continue
+                loss, cer, wer, chars, words = r
+                total_loss += loss; total_cer += cer; total_wer += wer; total_char += chars; total_word += words
+                n_batches += 1
+                frames += int(data[3].sum())
+                pbar.set_description("(Epoch {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} {:.0f} frames/s".format(
+                    epoch + 1, total_loss / (i + 1), total_cer * 100 / max(1, total_char), opt._rate, frames / (time.time() - t0)))
+            logging.info("(Epoch {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f}".format(
+                epoch + 1, total_loss / max(1, len(train_loader)), total_cer * 100 / max(1, total_char), opt._rate))
+
+            logging.info("VALID")
+            model.eval()
+            total_valid_loss = total_valid_cer = total_valid_wer = 0
+            n_valid = 1
+            for ind, valid_loader in enumerate(valid_loader_list):
+                total_valid_loss = total_valid_cer = total_valid_wer = total_valid_char = total_valid_word = 0
+                n_valid = max(1, len(valid_loader))
+                vbar = tqdm(iter(valid_loader), leave=True, total=len(valid_loader), disable=not rank0)
+                for i, data in enumerate(vbar):
+                    with torch.no_grad():
+                        r = self._run_batch(model, data, smoothing, loss_type, id2label, None)
+                    if r is None:
+                        continue
+                    loss, cer, wer, chars, words = r
+                    total_valid_loss += loss; total_valid_cer += cer; total_valid_wer += wer
+                    total_valid_char += chars; total_valid_word += words
+                    vbar.set_description("VALID SET {} LOSS:{:.4f} CER:{:.2f}%".format(
+                        ind, total_valid_loss / (i + 1), total_valid_cer * 100 / max(1, total_valid_char)))
+                logging.info("VALID SET {} LOSS:{:.4f} CER:{:.2f}%".format(
+                    ind, total_valid_loss / n_valid, total_valid_cer * 100 / max(1, total_valid_char)))
+
+            metrics = {"train_loss": total_loss / max(1, len(train_loader)), "valid_loss": total_valid_loss / n_valid,
+                       "train_cer": total_cer, "train_wer": total_wer, "valid_cer": total_valid_cer,
+                       "valid_wer": total_valid_wer, "history": history}
+            history.append(metrics)
+            if epoch % constant.args.save_every == 0:
+                save_model(model, epoch + 1, opt, metrics, label2id, id2label, best_model=False)
+            if best_valid_loss > total_valid_loss / n_valid:
+                best_valid_loss = total_valid_loss / n_valid
+                save_model(model, epoch + 1, opt, metrics, label2id, id2label, best_model=True)
+            if constant.args.shuffle:
+                logging.info("SHUFFLE")
+                train_sampler.shuffle(epoch)

@@ -1,0 +1,119 @@
+"""Manifest / label-file loader contract of the reference (reference: utils/data_loader.py):
+  * manifest: one "wav_path,transcript_path" per line (data_loader.py:112-119);
+  * transcripts: SOS + lower-cased text + EOS mapped through label2id, unknown characters AND id 0 dropped (:133-141);
+  * batch = (inputs f32 (B,1,F,Tmax) zero padded and sorted by length descending, targets i64 (B,Lmax) zero padded,
+             input_percentages f32 (B), input_sizes i32 (B), target_sizes i32 (B))   (:182-214).
+BucketingSampler keeps the reference's consecutive bins and additionally shards them over data-parallel ranks.
+"""
+import random
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+from torch.utils.data.sampler import Sampler
+
+from asr_hip.ddp import rank_shard
+from utils import constant
+from utils.audio import load_audio, log_spectrogram
+
+
+class SpectrogramParser(object):
+    def __init__(self, audio_conf, normalize=False, augment=False):
+        self.window_stride = audio_conf['window_stride']
+        self.window_size = audio_conf['window_size']
+        self.sample_rate = audio_conf['sample_rate']
+        if audio_conf.get('window', 'hamming') != 'hamming':
+            raise NotImplementedError("only the hamming window (the reference default) is implemented")
+        if augment or audio_conf.get('noise_dir') is not None:
+            raise NotImplementedError("sox tempo/gain augmentation and noise injection are outside the accelerated path")
+        self.normalize = normalize
+
+    def parse_audio(self, audio_path):
+        y = load_audio(audio_path)
+        return torch.from_numpy(log_spectrogram(y, self.sample_rate, self.window_size, self.window_stride, self.normalize))
+
+
+class SpectrogramDataset(Dataset, SpectrogramParser):
+    def __init__(self, audio_conf, manifest_filepath_list, label2id, normalize=False, augment=False):
+        self.ids_list = []
+        self.max_size = 0
+        for path in manifest_filepath_list:
+            with open(path) as f:
+                ids = [ln.strip().split(',') for ln in f if ln.strip()]
+            self.ids_list.append(ids)
+            self.max_size = max(self.max_size, len(ids))
+        self.manifest_filepath_list = manifest_filepath_list
+        self.label2id = label2id
+        SpectrogramParser.__init__(self, audio_conf, normalize, augment)
+
+    def __getitem__(self, index):
+        ids = self.ids_list[random.randint(0, len(self.ids_list) - 1)]      # one manifest at random, as the reference
+        audio_path, transcript_path = ids[index % len(ids)][:2]
+        spect = self.parse_audio(audio_path)[:, :constant.args.src_max_len]
+        return spect, self.parse_transcript(transcript_path)
+
+    def parse_transcript(self, transcript_path):
+        with open(transcript_path, 'r', encoding='utf8') as f:
+            text = constant.SOS_CHAR + f.read().replace('\n', '').lower() + constant.EOS_CHAR
+        return [i for i in (self.label2id.get(c) for c in text) if i]      # filter(None, ...): drops unknowns and id 0
+
+    def __len__(self):
+        return self.max_size
+
+
+def _collate_fn(batch):
+    batch = sorted(batch, key=lambda s: s[0].size(1), reverse=True)
+    B = len(batch)
+    t_max = batch[0][0].size(1)
+    f_bins = batch[0][0].size(0)
+    l_max = max(len(s[1]) for s in batch)
+    inputs = torch.zeros(B, 1, f_bins, t_max)
+    targets = torch.zeros(B, l_max, dtype=torch.int64)
+    input_sizes = torch.zeros(B, dtype=torch.int32)
+    target_sizes = torch.zeros(B, dtype=torch.int32)
+    input_percentages = torch.zeros(B, dtype=torch.float32)
+    for i, (spec, tgt) in enumerate(batch):
+        t = spec.size(1)
+        inputs[i, 0, :, :t] = spec
+        input_sizes[i] = t
+        input_percentages[i] = t / float(t_max)
+        target_sizes[i] = len(tgt)
+        targets[i, :len(tgt)] = torch.tensor(tgt, dtype=torch.int64)
+    return inputs, targets, input_percentages, input_sizes, target_sizes
+
+
+class AudioDataLoader(DataLoader):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.collate_fn = _collate_fn
+
+
+class BucketingSampler(Sampler):
+    """Consecutive bins of `batch_size` indices (data is assumed sorted by length), shuffled inside a bin at iteration
+    time and across bins by shuffle().  With rank/world given (or torch.distributed initialised) every rank iterates a
+    disjoint, equally sized subset of the bins."""
+
+    def __init__(self, data_source, batch_size=1, rank=None, world_size=None):
+        self.data_source = data_source
+        ids = list(range(len(data_source)))
+        self.all_bins = [ids[i:i + batch_size] for i in range(0, len(ids), batch_size)]
+        if rank is None and torch.distributed.is_available() and torch.distributed.is_initialized():
+            rank, world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
+        self.rank, self.world = (rank or 0), (world_size or 1)
+        self._shard()
+
+    def _shard(self):
+        self.bins = rank_shard(self.all_bins, self.rank, self.world) if self.world > 1 else self.all_bins
+
+    def __iter__(self):
+        for ids in self.bins:
+            np.random.shuffle(ids)
+            yield ids
+
+    def __len__(self):
+        return len(self.bins)
+
+    def shuffle(self, epoch):
+        rng = np.random.RandomState(1000003 * (epoch + 1))       # the same permutation on every rank
+        rng.shuffle(self.all_bins)
+        self._shard()

@@ -54,6 +54,13 @@ int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                 int M, int N, int K, float alpha, int flags, int splits, int in_dtype, int out_dtype,
                 asr_stream_t stream);
 
+/* Weight gradient without transposes: C[N,K] (fp32) += sum_m A[m*lda+n] * B[m*ldb+k]; colsum_acc[n] += sum_m A[m,n]
+ * (bias gradient, optional).  A = dY (M,N), B = X (M,K) row-major as the forward produced them.  Needs M to be a multiple
+ * of 128 (bf16) / 64 (fp32) and 16-byte aligned rows, else ASR_EUNSUPPORTED (callers fall back to asr_transpose +
+ * asr_gemm_nt).  splits <= 0: automatic split over m (fp32 atomics).                                              */
+int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc, int M,
+                int N, int K, int splits, int dtype, asr_stream_t stream);
+
 /* out[c*ld_out + r] = in[r*ld_in + c]   (operand preparation for dgrad / wgrad).  If colsum_acc != NULL also
  * colsum_acc[c] += sum_r in[r,c]  (the bias gradient, from the tile that is in LDS anyway).                    */
 int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, float* colsum_acc,

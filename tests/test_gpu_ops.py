@@ -92,6 +92,30 @@ def test_gemm_splitk_accumulate_and_mask(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(256, 64, 64), (384, 200, 70), (1280, 512, 2048), (128, 35, 161)])
+def test_gemm_tn_weight_gradient(ops, dtype, shape):
+    """dW += dY^T X and db += colsum(dY) straight from the natural layouts (transposing LDS reads)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N)
+    ldy, ldx = (N + 63) // 64 * 64, (K + 7) // 8 * 8
+    dy = torch.zeros(M, ldy); dy[:, :N] = q(torch.randn(M, N, generator=g), dtype)
+    x = torch.zeros(M, ldx); x[:, :K] = q(torch.randn(M, K, generator=g), dtype)
+    dw0 = torch.randn(N, K, generator=g)
+    db0 = torch.randn(N, generator=g)
+    dw, db = dw0.clone().to(dev()), db0.clone().to(dev())
+    dyd, xd = dy.to(dev(), dtype), x.to(dev(), dtype)
+    assert ops.gemm_tn_supported(dyd, xd)
+    ops.gemm_tn(dyd, xd, dw, colsum_acc=db, N=N, K=K)
+    sc = 8 if dtype == torch.float32 else 0.2
+    close("tn dW", dw, dw0 + dy[:, :N].t() @ x[:, :K], torch.float32 if dtype == torch.float32 else dtype, scale=sc)
+    close("tn db", db, db0 + dy[:, :N].sum(0), torch.float32, scale=8)
+    dw1 = dw0.clone().to(dev())
+    ops.gemm_tn(dyd, xd, dw1, N=N, K=K, splits=1)
+    close("tn dW (no split)", dw1, dw0 + dy[:, :N].t() @ x[:, :K], torch.float32 if dtype == torch.float32 else dtype, scale=sc)
+    assert not ops.gemm_tn_supported(dyd[:100], xd[:100])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_cast_colsum(ops, dtype):
     g = torch.Generator().manual_seed(3)
     x = q(torch.randn(203, 77, generator=g), dtype)

@@ -153,3 +153,54 @@ def test_grad_reducer_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=120)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and ("ok %d" % r) in o, o
+
+
+def test_log_spectrogram_matches_reference_convention():
+    """SpectrogramParser.parse_audio (reference: utils/data_loader.py:72-89): n_fft = win = 320, hop 160, SYMMETRIC hamming,
+    centred reflect-padded frames, |STFT| -> log1p -> (x - mean) / unbiased std.  Checked against torch.stft."""
+    import numpy as np
+    from utils.audio import hamming_window, log_spectrogram
+    rng = np.random.RandomState(0)
+    y = (rng.randn(5000) * 0.1).astype(np.float32)
+    win = torch.hamming_window(320, periodic=False)
+    assert np.allclose(hamming_window(320), win.numpy(), atol=1e-6)
+    ref = torch.stft(torch.from_numpy(y), 320, 160, 320, window=win, center=True, pad_mode="reflect", return_complex=True).abs()
+    ref = torch.log1p(ref)
+    got = log_spectrogram(y, normalize=False)
+    assert got.shape == (161, 1 + 5000 // 160) and np.allclose(got, ref.numpy(), atol=2e-4)
+    ref = (ref - ref.mean()) / ref.std()
+    assert np.allclose(log_spectrogram(y, normalize=True), ref.numpy(), atol=5e-4)
+
+
+def test_loader_contract(tmp_path):
+    """manifest 'wav,txt' lines -> (inputs (B,1,161,Tmax) sorted by length desc & zero padded, targets (B,Lmax) i64,
+    percentages, input_sizes i32, target_sizes i32); transcripts get SOS/EOS and lose unknown characters."""
+    import wave
+    import numpy as np
+    from utils import constant
+    from utils.data_loader import AudioDataLoader, BucketingSampler, SpectrogramDataset
+    rng = np.random.RandomState(1)
+    lines = []
+    for i, n in enumerate([8000, 16000, 4000]):
+        w = tmp_path / ("u%d.wav" % i)
+        with wave.open(str(w), "wb") as f:
+            f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+            f.writeframes((rng.randn(n) * 2000).astype("<i2").tobytes())
+        t = tmp_path / ("u%d.txt" % i)
+        t.write_text("Ab c#\n")                           # '#' is not in the label set -> dropped
+        lines.append("%s,%s" % (w, t))
+    man = tmp_path / "m.csv"
+    man.write_text("\n".join(lines))
+    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + list(" abc")
+    l2i = {c: i for i, c in enumerate(chars)}
+    conf = dict(sample_rate=16000, window_size=.02, window_stride=.01, window="hamming", noise_dir=None, noise_prob=0.4,
+                noise_levels=(0.0, 0.5))
+    ds = SpectrogramDataset(conf, [str(man)], l2i, normalize=True)
+    assert ds.parse_transcript(str(tmp_path / "u0.txt")) == [1, 4, 5, 3, 6, 2]
+    loader = AudioDataLoader(ds, num_workers=0, batch_sampler=BucketingSampler(ds, batch_size=3))
+    inputs, targets, pct, in_sizes, tgt_sizes = next(iter(loader))
+    assert inputs.shape == (3, 1, 161, 101) and inputs.dtype == torch.float32
+    assert in_sizes.tolist() == [101, 51, 26] and in_sizes.dtype == torch.int32
+    assert (inputs[1, :, :, 51:] == 0).all() and (inputs[2, :, :, 26:] == 0).all()
+    assert targets.dtype == torch.int64 and targets.shape == (3, 6) and tgt_sizes.tolist() == [6, 6, 6]
+    assert abs(pct[1].item() - 51 / 101) < 1e-6

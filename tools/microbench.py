@@ -43,6 +43,16 @@ def gemm():
             res.append("%s %6.1fus %5.0fTF" % (["128x128", "128x64", "64x64"][int(tile)], us, 2 * M * N * K / us / 1e6))
         os.environ.pop("ASR_GEMM_TILE", None)
         print("  fwd   %5d %5d %5d -> %-8s %s" % (M, N, K, str(od)[6:], " | ".join(res)))
+    print("== wgrad TN (natural layouts, tr reads)  dW(N,K) over M")
+    for N, K, M in [(512, 512, 6400), (2048, 512, 6400), (512, 2048, 6400), (512, 5120, 6400), (4364, 512, 3200), (512, 512, 3200)]:
+        dy = torch.randn(M, (N + 63) // 64 * 64, device=D).bfloat16()
+        x = torch.randn(M, K, device=D).bfloat16()
+        g = torch.zeros(N, K, device=D); gb = torch.zeros(N, device=D)
+        res = []
+        for sp in (1, 2, 4, 8, 0):
+            us = timeit(lambda: ops.gemm_tn(dy, x, g, colsum_acc=gb, N=N, K=K, splits=sp))
+            res.append("s%d %6.1fus %5.0fTF" % (sp, us, 2 * M * N * K / us / 1e6))
+        print("  tn    %5d %5d %5d : %s" % (N, K, M, " | ".join(res)))
     print("== wgrad (split-K, fp32 atomics)  dW(N,K) over M")
     for N, K, M in [(512, 512, 6400), (2048, 512, 6400), (512, 2048, 6400), (512, 5120, 6400), (4364, 512, 3200), (1536, 512, 6400)]:
         dyt = torch.randn(N, M, device=D).bfloat16()
