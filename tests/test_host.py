@@ -179,6 +179,7 @@ def test_loader_contract(tmp_path):
     import numpy as np
     from utils import constant
     from utils.data_loader import AudioDataLoader, BucketingSampler, SpectrogramDataset
+    constant.parse([])                                    # --src-max-len default (4000): no truncation here
     rng = np.random.RandomState(1)
     lines = []
     for i, n in enumerate([8000, 16000, 4000]):
