@@ -54,19 +54,65 @@ def _pad_cols(x2d):
 
 
 def _linear_fwd(x2d, wparam, bparam, relu=False, out_dtype=None):
-    W, _ = P.linear_shadow(wparam)
-    xp = _pad_cols(x2d)
+    W = P.linear_weight(wparam)
+    xp = _pad_cols(x2d) if W.shape[1] != x2d.shape[1] or not x2d.is_contiguous() else x2d
     return ops.gemm_nt(xp, W, bias=bparam.data if bparam is not None else None, relu=relu, out_dtype=out_dtype)
+
+
+def _dgrad(dy2d, wparam, dx_out=None, accumulate=False, relu_mask=None):
+    """dx (M,K) (+)= dy (M,N[p]) @ W (N,K).  Natural-layout weight + transposing LDS reads when the shape allows, else the
+    NT kernel on the padded W^T shadow."""
+    W = P.linear_weight(wparam)
+    if W.shape[1] == wparam.numel() // wparam.shape[0] and ops.gemm_nn_supported(dy2d, W):
+        return ops.gemm_nn(dy2d, W, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
+    _, Wt = P.linear_shadow(wparam)
+    return ops.gemm_nt(_pad_cols(dy2d), Wt, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
 
 
 def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
     """dy2d (M,N[p]) and x2d (M,K) in the compute dtype.  Accumulates dW / db, returns dx = dy W (M,K) or None."""
     _wgrad_bias(dy2d, x2d, wparam, bparam)
-    dx = None
-    if need_dx:
-        _, Wt = P.linear_shadow(wparam)
-        dx = ops.gemm_nt(_pad_cols(dy2d), Wt, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
-    return dx
+    return _dgrad(dy2d, wparam, dx_out, accumulate, relu_mask) if need_dx else None
+
+
+class _Fused:
+    """Several projections that read the same input, run as ONE GEMM because their weights (and biases) are adjacent in
+    the flat parameter buffers (FusedAdam lays Q/K/V out that way).  Duck-types the few things the helpers need."""
+
+    def __init__(self, weights, biases):
+        fw, fb = P.fused(weights), P.fused(biases)
+        self.ok = fw is not None and fb is not None and ops.compute_dtype() in (torch.float32, torch.bfloat16)
+        if not self.ok:
+            return
+        self.N = sum(w.shape[0] for w in weights)
+        self.K = weights[0].shape[1]
+        self.ok = self.K % 8 == 0
+        if not self.ok:
+            return
+        self.w_master, self.w_grad, flat, off = fw
+        self.b_master, self.b_grad = fb[0], fb[1]
+        cd = ops.compute_dtype()
+        if cd == torch.float32:
+            self.W = self.w_master.view(self.N, self.K)
+        else:
+            flat.shadow_view(weights[0], off, cd)                       # make sure the flat shadow is fresh
+            self.W = flat._shadow[cd][0][off:off + self.N * self.K].view(self.N, self.K)
+
+    def fwd(self, x2d):
+        return ops.gemm_nt(x2d, self.W, bias=self.b_master)
+
+    def bwd(self, dy2d, x2d, dx_out=None, accumulate=False, need_dx=True):
+        g = self.w_grad.view(self.N, self.K)
+        if ops.gemm_tn_supported(dy2d, x2d):
+            ops.gemm_tn(dy2d, x2d, g, colsum_acc=self.b_grad, N=self.N, K=self.K)
+        else:
+            ops.gemm_nt(ops.transpose_padded(dy2d, self.b_grad), ops.transpose_padded(x2d), out=g, accumulate=True, splits=0)
+        if not need_dx:
+            return None
+        if ops.gemm_nn_supported(dy2d, self.W):
+            return ops.gemm_nn(dy2d, self.W, out=dx_out, accumulate=accumulate)
+        wt = ops.transpose_padded(self.W)
+        return ops.gemm_nt(_pad_cols(dy2d), wt, out=dx_out, accumulate=accumulate)
 
 
 # ================================================================================================ plain linear
@@ -101,24 +147,34 @@ class MHAFn(Function):
     @staticmethod
     def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta, cfg):
         H, dk = cfg["H"], cfg["dk"]
+        HD = H * dk
         B, Tq, D = q_in.shape
         self_attn = kv_in is None
         kv = q_in if self_attn else kv_in
         Tk = kv.shape[1]
-        q2, kv2 = q_in.reshape(B * Tq, D), kv.reshape(B * Tk, D)
-        Q = _linear_fwd(q2, Wq, bq).view(B, Tq, H * dk)
-        K = _linear_fwd(kv2, Wk, bk).view(B, Tk, H * dk)
-        V = _linear_fwd(kv2, Wv, bv).view(B, Tk, H * dk)
+        q2, kv2 = q_in.reshape(B * Tq, D).contiguous(), kv.reshape(B * Tk, D).contiguous()
+        # one GEMM for Q|K|V (self attention) or K|V (cross attention) when the flat layout allows it
+        fused = _Fused([Wq, Wk, Wv], [bq, bk, bv]) if self_attn else _Fused([Wk, Wv], [bk, bv])
+        if fused.ok and self_attn:
+            qkv = fused.fwd(q2).view(B, Tq, 3 * HD)
+            Q, K, V = qkv[:, :, :HD], qkv[:, :, HD:2 * HD], qkv[:, :, 2 * HD:]
+        elif fused.ok:
+            Q = _linear_fwd(q2, Wq, bq).view(B, Tq, HD)
+            kvp = fused.fwd(kv2).view(B, Tk, 2 * HD)
+            K, V = kvp[:, :, :HD], kvp[:, :, HD:]
+        else:
+            Q = _linear_fwd(q2, Wq, bq).view(B, Tq, HD)
+            K = _linear_fwd(kv2, Wk, bk).view(B, Tk, HD)
+            V = _linear_fwd(kv2, Wv, bv).view(B, Tk, HD)
         p_att = cfg["p"]
         seed_a, seed_o = P.next_seed(), P.next_seed()
         scale = 1.0 / (dk ** 0.5)
         O, lse, attn = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
                                     causal=cfg.get("causal", False), scale=scale, p=p_att, seed=seed_a,
                                     want_attn=cfg.get("want_attn", False))
-        Y = _linear_fwd(O.view(B * Tq, H * dk), Wo, bo)
-        out, mean, rstd = ops.add_ln_fwd(Y, q2.contiguous(), gamma.data, beta.data, row_keep=cfg.get("row_keep"),
-                                         p=p_att, seed=seed_o)
-        ctx.cfg, ctx.self_attn = cfg, self_attn
+        Y = _linear_fwd(O.view(B * Tq, HD), Wo, bo)
+        out, mean, rstd = ops.add_ln_fwd(Y, q2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
+        ctx.cfg, ctx.self_attn, ctx.fused = cfg, self_attn, fused
         ctx.seeds = (seed_a, seed_o)
         ctx.scale = scale
         ctx.t = (q2, kv2, Q, K, V, O, lse, Y, mean, rstd)      # Y now holds z
@@ -133,8 +189,9 @@ class MHAFn(Function):
 
     @staticmethod
     def backward(ctx, dout, *unused):
-        cfg = ctx.cfg
+        cfg, fused = ctx.cfg, ctx.fused
         H, dk = cfg["H"], cfg["dk"]
+        HD = H * dk
         B, Tq, Tk, D = ctx.shape
         q2, kv2, Q, K, V, O, lse, Z, mean, rstd = ctx.t
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta = ctx.params
@@ -142,23 +199,37 @@ class MHAFn(Function):
         dout2 = dout.reshape(B * Tq, D).contiguous()
         d_res, d_y = ops.add_ln_bwd(dout2, Z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
                                     P.grad_of(beta), p=cfg["p"], seed=seed_o)
-        # output projection
-        dO = _linear_bwd(d_y, O.view(B * Tq, H * dk), Wo, bo)
-        dQ, dK, dV = ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, H * dk), lse, H, dk, key_len=cfg.get("key_len"),
-                                  key_pad=cfg.get("key_pad"), causal=cfg.get("causal", False), scale=ctx.scale,
-                                  p=cfg["p"], seed=seed_a)
-        dQ2, dK2, dV2 = dQ.view(B * Tq, H * dk), dK.view(B * Tk, H * dk), dV.view(B * Tk, H * dk)
-        # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulate straight into d_res
-        _linear_bwd(dQ2, q2, Wq, bq, dx_out=d_res, accumulate=True)
-        d_kv = None
-        if ctx.self_attn:
-            _linear_bwd(dK2, q2, Wk, bk, dx_out=d_res, accumulate=True)
-            _linear_bwd(dV2, q2, Wv, bv, dx_out=d_res, accumulate=True)
+        dO = _linear_bwd(d_y, O.view(B * Tq, HD), Wo, bo)
+        # gradient buffers mirror the forward layout so that the fused projections see one contiguous (M, 2|3*HD) operand
+        if fused.ok and ctx.self_attn:
+            dqkv = torch.empty((B, Tq, 3 * HD), device=dout.device, dtype=Q.dtype)
+            dQ, dK, dV = dqkv[:, :, :HD], dqkv[:, :, HD:2 * HD], dqkv[:, :, 2 * HD:]
+        elif fused.ok:
+            dQ = torch.empty((B, Tq, HD), device=dout.device, dtype=Q.dtype)
+            dkv = torch.empty((B, Tk, 2 * HD), device=dout.device, dtype=Q.dtype)
+            dK, dV = dkv[:, :, :HD], dkv[:, :, HD:]
         else:
-            d_kv = _linear_bwd(dK2, kv2, Wk, bk, need_dx=ctx.need_dkv)
-            _linear_bwd(dV2, kv2, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
-            if d_kv is not None:
-                d_kv = d_kv.view(B, Tk, D)
+            dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
+        ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, HD), lse, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
+                     causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV))
+        d_kv = None
+        # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulated straight into d_res
+        if fused.ok and ctx.self_attn:
+            fused.bwd(dqkv.view(B * Tq, 3 * HD), q2, dx_out=d_res, accumulate=True)
+        elif fused.ok:
+            _linear_bwd(dQ.view(B * Tq, HD), q2, Wq, bq, dx_out=d_res, accumulate=True)
+            d_kv = fused.bwd(dkv.view(B * Tk, 2 * HD), kv2, need_dx=ctx.need_dkv)
+        else:
+            dQ2, dK2, dV2 = dQ.view(B * Tq, HD), dK.view(B * Tk, HD), dV.view(B * Tk, HD)
+            _linear_bwd(dQ2, q2, Wq, bq, dx_out=d_res, accumulate=True)
+            if ctx.self_attn:
+                _linear_bwd(dK2, q2, Wk, bk, dx_out=d_res, accumulate=True)
+                _linear_bwd(dV2, q2, Wv, bv, dx_out=d_res, accumulate=True)
+            else:
+                d_kv = _linear_bwd(dK2, kv2, Wk, bk, need_dx=ctx.need_dkv)
+                _linear_bwd(dV2, kv2, Wv, bv, dx_out=d_kv, accumulate=True, need_dx=ctx.need_dkv)
+        if d_kv is not None:
+            d_kv = d_kv.view(B, Tk, D)
         P.grad_ready(*ctx.params)
         return (d_res.view(B, Tq, D), d_kv) + (None,) * 11
 

@@ -86,6 +86,33 @@ def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0):
            int(splits), L.dt(dy), L.stream())
 
 
+def gemm_nn_supported(dy, w):
+    """True when dx = dy (M,N) @ w (N,K) can run on the transpose-free data-gradient kernel."""
+    bkr = 32 if dy.dtype == torch.float32 else 64
+    epc = 4 if dy.dtype == torch.float32 else 8
+    return (dy.dtype == w.dtype and w.shape[0] % bkr == 0 and dy.shape[1] >= w.shape[0] and dy.stride(1) == 1 and
+            w.stride(1) == 1 and dy.stride(0) % epc == 0 and w.stride(0) % epc == 0 and dy.data_ptr() % 16 == 0 and
+            w.data_ptr() % 16 == 0)
+
+
+def gemm_nn(dy, w, out=None, accumulate=False, relu_mask=None, alpha=1.0):
+    """out (M,K) (+)= dy[:, :N] @ w (N,K), w in the weight's natural layout."""
+    M, (N, K) = dy.shape[0], w.shape
+    if out is None:
+        out = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+        assert not accumulate
+    assert out.shape == (M, K) and out.stride(1) == 1
+    if relu_mask is not None:
+        assert relu_mask.dtype == dy.dtype and relu_mask.stride(0) == out.stride(0)
+    L.call("asr_gemm_nn", L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(out), out.stride(0), L.ptr(relu_mask), M, K, N,
+           float(alpha), L.GEMM_ACCUMULATE if accumulate else 0, L.dt(dy), L.dt(out), L.stream())
+    return out
+
+
+def cast_flat(src, dst):
+    L.call("asr_cast_flat", L.ptr(src), L.ptr(dst), src.numel(), L.dt(dst), L.stream())
+
+
 def transpose_padded(x, colsum_acc=None):
     """(rows, cols) -> (cols, pad8(rows)) with zero pad columns (so a contraction may run over the padded axis).
     colsum_acc (fp32, cols): optionally accumulate the column sums of x (bias gradient) in the same pass."""
@@ -190,11 +217,17 @@ def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0,
     return o, lse, attn
 
 
-def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0):
+def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, out=None):
+    """out: optional (dq, dk, dv) destination tensors; they must have the strides of q, k, v (the ABI reuses them)."""
     B, Tq, _ = q.shape
     Tk = k.shape[1]
     assert do.is_contiguous() and o.is_contiguous()
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    if out is None:
+        dq = torch.empty_strided(q.shape, q.stride(), device=q.device, dtype=q.dtype)
+        dk = torch.empty_strided(k.shape, k.stride(), device=k.device, dtype=k.dtype)
+        dv = torch.empty_strided(v.shape, v.stride(), device=v.device, dtype=v.dtype)
+    else:
+        dq, dk, dv = out
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
     delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
     msb, msq = _mask_strides(key_pad, B, Tq, Tk)

@@ -31,6 +31,23 @@ def _key(p, dtype):
     return (p._version, _state["generation"], dtype, p.data_ptr())
 
 
+def linear_weight(p, dtype=None):
+    """Compute-dtype view (N,K) of a linear weight for the NT forward / NN data-gradient kernels.  Parameters that live
+    in a FlatParams buffer share ONE flat shadow refreshed by a single cast launch per optimiser step; fp32 mode reads
+    the master itself.  Falls back to the per-weight padded shadow when K is not a whole number of 16-byte chunks."""
+    dtype = dtype or ops.compute_dtype()
+    N = p.shape[0]
+    K = p.numel() // N
+    if K % 8 == 0:
+        if dtype == torch.float32:
+            return p.data.view(N, K)
+        home = p.__dict__.get("_asr_flat")
+        if home is not None:
+            flat, off = home
+            return flat.shadow_view(p, off, dtype).view(N, K)
+    return linear_shadow(p, dtype)[0]
+
+
 def linear_shadow(p, dtype=None):
     """p: (N,K) or (N,K,1) fp32 master -> (W (N,Kp) , Wt (K,Np)) in compute dtype, zero-padded to multiples of 8."""
     dtype = dtype or ops.compute_dtype()
@@ -66,6 +83,25 @@ def conv_shadow(p, dtype=None):
     return sh["wk"], sh["wd"]
 
 
+def fused(params):
+    """If the given parameters occupy CONSECUTIVE slots of one FlatParams buffer (e.g. the Q, K, V weights of an attention
+    block, which FlatParams lays out back to back), return (master_flat_view, grad_flat_view, flat, offset) over all of
+    them, else None.  Lets several projections run as one GEMM."""
+    homes = [p.__dict__.get("_asr_flat") for p in params]
+    if any(h is None for h in homes) or any(h[0] is not homes[0][0] for h in homes):
+        return None
+    flat, off = homes[0]
+    cur = off
+    for p, (_, o) in zip(params, homes):
+        if o != cur:
+            return None
+        cur = o + p.numel()            # slots are contiguous only if every size is a multiple of the slot alignment
+        if p.numel() % FlatParams.ALIGN != 0 and p is not params[-1]:
+            return None
+    n = cur - off
+    return flat.data[off:off + n], flat.grad[off:off + n], flat, off
+
+
 def grad_of(p):
     """fp32 gradient buffer of a parameter (kernels ACCUMULATE into it; `zero_grad` must zero, not drop, it)."""
     if p.grad is None:
@@ -93,7 +129,7 @@ class FlatParams:
 
     ALIGN = 64
 
-    def __init__(self, module_or_params):
+    def __init__(self, module_or_params, order=None):
         params = []
         seen = set()
         it = module_or_params.parameters() if hasattr(module_or_params, "parameters") else module_or_params
@@ -101,6 +137,9 @@ class FlatParams:
             if id(p) not in seen:
                 seen.add(id(p))
                 params.append(p)
+        if order is not None:           # a permutation of `params` (same objects): controls which weights are adjacent
+            assert len(order) == len(params) and {id(p) for p in order} == seen
+            params = list(order)
         if not params:
             raise ValueError("module has no parameters")
         dev = params[0].device
@@ -120,7 +159,9 @@ class FlatParams:
             if p.grad is not None:
                 self.grad[o:o + n].copy_(p.grad.reshape(-1))
             p.grad = self.grad[o:o + n].view(p.shape)
+            p.__dict__["_asr_flat"] = (self, o)
         self.index = {id(p): i for i, p in enumerate(params)}
+        self._shadow = {}               # dtype -> (tensor, generation, {id(p): version})
 
     def range_of(self, p):
         i = self.index[id(p)]
@@ -135,6 +176,19 @@ class FlatParams:
                 p.data = self.data[o:o + n].view(p.shape)
             if p.grad is None or p.grad.data_ptr() != self.grad[o:o + n].data_ptr():
                 p.grad = self.grad[o:o + n].view(p.shape)
+
+    def shadow_view(self, p, off, dtype):
+        """Slice of the flat compute-dtype shadow holding parameter p; the whole shadow is re-cast (one launch) whenever
+        the optimiser stepped (generation) or p was modified through torch (version counter)."""
+        ent = self._shadow.get(dtype)
+        if ent is None:
+            ent = [torch.empty(self.total, device=self.data.device, dtype=dtype), -1, {}]
+            self._shadow[dtype] = ent
+        if ent[1] != _state["generation"] or ent[2].get(id(p)) != p._version:
+            ops.cast_flat(self.data, ent[0])
+            ent[1] = _state["generation"]
+            ent[2] = {id(q): q._version for q in self.params}
+        return ent[0][off:off + p.numel()]
 
     def zero_grad(self):
         self.grad.zero_()

@@ -204,6 +204,18 @@ __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, c
     p[tail] -= step * (mo / (sqrtf(vo) / bc2_sqrt + eps));
   }
 }
+template <typename T>
+__global__ __launch_bounds__(256) void cast_flat_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i * 4 < n; i += stride) {
+    if (i * 4 + 4 <= n) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i];
+      DT<T>::st(dst + i * 4, v.x); DT<T>::st(dst + i * 4 + 1, v.y); DT<T>::st(dst + i * 4 + 2, v.z); DT<T>::st(dst + i * 4 + 3, v.w);
+    } else {
+      for (int64_t e = i * 4; e < n; ++e) DT<T>::st(dst + e, src[e]);
+    }
+  }
+}
 __global__ void step_advance_kernel(uint64_t* state) { state[0] += 1; state[1] += 1; }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* acc) {
@@ -355,6 +367,19 @@ extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, 
   AsrProfScope prof(ASR_OP_ADAM, s);
   hipLaunchKernelGGL(adam_noam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, n, state, beta1, beta2, eps,
                      factor_ms, warmup, min_lr, gscale, lr_out);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_cast_flat(const float* src, void* dst, int64_t n, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(src && dst && n >= 0 && aligned16(src));
+  if (n == 0) return ASR_OK;
+  int64_t blocks = ceil_div64(n, 1024 * 2);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  if (dtype == ASR_F32) hipLaunchKernelGGL((cast_flat_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, src, (float*)dst, n);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((cast_flat_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, src, (bf16_t*)dst, n);
+  else return ASR_EINVAL;
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

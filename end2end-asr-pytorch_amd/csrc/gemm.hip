@@ -347,6 +347,7 @@ template <typename T> struct TnPack;
 template <> struct TnPack<bf16_t> {
   static constexpr int RM = 128, ROWB = 128, CPR = 8;
   // 8 consecutive rows m = m0 + 8g .. +7 of column c0 + lr  (m0 = first row of this wave's macro step)
+  template <bool GMAJOR = false>
   static __device__ __forceinline__ uint4 load(const unsigned char* tile, int m0, int lr, int g, int c0) {
     const int row = m0 + 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);          // this lane SUPPLIES 4 columns of one row
     const int chunk = col >> 3, half = (col >> 2) & 1;
@@ -360,13 +361,17 @@ template <> struct TnPack<bf16_t> {
 };
 template <> struct TnPack<float> {
   static constexpr int RM = 64, ROWB = 256, CPR = 16;
+  // pack element s feeds the s-th 16x16x4 MFMA, lane group g is its k index.  GMAJOR = false: row = m0 + 4s + g (both
+  // operands come from this loader); GMAJOR = true: row = m0 + 4g + s, the k order of an operand read as one aligned 16-byte
+  // chunk of 4 consecutive k (the A side of the NN kernel) -- the two operands of an MFMA must agree on k.
+  template <bool GMAJOR = false>
   static __device__ __forceinline__ uint4 load(const unsigned char* tile, int m0, int lr, int g, int c0) {
     const int col = c0 + lr, chunk = col >> 2, sub = (col & 3) * 4;
     uint4 r;
     uint32_t* rr = &r.x;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int row = m0 + 4 * s + g;
+      const int row = m0 + (GMAJOR ? 4 * g + s : 4 * s + g);
       rr[s] = *reinterpret_cast<const uint32_t*>(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + sub);
     }
     return r;
@@ -498,6 +503,146 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     atomicAdd(p.colsum + n0 + tid, s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid]);
 }
 
+
+// ================================================================================================ NN (data gradient)
+// C[M,N] (op)= alpha * sum_k A[m,k] * B[k,n]  with B = W (K_red, N_out) in its NATURAL master layout: dX = dY . W needs the
+// contraction index as W's slow axis, so the B operand is built with the transposing LDS read (bf16) / 4-byte reads (fp32)
+// exactly like gemm_tn -- no transposed weight shadows.  A staging, pipeline and epilogue are those of gemm_glds (BN = 64).
+template <typename T, typename TO, int BM>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
+  using P = TnPack<T>;
+  constexpr int ESZ = (int)sizeof(T);
+  constexpr int BN = 64, BKB = 128;
+  constexpr int BKR = BKB / ESZ;                 // reduction rows per stage: 64 (bf16) / 32 (fp32)
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  constexpr int STAGE = BM * BKB + BKR * P::ROWB;
+  constexpr int CPITCH = BN * 4 + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, g = lane >> 4;
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  const int nk = p.K / BKR;
+  const int b_chunks = (int)(p.ldb * ESZ / 16);
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
+    unsigned char* s = smem + buf * STAGE;
+    stage_glds<BM>(s, A, p.lda * ESZ, nullptr, ESZ, m0, p.M, (int64_t)kt * BKB, tid, wave);
+    unsigned char* sb = s + BM * BKB;
+#pragma unroll
+    for (int i = 0; i < BKR * P::CPR / 256; ++i) {
+      const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
+      int cb = n0 * ESZ / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+      const unsigned char* src = B + ((int64_t)kt * BKR + row) * p.ldb * ESZ + (int64_t)cb * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  if (nk > 0) stage(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+    const unsigned char* sA = smem + (kt & 1) * STAGE;
+    const unsigned char* sB = sA + BM * BKB;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      uint4 a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int r = wm * WM + i * 16 + lr;
+        a[i] = *reinterpret_cast<const uint4*>(sA + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = P::template load<true>(sB, ms * (BKR / 2), lr, g, wn * WN + j * 16);
+      if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        *reinterpret_cast<float*>(smem + (wm * WM + i * 16 + g * 4 + r) * CPITCH + (wn * WN + j * 16 + lr) * 4) = acc[i][j][r] * p.alpha;
+  __syncthreads();
+  TO* C = static_cast<TO*>(p.C);
+  const T* Msk = static_cast<const T*>(p.mask);
+  constexpr int CPR = BN / 4;
+  for (int c = tid; c < BM * CPR; c += 256) {
+    const int row = c / CPR, col = (c % CPR) * 4;
+    const int gr = m0 + row, gc = n0 + col;
+    if (gr >= p.M || gc >= p.N) continue;
+    const float4 v4 = *reinterpret_cast<const float4*>(smem + row * CPITCH + col * 4);
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    TO* dst = C + (int64_t)gr * p.ldc + gc;
+    const int nvalid = min(4, p.N - gc);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (e < nvalid && Msk && !(DT<T>::ld(Msk + (int64_t)gr * p.ldc + gc + e) > 0.f)) v[e] = 0.f;
+    if (p.vecC && nvalid == 4) {
+      if constexpr (sizeof(TO) == 4) {
+        float4 o = make_float4(v[0], v[1], v[2], v[3]);
+        if (p.accumulate) { const float4 old = *reinterpret_cast<const float4*>(dst); o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
+        *reinterpret_cast<float4*>(dst) = o;
+      } else {
+        if (p.accumulate) {
+          const uint2 old = *reinterpret_cast<const uint2*>(dst);
+          v[0] += bf16_to_f32((bf16_t)(old.x & 0xffff)); v[1] += bf16_to_f32((bf16_t)(old.x >> 16));
+          v[2] += bf16_to_f32((bf16_t)(old.y & 0xffff)); v[3] += bf16_to_f32((bf16_t)(old.y >> 16));
+        }
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(dst) = o;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (e < nvalid) store_out<TO>(dst + e, v[e], p.accumulate, 0);
+    }
+  }
+}
+
+template <typename T, typename TO, int BM>
+int launch_nn(const GemmArgs& a, hipStream_t s) {
+  GemmArgs p = a;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + 63) / 64;
+  p.ntiles = tiles_m * p.tiles_n;
+  const int esz = (int)sizeof(T);
+  size_t lds = (size_t)2 * (BM * 128 + (128 / esz) * (64 * esz));
+  const size_t cl = (size_t)BM * (64 * 4 + 16);
+  if (cl > lds) lds = cl;
+  static bool granted = false;
+  if (lds > 48 * 1024 && !granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nn_kernel<T, TO, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = true;
+  }
+  hipLaunchKernelGGL((gemm_nn_kernel<T, TO, BM>), dim3((unsigned)p.ntiles), dim3(256), lds, s, p);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 template <typename T, typename TO, int BM, int BN>
 int launch(const GemmArgs& a, int splits, hipStream_t s) {
   GemmArgs p = a;
@@ -618,4 +763,27 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
+}
+
+extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask,
+                           int M, int N, int K, float alpha, int flags, int in_dtype, int out_dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0);
+  ASR_CHECK_ARG(in_dtype == ASR_F32 || in_dtype == ASR_BF16);
+  ASR_CHECK_ARG(out_dtype == in_dtype || (in_dtype == ASR_BF16 && out_dtype == ASR_F32));
+  if (M == 0 || N == 0) return ASR_OK;
+  const int esz = in_dtype == ASR_F32 ? 4 : 2, epc = 16 / esz, bkr = 128 / esz;
+  if (K <= 0 || K % bkr != 0 || lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || ldb < N || lda < K)
+    return ASR_EUNSUPPORTED;
+  GemmArgs p{};
+  p.A = A; p.B = B; p.C = C; p.mask = relu_mask;
+  p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.alpha = alpha;
+  p.accumulate = (flags & ASR_GEMM_ACCUMULATE) != 0;
+  p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0);
+  AsrProfScope prof(ASR_OP_GEMM, stream);
+  const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
+  const bool big = t64 >= 6000 && M > 64;
+  if (in_dtype == ASR_F32) return big ? launch_nn<float, float, 128>(p, stream) : launch_nn<float, float, 64>(p, stream);
+  if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);
+  return big ? launch_nn<bf16_t, float, 128>(p, stream) : launch_nn<bf16_t, float, 64>(p, stream);
 }

@@ -104,6 +104,7 @@ class MultiHeadAttention(nn.Module):
         self.output_linear = nn.Linear(num_heads * dim_value, dim_model)
         nn.init.xavier_normal_(self.output_linear.weight)
         self.dropout = nn.Dropout(dropout)
+        self.query_linear.weight._asr_qkv = True      # hint for the flat-parameter layout: q/k/v weights adjacent
 
     def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
                 need_attn=True):

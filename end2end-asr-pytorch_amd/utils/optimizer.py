@@ -30,7 +30,7 @@ class FusedAdam(torch.optim.Adam):
         if not plist or not plist[0].is_cuda:
             return
         old = {p: dict(self.state[p]) for p in plist if p in self.state and 'exp_avg' in self.state[p]}
-        self.flat = P.FlatParams(plist)
+        self.flat = P.FlatParams(plist, order=self._slot_order(plist))
         self._m = torch.zeros_like(self.flat.data)
         self._v = torch.zeros_like(self.flat.data)
         for p, o in zip(self.flat.params, self.flat.offsets):
@@ -47,6 +47,24 @@ class FusedAdam(torch.optim.Adam):
                 self.reducer = GradReducer(self.flat, bucket_bytes=self.ddp_bucket_bytes)
                 self.reducer.broadcast_parameters(0)
         P.set_reducer(self.reducer)
+
+    @staticmethod
+    def _slot_order(plist):
+        """Registration order, except that inside every attention block the three projection weights (and then their
+        three biases) are made adjacent, so Q/K/V (or K/V) run as ONE GEMM over a contiguous slice of the flat buffers.
+        nn.Module registration order inside MultiHeadAttention is q.w q.b k.w k.b v.w v.b ... (models/common_layers.py)."""
+        out, i = [], 0
+        while i < len(plist):
+            grp = plist[i:i + 6]
+            if (len(grp) == 6 and all(g.dim() == 2 for g in grp[0::2]) and all(g.dim() == 1 for g in grp[1::2]) and
+                    grp[0].shape == grp[2].shape == grp[4].shape and grp[1].shape == grp[3].shape == grp[5].shape and
+                    grp[0].shape[0] == grp[1].shape[0] and getattr(grp[0], "_asr_qkv", False)):
+                out += [grp[0], grp[2], grp[4], grp[1], grp[3], grp[5]]
+                i += 6
+            else:
+                out.append(plist[i])
+                i += 1
+        return out
 
     def _bind_state(self):
         for p, o in zip(self.flat.params, self.flat.offsets):

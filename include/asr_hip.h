@@ -61,6 +61,14 @@ int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
 int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc, int M,
                 int N, int K, int splits, int dtype, asr_stream_t stream);
 
+/* Data gradient without transposed weights: C[M,N] (op)= alpha * sum_k A[m*lda+k] * B[k*ldb+n] with B = W (K,N) in its
+ * master layout (transposing LDS reads).  flags: ASR_GEMM_ACCUMULATE; relu_mask as in asr_gemm_nt.  Needs K to be a
+ * multiple of 64 (bf16) / 32 (fp32) and 16-byte aligned rows, else ASR_EUNSUPPORTED.                              */
+int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask, int M,
+                int N, int K, float alpha, int flags, int in_dtype, int out_dtype, asr_stream_t stream);
+/* dst[i] = (dtype) src[i] : the one-launch refresh of the flat compute-dtype weight shadow after an optimiser step  */
+int asr_cast_flat(const float* src, void* dst, int64_t n, int dtype, asr_stream_t stream);
+
 /* out[c*ld_out + r] = in[r*ld_in + c]   (operand preparation for dgrad / wgrad).  If colsum_acc != NULL also
  * colsum_acc[c] += sum_r in[r,c]  (the bias gradient, from the tile that is in LDS anyway).                    */
 int asr_transpose(const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows, int cols, float* colsum_acc,

@@ -116,6 +116,27 @@ def test_gemm_tn_weight_gradient(ops, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(200, 64, 64), (130, 192, 72), (640, 512, 2048), (96, 1536, 512)])
+def test_gemm_nn_data_gradient(ops, dtype, shape):
+    """dx = dy @ W with W in its natural (N,K) layout; accumulate and ReLU-mask epilogues."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    dy = q(torch.randn(M, N, generator=g), dtype)
+    w = q(torch.randn(N, K, generator=g) / math.sqrt(N), dtype)
+    D = dev()
+    assert ops.gemm_nn_supported(dy.to(D, dtype), w.to(D, dtype))
+    out = ops.gemm_nn(dy.to(D, dtype), w.to(D, dtype))
+    close("nn", out, dy @ w, dtype)
+    base = q(torch.randn(M, K, generator=g), dtype)
+    acc = base.to(D, dtype)
+    ops.gemm_nn(dy.to(D, dtype), w.to(D, dtype), out=acc, accumulate=True)
+    close("nn accumulate", acc, base + dy @ w, dtype)
+    mask = q(torch.randn(M, K, generator=g), dtype)
+    out = ops.gemm_nn(dy.to(D, dtype), w.to(D, dtype), relu_mask=mask.to(D, dtype))
+    close("nn relu mask", out, (dy @ w) * (mask > 0), dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_cast_colsum(ops, dtype):
     g = torch.Generator().manual_seed(3)
     x = q(torch.randn(203, 77, generator=g), dtype)
