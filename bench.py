@@ -97,10 +97,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    if world > 1:
+    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+    force_ddp = os.environ.get("ASR_FORCE_DDP") == "1"
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(os.environ.get("ASR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
 
     from asr_hip import lib as L
     from asr_hip import ops
@@ -109,7 +111,7 @@ def main():
     from utils.metrics import calculate_loss
 
     flags = MODEL_FLAGS + ["--dropout", str(a.dropout), "--precision", a.precision, "--cuda", "--batch-size", str(a.batch)]
-    if world > 1:
+    if world > 1 or force_ddp:
         flags.append("--parallel")
     args = constant.parse(flags)
     l2i, i2l = labels()
@@ -159,6 +161,22 @@ def main():
     dt = float(tmax.item())
     final_loss = float(loss.item())
 
+    # roofline pass: the dominant kernel family bracketed by HIP events on its own stream, over `prof_steps` eager steps of
+    # the same workload (events cannot be recorded inside a graph replay).  Every rank takes part: the steps contain the
+    # gradient all-reduce.
+    prof = None
+    if not a.no_roofline:
+        prof_steps = min(a.steps, 3)
+        ops.prof_enable(L.OP_CONV_IGEMM, True)
+        for _ in range(prof_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        tot_ms, n = ops.prof_collect(L.OP_CONV_IGEMM)
+        ops.prof_enable(L.OP_CONV_IGEMM, False)
+        prof = (tot_ms, n, prof_steps)
+    if world > 1:
+        dist.barrier()
+
     out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
@@ -176,19 +194,11 @@ def main():
                           "step_tflops_whole_model": value * MFLOP_PER_FRAME * 1e6 / 1e12,
                           "frac_of_mfma_peak_whole_step": value * MFLOP_PER_FRAME * 1e6 / 1e12 / (peak * world),
                           "final_loss": final_loss}}
-        if not a.no_roofline:
-            # dominant kernel, bracketed by HIP events on its own stream over `prof_steps` eager steps of the same workload
-            prof_steps = min(a.steps, 3)
-            ops.prof_enable(L.OP_CONV_IGEMM, True)
-            for _ in range(prof_steps):
-                eager_step()
-            torch.cuda.synchronize()
-            tot_ms, n = ops.prof_collect(L.OP_CONV_IGEMM)
-            ops.prof_enable(L.OP_CONV_IGEMM, False)
+        if prof is not None:
+            tot_ms, n, prof_steps = prof
             fl, per_step = conv_igemm_flops(a.batch)
-            fl = fl * prof_steps / a.steps
             if n > 0 and tot_ms > 0:
-                ach = fl * a.steps / (tot_ms * 1e-3) / 1e12
+                ach = fl * prof_steps / (tot_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (3 fwd + 3 dgrad launches per step)",
                                    "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                                    "launches": n, "avg_launch_ms": tot_ms / n,
@@ -199,7 +209,7 @@ def main():
             except Exception as e:           # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -7,6 +7,8 @@ The backend is whatever torch.distributed was initialised with: "nccl" (= RCCL o
 tests.  Gradients are SUMMED, not averaged: the loss of each rank is local_sum / GLOBAL token count (CEFn), which is
 exactly the reference's loss over the gathered global batch (loss-normalisation note).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -16,6 +18,8 @@ class GradReducer:
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # ASR_FORCE_DDP=1: issue the collectives even with a single rank (exercises the RCCL + hipGraph path on one GPU)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("ASR_FORCE_DDP") == "1")
         # buckets are contiguous slices of the flat gradient buffer, filled from the END of the buffer backwards
         # because backward produces gradients roughly in reverse registration order (decoder first, conv stack last)
         n = len(flat.params)
@@ -44,7 +48,7 @@ class GradReducer:
         self.works = []
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(self.flat.data, src, group=self.group)
 
     def mark_ready(self, p):
@@ -58,7 +62,7 @@ class GradReducer:
 
     def _launch(self, b):
         self.launched[b] = True
-        if self.world > 1:
+        if self.active:
             bk = self.buckets[b]
             self.works.append(dist.all_reduce(self.flat.grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.group,
                                               async_op=True))
@@ -73,7 +77,7 @@ class GradReducer:
         self._reset()
 
     def all_reduce_scalar_(self, t):
-        if self.world > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 

@@ -380,7 +380,7 @@ class CEFn(Function):
         g = gold.reshape(-1).contiguous()
         lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id)
         red = P._state["reducer"]
-        if global_count is None and red is not None and red.world > 1:
+        if global_count is None and red is not None and red.active:
             global_count = red.all_reduce_scalar_(sums[1:2].clone())      # one scalar all-reduce per step
         count = global_count if global_count is not None else sums[1:2]
         ctx.t = (logits, g, lse, count)

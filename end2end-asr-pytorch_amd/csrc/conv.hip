@@ -9,24 +9,33 @@
 //   asr_conv3x3_wgrad : dW = dY^T . shift(X) over ~B*H*W pixels, split-K with fp32 atomics; operands are planar
 //                       zero-padded copies so every tap is a pure pointer shift (no boundary logic in the loop).
 //   conv1 / pooling / layout kernels are HBM-bound streaming kernels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 // ================================================================================================ conv1 (Cin = 1)
+// A thread keeps the 9 taps + bias of its EPC output channels in registers and walks pixels; the C0/EPC threads of a
+// pixel are adjacent lanes, so the NHWC store is one contiguous C0*sizeof(T) run per pixel and the 9 input loads are
+// broadcast within the group.  HBM bound: writes B*H*W*C0*sizeof(T) bytes (528 MB at B=32, bf16).
 template <typename T>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int H,
                                                         int W, int C0) {
   constexpr int EPC = DT<T>::EPC;
-  extern __shared__ float sw[];       // [C0*9] weights + [C0] bias
-  for (int i = threadIdx.x; i < C0 * 10; i += 256) sw[i] = i < C0 * 9 ? w[i] : bias[i - C0 * 9];
-  __syncthreads();
-  const int groups = C0 / EPC;
-  const int64_t total = (int64_t)B * H * W * groups;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(i % groups);
-    const int64_t pix = i / groups;
+  const int groups = C0 / EPC;                // 256 % groups == 0
+  const int cg = threadIdx.x % groups;
+  float wr[EPC][9], br[EPC];
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    br[j] = bias[cg * EPC + j];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[j][t] = w[(cg * EPC + j) * 9 + t];
+  }
+  const int64_t npix = (int64_t)B * H * W;
+  const int ppb = 256 / groups;
+  for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / groups; pix < npix; pix += (int64_t)gridDim.x * ppb) {
     const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
     const int64_t b = pix / ((int64_t)W * H);
     float in[9];
@@ -40,10 +49,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     Chunk<T> o;
 #pragma unroll
     for (int j = 0; j < EPC; ++j) {
-      const int c = cg * EPC + j;
-      float a = sw[C0 * 9 + c];
+      float a = br[j];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) a += sw[c * 9 + t] * in[t];
+      for (int t = 0; t < 9; ++t) a += wr[j][t] * in[t];
       o.e[j] = DT<T>::to(fmaxf(a, 0.f));
     }
     *reinterpret_cast<uint4*>(y + pix * C0 + cg * EPC) = o.v;
@@ -119,6 +127,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 struct ConvArgs {
   const void* x; const void* wk; const float* bias; const void* mask_src; void* y;
   int B, H, W, Cin, Cout, relu, tiles_h, tiles_w;
+  int ablate;   // tuning only (ASR_IGEMM_ABLATE): 1 = no patch loads, 2 = no weight loads, 4 = no stores, 8 = no MFMAs
 };
 
 template <typename T, int NCO>
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
       const int hp = c / CPP, ch = c % CPP;
       const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && !(p.ablate & 1))
         v = *reinterpret_cast<const uint4*>(X + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cin + cc * 64 + ch * EPC);
       *reinterpret_cast<uint4*>(sP + hp * PP + ch * 16) = v;
     }
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     }
     const bool has_next = step + 1 < nsteps;
     u32x4_t rw[WCH];
-    if (has_next) ASR_WLOAD(rw, step + 1)
+    if (has_next && !(p.ablate & 2)) ASR_WLOAD(rw, step + 1)
     const unsigned char* sW = (step & 1) ? sW1 : sW0;
     const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
@@ -206,10 +215,17 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #pragma unroll
       for (int j = 0; j < FN; ++j)
         bfr[j] = *reinterpret_cast<const uint4*>(sW + (wn * (NCO / 2) + j * 16 + lr) * PP + (ms * 4 + g) * 16);
+      if (!(p.ablate & 8)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], bfr[j]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i].x));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(bfr[j].x));
+      }
     }
     if (has_next) {
       unsigned char* dst = (step & 1) ? sW0 : sW1;
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
       if (Msk && !(DT<T>::from(m.e[e]) > 0.f)) x = 0.f;
       o.e[e] = DT<T>::to(x);
     }
-    *reinterpret_cast<uint4*>(Y + off) = o.v;
+    if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + off) = o.v;
   }
 }
 
@@ -722,11 +738,12 @@ extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, 
   const int epc = dtype == ASR_F32 ? 4 : 8;
   if (C0 % epc != 0 || !aligned16(y)) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
+  if (256 % (C0 / epc) != 0) return ASR_EUNSUPPORTED;
   const int64_t total = (int64_t)B * H * W * (C0 / epc);
-  const size_t lds = (size_t)C0 * 10 * sizeof(float);
+  unsigned grid1 = stream_grid(total / 8);
   AsrProfScope prof(ASR_OP_CONV1, s);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float>), dim3(stream_grid(total)), dim3(256), lds, s, x, w, bias, (float*)y, B, H, W, C0);
-  else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), lds, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
+  if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float>), dim3(grid1), dim3(256), 0, s, x, w, bias, (float*)y, B, H, W, C0);
+  else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t>), dim3(grid1), dim3(256), 0, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -771,6 +788,7 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   ConvArgs p{};
   p.x = x; p.wk = wk; p.bias = bias; p.mask_src = mask_src; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
+  { const char* ab = getenv("ASR_IGEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
   if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
   return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);

@@ -6,9 +6,8 @@
 
 namespace {
 
-constexpr int kMaxPerLane = 32;   // D <= 64 * 32 = 2048
 
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ post, int post_period,
@@ -17,13 +16,12 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, co
                                                          float eps, uint32_t thr, float inv_keep, uint64_t seed0,
                                                          const uint64_t* __restrict__ seed_dev) {
   constexpr int EPC = DT<T>::EPC;
-  constexpr int NCH = kMaxPerLane / EPC;
   const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   T* yr = y_z + (int64_t)row * D;
-  float z[kMaxPerLane];
+  float z[NCH * EPC];
   float s = 0.f;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -81,7 +79,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, co
 
 // Backward.  Each block owns `rows_per_block` consecutive rows; lane l of every wave owns the same columns, so
 // dgamma/dbeta partials live in registers across rows and are reduced across the block's 4 waves through LDS.
-template <typename T>
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ z,
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const uint8_t* __restrict__ keep,
@@ -90,17 +88,17 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          float inv_keep, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
   const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   constexpr int EPC = DT<T>::EPC;
-  constexpr int NCH = kMaxPerLane / EPC;
+  constexpr int NPL = NCH * EPC;   // elements per lane
   extern __shared__ float red[];   // [4][2*D] -> only waves 1..3 write
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[kMaxPerLane], ab[kMaxPerLane];
+  float ag[NPL], ab[NPL];
 #pragma unroll
-  for (int i = 0; i < kMaxPerLane; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+  for (int i = 0; i < NPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
   const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
   for (int row = r_beg + wave; row < r_end; row += 4) {
     const float kp = keep ? (keep[row] ? 1.f : 0.f) : 1.f;
     const float mu = mean[row], rs = rstd[row];
-    float xh[kMaxPerLane], dyh[kMaxPerLane];
+    float xh[NPL], dyh[NPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
@@ -175,26 +173,50 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
 
 }  // namespace
 
+namespace {
+template <typename T, int NCH>
+void launch_fwd(T* y_z, const T* res, const float* gamma, const float* beta, const float* post, int period, const uint8_t* keep,
+                T* out, float* mean, float* rstd, int M, int D, float eps, uint32_t thr, float inv, uint64_t seed,
+                const uint64_t* seed_dev, hipStream_t s) {
+  hipLaunchKernelGGL((add_ln_fwd_kernel<T, NCH>), dim3((M + 3) / 4), dim3(256), 0, s, y_z, res, gamma, beta, post, period, keep, out,
+                     mean, rstd, M, D, eps, thr, inv, seed, seed_dev);
+}
+template <typename T, int NCH>
+void launch_bwd(const T* dout, const T* z, const float* mean, const float* rstd, const float* gamma, const uint8_t* keep, T* d_res,
+                T* d_y, float* dgamma, float* dbeta, int M, int D, uint32_t thr, float inv, uint64_t seed, const uint64_t* seed_dev,
+                hipStream_t s) {
+  const int rpb = 32;
+  hipLaunchKernelGGL((add_ln_bwd_kernel<T, NCH>), dim3((M + rpb - 1) / rpb), dim3(256), (size_t)3 * 2 * D * sizeof(float), s, dout, z,
+                     mean, rstd, gamma, keep, d_res, d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed, seed_dev);
+}
+// chunks of 16 bytes per lane needed to cover a row of D elements with one wave
+template <typename T> int chunks_for(int D) { return (D + 64 * DT<T>::EPC - 1) / (64 * DT<T>::EPC); }
+}  // namespace
+
+#define ASR_LN_DISPATCH(T_, CALL)                                      \
+  switch (chunks_for<T_>(D)) {                                         \
+    case 1: CALL(T_, 1); break;                                        \
+    case 2: CALL(T_, 2); break;                                        \
+    case 3: case 4: CALL(T_, 4); break;                                \
+    default: CALL(T_, 8); break;                                       \
+  }
+
 extern "C" int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamma, const float* beta, const float* post_add,
                               int post_period, const uint8_t* row_keep, void* out, float* mean, float* rstd, int M, int D,
                               float eps, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(y_z && gamma && beta && out && mean && rstd && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   const int epc = dtype == ASR_F32 ? 4 : 8;
-  if (D % epc != 0 || D > 64 * kMaxPerLane) return ASR_EUNSUPPORTED;
+  if (D % epc != 0 || D > 64 * 8 * epc) return ASR_EUNSUPPORTED;
   ASR_CHECK_ARG(aligned16(y_z) && aligned16(out) && (!residual || aligned16(residual)));
   ASR_CHECK_ARG(!post_add || post_period > 0);
   if (M == 0) return ASR_OK;
   const uint32_t thr = asr_drop_threshold(p);
   const float inv = 1.f / (1.f - p);
-  dim3 grid((M + 3) / 4);
   AsrProfScope prof(ASR_OP_ADD_LN, s);
-  if (dtype == ASR_F32)
-    hipLaunchKernelGGL((add_ln_fwd_kernel<float>), grid, dim3(256), 0, s, (float*)y_z, (const float*)residual, gamma, beta,
-                       post_add, post_period, row_keep, (float*)out, mean, rstd, M, D, eps, thr, inv, seed, seed_dev);
-  else
-    hipLaunchKernelGGL((add_ln_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (bf16_t*)y_z, (const bf16_t*)residual, gamma, beta,
-                       post_add, post_period, row_keep, (bf16_t*)out, mean, rstd, M, D, eps, thr, inv, seed, seed_dev);
+#define ASR_CALL_F(T_, N_) launch_fwd<T_, N_>((T_*)y_z, (const T_*)residual, gamma, beta, post_add, post_period, row_keep, (T_*)out, mean, rstd, M, D, eps, thr, inv, seed, seed_dev, s)
+  if (dtype == ASR_F32) { ASR_LN_DISPATCH(float, ASR_CALL_F) } else { ASR_LN_DISPATCH(bf16_t, ASR_CALL_F) }
+#undef ASR_CALL_F
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -205,22 +227,16 @@ extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean
   ASR_CHECK_ARG(dout && z && mean && rstd && gamma && d_res && dgamma && dbeta && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   const int epc = dtype == ASR_F32 ? 4 : 8;
-  if (D % epc != 0 || D > 64 * kMaxPerLane) return ASR_EUNSUPPORTED;
+  if (D % epc != 0 || D > 64 * 8 * epc) return ASR_EUNSUPPORTED;
   ASR_CHECK_ARG(aligned16(dout) && aligned16(z) && aligned16(d_res) && (!d_y || aligned16(d_y)));
   if (p > 0.f) ASR_CHECK_ARG(d_y && d_y != d_res);
   if (M == 0) return ASR_OK;
   const uint32_t thr = asr_drop_threshold(p);
   const float inv = 1.f / (1.f - p);
-  const int rpb = 32;
-  dim3 grid((M + rpb - 1) / rpb);
-  const size_t lds = (size_t)3 * 2 * D * sizeof(float);
   AsrProfScope prof(ASR_OP_ADD_LN, s);
-  if (dtype == ASR_F32)
-    hipLaunchKernelGGL((add_ln_bwd_kernel<float>), grid, dim3(256), lds, s, (const float*)dout, (const float*)z, mean, rstd,
-                       gamma, row_keep, (float*)d_res, (float*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed, seed_dev);
-  else
-    hipLaunchKernelGGL((add_ln_bwd_kernel<bf16_t>), grid, dim3(256), lds, s, (const bf16_t*)dout, (const bf16_t*)z, mean,
-                       rstd, gamma, row_keep, (bf16_t*)d_res, (bf16_t*)d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed, seed_dev);
+#define ASR_CALL_B(T_, N_) launch_bwd<T_, N_>((const T_*)dout, (const T_*)z, mean, rstd, gamma, row_keep, (T_*)d_res, (T_*)d_y, dgamma, dbeta, M, D, thr, inv, seed, seed_dev, s)
+  if (dtype == ASR_F32) { ASR_LN_DISPATCH(float, ASR_CALL_B) } else { ASR_LN_DISPATCH(bf16_t, ASR_CALL_B) }
+#undef ASR_CALL_B
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

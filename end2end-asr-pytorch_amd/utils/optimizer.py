@@ -42,7 +42,8 @@ class FusedAdam(torch.optim.Adam):
         self._bind_state()
         if self.ddp_bucket_bytes is not None:
             import torch.distributed as dist
-            if dist.is_initialized() and dist.get_world_size() > 1:
+            import os
+            if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("ASR_FORCE_DDP") == "1"):
                 from asr_hip.ddp import GradReducer
                 self.reducer = GradReducer(self.flat, bucket_bytes=self.ddp_bucket_bytes)
                 self.reducer.broadcast_parameters(0)
