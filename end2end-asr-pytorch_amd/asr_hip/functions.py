@@ -9,6 +9,7 @@ Sub-layer -> reference code
   EmbedFn    models/asr/transformer.py:292-293
   LinearFn   models/asr/transformer.py:302 (output_linear) and any plain nn.Linear
   VGGFn      models/asr/transformer.py:42-53, :70-76
+  EmbCNNFn   models/asr/transformer.py:33-40, :70-76
   CEFn       utils/metrics.py:102-132
 """
 import torch
@@ -362,6 +363,94 @@ class VGGFn(Function):
         ops.conv1_wgrad(src, dy1, P.grad_of(w0), P.grad_of(b0))
         P.grad_ready(w0, b0)
         return (None,) * 9
+
+
+# ================================================================================================ emb_cnn front end
+def _conv_gemm_fwd(x_nhwc, g, w, b, tag):
+    """Strided big-window convolution as im2col + MFMA GEMM.  Returns (col (Mp,ld), Ws (64,ld), y fp32 (Mp,64), M, K)."""
+    cd = ops.compute_dtype()
+    dev = x_nhwc.device
+    Cout = w.shape[0]
+    M, K = g[0] * g[10] * g[11], g[3] * g[4] * g[5]
+    Mp, ld = (M + 127) // 128 * 128, max(64, ops._pad8(K))
+    col = ops.im2col(x_nhwc, g, ops.workspace(tag + "_col", (Mp, ld), cd, dev))
+    Ws = ops.workspace(tag + "_w", (64, ld), cd, dev)                  # rows >= Cout and columns >= K stay zero
+    Ws[:Cout, :K].copy_(w.data.permute(0, 2, 3, 1).reshape(Cout, K))   # (co, ky, kx, ci): the im2col column order
+    bias = ops.workspace(tag + "_b", (64,), torch.float32, dev)
+    bias[:Cout].copy_(b.data)
+    y = ops.gemm_nt(col, Ws, bias=bias, out=ops.workspace(tag + "_y", (Mp, 64), torch.float32, dev))
+    return col, Ws, y, M, K
+
+
+def _bn_stats(bn, y, M, C, training):
+    """nn.BatchNorm2d statistics (eps / momentum of the module; unbiased running variance) -> (mean, rstd)."""
+    if training:
+        mean, var = ops.bn_batch_stats(y, M, C)
+        if bn.track_running_stats:
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(var, alpha=mom * M / max(M - 1, 1))
+            bn.num_batches_tracked.add_(1)
+    else:
+        mean, var = bn.running_mean.float(), bn.running_var.float()
+    return mean.contiguous(), torch.rsqrt(var + bn.eps).contiguous()
+
+
+class EmbCNNFn(Function):
+    """Conv2d(1,32,(41,11),(2,2),(0,10)) -> BN -> Hardtanh(0,20) -> Conv2d(32,32,(21,11),(2,1)) -> BN -> Hardtanh(0,20)
+    -> (B, T', 32*F')   (reference: transformer.py:33-40, :70-76)."""
+
+    @staticmethod
+    def forward(ctx, src, w0, b0, g1, be1, w3, b3, g4, be4, bn1, bn4, training):
+        cd = ops.compute_dtype()
+        src = src.contiguous().float()
+        B, _, Fq, T = src.shape
+        C1, C2 = w0.shape[0], w3.shape[0]
+        gA = ops.conv_geom(B, Fq, T, 1, w0.shape[2], w0.shape[3], 2, 2, 0, 10)
+        colA, WsA, yA, MA, KA = _conv_gemm_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embA")
+        meanA, rstdA = _bn_stats(bn1, yA, MA, C1, training)
+        a1 = torch.empty((B, gA[10], gA[11], C1), device=src.device, dtype=cd)
+        ops.bn_act_fwd(yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, a1.view(MA, C1))
+        gB = ops.conv_geom(B, gA[10], gA[11], C1, w3.shape[2], w3.shape[3], 2, 1, 0, 0)
+        colB, WsB, yB, MB, KB = _conv_gemm_fwd(a1, gB, w3, b3, "embB")
+        meanB, rstdB = _bn_stats(bn4, yB, MB, C2, training)
+        out = torch.empty((B, gB[11], C2 * gB[10]), device=src.device, dtype=cd)
+        ops.bn_act_fwd(yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, out, tH=gB[10], tW=gB[11])
+        ctx.t = (colA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB)
+        ctx.geo = (gA, gB, MA, KA, MB, KB)
+        ctx.params = (w0, b0, g1, be1, w3, b3, g4, be4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        colA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB = ctx.t
+        gA, gB, MA, KA, MB, KB = ctx.geo
+        w0, b0, g1, be1, w3, b3, g4, be4 = ctx.params
+        cd = ops.compute_dtype()
+        dev = dout.device
+        C1, C2 = w0.shape[0], w3.shape[0]
+        dout = dout.contiguous()
+        if dout.dtype != cd:
+            dout = dout.to(cd)
+        # ---- second conv block
+        dyB = ops.workspace("embB_dy", (colB.shape[0], 64), cd, dev)
+        sB = ops.bn_act_bwd(dout, yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, dyB, tH=gB[10], tW=gB[11])
+        P.grad_of(be4).add_(sB[:C2])
+        P.grad_of(g4).add_(sB[C2:])
+        dwB = torch.zeros((C2, KB), device=dev, dtype=torch.float32)
+        ops.gemm_tn(dyB, colB, dwB, colsum_acc=P.grad_of(b3), N=C2, K=KB)
+        P.grad_of(w3).add_(dwB.view(C2, gB[4], gB[5], gB[3]).permute(0, 3, 1, 2))
+        P.grad_ready(w3, b3, g4, be4)
+        dcolB = ops.gemm_nn(dyB, WsB, out=colB)          # colB is dead after the weight gradient: reuse its storage
+        da1 = ops.col2im(dcolB, gB)
+        # ---- first conv block (no data gradient: the input is the spectrogram)
+        dyA = ops.workspace("embA_dy", (colA.shape[0], 64), cd, dev)
+        sA = ops.bn_act_bwd(da1.view(MA, C1), yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, dyA)
+        P.grad_of(be1).add_(sA[:C1])
+        P.grad_of(g1).add_(sA[C1:])
+        ops.gemm_tn(dyA, colA, P.grad_of(w0).view(C1, KA), colsum_acc=P.grad_of(b0), N=C1, K=KA)
+        P.grad_ready(w0, b0, g1, be1)
+        return (None,) * 12
 
 
 # ================================================================================================ loss

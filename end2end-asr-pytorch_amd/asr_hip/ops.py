@@ -438,6 +438,70 @@ def conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout):
     L.call("asr_conv3x3_wgrad", L.ptr(xp), L.ptr(dyp), L.ptr(dw), B, H, W, Cin, Cout, L.dt(xp), L.stream())
 
 
+# ------------------------------------------------------------------------------------------------ emb_cnn front end
+_ws = {}
+
+
+def workspace(tag, shape, dtype, device):
+    """Persistent zero-initialised buffer: kernels rewrite the live region only, padding rows/columns stay zero."""
+    key = (tag, tuple(shape), dtype, str(device))
+    buf = _ws.get(key)
+    if buf is None:
+        buf = torch.zeros(tuple(shape), device=device, dtype=dtype)
+        _ws[key] = buf
+    return buf
+
+
+def conv_geom(B, H, W, C, KH, KW, SH, SW, PH, PW):
+    """(B,H,W,C,KH,KW,SH,SW,PH,PW,OH,OW) of a strided 2-D convolution on an NHWC tensor."""
+    return (B, H, W, C, KH, KW, SH, SW, PH, PW, (H + 2 * PH - KH) // SH + 1, (W + 2 * PW - KW) // SW + 1)
+
+
+def im2col(x, g, col):
+    """col (rows_alloc, ld) <- patches of NHWC x; row (b,oh,ow), column (ky,kx,c); padding written as zeros."""
+    assert x.is_contiguous() and col.is_contiguous() and x.numel() == g[0] * g[1] * g[2] * g[3]
+    L.call("asr_im2col", L.ptr(x), L.ptr(col), *g, col.stride(0), col.shape[0], L.dt(x), L.dt(col), L.stream())
+    return col
+
+
+def col2im(dcol, g, dtype=None):
+    """dx (B,H,W,C) <- gather of dcol (B*OH*OW, ld): the data gradient of the convolution described by g."""
+    B, H, W, C = g[:4]
+    dx = torch.empty((B, H, W, C), device=dcol.device, dtype=dcol.dtype)
+    L.call("asr_col2im", L.ptr(dcol), L.ptr(dx), *g, dcol.stride(0), L.dt(dcol), L.stream())
+    return dx
+
+
+def bn_batch_stats(y, M, C):
+    """Training-mode BatchNorm statistics of the fp32 conv output y (rows, ld) over its first M rows / C columns:
+    (mean, biased var), two passes (mean, then centred second moment)."""
+    s1 = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+    L.call("asr_bn_stats", L.ptr(y), y.stride(0), M, C, None, L.ptr(s1), L.stream())
+    mean = s1[:C] / M
+    s2 = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+    L.call("asr_bn_stats", L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(s2), L.stream())
+    return mean, s2[C:] / M
+
+
+def bn_act_fwd(y, M, C, mean, rstd, gamma, beta, lo, hi, out, tH=0, tW=0):
+    ldo = 0 if tH else out.stride(0)
+    L.call("asr_bn_act_fwd", L.ptr(y), y.stride(0), L.ptr(out), ldo, M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta),
+           float(lo), float(hi), tH, tW, L.dt(out), L.stream())
+    return out
+
+
+def bn_act_bwd(dout, y, M, C, mean, rstd, gamma, beta, lo, hi, dy, tH=0, tW=0):
+    """-> sums (2C): [dbeta, dgamma]; writes dy[:M, :C] (the gradient w.r.t. the conv output) in dy's dtype."""
+    assert dout.dtype == dy.dtype and dout.is_contiguous()
+    ldo = 0 if tH else dout.stride(0)
+    sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
+    L.call("asr_bn_act_bwd_reduce", L.ptr(dout), ldo, L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
+           L.ptr(beta), float(lo), float(hi), tH, tW, L.ptr(sums), L.dt(dout), L.stream())
+    L.call("asr_bn_act_bwd", L.ptr(dout), ldo, L.ptr(y), y.stride(0), L.ptr(dy), dy.stride(0), M, C, L.ptr(mean), L.ptr(rstd),
+           L.ptr(gamma), L.ptr(beta), float(lo), float(hi), tH, tW, L.ptr(sums), L.dt(dout), L.stream())
+    return sums
+
+
 # ------------------------------------------------------------------------------------------------ profiling
 def prof_enable(op, on=True):
     L.call("asr_prof_enable", int(op), int(on))

@@ -1,0 +1,337 @@
+// emb_cnn front end (reference: models/asr/transformer.py:33-40): Conv2d(1,32,(41,11),s=(2,2),p=(0,10)) + BatchNorm2d +
+// Hardtanh(0,20) + Conv2d(32,32,(21,11),s=(2,1)) + BatchNorm2d + Hardtanh(0,20).
+//
+// The two big-window strided convolutions are lowered to GEMMs on the existing MFMA kernels (gemm.hip):
+//   forward   y  = col  . W^T (+bias)          asr_gemm_nt     col = im2col(x), rows m = (b, oh, ow), k = (ky, kx, c)
+//   wgrad     dW += dy^T . col  (db fused)     asr_gemm_tn
+//   dgrad     dcol = dy . W ;  dx = col2im(dcol)   asr_gemm_nn + asr_col2im (gather form, no atomics)
+// This file holds the data-movement kernels either side of those GEMMs and the BatchNorm(+Hardtanh) kernels.
+// Activations are NHWC; the last BN/Hardtanh writes the encoder's (B, T', C*F') layout directly (feature = c*F' + f).
+#include "common.h"
+
+namespace {
+
+struct ColArgs {
+  int B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW;
+  int64_t ld, M, rows_alloc;
+  int K;
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return DT<T>::ld(p); }
+
+// ---------------------------------------------------------------------------------------------- im2col
+// one thread = 8 consecutive k of one row.  C % 8 == 0: the 8 elements are 8 channels of one tap (one vector load).
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) im2col_kernel(const TI* __restrict__ x, TO* __restrict__ col, ColArgs a) {
+  const int64_t chunks = a.ld / 8;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= a.rows_alloc * chunks) return;
+  const int64_t m = gid / chunks;
+  const int k0 = (int)(gid - m * chunks) * 8;
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  if (m < a.M && k0 < a.K) {
+    const int ow = (int)(m % a.OW);
+    const int64_t t = m / a.OW;
+    const int oh = (int)(t % a.OH);
+    const int b = (int)(t / a.OH);
+    const int ih0 = oh * a.SH - a.PH, iw0 = ow * a.SW - a.PW;
+    if (a.C % 8 == 0) {
+      const int tap = k0 / a.C, c0 = k0 - tap * a.C;
+      const int ky = tap / a.KW, kx = tap - ky * a.KW;
+      const int ih = ih0 + ky, iw = iw0 + kx;
+      if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) {
+        const TI* p = x + (((int64_t)b * a.H + ih) * a.W + iw) * a.C + c0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ldf(p + j);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        if (k < a.K) {
+          const int tap = k / a.C, c = k - tap * a.C;
+          const int ky = tap / a.KW, kx = tap - ky * a.KW;
+          const int ih = ih0 + ky, iw = iw0 + kx;
+          if (ih >= 0 && ih < a.H && iw >= 0 && iw < a.W) v[j] = ldf(x + (((int64_t)b * a.H + ih) * a.W + iw) * a.C + c);
+        }
+      }
+    }
+  }
+  TO* o = col + m * a.ld + k0;
+  if constexpr (sizeof(TO) == 2) {
+    Chunk<bf16_t> c;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c.e[j] = f32_to_bf16(v[j]);
+    *reinterpret_cast<uint4*>(o) = c.v;
+  } else {
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- col2im (gather)
+// dx[b,h,w,c] = sum over the taps (ky,kx) whose window covers (h,w) of dcol[(b,oh,ow)][(ky,kx,c)].  One thread = 8 channels
+// of one input pixel; every dcol element is read exactly once.
+template <typename T>
+__global__ void __launch_bounds__(256) col2im_kernel(const T* __restrict__ dcol, T* __restrict__ dx, ColArgs a) {
+  const int cch = a.C / 8;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t npx = (int64_t)a.B * a.H * a.W;
+  if (gid >= npx * cch) return;
+  const int64_t px = gid / cch;
+  const int c0 = (int)(gid - px * cch) * 8;
+  const int w = (int)(px % a.W);
+  const int64_t t = px / a.W;
+  const int h = (int)(t % a.H);
+  const int b = (int)(t / a.H);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  for (int ky = 0; ky < a.KH; ++ky) {
+    const int th = h + a.PH - ky;
+    if (th < 0 || th % a.SH != 0) continue;
+    const int oh = th / a.SH;
+    if (oh >= a.OH) continue;
+    for (int kx = 0; kx < a.KW; ++kx) {
+      const int tw = w + a.PW - kx;
+      if (tw < 0 || tw % a.SW != 0) continue;
+      const int ow = tw / a.SW;
+      if (ow >= a.OW) continue;
+      const T* p = dcol + (((int64_t)b * a.OH + oh) * a.OW + ow) * a.ld + (ky * a.KW + kx) * a.C + c0;
+      if constexpr (sizeof(T) == 2) {
+        Chunk<bf16_t> c;
+        c.v = *reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += bf16_to_f32(c.e[j]);
+      } else {
+        const float4 u0 = *reinterpret_cast<const float4*>(p), u1 = *reinterpret_cast<const float4*>(p + 4);
+        acc[0] += u0.x; acc[1] += u0.y; acc[2] += u0.z; acc[3] += u0.w;
+        acc[4] += u1.x; acc[5] += u1.y; acc[6] += u1.z; acc[7] += u1.w;
+      }
+    }
+  }
+  T* o = dx + px * a.C + c0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) DT<T>::st(o + j, acc[j]);
+}
+
+// ---------------------------------------------------------------------------------------------- BatchNorm (+Hardtanh)
+// y is the fp32 GEMM output (M, ldy), channel = column.  256 threads = (256 / C) row lanes x C channels.
+struct BnArgs {
+  const float* y;
+  int64_t ldy, M;
+  int C;
+  const float *mean, *rstd, *gamma, *beta;
+  float lo, hi;
+  int tH, tW;          // > 0: rows are (b, h, w) over (B, tH, tW) and the activation side uses (B, tW, C*tH), feature c*tH + h
+  int64_t ldo;
+};
+
+__device__ __forceinline__ int64_t act_index(const BnArgs& a, int64_t m, int c) {
+  if (a.tH > 0) {
+    const int w = (int)(m % a.tW);
+    const int64_t t = m / a.tW;
+    const int h = (int)(t % a.tH);
+    const int64_t b = t / a.tH;
+    return ((b * a.tW + w) * a.C + c) * a.tH + h;
+  }
+  return m * a.ldo + c;
+}
+
+constexpr int BN_ROWS = 2048;      // rows per workgroup
+
+// out[0:C] += sum (y - center), out[C:2C] += sum (y - center)^2   (center == nullptr: 0)
+__global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __restrict__ center, float* __restrict__ out) {
+  __shared__ float red[2][256];
+  const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+  const float ctr = center ? center[c] : 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < a.M ? r0 + BN_ROWS : a.M;
+  float s = 0.f, q = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    const float v = a.y[r * a.ldy + c] - ctr;
+    s += v;
+    q += v * v;
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < nrl; ++i) {
+      s += red[0][i * C + c];
+      q += red[1][i * C + c];
+    }
+    atomicAdd(out + c, s);
+    atomicAdd(out + C + c, q);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_fwd_kernel(BnArgs a, T* __restrict__ out) {
+  const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+  const float mu = a.mean[c], rs = a.rstd[c], g = a.gamma[c], be = a.beta[c];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int64_t r = r0 + rl; r < r0 + 64 && r < a.M; r += nrl) {
+    float z = (a.y[r * a.ldy + c] - mu) * rs * g + be;
+    z = fminf(fmaxf(z, a.lo), a.hi);
+    DT<T>::st(out + act_index(a, r, c), z);
+  }
+}
+
+// sums[0:C] += sum dz, sums[C:2C] += sum dz * xhat   with dz = dout masked by lo < z < hi (Hardtanh backward)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const T* __restrict__ dout, float* __restrict__ sums) {
+  __shared__ float red[2][256];
+  const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+  const float mu = a.mean[c], rs = a.rstd[c], g = a.gamma[c], be = a.beta[c];
+  const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < a.M ? r0 + BN_ROWS : a.M;
+  float s = 0.f, q = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+    const float xh = (a.y[r * a.ldy + c] - mu) * rs;
+    const float z = xh * g + be;
+    if (z > a.lo && z < a.hi) {
+      const float d = DT<T>::ld(dout + act_index(a, r, c));
+      s += d;
+      q += d * xh;
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (rl == 0) {
+    for (int i = 1; i < nrl; ++i) {
+      s += red[0][i * C + c];
+      q += red[1][i * C + c];
+    }
+    atomicAdd(sums + c, s);
+    atomicAdd(sums + C + c, q);
+  }
+}
+
+// dy = gamma * rstd * (dz - sum(dz)/M - xhat * sum(dz*xhat)/M)     (training-mode BatchNorm backward)
+template <typename T>
+__global__ void __launch_bounds__(256) bn_act_bwd_kernel(BnArgs a, const T* __restrict__ dout, const float* __restrict__ sums,
+                                                         T* __restrict__ dy, int64_t lddy) {
+  const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
+  const float mu = a.mean[c], rs = a.rstd[c], g = a.gamma[c], be = a.beta[c];
+  const float inv = 1.f / (float)a.M;
+  const float m1 = sums[c] * inv, m2 = sums[C + c] * inv;
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int64_t r = r0 + rl; r < r0 + 64 && r < a.M; r += nrl) {
+    const float xh = (a.y[r * a.ldy + c] - mu) * rs;
+    const float z = xh * g + be;
+    const float d = (z > a.lo && z < a.hi) ? DT<T>::ld(dout + act_index(a, r, c)) : 0.f;
+    DT<T>::st(dy + r * lddy + c, g * rs * (d - m1 - xh * m2));
+  }
+}
+
+bool col_args_ok(const ColArgs& a) {
+  return a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.KH > 0 && a.KW > 0 && a.SH > 0 && a.SW > 0 && a.PH >= 0 && a.PW >= 0 &&
+         a.OH == (a.H + 2 * a.PH - a.KH) / a.SH + 1 && a.OW == (a.W + 2 * a.PW - a.KW) / a.SW + 1 && a.OH > 0 && a.OW > 0;
+}
+
+bool bn_args_ok(const BnArgs& a) {
+  return a.y && a.M > 0 && a.C > 0 && a.C <= 256 && 256 % a.C == 0 && a.ldy >= a.C && a.mean && a.rstd && a.gamma && a.beta &&
+         (a.tH == 0 || (a.tW > 0 && a.M % ((int64_t)a.tH * a.tW) == 0));
+}
+
+}  // namespace
+
+extern "C" int asr_im2col(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW,
+                          int OH, int OW, int64_t ld_col, int64_t rows_alloc, int in_dtype, int out_dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(x && col);
+  ColArgs a{B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW, ld_col, (int64_t)B * OH * OW, rows_alloc, KH * KW * C};
+  ASR_CHECK_ARG(col_args_ok(a) && ld_col % 8 == 0 && ld_col >= a.K && rows_alloc >= a.M && aligned16(col));
+  ASR_CHECK_ARG((in_dtype == ASR_F32 || in_dtype == ASR_BF16) && (out_dtype == ASR_F32 || out_dtype == ASR_BF16));
+  AsrProfScope prof(ASR_OP_LAYOUT, stream);
+  const int64_t n = rows_alloc * (ld_col / 8);
+  const unsigned grid = (unsigned)ceil_div64(n, 256);
+  if (in_dtype == ASR_F32 && out_dtype == ASR_F32)
+    im2col_kernel<float, float><<<grid, 256, 0, stream>>>((const float*)x, (float*)col, a);
+  else if (in_dtype == ASR_F32)
+    im2col_kernel<float, bf16_t><<<grid, 256, 0, stream>>>((const float*)x, (bf16_t*)col, a);
+  else if (out_dtype == ASR_BF16)
+    im2col_kernel<bf16_t, bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)x, (bf16_t*)col, a);
+  else
+    return ASR_EUNSUPPORTED;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW,
+                          int OH, int OW, int64_t ld_col, int dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(dcol && dx);
+  ColArgs a{B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW, ld_col, (int64_t)B * OH * OW, 0, KH * KW * C};
+  ASR_CHECK_ARG(col_args_ok(a) && C % 8 == 0 && ld_col % 8 == 0 && ld_col >= a.K && aligned16(dcol) && aligned16(dx));
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  AsrProfScope prof(ASR_OP_LAYOUT, stream);
+  const int64_t n = (int64_t)B * H * W * (C / 8);
+  const unsigned grid = (unsigned)ceil_div64(n, 256);
+  if (dtype == ASR_F32)
+    col2im_kernel<float><<<grid, 256, 0, stream>>>((const float*)dcol, (float*)dx, a);
+  else
+    col2im_kernel<bf16_t><<<grid, 256, 0, stream>>>((const bf16_t*)dcol, (bf16_t*)dx, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, hipStream_t stream) {
+  ASR_CHECK_ARG(y && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C);
+  BnArgs a{};
+  a.y = y; a.ldy = ldy; a.M = M; a.C = C;
+  AsrProfScope prof(ASR_OP_ADD_LN, stream);
+  bn_stats_kernel<<<(unsigned)ceil_div64(M, BN_ROWS), 256, 0, stream>>>(a, center, sums);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
+                              const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
+                              int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo};
+  ASR_CHECK_ARG(out && bn_args_ok(a) && (tH > 0 || ldo >= C));
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  AsrProfScope prof(ASR_OP_ADD_LN, stream);
+  const unsigned grid = (unsigned)ceil_div64(M, 64);
+  if (dtype == ASR_F32)
+    bn_act_fwd_kernel<float><<<grid, 256, 0, stream>>>(a, (float*)out);
+  else
+    bn_act_fwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a, (bf16_t*)out);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C,
+                                     const float* mean, const float* rstd, const float* gamma, const float* beta, float lo,
+                                     float hi, int tH, int tW, float* sums, int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo};
+  ASR_CHECK_ARG(dout && sums && bn_args_ok(a) && (tH > 0 || ldo >= C));
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  AsrProfScope prof(ASR_OP_ADD_LN, stream);
+  const unsigned grid = (unsigned)ceil_div64(M, BN_ROWS);
+  if (dtype == ASR_F32)
+    bn_act_bwd_reduce_kernel<float><<<grid, 256, 0, stream>>>(a, (const float*)dout, sums);
+  else
+    bn_act_bwd_reduce_kernel<bf16_t><<<grid, 256, 0, stream>>>(a, (const bf16_t*)dout, sums);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
+                              const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
+                              int tH, int tW, const float* sums, int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo};
+  ASR_CHECK_ARG(dout && dy && sums && bn_args_ok(a) && (tH > 0 || ldo >= C) && lddy >= C);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  AsrProfScope prof(ASR_OP_ADD_LN, stream);
+  const unsigned grid = (unsigned)ceil_div64(M, 64);
+  if (dtype == ASR_F32)
+    bn_act_bwd_kernel<float><<<grid, 256, 0, stream>>>(a, (const float*)dout, sums, (float*)dy, lddy);
+  else
+    bn_act_bwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a, (const bf16_t*)dout, sums, (bf16_t*)dy, lddy);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

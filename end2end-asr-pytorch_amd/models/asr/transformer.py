@@ -55,7 +55,9 @@ class Transformer(nn.Module):
             return F_.VGGFn.apply(padded_input, c[0].weight, c[0].bias, c[2].weight, c[2].bias, c[5].weight, c[5].bias,
                                   c[7].weight, c[7].bias)
         if self.feat_extractor == 'emb_cnn':
-            raise NotImplementedError("emb_cnn front end: HIP kernels not built yet (DESIGN.md, section 'next')")
+            c = self.conv
+            return F_.EmbCNNFn.apply(padded_input, c[0].weight, c[0].bias, c[1].weight, c[1].bias, c[3].weight, c[3].bias,
+                                     c[4].weight, c[4].bias, c[1], c[4], self.training)
         b, c, f, t = padded_input.shape
         return padded_input.reshape(b, c * f, t).transpose(1, 2).contiguous().to(ops.compute_dtype())
 

@@ -194,6 +194,32 @@ int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw_acc, int B, int
 int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw_acc, float* db_acc, int B, int H, int W, int Cin,
                            int Cout, int dtype, asr_stream_t stream);
 
+/* ---- emb_cnn front end (reference: models/asr/transformer.py:33-40: Conv2d(1,32,(41,11),(2,2),(0,10)) / BatchNorm2d /
+ * Hardtanh(0,20) / Conv2d(32,32,(21,11),(2,1)) / BatchNorm2d / Hardtanh(0,20)), embcnn.hip.  The strided big-window
+ * convolutions run as GEMMs (asr_gemm_nt / _tn / _nn) on im2col rows m = (b,oh,ow), columns k = (ky,kx,c).            */
+/* col (rows_alloc, ld_col) <- patches of NHWC x (B,H,W,C); columns >= KH*KW*C and rows >= B*OH*OW are written as 0.  */
+int asr_im2col(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW,
+               int OH, int OW, int64_t ld_col, int64_t rows_alloc, int in_dtype, int out_dtype, asr_stream_t stream);
+/* dx (B,H,W,C) <- sum of the dcol entries that cover each input pixel (the conv data gradient; gather, no atomics)  */
+int asr_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW,
+               int OH, int OW, int64_t ld_col, int dtype, asr_stream_t stream);
+/* nn.BatchNorm2d statistics over the rows of the fp32 conv output y (M, ldy), channel = column:
+ * sums[0:C] += sum(y - center), sums[C:2C] += sum((y - center)^2); center may be NULL (two-pass mean / variance).     */
+int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, asr_stream_t stream);
+/* out = clamp(gamma * (y - mean) * rstd + beta, lo, hi)   (BatchNorm2d + Hardtanh, transformer.py:35-36,38-39).
+ * tH > 0: rows are (b,h,w) over (B,tH,tW) and out is the encoder input (B, tW, C*tH), feature c*tH + h (:74-76).     */
+int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
+                   const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
+                   int dtype, asr_stream_t stream);
+/* sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat, dz = dout where lo < z < hi (= dbeta, dgamma of the BatchNorm)      */
+int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C, const float* mean,
+                          const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
+                          float* sums, int dtype, asr_stream_t stream);
+/* dy (M, lddy) = gamma * rstd * (dz - sums[c]/M - xhat * sums[C+c]/M)   (training-mode BatchNorm backward)           */
+int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
+                   const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
+                   int tH, int tW, const float* sums, int dtype, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -62,7 +62,13 @@ def margins(pred):
     return top2[..., 1] - top2[..., 0]
 
 
-@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny"])
+def _noise_driven(k, name):
+    """Parameters whose exact gradient is zero (softmax shift invariance; a conv bias followed by BatchNorm): the
+    reference's own values are rounding noise that Adam turns into +-lr moves."""
+    return k.endswith("key_linear.bias") or (name == "emb_tiny" and k in ("conv.0.bias", "conv.3.bias"))
+
+
+@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny", "emb_tiny"])
 def test_fp32_mode_matches_reference(golden_dir, name):
     z, args, model, opt = build(golden_dir, name, "fp32")
     sm = float(z["smoothing"])
@@ -81,6 +87,8 @@ def test_fp32_mode_matches_reference(golden_dir, name):
     for k, p in model.named_parameters():
         ref = z["g0/" + k]
         tol = 1e-6 + 2e-4 * np.abs(ref).max()
+        if name == "emb_tiny" and k in ("conv.0.bias", "conv.3.bias"):
+            tol = 2e-5                      # exact value 0; both sides hold summation noise of ~1e-6
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=0, atol=tol, err_msg=k)
     opt.step()
     assert abs(opt._rate - float(z["lr1"])) < 1e-12
@@ -93,11 +101,14 @@ def test_fp32_mode_matches_reference(golden_dir, name):
         if k.endswith(".pe"):
             continue
         # gradients that are identically zero in exact arithmetic are rounding noise that Adam turns into +-lr moves
-        atol = 2.1 * lr_sum if k.endswith("key_linear.bias") else 2e-5
+        atol = 2.1 * lr_sum if _noise_driven(k, name) else 2e-5
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(z["w2/" + k])
+            continue
         np.testing.assert_allclose(v.cpu().numpy(), z["w2/" + k], rtol=0, atol=atol, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny"])
+@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny", "emb_tiny"])
 def test_bf16_mode_within_tolerance(golden_dir, name):
     z, args, model, opt = build(golden_dir, name, "bf16")
     sm = float(z["smoothing"])
@@ -112,7 +123,7 @@ def test_bf16_mode_within_tolerance(golden_dir, name):
     bad = []
     for k, p in model.named_parameters():
         g, r = p.grad.cpu().numpy().ravel().astype(np.float64), z["g0/" + k].ravel().astype(np.float64)
-        if np.linalg.norm(r) < 1e-6:
+        if np.linalg.norm(r) < 1e-6 or _noise_driven(k, name):
             continue
         cos = float(g @ r / (np.linalg.norm(g) * np.linalg.norm(r) + 1e-30))
         if cos < 0.98:
