@@ -27,6 +27,8 @@ MODEL_FLAGS = ["--num-layers", "4", "--num-heads", "8", "--dim-model", "512", "-
                "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "vgg_cnn", "--tgt-max-len", str(T_TGT),
                "--src-max-len", str(T_SRC), "--label-smoothing", "0.1"]
 MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm/bmm) per input frame, SURVEY.md 8(d)
+# configs[3] (not the headline; `--workload librispeech`): enc 12 / dec 6 layers, emb_cnn, T_src=1600, B=16, V=32
+LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0, "enc_layers": 12, "dec_layers": 6}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 
@@ -38,19 +40,30 @@ def conv_igemm_flops(B):
     return 2 * fwd, 6
 
 
-def labels():
+def labels(vocab=V):
     from utils import constant
-    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(V - 3)]
+    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(vocab - 3)]
     l2i = {c: i for i, c in enumerate(chars)}
     return l2i, {i: c for c, i in l2i.items()}
 
 
-def synthetic_batch(B, torch):
+def synthetic_batch(B, torch, t_src=T_SRC, t_tgt=T_TGT, vocab=V):
     g = torch.Generator().manual_seed(1234)
-    src = torch.randn(B, 1, F_BINS, T_SRC, generator=g)
-    tgt = torch.randint(3, V, (B, T_TGT - 1), generator=g)
-    src_len = torch.full((B,), T_SRC, dtype=torch.int32)
+    src = torch.randn(B, 1, F_BINS, t_src, generator=g)
+    tgt = torch.randint(3, vocab, (B, t_tgt - 1), generator=g)
+    src_len = torch.full((B,), t_src, dtype=torch.int32)
     return src, src_len, tgt
+
+
+def build_librispeech_model(args, l2i, i2l):
+    """configs[3]: 12 encoder / 6 decoder layers need the constructors (the CLI has one --num-layers for both,
+    reference utils/functions.py:148-151)."""
+    from models.asr.transformer import Decoder, Encoder, Transformer
+    t_out = (LIBRI["T_SRC"] + 20 - 11) // 2 + 1 - 10
+    enc = Encoder(LIBRI["enc_layers"], 8, 512, 64, 64, 32 * 21, 2048, dropout=args.dropout, src_max_length=max(t_out, 2500))
+    dec = Decoder(i2l, len(l2i), len(l2i), LIBRI["dec_layers"], 8, 512, 512, 2048, 64, 64, dropout=args.dropout,
+                  trg_max_length=args.tgt_max_len, emb_trg_sharing=False)
+    return Transformer(enc, dec, feat_extractor="emb_cnn")
 
 
 def cpu_baseline(state_dict, dropout_free_flags, seconds_budget=25.0):
@@ -84,13 +97,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 16 for --workload librispeech)")
+    ap.add_argument("--workload", default="headline", choices=["headline", "librispeech"],
+                    help="headline = BASELINE configs[1] (the judged metric); librispeech = configs[3] (12/6 layers, emb_cnn)")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     a = ap.parse_args()
+    libri = a.workload == "librispeech"
+    if a.batch is None:
+        a.batch = LIBRI["B"] if libri else 32
+    t_src, t_tgt, vocab = (LIBRI["T_SRC"], LIBRI["T_TGT"], LIBRI["V"]) if libri else (T_SRC, T_TGT, V)
+    mflop_per_frame = LIBRI["MFLOP_PER_FRAME"] if libri else MFLOP_PER_FRAME
 
     import torch
     import torch.distributed as dist
@@ -111,18 +131,28 @@ def main():
     from utils.metrics import calculate_loss
 
     flags = MODEL_FLAGS + ["--dropout", str(a.dropout), "--precision", a.precision, "--cuda", "--batch-size", str(a.batch)]
+    if libri:
+        flags += ["--feat_extractor", "emb_cnn", "--src-max-len", str(t_src)]
     if world > 1 or force_ddp:
         flags.append("--parallel")
     args = constant.parse(flags)
-    l2i, i2l = labels()
+    l2i, i2l = labels(vocab)
     torch.manual_seed(123456)
-    model = init_transformer_model(args, l2i, i2l).cuda()
+    if libri:
+        args.dim_input = 32 * 21
+        ops.set_compute_dtype(torch.float32 if a.precision == "fp32" else torch.bfloat16)
+        model = build_librispeech_model(args, l2i, i2l).cuda()
+        if world > 1 or force_ddp:
+            from asr_hip.ddp import HipDataParallel
+            model = HipDataParallel(model, device_ids=args.device_ids)
+    else:
+        model = init_transformer_model(args, l2i, i2l).cuda()
     model.train()
     opt = init_optimizer(args, model, "noam")
-    src, src_len, tgt = synthetic_batch(a.batch, torch)
+    src, src_len, tgt = synthetic_batch(a.batch, torch, t_src, t_tgt, vocab)
     src, tgt = src.cuda(), tgt.cuda()
     sd_cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not libri:
         core = model.module if hasattr(model, "module") else model
         sd_cpu = {k: v.detach().cpu().clone() for k, v in core.state_dict().items()}
 
@@ -165,7 +195,7 @@ def main():
     # the same workload (events cannot be recorded inside a graph replay).  Every rank takes part: the steps contain the
     # gradient all-reduce.
     prof = None
-    if not a.no_roofline:
+    if not a.no_roofline and not libri:
         prof_steps = min(a.steps, 3)
         ops.prof_enable(L.OP_CONV_IGEMM, True)
         for _ in range(prof_steps):
@@ -180,19 +210,22 @@ def main():
     out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
-        frames = a.batch * world * T_SRC * a.steps
+        frames = a.batch * world * t_src * a.steps
         value = frames / dt
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
         out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
                "launch_mode": "hipGraph replay" if use_graph else "eager",
-               "config": {"workload": "configs[1]: 4-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Transformer ASR training "
-                                      "step, synthetic (B=%d/GPU,1,161,T_src=800) -> T_tgt=100, V=4364, label smoothing 0.1, "
-                                      "dropout %.2f, random init" % (a.batch, a.dropout),
+               "config": {"workload": ("configs[3]: 12-enc/6-dec-layer d_model=512 heads=8 dim-inner=2048 emb_cnn Transformer ASR "
+                                       "training step, synthetic (B=%d/GPU,1,161,T_src=1600) -> T_tgt=100, V=32, label "
+                                       "smoothing 0.1, dropout %.2f, random init" if libri else
+                                       "configs[1]: 4-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Transformer ASR training "
+                                       "step, synthetic (B=%d/GPU,1,161,T_src=800) -> T_tgt=100, V=4364, label smoothing 0.1, "
+                                       "dropout %.2f, random init") % (a.batch, a.dropout),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world,
-                          "step_tflops_whole_model": value * MFLOP_PER_FRAME * 1e6 / 1e12,
-                          "frac_of_mfma_peak_whole_step": value * MFLOP_PER_FRAME * 1e6 / 1e12 / (peak * world),
+                          "step_tflops_whole_model": value * mflop_per_frame * 1e6 / 1e12,
+                          "frac_of_mfma_peak_whole_step": value * mflop_per_frame * 1e6 / 1e12 / (peak * world),
                           "final_loss": final_loss}}
         if prof is not None:
             tot_ms, n, prof_steps = prof

@@ -70,9 +70,8 @@ def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, 
 
 def gemm_tn_supported(dy, x):
     """True when the transpose-free weight-gradient kernel applies to dy (M,N) / x (M,K)."""
-    rm = 64 if dy.dtype == torch.float32 else 128
     epc = 4 if dy.dtype == torch.float32 else 8
-    return (dy.shape[0] % rm == 0 and dy.shape[0] > 0 and dy.stride(1) == 1 and x.stride(1) == 1 and
+    return (dy.shape[0] > 0 and dy.stride(1) == 1 and x.stride(1) == 1 and
             dy.stride(0) % epc == 0 and x.stride(0) % epc == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 

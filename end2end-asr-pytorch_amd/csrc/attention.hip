@@ -10,20 +10,11 @@
 //                                                                                     accumulator registers
 // C-fragment layout (col = lane&15, row = 4*(lane>>4)+reg) makes a lane hold 4 consecutive keys of ONE query, which
 // is exactly a B-operand pack for the second contraction, so P never goes through LDS or cross-lane shuffles.
-#include "common.h"
+#include "attention.h"
+
+using namespace asr_attn;
 
 namespace {
-
-struct AttnArgs {
-  const void *Q, *K, *V, *O, *dO;
-  void *Out, *dQ, *dK, *dV;
-  float* lse; float* delta; float* attn_out;
-  int B, H, Tq, Tk;
-  int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
-  const int32_t* key_len; const uint8_t* key_pad; int64_t m_sb, m_sq;
-  int causal; float scale; uint32_t thr; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
-  int vec;     // all pointers 16-B aligned and all strides multiples of EPC
-};
 
 template <typename T, int HD> struct AT {
   static constexpr int EPC = DT<T>::EPC;
@@ -114,30 +105,6 @@ template <> __device__ __forceinline__ uint4 pack_c<bf16_t>(const f32x4_t* v, in
 ASR_FRAG_TR_F32(16) ASR_FRAG_TR_F32(32) ASR_FRAG_TR_F32(64)
 ASR_FRAG_TR_BF16(16) ASR_FRAG_TR_BF16(32) ASR_FRAG_TR_BF16(64)
 
-__device__ __forceinline__ float group_max(float v) {   // across the 4 lane groups that share lane&15
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-}
-
-__device__ __forceinline__ bool key_masked(const AttnArgs& p, int b, int kg, int q, int kend) {
-  if (kg >= kend) return true;
-  if (p.key_pad && p.key_pad[(int64_t)b * p.m_sb + (int64_t)(q < p.Tq ? q : p.Tq - 1) * p.m_sq + kg]) return true;
-  if (p.causal && kg > q) return true;
-  return false;
-}
-__device__ __forceinline__ int key_end(const AttnArgs& p, int b) {
-  int kend = p.Tk;
-  if (p.key_len) { int kl = p.key_len[b]; kend = kl < kend ? (kl < 0 ? 0 : kl) : kend; }
-  return kend;
-}
-__device__ __forceinline__ uint64_t drop_index(const AttnArgs& p, int b, int h, int q, int k) {
-  return (((uint64_t)(h * p.B + b) * p.Tq + q) * (uint64_t)p.Tk) + k;
-}
-
 // ================================================================================================ forward
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
@@ -203,7 +170,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         psum += pv;
         if (p.thr) {
           const int kg = k0 + kf * 16 + g * 4 + r;
-          pv = asr_keep(seed, drop_index(p, b, h, q, kg), p.thr) ? pv * p.inv_keep : 0.f;
+          pv = drop_keep(drop_row_key(seed, drop_row(p, b, h, q)), kg, p.thr) ? pv * p.inv_keep : 0.f;
         }
         s[kf][r] = pv;
       }
@@ -307,7 +274,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
         float pv = 0.f;
         if (!key_masked(p, b, kg, q, kend)) pv = expf(s[r] * p.scale - lse);
         float da = dp[r];
-        if (p.thr) da = asr_keep(seed, drop_index(p, b, h, q, kg), p.thr) ? da * p.inv_keep : 0.f;
+        if (p.thr) da = drop_keep(drop_row_key(seed, drop_row(p, b, h, q)), kg, p.thr) ? da * p.inv_keep : 0.f;
         ds_[kf][r] = pv * (da - dlt);
       }
     }
@@ -395,7 +362,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnArgs p) {
         float pv = 0.f;
         if (!key_dead && qq < p.Tq && !key_masked(p, b, key, qq, kend)) pv = expf(s[r] * p.scale - s_lse[ql]);
         float keepf = 1.f;
-        if (p.thr) keepf = asr_keep(seed, drop_index(p, b, h, qq, key), p.thr) ? p.inv_keep : 0.f;
+        if (p.thr) keepf = drop_keep(drop_row_key(seed, drop_row(p, b, h, qq)), key, p.thr) ? p.inv_keep : 0.f;
         ad[qf][r] = pv * keepf;
         dsv[qf][r] = pv * (dp[r] * keepf - s_dlt[ql]);
       }
@@ -442,13 +409,23 @@ __global__ __launch_bounds__(256) void attn_probs_kernel(AttnArgs p, int HD) {
   for (int c = 0; c < HD; ++c) s += DT<T>::ld(qp + c) * DT<T>::ld(kp + c);
   float pv = 0.f;
   if (!key_masked(p, b, k, q, key_end(p, b))) pv = expf(s * p.scale - p.lse[((int64_t)b * p.H + h) * p.Tq + q]);
-  if (p.thr) pv = asr_keep(seed, drop_index(p, b, h, q, k), p.thr) ? pv * p.inv_keep : 0.f;
+  if (p.thr) pv = drop_keep(drop_row_key(seed, drop_row(p, b, h, q)), k, p.thr) ? pv * p.inv_keep : 0.f;
   p.attn_out[i] = pv;
 }
 
 template <typename T, int HD> size_t lds_fwd() { return (size_t)64 * AT<T, HD>::PN + (size_t)HD * AT<T, HD>::PT; }
 template <typename T, int HD> size_t lds_dq() { return (size_t)2 * 64 * AT<T, HD>::PN + (size_t)HD * AT<T, HD>::PT; }
 template <typename T, int HD> size_t lds_dkv() { return (size_t)2 * 64 * AT<T, HD>::PN + (size_t)2 * HD * AT<T, HD>::PT + 128 * sizeof(float); }
+
+int launch_probs(const AttnArgs& p, int d, int dtype, hipStream_t s) {
+  const int64_t total = (int64_t)p.B * p.H * p.Tq * p.Tk;
+  if (dtype == ASR_F32)
+    hipLaunchKernelGGL((attn_probs_kernel<float>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, s, p, d);
+  else
+    hipLaunchKernelGGL((attn_probs_kernel<bf16_t>), dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, s, p, d);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
 
 template <typename T, int HD>
 int run_fwd(const AttnArgs& p, hipStream_t s) {
@@ -500,7 +477,11 @@ int fill_common(AttnArgs& p, int B, int H, int Tq, int Tk, int d, int64_t q_sb, 
   p.B = B; p.H = H; p.Tq = Tq; p.Tk = Tk;
   p.q_sb = q_sb; p.q_st = q_st; p.k_sb = k_sb; p.k_st = k_st; p.v_sb = v_sb; p.v_st = v_st; p.o_sb = o_sb; p.o_st = o_st;
   p.key_len = key_len; p.key_pad = key_pad; p.m_sb = m_sb; p.m_sq = m_sq; p.causal = causal; p.scale = scale;
-  p.thr = asr_drop_threshold(dropout_p); p.inv_keep = 1.f / (1.f - dropout_p); p.seed = seed; p.seed_dev = seed_dev;
+  // 16-bit dropout threshold; the rescale uses the QUANTISED probability so that E[dropout(x)] = x exactly
+  p.thr = (uint32_t)(dropout_p * 65536.f + 0.5f);
+  if (p.thr > 65535u) p.thr = 65535u;
+  p.inv_keep = 1.f / (1.f - (float)p.thr / 65536.f); p.seed = seed; p.seed_dev = seed_dev;
+  ASR_CHECK_ARG((int64_t)B * H * (Tq > 0 ? Tq : 1) < (int64_t)1 << 32);
   const int epc = dtype == ASR_F32 ? 4 : 8;
   p.vec = (q_sb % epc == 0) && (q_st % epc == 0) && (k_sb % epc == 0) && (k_st % epc == 0) && (v_sb % epc == 0) &&
           (v_st % epc == 0) && (o_sb % epc == 0) && (o_st % epc == 0);
@@ -523,6 +504,13 @@ extern "C" int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O
   p.Q = Q; p.K = K; p.V = V; p.Out = O; p.lse = lse; p.attn_out = attn_out;
   p.vec = p.vec && aligned16(Q) && aligned16(K) && aligned16(V);
   AsrProfScope prof(ASR_OP_ATTN_FWD, stream);
+  {
+    rc = attn_fast_fwd(p, d, dtype, stream);
+    if (rc != ASR_EUNSUPPORTED) {
+      if (rc == ASR_OK && attn_out) rc = launch_probs(p, d, dtype, stream);
+      return rc;
+    }
+  }
   return dtype == ASR_F32 ? dispatch<float>(p, d, false, stream) : dispatch<bf16_t>(p, d, false, stream);
 }
 
@@ -542,5 +530,7 @@ extern "C" int asr_attn_bwd(const void* Q, const void* K, const void* V, const v
   p.dQ = dQ; p.dK = dK; p.dV = dV;
   p.vec = p.vec && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(dO);
   AsrProfScope prof(ASR_OP_ATTN_BWD, stream);
+  rc = attn_fast_bwd(p, d, dtype, stream);
+  if (rc != ASR_EUNSUPPORTED) return rc;
   return dtype == ASR_F32 ? dispatch<float>(p, d, true, stream) : dispatch<bf16_t>(p, d, true, stream);
 }

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
   const int split = wid / p.ntiles, tile = wid % p.ntiles;
   const int n0 = (tile / p.tiles_k) * 64, k0 = (tile % p.tiles_k) * 64;
   const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
-  const int nstage = (m_end - m_beg) / P::RM;
+  const int nstage = (m_end - m_beg + P::RM - 1) / P::RM;   // the last stage of the last split may be partial
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
   // column chunk (16 B) this tile may read: clamp to the operand's last whole chunk (columns past N / K are never stored)
@@ -406,8 +406,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
       const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
       int ca = n0 * ESZ / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;
       int cb = k0 * ESZ / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
-      const unsigned char* sa = A + (mrow + row) * p.lda * ESZ + (int64_t)ca * 16;
-      const unsigned char* sb = B + (mrow + row) * p.ldb * ESZ + (int64_t)cb * 16;
+      // rows past M: re-read the last valid row (finite data); the A side of those rows is zeroed in LDS before use
+      const int64_t gr = mrow + row < p.M ? mrow + row : (int64_t)p.M - 1;
+      const unsigned char* sa = A + gr * p.lda * ESZ + (int64_t)ca * 16;
+      const unsigned char* sb = B + gr * p.ldb * ESZ + (int64_t)cb * 16;
       unsigned char* d = s + (i * 256 + wave * 64) * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
                                        (__attribute__((address_space(3))) void*)d, 16, 0, 0);
@@ -431,6 +433,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
     const unsigned char* sA = smem + (st & 1) * STAGE;
     const unsigned char* sB = sA + P::RM * P::ROWB;
+    const int valid = m_end - (m_beg + st * P::RM);          // rows of this stage that exist (uniform over the workgroup)
+    if (valid < P::RM) {
+      unsigned char* zA = smem + (st & 1) * STAGE;
+      for (int c = valid * (P::ROWB / 16) + tid; c < P::RM * (P::ROWB / 16); c += 256)
+        *reinterpret_cast<uint4*>(zA + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
     uint4 a[4], b[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[i] = P::load(sA, wave * MS_ROWS, lr, g, i * 16);
@@ -729,8 +738,8 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   if (N == 0 || K == 0 || M == 0) return ASR_OK;
   const int esz = dtype == ASR_F32 ? 4 : 2, epc = 16 / esz;
   const int rm = dtype == ASR_F32 ? 64 : 128;
-  // whole stages of m only (rows cannot be zero-filled by the LDS-DMA), 16-byte aligned rows
-  if (M % rm != 0 || lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K)
+  // 16-byte aligned rows; a partial last stage of m is zero-filled in LDS by the kernel
+  if (lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K)
     return ASR_EUNSUPPORTED;
   TnArgs p{};
   p.A = A; p.B = B; p.C = C; p.colsum = colsum_acc;
@@ -739,7 +748,7 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   const int tiles_n = (N + 63) / 64;
   p.tiles_k = (K + 63) / 64;
   p.ntiles = tiles_n * p.tiles_k;
-  const int stages = M / rm;
+  const int stages = (M + rm - 1) / rm;
   if (splits <= 0) {                                  // auto: fill ~256-512 workgroups, atomics are the price
     splits = (160 + p.ntiles - 1) / p.ntiles;        // measured optimum: ~128-256 workgroups, at most 4 slices
     if (splits > 4) splits = 4;

@@ -105,19 +105,23 @@ def wgrad():
 
 
 def attn():
-    print("== attention (B,H,Tq,Tk,d) bf16")
-    for B, H, Tq, Tk, d, causal in [(32, 8, 200, 200, 64, False), (32, 8, 100, 100, 64, True), (32, 8, 100, 200, 64, False),
-                                    (32, 8, 800, 800, 64, False)]:
+    print("== attention (B,H,Tq,Tk,d) bf16   [p = dropout, len = key_len mask as in the encoder]")
+    for B, H, Tq, Tk, d, causal, pd in [(32, 8, 200, 200, 64, False, 0.0), (32, 8, 200, 200, 64, False, 0.1),
+                                        (32, 8, 100, 100, 64, True, 0.1), (32, 8, 100, 200, 64, False, 0.1),
+                                        (32, 8, 800, 800, 64, False, 0.0), (32, 8, 800, 800, 64, False, 0.1),
+                                        (16, 8, 795, 795, 64, False, 0.1)]:
         q = torch.randn(B, Tq, H * d, device=D).bfloat16()
         k = torch.randn(B, Tk, H * d, device=D).bfloat16()
         v = torch.randn(B, Tk, H * d, device=D).bfloat16()
         do = torch.randn(B, Tq, H * d, device=D).bfloat16()
-        us = timeit(lambda: ops.attn_fwd(q, k, v, H, d, causal=causal, scale=0.125))
-        o, lse, _ = ops.attn_fwd(q, k, v, H, d, causal=causal, scale=0.125)
+        kl = None if causal else torch.full((B,), Tk, device=D, dtype=torch.int32)
+        kw = dict(causal=causal, scale=0.125, p=pd, seed=1234, key_len=kl)
+        us = timeit(lambda: ops.attn_fwd(q, k, v, H, d, **kw))
+        o, lse, _ = ops.attn_fwd(q, k, v, H, d, **kw)
         fl = 4 * B * H * Tq * Tk * d * (0.5 if causal else 1.0)
-        usb = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, H, d, causal=causal, scale=0.125))
-        print("  attn %s fwd %8.1f us %7.1f TF/s | bwd %8.1f us %7.1f TF/s" %
-              ((B, H, Tq, Tk, d, causal), us, fl / us / 1e6, usb, 2.5 * fl / usb / 1e6))
+        usb = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, H, d, **kw))
+        print("  attn %s p=%.1f fwd %8.1f us %7.1f TF/s (%4.1f%% of 2.5 PF) | bwd %8.1f us %7.1f TF/s (%4.1f%%)" %
+              ((B, H, Tq, Tk, d, causal), pd, us, fl / us / 1e6, fl / us / 25e6, usb, 2.5 * fl / usb / 1e6, 2.5 * fl / usb / 25e6))
 
 
 def misc():
