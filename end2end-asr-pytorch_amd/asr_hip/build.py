@@ -10,7 +10,10 @@ CSRC = os.path.join(os.path.dirname(HERE), "csrc")
 INCLUDE = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include")
 LIB = os.path.join(HERE, "libasr_hip.so")
 OBJ = os.path.join(HERE, "_obj")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs (gfx950 has a unified file); without it the
+# softmax / epilogue code pays a v_accvgpr_read/write pair for every accumulator element it touches.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def _hipcc():

@@ -23,11 +23,8 @@ struct AttnArgs {
 // probability dump evaluate the same function, so the mask is identical everywhere (the reference draws from torch's Philox
 // stream; RNG streams cannot match across implementations).
 __device__ __forceinline__ uint32_t drop_row_key(uint64_t seed, uint32_t row) {
-  uint32_t x = (uint32_t)seed ^ (row * 0x9E3779B1u);
-  x ^= x >> 15;
-  x *= 0x85EBCA6Bu;
-  x ^= (uint32_t)(seed >> 32);
-  return x;
+  // linear in the row (one multiply-add per row even where rows change per element); drop_pair_bits does the mixing
+  return (uint32_t)seed + (uint32_t)(seed >> 32) * 0x85EBCA6Bu + row * 0x9E3779B1u;
 }
 __device__ __forceinline__ uint32_t drop_pair_bits(uint32_t row_key, uint32_t key_pair) {
   uint32_t y = (row_key + key_pair) * 0xC2B2AE35u;

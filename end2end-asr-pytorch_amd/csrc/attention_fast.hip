@@ -32,6 +32,23 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
+// all-reduce over the 4 lane groups that share lane & 15, on the VALU (gfx950 lane-swap instructions) instead of two
+// ds_bpermute round trips: v_permlane16_swap(v, v) -> {rows 0,0,2,2} / {rows 1,1,3,3}; v_permlane32_swap(v, v) -> {lo,lo} / {hi,hi}
+__device__ __forceinline__ float group_max4(float v) {
+  uint32_t u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1])));
+  auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+}
+__device__ __forceinline__ float group_sum4(float v) {
+  uint32_t u = __float_as_uint(v);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  u = __float_as_uint(__uint_as_float(a[0]) + __uint_as_float(a[1]));
+  auto c = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+}
+
 // XCD-aware linear workgroup id: consecutive ids run on the same XCD (hardware deals blockIdx round-robin over 8 XCDs)
 __device__ __forceinline__ int xcd_linear_id() {
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
@@ -192,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qi][kf][r]);
-      mx = group_max(mx);
+      mx = group_max4(mx);
       const float m_new = fmaxf(m[qi], mx);
       const float m_safe = m_new == -INFINITY ? 0.f : m_new;
       const float alpha = __builtin_amdgcn_exp2f((m[qi] - m_safe) * c2);
@@ -216,7 +233,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
             if ((y >> 16) < p.thr) s[qi][kf][2 * pr + 1] = 0.f;
           }
       }
-      psum = group_sum(psum);
+      psum = group_sum4(psum);
       l[qi] = l[qi] * alpha + psum;
       m[qi] = m_new;
 #pragma unroll
@@ -251,6 +268,323 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
   }
 }
 
+// ================================================================================================ backward: dQ
+// Same work split as the forward (wave = 32 queries, 64-key K / V tiles double buffered in LDS):
+//   S^T = K Q^T, dP^T = V dO^T (A operands: K / V rows from LDS; B: Q / dO rows in registers)
+//   P = exp2(S c - lse c'), dS = P (keep/(1-p) dP - delta)
+//   dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (A: transposing reads of the natural K tile; B: dS from the accumulators)
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nqb = (p.Tq + FQ - 1) / FQ;
+  const int vid = xcd_linear_id();
+  const int bh = vid / nqb, qb = vid - bh * nqb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int qw = qb * FQ + wave * 32;
+  const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
+  const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
+  const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
+  const bf16_t* dOb = static_cast<const bf16_t*>(p.dO) + (int64_t)b * p.o_sb + (int64_t)h * HD;
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
+  const float c2 = p.scale * LOG2E;
+
+  uint4 qf[2][2], dof[2][2];
+  uint32_t rkey[2];
+  float lse2[2], dlt[2];
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const int q = qw + qi * 16 + lr;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      qf[qi][ds] = load_row16(Qb, p.q_st, q, p.Tq, ds * 32 + g * 8);
+      dof[qi][ds] = load_row16(dOb, p.o_st, q, p.Tq, ds * 32 + g * 8);
+    }
+    rkey[qi] = drop_row_key(seed, drop_row(p, b, h, q));
+    const int64_t si = ((int64_t)b * p.H + h) * p.Tq + (q < p.Tq ? q : p.Tq - 1);
+    lse2[qi] = p.lse[si] * LOG2E;                 // +inf for fully masked rows: exp2(-inf) = 0
+    dlt[qi] = p.delta[si];
+  }
+  f32x4_t dq[2][4];
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+    for (int df = 0; df < 4; ++df) dq[qi][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int kend = key_end(p, b);
+  int kstop = kend;
+  if (p.causal) kstop = min(kend, qb * FQ + FQ);
+  const int ntile = (kstop + 63) >> 6;
+
+  if (ntile > 0) {
+    stage_tile(smem, Kb, p.k_st, 0, p.Tk, tid, wave);
+    stage_tile(smem + TILE, Vb, p.v_st, 0, p.Tk, tid, wave);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int k0 = t << 6;
+    const unsigned char* sK = smem + (t & 1) * 2 * TILE;
+    const unsigned char* sV = sK + TILE;
+    f32x4_t s[2][4], dp[2][4];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      s[0][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      s[1][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[0][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[1][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const uint4 ak = frag_rows(sK, kf * 16 + lr, ds, g);
+        const uint4 av = frag_rows(sV, kf * 16 + lr, ds, g);
+        mma(s[0][kf], ak, qf[0][ds]);
+        mma(s[1][kf], ak, qf[1][ds]);
+        mma(dp[0][kf], av, dof[0][ds]);
+        mma(dp[1][kf], av, dof[1][ds]);
+      }
+    }
+    uint4 kt[2][4];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int df = 0; df < 4; ++df) kt[ms][df] = frag_cols(sK, df * 16, ms, lr, g);
+    const bool need_mask = (k0 + 64 > kend) || p.key_pad != nullptr || (p.causal && k0 + 63 > qw);
+    if (need_mask) mask_scores(p, s, b, k0, g, qw + lr, kend);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < ntile) {
+      unsigned char* nb = smem + ((t + 1) & 1) * 2 * TILE;
+      stage_tile(nb, Kb, p.k_st, k0 + 64, p.Tk, tid, wave);
+      stage_tile(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, tid, wave);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 pb[2][2];
+#pragma unroll
+    for (int qi = 0; qi < 2; ++qi) {
+      if (p.thr) {
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const uint32_t y = drop_pair_bits(rkey[qi], (uint32_t)(k0 + kf * 16 + g * 4 + pr * 2) >> 1);
+            dp[qi][kf][2 * pr] = (y & 0xffffu) < p.thr ? 0.f : dp[qi][kf][2 * pr] * p.inv_keep;
+            dp[qi][kf][2 * pr + 1] = (y >> 16) < p.thr ? 0.f : dp[qi][kf][2 * pr + 1] * p.inv_keep;
+          }
+      }
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[qi][kf][r] * c2 - lse2[qi]);       // masked: s = -inf -> 0
+          s[qi][kf][r] = pv * (dp[qi][kf][r] - dlt[qi]);
+        }
+      pb[qi][0] = pack_p(s[qi], 0);
+      pb[qi][1] = pack_p(s[qi], 1);
+    }
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        mma(dq[0][df], kt[ms][df], pb[0][ms]);
+        mma(dq[1][df], kt[ms][df], pb[1][ms]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int qi = 0; qi < 2; ++qi) {
+    const int q = qw + qi * 16 + lr;
+    if (q >= p.Tq) continue;
+    bf16_t* o = static_cast<bf16_t*>(p.dQ) + (int64_t)b * p.q_sb + (int64_t)q * p.q_st + (int64_t)h * HD;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      const f32x4_t v = dq[qi][df] * p.scale;
+      *reinterpret_cast<uint2*>(o + df * 16 + g * 4) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    }
+  }
+}
+
+// ================================================================================================ backward: dK, dV
+// wave = 32 keys (two B fragments, K / V rows in registers); 64-query Q / dO tiles double buffered in LDS with their
+// lse / delta rows.   S = Q K^T, dP = dO V^T (A: Q / dO rows from LDS), P, dS as above, then
+//   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]   (A: transposing reads of dO / Q tiles)
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  __shared__ float s_stat[2][2][64];                                              // [buffer][lse*log2e | delta][q]
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nkb = (p.Tk + FQ - 1) / FQ;
+  const int vid = xcd_linear_id();
+  const int bh = vid / nkb, kb = vid - bh * nkb;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int kw = kb * FQ + wave * 32;                       // first key of this wave
+  const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
+  const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
+  const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
+  const bf16_t* dOb = static_cast<const bf16_t*>(p.dO) + (int64_t)b * p.o_sb + (int64_t)h * HD;
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
+  const float c2 = p.scale * LOG2E;
+  const int kend = key_end(p, b);
+  const int64_t stat0 = ((int64_t)b * p.H + h) * p.Tq;
+
+  uint4 kfr[2][2], vfr[2][2];
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      kfr[ki][ds] = load_row16(Kb, p.k_st, kw + ki * 16 + lr, p.Tk, ds * 32 + g * 8);
+      vfr[ki][ds] = load_row16(Vb, p.v_st, kw + ki * 16 + lr, p.Tk, ds * 32 + g * 8);
+    }
+  f32x4_t dk[2][4], dv[2][4];
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki)
+#pragma unroll
+    for (int df = 0; df < 4; ++df) { dk[ki][df] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[ki][df] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  // causal: query tiles that end before the first key of this workgroup never see it
+  const int t0 = p.causal ? (kb * FQ) >> 6 : 0;
+  const int ntile = (p.Tq + 63) >> 6;
+
+  auto stage_stats = [&](int t, int buf) __attribute__((always_inline)) {
+    if (tid < 128) {
+      const int ql = tid & 63, qq = (t << 6) + ql;
+      float v;
+      if (tid < 64) v = qq < p.Tq ? p.lse[stat0 + qq] * LOG2E : INFINITY;        // rows past Tq: P = exp2(-inf) = 0
+      else v = qq < p.Tq ? p.delta[stat0 + qq] : 0.f;
+      s_stat[buf][tid >> 6][ql] = v;
+    }
+  };
+  if (t0 < ntile) {
+    stage_tile(smem, Qb, p.q_st, t0 << 6, p.Tq, tid, wave);
+    stage_tile(smem + TILE, dOb, p.o_st, t0 << 6, p.Tq, tid, wave);
+    stage_stats(t0, t0 & 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = t0; t < ntile; ++t) {
+    const int q0 = t << 6;
+    const unsigned char* sQ = smem + ((t - t0) & 1) * 2 * TILE;
+    const unsigned char* sdO = sQ + TILE;
+    const float* st_lse = s_stat[t & 1][0];
+    const float* st_dlt = s_stat[t & 1][1];
+    f32x4_t s[2][4], dp[2][4];
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf) {
+      s[0][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      s[1][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[0][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      dp[1][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const uint4 aq = frag_rows(sQ, qf * 16 + lr, ds, g);
+        const uint4 ao = frag_rows(sdO, qf * 16 + lr, ds, g);
+        mma(s[0][qf], aq, kfr[0][ds]);
+        mma(s[1][qf], aq, kfr[1][ds]);
+        mma(dp[0][qf], ao, vfr[0][ds]);
+        mma(dp[1][qf], ao, vfr[1][ds]);
+      }
+    }
+    // per-row statistics of the 16 queries this lane sees: q = q0 + 16 qf + 4 g + r
+    f32x4_t lse2[4], dlt[4];
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf) {
+      lse2[qf] = *reinterpret_cast<const f32x4_t*>(st_lse + qf * 16 + g * 4);
+      dlt[qf] = *reinterpret_cast<const f32x4_t*>(st_dlt + qf * 16 + g * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 1 < ntile) {
+      unsigned char* nb = smem + ((t + 1 - t0) & 1) * 2 * TILE;
+      stage_tile(nb, Qb, p.q_st, q0 + 64, p.Tq, tid, wave);
+      stage_tile(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, tid, wave);
+      stage_stats(t + 1, (t + 1) & 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool need_mask = p.key_pad != nullptr || (p.causal && kw + 31 > q0) || (kw + 32 > kend);
+    uint4 pa[2][2], pd[2][2];
+#pragma unroll
+    for (int ki = 0; ki < 2; ++ki) {
+      const int key = kw + ki * 16 + lr;
+      if (need_mask) {
+        const uint8_t* mcol = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (key < p.Tk ? key : p.Tk - 1) : nullptr;
+#pragma unroll
+        for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = q0 + qf * 16 + g * 4 + r;
+            bool dead = key >= kend;
+            if (p.causal) dead = dead || key > qq;
+            if (mcol) dead = dead || mcol[(int64_t)(qq < p.Tq ? qq : p.Tq - 1) * p.m_sq] != 0;
+            s[ki][qf][r] = dead ? -INFINITY : s[ki][qf][r];
+          }
+      }
+#pragma unroll
+      for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(s[ki][qf][r] * c2 - lse2[qf][r]);
+          float keepf = 1.f;
+          if (p.thr) {
+            const uint32_t rk = drop_row_key(seed, drop_row(p, b, h, q0 + qf * 16 + g * 4 + r));
+            const uint32_t y = drop_pair_bits(rk, (uint32_t)key >> 1);
+            keepf = ((key & 1) ? (y >> 16) : (y & 0xffffu)) < p.thr ? 0.f : p.inv_keep;
+          }
+          s[ki][qf][r] = pv * keepf;                                   // dropped / rescaled probabilities (for dV)
+          dp[ki][qf][r] = pv * (dp[ki][qf][r] * keepf - dlt[qf][r]);   // dS (for dK)
+        }
+      pa[ki][0] = pack_p(s[ki], 0);
+      pa[ki][1] = pack_p(s[ki], 1);
+      pd[ki][0] = pack_p(dp[ki], 0);
+      pd[ki][1] = pack_p(dp[ki], 1);
+    }
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const uint4 aot = frag_cols(sdO, df * 16, ms, lr, g);
+        const uint4 aqt = frag_cols(sQ, df * 16, ms, lr, g);
+        mma(dv[0][df], aot, pa[0][ms]);
+        mma(dv[1][df], aot, pa[1][ms]);
+        mma(dk[0][df], aqt, pd[0][ms]);
+        mma(dk[1][df], aqt, pd[1][ms]);
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#pragma unroll
+  for (int ki = 0; ki < 2; ++ki) {
+    const int key = kw + ki * 16 + lr;
+    if (key >= p.Tk) continue;
+    bf16_t* ok = static_cast<bf16_t*>(p.dK) + (int64_t)b * p.k_sb + (int64_t)key * p.k_st + (int64_t)h * HD;
+    bf16_t* ov = static_cast<bf16_t*>(p.dV) + (int64_t)b * p.v_sb + (int64_t)key * p.v_st + (int64_t)h * HD;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      const f32x4_t a = dk[ki][df] * p.scale, c = dv[ki][df];
+      *reinterpret_cast<uint2*>(ok + df * 16 + g * 4) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+      *reinterpret_cast<uint2*>(ov + df * 16 + g * 4) = make_uint2(pack_bf16(c[0], c[1]), pack_bf16(c[2], c[3]));
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_delta_bf16_d64_kernel(AttnArgs p) {
+  // delta[b,h,q] = sum_d dO * O : one 8-lane group per row (8 x 16 B = one 128-byte head row)
+  const int64_t idx = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int64_t total = (int64_t)p.B * p.H * p.Tq;
+  const int sub = threadIdx.x & 7;
+  float acc = 0.f;
+  if (idx < total) {
+    const int q = (int)(idx % p.Tq);
+    const int h = (int)((idx / p.Tq) % p.H);
+    const int b = (int)(idx / ((int64_t)p.Tq * p.H));
+    const int64_t off = (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD + sub * 8;
+    Chunk<bf16_t> o, d;
+    o.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.O) + off);
+    d.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.dO) + off);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += bf16_to_f32(o.e[j]) * bf16_to_f32(d.e[j]);
+  }
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 1, 64);
+  if (idx < total && sub == 0) p.delta[idx] = acc;
+}
+
 bool fast_ok(const AttnArgs& p, int d, int dtype) {
   return dtype == ASR_BF16 && d == HD && p.vec && p.Tq > 0 && p.Tk > 0 && getenv("ASR_ATTN_GENERIC") == nullptr;
 }
@@ -266,8 +600,17 @@ int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
 }
 
 int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
-  (void)p; (void)d; (void)dtype; (void)s;
-  return ASR_EUNSUPPORTED;
+  if (!fast_ok(p, d, dtype)) return ASR_EUNSUPPORTED;
+  for (const void* ptr : {(const void*)p.dQ, (const void*)p.dK, (const void*)p.dV, p.O})
+    if ((((uintptr_t)ptr) & 15) != 0) return ASR_EUNSUPPORTED;
+  const int64_t rows = (int64_t)p.B * p.H * p.Tq;
+  attn_delta_bf16_d64_kernel<<<dim3((unsigned)ceil_div64(rows, 32)), dim3(256), 0, s>>>(p);
+  ASR_LAUNCH_CHECK();
+  attn_bwd_dq_bf16_d64_kernel<<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+  ASR_LAUNCH_CHECK();
+  attn_bwd_dkv_bf16_d64_kernel<<<dim3((unsigned)(((p.Tk + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
 }
 
 }  // namespace asr_attn

@@ -104,12 +104,14 @@ def wgrad():
               ((B, H, W, Ci, Co), us, fl / us / 1e6, us_p, 2 * x.numel() * 2 / us_p / 1e3))
 
 
-def attn():
+ATTN_CASES = [(32, 8, 200, 200, 64, False, 0.0), (32, 8, 200, 200, 64, False, 0.1), (32, 8, 100, 100, 64, True, 0.1),
+              (32, 8, 100, 200, 64, False, 0.1), (32, 8, 800, 800, 64, False, 0.0), (32, 8, 800, 800, 64, False, 0.1),
+              (16, 8, 795, 795, 64, False, 0.1)]
+
+
+def attn(cases=None):
     print("== attention (B,H,Tq,Tk,d) bf16   [p = dropout, len = key_len mask as in the encoder]")
-    for B, H, Tq, Tk, d, causal, pd in [(32, 8, 200, 200, 64, False, 0.0), (32, 8, 200, 200, 64, False, 0.1),
-                                        (32, 8, 100, 100, 64, True, 0.1), (32, 8, 100, 200, 64, False, 0.1),
-                                        (32, 8, 800, 800, 64, False, 0.0), (32, 8, 800, 800, 64, False, 0.1),
-                                        (16, 8, 795, 795, 64, False, 0.1)]:
+    for B, H, Tq, Tk, d, causal, pd in cases or ATTN_CASES:
         q = torch.randn(B, Tq, H * d, device=D).bfloat16()
         k = torch.randn(B, Tk, H * d, device=D).bfloat16()
         v = torch.randn(B, Tk, H * d, device=D).bfloat16()
@@ -151,3 +153,5 @@ if __name__ == "__main__":
     for name, fn in (("gemm", gemm), ("conv", conv), ("wgrad", wgrad), ("attn", attn), ("misc", misc)):
         if which in (name, "all"):
             fn()
+    if which == "attn800":          # the north-star shape only (encoder self-attention, T = 800, bs 32, dropout 0.1)
+        attn([ATTN_CASES[5]])
