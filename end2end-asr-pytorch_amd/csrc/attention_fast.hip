@@ -97,18 +97,19 @@ __device__ __forceinline__ uint4 load_row16(const bf16_t* base, int64_t st, int 
   return *reinterpret_cast<const uint4*>(base + (int64_t)r * st + col0);
 }
 
-// Mask one 64-key tile of raw scores s[qi][kf][r] (key = k0 + 16 kf + 4 g + r, query = q_lane + 16 qi): straight-line
+// Mask NKF key fragments of raw scores s[qi][kf][r] (key = kbase + 16 kf + 4 g + r, query = q_lane + 16 qi): straight-line
 // selects, mask bytes read with clamped (always valid) addresses.
-__device__ __forceinline__ void mask_scores(const AttnArgs& p, f32x4_t (*s)[4], int b, int k0, int g, int q_lane, int kend) {
+template <int NKF>
+__device__ __forceinline__ void mask_scores(const AttnArgs& p, f32x4_t (*s)[NKF], int b, int kbase, int g, int q_lane, int kend) {
 #pragma unroll
   for (int qi = 0; qi < 2; ++qi) {
     const int q = q_lane + qi * 16;
     const uint8_t* mrow = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (int64_t)(q < p.Tq ? q : p.Tq - 1) * p.m_sq : nullptr;
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+    for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int kg = k0 + kf * 16 + g * 4 + r;
+        const int kg = kbase + kf * 16 + g * 4 + r;
         bool dead = kg >= kend;
         if (p.causal) dead = dead || kg > q;
         if (mrow) dead = dead || mrow[kg < p.Tk ? kg : p.Tk - 1] != 0;
@@ -181,15 +182,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
         mma(s[1][kf], a, qf[1][ds]);
       }
     }
-    // V^T operand packs: issued now so that the transposing LDS reads complete under the softmax arithmetic
-    uint4 vt[2][4];
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-      for (int df = 0; df < 4; ++df) vt[ms][df] = frag_cols(sV, df * 16, ms, lr, g);
     // ---- masks only where a boundary crosses this tile (wave-uniform test)
     const bool need_mask = (k0 + 64 > kend) || p.key_pad != nullptr || (p.causal && k0 + 63 > qw);
-    if (need_mask) mask_scores(p, s, b, k0, g, qw + lr, kend);
+    if (need_mask) mask_scores<4>(p, s, b, k0, g, qw + lr, kend);
     // next tile: HBM -> LDS in flight under the softmax and the second contraction.  Issued AFTER the mask bytes were
     // consumed: ordinary loads and LDS-DMA loads share vmcnt, and waiting for the former with the latter in flight
     // was observed to return stale mask bytes.
@@ -246,8 +241,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        mma(o[0][df], vt[ms][df], pb[0][ms]);
-        mma(o[1][df], vt[ms][df], pb[1][ms]);
+        const uint4 vt = frag_cols(sV, df * 16, ms, lr, g);
+        mma(o[0][df], vt, pb[0][ms]);
+        mma(o[1][df], vt, pb[1][ms]);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -325,67 +321,66 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
     const int k0 = t << 6;
     const unsigned char* sK = smem + (t & 1) * 2 * TILE;
     const unsigned char* sV = sK + TILE;
-    f32x4_t s[2][4], dp[2][4];
-#pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      s[0][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      s[1][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dp[0][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dp[1][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ds = 0; ds < 2; ++ds) {
-        const uint4 ak = frag_rows(sK, kf * 16 + lr, ds, g);
-        const uint4 av = frag_rows(sV, kf * 16 + lr, ds, g);
-        mma(s[0][kf], ak, qf[0][ds]);
-        mma(s[1][kf], ak, qf[1][ds]);
-        mma(dp[0][kf], av, dof[0][ds]);
-        mma(dp[1][kf], av, dof[1][ds]);
-      }
-    }
-    uint4 kt[2][4];
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-      for (int df = 0; df < 4; ++df) kt[ms][df] = frag_cols(sK, df * 16, ms, lr, g);
     const bool need_mask = (k0 + 64 > kend) || p.key_pad != nullptr || (p.causal && k0 + 63 > qw);
-    if (need_mask) mask_scores(p, s, b, k0, g, qw + lr, kend);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < ntile) {
-      unsigned char* nb = smem + ((t + 1) & 1) * 2 * TILE;
-      stage_tile(nb, Kb, p.k_st, k0 + 64, p.Tk, tid, wave);
-      stage_tile(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, tid, wave);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    uint4 pb[2][2];
+    // the tile is consumed in two halves of 32 keys (one macro step of the dQ contraction each): half the live accumulators
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
-      if (p.thr) {
+    for (int ms = 0; ms < 2; ++ms) {
+      f32x4_t s[2][2], dp[2][2];
 #pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
+      for (int k2 = 0; k2 < 2; ++k2) {
+        s[0][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s[1][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[0][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[1][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const uint32_t y = drop_pair_bits(rkey[qi], (uint32_t)(k0 + kf * 16 + g * 4 + pr * 2) >> 1);
-            dp[qi][kf][2 * pr] = (y & 0xffffu) < p.thr ? 0.f : dp[qi][kf][2 * pr] * p.inv_keep;
-            dp[qi][kf][2 * pr + 1] = (y >> 16) < p.thr ? 0.f : dp[qi][kf][2 * pr + 1] * p.inv_keep;
-          }
-      }
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[qi][kf][r] * c2 - lse2[qi]);       // masked: s = -inf -> 0
-          s[qi][kf][r] = pv * (dp[qi][kf][r] - dlt[qi]);
+        for (int ds = 0; ds < 2; ++ds) {
+          const uint4 ak = frag_rows(sK, (2 * ms + k2) * 16 + lr, ds, g);
+          const uint4 av = frag_rows(sV, (2 * ms + k2) * 16 + lr, ds, g);
+          mma(s[0][k2], ak, qf[0][ds]);
+          mma(s[1][k2], ak, qf[1][ds]);
+          mma(dp[0][k2], av, dof[0][ds]);
+          mma(dp[1][k2], av, dof[1][ds]);
         }
-      pb[qi][0] = pack_p(s[qi], 0);
-      pb[qi][1] = pack_p(s[qi], 1);
-    }
+      }
+      if (need_mask) mask_scores<2>(p, s, b, k0 + 32 * ms, g, qw + lr, kend);
+      if (ms == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntile) {
+          unsigned char* nb = smem + ((t + 1) & 1) * 2 * TILE;
+          stage_tile(nb, Kb, p.k_st, k0 + 64, p.Tk, tid, wave);
+          stage_tile(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, tid, wave);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      uint4 pb[2];
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
+      for (int qi = 0; qi < 2; ++qi) {
+        if (p.thr) {
+#pragma unroll
+          for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const uint32_t y = drop_pair_bits(rkey[qi], (uint32_t)(k0 + (2 * ms + k2) * 16 + g * 4 + pr * 2) >> 1);
+              dp[qi][k2][2 * pr] = (y & 0xffffu) < p.thr ? 0.f : dp[qi][k2][2 * pr] * p.inv_keep;
+              dp[qi][k2][2 * pr + 1] = (y >> 16) < p.thr ? 0.f : dp[qi][k2][2 * pr + 1] * p.inv_keep;
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(s[qi][k2][r] * c2 - lse2[qi]);       // masked: s = -inf -> 0
+            s[qi][k2][r] = pv * (dp[qi][k2][r] - dlt[qi]);
+          }
+        pb[qi] = pack_p(s[qi], 0);
+      }
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        mma(dq[0][df], kt[ms][df], pb[0][ms]);
-        mma(dq[1][df], kt[ms][df], pb[1][ms]);
+        const uint4 kt = frag_cols(sK, df * 16, ms, lr, g);
+        mma(dq[0][df], kt, pb[0]);
+        mma(dq[1][df], kt, pb[1]);
       }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -464,86 +459,88 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
     const unsigned char* sdO = sQ + TILE;
     const float* st_lse = s_stat[t & 1][0];
     const float* st_dlt = s_stat[t & 1][1];
-    f32x4_t s[2][4], dp[2][4];
-#pragma unroll
-    for (int qf = 0; qf < 4; ++qf) {
-      s[0][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      s[1][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dp[0][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      dp[1][qf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ds = 0; ds < 2; ++ds) {
-        const uint4 aq = frag_rows(sQ, qf * 16 + lr, ds, g);
-        const uint4 ao = frag_rows(sdO, qf * 16 + lr, ds, g);
-        mma(s[0][qf], aq, kfr[0][ds]);
-        mma(s[1][qf], aq, kfr[1][ds]);
-        mma(dp[0][qf], ao, vfr[0][ds]);
-        mma(dp[1][qf], ao, vfr[1][ds]);
-      }
-    }
-    // per-row statistics of the 16 queries this lane sees: q = q0 + 16 qf + 4 g + r
-    f32x4_t lse2[4], dlt[4];
-#pragma unroll
-    for (int qf = 0; qf < 4; ++qf) {
-      lse2[qf] = *reinterpret_cast<const f32x4_t*>(st_lse + qf * 16 + g * 4);
-      dlt[qf] = *reinterpret_cast<const f32x4_t*>(st_dlt + qf * 16 + g * 4);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < ntile) {
-      unsigned char* nb = smem + ((t + 1 - t0) & 1) * 2 * TILE;
-      stage_tile(nb, Qb, p.q_st, q0 + 64, p.Tq, tid, wave);
-      stage_tile(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, tid, wave);
-      stage_stats(t + 1, (t + 1) & 1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
     const bool need_mask = p.key_pad != nullptr || (p.causal && kw + 31 > q0) || (kw + 32 > kend);
-    uint4 pa[2][2], pd[2][2];
+    // the query tile is consumed in two halves of 32 queries (one macro step of the dV / dK contractions each)
 #pragma unroll
-    for (int ki = 0; ki < 2; ++ki) {
-      const int key = kw + ki * 16 + lr;
-      if (need_mask) {
-        const uint8_t* mcol = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (key < p.Tk ? key : p.Tk - 1) : nullptr;
+    for (int ms = 0; ms < 2; ++ms) {
+      f32x4_t s[2][2], dp[2][2];
 #pragma unroll
-        for (int qf = 0; qf < 4; ++qf)
+      for (int q2 = 0; q2 < 2; ++q2) {
+        s[0][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        s[1][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[0][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        dp[1][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          const uint4 aq = frag_rows(sQ, (2 * ms + q2) * 16 + lr, ds, g);
+          const uint4 ao = frag_rows(sdO, (2 * ms + q2) * 16 + lr, ds, g);
+          mma(s[0][q2], aq, kfr[0][ds]);
+          mma(s[1][q2], aq, kfr[1][ds]);
+          mma(dp[0][q2], ao, vfr[0][ds]);
+          mma(dp[1][q2], ao, vfr[1][ds]);
+        }
+      }
+      // per-row statistics of the 8 queries this lane sees in this half: q = q0 + 32 ms + 16 q2 + 4 g + r
+      f32x4_t lse2[2], dlt[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        lse2[q2] = *reinterpret_cast<const f32x4_t*>(st_lse + (2 * ms + q2) * 16 + g * 4);
+        dlt[q2] = *reinterpret_cast<const f32x4_t*>(st_dlt + (2 * ms + q2) * 16 + g * 4);
+      }
+      if (ms == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < ntile) {
+          unsigned char* nb = smem + ((t + 1 - t0) & 1) * 2 * TILE;
+          stage_tile(nb, Qb, p.q_st, q0 + 64, p.Tq, tid, wave);
+          stage_tile(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, tid, wave);
+          stage_stats(t + 1, (t + 1) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      uint4 pa[2], pd[2];
+#pragma unroll
+      for (int ki = 0; ki < 2; ++ki) {
+        const int key = kw + ki * 16 + lr;
+        if (need_mask) {
+          const uint8_t* mcol = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (key < p.Tk ? key : p.Tk - 1) : nullptr;
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qq = q0 + (2 * ms + q2) * 16 + g * 4 + r;
+              bool dead = key >= kend;
+              if (p.causal) dead = dead || key > qq;
+              if (mcol) dead = dead || mcol[(int64_t)(qq < p.Tq ? qq : p.Tq - 1) * p.m_sq] != 0;
+              s[ki][q2][r] = dead ? -INFINITY : s[ki][q2][r];
+            }
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int qq = q0 + qf * 16 + g * 4 + r;
-            bool dead = key >= kend;
-            if (p.causal) dead = dead || key > qq;
-            if (mcol) dead = dead || mcol[(int64_t)(qq < p.Tq ? qq : p.Tq - 1) * p.m_sq] != 0;
-            s[ki][qf][r] = dead ? -INFINITY : s[ki][qf][r];
+            const float pv = __builtin_amdgcn_exp2f(s[ki][q2][r] * c2 - lse2[q2][r]);
+            float keepf = 1.f;
+            if (p.thr) {
+              const uint32_t rk = drop_row_key(seed, drop_row(p, b, h, q0 + (2 * ms + q2) * 16 + g * 4 + r));
+              const uint32_t y = drop_pair_bits(rk, (uint32_t)key >> 1);
+              keepf = ((key & 1) ? (y >> 16) : (y & 0xffffu)) < p.thr ? 0.f : p.inv_keep;
+            }
+            s[ki][q2][r] = pv * keepf;                                   // dropped / rescaled probabilities (for dV)
+            dp[ki][q2][r] = pv * (dp[ki][q2][r] * keepf - dlt[q2][r]);   // dS (for dK)
           }
+        pa[ki] = pack_p(s[ki], 0);
+        pd[ki] = pack_p(dp[ki], 0);
       }
-#pragma unroll
-      for (int qf = 0; qf < 4; ++qf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[ki][qf][r] * c2 - lse2[qf][r]);
-          float keepf = 1.f;
-          if (p.thr) {
-            const uint32_t rk = drop_row_key(seed, drop_row(p, b, h, q0 + qf * 16 + g * 4 + r));
-            const uint32_t y = drop_pair_bits(rk, (uint32_t)key >> 1);
-            keepf = ((key & 1) ? (y >> 16) : (y & 0xffffu)) < p.thr ? 0.f : p.inv_keep;
-          }
-          s[ki][qf][r] = pv * keepf;                                   // dropped / rescaled probabilities (for dV)
-          dp[ki][qf][r] = pv * (dp[ki][qf][r] * keepf - dlt[qf][r]);   // dS (for dK)
-        }
-      pa[ki][0] = pack_p(s[ki], 0);
-      pa[ki][1] = pack_p(s[ki], 1);
-      pd[ki][0] = pack_p(dp[ki], 0);
-      pd[ki][1] = pack_p(dp[ki], 1);
-    }
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const uint4 aot = frag_cols(sdO, df * 16, ms, lr, g);
         const uint4 aqt = frag_cols(sQ, df * 16, ms, lr, g);
-        mma(dv[0][df], aot, pa[0][ms]);
-        mma(dv[1][df], aot, pa[1][ms]);
-        mma(dk[0][df], aqt, pd[0][ms]);
-        mma(dk[1][df], aqt, pd[1][ms]);
+        mma(dv[0][df], aot, pa[0]);
+        mma(dv[1][df], aot, pa[1]);
+        mma(dk[0][df], aqt, pd[0]);
+        mma(dk[1][df], aqt, pd[1]);
       }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
