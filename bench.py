@@ -40,6 +40,18 @@ def conv_igemm_flops(B):
     return 2 * fwd, 6
 
 
+def measured_traffic(a):
+    """HBM bytes per igemm launch from the committed rocprofv3 PMC passes (profiles/r01_roofline_traffic.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
+    if a.batch != 32 or a.precision != "bf16":
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch_avg"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def labels(vocab=V):
     from utils import constant
     chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(vocab - 3)]
@@ -233,7 +245,8 @@ def main():
             if n > 0 and tot_ms > 0:
                 ach = fl * prof_steps / (tot_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (3 fwd + 3 dgrad launches per step)",
-                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                                   "traffic": measured_traffic(a),
                                    "launches": n, "avg_launch_ms": tot_ms / n,
                                    "algorithmic_flop_per_launch_avg": fl / per_step}
         if sd_cpu is not None:
