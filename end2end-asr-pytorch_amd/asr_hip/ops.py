@@ -177,9 +177,11 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     assert dout.is_contiguous() and z.is_contiguous()
     d_res = torch.empty_like(z)
     d_y = torch.empty_like(z) if p > 0 else d_res
+    n_ws = L.load().asr_add_ln_bwd_workspace(M, D)
+    ws = torch.empty(n_ws, device=z.device, dtype=torch.float32)       # caching allocator: no cost after the first step
     L.call("asr_add_ln_bwd", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
-           L.ptr(d_res), L.ptr(d_y), L.ptr(dgamma), L.ptr(dbeta), M, D, float(p), int(seed), _seed_dev(z), L.dt(z),
-           L.stream())
+           L.ptr(d_res), L.ptr(d_y), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), n_ws, M, D, float(p), int(seed), _seed_dev(z),
+           L.dt(z), L.stream())
     return d_res, d_y
 
 

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, const uint8_t* __restrict__ keep,
                                                          T* __restrict__ d_res, T* __restrict__ d_y, float* dgamma,
-                                                         float* dbeta, int M, int D, int rows_per_block, uint32_t thr,
+                                                         float* dbeta, float* __restrict__ partial, int M, int D,
+                                                         int rows_per_block, uint32_t thr,
                                                          float inv_keep, uint64_t seed0, const uint64_t* __restrict__ seed_dev) {
   const uint64_t seed = asr_mix_seed(seed0, seed_dev);
   constexpr int EPC = DT<T>::EPC;
@@ -163,12 +164,30 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
           float g = ag[ch * EPC + j], b = ab[ch * EPC + j];
 #pragma unroll
           for (int w = 0; w < 3; ++w) { g += red[w * 2 * D + c0 + j]; b += red[w * 2 * D + D + c0 + j]; }
-          atomicAdd(dgamma + c0 + j, g);
-          atomicAdd(dbeta + c0 + j, b);
+          if (partial) {                 // two-stage reduction: no atomics on the 2*D hot addresses
+            partial[(int64_t)blockIdx.x * 2 * D + c0 + j] = g;
+            partial[(int64_t)blockIdx.x * 2 * D + D + c0 + j] = b;
+          } else {
+            atomicAdd(dgamma + c0 + j, g);
+            atomicAdd(dbeta + c0 + j, b);
+          }
         }
       }
     }
   }
+}
+
+// second stage: column c of [dgamma | dbeta] += sum over a slice of the per-block partial rows (grid.y slices)
+__global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __restrict__ partial, int nblk, int D2,
+                                                                float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D2) return;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) acc += partial[(int64_t)b * D2 + c];
+  const int D = D2 / 2;
+  atomicAdd(c < D ? dgamma + c : dbeta + (c - D), acc);
 }
 
 }  // namespace
@@ -183,11 +202,18 @@ void launch_fwd(T* y_z, const T* res, const float* gamma, const float* beta, con
 }
 template <typename T, int NCH>
 void launch_bwd(const T* dout, const T* z, const float* mean, const float* rstd, const float* gamma, const uint8_t* keep, T* d_res,
-                T* d_y, float* dgamma, float* dbeta, int M, int D, uint32_t thr, float inv, uint64_t seed, const uint64_t* seed_dev,
-                hipStream_t s) {
-  const int rpb = 32;
-  hipLaunchKernelGGL((add_ln_bwd_kernel<T, NCH>), dim3((M + rpb - 1) / rpb), dim3(256), (size_t)3 * 2 * D * sizeof(float), s, dout, z,
-                     mean, rstd, gamma, keep, d_res, d_y, dgamma, dbeta, M, D, rpb, thr, inv, seed, seed_dev);
+                T* d_y, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, int M, int D, uint32_t thr, float inv, uint64_t seed,
+                const uint64_t* seed_dev, hipStream_t s) {
+  // with a workspace: 8 rows per block (fills the chip) and a two-stage column reduction; without: 32 rows + atomics
+  int rpb = 8;
+  int nblk = (M + rpb - 1) / rpb;
+  if (!ws || ws_floats < (int64_t)nblk * 2 * D) { rpb = 32; nblk = (M + rpb - 1) / rpb; ws = nullptr; }
+  hipLaunchKernelGGL((add_ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), (size_t)3 * 2 * D * sizeof(float), s, dout, z,
+                     mean, rstd, gamma, keep, d_res, d_y, dgamma, dbeta, ws, M, D, rpb, thr, inv, seed, seed_dev);
+  if (ws) {
+    const int slices = nblk >= 64 ? 16 : 1;
+    hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * D + 255) / 256, slices), dim3(256), 0, s, ws, nblk, 2 * D, dgamma, dbeta);
+  }
 }
 // chunks of 16 bytes per lane needed to cover a row of D elements with one wave
 template <typename T> int chunks_for(int D) { return (D + 64 * DT<T>::EPC - 1) / (64 * DT<T>::EPC); }
@@ -221,9 +247,12 @@ extern "C" int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamm
   return ASR_OK;
 }
 
+extern "C" int64_t asr_add_ln_bwd_workspace(int M, int D) { return (int64_t)((M + 7) / 8) * 2 * D; }
+
 extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
-                              const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma, float* dbeta, int M, int D,
-                              float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t s) {
+                              const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma, float* dbeta, float* workspace,
+                              int64_t workspace_floats, int M, int D, float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
+                              hipStream_t s) {
   ASR_CHECK_ARG(dout && z && mean && rstd && gamma && d_res && dgamma && dbeta && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   const int epc = dtype == ASR_F32 ? 4 : 8;
@@ -234,7 +263,7 @@ extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean
   const uint32_t thr = asr_drop_threshold(p);
   const float inv = 1.f / (1.f - p);
   AsrProfScope prof(ASR_OP_ADD_LN, s);
-#define ASR_CALL_B(T_, N_) launch_bwd<T_, N_>((const T_*)dout, (const T_*)z, mean, rstd, gamma, row_keep, (T_*)d_res, (T_*)d_y, dgamma, dbeta, M, D, thr, inv, seed, seed_dev, s)
+#define ASR_CALL_B(T_, N_) launch_bwd<T_, N_>((const T_*)dout, (const T_*)z, mean, rstd, gamma, row_keep, (T_*)d_res, (T_*)d_y, dgamma, dbeta, workspace, workspace_floats, M, D, thr, inv, seed, seed_dev, s)
   if (dtype == ASR_F32) { ASR_LN_DISPATCH(float, ASR_CALL_B) } else { ASR_LN_DISPATCH(bf16_t, ASR_CALL_B) }
 #undef ASR_CALL_B
   ASR_LAUNCH_CHECK();

@@ -89,10 +89,14 @@ int asr_add_ln_fwd(void* y_z, const void* residual, const float* gamma, const fl
                    int post_period, const uint8_t* row_keep, void* out, float* mean, float* rstd, int M, int D,
                    float eps, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 /* d_res = LN'(dout*row_keep) ; d_y = d_res * dropmask/(1-p) (d_y may alias d_res when p == 0, or be NULL);
- * dgamma_acc/dbeta_acc (fp32, D) are accumulated into.                                                         */
+ * dgamma_acc/dbeta_acc (fp32, D) are accumulated into.  workspace (fp32, >= asr_add_ln_bwd_workspace(M, D) elements,
+ * optional): per-block column partials for a two-stage reduction; without it the kernel falls back to 32-row blocks
+ * and atomics on the 2*D gradient addresses.                                                                     */
+int64_t asr_add_ln_bwd_workspace(int M, int D);
 int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
-                   const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma_acc, float* dbeta_acc, int M,
-                   int D, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
+                   const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma_acc, float* dbeta_acc,
+                   float* workspace, int64_t workspace_floats, int M, int D, float dropout_p, uint64_t seed,
+                   const uint64_t* seed_dev, int dtype, asr_stream_t stream);
 
 /* ---- fused multi-head attention core: softmax(mask(Q K^T * scale)) (dropout) V -------------------------------
  * Q (B,Tq,H,d) with element strides (q_sb, q_st) and head h at offset h*d; same for K,V (B,Tk,H,d), O (B,Tq,H,d).
