@@ -130,26 +130,34 @@ struct ConvArgs {
   int ablate;   // tuning only (ASR_IGEMM_ABLATE): 1 = no patch loads, 2 = no weight loads, 4 = no stores, 8 = no MFMAs
 };
 
-template <typename T, int NCO>
+// Workgroup tile = TH x 16 pixels x NCO output channels, K step = (tap, 64-channel slice).  The TH+2 x 18 halo patch of a
+// channel slice is staged once and read at 9 shifted positions; the tap's weight rows are double buffered (register
+// prefetch).  Waves: (TH/4) along pixel rows x WN along Cout, each wave 4 pixel-row fragments x FN = NCO/(16 WN) Cout
+// fragments.  TH = 16 gives 4 x 4 (NCO 64) / 4 x 8 (NCO 128) fragments per wave: 2 / 2.7 MFMAs per LDS operand read
+// instead of 1.3 / 2 with TH = 8 -- the kernel is bound by LDS read bandwidth, not by the matrix cores.
+template <typename T, int NCO, int TH>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CPP = 64 / EPC;            // 16-B chunks per 64-channel pixel slice
   constexpr int PP = 64 * ESZ + 16;        // LDS pitch of a pixel slice / weight row
   constexpr int NMS = 64 / (4 * EPC);      // macro steps per 64 channels
-  constexpr int FN = NCO / 32;             // cout fragments per wave
+  constexpr int WM = TH / 4, WN = 4 / WM;  // wave grid
+  constexpr int FN = NCO / (16 * WN);      // cout fragments per wave
   constexpr int WCH = NCO * CPP / 256;     // weight chunks per thread
+  constexpr int NHALO = (TH + 2) * 18;     // halo pixels
+  constexpr int NPX = TH * 16;             // output pixels
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sP = smem;                       // 180 halo pixels
-  unsigned char* sW0 = smem + 180 * PP;           // weight tile, buffer 0
+  unsigned char* sP = smem;
+  unsigned char* sW0 = smem + NHALO * PP;         // weight tile, buffer 0
   unsigned char* sW1 = sW0 + NCO * PP;            // buffer 1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   int t = blockIdx.x;
   const int tw = t % p.tiles_w; t /= p.tiles_w;
   const int th = t % p.tiles_h;
   const int b = t / p.tiles_h;
-  const int h0 = th * 8, w0 = tw * 16;
+  const int h0 = th * TH, w0 = tw * 16;
   const T* X = static_cast<const T*>(p.x);
   const T* Wk = static_cast<const T*>(p.wk);
   const int nchunk = p.Cin / 64;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     }                                                                                                         \
   }
   auto pstage = [&](int cc) __attribute__((always_inline)) {
-    for (int c = tid; c < 180 * CPP; c += 256) {
+    for (int c = tid; c < NHALO * CPP; c += 256) {
       const int hp = c / CPP, ch = c % CPP;
       const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
         a[i] = *reinterpret_cast<const uint4*>(sP + ((wm * 4 + i + dy) * 18 + lr + dx) * PP + (ms * 4 + g) * 16);
 #pragma unroll
       for (int j = 0; j < FN; ++j)
-        bfr[j] = *reinterpret_cast<const uint4*>(sW + (wn * (NCO / 2) + j * 16 + lr) * PP + (ms * 4 + g) * 16);
+        bfr[j] = *reinterpret_cast<const uint4*>(sW + (wn * (NCO / WN) + j * 16 + lr) * PP + (ms * 4 + g) * 16);
       if (!(p.ablate & 8)) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -238,40 +246,40 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #undef ASR_WLOAD
 #undef ASR_WWRITE
 
-  // ---- epilogue through LDS: (128 px, NCO) fp32 tile -> per pixel 16-byte channel-contiguous chunks, so that the
-  // bias / ReLU / mask reads and the NHWC stores are all row-contiguous vector accesses
-  constexpr int CP = NCO * 4 + 16;
+  // ---- epilogue through LDS: bias / ReLU on the accumulators, then the (NPX px, NCO) tile in the storage dtype -> per pixel
+  // 16-byte channel-contiguous chunks, so that the mask reads and the NHWC stores are row-contiguous vector accesses
+  constexpr int CP = NCO * ESZ + 16;
   __syncthreads();                               // all waves are done reading the patch / weight tiles
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int j = 0; j < FN; ++j) {
+    const int co = wn * (NCO / WN) + j * 16 + lr;
+    const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-    for (int j = 0; j < FN; ++j)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<float*>(smem + ((wm * 4 + i) * 16 + g * 4 + r) * CP + (wn * (NCO / 2) + j * 16 + lr) * 4) = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) {
+        float x = acc[i][j][r] + bv;
+        if (p.relu) x = fmaxf(x, 0.f);
+        *reinterpret_cast<T*>(smem + ((wm * 4 + i) * 16 + g * 4 + r) * CP + co * ESZ) = DT<T>::to(x);
+      }
+  }
   __syncthreads();
   T* Y = static_cast<T*>(p.y);
   const T* Msk = static_cast<const T*>(p.mask_src);
   constexpr int CPX = NCO / EPC;                 // 16-byte output chunks per pixel
-  for (int c = tid; c < 128 * CPX; c += 256) {
+  for (int c = tid; c < NPX * CPX; c += 256) {
     const int px = c / CPX, ch0 = (c % CPX) * EPC;
     const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
     if (gy >= p.H || gx >= p.W) continue;
     const int64_t off = (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0;
-    float v[EPC];
+    Chunk<T> o;
+    o.v = *reinterpret_cast<const uint4*>(smem + px * CP + ch0 * ESZ);
+    if (Msk) {
+      Chunk<T> m;
+      m.v = *reinterpret_cast<const uint4*>(Msk + off);
 #pragma unroll
-    for (int e = 0; e < EPC; e += 4) {
-      const float4 t4 = *reinterpret_cast<const float4*>(smem + px * CP + (ch0 + e) * 4);
-      v[e] = t4.x; v[e + 1] = t4.y; v[e + 2] = t4.z; v[e + 3] = t4.w;
-    }
-    Chunk<T> m, o;
-    if (Msk) m.v = *reinterpret_cast<const uint4*>(Msk + off);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      float x = v[e] + (p.bias ? p.bias[ch0 + e] : 0.f);
-      if (p.relu) x = fmaxf(x, 0.f);
-      if (Msk && !(DT<T>::from(m.e[e]) > 0.f)) x = 0.f;
-      o.e[e] = DT<T>::to(x);
+      for (int e = 0; e < EPC; ++e)
+        if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<T>::to(0.f);
     }
     if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + off) = o.v;
   }
@@ -705,18 +713,27 @@ template <typename K> void allow_big_lds(K kernel, size_t lds) {
   }
 }
 
-template <typename T, int NCO>
-int launch_igemm(const ConvArgs& a, hipStream_t s) {
+template <typename T, int NCO, int TH>
+int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
-  p.tiles_h = (p.H + 7) / 8;
+  p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + 15) / 16;
-  size_t lds = (size_t)(180 + 2 * NCO) * (64 * sizeof(T) + 16);
-  const size_t lds_epi = (size_t)128 * (NCO * 4 + 16);
+  size_t lds = (size_t)((TH + 2) * 18 + 2 * NCO) * (64 * sizeof(T) + 16);
+  const size_t lds_epi = (size_t)(TH * 16) * (NCO * sizeof(T) + 16);
   if (lds_epi > lds) lds = lds_epi;
-  allow_big_lds(conv3x3_igemm_kernel<T, NCO>, lds);
-  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
+  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH>, lds);
+  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
+}
+// tile height: 8 rows (3 / 2 workgroups per CU at NCO 64 / 128).  The 16-row tile does more MFMAs per LDS operand read but
+// its patch and accumulators cost a workgroup per CU; measured (profiles/r01_microbench_v3.txt) it only wins for 128 -> 64
+// channels, so it stays a tuning option (ASR_IGEMM_TH=16).
+template <typename T, int NCO>
+int launch_igemm(const ConvArgs& a, hipStream_t s) {
+  static const int forced = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 0;
+  if (forced == 16 && sizeof(T) == 2) return launch_igemm_t<T, NCO, 16>(a, s);
+  return launch_igemm_t<T, NCO, 8>(a, s);
 }
 
 inline unsigned stream_grid(int64_t total_threads) {
