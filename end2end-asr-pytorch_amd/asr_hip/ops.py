@@ -432,7 +432,10 @@ def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
     B, H, W, Cin = x.shape
     Cout = dy.shape[3]
     assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3]
-    L.call("asr_conv3x3_wgrad_nhwc", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), B, H, W, Cin, Cout, L.dt(x), L.stream())
+    n_ws = L.load().asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout)
+    ws = workspace("wgrad_ws", (n_ws,), torch.float32, x.device)      # 75 MB, shared by the three conv layers
+    L.call("asr_conv3x3_wgrad_nhwc", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x),
+           L.stream())
 
 
 def conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout):

@@ -26,12 +26,6 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
-typedef __attribute__((ext_vector_type(4))) short s16x4_t;
-__device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
-  const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(uintptr_t)p);
-  return __builtin_bit_cast(uint2, v);
-}
-
 // all-reduce over the 4 lane groups that share lane & 15, on the VALU (gfx950 lane-swap instructions) instead of two
 // ds_bpermute round trips: v_permlane16_swap(v, v) -> {rows 0,0,2,2} / {rows 1,1,3,3}; v_permlane32_swap(v, v) -> {lo,lo} / {hi,hi}
 __device__ __forceinline__ float group_max4(float v) {
@@ -80,8 +74,8 @@ __device__ __forceinline__ uint4 frag_cols(const unsigned char* tile, int c0, in
   const int row = 32 * ms + 4 * g + (lr >> 2), col = c0 + 4 * (lr & 3);
   const int chunk = col >> 3, half = (col >> 2) & 1;
   // the builtin (not inline asm) so that the compiler tracks lgkmcnt for the result registers itself
-  const uint2 lo = lds_read_tr16(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
-  const uint2 hi = lds_read_tr16(tile + (row + 16) * ROWB + ((chunk ^ ((row + 16) & 7)) << 4) + half * 8);
+  const uint2 lo = asr_lds_read_tr16(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
+  const uint2 hi = asr_lds_read_tr16(tile + (row + 16) * ROWB + ((chunk ^ ((row + 16) & 7)) << 4) + half * 8);
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 // B-operand pack from C fragments v[f][r] = X[16 f + 4 g + r][col]: k = 32 ms + 4 g + r (f = 2 ms), 32 ms + 16 + 4 g + r (f = 2 ms + 1)

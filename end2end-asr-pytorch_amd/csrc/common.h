@@ -66,6 +66,16 @@ template <> __device__ __forceinline__ void mma16<float>(f32x4_t& acc, const uin
   acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
 }
 
+// ---------------------------------------------------------------------------------------------- transposing LDS read
+// ds_read_b64_tr_b16 through the compiler builtin (NOT inline asm: the compiler then tracks lgkmcnt for the result and is
+// free to issue several reads back to back and to schedule MFMAs under them).  In each 16-lane group, lane i supplying the
+// address of T[p0 + (i >> 2)][c0 + 4 (i & 3)] (8 bytes) receives T[p0 .. p0+3][c0 + i]  (tools/probes/tr_read_probe.hip).
+typedef __attribute__((ext_vector_type(4))) short asr_s16x4_t;
+__device__ __forceinline__ uint2 asr_lds_read_tr16(const unsigned char* p) {
+  const asr_s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) asr_s16x4_t*)(uintptr_t)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
 // ---------------------------------------------------------------------------------------------- reductions
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

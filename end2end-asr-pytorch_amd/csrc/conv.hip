@@ -551,7 +551,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
 // fp32 mode uses one 4-byte read per MFMA operand element instead (k <-> lane group, conflict free).
 struct WgradNArgs {
   const void* x; const void* dy; float* dw; float* db;
+  float* ws;    // optional: per-workgroup partial dW blocks [gridDim.y][gridDim.x][9][64 co][64 ci] (two-stage reduction)
   int B, H, W, Cin, Cout, tiles_h, tiles_w, npatch, patches_per_wg, nci;
+  int ablate;   // tuning only (ASR_WGRAD_ABLATE): 1 = no global loads, 2 = no MFMA loop, 4 = no final atomics
 };
 
 template <typename T> struct WgPack;
@@ -563,9 +565,7 @@ template <> struct WgPack<bf16_t> {
                                                int dy, int dx) {
     const int y = 2 * ms + (g >> 1), x = 8 * (g & 1) + (lr >> 2);
     const unsigned char* p = tile + ((y + dy) * row_pitch_px + x + dx) * PITCH + (c0 + 4 * (lr & 3)) * 2;
-    uint2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"((uint32_t)(uintptr_t)p));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"((uint32_t)(uintptr_t)(p + 4 * PITCH)));
+    const uint2 lo = asr_lds_read_tr16(p), hi = asr_lds_read_tr16(p + 4 * PITCH);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   }
   static constexpr int NMS = 4;      // 128 pixels / 32
@@ -656,14 +656,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
   for (int patch = p_beg; patch < p_end; ++patch) {
     swrite();
     __syncthreads();
-    if (patch + 1 < p_end) gload(patch + 1);          // next patch's HBM latency hides under this patch's MFMAs
+    if (patch + 1 < p_end && !(p.ablate & 1)) gload(patch + 1);          // next patch's HBM latency hides under this patch's MFMAs
 #pragma unroll 1
-    for (int ms = 0; ms < WgPack<T>::NMS; ++ms) {
+    for (int ms = 0; ms < ((p.ablate & 2) ? 0 : WgPack<T>::NMS); ++ms) {
       uint4 a[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = WgPack<T>::template load<PP>(sD, ms, lr, g, i * 16, 16, 0, 0);
-      if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
       if (do_bias) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -675,8 +673,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         const uint4 bfr = WgPack<T>::template load<PP>(sX, ms, lr, g, wave * 16, 18, t / 3, t % 3);
-        if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) mma16<T>(acc[t][i], a[i], bfr);
       }
@@ -684,15 +680,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
     __syncthreads();
   }
 
+  if (p.ws) {
+    // two-stage reduction: 36,864 plain stores per workgroup instead of as many fp32 atomics on the same 147 KB of dW
+    // (measured: the atomics were > 50 % of this kernel's time); wgrad_reduce_kernel folds the partial blocks into dW
+    float* part = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64);
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + i * 16 + g * 4 + r, ci = ci0 + wave * 16 + lr;
-        atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + t, acc[t][i][r]);
-      }
+        for (int r = 0; r < 4; ++r) part[(t * 64 + i * 16 + g * 4 + r) * 64 + wave * 16 + lr] = acc[t][i][r];
+  } else {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + i * 16 + g * 4 + r, ci = ci0 + wave * 16 + lr;
+          if (!(p.ablate & 4) || acc[t][i][r] == 12345.f) atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + t, acc[t][i][r]);
+        }
+  }
   if (do_bias) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -702,6 +710,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
       if (g == 0) atomicAdd(p.db + co0 + i * 16 + lr, v);
     }
   }
+}
+
+// dW[co0+co][ci0+ci][t] += sum over this slice of the workgroup partials ws[by][wg][t][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* dw, int wgx, int nci, int Cin) {
+  const int e = blockIdx.x * 256 + threadIdx.x;          // element of the 9 x 64 x 64 block: (t, co, ci), ci fastest
+  const int by = blockIdx.y, slices = gridDim.z, sl = blockIdx.z;
+  const int per = (wgx + slices - 1) / slices;
+  const int w0 = sl * per, w1 = min(wgx, w0 + per);
+  const float* src = ws + ((int64_t)by * wgx) * (9 * 64 * 64) + e;
+  float acc = 0.f;
+  for (int w = w0; w < w1; ++w) acc += src[(int64_t)w * (9 * 64 * 64)];
+  const int ci = e & 63, co = (e >> 6) & 63, t = e >> 12;
+  const int co0 = (by / nci) * 64, ci0 = (by % nci) * 64;
+  atomicAdd(dw + ((int64_t)(co0 + co) * Cin + ci0 + ci) * 9 + t, acc);
 }
 
 // once per kernel instantiation (never during a stream capture: the first eager/warm-up launch does it)
@@ -904,8 +926,29 @@ extern "C" int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw, int
   return ASR_OK;
 }
 
-extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, float* db, int B, int H, int W, int Cin, int Cout,
-                                      int dtype, hipStream_t s) {
+namespace {
+// workgroups along the pixel axis (x) and dW blocks (y) of the NHWC weight-gradient launch
+void wgrad_grid(int B, int H, int W, int Cin, int Cout, int* wgx, int* blocks_y, int* patches_per_wg) {
+  const int npatch = B * ((H + 7) / 8) * ((W + 15) / 16);
+  *blocks_y = (Cout / 64) * (Cin / 64);
+  int gx = 512 / *blocks_y;                         // ~2 workgroups per CU in flight
+  if (gx < 1) gx = 1;
+  int ppw = (npatch + gx - 1) / gx;
+  if (ppw < 4) ppw = 4;
+  *patches_per_wg = ppw;
+  *wgx = (npatch + ppw - 1) / ppw;
+}
+}  // namespace
+
+extern "C" int64_t asr_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 != 0 || Cout % 64 != 0) return 0;
+  int wgx, by, ppw;
+  wgrad_grid(B, H, W, Cin, Cout, &wgx, &by, &ppw);
+  return (int64_t)wgx * by * 9 * 64 * 64;
+}
+
+extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, float* db, float* workspace,
+                                      int64_t workspace_floats, int B, int H, int W, int Cin, int Cout, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && dy && dw && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   if (Cin % 64 != 0 || Cout % 64 != 0 || !aligned16(x) || !aligned16(dy)) return ASR_EUNSUPPORTED;
@@ -916,17 +959,22 @@ extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, 
   p.tiles_h = (H + 7) / 8; p.tiles_w = (W + 15) / 16;
   p.npatch = B * p.tiles_h * p.tiles_w;
   p.nci = Cin / 64;
-  const int blocks_y = (Cout / 64) * p.nci;
-  int wgx = 512 / blocks_y;                         // ~2 workgroups per CU in flight
-  if (wgx < 1) wgx = 1;
-  p.patches_per_wg = (p.npatch + wgx - 1) / wgx;
-  if (p.patches_per_wg < 4) p.patches_per_wg = 4;
-  wgx = (p.npatch + p.patches_per_wg - 1) / p.patches_per_wg;
+  static const int ablate = getenv("ASR_WGRAD_ABLATE") ? atoi(getenv("ASR_WGRAD_ABLATE")) : 0;
+  p.ablate = ablate;
+  int wgx, blocks_y;
+  wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &p.patches_per_wg);
+  p.ws = (workspace && workspace_floats >= (int64_t)wgx * blocks_y * 9 * 64 * 64) ? workspace : nullptr;
   const int esz = dtype == ASR_F32 ? 4 : 2;
   const size_t lds = (size_t)(180 + 128) * (64 * esz + 16);
   AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
   if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_nhwc_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<float>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   else { allow_big_lds(conv3x3_wgrad_nhwc_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<bf16_t>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   ASR_LAUNCH_CHECK();
+  if (p.ws) {
+    const int slices = wgx >= 32 ? 8 : 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y, (unsigned)slices), dim3(256), 0, s, p.ws, dw, wgx,
+                       p.nci, Cin);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }

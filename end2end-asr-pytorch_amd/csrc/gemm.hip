@@ -351,11 +351,8 @@ template <> struct TnPack<bf16_t> {
   static __device__ __forceinline__ uint4 load(const unsigned char* tile, int m0, int lr, int g, int c0) {
     const int row = m0 + 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);          // this lane SUPPLIES 4 columns of one row
     const int chunk = col >> 3, half = (col >> 2) & 1;
-    uint2 lo, hi;
-    const uint32_t a0 = (uint32_t)(uintptr_t)(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
-    const uint32_t a1 = (uint32_t)(uintptr_t)(tile + (row + 4) * ROWB + ((chunk ^ ((row + 4) & 7)) << 4) + half * 8);
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+    const uint2 lo = asr_lds_read_tr16(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
+    const uint2 hi = asr_lds_read_tr16(tile + (row + 4) * ROWB + ((chunk ^ ((row + 4) & 7)) << 4) + half * 8);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   }
 };
@@ -445,8 +442,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     for (int i = 0; i < 4; ++i) a[i] = P::load(sA, wave * MS_ROWS, lr, g, i * 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b[j] = P::load(sB, wave * MS_ROWS, lr, g, j * 16);
-    if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
     if (do_colsum) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -575,8 +570,6 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) b[j] = P::template load<true>(sB, ms * (BKR / 2), lr, g, wn * WN + j * 16);
-      if (sizeof(T) == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll

@@ -195,8 +195,11 @@ int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw_acc, int B, int
 
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
  * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip).                          */
-int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw_acc, float* db_acc, int B, int H, int W, int Cin,
-                           int Cout, int dtype, asr_stream_t stream);
+/* workspace (fp32, >= asr_conv3x3_wgrad_workspace(...) elements, optional): per-workgroup partial dW blocks for a two-stage
+ * reduction; without it every workgroup adds its 36,864 partial sums with fp32 atomics (more than half of the kernel time) */
+int64_t asr_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
+int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw_acc, float* db_acc, float* workspace,
+                           int64_t workspace_floats, int B, int H, int W, int Cin, int Cout, int dtype, asr_stream_t stream);
 
 /* ---- emb_cnn front end (reference: models/asr/transformer.py:33-40: Conv2d(1,32,(41,11),(2,2),(0,10)) / BatchNorm2d /
  * Hardtanh(0,20) / Conv2d(32,32,(21,11),(2,1)) / BatchNorm2d / Hardtanh(0,20)), embcnn.hip.  The strided big-window
