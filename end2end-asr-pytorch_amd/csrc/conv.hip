@@ -135,21 +135,27 @@ struct ConvArgs {
 // prefetch).  Waves: (TH/4) along pixel rows x WN along Cout, each wave 4 pixel-row fragments x FN = NCO/(16 WN) Cout
 // fragments.  TH = 16 gives 4 x 4 (NCO 64) / 4 x 8 (NCO 128) fragments per wave: 2 / 2.7 MFMAs per LDS operand read
 // instead of 1.3 / 2 with TH = 8 -- the kernel is bound by LDS read bandwidth, not by the matrix cores.
-template <typename T, int NCO, int TH>
+template <typename T, int NCO, int TH, int TPS>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CPP = 64 / EPC;            // 16-B chunks per 64-channel pixel slice
-  constexpr int PP = 64 * ESZ + 16;        // LDS pitch of a pixel slice / weight row
+  // LDS rows (pixel slices / weight rows).  Cout 64: unpadded 128-byte rows, 16-B chunk c of row r in slot c ^ (r & 7) -- 39 KB,
+  // 4 workgroups per CU instead of 3 (+9 % measured).  Cout 128 (2 workgroups per CU either way): rows padded by 16 B.
+  constexpr bool SWZ = NCO == 64;
+  constexpr int PP = 64 * ESZ + (SWZ ? 0 : 16);
+#define ASR_SLOT(ROW, CH) ((SWZ ? ((CH) ^ ((ROW) & 7)) : (CH)) << 4)
   constexpr int NMS = 64 / (4 * EPC);      // macro steps per 64 channels
   constexpr int WM = TH / 4, WN = 4 / WM;  // wave grid
   constexpr int FN = NCO / (16 * WN);      // cout fragments per wave
-  constexpr int WCH = NCO * CPP / 256;     // weight chunks per thread
+  constexpr int WROWS = TPS * NCO;         // weight rows per step (TPS taps)
+  constexpr int WCH = WROWS * CPP / 256;   // weight chunks per thread
+  constexpr int SPS = (9 + TPS - 1) / TPS; // steps per 64-channel slice
   constexpr int NHALO = (TH + 2) * 18;     // halo pixels
   constexpr int NPX = TH * 16;             // output pixels
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sP = smem;
   unsigned char* sW0 = smem + NHALO * PP;         // weight tile, buffer 0
-  unsigned char* sW1 = sW0 + NCO * PP;            // buffer 1
+  unsigned char* sW1 = sW0 + WROWS * PP;          // buffer 1
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   const T* X = static_cast<const T*>(p.x);
   const T* Wk = static_cast<const T*>(p.wk);
   const int nchunk = p.Cin / 64;
-  const int nsteps = nchunk * 9;
+  const int nsteps = nchunk * SPS;
 
   f32x4_t acc[4][FN];
 #pragma unroll
@@ -169,20 +175,22 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  // weight tile (tap, 64-channel slice) : global -> registers -> LDS; the register copy lives for one iteration only
+  // weight tile (TPS taps, 64-channel slice): global -> registers -> LDS; the register copy lives for one iteration only.
+  // Row tt * NCO + co of the tile holds tap (first tap of the step + tt); a step past tap 8 loads nothing for that row.
 #define ASR_WLOAD(RW, STEP)                                                                                   \
   {                                                                                                           \
-    const int cc_ = (STEP) / 9, tap_ = (STEP) % 9;                                                            \
+    const int cc_ = (STEP) / SPS, tap0_ = ((STEP) % SPS) * TPS;                                               \
     _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                         \
-      const int c = tid + i * 256, co = c / CPP, ch = c % CPP;                                                \
-      RW[i] = *reinterpret_cast<const u32x4_t*>(Wk + ((int64_t)co * 9 + tap_) * p.Cin + cc_ * 64 + ch * EPC); \
+      const int c = tid + i * 256, row = c / CPP, ch = c % CPP, tt = row / NCO, co = row % NCO;               \
+      if (TPS == 1 || tap0_ + tt < 9)                                                                         \
+        RW[i] = *reinterpret_cast<const u32x4_t*>(Wk + ((int64_t)co * 9 + tap0_ + tt) * p.Cin + cc_ * 64 + ch * EPC); \
     }                                                                                                         \
   }
 #define ASR_WWRITE(RW, DST)                                                                                   \
   {                                                                                                           \
     _Pragma("unroll") for (int i = 0; i < WCH; ++i) {                                                         \
-      const int c = tid + i * 256, co = c / CPP, ch = c % CPP;                                                \
-      *reinterpret_cast<u32x4_t*>((DST) + co * PP + ch * 16) = RW[i];                                         \
+      const int c = tid + i * 256, row = c / CPP, ch = c % CPP;                                               \
+      *reinterpret_cast<u32x4_t*>((DST) + row * PP + ASR_SLOT(row, ch)) = RW[i];                                        \
     }                                                                                                         \
   }
   auto pstage = [&](int cc) __attribute__((always_inline)) {
@@ -192,59 +200,73 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && !(p.ablate & 1))
         v = *reinterpret_cast<const uint4*>(X + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cin + cc * 64 + ch * EPC);
-      *reinterpret_cast<uint4*>(sP + hp * PP + ch * 16) = v;
+      *reinterpret_cast<uint4*>(sP + hp * PP + ASR_SLOT(hp, ch)) = v;
     }
   };
 
   {
     u32x4_t rw0[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) rw0[i] = u32x4_t{0u, 0u, 0u, 0u};
     ASR_WLOAD(rw0, 0)
     ASR_WWRITE(rw0, sW0)
   }
 #pragma unroll 1
   for (int step = 0; step < nsteps; ++step) {
-    const int tap = step % 9;
-    if (tap == 0) {
+    const int sstep = step % SPS;
+    if (sstep == 0) {
       if (step > 0) __syncthreads();      // everybody is done with the previous channel slice of the patch
-      pstage(step / 9);
+      pstage(step / SPS);
       __syncthreads();                     // patch + weight buffer (step&1) visible
     }
     const bool has_next = step + 1 < nsteps;
     u32x4_t rw[WCH];
+#pragma unroll
+    for (int i = 0; i < WCH; ++i) rw[i] = u32x4_t{0u, 0u, 0u, 0u};
     if (has_next && !(p.ablate & 2)) ASR_WLOAD(rw, step + 1)
     const unsigned char* sW = (step & 1) ? sW1 : sW0;
-    const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-    for (int ms = 0; ms < NMS; ++ms) {
-      uint4 a[4], bfr[FN];
+    for (int tt = 0; tt < TPS; ++tt) {
+      const int tap = sstep * TPS + tt;
+      if (TPS > 1 && tap >= 9) break;
+      const int dy = tap / 3, dx = tap % 3;
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        a[i] = *reinterpret_cast<const uint4*>(sP + ((wm * 4 + i + dy) * 18 + lr + dx) * PP + (ms * 4 + g) * 16);
+      for (int ms = 0; ms < NMS; ++ms) {
+        uint4 a[4], bfr[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j)
-        bfr[j] = *reinterpret_cast<const uint4*>(sW + (wn * (NCO / WN) + j * 16 + lr) * PP + (ms * 4 + g) * 16);
-      if (!(p.ablate & 8)) {
+        for (int i = 0; i < 4; ++i) {
+          const int hp = (wm * 4 + i + dy) * 18 + lr + dx;
+          a[i] = *reinterpret_cast<const uint4*>(sP + hp * PP + ASR_SLOT(hp, ms * 4 + g));
+        }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < FN; ++j) {
+          const int row = tt * NCO + wn * (NCO / WN) + j * 16 + lr;
+          bfr[j] = *reinterpret_cast<const uint4*>(sW + row * PP + ASR_SLOT(row, ms * 4 + g));
+        }
+        if (!(p.ablate & 8)) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], bfr[j]);
-      } else {
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i].x));
+            for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], bfr[j]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(bfr[j].x));
+          for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i].x));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(bfr[j].x));
+        }
       }
     }
     if (has_next) {
       unsigned char* dst = (step & 1) ? sW0 : sW1;
       ASR_WWRITE(rw, dst)
-      // the next step either re-stages the patch (tap 8 -> barrier pair above) or needs this barrier
-      if (tap != 8) __syncthreads();
+      // the next step either re-stages the patch (last step of a slice -> barrier pair above) or needs this barrier
+      if (sstep != SPS - 1) __syncthreads();
     }
   }
 
 #undef ASR_WLOAD
 #undef ASR_WWRITE
+#undef ASR_SLOT
 
   // ---- epilogue through LDS: bias / ReLU on the accumulators, then the (NPX px, NCO) tile in the storage dtype -> per pixel
   // 16-byte channel-contiguous chunks, so that the mask reads and the NHWC stores are row-contiguous vector accesses
@@ -735,27 +757,29 @@ template <typename K> void allow_big_lds(K kernel, size_t lds) {
   }
 }
 
-template <typename T, int NCO, int TH>
+template <typename T, int NCO, int TH, int TPS>
 int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + 15) / 16;
-  size_t lds = (size_t)((TH + 2) * 18 + 2 * NCO) * (64 * sizeof(T) + 16);
+  size_t lds = (size_t)((TH + 2) * 18 + 2 * TPS * NCO) * (64 * sizeof(T) + (NCO == 64 ? 0 : 16));
   const size_t lds_epi = (size_t)(TH * 16) * (NCO * sizeof(T) + 16);
   if (lds_epi > lds) lds = lds_epi;
-  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH>, lds);
-  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
+  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS>, lds);
+  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH, TPS>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
-// tile height: 8 rows (3 / 2 workgroups per CU at NCO 64 / 128).  The 16-row tile does more MFMAs per LDS operand read but
-// its patch and accumulators cost a workgroup per CU; measured (profiles/r01_microbench_v3.txt) it only wins for 128 -> 64
-// channels, so it stays a tuning option (ASR_IGEMM_TH=16).
+// Tile height 8 rows (the 16-row tile does more MFMAs per LDS operand read but costs a workgroup per CU; it only wins for
+// 128 -> 64 channels, ASR_IGEMM_TH=16 keeps it as a tuning option).  ASR_IGEMM_TPS=2 stages TWO taps per step at Cout 64 (32
+// MFMAs between barriers) -- measured slower: it costs a workgroup per CU, and occupancy is what this kernel lives on.
 template <typename T, int NCO>
 int launch_igemm(const ConvArgs& a, hipStream_t s) {
-  static const int forced = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 0;
-  if (forced == 16 && sizeof(T) == 2) return launch_igemm_t<T, NCO, 16>(a, s);
-  return launch_igemm_t<T, NCO, 8>(a, s);
+  static const int th = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 8;
+  static const int tps = getenv("ASR_IGEMM_TPS") ? atoi(getenv("ASR_IGEMM_TPS")) : 1;
+  if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1>(a, s);
+  if (sizeof(T) == 2 && NCO == 64 && tps == 2) return launch_igemm_t<T, NCO, 8, 2>(a, s);
+  return launch_igemm_t<T, NCO, 8, 1>(a, s);
 }
 
 inline unsigned stream_grid(int64_t total_threads) {
