@@ -1,0 +1,129 @@
+"""KV-cached incremental decoding for models.asr.transformer.Decoder.
+
+The reference (models/asr/transformer.py:316-517) re-runs the WHOLE decoder over the growing prefix for every one of its
+300 greedy steps (and once per live hypothesis per step in beam search).  Decoding is causal, so position t of that
+re-run depends only on positions <= t; this module computes exactly that row: per layer the self-attention keys/values
+of the prefix are cached, the cross-attention keys/values of the encoder output are projected once, and a step pushes
+ONE token per sequence through the same HIP kernels (asr_gemm_nt / asr_attn_fwd / asr_add_ln_fwd) in the same operand
+order -- row t of the full recomputation and the cached step are the same arithmetic.
+
+Decode-time masks are the reference's: causal only for self attention, no encoder-length mask for cross attention
+(dec_enc_attn_mask=None, transformer.py:336-350); dropout off.
+"""
+import torch
+
+from . import functions as F_
+from . import ops
+from utils import constant
+
+
+class DecoderKVCache:
+    def __init__(self, decoder, encoder_padded_outputs, max_len, batch=None):
+        """encoder_padded_outputs (Be,Te,D).  batch: number of decoder rows (hypotheses); with Be == 1 the cross-attention
+        keys/values are shared by every row (stride-0 batch axis)."""
+        self.dec = decoder
+        cd = ops.compute_dtype()
+        enc = encoder_padded_outputs
+        if enc.dtype != cd:
+            enc = enc.to(cd)
+        enc = enc.contiguous()
+        Be, Te, D = enc.shape
+        self.B = Be if batch is None else batch
+        assert Be in (1, self.B)
+        self.H, self.dk = decoder.num_heads, decoder.dim_key
+        HD = self.H * self.dk
+        self.max_len = max_len
+        self.t = 0
+        dev = enc.device
+        self.cross, self.self_k, self.self_v = [], [], []
+        enc2 = enc.view(Be * Te, D)
+        for layer in decoder.layers:
+            a = layer.encoder_attn
+            k = F_._linear_fwd(enc2, a.key_linear.weight, a.key_linear.bias).view(Be, Te, HD)
+            v = F_._linear_fwd(enc2, a.value_linear.weight, a.value_linear.bias).view(Be, Te, HD)
+            if Be != self.B:
+                k, v = k.expand(self.B, Te, HD), v.expand(self.B, Te, HD)
+            self.cross.append((k, v))
+            self.self_k.append(torch.empty((self.B, max_len, HD), device=dev, dtype=cd))
+            self.self_v.append(torch.empty((self.B, max_len, HD), device=dev, dtype=cd))
+
+    # ------------------------------------------------------------------------------------------------ hypotheses
+    def select(self, rows):
+        """Keep / duplicate / reorder decoder rows (beam search: row i of the new state continues old row rows[i])."""
+        idx = torch.as_tensor(rows, device=self.self_k[0].device, dtype=torch.int64)
+        t = self.t
+        for i in range(len(self.self_k)):
+            nk = torch.empty((len(rows),) + tuple(self.self_k[i].shape[1:]), device=idx.device, dtype=self.self_k[i].dtype)
+            nv = torch.empty_like(nk)
+            nk[:, :t] = self.self_k[i][:, :t].index_select(0, idx)
+            nv[:, :t] = self.self_v[i][:, :t].index_select(0, idx)
+            self.self_k[i], self.self_v[i] = nk, nv
+            k, v = self.cross[i]
+            if k.stride(0) == 0:
+                self.cross[i] = (k[:1].expand(len(rows), -1, -1), v[:1].expand(len(rows), -1, -1))
+            else:
+                self.cross[i] = (k.index_select(0, idx), v.index_select(0, idx))
+        self.B = len(rows)
+
+    # ------------------------------------------------------------------------------------------------ one token
+    def _attend(self, attn_mod, x, q_in, k, v):
+        """MultiHeadAttention on one query row per sequence: out = LN(W_o . attn(q, K, V) + b_o + x)."""
+        B = x.shape[0]
+        HD = self.H * self.dk
+        o, _, _ = ops.attn_fwd(q_in.view(B, 1, HD), k, v, self.H, self.dk, scale=1.0 / (self.dk ** 0.5))
+        y = F_._linear_fwd(o.view(B, HD), attn_mod.output_linear.weight, attn_mod.output_linear.bias)
+        out, _, _ = ops.add_ln_fwd(y, x, attn_mod.layer_norm.weight.data, attn_mod.layer_norm.bias.data)
+        return out
+
+    @torch.no_grad()
+    def step(self, tokens):
+        """tokens (B,) int64: the input token at position self.t -> logits (B,V) fp32 for position self.t."""
+        dec = self.dec
+        t = self.t
+        if t >= self.max_len:
+            raise RuntimeError("decode position %d exceeds the cache length %d" % (t, self.max_len))
+        B = self.B
+        HD = self.H * self.dk
+        pe = dec.positional_encoding.pe[0]
+        x = ops.embed_fwd(tokens.view(B, 1).contiguous(), dec.trg_embedding.weight.data, pe[t:t + 1].contiguous(),
+                          dec.x_logit_scale, 0.0, 0, ops.compute_dtype()).view(B, -1)
+        for i, layer in enumerate(dec.layers):
+            sa = layer.self_attn
+            q = F_._linear_fwd(x, sa.query_linear.weight, sa.query_linear.bias)
+            # this position's key / value rows go straight into the cache (strided GEMM output)
+            kt, vt = self.self_k[i][:, t], self.self_v[i][:, t]
+            W, Wv = F_.P.linear_weight(sa.key_linear.weight), F_.P.linear_weight(sa.value_linear.weight)
+            xp = F_._pad_cols(x) if W.shape[1] != x.shape[1] else x
+            ops.gemm_nt(xp, W, bias=sa.key_linear.bias.data, out=kt)
+            ops.gemm_nt(xp, Wv, bias=sa.value_linear.bias.data, out=vt)
+            x = self._attend(sa, x, q, self.self_k[i][:, :t + 1], self.self_v[i][:, :t + 1])
+            ca = layer.encoder_attn
+            q = F_._linear_fwd(x, ca.query_linear.weight, ca.query_linear.bias)
+            x = self._attend(ca, x, q, self.cross[i][0], self.cross[i][1])
+            ff = layer.pos_ffn
+            w1, w2 = (ff.conv_1, ff.conv_2) if hasattr(ff, "conv_1") else (ff.linear_1, ff.linear_2)
+            h = F_._linear_fwd(x, w1.weight, w1.bias, relu=True)
+            y = F_._linear_fwd(h, w2.weight, w2.bias)
+            x, _, _ = ops.add_ln_fwd(y, x, ff.layer_norm.weight.data, ff.layer_norm.bias.data)
+        self.t = t + 1
+        return F_._linear_fwd(x, dec.output_linear.weight, None, out_dtype=torch.float32)
+
+
+@torch.no_grad()
+def greedy_search(decoder, encoder_padded_outputs, steps=300, check_every=16):
+    """Token ids (B, n<=steps) of the reference's greedy loop (transformer.py:316-394): argmax fed back for `steps`
+    positions.  The loop stops early once every sequence has produced EOS -- what follows an EOS is never read."""
+    B = encoder_padded_outputs.size(0)
+    dev = encoder_padded_outputs.device
+    cache = DecoderKVCache(decoder, encoder_padded_outputs, max_len=steps)
+    tok = torch.full((B,), constant.SOS_TOKEN, dtype=torch.int64, device=dev)
+    done = torch.zeros(B, dtype=torch.bool, device=dev)
+    out = []
+    for i in range(steps):
+        logits = cache.step(tok)
+        tok = ops.argmax_rows(logits)
+        out.append(tok)
+        done |= tok.eq(constant.EOS_TOKEN)
+        if (i + 1) % check_every == 0 and bool(done.all()):
+            break
+    return torch.stack(out, dim=1)

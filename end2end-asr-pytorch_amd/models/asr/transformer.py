@@ -202,7 +202,7 @@ class Decoder(nn.Module):
     def post_process_hyp(self, hyp):
         return "".join(self.id2label[int(x)] for x in hyp['yseq'][1:])
 
-    # ---- decoding (KV-cached HIP decode is the next scope row) -----------------------------
+    # ---- decoding: KV-cached by default, the reference's full re-run kept for equivalence tests ----
     def _step_logits(self, ys, encoder_padded_outputs):
         """Teacher-forced decoder pass over the prefix `ys` (B,t) with the reference's decode-time masks: causal only,
         no encoder-length mask (reference: transformer.py:336-350, dec_enc_attn_mask=None)."""
@@ -214,19 +214,26 @@ class Decoder(nn.Module):
         return F_.LinearFn.apply(x, self.output_linear.weight, None, True, False)
 
     @torch.no_grad()
-    def greedy_search(self, encoder_padded_outputs, beam_width=2, lm_rescoring=False, lm=None, lm_weight=0.1, c_weight=1):
-        """1-best strings, always 300 steps as the reference (transformer.py:316-394).  Needs --tgt-max-len >= 301."""
+    def greedy_search(self, encoder_padded_outputs, beam_width=2, lm_rescoring=False, lm=None, lm_weight=0.1, c_weight=1,
+                      use_cache=True):
+        """1-best strings of the reference's 300-step greedy loop (transformer.py:316-394).  Needs --tgt-max-len >= 301.
+        use_cache=True decodes incrementally with per-layer key/value caches (asr_hip/decode.py); False re-runs the full
+        decoder over the prefix at every step like the reference -- same tokens either way (tests/test_gpu_decode.py)."""
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
-        B = encoder_padded_outputs.size(0)
-        ys = torch.full((B, 1), constant.SOS_TOKEN, dtype=torch.int64, device=encoder_padded_outputs.device)
-        steps = []
-        for _ in range(300):
-            logits = self._step_logits(ys, encoder_padded_outputs)
-            nxt = ops.argmax_rows(logits[:, -1].contiguous())
-            steps.append(nxt)
-            ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
-        toks = torch.stack(steps, dim=1).cpu().tolist()       # one D2H copy instead of per-token .item()
+        if use_cache:
+            from asr_hip.decode import greedy_search as cached_greedy
+            toks = cached_greedy(self, encoder_padded_outputs, steps=300).cpu().tolist()
+        else:
+            B = encoder_padded_outputs.size(0)
+            ys = torch.full((B, 1), constant.SOS_TOKEN, dtype=torch.int64, device=encoder_padded_outputs.device)
+            steps = []
+            for _ in range(300):
+                logits = self._step_logits(ys, encoder_padded_outputs)
+                nxt = ops.argmax_rows(logits[:, -1].contiguous())
+                steps.append(nxt)
+                ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
+            toks = torch.stack(steps, dim=1).cpu().tolist()       # one D2H copy instead of per-token .item()
         sents = []
         for row in toks:
             st = ''
@@ -239,11 +246,14 @@ class Decoder(nn.Module):
 
     @torch.no_grad()
     def beam_search(self, encoder_padded_outputs, beam_width=2, nbest=5, lm_rescoring=False, lm=None, lm_weight=0.1,
-                    c_weight=1, prob_weight=1.0):
-        """Per-utterance beam search with the reference's scoring (transformer.py:396-517, LM branch excluded)."""
+                    c_weight=1, prob_weight=1.0, use_cache=True):
+        """Per-utterance beam search with the reference's scoring (transformer.py:396-517, LM branch excluded).  With
+        use_cache the live hypotheses of an utterance are one batch of the KV-cached decoder (one step = one token per
+        hypothesis); the candidate bookkeeping on the host is the reference's, including its in-loop re-sort (:460)."""
         import math
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
+        from asr_hip.decode import DecoderKVCache
         ids_out, strs_out = [], []
         max_len = encoder_padded_outputs.size(1)
         dev = encoder_padded_outputs.device
@@ -251,16 +261,25 @@ class Decoder(nn.Module):
             enc = encoder_padded_outputs[b:b + 1]
             hyps = [{'score': 0.0, 'yseq': [constant.SOS_TOKEN]}]
             ended = []
+            cache = DecoderKVCache(self, enc, max_len=300, batch=1) if use_cache else None
             for i in range(300):
+                if use_cache:
+                    last = torch.tensor([h['yseq'][-1] for h in hyps], dtype=torch.int64, device=dev)
+                    lp_all = torch.log_softmax(cache.step(last).float(), dim=1)
+                    best_all, idx_all = torch.topk(lp_all, beam_width, dim=1)
+                    best_all, idx_all = best_all.tolist(), idx_all.tolist()
                 cand = []
-                for hyp in hyps:
-                    ys = torch.tensor([hyp['yseq']], dtype=torch.int64, device=dev)
-                    logits = self._step_logits(ys, enc)[:, -1]
-                    lp = torch.log_softmax(logits.float(), dim=1)
-                    best, idx = torch.topk(lp, beam_width, dim=1)
-                    best, idx = best[0].tolist(), idx[0].tolist()
+                for hi, hyp in enumerate(hyps):
+                    if use_cache:
+                        best, idx = best_all[hi], idx_all[hi]
+                    else:
+                        ys = torch.tensor([hyp['yseq']], dtype=torch.int64, device=dev)
+                        logits = self._step_logits(ys, enc)[:, -1]
+                        lp = torch.log_softmax(logits.float(), dim=1)
+                        best, idx = torch.topk(lp, beam_width, dim=1)
+                        best, idx = best[0].tolist(), idx[0].tolist()
                     for j in range(beam_width):
-                        cand.append({'score': hyp['score'] + best[j], 'yseq': hyp['yseq'] + [idx[j]]})
+                        cand.append({'score': hyp['score'] + best[j], 'yseq': hyp['yseq'] + [idx[j]], 'parent': hi})
                     # the reference re-sorts the running candidate list inside the hypothesis loop (:460)
                     cand = sorted(cand, key=lambda h: h['score'], reverse=True)[:beam_width]
                 hyps = cand
@@ -281,6 +300,8 @@ class Decoder(nn.Module):
                 hyps = alive
                 if not hyps:
                     break
+                if use_cache:
+                    cache.select([h['parent'] for h in hyps])
             for hyp in sorted(ended, key=lambda h: h['final_score'], reverse=True)[:min(len(ended), nbest)]:
                 ids_out.append(hyp['yseq'])
                 strs_out.append(self.post_process_hyp(hyp))

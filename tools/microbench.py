@@ -148,10 +148,37 @@ def misc():
     print("  conv1_fwd %7.1f us  %.0f GB/s" % (us, x1.numel() * 2 / us / 1e3))
 
 
+def decode():
+    """greedy decode of configs[1]'s model: KV-cached vs the reference-style full re-run per step (B=32, T'=200)."""
+    import time
+    from utils import constant
+    from utils.functions import init_transformer_model
+    Vd = 4364
+    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(Vd - 3)]
+    l2i = {c: i for i, c in enumerate(chars)}
+    args = constant.parse(["--num-layers", "4", "--num-heads", "8", "--dim-model", "512", "--dim-key", "64", "--dim-value", "64",
+                           "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "301",
+                           "--src-max-len", "800", "--cuda"])
+    torch.manual_seed(1)
+    model = init_transformer_model(args, l2i, {i: c for c, i in l2i.items()}).cuda().eval()
+    enc = torch.randn(32, 200, 512, device=D)
+    print("== greedy decode, 300 steps, B=32, T'=200, 4 layers d512 (random weights: no early EOS)")
+    for cached in (True, False):
+        model.decoder.greedy_search(enc[:2], use_cache=cached)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model.decoder.greedy_search(enc, use_cache=cached)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("  %-28s %8.1f ms  (%.0f tokens/s)" % ("KV cache" if cached else "full re-run per step", dt * 1e3, 32 * 300 / dt))
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     for name, fn in (("gemm", gemm), ("conv", conv), ("wgrad", wgrad), ("attn", attn), ("misc", misc)):
         if which in (name, "all"):
             fn()
+    if which == "decode":
+        decode()
     if which == "attn800":          # the north-star shape only (encoder self-attention, T = 800, bs 32, dropout 0.1)
         attn([ATTN_CASES[5]])
