@@ -75,14 +75,16 @@ def gemm_tn_supported(dy, x):
             dy.stride(0) % epc == 0 and x.stride(0) % epc == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0):
+def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0, use_ws=True):
     """dw (N,K) fp32 += dy[:, :N]^T @ x[:, :K]; colsum_acc (N) += column sums of dy.  dy, x row-major (M, ld)."""
     M = dy.shape[0]
     N = dy.shape[1] if N is None else N
     K = x.shape[1] if K is None else K
     assert dw.dtype == torch.float32 and dw.stride(1) == 1 and dy.dtype == x.dtype
-    L.call("asr_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(dw), dw.stride(0), L.ptr(colsum_acc), M, N, K,
-           int(splits), L.dt(dy), L.stream())
+    n_ws = L.load().asr_gemm_tn_workspace(M, N, K, int(splits), L.dt(dy)) if use_ws else 0
+    ws = torch.empty(n_ws, device=dy.device, dtype=torch.float32) if n_ws else None
+    L.call("asr_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(dw), dw.stride(0), L.ptr(colsum_acc), L.ptr(ws),
+           n_ws, M, N, K, int(splits), L.dt(dy), L.stream())
 
 
 def gemm_nn_supported(dy, w):

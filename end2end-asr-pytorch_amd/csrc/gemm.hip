@@ -339,6 +339,7 @@ int dispatch_fast(const GemmArgs& a, int splits, hipStream_t s) {
 // the full 64x64 tile (16 operand reads feed 16 MFMAs), the four partial tiles are summed through LDS at the end.
 struct TnArgs {
   const void* A; const void* B; float* C; float* colsum;
+  float* ws;     // split over m with a workspace: partial 64x64 tiles [split][tile][64][64], folded by tn_reduce_kernel
   int64_t lda, ldb, ldc;
   int M, N, K, m_per_split, tiles_k, ntiles;
 };
@@ -480,6 +481,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
   }
   __syncthreads();
   const bool single = gridDim.x == (unsigned)p.ntiles;       // no split over m: plain read-modify-write
+  if (!single && p.ws) {
+    // two-stage reduction: the partial tile goes to the workspace with plain coalesced stores (fp32 atomics on C cost more
+    // than the MFMAs of a split), tn_reduce_kernel adds the slices into C
+    float* part = p.ws + ((int64_t)split * p.ntiles + tile) * 4096;
+    for (int c = tid; c < 64 * 16; c += 256) {
+      const int row = c >> 4, col = (c & 15) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float4 t = *reinterpret_cast<const float4*>(smem + w * 64 * CP + row * CP + col * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      *reinterpret_cast<float4*>(part + row * 64 + col) = v;
+    }
+  } else
   for (int c = tid; c < 64 * 16; c += 256) {
     const int row = c >> 4, col = (c & 15) * 4;
     const int gn = n0 + row, gk = k0 + col;
@@ -507,6 +523,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     atomicAdd(p.colsum + n0 + tid, s_col[0][tid] + s_col[1][tid] + s_col[2][tid] + s_col[3][tid]);
 }
 
+
+// C tile += sum over the m-slices of the partial tiles written by gemm_tn_kernel
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* C, int64_t ldc, int N, int K,
+                                                        int ntiles, int tiles_k, int splits) {
+  const int tile = blockIdx.x >> 2;
+  const int e = ((blockIdx.x & 3) * 256 + threadIdx.x) * 4;        // 4 consecutive columns of one row of the tile
+  const int row = e >> 6, col = e & 63;
+  const int gn = (tile / tiles_k) * 64 + row, gk = (tile % tiles_k) * 64 + col;
+  if (gn >= N || gk >= K) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4 t = *reinterpret_cast<const float4*>(ws + ((int64_t)sp * ntiles + tile) * 4096 + e);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  float* dst = C + (int64_t)gn * ldc + gk;
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (gk + i < K) dst[i] += vv[i];
+}
 
 // ================================================================================================ NN (data gradient)
 // C[M,N] (op)= alpha * sum_k A[m,k] * B[k,n]  with B = W (K_red, N_out) in its NATURAL master layout: dX = dY . W needs the
@@ -724,8 +760,39 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   return dispatch_tile<bf16_t, float>(p, splits, stream);
 }
 
+namespace {
+// slices over m: explicit, or automatic.  With a workspace the split costs one extra pass over splits*N*K floats, so the grid is
+// filled to ~2 workgroups per CU; without one the slices meet in fp32 atomics and are kept to the measured optimum (<= 4).
+int tn_splits(int M, int N, int K, int splits, int dtype, bool have_ws) {
+  const int rm = dtype == ASR_F32 ? 64 : 128;
+  const int ntiles = ((N + 63) / 64) * ((K + 63) / 64);
+  const int stages = (M + rm - 1) / rm;
+  if (splits <= 0) {
+    if (have_ws) {
+      splits = (512 + ntiles / 2) / ntiles;
+      if (splits > 8) splits = 8;
+      while (splits > 1 && stages / splits < 4) --splits;      // at least 4 stages per slice
+    } else {
+      splits = (160 + ntiles - 1) / ntiles;
+      if (splits > 4) splits = 4;
+    }
+  }
+  if (splits > stages) splits = stages;
+  if (splits < 1) splits = 1;
+  const int sps = (stages + splits - 1) / splits;
+  return (stages + sps - 1) / sps;
+}
+}  // namespace
+
+extern "C" int64_t asr_gemm_tn_workspace(int M, int N, int K, int splits, int dtype) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int sp = tn_splits(M, N, K, splits, dtype, true);
+  return sp > 1 ? (int64_t)sp * ((N + 63) / 64) * ((K + 63) / 64) * 4096 : 0;
+}
+
 extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc,
-                           int M, int N, int K, int splits, int dtype, hipStream_t stream) {
+                           float* workspace, int64_t workspace_floats, int M, int N, int K, int splits, int dtype,
+                           hipStream_t stream) {
   ASR_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   if (N == 0 || K == 0 || M == 0) return ASR_OK;
@@ -742,15 +809,14 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   p.tiles_k = (K + 63) / 64;
   p.ntiles = tiles_n * p.tiles_k;
   const int stages = (M + rm - 1) / rm;
-  if (splits <= 0) {                                  // auto: fill ~256-512 workgroups, atomics are the price
-    splits = (160 + p.ntiles - 1) / p.ntiles;        // measured optimum: ~128-256 workgroups, at most 4 slices
-    if (splits > 4) splits = 4;
-  }
-  if (splits > stages) splits = stages;
-  if (splits < 1) splits = 1;
+  const int64_t tile_floats = (int64_t)p.ntiles * 4096;
+  bool have_ws = workspace != nullptr && workspace_floats >= 2 * tile_floats;
+  const int want = tn_splits(M, N, K, splits, dtype, have_ws);
+  if (have_ws && workspace_floats < (int64_t)want * tile_floats) have_ws = false;
+  splits = have_ws ? want : tn_splits(M, N, K, splits, dtype, false);
   const int sps = (stages + splits - 1) / splits;
-  splits = (stages + sps - 1) / sps;
   p.m_per_split = sps * rm;
+  p.ws = (have_ws && splits > 1) ? workspace : nullptr;
   const size_t lds_stage = (size_t)2 * 2 * rm * (64 * esz);
   const size_t lds_epi = (size_t)4 * 64 * (64 * 4 + 16) + 4 * 64 * sizeof(float);
   const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
@@ -764,6 +830,11 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
     hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), dim3((unsigned)(p.ntiles * splits)), dim3(256), lds, stream, p);
   }
   ASR_LAUNCH_CHECK();
+  if (p.ws) {
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(p.ntiles * 4)), dim3(256), 0, stream, p.ws, C, ldc, N, K, p.ntiles, p.tiles_k,
+                       splits);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }
 

@@ -55,11 +55,15 @@ int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
                 asr_stream_t stream);
 
 /* Weight gradient without transposes: C[N,K] (fp32) += sum_m A[m*lda+n] * B[m*ldb+k]; colsum_acc[n] += sum_m A[m,n]
- * (bias gradient, optional).  A = dY (M,N), B = X (M,K) row-major as the forward produced them.  Needs M to be a multiple
- * of 128 (bf16) / 64 (fp32) and 16-byte aligned rows, else ASR_EUNSUPPORTED (callers fall back to asr_transpose +
- * asr_gemm_nt).  splits <= 0: automatic split over m (fp32 atomics).                                              */
-int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc, int M,
-                int N, int K, int splits, int dtype, asr_stream_t stream);
+ * (bias gradient, optional).  A = dY (M,N), B = X (M,K) row-major as the forward produced them.  Needs 16-byte aligned
+ * rows, else ASR_EUNSUPPORTED (callers fall back to asr_transpose + asr_gemm_nt); any M (a partial last stage is
+ * zero-filled in LDS).  splits <= 0: automatic split over m.  workspace (fp32, >= asr_gemm_tn_workspace(...) elements,
+ * optional): the m-slices write partial tiles there and a second kernel folds them into C; without it they meet in fp32
+ * atomics on C (slower, and limited to 4 slices).                                                                  */
+int64_t asr_gemm_tn_workspace(int M, int N, int K, int splits, int dtype);
+int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc,
+                float* workspace, int64_t workspace_floats, int M, int N, int K, int splits, int dtype,
+                asr_stream_t stream);
 
 /* Data gradient without transposed weights: C[M,N] (op)= alpha * sum_k A[m*lda+k] * B[k*ldb+n] with B = W (K,N) in its
  * master layout (transposing LDS reads).  flags: ASR_GEMM_ACCUMULATE; relu_mask as in asr_gemm_nt.  Needs K to be a
