@@ -376,59 +376,6 @@ def maxpool_bwd(x, dy, tcf=False):
     return dx
 
 
-_planar_ws = {}
-_rowoff_cache = {}
-
-
-def planar_workspace(tag, C, B, H, W, dtype, device, copies=1):
-    """Persistent zero-initialised planar buffer (pads must stay zero between uses; only real pixels are rewritten)."""
-    key = (tag, C, B, H, W, dtype, str(device), copies)
-    buf = _planar_ws.get(key)
-    if buf is None:
-        Np = L.load().asr_planar_size(B, H, W, L.dt_of(dtype))
-        buf = torch.zeros((copies, C, Np) if copies > 1 else (C, Np), device=device, dtype=dtype)
-        _planar_ws[key] = buf
-    return buf
-
-
-def nhwc_to_planar(x, tag, shifted3=False, chan_sum_acc=None):
-    """NHWC -> zero padded planar workspace; chan_sum_acc (fp32, C) optionally accumulates per-channel sums of x."""
-    B, H, W, C = x.shape
-    xp = planar_workspace(tag, C, B, H, W, x.dtype, x.device, copies=3 if shifted3 else 1)
-    L.call("asr_nhwc_to_planar", L.ptr(x), L.ptr(xp), B, H, W, C, int(shifted3), L.ptr(chan_sum_acc), L.dt(x), L.stream())
-    return xp
-
-
-def conv3x3_wgrad_gemm(x, dy, dw):
-    """dW (Cout,Cin,3,3) += sum_p dy[p,co] * x[p+tap,ci] as ONE split-K NT GEMM over the padded pixel axis:
-    A = planar dy (Cout, Np), B row (ci, tap) = shifted planar copy of x at an aligned offset (b_rowoff table)."""
-    B, H, W, Cin = x.shape
-    Cout = dy.shape[3]
-    lib = L.load()
-    dtc = L.dt(x)
-    WP, Np = lib.asr_planar_pitch(W, dtc), lib.asr_planar_size(B, H, W, dtc)
-    xp3 = nhwc_to_planar(x, "wg_x", shifted3=True)
-    dyp = nhwc_to_planar(dy, "wg_dy")
-    key = (Cin, Np, WP, str(x.device))
-    tab = _rowoff_cache.get(key)
-    if tab is None:
-        ci = torch.arange(Cin, dtype=torch.int64).repeat_interleave(9)
-        tap = torch.arange(9, dtype=torch.int64).repeat(Cin)
-        dyi, dxi = tap // 3, tap % 3
-        tab = (dxi * Cin * Np + ci * Np + (dyi - 1) * WP).to(x.device)
-        _rowoff_cache[key] = tab
-    k_beg = 2 * WP
-    K = B * (H + 1) * WP
-    bk = 32 if x.dtype == torch.float32 else 64
-    K = (K + bk - 1) // bk * bk                     # runs into the zero guard rows
-    tiles = ((Cout + 63) // 64) * ((9 * Cin + 63) // 64)
-    splits = max(1, min(512 // tiles, K // (8 * bk)))
-    a = dyp[:, k_beg:]
-    b = xp3.view(-1)[k_beg:]
-    L.call("asr_gemm_nt", L.ptr(a), Np, L.ptr(b), 0, L.ptr(dw), 9 * Cin, None, None, L.ptr(tab), Cout, 9 * Cin, K, 1.0,
-           L.GEMM_ACCUMULATE, splits, dtc, L.F32, L.stream())
-
-
 def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
     """dW (Cout,Cin,3,3) += , db (Cout) += from NHWC activations x (B,H,W,Cin) and gradients dy (B,H,W,Cout)."""
     B, H, W, Cin = x.shape
@@ -439,9 +386,6 @@ def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
     L.call("asr_conv3x3_wgrad_nhwc", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x),
            L.stream())
 
-
-def conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout):
-    L.call("asr_conv3x3_wgrad", L.ptr(xp), L.ptr(dyp), L.ptr(dw), B, H, W, Cin, Cout, L.dt(xp), L.stream())
 
 
 # ------------------------------------------------------------------------------------------------ emb_cnn front end

@@ -6,9 +6,9 @@
 //   asr_conv3x3_igemm : forward (+bias+ReLU) and dgrad (tap-flipped weights, ReLU mask of the consumer's input).
 //                       MFMA-bound: 2*9*Cin*Cout flop per output pixel; HBM bytes per pixel = (Cin + Cout)*sizeof(T)
 //                       (+ halo overlap 1.4x on the read side, served by L2).
-//   asr_conv3x3_wgrad : dW = dY^T . shift(X) over ~B*H*W pixels, split-K with fp32 atomics; operands are planar
-//                       zero-padded copies so every tap is a pure pointer shift (no boundary logic in the loop).
-//   conv1 / pooling / layout kernels are HBM-bound streaming kernels.
+//   asr_conv3x3_wgrad_nhwc : dW = dY^T . shift(X) over the B*H*W pixels straight from the NHWC tensors (transposing LDS
+//                       reads build the pixel-major MFMA operands); per-workgroup partial dW blocks meet in a workspace.
+//   conv1 / pooling kernels are HBM-bound streaming kernels.
 #include <stdlib.h>
 
 #include "common.h"
@@ -414,154 +414,6 @@ __global__ __launch_bounds__(256) void pool_bwd_edges_kernel(T* __restrict__ dx,
   }
 }
 
-// ================================================================================================ NHWC -> planar
-// block per (b, y, 64-wide x tile): (64 px, C) -> LDS -> C rows of 64 contiguous px.  Optionally also accumulates the
-// per-channel sums of the tile (= the conv bias gradient when x is dY) -- the tile is in LDS anyway.
-// shifted3: three copies copy0[p] = x[p-1], copy1[p] = x[p], copy2[p] = x[p+1] (positions never written stay zero).
-template <typename T>
-__global__ __launch_bounds__(256) void nhwc_to_planar_kernel(const T* __restrict__ x, T* __restrict__ xp, int B, int H, int W, int C,
-                                                             int64_t WP, int64_t Np, int tiles_w, int shifted3,
-                                                             float* __restrict__ chan_sum) {
-  extern __shared__ float sp[];     // [64][C+1]
-  int t = blockIdx.x;
-  const int tw = t % tiles_w; t /= tiles_w;
-  const int yh = t % H;
-  const int b = t / H;
-  const int x0 = tw * 64;
-  const int npx = min(64, W - x0);
-  const T* in = x + (((int64_t)b * H + yh) * W + x0) * (int64_t)C;
-  for (int i = threadIdx.x; i < 64 * C; i += 256) sp[(i / C) * (C + 1) + (i % C)] = i < npx * C ? DT<T>::ld(in + i) : 0.f;
-  __syncthreads();
-  const int64_t pbase = ((int64_t)b * (H + 1) + yh + 2) * WP + x0;
-  const int64_t CN = (int64_t)C * Np;
-  for (int i = threadIdx.x; i < C * 64; i += 256) {
-    const int px = i & 63, c = i >> 6;
-    const float v = sp[px * (C + 1) + c];
-    if (px < npx) {
-      T* d = xp + (int64_t)c * Np + pbase + px;
-      if (!shifted3) {
-        DT<T>::st(d, v);
-      } else {
-        DT<T>::st(d + 1, v);
-        DT<T>::st(d + CN, v);
-        DT<T>::st(d + 2 * CN - 1, v);
-      }
-    }
-    if (chan_sum) {                 // a wave = the 64 pixels of one channel
-      const float sum = wave_sum(v);
-      if (px == 0) atomicAdd(chan_sum + c, sum);
-    }
-  }
-}
-
-// ================================================================================================ wgrad
-struct WgradArgs {
-  const void* xp; const void* dyp; float* dw;
-  int Cin, Cout;
-  int64_t WP, Np, k_beg, k_end, k_per_slice;
-  int nci;     // Cin / 64
-};
-
-// workgroup: 64 output channels x (3x3 taps x 64 input channels) over one slice of the padded pixel axis.
-template <typename T>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(WgradArgs p) {
-  constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
-  constexpr int BKP = 64 / ESZ;            // pixels per stage: 64 data bytes per row
-  constexpr int NMS = BKP / (4 * EPC);     // macro steps per stage (bf16: 1, f32: 1)
-  constexpr int PW = 80;                   // LDS row pitch (64 data + 16 pad)
-  static_assert(NMS == 1, "one macro step per stage");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;                // 64 rows  (co)
-  unsigned char* sB = smem + 64 * PW;      // 576 rows (tap, ci)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
-  const int co0 = (blockIdx.y / p.nci) * 64, ci0 = (blockIdx.y % p.nci) * 64;
-  const T* Xp = static_cast<const T*>(p.xp);
-  const T* Dp = static_cast<const T*>(p.dyp);
-  const int64_t kb = p.k_beg + (int64_t)blockIdx.x * p.k_per_slice;
-  const int64_t ke = min(p.k_end, kb + p.k_per_slice);
-
-  f32x4_t acc[4][9];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // loader assignment: A: thread -> (row = tid/4, chunk = tid%4); B: 3 units per thread, unit u = tid + i*256 ->
-  // (dyi = u / 256, ci = (u % 256) / 4, chunk = u % 4)
-  uint4 ra; Chunk<T> rb[3]; T rprev[3], rnext[3];
-  auto gload = [&](int64_t k0) __attribute__((always_inline)) {
-    {
-      const int row = tid >> 2, ch = tid & 3;
-      const int64_t k = k0 + ch * EPC;
-      ra = k < ke ? *reinterpret_cast<const uint4*>(Dp + (int64_t)(co0 + row) * p.Np + k) : make_uint4(0u, 0u, 0u, 0u);
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int ci = tid >> 2, ch = tid & 3;
-      const int64_t k = k0 + ch * EPC;
-      const T* a = Xp + (int64_t)(ci0 + ci) * p.Np + k + (int64_t)(i - 1) * p.WP;
-      if (k < ke) {
-        rb[i].v = *reinterpret_cast<const uint4*>(a);
-        rprev[i] = a[-1];
-        rnext[i] = a[EPC];
-      } else {
-        rb[i].v = make_uint4(0u, 0u, 0u, 0u);
-        rprev[i] = T(0); rnext[i] = T(0);
-      }
-    }
-  };
-  auto swrite = [&]() __attribute__((always_inline)) {
-    {
-      const int row = tid >> 2, ch = tid & 3;
-      *reinterpret_cast<uint4*>(sA + row * PW + ch * 16) = ra;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const int ci = tid >> 2, ch = tid & 3;
-      Chunk<T> lo, hi;
-      lo.e[0] = rprev[i];
-#pragma unroll
-      for (int j = 1; j < EPC; ++j) lo.e[j] = rb[i].e[j - 1];
-#pragma unroll
-      for (int j = 0; j < EPC - 1; ++j) hi.e[j] = rb[i].e[j + 1];
-      hi.e[EPC - 1] = rnext[i];
-      *reinterpret_cast<uint4*>(sB + ((i * 3 + 0) * 64 + ci) * PW + ch * 16) = lo.v;     // dx = -1 : x[p-1]
-      *reinterpret_cast<uint4*>(sB + ((i * 3 + 1) * 64 + ci) * PW + ch * 16) = rb[i].v;  // dx =  0
-      *reinterpret_cast<uint4*>(sB + ((i * 3 + 2) * 64 + ci) * PW + ch * 16) = hi.v;     // dx = +1 : x[p+1]
-    }
-  };
-
-  if (kb < ke) gload(kb);
-  for (int64_t k0 = kb; k0 < ke; k0 += BKP) {
-    swrite();
-    __syncthreads();
-    if (k0 + BKP < ke) gload(k0 + BKP);
-    uint4 a[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(sA + (i * 16 + lr) * PW + g * 16);
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const uint4 bfr = *reinterpret_cast<const uint4*>(sB + (wave * 144 + j * 16 + lr) * PW + g * 16);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) mma16<T>(acc[i][j], a[i], bfr);
-    }
-    __syncthreads();
-  }
-
-#pragma unroll
-  for (int j = 0; j < 9; ++j) {
-    const int n = wave * 144 + j * 16 + lr;
-    const int tap = n >> 6, ci = ci0 + (n & 63);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + i * 16 + g * 4 + r;
-        atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + tap, acc[i][j][r]);
-      }
-  }
-}
-
 // ================================================================================================ wgrad, NHWC native
 // dW[co][ci][tap] += sum_px dY[px][co] * X[px + tap][ci]   straight from the NHWC tensors (no planar copies):
 // a workgroup owns a 64(co) x 64(ci) x 9(tap) block of dW and walks 8x16-pixel patches; per patch it stages the halo
@@ -791,9 +643,6 @@ inline unsigned stream_grid(int64_t total_threads) {
 
 }  // namespace
 
-extern "C" int64_t asr_planar_pitch(int W, int dtype) { (void)dtype; return ((int64_t)W + 1 + 7) / 8 * 8; }
-extern "C" int64_t asr_planar_size(int B, int H, int W, int dtype) { return ((int64_t)B * (H + 1) + 4) * asr_planar_pitch(W, dtype) + 128; }
-
 extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0, int dtype,
                              hipStream_t s) {
   ASR_CHECK_ARG(x && w && bias && y && B >= 0 && H > 0 && W > 0 && C0 > 0);
@@ -902,50 +751,6 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
     if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_nhwc_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
     else hipLaunchKernelGGL((pool_bwd_nhwc_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
   }
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
-}
-
-extern "C" int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, float* chan_sum_acc,
-                                  int dtype, hipStream_t s) {
-  ASR_CHECK_ARG(x && xp && B >= 0 && H > 0 && W > 0 && C > 0);
-  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
-  if (B == 0) return ASR_OK;
-  const int64_t WP = asr_planar_pitch(W, dtype), Np = asr_planar_size(B, H, W, dtype);
-  const int tiles_w = (W + 63) / 64;
-  const size_t lds = (size_t)64 * (C + 1) * sizeof(float);
-  AsrProfScope prof(ASR_OP_LAYOUT, s);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((nhwc_to_planar_kernel<float>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const float*)x, (float*)xp, B, H, W, C, WP, Np, tiles_w, shifted3, chan_sum_acc);
-  else hipLaunchKernelGGL((nhwc_to_planar_kernel<bf16_t>), dim3((unsigned)(B * H * tiles_w)), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)xp, B, H, W, C, WP, Np, tiles_w, shifted3, chan_sum_acc);
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
-}
-
-extern "C" int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw, int B, int H, int W, int Cin, int Cout, int dtype,
-                                 hipStream_t s) {
-  ASR_CHECK_ARG(xp && dyp && dw && B >= 0 && H > 0 && W > 0);
-  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
-  if (Cin % 64 != 0 || Cout % 64 != 0 || !aligned16(xp) || !aligned16(dyp)) return ASR_EUNSUPPORTED;
-  if (B == 0) return ASR_OK;
-  WgradArgs p{};
-  p.xp = xp; p.dyp = dyp; p.dw = dw; p.Cin = Cin; p.Cout = Cout;
-  p.WP = asr_planar_pitch(W, dtype); p.Np = asr_planar_size(B, H, W, dtype);
-  p.k_beg = 2 * p.WP;                                  // rows 0,1 are guard / zero rows (tap reads reach row-1, elem-1)
-  p.k_end = ((int64_t)B * (H + 1) + 2) * p.WP;          // two more guard rows follow
-  p.nci = Cin / 64;
-  const int bkp = dtype == ASR_F32 ? 16 : 32;
-  const int tiles = (Cout / 64) * p.nci;
-  int64_t slices = 768 / tiles;
-  if (slices < 1) slices = 1;
-  const int64_t klen = p.k_end - p.k_beg;
-  int64_t kps = ceil_div64(ceil_div64(klen, slices), bkp) * bkp;
-  if (kps < 4 * bkp) kps = 4 * bkp;
-  slices = ceil_div64(klen, kps);
-  p.k_per_slice = kps;
-  const size_t lds = (size_t)(64 + 576) * 80;
-  AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
-  if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_kernel<float>), dim3((unsigned)slices, (unsigned)tiles), dim3(256), lds, s, p); }
-  else { allow_big_lds(conv3x3_wgrad_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_kernel<bf16_t>), dim3((unsigned)slices, (unsigned)tiles), dim3(256), lds, s, p); }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

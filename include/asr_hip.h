@@ -183,20 +183,6 @@ int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_
 /* dx = scatter of dy to the first maximum of each window, times (x > 0); dy layout per in_tcf                   */
 int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
                     asr_stream_t stream);
-/* NHWC (B,H,W,C) -> planar zero-padded (C, Np): pixel (b,y,x) at plane offset ((b*(H+1)+y+2)*WP + x), WP =
- * asr_planar_pitch(W) >= W+1, one zero row between images, two guard rows at either end; Np = (B*(H+1)+4)*WP+128.
- * Pads must be zero: the caller zero-initialises the buffer once, the kernel only writes real pixels.
- * shifted3 != 0: xp is (3, C, Np) with copy0[p] = x[p-1], copy1[p] = x[p], copy2[p] = x[p+1], which turns the +-1
- * pixel taps of the weight-gradient contraction into 16-byte aligned pointer shifts (asr_gemm_nt + b_rowoff).    */
-int64_t asr_planar_pitch(int W, int dtype);
-int64_t asr_planar_size(int B, int H, int W, int dtype); /* Np, elements per channel plane                        */
-/* chan_sum_acc (fp32, C; optional): += per-channel sums of x (the conv bias gradient when x is dY).                */
-int asr_nhwc_to_planar(const void* x, void* xp, int B, int H, int W, int C, int shifted3, float* chan_sum_acc,
-                       int dtype, asr_stream_t stream);
-/* dW (Cout,Cin,3,3) += sum_p dy[p,co] * x[p+tap,ci] from planar operands (bias grad: asr_colsum_acc on NHWC dy)   */
-int asr_conv3x3_wgrad(const void* xp, const void* dyp, float* dw_acc, int B, int H, int W, int Cin, int Cout,
-                      int dtype, asr_stream_t stream);
-
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
  * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip).                          */
 /* workspace (fp32, >= asr_conv3x3_wgrad_workspace(...) elements, optional): per-workgroup partial dW blocks for a two-stage

@@ -448,14 +448,6 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     # dgrad, masked by the ReLU that produced x
     dx = ops.conv3x3(dy.to(D, dtype), wd, None, Cin, relu=False, mask_src=nhwc(x).to(D, dtype))
     close("conv3x3 dgrad", dx, nhwc(xr.grad * (x > 0)), dtype, scale=2)
-    # wgrad from planar operands
-    xp = ops.nhwc_to_planar(nhwc(x).to(D, dtype), "tx")
-    dbp = torch.zeros(Cout, device=D)
-    dyp = ops.nhwc_to_planar(dy.to(D, dtype), "tdy", chan_sum_acc=dbp)
-    close("conv3x3 db (fused into the planar pass)", dbp, br.grad, torch.float32, scale=16)
-    dw = torch.zeros(Cout, Cin, 3, 3, device=D)
-    ops.conv3x3_wgrad(xp, dyp, dw, B, H, W, Cin, Cout)
-    close("conv3x3 wgrad", dw, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
     db = torch.zeros(Cout, device=D)
     ops.colsum_acc(dy.to(D, dtype).view(-1, Cout), db)
     close("conv3x3 db", db, br.grad, torch.float32, scale=16)
@@ -464,18 +456,9 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     ops.conv3x3_wgrad_nhwc(nhwc(x).to(D, dtype), dy.to(D, dtype), dwn, dbn)
     close("conv3x3 wgrad (NHWC native)", dwn, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
     close("conv3x3 db (NHWC native)", dbn, br.grad, torch.float32, scale=16)
-    # shifted planar copies + one split-K GEMM with a B row-offset table
-    dwg = torch.zeros(Cout, Cin, 3, 3, device=D)
-    ops.conv3x3_wgrad_gemm(nhwc(x).to(D, dtype), dy.to(D, dtype), dwg)
-    close("conv3x3 wgrad (GEMM path)", dwg, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
-    ops.conv3x3_wgrad_gemm(nhwc(x).to(D, dtype), dy.to(D, dtype), dwg)
-    close("conv3x3 wgrad (GEMM path, accumulates)", dwg, 2 * wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
-    # run it twice through the persistent planar workspace: pads must still be zero
-    xp2 = ops.nhwc_to_planar(nhwc(x).to(D, dtype), "tx")
-    assert xp2.data_ptr() == xp.data_ptr()
-    dw2 = torch.zeros_like(dw)
-    ops.conv3x3_wgrad(xp2, dyp, dw2, B, H, W, Cin, Cout)
-    close("conv3x3 wgrad (2nd use of workspace)", dw2, wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
+    # accumulation into existing gradients, with and without the two-stage workspace
+    ops.conv3x3_wgrad_nhwc(nhwc(x).to(D, dtype), dy.to(D, dtype), dwn, dbn)
+    close("conv3x3 wgrad accumulates", dwn, 2 * wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

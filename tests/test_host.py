@@ -22,9 +22,10 @@ def test_library_loads_and_exports_header_symbols():
     assert set(syms) == set(lib._SIGS), set(syms) ^ set(lib._SIGS)
     assert h.asr_abi_version() == 1
     assert h.asr_strerror(-3).decode().startswith("unsupported")
-    # pure host helpers of the ABI (no device needed)
-    assert h.asr_planar_pitch(800, 1) == 808 and h.asr_planar_pitch(7, 0) == 8
-    assert h.asr_planar_size(32, 161, 800, 1) == (32 * 162 + 4) * 808 + 128
+    # pure host helpers of the ABI (no device needed): workspace sizes
+    assert h.asr_add_ln_bwd_workspace(6400, 512) == 800 * 1024
+    assert h.asr_conv3x3_wgrad_workspace(32, 161, 800, 64, 64) == 510 * 9 * 64 * 64      # 33600 patches, 66 per workgroup
+    assert h.asr_gemm_tn_workspace(6400, 2048, 512, 0, 1) == 2 * 256 * 4096
 
 
 def test_product_path_has_no_cpu_fallback():

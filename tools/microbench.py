@@ -84,24 +84,14 @@ def conv():
 
 
 def wgrad():
-    print("== conv3x3 wgrad (B,H,W,Cin,Cout) bf16  (+ nhwc_to_planar)")
+    print("== conv3x3 wgrad (B,H,W,Cin,Cout) bf16, NHWC native kernel + two-stage dW reduction")
     for B, H, W, Ci, Co in [(32, 161, 800, 64, 64), (32, 80, 400, 64, 128), (32, 80, 400, 128, 128)]:
         x = torch.randn(B, H, W, Ci, device=D).bfloat16()
         dy = torch.randn(B, H, W, Co, device=D).bfloat16()
-        us_p = timeit(lambda: ops.nhwc_to_planar(x, "mbx"), iters=10)
-        xp = ops.nhwc_to_planar(x, "mbx")
-        dyp = ops.nhwc_to_planar(dy, "mbdy")
         dw = torch.zeros(Co, Ci, 3, 3, device=D)
-        us = timeit(lambda: ops.conv3x3_wgrad(xp, dyp, dw, B, H, W, Ci, Co), iters=10)
-        fl = 2 * 9 * Ci * Co * B * H * W
         dbb = torch.zeros(Co, device=D)
         us_n = timeit(lambda: ops.conv3x3_wgrad_nhwc(x, dy, dw, dbb), iters=10)
         print("  wgrad-NHWC %s %8.1f us  %7.1f TF/s" % ((B, H, W, Ci, Co), us_n, 2 * 9 * Ci * Co * B * H * W / us_n / 1e6))
-        us_g = timeit(lambda: ops.conv3x3_wgrad_gemm(x, dy, dw), iters=10)
-        us_p3 = timeit(lambda: ops.nhwc_to_planar(x, "wg_x", shifted3=True), iters=10)
-        print("  wgrad-gemm path total %8.1f us (%6.1f TF/s incl. layout)   planar3(x) %7.1f us" % (us_g, fl / us_g / 1e6, us_p3))
-        print("  wgrad %s %8.1f us  %7.1f TF/s   planar(x) %7.1f us (%.0f GB/s)" %
-              ((B, H, W, Ci, Co), us, fl / us / 1e6, us_p, 2 * x.numel() * 2 / us_p / 1e3))
 
 
 ATTN_CASES = [(32, 8, 200, 200, 64, False, 0.0), (32, 8, 200, 200, 64, False, 0.1), (32, 8, 100, 100, 64, True, 0.1),
