@@ -27,7 +27,7 @@ _SIGS = {
     "asr_abi_version": (_I, []),
     "asr_prof_enable": (_I, [_I, _I]),
     "asr_prof_collect": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
-    "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
+    "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
     "asr_gemm_tn_workspace": (_L, [_I, _I, _I, _I, _I]),
     "asr_gemm_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "asr_gemm_nn": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _I, _I, _I, _P]),

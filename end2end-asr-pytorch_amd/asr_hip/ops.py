@@ -50,11 +50,11 @@ def _pad8(n):
 
 # ------------------------------------------------------------------------------------------------ dense
 def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, splits=1, out_dtype=None, K=None,
-            relu_mask=None, b_rowoff=None, N=None):
+            relu_mask=None, N=None):
     """C[M,N] (+)= alpha * A[M,K] . B[N,K]^T (+bias) ; A, B 2-D with unit inner stride (row stride arbitrary)."""
     assert A.dim() == 2 and B.dim() == 2 and A.stride(1) == 1 and B.stride(1) == 1 and A.dtype == B.dtype
     M = A.shape[0]
-    N = (b_rowoff.numel() if b_rowoff is not None else B.shape[0]) if N is None else N
+    N = B.shape[0] if N is None else N
     K = A.shape[1] if K is None else K
     if out is None:
         out = torch.empty((M, N), device=A.device, dtype=out_dtype or A.dtype)
@@ -64,7 +64,7 @@ def gemm_nt(A, B, out=None, bias=None, relu=False, accumulate=False, alpha=1.0, 
         assert relu_mask.dtype == A.dtype and relu_mask.stride(0) == out.stride(0) and relu_mask.stride(1) == 1
     flags = (L.GEMM_RELU if relu else 0) | (L.GEMM_ACCUMULATE if accumulate else 0)
     L.call("asr_gemm_nt", L.ptr(A), A.stride(0), L.ptr(B), B.stride(0), L.ptr(out), out.stride(0), L.ptr(bias),
-           L.ptr(relu_mask), L.ptr(b_rowoff), M, N, K, float(alpha), flags, int(splits), L.dt(A), L.dt(out), L.stream())
+           L.ptr(relu_mask), M, N, K, float(alpha), flags, int(splits), L.dt(A), L.dt(out), L.stream())
     return out
 
 

@@ -13,7 +13,7 @@
 namespace {
 
 struct GemmArgs {
-  const void* A; const void* B; void* C; const float* bias; const void* mask; const int64_t* b_rowoff;
+  const void* A; const void* B; void* C; const float* bias; const void* mask;
   int64_t lda, ldb, ldc;
   int M, N, K;
   int k_per_split;     // multiple of BK
@@ -160,27 +160,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs p) {
 // Requirements: 16-B aligned operands, lda/ldb multiples of a 16-B chunk, every K range a multiple of BK (128 bytes).
 template <int ROWS>
 __device__ __forceinline__ void stage_glds(unsigned char* lds_stage, const unsigned char* gbase, int64_t ld_bytes,
-                                           const int64_t* rowoff, int esz, int row0, int row_limit, int64_t kbyte0, int tid,
+                                           int row0, int row_limit, int64_t kbyte0, int tid,
                                            int wave) {
 #pragma unroll
   for (int i = 0; i < ROWS * 8 / 256; ++i) {
     const int c = i * 256 + tid, row = c >> 3, slot = (c & 7) ^ (row & 7);
     int gr = row0 + row;
     gr = gr < row_limit ? gr : row_limit - 1;                       // clamp: rows past the edge are never stored
-    const int64_t roff = rowoff ? rowoff[gr] * esz : (int64_t)gr * ld_bytes;
-    const unsigned char* src = gbase + roff + kbyte0 + slot * 16;
+    const unsigned char* src = gbase + (int64_t)gr * ld_bytes + kbyte0 + slot * 16;
     unsigned char* dst = lds_stage + (i * 256 + wave * 64) * 16;    // wave-uniform; the DMA adds lane * 16
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
   }
 }
 
-template <typename T, typename TO, int BM, int BN>
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NS LDS stages, NS-1 K steps of LDS-DMA in flight (NS = 2 is the default; 3 / 4 via ASR_GEMM_NS).  A deeper pipeline needs
+// counted s_waitcnt vmcnt(N), a RAW s_barrier (__syncthreads() carries a fence that drains every pending LDS-DMA write) and
+// operand reads the compiler cannot see (see the asm block below).  Measured (profiles/r01_microbench_v3.txt, MI355X): with
+// all of that in place 3 and 4 stages are SLOWER than 2 on every shape of this model (6400x512x512: 13.0 / 15.8 / 16.6 us;
+// K = 5120: 59 / 70 / 68 us): the 64x64 tile moves 32 flop per byte through L2 (17 TB/s at K = 5120), so the kernel lives on
+// workgroups per CU, and each extra stage costs one.
+template <typename T, typename TO, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   constexpr int ESZ = (int)sizeof(T);
   constexpr int BKB = 128;                       // bytes of K per stage row
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
   constexpr int STAGE = (BM + BN) * BKB;
+  constexpr int LPS = (BM + BN) * 8 / 256;       // LDS-DMA instructions per thread per stage
   constexpr int CPITCH = BN * 4 + 16;            // fp32 C tile staged in LDS for the epilogue
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -209,38 +217,74 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
     unsigned char* s = smem + buf * STAGE;
     const int64_t kb = (kbeg * ESZ) + (int64_t)kt * BKB;
-    stage_glds<BM>(s, A, p.lda * ESZ, nullptr, ESZ, m0, p.M, kb, tid, wave);
-    stage_glds<BN>(s + BM * BKB, B, p.ldb * ESZ, p.b_rowoff, ESZ, n0, p.N, kb, tid, wave);
+    stage_glds<BM>(s, A, p.lda * ESZ, m0, p.M, kb, tid, wave);
+    stage_glds<BN>(s + BM * BKB, B, p.ldb * ESZ, n0, p.N, kb, tid, wave);
   };
 
-  if (nk > 0) stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nk) stage(st, st);
+  int buf = 0;                                   // LDS stage of K step kt
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const unsigned char* sA = smem + (kt & 1) * STAGE;
+    // this thread's DMA of step kt has landed once at most the later steps' loads are outstanding
+    const int ahead = min(NS - 2, nk - 1 - kt);
+    if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * LPS>();
+    else if (NS >= 3 && ahead >= 1) wait_vmcnt<LPS>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                // step kt visible to all waves; everybody is done reading step kt-1
+    if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);      // refill the stage step kt-1 used
+    const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + BM * BKB;
+    if constexpr (FM == 2 && FN == 2 && NS > 2) {
+      // Operand fragments by inline asm: for a compiler-visible LDS read the waitcnt pass cannot tell the read apart from the
+      // LDS-DMA writes still in flight for later stages and inserts s_waitcnt vmcnt(0) -- which serialises the pipeline again.
+      // One block = the 8 reads of this K step + the wait for them; rows i*16 apart share their swizzle slot (offset:2048).
+      const int ra = wm * WM + lr, rb = wn * WN + lr;
+      const uint32_t aa0 = (uint32_t)(uintptr_t)(sA + ra * BKB + ((g ^ (ra & 7)) << 4));
+      const uint32_t aa1 = (uint32_t)(uintptr_t)(sA + ra * BKB + (((4 + g) ^ (ra & 7)) << 4));
+      const uint32_t ab0 = (uint32_t)(uintptr_t)(sB + rb * BKB + ((g ^ (rb & 7)) << 4));
+      const uint32_t ab1 = (uint32_t)(uintptr_t)(sB + rb * BKB + (((4 + g) ^ (rb & 7)) << 4));
+      u32x4_t fa[2][2], fb[2][2];                  // [ms][fragment]
+      asm volatile(
+          "ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:2048\n\t"
+          "ds_read_b128 %2, %10\n\tds_read_b128 %3, %10 offset:2048\n\t"
+          "ds_read_b128 %4, %9\n\tds_read_b128 %5, %9 offset:2048\n\t"
+          "ds_read_b128 %6, %11\n\tds_read_b128 %7, %11 offset:2048\n\t"
+          "s_waitcnt lgkmcnt(0)"
+          : "=&v"(fa[0][0]), "=&v"(fa[0][1]), "=&v"(fb[0][0]), "=&v"(fb[0][1]), "=&v"(fa[1][0]), "=&v"(fa[1][1]), "=&v"(fb[1][0]),
+            "=&v"(fb[1][1])
+          : "v"(aa0), "v"(aa1), "v"(ab0), "v"(ab1)
+          : "memory");
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-      uint4 a[FM], b[FN];
+      for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int r = wm * WM + i * 16 + lr;
-        a[i] = *reinterpret_cast<const uint4*>(sA + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            mma16<T>(acc[i][j], __builtin_bit_cast(uint4, fa[ms][i]), __builtin_bit_cast(uint4, fb[ms][j]));
+    } else {
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        uint4 a[FM], b[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int r = wm * WM + i * 16 + lr;
+          a[i] = *reinterpret_cast<const uint4*>(sA + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int r = wn * WN + j * 16 + lr;
+          b[j] = *reinterpret_cast<const uint4*>(sB + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], b[j]);
       }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int r = wn * WN + j * 16 + lr;
-        b[j] = *reinterpret_cast<const uint4*>(sB + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
-      }
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], b[j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    buf = buf + 1 == NS ? 0 : buf + 1;
   }
+  __syncthreads();                               // all waves are done with the operand stages before the epilogue reuses them
 
   // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> row-contiguous 16-byte global accesses
 #pragma unroll
@@ -295,24 +339,31 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   }
 }
 
-template <typename T, typename TO, int BM, int BN>
-int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
+template <typename T, typename TO, int BM, int BN, int NS>
+int launch_fast_ns(const GemmArgs& a, int splits, hipStream_t s) {
   GemmArgs p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   p.ntiles = tiles_m * p.tiles_n;
   dim3 grid((unsigned)(p.ntiles * splits), 1, 1);
-  size_t lds = (size_t)2 * (BM + BN) * 128;
+  size_t lds = (size_t)NS * (BM + BN) * 128;
   const size_t cl = (size_t)BM * (BN * 4 + 16);
   if (cl > lds) lds = cl;
   static bool granted = false;
   if (lds > 48 * 1024 && !granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<T, TO, BM, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<T, TO, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     granted = true;
   }
-  hipLaunchKernelGGL((gemm_glds_kernel<T, TO, BM, BN>), grid, dim3(256), lds, s, p);
+  hipLaunchKernelGGL((gemm_glds_kernel<T, TO, BM, BN, NS>), grid, dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
+}
+template <typename T, typename TO, int BM, int BN>
+int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
+  static const int ns = getenv("ASR_GEMM_NS") ? atoi(getenv("ASR_GEMM_NS")) : 2;      // LDS stages (tuning hook)
+  if (ns == 3) return launch_fast_ns<T, TO, BM, BN, 3>(a, splits, s);
+  if (ns == 4) return launch_fast_ns<T, TO, BM, BN, 4>(a, splits, s);
+  return launch_fast_ns<T, TO, BM, BN, 2>(a, splits, s);
 }
 
 template <typename T, typename TO>
@@ -577,7 +628,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
 
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
     unsigned char* s = smem + buf * STAGE;
-    stage_glds<BM>(s, A, p.lda * ESZ, nullptr, ESZ, m0, p.M, (int64_t)kt * BKB, tid, wave);
+    stage_glds<BM>(s, A, p.lda * ESZ, m0, p.M, (int64_t)kt * BKB, tid, wave);
     unsigned char* sb = s + BM * BKB;
 #pragma unroll
     for (int i = 0; i < BKR * P::CPR / 256; ++i) {
@@ -705,7 +756,7 @@ int dispatch_tile(const GemmArgs& a, int splits, hipStream_t s) {
 }  // namespace
 
 extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                           const float* bias, const void* relu_mask, const int64_t* b_rowoff, int M, int N, int K,
+                           const float* bias, const void* relu_mask, int M, int N, int K,
                            float alpha, int flags, int splits, int in_dtype, int out_dtype, hipStream_t stream) {
   ASR_CHECK_ARG(A && B && C && M >= 0 && N >= 0 && K >= 0);
   if (M == 0 || N == 0) return ASR_OK;
@@ -714,7 +765,7 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   ASR_CHECK_ARG(!(in_dtype == ASR_F32 && out_dtype == ASR_BF16));
   const int esz = in_dtype == ASR_F32 ? 4 : 2, epc = 16 / esz, bk = 128 / esz;
   GemmArgs p{};
-  p.A = A; p.B = B; p.C = C; p.bias = bias; p.mask = relu_mask; p.b_rowoff = b_rowoff;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.mask = relu_mask;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;
   p.M = M; p.N = N; p.K = K;
   p.alpha = alpha;
@@ -747,14 +798,13 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0) && (oesz == 4 || ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
   // fast path: LDS-DMA staging needs whole 16-B chunks everywhere and whole 128-byte K steps
-  const bool fast = p.vecA && (b_rowoff ? aligned16(B) : p.vecB) && K > 0 && (K % bk == 0) && (kps % bk == 0) &&
+  const bool fast = p.vecA && p.vecB && K > 0 && (K % bk == 0) && (kps % bk == 0) &&
                     getenv("ASR_GEMM_GENERIC") == nullptr;
   if (fast) {
     if (in_dtype == ASR_F32) return dispatch_fast<float, float>(p, splits, stream);
     if (out_dtype == ASR_BF16) return dispatch_fast<bf16_t, bf16_t>(p, splits, stream);
     return dispatch_fast<bf16_t, float>(p, splits, stream);
   }
-  if (b_rowoff) return ASR_EUNSUPPORTED;
   if (in_dtype == ASR_F32) return dispatch_tile<float, float>(p, splits, stream);
   if (out_dtype == ASR_BF16) return dispatch_tile<bf16_t, bf16_t>(p, splits, stream);
   return dispatch_tile<bf16_t, float>(p, splits, stream);

@@ -50,7 +50,6 @@ int asr_prof_collect(int op_id, double* total_ms, int64_t* launches); /* synchro
  * transformer.py:172 (input_linear), :302 (output_linear) and their autograd backward.                        */
 int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const float* bias,
                 const void* relu_mask /* optional (M,ldc) tensor of the input dtype: C = 0 where relu_mask <= 0 */,
-                const int64_t* b_rowoff /* optional device table: row n of B starts at B + b_rowoff[n] elements */,
                 int M, int N, int K, float alpha, int flags, int splits, int in_dtype, int out_dtype,
                 asr_stream_t stream);
 
