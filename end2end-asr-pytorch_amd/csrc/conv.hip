@@ -16,92 +16,131 @@
 namespace {
 
 // ================================================================================================ conv1 (Cin = 1)
-// A thread keeps the 9 taps + bias of its EPC output channels in registers and walks pixels; the C0/EPC threads of a
-// pixel are adjacent lanes, so the NHWC store is one contiguous C0*sizeof(T) run per pixel and the 9 input loads are
-// broadcast within the group.  HBM bound: writes B*H*W*C0*sizeof(T) bytes (528 MB at B=32, bf16).
-template <typename T>
-__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int H,
-                                                        int W, int C0) {
-  constexpr int EPC = DT<T>::EPC;
-  const int groups = C0 / EPC;                // 256 % groups == 0
-  const int cg = threadIdx.x % groups;
-  float wr[EPC][9], br[EPC];
+// Direct convolution on the vector ALU, HBM bound (528 MB of bf16 activations written / read at B = 32).  A thread owns EPC
+// output channels (taps + bias in registers) and walks QUADS of 4 horizontally adjacent pixels: the 3 x 6 input window of a
+// quad is loaded once (4.5 instead of 9 input loads per pixel, bounds handled by clamped addresses + selects), channel
+// pairs are packed fp32 (v_pk_fma_f32).  The C0/EPC threads of a quad are adjacent lanes, so a pixel's NHWC row is one
+// contiguous C0*sizeof(T) run.
+typedef __attribute__((ext_vector_type(2))) float asr_f32x2_t;
+constexpr int C1_PW = 4;
+
+__device__ __forceinline__ void conv1_window(const float* __restrict__ x, int64_t b, int yh, int x0, int H, int W,
+                                             float (*in)[C1_PW + 2]) {
 #pragma unroll
-  for (int j = 0; j < EPC; ++j) {
-    br[j] = bias[cg * EPC + j];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = yh + ky - 1;
+    const bool rowok = yy >= 0 && yy < H;
+    const float* xr = x + (b * H + (rowok ? yy : yh)) * (int64_t)W;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wr[j][t] = w[(cg * EPC + j) * 9 + t];
-  }
-  const int64_t npix = (int64_t)B * H * W;
-  const int ppb = 256 / groups;
-  for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / groups; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
-    const int64_t b = pix / ((int64_t)W * H);
-    float in[9];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int yy = yh + ky - 1, xx = xw + kx - 1;
-        in[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(b * H + yy) * W + xx] : 0.f;
-      }
-    Chunk<T> o;
-#pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-      float a = br[j];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) a += wr[j][t] * in[t];
-      o.e[j] = DT<T>::to(fmaxf(a, 0.f));
+    for (int k = 0; k < C1_PW + 2; ++k) {
+      const int xx = x0 + k - 1;
+      const bool ok = rowok && xx >= 0 && xx < W;
+      const float v = xr[xx < 0 ? 0 : (xx < W ? xx : W - 1)];
+      in[ky][k] = ok ? v : 0.f;
     }
-    *reinterpret_cast<uint4*>(y + pix * C0 + cg * EPC) = o.v;
   }
 }
 
 template <typename T>
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, T* __restrict__ y, int B, int H,
+                                                        int W, int C0) {
+  constexpr int EPC = DT<T>::EPC, NP = EPC / 2;
+  const int groups = C0 / EPC;                // 256 % groups == 0
+  const int cg = threadIdx.x % groups;
+  asr_f32x2_t wr[NP][9], br[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    br[j] = asr_f32x2_t{bias[cg * EPC + 2 * j], bias[cg * EPC + 2 * j + 1]};
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[j][t] = asr_f32x2_t{w[(cg * EPC + 2 * j) * 9 + t], w[(cg * EPC + 2 * j + 1) * 9 + t]};
+  }
+  const int wq = (W + C1_PW - 1) / C1_PW;
+  const int64_t nquad = (int64_t)B * H * wq;
+  const int qpb = 256 / groups;
+  for (int64_t quad = (int64_t)blockIdx.x * qpb + threadIdx.x / groups; quad < nquad; quad += (int64_t)gridDim.x * qpb) {
+    const int x0 = (int)(quad % wq) * C1_PW, yh = (int)((quad / wq) % H);
+    const int64_t b = quad / ((int64_t)wq * H);
+    float in[3][C1_PW + 2];
+    conv1_window(x, b, yh, x0, H, W, in);
+#pragma unroll
+    for (int px = 0; px < C1_PW; ++px) {
+      if (x0 + px >= W) break;
+      Chunk<T> o;
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        asr_f32x2_t a = br[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float v = in[ky][px + kx];
+            a += wr[j][ky * 3 + kx] * asr_f32x2_t{v, v};
+          }
+        o.e[2 * j] = DT<T>::to(fmaxf(a[0], 0.f));
+        o.e[2 * j + 1] = DT<T>::to(fmaxf(a[1], 0.f));
+      }
+      *reinterpret_cast<uint4*>(y + (((b * H + yh) * (int64_t)W) + x0 + px) * C0 + cg * EPC) = o.v;
+    }
+  }
+}
+
+// dw[c][tap] += sum_px dy[px][c] * x[px + tap], db[c] += sum_px dy[px][c]: same quad walk, per-thread accumulators for
+// its EPC channels, then LDS atomics per block and one global atomic per (block, element).
+template <typename T>
 __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const T* __restrict__ dy,
                                                           float* dw, float* db, int B, int H, int W, int C0) {
-  constexpr int EPC = DT<T>::EPC;
+  constexpr int EPC = DT<T>::EPC, NP = EPC / 2;
   extern __shared__ float sacc[];     // [C0*10]
   for (int i = threadIdx.x; i < C0 * 10; i += 256) sacc[i] = 0.f;
   __syncthreads();
   const int groups = C0 / EPC;        // 256 % groups == 0 -> a thread keeps its channel group across the loop
   const int cg = threadIdx.x % groups;
-  float aw[EPC][9], ab[EPC];
+  asr_f32x2_t aw[NP][9], ab[NP];
 #pragma unroll
-  for (int j = 0; j < EPC; ++j) { ab[j] = 0.f;
+  for (int j = 0; j < NP; ++j) {
+    ab[j] = asr_f32x2_t{0.f, 0.f};
 #pragma unroll
-    for (int t = 0; t < 9; ++t) aw[j][t] = 0.f; }
-  const int64_t npix = (int64_t)B * H * W;
-  const int ppb = 256 / groups;
-  for (int64_t pix = (int64_t)blockIdx.x * ppb + threadIdx.x / groups; pix < npix; pix += (int64_t)gridDim.x * ppb) {
-    const int xw = (int)(pix % W), yh = (int)((pix / W) % H);
-    const int64_t b = pix / ((int64_t)W * H);
-    Chunk<T> d;
-    d.v = *reinterpret_cast<const uint4*>(dy + pix * C0 + cg * EPC);
-    float in[9];
+    for (int t = 0; t < 9; ++t) aw[j][t] = asr_f32x2_t{0.f, 0.f};
+  }
+  const int wq = (W + C1_PW - 1) / C1_PW;
+  const int64_t nquad = (int64_t)B * H * wq;
+  const int qpb = 256 / groups;
+  for (int64_t quad = (int64_t)blockIdx.x * qpb + threadIdx.x / groups; quad < nquad; quad += (int64_t)gridDim.x * qpb) {
+    const int x0 = (int)(quad % wq) * C1_PW, yh = (int)((quad / wq) % H);
+    const int64_t b = quad / ((int64_t)wq * H);
+    Chunk<T> d[C1_PW];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int yy = yh + ky - 1, xx = xw + kx - 1;
-        in[ky * 3 + kx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? x[(b * H + yy) * W + xx] : 0.f;
-      }
-#pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-      const float g = DT<T>::from(d.e[j]);
-      ab[j] += g;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) aw[j][t] += g * in[t];
+    for (int px = 0; px < C1_PW; ++px) {
+      d[px].v = make_uint4(0u, 0u, 0u, 0u);
+      if (x0 + px < W) d[px].v = *reinterpret_cast<const uint4*>(dy + (((b * H + yh) * (int64_t)W) + x0 + px) * C0 + cg * EPC);
     }
+    float in[3][C1_PW + 2];
+    conv1_window(x, b, yh, x0, H, W, in);
+#pragma unroll
+    for (int px = 0; px < C1_PW; ++px)
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const asr_f32x2_t g = asr_f32x2_t{DT<T>::from(d[px].e[2 * j]), DT<T>::from(d[px].e[2 * j + 1])};
+        ab[j] += g;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const float v = in[ky][px + kx];
+            aw[j][ky * 3 + kx] += g * asr_f32x2_t{v, v};
+          }
+      }
   }
 #pragma unroll
-  for (int j = 0; j < EPC; ++j) {
-    const int c = cg * EPC + j;
-    atomicAdd(&sacc[C0 * 9 + c], ab[j]);
+  for (int j = 0; j < NP; ++j)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) atomicAdd(&sacc[c * 9 + t], aw[j][t]);
-  }
+    for (int h = 0; h < 2; ++h) {
+      const int c = cg * EPC + 2 * j + h;
+      atomicAdd(&sacc[C0 * 9 + c], ab[j][h]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) atomicAdd(&sacc[c * 9 + t], aw[j][t][h]);
+    }
   __syncthreads();
   for (int i = threadIdx.x; i < C0 * 10; i += 256) {
     if (i < C0 * 9) atomicAdd(dw + i, sacc[i]);
@@ -651,8 +690,8 @@ extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, 
   if (C0 % epc != 0 || !aligned16(y)) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
   if (256 % (C0 / epc) != 0) return ASR_EUNSUPPORTED;
-  const int64_t total = (int64_t)B * H * W * (C0 / epc);
-  unsigned grid1 = stream_grid(total / 8);
+  const int64_t total = (int64_t)B * H * ((W + 3) / 4) * (C0 / epc);      // one thread per (pixel quad, channel group)
+  unsigned grid1 = stream_grid(total / 4);
   AsrProfScope prof(ASR_OP_CONV1, s);
   if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float>), dim3(grid1), dim3(256), 0, s, x, w, bias, (float*)y, B, H, W, C0);
   else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t>), dim3(grid1), dim3(256), 0, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
@@ -667,10 +706,10 @@ extern "C" int asr_conv1_wgrad(const float* x, const void* dy, float* dw, float*
   const int epc = dtype == ASR_F32 ? 4 : 8;
   if (C0 % epc != 0 || 256 % (C0 / epc) != 0 || !aligned16(dy)) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
-  const int64_t npix = (int64_t)B * H * W;
-  const int ppb = 256 / (C0 / epc);
-  int64_t blocks = ceil_div64(npix, (int64_t)ppb * 64);
-  if (blocks > 2048) blocks = 2048;
+  const int64_t nquad = (int64_t)B * H * ((W + 3) / 4);
+  const int qpb = 256 / (C0 / epc);
+  int64_t blocks = ceil_div64(nquad, (int64_t)qpb * 16);
+  if (blocks > 1024) blocks = 1024;       // every block ends with C0*10 same-address global atomics
   if (blocks < 1) blocks = 1;
   const size_t lds = (size_t)C0 * 10 * sizeof(float);
   AsrProfScope prof(ASR_OP_CONV1, s);
