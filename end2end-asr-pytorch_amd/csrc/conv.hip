@@ -174,7 +174,7 @@ struct ConvArgs {
 // prefetch).  Waves: (TH/4) along pixel rows x WN along Cout, each wave 4 pixel-row fragments x FN = NCO/(16 WN) Cout
 // fragments.  TH = 16 gives 4 x 4 (NCO 64) / 4 x 8 (NCO 128) fragments per wave: 2 / 2.7 MFMAs per LDS operand read
 // instead of 1.3 / 2 with TH = 8 -- the kernel is bound by LDS read bandwidth, not by the matrix cores.
-template <typename T, int NCO, int TH, int TPS>
+template <typename T, int NCO, int TH, int TPS, int WBUF>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CPP = 64 / EPC;            // 16-B chunks per 64-channel pixel slice
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sP = smem;
   unsigned char* sW0 = smem + NHALO * PP;         // weight tile, buffer 0
-  unsigned char* sW1 = sW0 + WROWS * PP;          // buffer 1
+  unsigned char* sW1 = WBUF == 2 ? sW0 + WROWS * PP : sW0;   // buffer 1 (WBUF == 1: one weight buffer, an extra barrier per step)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
@@ -297,6 +297,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     }
     if (has_next) {
       unsigned char* dst = (step & 1) ? sW0 : sW1;
+      if (WBUF == 1) __syncthreads();       // single buffer: everybody must be done reading this step's weights first
       ASR_WWRITE(rw, dst)
       // the next step either re-stages the patch (last step of a slice -> barrier pair above) or needs this barrier
       if (sstep != SPS - 1) __syncthreads();
@@ -648,29 +649,33 @@ template <typename K> void allow_big_lds(K kernel, size_t lds) {
   }
 }
 
-template <typename T, int NCO, int TH, int TPS>
+template <typename T, int NCO, int TH, int TPS, int WBUF>
 int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + 15) / 16;
-  size_t lds = (size_t)((TH + 2) * 18 + 2 * TPS * NCO) * (64 * sizeof(T) + (NCO == 64 ? 0 : 16));
+  size_t lds = (size_t)((TH + 2) * 18 + WBUF * TPS * NCO) * (64 * sizeof(T) + (NCO == 64 ? 0 : 16));
   const size_t lds_epi = (size_t)(TH * 16) * (NCO * sizeof(T) + 16);
   if (lds_epi > lds) lds = lds_epi;
-  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS>, lds);
-  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH, TPS>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
+  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>, lds);
+  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
 // Tile height 8 rows (the 16-row tile does more MFMAs per LDS operand read but costs a workgroup per CU; it only wins for
 // 128 -> 64 channels, ASR_IGEMM_TH=16 keeps it as a tuning option).  ASR_IGEMM_TPS=2 stages TWO taps per step at Cout 64 (32
 // MFMAs between barriers) -- measured slower: it costs a workgroup per CU, and occupancy is what this kernel lives on.
+// Weights are SINGLE buffered in LDS (prefetched in registers): one more barrier per step, but one more workgroup per CU --
+// +9 % (Cout 64) to +23 % (Cout 128) measured; ASR_IGEMM_WBUF=2 restores the double buffer.
 template <typename T, int NCO>
 int launch_igemm(const ConvArgs& a, hipStream_t s) {
   static const int th = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 8;
   static const int tps = getenv("ASR_IGEMM_TPS") ? atoi(getenv("ASR_IGEMM_TPS")) : 1;
-  if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1>(a, s);
-  if (sizeof(T) == 2 && NCO == 64 && tps == 2) return launch_igemm_t<T, NCO, 8, 2>(a, s);
-  return launch_igemm_t<T, NCO, 8, 1>(a, s);
+  static const int wbuf = getenv("ASR_IGEMM_WBUF") ? atoi(getenv("ASR_IGEMM_WBUF")) : 1;
+  if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1, 2>(a, s);
+  if (sizeof(T) == 2 && NCO == 64 && tps == 2) return launch_igemm_t<T, NCO, 8, 2, 2>(a, s);
+  if (wbuf == 1) return launch_igemm_t<T, NCO, 8, 1, 1>(a, s);
+  return launch_igemm_t<T, NCO, 8, 1, 2>(a, s);
 }
 
 inline unsigned stream_grid(int64_t total_threads) {
