@@ -427,7 +427,7 @@ template <> struct TnPack<float> {
   }
 };
 
-template <typename T>
+template <typename T, int NBUF>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
   using P = TnPack<T>;
   constexpr int ESZ = (int)sizeof(T);
@@ -475,16 +475,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
   const bool do_colsum = p.colsum != nullptr && k0 == 0;
 
-  if (nstage > 0) stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // NBUF == 2: the next stage's LDS-DMA overlaps this stage's MFMAs.  NBUF == 1: load, wait, compute -- half the LDS, twice the
+  // workgroups per CU, and the overlap comes from the other workgroups (measured faster, like every occupancy trade here).
+  if (NBUF == 2) {
+    if (nstage > 0) stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   for (int st = 0; st < nstage; ++st) {
-    if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
-    const unsigned char* sA = smem + (st & 1) * STAGE;
+    if (NBUF == 2) {
+      if (st + 1 < nstage) stage(st + 1, (st + 1) & 1);
+    } else {
+      stage(st, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    const int cur = NBUF == 2 ? (st & 1) : 0;
+    const unsigned char* sA = smem + cur * STAGE;
     const unsigned char* sB = sA + P::RM * P::ROWB;
     const int valid = m_end - (m_beg + st * P::RM);          // rows of this stage that exist (uniform over the workgroup)
     if (valid < P::RM) {
-      unsigned char* zA = smem + (st & 1) * STAGE;
+      unsigned char* zA = smem + cur * STAGE;
       for (int c = valid * (P::ROWB / 16) + tid; c < P::RM * (P::ROWB / 16); c += 256)
         *reinterpret_cast<uint4*>(zA + c * 16) = make_uint4(0u, 0u, 0u, 0u);
       __syncthreads();
@@ -510,17 +521,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     __syncthreads();
   }
 
-  // ---- sum the four waves' partial tiles through LDS, then row-contiguous fp32 accumulation into C
+  // ---- sum the four waves' partial tiles (tree, in fragment layout: lane-private slots, no index math), then wave 0 lays the
+  // total out row-major for 16-byte row-contiguous accumulation into C.  32 KB of LDS instead of four 17 KB tiles.
   constexpr int CP = 64 * 4 + 16;
-  float* part = reinterpret_cast<float*>(smem + wave * 64 * CP);
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        *reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(part) + (i * 16 + g * 4 + r) * CP + (j * 16 + lr) * 4) = acc[i][j][r];
-  float (*s_col)[64] = reinterpret_cast<float (*)[64]>(smem + 4 * 64 * CP);     // (all LDS in the one dynamic array)
+  float* slot = reinterpret_cast<float*>(smem);                 // [2][64 values][64 lanes]
+  float (*s_col)[64] = reinterpret_cast<float (*)[64]>(smem + 2 * 64 * 64 * 4);
   if (do_colsum) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -530,6 +535,39 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
       if (g == 0) s_col[wave][i * 16 + lr] = v;
     }
   }
+  auto put = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[(sl * 64 + (i * 4 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+  };
+  auto add = [&](int sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] += slot[(sl * 64 + (i * 4 + j) * 4 + r) * 64 + lane];
+  };
+  if (wave & 1) put(wave >> 1);
+  __syncthreads();
+  if (!(wave & 1)) add(wave >> 1);
+  __syncthreads();
+  if (wave == 2) put(0);
+  __syncthreads();
+  if (wave == 0) add(0);
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<float*>(smem + (i * 16 + g * 4 + r) * CP + (j * 16 + lr) * 4) = acc[i][j][r];
+  }
   __syncthreads();
   const bool single = gridDim.x == (unsigned)p.ntiles;       // no split over m: plain read-modify-write
   if (!single && p.ws) {
@@ -538,25 +576,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
     float* part = p.ws + ((int64_t)split * p.ntiles + tile) * 4096;
     for (int c = tid; c < 64 * 16; c += 256) {
       const int row = c >> 4, col = (c & 15) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float4 t = *reinterpret_cast<const float4*>(smem + w * 64 * CP + row * CP + col * 4);
-        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-      }
-      *reinterpret_cast<float4*>(part + row * 64 + col) = v;
+      *reinterpret_cast<float4*>(part + row * 64 + col) = *reinterpret_cast<const float4*>(smem + row * CP + col * 4);
     }
   } else
   for (int c = tid; c < 64 * 16; c += 256) {
     const int row = c >> 4, col = (c & 15) * 4;
     const int gn = n0 + row, gk = k0 + col;
     if (gn >= p.N || gk >= p.K) continue;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float4 t = *reinterpret_cast<const float4*>(smem + w * 64 * CP + row * CP + col * 4);
-      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-    }
+    const float4 v = *reinterpret_cast<const float4*>(smem + row * CP + col * 4);
     float* dst = p.C + (int64_t)gn * p.ldc + gk;
     const int nv = min(4, p.K - gk);
     const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -814,12 +841,13 @@ namespace {
 // slices over m: explicit, or automatic.  With a workspace the split costs one extra pass over splits*N*K floats, so the grid is
 // filled to ~2 workgroups per CU; without one the slices meet in fp32 atomics and are kept to the measured optimum (<= 4).
 int tn_splits(int M, int N, int K, int splits, int dtype, bool have_ws) {
+  static const int ASR_TN_TARGET_WGS = getenv("ASR_TN_WGS") ? atoi(getenv("ASR_TN_WGS")) : 512;
   const int rm = dtype == ASR_F32 ? 64 : 128;
   const int ntiles = ((N + 63) / 64) * ((K + 63) / 64);
   const int stages = (M + rm - 1) / rm;
   if (splits <= 0) {
     if (have_ws) {
-      splits = (512 + ntiles / 2) / ntiles;
+      splits = (ASR_TN_TARGET_WGS + ntiles / 2) / ntiles;
       if (splits > 8) splits = 8;
       while (splits > 1 && stages / splits < 4) --splits;      // at least 4 stages per slice
     } else {
@@ -867,18 +895,21 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   const int sps = (stages + splits - 1) / splits;
   p.m_per_split = sps * rm;
   p.ws = (have_ws && splits > 1) ? workspace : nullptr;
-  const size_t lds_stage = (size_t)2 * 2 * rm * (64 * esz);
-  const size_t lds_epi = (size_t)4 * 64 * (64 * 4 + 16) + 4 * 64 * sizeof(float);
+  static const int nbuf = getenv("ASR_TN_NBUF") ? atoi(getenv("ASR_TN_NBUF")) : 1;       // LDS stages (tuning hook)
+  const size_t lds_stage = (size_t)(nbuf == 2 ? 2 : 1) * 2 * rm * (64 * esz);
+  const size_t lds_epi = (size_t)2 * 64 * 64 * 4 + 4 * 64 * sizeof(float);
   const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
   AsrProfScope prof(ASR_OP_GEMM, stream);
-  static bool granted[2] = {false, false};
-  if (dtype == ASR_F32) {
-    if (!granted[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted[0] = true; }
-    hipLaunchKernelGGL((gemm_tn_kernel<float>), dim3((unsigned)(p.ntiles * splits)), dim3(256), lds, stream, p);
-  } else {
-    if (!granted[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); granted[1] = true; }
-    hipLaunchKernelGGL((gemm_tn_kernel<bf16_t>), dim3((unsigned)(p.ntiles * splits)), dim3(256), lds, stream, p);
+  const dim3 grid((unsigned)(p.ntiles * splits));
+#define ASR_TN_LAUNCH(T_, NB_)                                                                                                  \
+  {                                                                                                                              \
+    static bool granted = false;                                                                                                 \
+    if (!granted) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_kernel<T_, NB_>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); granted = true; } \
+    hipLaunchKernelGGL((gemm_tn_kernel<T_, NB_>), grid, dim3(256), lds, stream, p);                                              \
   }
+  if (dtype == ASR_F32) { if (nbuf == 2) ASR_TN_LAUNCH(float, 2) else ASR_TN_LAUNCH(float, 1) }
+  else { if (nbuf == 2) ASR_TN_LAUNCH(bf16_t, 2) else ASR_TN_LAUNCH(bf16_t, 1) }
+#undef ASR_TN_LAUNCH
   ASR_LAUNCH_CHECK();
   if (p.ws) {
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(p.ntiles * 4)), dim3(256), 0, stream, p.ws, C, ldc, N, K, p.ntiles, p.tiles_k,
