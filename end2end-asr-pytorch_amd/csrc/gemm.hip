@@ -176,12 +176,12 @@ __device__ __forceinline__ void stage_glds(unsigned char* lds_stage, const unsig
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// NS LDS stages, NS-1 K steps of LDS-DMA in flight (NS = 2 is the default; 3 / 4 via ASR_GEMM_NS).  A deeper pipeline needs
-// counted s_waitcnt vmcnt(N), a RAW s_barrier (__syncthreads() carries a fence that drains every pending LDS-DMA write) and
-// operand reads the compiler cannot see (see the asm block below).  Measured (profiles/r01_microbench_v3.txt, MI355X): with
-// all of that in place 3 and 4 stages are SLOWER than 2 on every shape of this model (6400x512x512: 13.0 / 15.8 / 16.6 us;
-// K = 5120: 59 / 70 / 68 us): the 64x64 tile moves 32 flop per byte through L2 (17 TB/s at K = 5120), so the kernel lives on
-// workgroups per CU, and each extra stage costs one.
+// NS LDS stages (default ONE; 2 / 3 / 4 via ASR_GEMM_NS), NS-1 K steps of LDS-DMA in flight.  A deeper pipeline needs counted
+// s_waitcnt vmcnt(N), a RAW s_barrier (__syncthreads() carries a fence that drains every pending LDS-DMA write) and operand
+// reads the compiler cannot see (see the asm block below).  Measured (profiles/r01_microbench_v4.txt, MI355X): with all of that
+// in place, MORE stages are SLOWER on every shape of this model -- 6400x2048x512: 33.0 / 39.6 / 44 / 55 us for 1 / 2 / 3 / 4
+// stages; 3200x4364x512: 37.9 / 47.9 / 53 / 66 us.  The 64x64 tile moves 32 flop per byte through L2, the kernel lives on
+// workgroups per CU (8 at one stage), and the other workgroups hide the load latency better than a private prefetch queue.
 template <typename T, typename TO, int BM, int BN, int NS>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   constexpr int ESZ = (int)sizeof(T);
@@ -226,13 +226,17 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
     if (st < nk) stage(st, st);
   int buf = 0;                                   // LDS stage of K step kt
   for (int kt = 0; kt < nk; ++kt) {
+    if (NS == 1) {                               // one stage: load, wait, compute; the overlap comes from the other workgroups
+      if (kt > 0) __builtin_amdgcn_s_barrier(); // everybody is done reading step kt-1
+      stage(kt, 0);
+    }
     // this thread's DMA of step kt has landed once at most the later steps' loads are outstanding
     const int ahead = min(NS - 2, nk - 1 - kt);
     if (NS >= 4 && ahead >= 2) wait_vmcnt<2 * LPS>();
     else if (NS >= 3 && ahead >= 1) wait_vmcnt<LPS>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();                // step kt visible to all waves; everybody is done reading step kt-1
-    if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);      // refill the stage step kt-1 used
+    if (NS > 1 && kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);      // refill the stage step kt-1 used
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + BM * BKB;
     if constexpr (FM == 2 && FN == 2 && NS > 2) {
@@ -360,10 +364,11 @@ int launch_fast_ns(const GemmArgs& a, int splits, hipStream_t s) {
 }
 template <typename T, typename TO, int BM, int BN>
 int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
-  static const int ns = getenv("ASR_GEMM_NS") ? atoi(getenv("ASR_GEMM_NS")) : 2;      // LDS stages (tuning hook)
+  static const int ns = getenv("ASR_GEMM_NS") ? atoi(getenv("ASR_GEMM_NS")) : 1;      // LDS stages (tuning hook)
+  if (ns == 2) return launch_fast_ns<T, TO, BM, BN, 2>(a, splits, s);
   if (ns == 3) return launch_fast_ns<T, TO, BM, BN, 3>(a, splits, s);
   if (ns == 4) return launch_fast_ns<T, TO, BM, BN, 4>(a, splits, s);
-  return launch_fast_ns<T, TO, BM, BN, 2>(a, splits, s);
+  return launch_fast_ns<T, TO, BM, BN, 1>(a, splits, s);
 }
 
 template <typename T, typename TO>
@@ -667,12 +672,13 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
     }
   };
 
-  if (nk > 0) stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // one LDS stage: load, wait, compute (see gemm_glds_kernel: workgroups per CU beat a private prefetch queue here)
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const unsigned char* sA = smem + (kt & 1) * STAGE;
+    if (kt > 0) __syncthreads();                 // everybody is done reading step kt-1
+    stage(kt, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* sA = smem;
     const unsigned char* sB = sA + BM * BKB;
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -689,9 +695,8 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], b[j]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
+  __syncthreads();                               // operand stage free for the epilogue
 
 #pragma unroll
   for (int i = 0; i < FM; ++i)
@@ -746,7 +751,7 @@ int launch_nn(const GemmArgs& a, hipStream_t s) {
   p.tiles_n = (p.N + 63) / 64;
   p.ntiles = tiles_m * p.tiles_n;
   const int esz = (int)sizeof(T);
-  size_t lds = (size_t)2 * (BM * 128 + (128 / esz) * (64 * esz));
+  size_t lds = (size_t)(BM * 128 + (128 / esz) * (64 * esz));      // one operand stage
   const size_t cl = (size_t)BM * (64 * 4 + 16);
   if (cl > lds) lds = cl;
   static bool granted = false;
