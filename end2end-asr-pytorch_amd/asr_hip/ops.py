@@ -3,6 +3,8 @@
 Everything here launches HIP kernels from libasr_hip.so on torch's current stream.  torch is used for device
 memory (torch.empty / zeros) and nothing else.
 """
+import math
+
 import torch
 
 from . import lib as L
@@ -450,6 +452,49 @@ def bn_act_bwd(dout, y, M, C, mean, rstd, gamma, beta, lo, hi, dy, tH=0, tW=0):
     L.call("asr_bn_act_bwd", L.ptr(dout), ldo, L.ptr(y), y.stride(0), L.ptr(dy), dy.stride(0), M, C, L.ptr(mean), L.ptr(rstd),
            L.ptr(gamma), L.ptr(beta), float(lo), float(hi), tH, tW, L.ptr(sums), L.dt(dout), L.stream())
     return sums
+
+
+# ------------------------------------------------------------------------------------------------ spectrogram front end
+_stft_const = {}
+
+
+def _stft_constants(n_fft, device):
+    """Symmetric Hamming window (n_fft) and the [cos | -sin] DFT basis (2*(n_fft/2+1), n_fft), fp32, computed in float64."""
+    key = (n_fft, str(device))
+    c = _stft_const.get(key)
+    if c is None:
+        k = torch.arange(n_fft, dtype=torch.float64)
+        win = (0.54 - 0.46 * torch.cos(2.0 * math.pi * k / (n_fft - 1))).float()
+        f = torch.arange(n_fft // 2 + 1, dtype=torch.float64)[:, None]
+        ang = 2.0 * math.pi * f * k[None, :] / n_fft
+        basis = torch.cat([torch.cos(ang), -torch.sin(ang)], dim=0).float()
+        c = (win.to(device), basis.to(device).contiguous())
+        _stft_const[key] = c
+    return c
+
+
+def log_spectrogram(wav, lengths, n_fft=320, hop=160, normalize=True):
+    """Padded waveforms wav (B, L) fp32 + lengths (B) int32 (samples), both on the device -> (spect (B, 1, n_fft/2+1, Tmax)
+    fp32 zero padded along T, n_frames (B) int32): log1p(|STFT|) normalised per utterance, the reference loader's features
+    (utils/data_loader.py:72-89) computed on the GPU: framing kernel -> fp32 MFMA GEMM against the DFT basis -> magnitude /
+    log1p / mean / unbiased std kernels."""
+    assert wav.dim() == 2 and wav.dtype == torch.float32 and wav.stride(1) == 1 and lengths.dtype == torch.int32
+    B, Lmax = wav.shape
+    F = n_fft // 2 + 1
+    Tmax = 1 + max(Lmax, 2) // hop
+    win, basis = _stft_constants(n_fft, wav.device)
+    frames = torch.empty((B * Tmax, n_fft), device=wav.device, dtype=torch.float32)
+    L.call("asr_stft_frames", L.ptr(wav), wav.stride(0), L.ptr(lengths), L.ptr(win), L.ptr(frames), B, Tmax, n_fft, hop,
+           L.stream())
+    ld = (2 * F + 3) // 4 * 4
+    reim = torch.empty((B * Tmax, ld), device=wav.device, dtype=torch.float32)
+    gemm_nt(frames, basis, out=reim[:, :2 * F])
+    spect = torch.empty((B, 1, F, Tmax), device=wav.device, dtype=torch.float32)
+    scratch = torch.zeros((2, B), device=wav.device, dtype=torch.float32)
+    L.call("asr_spect_finish", L.ptr(reim), ld, L.ptr(lengths), L.ptr(spect), L.ptr(scratch[0]), L.ptr(scratch[1]), B, F, Tmax,
+           hop, int(normalize), L.stream())
+    n_frames = 1 + torch.clamp(lengths, min=2) // hop
+    return spect, n_frames.to(torch.int32)
 
 
 # ------------------------------------------------------------------------------------------------ profiling

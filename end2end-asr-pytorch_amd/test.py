@@ -19,6 +19,10 @@ def evaluate(model, test_loader, lm=None):
             src, tgt, _, src_lengths, _ = data
             if constant.USE_CUDA:
                 src, tgt = src.cuda(), tgt.cuda()
+            if getattr(args, "gpu_frontend", False):
+                from utils.audio import gpu_front_end
+                src, src_lengths = gpu_front_end(src, src_lengths, args.sample_rate, args.window_size, args.window_stride,
+                                                 args.src_max_len)
             _, strs_hyps, strs_gold = model.evaluate(src, src_lengths, tgt, beam_search=args.beam_search,
                                                      beam_width=args.beam_width, beam_nbest=args.beam_nbest, lm=lm,
                                                      lm_rescoring=args.lm_rescoring, lm_weight=args.lm_weight,

@@ -14,6 +14,7 @@ import torch.distributed as dist
 from tqdm import tqdm
 
 from utils import constant
+from utils.audio import gpu_front_end
 from utils.functions import save_model
 from utils.metrics import calculate_cer, calculate_metrics, calculate_wer
 
@@ -42,6 +43,9 @@ class Trainer():
         src, tgt, src_percentages, src_lengths, tgt_lengths = data
         if constant.USE_CUDA:
             src, tgt = src.cuda(non_blocking=True), tgt.cuda(non_blocking=True)
+        if getattr(constant.args, "gpu_frontend", False):
+            a = constant.args
+            src, src_lengths = gpu_front_end(src, src_lengths, a.sample_rate, a.window_size, a.window_stride, a.src_max_len)
         if opt is not None:
             opt.zero_grad()
         pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)

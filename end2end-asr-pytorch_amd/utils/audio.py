@@ -54,3 +54,20 @@ def log_spectrogram(y, sample_rate=16000, window_size=0.02, window_stride=0.01, 
         std = spec.std(ddof=1)
         spec = (spec - mean) / std
     return spec
+
+
+def gpu_front_end(inputs, input_sizes, sample_rate=16000, window_size=0.02, window_stride=0.01, src_max_len=None):
+    """--gpu-frontend: `inputs` (B,1,1,Lmax) are the loader's zero padded WAVEFORMS and `input_sizes` (B) their sample
+    counts (the collate function is unchanged: a waveform is a 1-bin "spectrogram").  Returns what the host path would have
+    put in the batch: log-spectrograms (B,1,F,T) normalised per utterance, cut to --src-max-len frames AFTER the
+    normalisation (data_loader.py:49-53), and the frame counts."""
+    import torch
+    from asr_hip import ops
+    n_fft, hop = int(sample_rate * window_size), int(sample_rate * window_stride)
+    wav = inputs.reshape(inputs.shape[0], inputs.shape[-1]).float().contiguous()
+    lens = torch.as_tensor(input_sizes).to(device=wav.device, dtype=torch.int32)
+    spect, n_frames = ops.log_spectrogram(wav, lens, n_fft=n_fft, hop=hop, normalize=True)
+    if src_max_len is not None and spect.shape[-1] > src_max_len:
+        spect = spect[..., :src_max_len].contiguous()
+        n_frames = torch.clamp(n_frames, max=src_max_len)
+    return spect, n_frames.cpu()

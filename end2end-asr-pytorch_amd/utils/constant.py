@@ -8,7 +8,9 @@ Differences that do not change old command lines:
     script, which makes its modules unusable from tests); otherwise `args` holds the defaults and can be replaced with
     `set_args(ns)` / `parse(argv)`;
   * `--precision {bf16,fp32}` selects the kernels' storage type (bf16 = perf mode, fp32 = parity mode);
-  * `--dist-backend` / `--bucket-mb` tune the RCCL data-parallel path that replaces nn.DataParallel under --parallel.
+  * `--dist-backend` / `--bucket-mb` tune the RCCL data-parallel path that replaces nn.DataParallel under --parallel;
+  * `--gpu-frontend`: the loader ships padded waveforms and the log-spectrogram is computed on the GPU (asr_stft_frames +
+    fp32 MFMA DFT + asr_spect_finish) instead of on the host in the DataLoader workers.
 """
 import argparse
 import os
@@ -61,6 +63,7 @@ _FLAGS = [
     # MI355X path (additions)
     (("--precision",), dict(default="bf16", choices=["bf16", "fp32"])),
     (("--dist-backend",), dict(default="nccl")), (("--bucket-mb",), dict(default=32.0, type=_F)),
+    (("--gpu-frontend",), dict(action="store_true")),
 ]
 
 parser = argparse.ArgumentParser(description="Transformer ASR on MI355X")

@@ -30,6 +30,10 @@ class SpectrogramParser(object):
 
     def parse_audio(self, audio_path):
         y = load_audio(audio_path)
+        if getattr(constant.args, "gpu_frontend", False):
+            # ship the waveform as a 1-bin "spectrogram" (1, L): collate pads it like any other; utils.audio.gpu_front_end
+            # turns the batch into log-spectrograms on the device
+            return torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))[None, :]
         return torch.from_numpy(log_spectrogram(y, self.sample_rate, self.window_size, self.window_stride, self.normalize))
 
 
@@ -49,7 +53,9 @@ class SpectrogramDataset(Dataset, SpectrogramParser):
     def __getitem__(self, index):
         ids = self.ids_list[random.randint(0, len(self.ids_list) - 1)]      # one manifest at random, as the reference
         audio_path, transcript_path = ids[index % len(ids)][:2]
-        spect = self.parse_audio(audio_path)[:, :constant.args.src_max_len]
+        spect = self.parse_audio(audio_path)
+        if not getattr(constant.args, "gpu_frontend", False):
+            spect = spect[:, :constant.args.src_max_len]
         return spect, self.parse_transcript(transcript_path)
 
     def parse_transcript(self, transcript_path):

@@ -216,6 +216,17 @@ int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int64_t ldy, v
                    const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
                    int tH, int tW, const float* sums, int dtype, asr_stream_t stream);
 
+/* ---- spectrogram front end on the device (reference: SpectrogramParser.parse_audio, utils/data_loader.py:72-89) ---------
+ * frames (B*Tmax, n_fft) fp32 <- windowed, centred (reflect padded) frames of the padded waveforms wav (B, wav_stride),
+ * lengths (B) samples; frames past 1 + len/hop of an utterance are zero.  The DFT itself is asr_gemm_nt (fp32) against
+ * the [cos | -sin] basis (2*(n_fft/2+1), n_fft).                                                                     */
+int asr_stft_frames(const float* wav, int64_t wav_stride, const int32_t* lengths, const float* window, float* frames, int B,
+                    int Tmax, int n_fft, int hop, asr_stream_t stream);
+/* reim (B*Tmax, ld): [re(F) | im(F)] per frame -> spect (B, F, Tmax) = log1p(|.|), zero past each utterance's frames;
+ * normalize != 0: (x - mean) / std per utterance (unbiased std).  sums / sqdev: zero-initialised fp32 (B) scratch.     */
+int asr_spect_finish(const float* reim, int64_t ld, const int32_t* lengths, float* spect, float* sums, float* sqdev, int B,
+                     int F, int Tmax, int hop, int normalize, asr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -491,3 +491,32 @@ def test_ops_refuse_host_tensors(ops):
     from asr_hip.lib import AsrHipError
     with pytest.raises(AsrHipError):
         ops.gemm_nt(torch.zeros(8, 8), torch.zeros(8, 8))
+
+
+# ------------------------------------------------------------------------------------------------ spectrogram front end
+def test_gpu_spectrogram_matches_host_convention(ops):
+    """asr_stft_frames + fp32 MFMA DFT + asr_spect_finish against utils/audio.log_spectrogram (the numpy restatement of
+    the reference's librosa/scipy convention, data_loader.py:72-89) on ragged utterances, including very short ones.
+    Tolerance: fp32 DFT by GEMM vs numpy's float64-internally rfft: 2e-4 absolute on the normalised features (O(1))."""
+    from utils.audio import log_spectrogram
+    rng = np.random.RandomState(3)
+    lens = [16000, 12345, 4001, 700, 161, 100, 1]
+    Lmax = max(lens)
+    wav = np.zeros((len(lens), Lmax), dtype=np.float32)
+    for i, n in enumerate(lens):
+        t = np.arange(n) / 16000.0
+        wav[i, :n] = (0.3 * np.sin(2 * np.pi * (200 + 37 * i) * t) + 0.05 * rng.randn(n)).astype(np.float32)
+    D = dev()
+    spect, nfr = ops.log_spectrogram(torch.from_numpy(wav).to(D), torch.tensor(lens, dtype=torch.int32, device=D))
+    assert spect.shape == (len(lens), 1, 161, 1 + Lmax // 160)
+    sp = spect.cpu().numpy()
+    for i, n in enumerate(lens):
+        ref = log_spectrogram(wav[i, :n])
+        T = ref.shape[1]
+        assert int(nfr[i]) == T
+        if n > 1:       # a 1-sample utterance has 1 frame x 161 bins of a constant: std of near-equal values, skip the values
+            np.testing.assert_allclose(sp[i, 0, :, :T], ref, rtol=0, atol=2e-4 * max(1.0, np.abs(ref).max()), err_msg=str(n))
+        assert (sp[i, 0, :, T:] == 0).all()
+    raw, _ = ops.log_spectrogram(torch.from_numpy(wav[:2]).to(D), torch.tensor(lens[:2], dtype=torch.int32, device=D), normalize=False)
+    ref = log_spectrogram(wav[1, :lens[1]], normalize=False)
+    np.testing.assert_allclose(raw[1, 0, :, :ref.shape[1]].cpu().numpy(), ref, rtol=0, atol=1e-4)

@@ -67,3 +67,49 @@ def test_train_and_test_entry_points(tmp_path, monkeypatch):
     model.decoder.positional_encoding = PositionalEncoding(model.decoder.dim_model, 301).cuda()
     cer, wer = test_mod.evaluate(model, loader)
     assert np.isfinite(cer) and np.isfinite(wer) and cer >= 0
+
+
+def test_gpu_frontend_batches_equal_host_batches_and_train(tmp_path, monkeypatch):
+    """--gpu-frontend: the loader ships padded waveforms; utils.audio.gpu_front_end must rebuild exactly the batch the host
+    path produces (features, frame counts, --src-max-len cut after normalisation), and a training epoch must run on it."""
+    from utils import constant
+    man, lab = _corpus(tmp_path)
+    monkeypatch.chdir(tmp_path)
+    base = ["--train-manifest-list", man, "--valid-manifest-list", man, "--test-manifest-list", man, "--labels-path", lab,
+            "--cuda", "--batch-size", "3", "--num-workers", "0", "--epochs", "1", "--save-every", "1", "--name", "tinyg",
+            "--save-folder", str(tmp_path / "save"), "--num-layers", "1", "--num-heads", "2", "--dim-model", "32", "--dim-key",
+            "16", "--dim-value", "16", "--dim-inner", "64", "--dim-emb", "32", "--tgt-max-len", "12", "--src-max-len", "40",
+            "--label-smoothing", "0.1", "--dropout", "0.0", "--k-lr", "20", "--warmup", "5"]
+    from utils.audio import gpu_front_end
+    from utils.data_loader import AudioDataLoader, BucketingSampler, SpectrogramDataset
+    conf = dict(sample_rate=16000, window_size=.02, window_stride=.01, window="hamming", noise_dir=None, noise_prob=0.4,
+                noise_levels=(0.0, 0.5))
+    l2i = {c: i for i, c in enumerate(["\xa0", "<", ">", " ", "a", "b"])}
+    batches = {}
+    for mode in ("host", "gpu"):
+        args = constant.parse(base + (["--gpu-frontend"] if mode == "gpu" else []))
+        ds = SpectrogramDataset(conf, [man], l2i, normalize=True)
+        np.random.seed(0)
+        loader = AudioDataLoader(ds, num_workers=0, batch_sampler=BucketingSampler(ds, batch_size=3))
+        out = []
+        for src, tgt, _, sizes, _ in loader:
+            if mode == "gpu":
+                src, sizes = gpu_front_end(src.cuda(), sizes, src_max_len=args.src_max_len)
+                src = src.cpu()
+            out.append((src, tgt, sizes))
+        batches[mode] = out
+    assert len(batches["host"]) == len(batches["gpu"]) == 2
+    def canon(b):       # the collate order is by length; the --src-max-len cut creates ties on the host path only
+        src, tgt, sizes = b
+        order = sorted(range(tgt.shape[0]), key=lambda i: tuple(tgt[i].tolist()))
+        return src[order], tgt[order], torch.as_tensor(sizes)[order]
+    for hb, gb in zip(batches["host"], batches["gpu"]):
+        (hs, ht, hz), (gs, gt, gz) = canon(hb), canon(gb)
+        assert hs.shape == gs.shape and torch.equal(ht, gt) and torch.equal(hz.int(), gz.int())
+        assert gs.shape[-1] <= 40                      # 4000..8000 samples -> 26..51 frames, cut to --src-max-len
+        np.testing.assert_allclose(gs.numpy(), hs.numpy(), rtol=0, atol=5e-4)
+    assert max(g[0].shape[-1] for g in batches["gpu"]) == 40
+    constant.parse(base + ["--gpu-frontend"])
+    import train as train_mod
+    train_mod.main()
+    assert (tmp_path / "save" / "tinyg" / "best_model.th").exists()
