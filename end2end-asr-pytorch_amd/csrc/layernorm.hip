@@ -211,7 +211,7 @@ void launch_bwd(const T* dout, const T* z, const float* mean, const float* rstd,
   hipLaunchKernelGGL((add_ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), (size_t)3 * 2 * D * sizeof(float), s, dout, z,
                      mean, rstd, gamma, keep, d_res, d_y, dgamma, dbeta, ws, M, D, rpb, thr, inv, seed, seed_dev);
   if (ws) {
-    const int slices = nblk >= 64 ? 16 : 1;
+    const int slices = nblk >= 512 ? 64 : (nblk >= 64 ? 16 : 1);      // ~13 partial rows per thread
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * D + 255) / 256, slices), dim3(256), 0, s, ws, nblk, 2 * D, dgamma, dbeta);
   }
 }

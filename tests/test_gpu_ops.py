@@ -201,6 +201,11 @@ def test_add_ln_dropout_consistency(ops, dtype):
     rate = kept.float().mean().item()
     assert abs(rate - (1 - p)) < 0.01, rate
     assert torch.allclose(zf[kept], torch.full_like(zf[kept], 1 / (1 - p)), rtol=1e-2)
+    # the mask must be uncorrelated along columns and rows (the counter hash is cheap 32-bit arithmetic)
+    zc = (~kept).float().cpu() - p
+    for sh, dim in ((1, 1), (2, 1), (8, 1), (1, 0), (4, 0)):
+        corr = (zc * torch.roll(zc, sh, dim)).mean().item() / (p * (1 - p))
+        assert abs(corr) < 0.02, (sh, dim, corr)
     dg = torch.zeros(D, device=dev()); db = torch.zeros(D, device=dev())
     dout = torch.randn(M, D, device=dev()).to(dtype)
     d_res, d_y = ops.add_ln_bwd(dout, yz, mean, rstd, gamma, None, dg, db, p=p, seed=1234)
