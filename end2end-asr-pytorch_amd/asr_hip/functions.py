@@ -72,8 +72,15 @@ def _dgrad(dy2d, wparam, dx_out=None, accumulate=False, relu_mask=None):
 
 def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
     """dy2d (M,N[p]) and x2d (M,K) in the compute dtype.  Accumulates dW / db, returns dx = dy W (M,K) or None."""
-    _wgrad_bias(dy2d, x2d, wparam, bparam)
-    return _dgrad(dy2d, wparam, dx_out, accumulate, relu_mask) if need_dx else None
+    if not need_dx:
+        _wgrad_bias(dy2d, x2d, wparam, bparam)
+        return None
+    f = ops.fork()
+    with f:                                   # dW / db on the second stream, next to dX on this one
+        _wgrad_bias(dy2d, x2d, wparam, bparam)
+    dx = _dgrad(dy2d, wparam, dx_out, accumulate, relu_mask)
+    f.join()
+    return dx
 
 
 class _Fused:
@@ -104,16 +111,26 @@ class _Fused:
 
     def bwd(self, dy2d, x2d, dx_out=None, accumulate=False, need_dx=True):
         g = self.w_grad.view(self.N, self.K)
-        if ops.gemm_tn_supported(dy2d, x2d):
-            ops.gemm_tn(dy2d, x2d, g, colsum_acc=self.b_grad, N=self.N, K=self.K)
-        else:
-            ops.gemm_nt(ops.transpose_padded(dy2d, self.b_grad), ops.transpose_padded(x2d), out=g, accumulate=True, splits=0)
+        f = ops.fork() if need_dx else None
+        if f is not None:
+            f.__enter__()
+        try:
+            if ops.gemm_tn_supported(dy2d, x2d):
+                ops.gemm_tn(dy2d, x2d, g, colsum_acc=self.b_grad, N=self.N, K=self.K)
+            else:
+                ops.gemm_nt(ops.transpose_padded(dy2d, self.b_grad), ops.transpose_padded(x2d), out=g, accumulate=True, splits=0)
+        finally:
+            if f is not None:
+                f.__exit__(None, None, None)
         if not need_dx:
             return None
         if ops.gemm_nn_supported(dy2d, self.W):
-            return ops.gemm_nn(dy2d, self.W, out=dx_out, accumulate=accumulate)
-        wt = ops.transpose_padded(self.W)
-        return ops.gemm_nt(_pad_cols(dy2d), wt, out=dx_out, accumulate=accumulate)
+            dx = ops.gemm_nn(dy2d, self.W, out=dx_out, accumulate=accumulate)
+        else:
+            wt = ops.transpose_padded(self.W)
+            dx = ops.gemm_nt(_pad_cols(dy2d), wt, out=dx_out, accumulate=accumulate)
+        f.join()
+        return dx
 
 
 # ================================================================================================ plain linear
