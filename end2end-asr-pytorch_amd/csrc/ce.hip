@@ -12,54 +12,76 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {     // greater va
   return a;
 }
 
-__global__ __launch_bounds__(256) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld,
-                                                     const int64_t* __restrict__ gold, int V, float eps, int pad_id,
-                                                     float* __restrict__ row_lse, int64_t* __restrict__ argmax, float* sums) {
-  __shared__ float s_v[4]; __shared__ int s_i[4]; __shared__ float s_s[4]; __shared__ float s_e[4];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* l = logits + (int64_t)row * ld;
-  MaxIdx mi{-INFINITY, 0x7fffffff};
-  float sum = 0.f;
-  for (int v = tid; v < V; v += 256) {
-    const float x = l[v];
-    sum += x;
-    if (x > mi.v) { mi.v = x; mi.i = v; }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    MaxIdx t{__shfl_xor(mi.v, o, 64), __shfl_xor(mi.i, o, 64)};
-    mi = better(mi, t);
-  }
-  sum = wave_sum(sum);
-  if (lane == 0) { s_v[wave] = mi.v; s_i[wave] = mi.i; s_s[wave] = sum; }
-  __syncthreads();
-  MaxIdx m{s_v[0], s_i[0]};
-#pragma unroll
-  for (int w = 1; w < 4; ++w) m = better(m, MaxIdx{s_v[w], s_i[w]});
-  sum = s_s[0] + s_s[1] + s_s[2] + s_s[3];
-  float e = 0.f;
-  for (int v = tid; v < V; v += 256) e += expf(l[v] - m.v);
-  e = wave_sum(e);
-  if (lane == 0) s_e[wave] = e;
-  __syncthreads();
-  if (tid == 0) {
-    const float lse = m.v + logf(s_e[0] + s_e[1] + s_e[2] + s_e[3]);
-    row_lse[row] = lse;
-    argmax[row] = m.i;
-    const int64_t g = gold[row];
-    if (g != pad_id) {
-      const float lpg = l[g] - lse;
-      float loss;
-      if (eps > 0.f) {
-        const float sum_lp = sum - (float)V * lse;
-        loss = -((1.f - eps) * lpg + (eps / (float)V) * (sum_lp - lpg));
-      } else {
-        loss = -lpg;
-      }
-      atomicAdd(sums + 0, loss);
-      atomicAdd(sums + 1, 1.f);
-      if (m.i == g) atomicAdd(sums + 2, 1.f);
+// One wave per row, CE_ROWS rows per block: the three running sums (loss, #non-PAD rows, #correct) are reduced over the block's
+// rows in LDS first -- one set of same-address atomics per block instead of per row (they were most of this kernel's time).
+constexpr int CE_ROWS = 8;
+
+__global__ __launch_bounds__(64 * CE_ROWS) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld,
+                                                              const int64_t* __restrict__ gold, int M, int V, float eps, int pad_id,
+                                                              float* __restrict__ row_lse, int64_t* __restrict__ argmax, float* sums) {
+  __shared__ float s_part[CE_ROWS][3];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * CE_ROWS + wave;
+  float part[3] = {0.f, 0.f, 0.f};
+  if (row < M) {
+    const float* l = logits + (int64_t)row * ld;
+    const bool vec = ((((uintptr_t)l) & 15) == 0);
+    const int V4 = vec ? (V & ~3) : 0;
+    MaxIdx mi{-INFINITY, 0x7fffffff};
+    float sum = 0.f;
+    for (int v = lane * 4; v < V4; v += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(l + v);
+      sum += (x.x + x.y) + (x.z + x.w);
+      if (x.x > mi.v) { mi.v = x.x; mi.i = v; }
+      if (x.y > mi.v) { mi.v = x.y; mi.i = v + 1; }
+      if (x.z > mi.v) { mi.v = x.z; mi.i = v + 2; }
+      if (x.w > mi.v) { mi.v = x.w; mi.i = v + 3; }
     }
+    for (int v = V4 + lane; v < V; v += 64) {
+      const float x = l[v];
+      sum += x;
+      if (x > mi.v) { mi.v = x; mi.i = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      MaxIdx t{__shfl_xor(mi.v, o, 64), __shfl_xor(mi.i, o, 64)};
+      mi = better(mi, t);
+    }
+    sum = wave_sum(sum);
+    float e = 0.f;
+    for (int v = lane * 4; v < V4; v += 256) {
+      const float4 x = *reinterpret_cast<const float4*>(l + v);
+      e += (expf(x.x - mi.v) + expf(x.y - mi.v)) + (expf(x.z - mi.v) + expf(x.w - mi.v));
+    }
+    for (int v = V4 + lane; v < V; v += 64) e += expf(l[v] - mi.v);
+    e = wave_sum(e);
+    if (lane == 0) {
+      const float lse = mi.v + logf(e);
+      row_lse[row] = lse;
+      argmax[row] = mi.i;
+      const int64_t g = gold[row];
+      if (g != pad_id) {
+        const float lpg = l[g] - lse;
+        float loss;
+        if (eps > 0.f) {
+          const float sum_lp = sum - (float)V * lse;
+          loss = -((1.f - eps) * lpg + (eps / (float)V) * (sum_lp - lpg));
+        } else {
+          loss = -lpg;
+        }
+        part[0] = loss;
+        part[1] = 1.f;
+        part[2] = mi.i == g ? 1.f : 0.f;
+      }
+    }
+  }
+  if (lane == 0) { s_part[wave][0] = part[0]; s_part[wave][1] = part[1]; s_part[wave][2] = part[2]; }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < CE_ROWS; ++w) t += s_part[w][threadIdx.x];
+    if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
   }
 }
 
@@ -120,7 +142,8 @@ extern "C" int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, 
   ASR_CHECK_ARG(logits && gold && row_lse && argmax && sums && M >= 0 && V > 0 && ld >= V && smoothing >= 0.f);
   if (M == 0) return ASR_OK;
   AsrProfScope prof(ASR_OP_CE, s);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(M), dim3(256), 0, s, logits, ld, gold, V, smoothing, pad_id, row_lse, argmax, sums);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + CE_ROWS - 1) / CE_ROWS), dim3(64 * CE_ROWS), 0, s, logits, ld, gold, M, V, smoothing, pad_id,
+                     row_lse, argmax, sums);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
