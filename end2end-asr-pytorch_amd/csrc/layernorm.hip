@@ -7,6 +7,15 @@
 namespace {
 
 
+// fp32 parameter vector: EPC consecutive values starting at c0 (16-byte aligned: c0 is a multiple of EPC >= 4)
+template <int EPC> __device__ __forceinline__ void load_params(const float* __restrict__ p, int c0, float* out) {
+#pragma unroll
+  for (int j = 0; j < EPC; j += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + c0 + j);
+    out[j] = v.x; out[j + 1] = v.y; out[j + 2] = v.z; out[j + 3] = v.w;
+  }
+}
+
 template <typename T, int NCH>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, const T* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -21,27 +30,42 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, co
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   T* yr = y_z + (int64_t)row * D;
+  // every load of the row is issued up front (optional operands read a valid dummy address and are masked by a flag): the
+  // row costs ONE memory round trip, not one per operand
+  const T* rr = res ? res + (int64_t)row * D : yr;
+  const float* pr = post ? post + (int64_t)(row % post_period) * D : beta;
+  const float fres = res ? 1.f : 0.f, fpost = post ? 1.f : 0.f;
+  const float kp = keep ? (keep[row] ? 1.f : 0.f) : 1.f;
+  Chunk<T> cy[NCH], cr[NCH];
+  float gm[NCH][EPC], bt[NCH][EPC], ps[NCH][EPC];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = (ch * 64 + lane) * EPC;
+    const int cc = c0 < D ? c0 : 0;
+    cy[ch].v = *reinterpret_cast<const uint4*>(yr + cc);
+    cr[ch].v = *reinterpret_cast<const uint4*>(rr + cc);
+    load_params<EPC>(gamma, cc, gm[ch]);
+    load_params<EPC>(beta, cc, bt[ch]);
+    load_params<EPC>(pr, cc, ps[ch]);
+  }
   float z[NCH * EPC];
   float s = 0.f;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = (ch * 64 + lane) * EPC;
     if (c0 < D) {
-      Chunk<T> cy, cr;
-      cy.v = *reinterpret_cast<const uint4*>(yr + c0);
-      if (res) cr.v = *reinterpret_cast<const uint4*>(res + (int64_t)row * D + c0);
 #pragma unroll
       for (int j = 0; j < EPC; ++j) {
-        float v = DT<T>::from(cy.e[j]);
+        float v = DT<T>::from(cy[ch].e[j]);
         if (thr) v = asr_keep(seed, (uint64_t)row * D + c0 + j, thr) ? v * inv_keep : 0.f;
-        if (res) v += DT<T>::from(cr.e[j]);
+        v += fres * DT<T>::from(cr[ch].e[j]);
         // z is what backward sees: round it to the storage type first so fwd and bwd agree bit for bit
-        cy.e[j] = DT<T>::to(v);
-        v = DT<T>::from(cy.e[j]);
+        cy[ch].e[j] = DT<T>::to(v);
+        v = DT<T>::from(cy[ch].e[j]);
         z[ch * EPC + j] = v;
         s += v;
       }
-      *reinterpret_cast<uint4*>(yr + c0) = cy.v;
+      *reinterpret_cast<uint4*>(yr + c0) = cy[ch].v;
     } else {
 #pragma unroll
       for (int j = 0; j < EPC; ++j) z[ch * EPC + j] = 0.f;
@@ -59,8 +83,6 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, co
   }
   const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
   if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-  const float kp = keep ? (keep[row] ? 1.f : 0.f) : 1.f;
-  const float* pr = post ? post + (int64_t)(row % post_period) * D : nullptr;
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
     const int c0 = (ch * 64 + lane) * EPC;
@@ -68,8 +90,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(T* __restrict__ y_z, co
       Chunk<T> co;
 #pragma unroll
       for (int j = 0; j < EPC; ++j) {
-        float v = (z[ch * EPC + j] - mu) * rs * gamma[c0 + j] + beta[c0 + j];
-        if (pr) v += pr[c0 + j];
+        const float v = (z[ch * EPC + j] - mu) * rs * gm[ch][j] + bt[ch][j] + fpost * ps[ch][j];
         co.e[j] = DT<T>::to(v * kp);
       }
       *reinterpret_cast<uint4*>(out + (int64_t)row * D + c0) = co.v;
@@ -108,11 +129,13 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
         Chunk<T> cd, cz;
         cd.v = *reinterpret_cast<const uint4*>(dout + (int64_t)row * D + c0);
         cz.v = *reinterpret_cast<const uint4*>(z + (int64_t)row * D + c0);
+        float gm[EPC];
+        load_params<EPC>(gamma, c0, gm);
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
           const float go = DT<T>::from(cd.e[j]) * kp;
           const float x = (DT<T>::from(cz.e[j]) - mu) * rs;
-          const float gy = go * gamma[c0 + j];
+          const float gy = go * gm[j];
           xh[ch * EPC + j] = x; dyh[ch * EPC + j] = gy;
           s1 += gy; s2 += gy * x;
           ag[ch * EPC + j] += go * x; ab[ch * EPC + j] += go;

@@ -127,6 +127,10 @@ def misc():
     dg = torch.zeros(Dm, device=D); db = torch.zeros(Dm, device=D)
     us = timeit(lambda: ops.add_ln_bwd(out, y, mean, rstd, g, None, dg, db, p=0.1, seed=1))
     print("  add_ln_bwd 6400x512 %7.1f us  %.0f GB/s" % (us, 4 * M * Dm * 2 / us / 1e3))
+    for Mx in (1600, 25600, 102400):          # latency floor vs streaming rate of the LayerNorm kernels
+        yy = torch.randn(Mx, Dm, device=D).bfloat16(); rr = torch.randn(Mx, Dm, device=D).bfloat16()
+        us = timeit(lambda: ops.add_ln_fwd(yy, rr, g, b, p=0.1, seed=1))
+        print("  add_ln_fwd %dx512 %7.1f us  %.0f GB/s" % (Mx, us, 4 * Mx * Dm * 2 / us / 1e3))
     x = torch.randn(M, 2048, device=D).bfloat16()
     us = timeit(lambda: ops.transpose_padded(x))
     print("  transpose 6400x2048 %7.1f us  %.0f GB/s" % (us, 2 * x.numel() * 2 / us / 1e3))
