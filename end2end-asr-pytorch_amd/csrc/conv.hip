@@ -111,9 +111,10 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const int64_t b = quad / ((int64_t)wq * H);
     Chunk<T> d[C1_PW];
 #pragma unroll
-    for (int px = 0; px < C1_PW; ++px) {
-      d[px].v = make_uint4(0u, 0u, 0u, 0u);
-      if (x0 + px < W) d[px].v = *reinterpret_cast<const uint4*>(dy + (((b * H + yh) * (int64_t)W) + x0 + px) * C0 + cg * EPC);
+    for (int px = 0; px < C1_PW; ++px) {          // unconditional loads (clamped address + select): one round trip for all
+      const int xx = x0 + px < W ? x0 + px : W - 1;
+      const uint4 v = *reinterpret_cast<const uint4*>(dy + (((b * H + yh) * (int64_t)W) + xx) * C0 + cg * EPC);
+      d[px].v = x0 + px < W ? v : make_uint4(0u, 0u, 0u, 0u);
     }
     float in[3][C1_PW + 2];
     conv1_window(x, b, yh, x0, H, W, in);
