@@ -55,12 +55,15 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #pragma unroll
     for (int t = 0; t < 9; ++t) wr[j][t] = asr_f32x2_t{w[(cg * EPC + 2 * j) * 9 + t], w[(cg * EPC + 2 * j + 1) * 9 + t]};
   }
+  // a block walks whole image rows (b, yh); its threads cover the row's quads: no 64-bit division per work item (an emulated
+  // int64 div/mod costs more instructions than the 288 FMAs of a quad)
   const int wq = (W + C1_PW - 1) / C1_PW;
-  const int64_t nquad = (int64_t)B * H * wq;
   const int qpb = 256 / groups;
-  for (int64_t quad = (int64_t)blockIdx.x * qpb + threadIdx.x / groups; quad < nquad; quad += (int64_t)gridDim.x * qpb) {
-    const int x0 = (int)(quad % wq) * C1_PW, yh = (int)((quad / wq) % H);
-    const int64_t b = quad / ((int64_t)wq * H);
+  for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+   const int yh = row % H;
+   const int64_t b = row / H;
+   for (int qx = threadIdx.x / groups; qx < wq; qx += qpb) {
+    const int x0 = qx * C1_PW;
     float in[3][C1_PW + 2];
     conv1_window(x, b, yh, x0, H, W, in);
 #pragma unroll
@@ -82,6 +85,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       }
       *reinterpret_cast<uint4*>(y + (((b * H + yh) * (int64_t)W) + x0 + px) * C0 + cg * EPC) = o.v;
     }
+   }
   }
 }
 
@@ -104,11 +108,12 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     for (int t = 0; t < 9; ++t) aw[j][t] = asr_f32x2_t{0.f, 0.f};
   }
   const int wq = (W + C1_PW - 1) / C1_PW;
-  const int64_t nquad = (int64_t)B * H * wq;
   const int qpb = 256 / groups;
-  for (int64_t quad = (int64_t)blockIdx.x * qpb + threadIdx.x / groups; quad < nquad; quad += (int64_t)gridDim.x * qpb) {
-    const int x0 = (int)(quad % wq) * C1_PW, yh = (int)((quad / wq) % H);
-    const int64_t b = quad / ((int64_t)wq * H);
+  for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
+   const int yh = row % H;
+   const int64_t b = row / H;
+   for (int qx = threadIdx.x / groups; qx < wq; qx += qpb) {
+    const int x0 = qx * C1_PW;
     Chunk<T> d[C1_PW];
 #pragma unroll
     for (int px = 0; px < C1_PW; ++px) {          // unconditional loads (clamped address + select): one round trip for all
@@ -132,6 +137,7 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             aw[j][ky * 3 + kx] += g * asr_f32x2_t{v, v};
           }
       }
+   }
   }
 #pragma unroll
   for (int j = 0; j < NP; ++j)
@@ -349,29 +355,28 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 }
 
 // ================================================================================================ max pooling
+// grid.y = pooled rows (b, oh), grid.x * 256 threads = (ow, 16-byte channel group) items of a row
 template <typename T>
 __global__ __launch_bounds__(256) void pool_fwd_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
   constexpr int EPC = DT<T>::EPC;
   const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
-  const int64_t total = (int64_t)B * H2 * W2 * groups;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(i % groups);
-    const int64_t op = i / groups;
-    const int ow = (int)(op % W2), oh = (int)((op / W2) % H2);
-    const int64_t b = op / ((int64_t)W2 * H2);
-    const T* base = x + (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
-    Chunk<T> a, bq, c, d, o;
-    a.v = *reinterpret_cast<const uint4*>(base);
-    bq.v = *reinterpret_cast<const uint4*>(base + C);
-    c.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C);
-    d.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C + C);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W2 * groups) return;
+  const int cg = t % groups, ow = t / groups;
+  const int oh = blockIdx.y % H2;
+  const int64_t b = blockIdx.y / H2;
+  const T* base = x + (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+  Chunk<T> a, bq, c, d, o;
+  a.v = *reinterpret_cast<const uint4*>(base);
+  bq.v = *reinterpret_cast<const uint4*>(base + C);
+  c.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C);
+  d.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C + C);
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-      const float m = fmaxf(fmaxf(DT<T>::from(a.e[j]), DT<T>::from(bq.e[j])), fmaxf(DT<T>::from(c.e[j]), DT<T>::from(d.e[j])));
-      o.e[j] = DT<T>::to(m);
-    }
-    *reinterpret_cast<uint4*>(y + op * C + cg * EPC) = o.v;
+  for (int j = 0; j < EPC; ++j) {
+    const float m = fmaxf(fmaxf(DT<T>::from(a.e[j]), DT<T>::from(bq.e[j])), fmaxf(DT<T>::from(c.e[j]), DT<T>::from(d.e[j])));
+    o.e[j] = DT<T>::to(m);
   }
+  *reinterpret_cast<uint4*>(y + (((b * H2 + oh) * (int64_t)W2 + ow) * C) + cg * EPC) = o.v;
 }
 // block per (b, ow): pooled (H2, C) slab -> LDS -> written as (C, H2) i.e. feature index c*H2 + oh (transformer.py:74-76)
 template <typename T>
@@ -408,45 +413,44 @@ __device__ __forceinline__ void pool_bwd_window(const T* __restrict__ x, T* __re
   DT<T>::st(dx + base + (int64_t)W * C, arg == 2 ? gr : 0.f);
   DT<T>::st(dx + base + (int64_t)W * C + C, arg == 3 ? gr : 0.f);
 }
-// NHWC backward, one thread = EPC channels (16 bytes) of one 2x2 window: 5 vector loads, 4 vector stores
+// NHWC backward, one thread = EPC channels (16 bytes) of one 2x2 window: 5 vector loads, 4 vector stores.
+// grid.y = pooled rows (b, oh), grid.x * 256 threads = (ow, channel group) items of a row.
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_nhwc_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
                                                             int B, int H, int W, int C) {
   constexpr int EPC = DT<T>::EPC;
   const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
-  const int64_t total = (int64_t)B * H2 * W2 * groups;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W2 * groups) return;
+  const int cg = t % groups, ow = t / groups;
+  const int oh = blockIdx.y % H2;
+  const int64_t b = blockIdx.y / H2;
   const int64_t rowp = (int64_t)W * C;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int cg = (int)(i % groups);
-    const int64_t op = i / groups;
-    const int ow = (int)(op % W2), oh = (int)((op / W2) % H2);
-    const int64_t b = op / ((int64_t)W2 * H2);
-    const int64_t base = (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
-    Chunk<T> v0, v1, v2, v3, g, o0, o1, o2, o3;
-    v0.v = *reinterpret_cast<const uint4*>(x + base);
-    v1.v = *reinterpret_cast<const uint4*>(x + base + C);
-    v2.v = *reinterpret_cast<const uint4*>(x + base + rowp);
-    v3.v = *reinterpret_cast<const uint4*>(x + base + rowp + C);
-    g.v = *reinterpret_cast<const uint4*>(dy + op * C + cg * EPC);
+  const int64_t base = (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+  Chunk<T> v0, v1, v2, v3, g, o0, o1, o2, o3;
+  v0.v = *reinterpret_cast<const uint4*>(x + base);
+  v1.v = *reinterpret_cast<const uint4*>(x + base + C);
+  v2.v = *reinterpret_cast<const uint4*>(x + base + rowp);
+  v3.v = *reinterpret_cast<const uint4*>(x + base + rowp + C);
+  g.v = *reinterpret_cast<const uint4*>(dy + (((b * H2 + oh) * (int64_t)W2 + ow) * C) + cg * EPC);
 #pragma unroll
-    for (int j = 0; j < EPC; ++j) {
-      const float a0 = DT<T>::from(v0.e[j]), a1 = DT<T>::from(v1.e[j]), a2 = DT<T>::from(v2.e[j]), a3 = DT<T>::from(v3.e[j]);
-      int arg = 0; float m = a0;                      // the FIRST maximum in scan order takes the gradient (PyTorch max_pool2d)
-      if (a1 > m) { m = a1; arg = 1; }
-      if (a2 > m) { m = a2; arg = 2; }
-      if (a3 > m) { m = a3; arg = 3; }
-      const T gr = m > 0.f ? g.e[j] : DT<T>::to(0.f); // times ReLU'(x)
-      const T zero = DT<T>::to(0.f);
-      o0.e[j] = arg == 0 ? gr : zero;
-      o1.e[j] = arg == 1 ? gr : zero;
-      o2.e[j] = arg == 2 ? gr : zero;
-      o3.e[j] = arg == 3 ? gr : zero;
-    }
-    *reinterpret_cast<uint4*>(dx + base) = o0.v;
-    *reinterpret_cast<uint4*>(dx + base + C) = o1.v;
-    *reinterpret_cast<uint4*>(dx + base + rowp) = o2.v;
-    *reinterpret_cast<uint4*>(dx + base + rowp + C) = o3.v;
+  for (int j = 0; j < EPC; ++j) {
+    const float a0 = DT<T>::from(v0.e[j]), a1 = DT<T>::from(v1.e[j]), a2 = DT<T>::from(v2.e[j]), a3 = DT<T>::from(v3.e[j]);
+    int arg = 0; float m = a0;                      // the FIRST maximum in scan order takes the gradient (PyTorch max_pool2d)
+    if (a1 > m) { m = a1; arg = 1; }
+    if (a2 > m) { m = a2; arg = 2; }
+    if (a3 > m) { m = a3; arg = 3; }
+    const T gr = m > 0.f ? g.e[j] : DT<T>::to(0.f); // times ReLU'(x)
+    const T zero = DT<T>::to(0.f);
+    o0.e[j] = arg == 0 ? gr : zero;
+    o1.e[j] = arg == 1 ? gr : zero;
+    o2.e[j] = arg == 2 ? gr : zero;
+    o3.e[j] = arg == 3 ? gr : zero;
   }
+  *reinterpret_cast<uint4*>(dx + base) = o0.v;
+  *reinterpret_cast<uint4*>(dx + base + C) = o1.v;
+  *reinterpret_cast<uint4*>(dx + base + rowp) = o2.v;
+  *reinterpret_cast<uint4*>(dx + base + rowp + C) = o3.v;
 }
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_tcf_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
@@ -723,8 +727,9 @@ extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, 
   if (C0 % epc != 0 || !aligned16(y)) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
   if (256 % (C0 / epc) != 0) return ASR_EUNSUPPORTED;
-  const int64_t total = (int64_t)B * H * ((W + 3) / 4) * (C0 / epc);      // one thread per (pixel quad, channel group)
-  unsigned grid1 = stream_grid(total / 4);
+  int64_t rows = (int64_t)B * H;                                          // blocks walk image rows
+  ASR_CHECK_ARG(rows < ((int64_t)1 << 31));
+  unsigned grid1 = (unsigned)(rows < 8192 ? rows : 8192);
   AsrProfScope prof(ASR_OP_CONV1, s);
   if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float>), dim3(grid1), dim3(256), 0, s, x, w, bias, (float*)y, B, H, W, C0);
   else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t>), dim3(grid1), dim3(256), 0, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
@@ -739,9 +744,8 @@ extern "C" int asr_conv1_wgrad(const float* x, const void* dy, float* dw, float*
   const int epc = dtype == ASR_F32 ? 4 : 8;
   if (C0 % epc != 0 || 256 % (C0 / epc) != 0 || !aligned16(dy)) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
-  const int64_t nquad = (int64_t)B * H * ((W + 3) / 4);
-  const int qpb = 256 / (C0 / epc);
-  int64_t blocks = ceil_div64(nquad, (int64_t)qpb * 16);
+  int64_t blocks = (int64_t)B * H;        // blocks walk image rows
+  ASR_CHECK_ARG(blocks < ((int64_t)1 << 31));
   if (blocks > 1024) blocks = 1024;       // every block ends with C0*10 same-address global atomics
   if (blocks < 1) blocks = 1;
   const size_t lds = (size_t)C0 * 10 * sizeof(float);
@@ -792,9 +796,10 @@ extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int 
     else { allow_big_lds(pool_fwd_tcf_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_fwd_tcf_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C); }
   } else {
     if (C % epc != 0 || !aligned16(x) || !aligned16(y)) return ASR_EUNSUPPORTED;
-    const int64_t total = (int64_t)B * H2 * W2 * (C / epc);
-    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_fwd_nhwc_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
-    else hipLaunchKernelGGL((pool_fwd_nhwc_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+    if ((int64_t)B * H2 > 65535) return ASR_EUNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div64((int64_t)W2 * (C / epc), 256), (unsigned)(B * H2));
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_fwd_nhwc_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
+    else hipLaunchKernelGGL((pool_fwd_nhwc_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -821,9 +826,10 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
   } else {
     const int epc = dtype == ASR_F32 ? 4 : 8;
     if (C % epc != 0 || !aligned16(x) || !aligned16(dy) || !aligned16(dx)) return ASR_EUNSUPPORTED;
-    const int64_t total = (int64_t)B * H2 * W2 * (C / epc);
-    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_nhwc_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
-    else hipLaunchKernelGGL((pool_bwd_nhwc_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
+    if ((int64_t)B * H2 > 65535) return ASR_EUNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div64((int64_t)W2 * (C / epc), 256), (unsigned)(B * H2));
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_nhwc_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
+    else hipLaunchKernelGGL((pool_bwd_nhwc_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
