@@ -117,25 +117,40 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const T* __restrict__ d
 #pragma unroll
   for (int i = 0; i < NPL; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
   const int r_beg = blockIdx.x * rows_per_block, r_end = min(M, r_beg + rows_per_block);
+  // gamma does not depend on the row: loaded once per thread
+  float gm[NCH][EPC];
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int c0 = (ch * 64 + lane) * EPC;
+    load_params<EPC>(gamma, c0 < D ? c0 : 0, gm[ch]);
+  }
+  const uint8_t* kptr = keep ? keep : reinterpret_cast<const uint8_t*>(gamma);     // dummy byte source when there is no row mask
   for (int row = r_beg + wave; row < r_end; row += 4) {
-    const float kp = keep ? (keep[row] ? 1.f : 0.f) : 1.f;
+    // all loads of the row up front and unconditional (clamped column, dummy mask byte): one memory round trip per row
+    Chunk<T> cdv[NCH], czv[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+      const int c0 = (ch * 64 + lane) * EPC;
+      const int cc = c0 < D ? c0 : 0;
+      cdv[ch].v = *reinterpret_cast<const uint4*>(dout + (int64_t)row * D + cc);
+      czv[ch].v = *reinterpret_cast<const uint4*>(z + (int64_t)row * D + cc);
+    }
+    const uint8_t kb = kptr[keep ? row : 0];
     const float mu = mean[row], rs = rstd[row];
+    const float kp = keep ? (kb ? 1.f : 0.f) : 1.f;
     float xh[NPL], dyh[NPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       const int c0 = (ch * 64 + lane) * EPC;
       if (c0 < D) {
-        Chunk<T> cd, cz;
-        cd.v = *reinterpret_cast<const uint4*>(dout + (int64_t)row * D + c0);
-        cz.v = *reinterpret_cast<const uint4*>(z + (int64_t)row * D + c0);
-        float gm[EPC];
-        load_params<EPC>(gamma, c0, gm);
+        const Chunk<T>& cd = cdv[ch];
+        const Chunk<T>& cz = czv[ch];
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
           const float go = DT<T>::from(cd.e[j]) * kp;
           const float x = (DT<T>::from(cz.e[j]) - mu) * rs;
-          const float gy = go * gm[j];
+          const float gy = go * gm[ch][j];
           xh[ch * EPC + j] = x; dyh[ch * EPC + j] = gy;
           s1 += gy; s2 += gy * x;
           ag[ch * EPC + j] += go * x; ab[ch * EPC + j] += go;
