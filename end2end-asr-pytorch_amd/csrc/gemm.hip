@@ -290,7 +290,51 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   }
   __syncthreads();                               // all waves are done with the operand stages before the epilogue reuses them
 
-  // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> row-contiguous 16-byte global accesses
+  // ---- epilogue, storage-dtype output with whole 16-byte chunks (every bf16 / fp32-parity activation GEMM of the model):
+  // alpha / bias / ReLU on the accumulators, the tile staged in the OUTPUT dtype (half the LDS bytes of an fp32 tile in
+  // bf16), then one 16-byte LDS read, mask read, optional read-modify-write and store per EPC columns
+  if constexpr (sizeof(TO) == sizeof(T)) {
+    constexpr int EPCO = 16 / (int)sizeof(TO);
+    if (p.vecC && !p.atomic && !p.accumulate && p.N % EPCO == 0 && p.ldc % EPCO == 0) {     // (+= keeps the single rounding of the fp32 path)
+      constexpr int OP = BN * (int)sizeof(TO) + 16;
+      const bool add_bias = p.bias != nullptr && split == 0;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int col = wn * WN + j * 16 + lr;
+        const float bv = (add_bias && n0 + col < p.N) ? p.bias[n0 + col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[i][j][r] * p.alpha + bv;
+            if (p.relu) v = fmaxf(v, 0.f);
+            *reinterpret_cast<TO*>(smem + (wm * WM + i * 16 + g * 4 + r) * OP + col * sizeof(TO)) = DT<TO>::to(v);
+          }
+      }
+      __syncthreads();
+      TO* C = static_cast<TO*>(p.C);
+      const T* Msk = static_cast<const T*>(p.mask);
+      constexpr int CPRO = BN / EPCO;
+      for (int c = tid; c < BM * CPRO; c += 256) {
+        const int row = c / CPRO, col = (c % CPRO) * EPCO;
+        const int gr = m0 + row, gc = n0 + col;
+        if (gr >= p.M || gc >= p.N) continue;
+        Chunk<TO> o;
+        o.v = *reinterpret_cast<const uint4*>(smem + row * OP + col * sizeof(TO));
+        TO* dst = C + (int64_t)gr * p.ldc + gc;
+        if (Msk) {
+          Chunk<T> m;
+          m.v = *reinterpret_cast<const uint4*>(Msk + (int64_t)gr * p.ldc + gc);
+#pragma unroll
+          for (int e = 0; e < EPCO; ++e)
+            if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<TO>::to(0.f);
+        }
+        *reinterpret_cast<uint4*>(dst) = o.v;
+      }
+      return;
+    }
+  }
+  // ---- general epilogue: accumulators -> LDS (fp32, padded rows) -> row-contiguous 16-byte global accesses
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
