@@ -742,6 +742,70 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
   }
   __syncthreads();                               // operand stage free for the epilogue
 
+  // ---- storage-dtype output in whole 16-byte chunks (every data-gradient GEMM of the model).  Plain store: the tile is staged
+  // in the output dtype.  Accumulate (dX added into the residual gradient): staged in fp32 so that C + acc is rounded ONCE.
+  if constexpr (sizeof(TO) == sizeof(T)) {
+    constexpr int EPCO = 16 / (int)sizeof(TO);
+    if (p.vecC && p.N % EPCO == 0 && p.ldc % EPCO == 0) {
+      TO* C = static_cast<TO*>(p.C);
+      const T* Msk = static_cast<const T*>(p.mask);
+      constexpr int CPRO = BN / EPCO;
+      if (!p.accumulate) {
+        constexpr int OP = BN * (int)sizeof(TO) + 16;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *reinterpret_cast<TO*>(smem + (wm * WM + i * 16 + g * 4 + r) * OP + (wn * WN + j * 16 + lr) * sizeof(TO)) =
+                  DT<TO>::to(acc[i][j][r] * p.alpha);
+        __syncthreads();
+        for (int c = tid; c < BM * CPRO; c += 256) {
+          const int row = c / CPRO, col = (c % CPRO) * EPCO;
+          const int gr = m0 + row, gc = n0 + col;
+          if (gr >= p.M || gc >= p.N) continue;
+          Chunk<TO> o;
+          o.v = *reinterpret_cast<const uint4*>(smem + row * OP + col * sizeof(TO));
+          if (Msk) {
+            Chunk<T> m;
+            m.v = *reinterpret_cast<const uint4*>(Msk + (int64_t)gr * p.ldc + gc);
+#pragma unroll
+            for (int e = 0; e < EPCO; ++e)
+              if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<TO>::to(0.f);
+          }
+          *reinterpret_cast<uint4*>(C + (int64_t)gr * p.ldc + gc) = o.v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              *reinterpret_cast<float*>(smem + (wm * WM + i * 16 + g * 4 + r) * CPITCH + (wn * WN + j * 16 + lr) * 4) = acc[i][j][r] * p.alpha;
+        __syncthreads();
+        for (int c = tid; c < BM * CPRO; c += 256) {
+          const int row = c / CPRO, col = (c % CPRO) * EPCO;
+          const int gr = m0 + row, gc = n0 + col;
+          if (gr >= p.M || gc >= p.N) continue;
+          TO* dst = C + (int64_t)gr * p.ldc + gc;
+          Chunk<TO> o, old;
+          old.v = *reinterpret_cast<const uint4*>(dst);
+          Chunk<T> m;
+          if (Msk) m.v = *reinterpret_cast<const uint4*>(Msk + (int64_t)gr * p.ldc + gc);
+#pragma unroll
+          for (int e = 0; e < EPCO; ++e) {
+            float v = *reinterpret_cast<const float*>(smem + row * CPITCH + (col + e) * 4);
+            if (Msk && !(DT<T>::from(m.e[e]) > 0.f)) v = 0.f;
+            o.e[e] = DT<TO>::to(v + DT<TO>::from(old.e[e]));
+          }
+          *reinterpret_cast<uint4*>(dst) = o.v;
+        }
+      }
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
