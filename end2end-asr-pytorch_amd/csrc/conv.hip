@@ -185,10 +185,11 @@ template <typename T, int NCO, int TH, int TPS, int WBUF>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CPP = 64 / EPC;            // 16-B chunks per 64-channel pixel slice
-  // LDS rows (pixel slices / weight rows).  Cout 64: unpadded 128-byte rows, 16-B chunk c of row r in slot c ^ (r & 7) -- 39 KB,
-  // 4 workgroups per CU instead of 3 (+9 % measured).  Cout 128 (2 workgroups per CU either way): rows padded by 16 B.
-  constexpr bool SWZ = NCO == 64;
-  constexpr int PP = 64 * ESZ + (SWZ ? 0 : 16);
+  // LDS rows (pixel slices / weight rows): unpadded rows of 64 channels, 16-B chunk c of row r in slot c ^ (r & 7) (conflict-free
+  // operand reads; the image is lane-linear, so the halo patch can be filled by the LDS-DMA with the swizzle applied on the
+  // source address).  fp32 rows are 256 B = 16 chunks: the XOR only permutes the low 3 bits of the chunk index.
+  constexpr bool SWZ = true;
+  constexpr int PP = 64 * ESZ;
 #define ASR_SLOT(ROW, CH) ((SWZ ? ((CH) ^ ((ROW) & 7)) : (CH)) << 4)
   constexpr int NMS = 64 / (4 * EPC);      // macro steps per 64 channels
   constexpr int WM = TH / 4, WN = 4 / WM;  // wave grid
@@ -239,17 +240,33 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
       *reinterpret_cast<u32x4_t*>((DST) + row * PP + ASR_SLOT(row, ch)) = RW[i];                                        \
     }                                                                                                         \
   }
+  // halo patch of one 64-channel slice, HBM -> LDS by the LDS-DMA (no registers, one round trip): chunk c = (pixel hp, slot) of the
+  // lane-linear image takes source chunk slot ^ (hp & 7).  The DMA cannot zero-fill: pixels outside the image are read from a
+  // clamped (valid) address and zeroed afterwards -- only workgroups on the image border have any.
+  constexpr int PIT = (NHALO * CPP + 255) / 256;
+  const bool border = h0 == 0 || w0 == 0 || h0 + TH + 1 > p.H || w0 + 17 > p.W;
   auto pstage = [&](int cc) __attribute__((always_inline)) {
-    for (int c = tid; c < NHALO * CPP; c += 256) {
-      const int hp = c / CPP, ch = c % CPP;
-      const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
-      uint4 v = make_uint4(0u, 0u, 0u, 0u);
-      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && !(p.ablate & 1))
-        v = *reinterpret_cast<const uint4*>(X + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cin + cc * 64 + ch * EPC);
-      *reinterpret_cast<uint4*>(sP + hp * PP + ASR_SLOT(hp, ch)) = v;
+#pragma unroll 1                         // rolled on purpose: a DMA is fire-and-forget, unrolling only pins 2 address registers per pass
+    for (int it = 0; it < PIT; ++it) {
+      const int c = tid + it * 256;
+      if (c < NHALO * CPP) {
+        const int hp = c / CPP, slot = c % CPP, ch = SWZ ? (slot ^ (hp & 7)) : slot;
+        const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
+        const int cy = gy < 0 ? 0 : (gy < p.H ? gy : p.H - 1), cx = gx < 0 ? 0 : (gx < p.W ? gx : p.W - 1);
+        const T* src = X + (((int64_t)b * p.H + cy) * p.W + cx) * p.Cin + cc * 64 + ch * EPC;
+        unsigned char* dst = sP + (it * 256 + (tid & ~63)) * 16;      // wave-uniform; the DMA adds lane * 16
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
     }
   };
-
+  auto pzero = [&]() __attribute__((always_inline)) {
+    for (int c = tid; c < NHALO * CPP; c += 256) {
+      const int hp = c / CPP;
+      const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
+      if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) *reinterpret_cast<u32x4_t*>(sP + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
+    }
+  };
   {
     u32x4_t rw0[WCH];
 #pragma unroll
@@ -263,7 +280,12 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     if (sstep == 0) {
       if (step > 0) __syncthreads();      // everybody is done with the previous channel slice of the patch
       pstage(step / SPS);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                     // patch + weight buffer (step&1) visible
+      if (border) {                        // (workgroup-uniform)
+        pzero();
+        __syncthreads();
+      }
     }
     const bool has_next = step + 1 < nsteps;
     u32x4_t rw[WCH];
@@ -686,7 +708,7 @@ int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + 15) / 16;
-  size_t lds = (size_t)((TH + 2) * 18 + WBUF * TPS * NCO) * (64 * sizeof(T) + (NCO == 64 ? 0 : 16));
+  size_t lds = (size_t)((TH + 2) * 18 + WBUF * TPS * NCO) * (64 * sizeof(T));
   const size_t lds_epi = (size_t)(TH * 16) * (NCO * sizeof(T) + 16);
   if (lds_epi > lds) lds = lds_epi;
   allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>, lds);
