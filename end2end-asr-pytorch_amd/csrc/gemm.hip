@@ -422,10 +422,11 @@ int dispatch_fast(const GemmArgs& a, int splits, hipStream_t s) {
     if (force[0] == '1') return launch_fast<T, TO, 128, 64>(a, splits, s);
     if (force[0] == '2') return launch_fast<T, TO, 64, 64>(a, splits, s);
   }
-  // Measured on MI355X (tools/microbench.py): with this two-stage pipeline the kernel is latency bound, so occupancy
-  // (64x64: 8 workgroups per CU) beats tile size until the grid is very large.
+  // Measured on MI355X (tools/microbench.py, profiles/r01_microbench_v5.txt): 64x64 tiles (8 workgroups per CU) win while the
+  // grid is small; once 128x64 tiles still give >= ~1200 workgroups they tie or win (half the B-operand traffic through L2):
+  // 6400x2048x512 26.4 vs 27.5 us, 6400x5120x512 57.8 vs 71.6 us.  The fp32-output epilogue (vocabulary logits) prefers 64x64.
   const int64_t t64 = ceil_div64(a.M, 64) * ceil_div64(a.N, 64) * splits;
-  if (t64 >= 6000 && a.M > 64) return launch_fast<T, TO, 128, 64>(a, splits, s);
+  if (t64 >= 2400 && a.M > 64 && sizeof(TO) == sizeof(T)) return launch_fast<T, TO, 128, 64>(a, splits, s);
   return launch_fast<T, TO, 64, 64>(a, splits, s);
 }
 
