@@ -1050,7 +1050,8 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
   const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
-  const bool big = t64 >= 6000 && M > 64;
+  static const int64_t nn_big = getenv("ASR_NN_BIG") ? atoll(getenv("ASR_NN_BIG")) : 800;      // 128x64 tiles from this many 64x64 tiles on
+  const bool big = t64 >= nn_big && M > 64;
   if (in_dtype == ASR_F32) return big ? launch_nn<float, float, 128>(p, stream) : launch_nn<float, float, 64>(p, stream);
   if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);
   return big ? launch_nn<bf16_t, float, 128>(p, stream) : launch_nn<bf16_t, float, 64>(p, stream);
