@@ -672,6 +672,147 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
     if (gk + i < K) dst[i] += vv[i];
 }
 
+// ------------------------------------------------------------------------------------------------ TN, 128 x 128 tiles (bf16)
+// Same contraction for the larger weight gradients.  The 64x64-tile kernel above moves 32 flop per byte through L2 (12 TB/s
+// on the 2048x512 FFN gradient): this one owns a 128 x 128 block of dW per workgroup (64 flop per byte), waves in a 2 x 2 grid
+// of 64 x 64 quadrants (each wave contracts EVERY row of a stage: no cross-wave reduction, the partial block goes from the
+// accumulators straight to the workspace / C), 64 rows of m per stage (one LDS stage of 32 KB).
+struct Tn128Args {
+  const void* A; const void* B; float* C; float* colsum; float* ws;
+  int64_t lda, ldb, ldc;
+  int M, N, K, m_per_split, tiles_k, ntiles;
+};
+
+__device__ __forceinline__ uint4 tn128_pack(const unsigned char* tile, int m0, int lr, int g, int c0) {
+  // 8 consecutive rows m0 + 8g .. +7 of column c0 + lr of a [64][128] bf16 tile (256-byte rows, chunk c of row r in slot
+  // c ^ (r & 7): the XOR permutes the low 3 bits of the 4-bit chunk index)
+  const int row = m0 + 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);
+  const int chunk = col >> 3, half = (col >> 2) & 1;
+  const uint2 lo = asr_lds_read_tr16(tile + row * 256 + ((chunk ^ (row & 7)) << 4) + half * 8);
+  const uint2 hi = asr_lds_read_tr16(tile + (row + 4) * 256 + ((chunk ^ ((row + 4) & 7)) << 4) + half * 8);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn128_kernel(Tn128Args p) {
+  constexpr int RM = 64, ROWB = 256, TILEB = RM * ROWB;      // one operand tile of a stage: 16 KB
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int split = wid / p.ntiles, tile = wid % p.ntiles;
+  const int n0 = (tile / p.tiles_k) * 128, k0 = (tile % p.tiles_k) * 128;
+  const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+  const int nstage = (m_end - m_beg + RM - 1) / RM;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)(p.ldb * 2 / 16);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = p.colsum != nullptr && k0 == 0 && wk == 0;
+
+  for (int st = 0; st < nstage; ++st) {
+    if (st > 0) __syncthreads();                 // everybody is done reading the previous stage
+    const int64_t mrow = m_beg + (int64_t)st * RM;
+#pragma unroll
+    for (int i = 0; i < RM * 16 / 256; ++i) {
+      const int c = i * 256 + tid, row = c >> 4, slot = (c & 15) ^ (row & 7);
+      int ca = n0 * 2 / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;       // columns past N / K are never stored
+      int cb = k0 * 2 / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+      const int64_t gr = mrow + row < p.M ? mrow + row : (int64_t)p.M - 1;       // rows past M: see the zero fill below
+      unsigned char* d = smem + (i * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + gr * p.lda * 2 + (int64_t)ca * 16),
+                                       (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + gr * p.ldb * 2 + (int64_t)cb * 16),
+                                       (__attribute__((address_space(3))) void*)(d + TILEB), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int valid = m_end - (m_beg + st * RM);
+    if (valid < RM) {                            // partial last stage: zero the A rows that do not exist (B holds finite data)
+      for (int c = valid * 16 + tid; c < RM * 16; c += 256) *reinterpret_cast<uint4*>(smem + c * 16) = make_uint4(0u, 0u, 0u, 0u);
+      __syncthreads();
+    }
+    const unsigned char* sA = smem;
+    const unsigned char* sB = smem + TILEB;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      uint4 a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = tn128_pack(sA, ms * 32, lr, g, wn * 64 + i * 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = tn128_pack(sB, ms * 32, lr, g, wk * 64 + j * 16);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Chunk<bf16_t> c; c.v = a[i];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma16<bf16_t>(acc[i][j], a[i], b[j]);
+    }
+  }
+
+  // ---- the wave's 64 x 64 quadrant: lane (lr, g) holds rows 4g..4g+3 of column lr of every fragment
+  const bool single = gridDim.x == (unsigned)p.ntiles;
+  float* part = p.ws ? p.ws + ((int64_t)split * p.ntiles + tile) * 16384 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wn * 64 + i * 16 + g * 4 + r, gn = n0 + row;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wk * 64 + j * 16 + lr, gk = k0 + col;
+        const float v = acc[i][j][r];
+        if (!single && part) part[row * 128 + col] = v;
+        else if (gn < p.N && gk < p.K) {
+          float* dst = p.C + (int64_t)gn * p.ldc + gk;
+          if (single) *dst += v; else atomicAdd(dst, v);
+        }
+      }
+    }
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int gn = n0 + wn * 64 + i * 16 + lr;
+      if (g == 0 && gn < p.N) atomicAdd(p.colsum + gn, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tn128_reduce_kernel(const float* __restrict__ ws, float* C, int64_t ldc, int N, int K,
+                                                           int ntiles, int tiles_k, int splits) {
+  const int tile = blockIdx.x >> 4;
+  const int e = ((blockIdx.x & 15) * 256 + threadIdx.x) * 4;       // 4 consecutive columns of one row of the 128 x 128 block
+  const int row = e >> 7, col = e & 127;
+  const int gn = (tile / tiles_k) * 128 + row, gk = (tile % tiles_k) * 128 + col;
+  if (gn >= N || gk >= K) return;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4 t = *reinterpret_cast<const float4*>(ws + ((int64_t)sp * ntiles + tile) * 16384 + e);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  float* dst = C + (int64_t)gn * ldc + gk;
+  const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (gk + i < K) dst[i] += vv[i];
+}
+
 // ================================================================================================ NN (data gradient)
 // C[M,N] (op)= alpha * sum_k A[m,k] * B[k,n]  with B = W (K_red, N_out) in its NATURAL master layout: dX = dY . W needs the
 // contraction index as W's slow axis, so the B operand is built with the transposing LDS read (bf16) / 4-byte reads (fp32)
@@ -976,8 +1117,29 @@ int tn_splits(int M, int N, int K, int splits, int dtype, bool have_ws) {
 }
 }  // namespace
 
+namespace {
+// 128 x 128-tile kernel: bf16, automatic split, a workspace, and enough 128-blocks that ~512 workgroups of >= 4 stages exist.
+// Returns the number of m-slices (0 = use the 64 x 64-tile kernel).
+int tn128_splits(int M, int N, int K, int splits, int dtype) {
+  static const int enabled = getenv("ASR_TN_128") ? atoi(getenv("ASR_TN_128")) : 1;
+  static const int min_tiles = getenv("ASR_TN_128_MIN") ? atoi(getenv("ASR_TN_128_MIN")) : 128;      // measured: wins for 512x5120 (160 blocks), loses for 64-block outputs
+  if (!enabled || dtype != ASR_BF16 || splits > 0 || N < 128 || K < 128) return 0;
+  const int nt = ((N + 127) / 128) * ((K + 127) / 128);
+  if (nt < min_tiles) return 0;
+  const int stages = (M + 63) / 64;
+  int sp = (512 + nt / 2) / nt;
+  if (sp > 16) sp = 16;
+  while (sp > 1 && stages / sp < 4) --sp;
+  if (sp < 1) sp = 1;
+  const int sps = (stages + sp - 1) / sp;
+  return (stages + sps - 1) / sps;
+}
+}  // namespace
+
 extern "C" int64_t asr_gemm_tn_workspace(int M, int N, int K, int splits, int dtype) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int s128 = tn128_splits(M, N, K, splits, dtype);
+  if (s128 > 1) return (int64_t)s128 * ((N + 127) / 128) * ((K + 127) / 128) * 16384;
   const int sp = tn_splits(M, N, K, splits, dtype, true);
   return sp > 1 ? (int64_t)sp * ((N + 63) / 64) * ((K + 63) / 64) * 4096 : 0;
 }
@@ -993,6 +1155,28 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   // 16-byte aligned rows; a partial last stage of m is zero-filled in LDS by the kernel
   if (lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K)
     return ASR_EUNSUPPORTED;
+  {
+    const int s128 = tn128_splits(M, N, K, splits, dtype);
+    const int64_t need = (int64_t)s128 * ((N + 127) / 128) * ((K + 127) / 128) * 16384;
+    if (s128 >= 1 && (s128 == 1 || (workspace && workspace_floats >= need))) {
+      Tn128Args q{};
+      q.A = A; q.B = B; q.C = C; q.colsum = colsum_acc; q.ws = s128 > 1 ? workspace : nullptr;
+      q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.M = M; q.N = N; q.K = K;
+      q.tiles_k = (K + 127) / 128;
+      q.ntiles = ((N + 127) / 128) * q.tiles_k;
+      const int stages = (M + 63) / 64;
+      q.m_per_split = ((stages + s128 - 1) / s128) * 64;
+      AsrProfScope prof(ASR_OP_GEMM, stream);
+      hipLaunchKernelGGL(gemm_tn128_kernel, dim3((unsigned)(q.ntiles * s128)), dim3(256), 2 * 64 * 256, stream, q);
+      ASR_LAUNCH_CHECK();
+      if (q.ws) {
+        hipLaunchKernelGGL(tn128_reduce_kernel, dim3((unsigned)(q.ntiles * 16)), dim3(256), 0, stream, q.ws, C, ldc, N, K, q.ntiles,
+                           q.tiles_k, s128);
+        ASR_LAUNCH_CHECK();
+      }
+      return ASR_OK;
+    }
+  }
   TnArgs p{};
   p.A = A; p.B = B; p.C = C; p.colsum = colsum_acc;
   p.lda = lda; p.ldb = ldb; p.ldc = ldc;

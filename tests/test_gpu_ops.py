@@ -93,7 +93,7 @@ def test_gemm_splitk_accumulate_and_mask(ops, dtype):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(256, 64, 64), (384, 200, 70), (1280, 512, 2048), (128, 35, 161), (100, 64, 64),
-                                   (12720, 512, 512), (1, 8, 8), (333, 96, 40)])
+                                   (12720, 512, 512), (1, 8, 8), (333, 96, 40), (700, 1024, 2056)])
 def test_gemm_tn_weight_gradient(ops, dtype, shape):
     """dW += dY^T X and db += colsum(dY) straight from the natural layouts (transposing LDS reads)."""
     M, N, K = shape
