@@ -693,8 +693,9 @@ __device__ __forceinline__ uint4 tn128_pack(const unsigned char* tile, int m0, i
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 
+template <int RM>
 __global__ __launch_bounds__(256) void gemm_tn128_kernel(Tn128Args p) {
-  constexpr int RM = 64, ROWB = 256, TILEB = RM * ROWB;      // one operand tile of a stage: 16 KB
+  constexpr int ROWB = 256, TILEB = RM * ROWB;               // one operand tile of a stage: 16 KB (RM = 64) / 32 KB (128)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(256) void gemm_tn128_kernel(Tn128Args p) {
     const unsigned char* sA = smem;
     const unsigned char* sB = smem + TILEB;
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
+    for (int ms = 0; ms < RM / 32; ++ms) {
       uint4 a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = tn128_pack(sA, ms * 32, lr, g, wn * 64 + i * 16);
@@ -1167,7 +1168,13 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
       const int stages = (M + 63) / 64;
       q.m_per_split = ((stages + s128 - 1) / s128) * 64;
       AsrProfScope prof(ASR_OP_GEMM, stream);
-      hipLaunchKernelGGL(gemm_tn128_kernel, dim3((unsigned)(q.ntiles * s128)), dim3(256), 2 * 64 * 256, stream, q);
+      static const int rm128 = getenv("ASR_TN_128_RM") ? atoi(getenv("ASR_TN_128_RM")) : 64;
+      if (rm128 == 128) {
+        static bool granted = false;
+        if (!granted) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 256); granted = true; }
+        hipLaunchKernelGGL(gemm_tn128_kernel<128>, dim3((unsigned)(q.ntiles * s128)), dim3(256), 2 * 128 * 256, stream, q);
+      } else
+      hipLaunchKernelGGL(gemm_tn128_kernel<64>, dim3((unsigned)(q.ntiles * s128)), dim3(256), 2 * 64 * 256, stream, q);
       ASR_LAUNCH_CHECK();
       if (q.ws) {
         hipLaunchKernelGGL(tn128_reduce_kernel, dim3((unsigned)(q.ntiles * 16)), dim3(256), 0, stream, q.ws, C, ldc, N, K, q.ntiles,
