@@ -358,21 +358,38 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   T* Y = static_cast<T*>(p.y);
   const T* Msk = static_cast<const T*>(p.mask_src);
   constexpr int CPX = NCO / EPC;                 // 16-byte output chunks per pixel
-  for (int c = tid; c < NPX * CPX; c += 256) {
-    const int px = c / CPX, ch0 = (c % CPX) * EPC;
-    const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
-    if (gy >= p.H || gx >= p.W) continue;
-    const int64_t off = (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0;
-    Chunk<T> o;
-    o.v = *reinterpret_cast<const uint4*>(smem + px * CP + ch0 * ESZ);
-    if (Msk) {
-      Chunk<T> m;
-      m.v = *reinterpret_cast<const uint4*>(Msk + off);
+  constexpr int EIT = NPX * CPX / 256;           // chunks per thread (exact: NPX * CPX is a multiple of 256)
+  if (Msk) {
+    // ReLU mask of the consumer's input: ALL of the thread's mask chunks are loaded first (clamped addresses), so the epilogue
+    // pays one memory round trip, not one per chunk
+    u32x4_t mk[EIT];
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int c = tid + it * 256, px = c / CPX, ch0 = (c % CPX) * EPC;
+      const int gy = min(h0 + (px >> 4), p.H - 1), gx = min(w0 + (px & 15), p.W - 1);
+      mk[it] = *reinterpret_cast<const u32x4_t*>(Msk + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0);
+    }
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
+      const int c = tid + it * 256, px = c / CPX, ch0 = (c % CPX) * EPC;
+      const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
+      if (gy >= p.H || gx >= p.W) continue;
+      Chunk<T> o, m;
+      o.v = *reinterpret_cast<const uint4*>(smem + px * CP + ch0 * ESZ);
+      m.v = __builtin_bit_cast(uint4, mk[it]);
 #pragma unroll
       for (int e = 0; e < EPC; ++e)
         if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<T>::to(0.f);
+      if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0) = o.v;
     }
-    if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + off) = o.v;
+  } else {
+    for (int c = tid; c < NPX * CPX; c += 256) {
+      const int px = c / CPX, ch0 = (c % CPX) * EPC;
+      const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
+      if (gy >= p.H || gx >= p.W) continue;
+      const uint4 o = *reinterpret_cast<const uint4*>(smem + px * CP + ch0 * ESZ);
+      if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0) = o;
+    }
   }
 }
 
@@ -716,17 +733,19 @@ int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
-// Tile height 8 rows (the 16-row tile does more MFMAs per LDS operand read but costs a workgroup per CU; it only wins for
-// 128 -> 64 channels, ASR_IGEMM_TH=16 keeps it as a tuning option).  ASR_IGEMM_TPS=2 stages TWO taps per step at Cout 64 (32
-// MFMAs between barriers) -- measured slower: it costs a workgroup per CU, and occupancy is what this kernel lives on.
+// Tile height: 16 rows in bf16 (wave tile 4 x 4 / 4 x 8 fragments: 2 / 2.7 MFMAs per LDS operand read), 8 rows in fp32 (LDS).
+// History of this choice: with register-staged patches and double-buffered weights the 16-row tile LOST to the 8-row one (a
+// workgroup per CU less); once the patch came in by LDS-DMA, the weights were single buffered and the mask loads of the epilogue
+// hoisted, it wins on every layer (profiles/r01_microbench_v7.txt; ASR_IGEMM_TH=8 restores the small tile).
+// ASR_IGEMM_TPS=2 stages TWO taps per step at Cout 64 with the 8-row tile -- measured slower.
 // Weights are SINGLE buffered in LDS (prefetched in registers): one more barrier per step, but one more workgroup per CU --
 // +9 % (Cout 64) to +23 % (Cout 128) measured; ASR_IGEMM_WBUF=2 restores the double buffer.
 template <typename T, int NCO>
 int launch_igemm(const ConvArgs& a, hipStream_t s) {
-  static const int th = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 8;
+  static const int th = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 16;
   static const int tps = getenv("ASR_IGEMM_TPS") ? atoi(getenv("ASR_IGEMM_TPS")) : 1;
   static const int wbuf = getenv("ASR_IGEMM_WBUF") ? atoi(getenv("ASR_IGEMM_WBUF")) : 1;
-  if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1, 2>(a, s);
+  if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1, 1>(a, s);
   if (sizeof(T) == 2 && NCO == 64 && tps == 2) return launch_igemm_t<T, NCO, 8, 2, 2>(a, s);
   if (wbuf == 1) return launch_igemm_t<T, NCO, 8, 1, 1>(a, s);
   return launch_igemm_t<T, NCO, 8, 1, 2>(a, s);
