@@ -15,6 +15,7 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "asr_hi
 
 F32, BF16 = 0, 1
 GEMM_RELU, GEMM_ACCUMULATE = 1, 2
+ATTN_DELTA, ATTN_DQ, ATTN_DKV, ATTN_ALL = 1, 2, 4, 7
 OP_GEMM, OP_CONV_IGEMM, OP_CONV_WGRAD, OP_ATTN_FWD, OP_ATTN_BWD, OP_ADD_LN, OP_CE, OP_ADAM, OP_CONV1, OP_POOL, \
     OP_LAYOUT = range(11)
 
@@ -41,7 +42,7 @@ _SIGS = {
     "asr_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _P, _L, _L,
                           _I, _F, _F, _U64, _P, _I, _P]),
     "asr_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,
-                          _P, _P, _L, _L, _I, _F, _F, _U64, _P, _I, _P]),
+                          _P, _P, _L, _L, _I, _F, _F, _U64, _P, _I, _I, _P]),
     "asr_decoder_preprocess": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "asr_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _P]),
     "asr_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _I, _P]),

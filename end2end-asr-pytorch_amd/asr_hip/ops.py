@@ -275,10 +275,23 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
     delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
     msb, msq = _mask_strides(key_pad, B, Tq, Tk)
     qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
-    L.call("asr_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dq),
-           L.ptr(dk), L.ptr(dv), B, H, Tq, Tk, d, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],
-           L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), _seed_dev(q),
-           L.dt(q), L.stream())
+    sd = _seed_dev(q)
+
+    def launch(parts):
+        L.call("asr_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dq),
+               L.ptr(dk), L.ptr(dv), B, H, Tq, Tk, d, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],
+               L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), sd, parts,
+               L.dt(q), L.stream())
+
+    f = fork()
+    if f.on and os.environ.get('ASR_ATTN_SPLIT', '1') != '0':   # inside a captured graph: dK/dV on the second stream next to dQ (both only need delta)
+        launch(L.ATTN_DELTA)
+        with f:
+            launch(L.ATTN_DKV)
+        launch(L.ATTN_DQ)
+        f.join()
+    else:
+        launch(L.ATTN_ALL)
     return dq, dk, dv
 
 

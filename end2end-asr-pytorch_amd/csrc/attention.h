@@ -14,6 +14,7 @@ struct AttnArgs {
   const int32_t* key_len; const uint8_t* key_pad; int64_t m_sb, m_sq;
   int causal; float scale; uint32_t thr /* 16-bit dropout threshold */; float inv_keep; uint64_t seed; const uint64_t* seed_dev;
   int vec;     // all pointers 16-B aligned and all strides multiples of EPC
+  int parts;   // backward: ASR_ATTN_DELTA | ASR_ATTN_DQ | ASR_ATTN_DKV (which of its three kernels this call launches)
 };
 
 

@@ -443,18 +443,24 @@ int run_fwd(const AttnArgs& p, hipStream_t s) {
 template <typename T, int HD>
 int run_bwd(const AttnArgs& p, hipStream_t s) {
   const int64_t rows = (int64_t)p.B * p.H * p.Tq;
-  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, p, HD);
-  ASR_LAUNCH_CHECK();
+  if (p.parts & ASR_ATTN_DELTA) {
+    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, p, HD);
+    ASR_LAUNCH_CHECK();
+  }
   const size_t l1 = lds_dq<T, HD>(), l2 = lds_dkv<T, HD>();
   static bool granted = false;
   if (l2 > 48 * 1024 && !granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
     granted = true;
   }
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3((p.Tq + 63) / 64, p.B * p.H), dim3(256), l1, s, p);
-  ASR_LAUNCH_CHECK();
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3((p.Tk + 63) / 64, p.B * p.H), dim3(256), l2, s, p);
-  ASR_LAUNCH_CHECK();
+  if (p.parts & ASR_ATTN_DQ) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<T, HD>), dim3((p.Tq + 63) / 64, p.B * p.H), dim3(256), l1, s, p);
+    ASR_LAUNCH_CHECK();
+  }
+  if (p.parts & ASR_ATTN_DKV) {
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<T, HD>), dim3((p.Tk + 63) / 64, p.B * p.H), dim3(256), l2, s, p);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }
 
@@ -518,16 +524,17 @@ extern "C" int asr_attn_bwd(const void* Q, const void* K, const void* V, const v
                             float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
                             int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
                             const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,
-                            float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype,
+                            float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int parts, int dtype,
                             hipStream_t stream) {
   ASR_CHECK_ARG(Q && K && V && O && dO && lse && delta && dQ && dK && dV);
+  ASR_CHECK_ARG(parts > 0 && parts <= (ASR_ATTN_DELTA | ASR_ATTN_DQ | ASR_ATTN_DKV));
   AttnArgs p{};
   int rc = fill_common(p, B, H, Tq, Tk, d, q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st, key_len, key_pad, mask_sb, mask_sq, causal,
                        scale, dropout_p, seed, seed_dev, dtype);
   if (rc != ASR_OK) return rc;
   if (B == 0 || Tq == 0 || Tk == 0) return ASR_OK;
   p.Q = Q; p.K = K; p.V = V; p.O = O; p.dO = dO; p.lse = const_cast<float*>(lse); p.delta = delta;
-  p.dQ = dQ; p.dK = dK; p.dV = dV;
+  p.dQ = dQ; p.dK = dK; p.dV = dV; p.parts = parts;
   p.vec = p.vec && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(dO);
   AsrProfScope prof(ASR_OP_ATTN_BWD, stream);
   rc = attn_fast_bwd(p, d, dtype, stream);

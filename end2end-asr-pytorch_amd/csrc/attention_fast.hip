@@ -595,12 +595,18 @@ int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   for (const void* ptr : {(const void*)p.dQ, (const void*)p.dK, (const void*)p.dV, p.O})
     if ((((uintptr_t)ptr) & 15) != 0) return ASR_EUNSUPPORTED;
   const int64_t rows = (int64_t)p.B * p.H * p.Tq;
-  attn_delta_bf16_d64_kernel<<<dim3((unsigned)ceil_div64(rows, 32)), dim3(256), 0, s>>>(p);
-  ASR_LAUNCH_CHECK();
-  attn_bwd_dq_bf16_d64_kernel<<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
-  ASR_LAUNCH_CHECK();
-  attn_bwd_dkv_bf16_d64_kernel<<<dim3((unsigned)(((p.Tk + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
-  ASR_LAUNCH_CHECK();
+  if (p.parts & ASR_ATTN_DELTA) {
+    attn_delta_bf16_d64_kernel<<<dim3((unsigned)ceil_div64(rows, 32)), dim3(256), 0, s>>>(p);
+    ASR_LAUNCH_CHECK();
+  }
+  if (p.parts & ASR_ATTN_DQ) {
+    attn_bwd_dq_bf16_d64_kernel<<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    ASR_LAUNCH_CHECK();
+  }
+  if (p.parts & ASR_ATTN_DKV) {
+    attn_bwd_dkv_bf16_d64_kernel<<<dim3((unsigned)(((p.Tk + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    ASR_LAUNCH_CHECK();
+  }
   return ASR_OK;
 }
 

@@ -28,6 +28,9 @@ typedef struct ihipStream_t* asr_stream_t; /* == hipStream_t */
 
 enum { ASR_OK = 0, ASR_EINVAL = -1, ASR_ELAUNCH = -2, ASR_EUNSUPPORTED = -3, ASR_ERUNTIME = -4 };
 enum { ASR_F32 = 0, ASR_BF16 = 1 };
+/* asr_attn_bwd `parts`: the backward is three kernels (delta = rowsum(dO*O); dQ; dK/dV).  dQ and dK/dV only depend on delta, so
+ * a caller may launch them on two streams: parts = DELTA on the first, then DQ on one and DKV on the other.                     */
+enum { ASR_ATTN_DELTA = 1, ASR_ATTN_DQ = 2, ASR_ATTN_DKV = 4, ASR_ATTN_ALL = 7 };
 enum { ASR_GEMM_RELU = 1, ASR_GEMM_ACCUMULATE = 2 };
 /* op ids for the built-in HIP-event profiler (asr_prof_*) */
 enum {
@@ -117,7 +120,7 @@ int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, con
                  float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
                  int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
                  const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,
-                 float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
+                 float scale, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int parts, int dtype, asr_stream_t stream);
 
 /* ---- decoder input side ---------------------------------------------------------------------------------------
  * Decoder.preprocess (transformer.py:254-266) + masks (:282-286): strip PAD(0) anywhere, seq_in = [SOS]+y padded
