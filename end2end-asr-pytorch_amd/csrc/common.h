@@ -23,12 +23,10 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // ---------------------------------------------------------------------------------------------- conversions
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)0x7fc0;   // NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                               // round to nearest even
-  return (bf16_t)(u >> 16);
-}
+// round to nearest even, NaN -> quiet NaN: the hardware conversion (v_cvt_pk_bf16_f32), one instruction instead of the five of
+// the integer formulation (the same values for every finite input and for infinities)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+
 template <typename T> struct DT;
 template <> struct DT<float> {
   static constexpr int kDtype = ASR_F32;
