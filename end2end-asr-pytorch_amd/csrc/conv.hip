@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv_c64.h"
 
 namespace {
 
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     const int sstep = step % SPS;
     if (sstep == 0) {
       if (step > 0) __syncthreads();      // everybody is done with the previous channel slice of the patch
-      pstage(step / SPS);
+      if (!(p.ablate & 1)) pstage(step / SPS);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                     // patch + weight buffer (step&1) visible
       if (border) {                        // (workgroup-uniform)
@@ -315,7 +316,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], bfr[j]);
+            for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], bfr[j], a[i]);   // D = (co rows) x (pixel columns)
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(a[i].x));
@@ -337,58 +338,70 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #undef ASR_WWRITE
 #undef ASR_SLOT
 
-  // ---- epilogue through LDS: bias / ReLU on the accumulators, then the (NPX px, NCO) tile in the storage dtype -> per pixel
-  // 16-byte channel-contiguous chunks, so that the mask reads and the NHWC stores are row-contiguous vector accesses
-  constexpr int CP = NCO * ESZ + 16;
-  __syncthreads();                               // all waves are done reading the patch / weight tiles
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int co = wn * (NCO / WN) + j * 16 + lr;
-    const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = acc[i][j][r] + bv;
-        if (p.relu) x = fmaxf(x, 0.f);
-        *reinterpret_cast<T*>(smem + ((wm * 4 + i) * 16 + g * 4 + r) * CP + co * ESZ) = DT<T>::to(x);
-      }
-  }
-  __syncthreads();
+  // ---- epilogue straight from the accumulators (operands were swapped: a fragment is (16 co rows) x (16 pixel columns), so a
+  // lane holds 4 consecutive output channels of ONE pixel).  bias / ReLU in fp32, then the storage dtype; bf16 lanes exchange
+  // halves with the neighbouring lane group (v_permlane16_swap) so that every lane owns one aligned 16-byte chunk of a pixel's
+  // NHWC row: no LDS staging, no barrier, 64 contiguous bytes per pixel per store instruction.
   T* Y = static_cast<T*>(p.y);
   const T* Msk = static_cast<const T*>(p.mask_src);
-  constexpr int CPX = NCO / EPC;                 // 16-byte output chunks per pixel
-  constexpr int EIT = NPX * CPX / 256;           // chunks per thread (exact: NPX * CPX is a multiple of 256)
-  if (Msk) {
-    // ReLU mask of the consumer's input: ALL of the thread's mask chunks are loaded first (clamped addresses), so the epilogue
-    // pays one memory round trip, not one per chunk
-    u32x4_t mk[EIT];
+  const int gx = w0 + lr;
+  constexpr int NJ = ESZ == 2 ? FN / 2 : FN;        // chunks per pixel fragment and lane
+  // channel of the lane's chunk q: bf16 pairs fragments (2q, 2q+1) -- even lane groups end up with 8 channels of 2q, odd ones of 2q+1
+  int cho[NJ];
 #pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-      const int c = tid + it * 256, px = c / CPX, ch0 = (c % CPX) * EPC;
-      const int gy = min(h0 + (px >> 4), p.H - 1), gx = min(w0 + (px & 15), p.W - 1);
-      mk[it] = *reinterpret_cast<const u32x4_t*>(Msk + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0);
+  for (int q = 0; q < NJ; ++q)
+    cho[q] = wn * (NCO / WN) + (ESZ == 2 ? (2 * q + (g & 1)) * 16 + 4 * (g & 2) : q * 16 + 4 * g);
+  u32x4_t mk[4][NJ];
+  if (Msk) {                                        // all mask chunks first (clamped addresses): one memory round trip
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int gy = min(h0 + wm * 4 + i, p.H - 1);
+      const T* mrow = Msk + (((int64_t)b * p.H + gy) * p.W + min(gx, p.W - 1)) * p.Cout;
+#pragma unroll
+      for (int q = 0; q < NJ; ++q) mk[i][q] = *reinterpret_cast<const u32x4_t*>(mrow + cho[q]);
     }
+  }
+  f32x4_t bv[FN];
 #pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-      const int c = tid + it * 256, px = c / CPX, ch0 = (c % CPX) * EPC;
-      const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
-      if (gy >= p.H || gx >= p.W) continue;
-      Chunk<T> o, m;
-      o.v = *reinterpret_cast<const uint4*>(smem + px * CP + ch0 * ESZ);
-      m.v = __builtin_bit_cast(uint4, mk[it]);
+  for (int j = 0; j < FN; ++j)
+    bv[j] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + wn * (NCO / WN) + j * 16 + 4 * g) : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < EPC; ++e)
-        if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<T>::to(0.f);
-      if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0) = o.v;
-    }
-  } else {
-    for (int c = tid; c < NPX * CPX; c += 256) {
-      const int px = c / CPX, ch0 = (c % CPX) * EPC;
-      const int gy = h0 + (px >> 4), gx = w0 + (px & 15);
-      if (gy >= p.H || gx >= p.W) continue;
-      const uint4 o = *reinterpret_cast<const uint4*>(smem + px * CP + ch0 * ESZ);
-      if (!(p.ablate & 4)) *reinterpret_cast<uint4*>(Y + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cout + ch0) = o;
+  for (int i = 0; i < 4; ++i) {
+    const int gy = h0 + wm * 4 + i;
+    const bool ok = gy < p.H && gx < p.W;
+    T* yrow = Y + (((int64_t)b * p.H + (ok ? gy : 0)) * p.W + (ok ? gx : 0)) * p.Cout;
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) {
+      Chunk<T> o;
+      if constexpr (ESZ == 2) {
+        uint32_t lo[2], hi[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          f32x4_t xa = acc[i][2 * q] + bv[2 * q], xb = acc[i][2 * q + 1] + bv[2 * q + 1];
+          if (p.relu) {
+            xa[2 * d] = fmaxf(xa[2 * d], 0.f); xa[2 * d + 1] = fmaxf(xa[2 * d + 1], 0.f);
+            xb[2 * d] = fmaxf(xb[2 * d], 0.f); xb[2 * d + 1] = fmaxf(xb[2 * d + 1], 0.f);
+          }
+          const uint32_t pa = (uint32_t)DT<T>::to(xa[2 * d]) | ((uint32_t)DT<T>::to(xa[2 * d + 1]) << 16);
+          const uint32_t pb = (uint32_t)DT<T>::to(xb[2 * d]) | ((uint32_t)DT<T>::to(xb[2 * d + 1]) << 16);
+          // (a, b) -> a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3}
+          auto sw = __builtin_amdgcn_permlane16_swap(pa, pb, false, false);
+          lo[d] = sw[0]; hi[d] = sw[1];
+        }
+        o.v = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+      } else {
+        f32x4_t x = acc[i][q] + bv[q];
+        if (p.relu) { x[0] = fmaxf(x[0], 0.f); x[1] = fmaxf(x[1], 0.f); x[2] = fmaxf(x[2], 0.f); x[3] = fmaxf(x[3], 0.f); }
+        o.v = __builtin_bit_cast(uint4, x);
+      }
+      if (Msk) {
+        Chunk<T> m;
+        m.v = __builtin_bit_cast(uint4, mk[i][q]);
+#pragma unroll
+        for (int e = 0; e < EPC; ++e)
+          if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<T>::to(0.f);
+      }
+      if (ok && !(p.ablate & 4)) *reinterpret_cast<uint4*>(yrow + cho[q]) = o.v;
     }
   }
 }
@@ -726,8 +739,6 @@ int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + 15) / 16;
   size_t lds = (size_t)((TH + 2) * 18 + WBUF * TPS * NCO) * (64 * sizeof(T));
-  const size_t lds_epi = (size_t)(TH * 16) * (NCO * sizeof(T) + 16);
-  if (lds_epi > lds) lds = lds_epi;
   allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>, lds);
   hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
@@ -819,6 +830,15 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
   { const char* ab = getenv("ASR_IGEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  // the 64 -> 64 channel bf16 layer (full-resolution conv2 and its dgrad) has a persistent kernel with register-resident weights
+  static const bool c64 = !(getenv("ASR_C64") && atoi(getenv("ASR_C64")) == 0);
+  if (c64 && dtype == ASR_BF16 && Cin == 64 && Cout == 64 && (int64_t)B * H * W * 128 < ((int64_t)1 << 32) && !p.ablate) {
+    C64Args a{};
+    a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
+    a.mask = static_cast<const bf16_t*>(mask_src); a.y = static_cast<bf16_t*>(y);
+    a.B = B; a.H = H; a.W = W; a.relu = relu;
+    return asr_conv3x3_c64_launch(a, s);
+  }
   if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
   return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);
 }

@@ -1,0 +1,16 @@
+// Internal interface between conv.hip (asr_conv3x3_igemm dispatch) and conv_c64.hip (persistent 64 -> 64 channel bf16 kernel).
+#pragma once
+#include "common.h"
+
+struct C64Args {
+  const bf16_t* x;      // (B, H, W, 64) NHWC
+  const bf16_t* wk;     // (64 co, 9 taps, 64 ci) packed weights (asr_conv_pack_weight)
+  const float* bias;    // (64) or null
+  const bf16_t* mask;   // (B, H, W, 64) or null: output zeroed where mask <= 0 (ReLU mask of the consumer's input, dgrad)
+  bf16_t* y;            // (B, H, W, 64)
+  int B, H, W, relu;
+  int tiles_h, tiles_w, ntiles;   // filled by the launcher
+  int ablate;                     // tuning only (ASR_C64_ABLATE): 1 = no patch DMA, 2 = no operand reads / MFMAs, 4 = no stores
+};
+
+int asr_conv3x3_c64_launch(const C64Args& a, hipStream_t s);

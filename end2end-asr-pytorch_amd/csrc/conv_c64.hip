@@ -1,0 +1,329 @@
+// 3x3 convolution, 64 -> 64 channels, bf16 NHWC: the full-resolution layer of vgg_cnn (reference: models/asr/transformer.py:44-47,
+// conv2 forward and its dgrad), the largest single kernel of the training step.  A persistent, software-pipelined variant of the
+// implicit GEMM of conv.hip, possible because ALL of the layer's weights (64 co x 9 taps x 64 ci = 72 KB) fit in the register
+// files of one 8-wave workgroup:
+//   * one workgroup per CU walks tiles of 256 output pixels (TH x TW, TW = 16 or 32) x 64 co; wave (wm, wn) owns 4 pixel
+//     fragments x 2 co fragments and keeps its 32 co x 576 k weights in 144 VGPRs for the whole kernel: no weight traffic, no
+//     per-tap barrier;
+//   * the halo patch of tile n+2 travels HBM -> LDS by the LDS-DMA into one of THREE patch buffers while tile n is contracted:
+//     one s_barrier per tile, and the wait on the DMA counter sits after the MFMAs of a whole tile;
+//   * pixels outside the image are DMA'd from a 16-byte zero page (no zero-fill pass);
+//   * operand reads are hand-issued ds_read_b128 (inline asm, double buffered per k step) -- the compiler would otherwise drain
+//     the DMA counter before every LDS read it can see;
+//   * epilogue from the accumulators (co rows x pixel columns): bias / ReLU / bf16 / v_permlane16_swap -> one 16-byte chunk of a
+//     pixel's NHWC row per lane; the dgrad's ReLU-mask chunks are prefetched per lane through a private LDS stash by the same DMA.
+// MFMA-bound: 2*9*64*64 flop per output pixel; HBM bytes per pixel = 2 * 64 * 2 (+ halo overlap on the read side).
+#include "common.h"
+#include "conv_c64.h"
+
+#include <stdlib.h>
+
+#include <utility>
+
+namespace {
+
+__device__ const uint4 c64_zero_page = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((ext_vector_type(2))) float c64_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 c64_bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32
+  const c64_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, c64_bf16x2_t));
+}
+
+#define C64_COMPILER_FENCE() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ void lds_read16(u32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+// k step S = (tap, 32-channel half): the 4 pixel-fragment operands of the step.  Address = the lane's register for this
+// (dx, half) -- buffer base + wave / lane part + swizzled chunk -- plus a compile-time (fragment, tap) offset (instruction immediate).
+template <int S, int PW, int CB>
+__device__ __forceinline__ void c64_issue(u32x4_t (&dst)[4], const unsigned (&pbd)[3][2]) {
+  constexpr int tap = S >> 1, ms = S & 1, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                 : "=v"(dst[i])
+                 : "v"(pbd[dx][ms]), "n"((((i / CB) + dy) * PW + (i % CB) * 16 + dx) * 128));
+}
+
+template <int S, int PW, int CB>
+__device__ __forceinline__ void c64_step(f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4], const u32x4_t (&wB)[9][2][2],
+                                         const unsigned (&pbd)[3][2], const f32x4_t (&bv)[2]) {
+  u32x4_t(&cur)[4] = a[S & 1];
+  if constexpr (S + 1 < 18) {
+    c64_issue<S + 1, PW, CB>(a[(S + 1) & 1], pbd);           // next step's operands in flight under this step's MFMAs
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  }
+  constexpr int tap = S >> 1, ms = S & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)      // the first step starts every accumulator from the bias of its 4 output channels
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wB[tap][ms][j]),
+                                                          __builtin_bit_cast(bf16x8_t, cur[i]), S == 0 ? bv[j] : acc[i][j], 0, 0, 0);
+}
+
+template <int PW, int CB, int... S>
+__device__ __forceinline__ void c64_steps(std::integer_sequence<int, S...>, f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4],
+                                          const u32x4_t (&wB)[9][2][2], const unsigned (&pbd)[3][2], const f32x4_t (&bv)[2]) {
+  (c64_step<S, PW, CB>(acc, a, wB, pbd, bv), ...);
+}
+
+// 2 bf16 of `o` zeroed where the mask element is not > 0 (packed 16-bit integer ops: a bf16 is > 0 iff its bits are > 0 as int16;
+// op_sel_hi:[0,1]: the high lane takes the shift count from the LOW half of the inline constant too)
+__device__ __forceinline__ uint32_t c64_mask2(uint32_t o, uint32_t m) {
+  uint32_t t;
+  asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_sub_i16 %0, 0, %0\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(t) : "v"(m));
+  return o & t;
+}
+
+template <int TW, int TH, bool MASK, int NBUF>
+__global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) {
+  constexpr int CB = TW / 16;                         // 16-pixel column blocks per tile row
+  constexpr int WM = TW * TH / 64;                    // wave rows (4 pixel fragments each); waves = WM x 2 (32 co each)
+  constexpr int NT = WM * 128;                        // threads
+  constexpr int PW = TW + 2, NHALO = (TH + 2) * PW;   // halo patch
+  constexpr int PBYTES = NHALO * 128;                 // 64 bf16 channels per pixel, 16-B chunk c of the pixel in patch column x in slot c ^ (x & 7)
+  constexpr int NCH = NHALO * 8;                      // 16-byte chunks of a patch
+  constexpr int PIT = (NCH + NT - 1) / NT;            // DMA instructions per thread and patch (the last one partial)
+  constexpr int DIST = NBUF - 1;                      // tiles the patch DMA runs ahead
+  constexpr int STASH = MASK ? WM * 2 * 4096 : 0;     // MASK: 4 chunks per lane
+  constexpr int BIAS_OFF = NBUF * PBYTES + STASH;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* stash = smem + NBUF * PBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware walk: the workgroups of one XCD (blockIdx % 8) take consecutive tiles, so most halo rows are shared in ONE L2
+  const int nwg = gridDim.x;
+  const int vid = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int cnt = vid < p.ntiles ? (p.ntiles - vid + nwg - 1) / nwg : 0;
+  const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x);
+
+  // ---- weights: A operand of every MFMA, resident in registers
+  u32x4_t wB[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wB[tap][ms][j] = *reinterpret_cast<const u32x4_t*>(p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * 64 + ms * 32 + g * 8);
+  // bias: parked in LDS (256 B), re-read at the start of every tile as the initial accumulator
+  if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = p.bias ? p.bias[tid] : 0.f;
+  __syncthreads();
+
+  auto origin = [&](int n, int& b, int& h0, int& w0) __attribute__((always_inline)) {
+    int t = vid + n * nwg;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    const int th = t % p.tiles_h;
+    b = t / p.tiles_h; h0 = th * TH; w0 = tw * TW;
+  };
+  // per-thread byte offsets relative to the tile's first pixel: rel = the thread's PIT patch chunks, relo = its 4 output chunks
+  // (pixel of fragment f = 4 wm + i: row f / CB, column block f % CB, column lr; channels co0 .. co0 + 7)
+  const int co0 = wn * 32 + (g & 1) * 16 + (g & 2) * 4;
+  int rel[PIT], relo[4];
+#pragma unroll
+  for (int it = 0; it < PIT; ++it) {
+    const int c = tid + it * NT, hp = c >> 3, px = hp % PW;
+    rel[it] = ((hp / PW - 1) * p.W + px - 1) * 128 + (((c & 7) ^ (px & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = wm * 4 + i;
+    relo[i] = ((f / CB) * p.W + (f % CB) * 16 + lr) * 128 + co0 * 2;
+  }
+  // halo patch of tile n -> buffer n % NBUF.  Tiles whose halo lies inside the image: one add per chunk.  Border tiles: per-chunk
+  // bounds test, outside pixels come from the zero page (`t_` = the thread index, laundered per tile by the caller so that this
+  // arithmetic is redone every tile instead of being hoisted out of the tile loop into registers that the weights leave no room for)
+  auto stage = [&](int n, int t_) __attribute__((always_inline)) {
+    int b, h0, w0;
+    origin(n, b, h0, w0);
+    unsigned char* buf = smem + (n % NBUF) * PBYTES;
+    const unsigned base = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * 128u;   // < 4 GB (launcher)
+    const bool inside = h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= p.H && w0 + TW + 1 <= p.W;
+    if (inside) {
+#pragma unroll
+      for (int it = 0; it < PIT; ++it) {
+        if (it < PIT - 1 || tid + it * NT < NCH) {
+          unsigned char* dst = buf + (it * NT + (tid & ~63)) * 16;       // wave-uniform; the DMA adds lane * 16
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + (base + (unsigned)rel[it])),
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < PIT; ++it) {
+        const int c = t_ + it * NT;
+        if (it < PIT - 1 || c < NCH) {
+          const int hp = c >> 3, px = hp % PW;
+          const int gy = h0 + hp / PW - 1, gx = w0 + px - 1;
+          const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          const unsigned char* src = in ? X + (base + (unsigned)rel[it]) : reinterpret_cast<const unsigned char*>(&c64_zero_page);
+          unsigned char* dst = buf + (it * NT + (t_ & ~63)) * 16;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+      }
+    }
+  };
+
+#pragma unroll
+  for (int d = 0; d < DIST; ++d)
+    if (cnt > d) stage(d, tid);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // per-lane operand addressing: LDS byte address of the lane's chunk of (fragment 0, tap row 0) for column shift dx and channel half
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned offk[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+      offk[dx][ms] = smem_base + (unsigned)((((wm * 4) / CB) * PW + ((wm * 4) % CB) * 16 + lr) * 128) +
+                     (unsigned)(((ms * 4 + g) ^ ((lr + dx) & 7)) << 4);
+  const unsigned bias_addr = smem_base + (unsigned)(BIAS_OFF + (wn * 32 + 4 * g) * 4);
+  const unsigned stash_addr = smem_base + (unsigned)(NBUF * PBYTES + (wave * 4 * 64 + lane) * 16);
+
+  for (int n = 0; n < cnt; ++n) {
+    C64_COMPILER_FENCE();
+    __builtin_amdgcn_s_barrier();       // patch n landed for every wave; everybody is done with tile n-1 (its buffer is free)
+    C64_COMPILER_FENCE();
+    const bool more = n + DIST < cnt;
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    int b, h0, w0;
+    origin(n, b, h0, w0);
+    const unsigned obase = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * 128u;
+    const bool whole = h0 + TH <= p.H && w0 + TW <= p.W;          // every output pixel of the tile is inside the image
+    if (MASK) {                        // this tile's mask chunks -> the lane's private stash (pixels outside the image: clamped)
+      const unsigned char* Mk = reinterpret_cast<const unsigned char*>(p.mask);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        unsigned off = obase + (unsigned)relo[i];
+        if (!whole) {
+          const int f = (tl >> 7) * 4 + i;
+          const int gy = min(h0 + f / CB, p.H - 1), gx = min(w0 + (f % CB) * 16 + (tl & 15), p.W - 1);
+          off = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * 128u + (unsigned)co0 * 2u;
+        }
+        unsigned char* dst = stash + ((wave * 4 + i) * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Mk + off),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+    if (more && !(p.ablate & 1)) stage(n + DIST, tl);
+    C64_COMPILER_FENCE();
+
+    u32x4_t bq[2];
+    lds_read16(bq[0], bias_addr);
+    lds_read16(bq[1], bias_addr + 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]));
+    const f32x4_t bv[2] = {__builtin_bit_cast(f32x4_t, bq[0]), __builtin_bit_cast(f32x4_t, bq[1])};
+    f32x4_t acc[4][2];
+    unsigned pbd[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n % NBUF) * PBYTES);
+    u32x4_t a[2][4];
+    if (!(p.ablate & 2)) {
+      c64_issue<0, PW, CB>(a[0], pbd);
+      c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bv);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = bv[0];
+    }
+
+    // patch n+1 (and this tile's mask chunks) must have landed before the next barrier; with NBUF = 3, patch n+2 (just issued) may
+    // stay in flight: loads complete in order, so "at most PIT-1 outstanding" implies that everything older than it is done
+    C64_COMPILER_FENCE();
+    if (DIST == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIT - 1) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: bf16 pairs, ReLU / mask on the packed halves, lane-group exchange, one 16-byte store per fragment
+    u32x4_t mk[4];
+    if (MASK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(mk[i]) : "v"(stash_addr), "n"(i * 1024));
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t lo[2], hi[2];
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        uint32_t pa = pack_bf16(acc[i][0][2 * d], acc[i][0][2 * d + 1]);
+        uint32_t pb2 = pack_bf16(acc[i][1][2 * d], acc[i][1][2 * d + 1]);
+        if (p.relu) {               // max(x, 0) on bf16 bits = signed 16-bit max with 0 (rounding keeps the sign)
+          asm("v_pk_max_i16 %0, %0, 0" : "+v"(pa));
+          asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb2));
+        }
+        // (a, b) -> a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3}
+        auto sw = __builtin_amdgcn_permlane16_swap(pa, pb2, false, false);
+        lo[d] = sw[0]; hi[d] = sw[1];
+      }
+      uint4 o = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+      if (MASK) {
+        o.x = c64_mask2(o.x, mk[i][0]); o.y = c64_mask2(o.y, mk[i][1]);
+        o.z = c64_mask2(o.z, mk[i][2]); o.w = c64_mask2(o.w, mk[i][3]);
+      }
+      bool ok = true;
+      if (!whole) {
+        const int f = (tl >> 7) * 4 + i;
+        ok = h0 + f / CB < p.H && w0 + (f % CB) * 16 + (tl & 15) < p.W;
+      }
+      if (ok && !(p.ablate & 4))
+        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
+    }
+  }
+}
+
+template <int TW, int TH, bool MASK, int NBUF>
+int launch_t(C64Args p, hipStream_t s) {
+  p.tiles_h = (p.H + TH - 1) / TH;
+  p.tiles_w = (p.W + TW - 1) / TW;
+  const int64_t nt = (int64_t)p.B * p.tiles_h * p.tiles_w;
+  if (nt >= ((int64_t)1 << 31)) return ASR_EUNSUPPORTED;
+  p.ntiles = (int)nt;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    cus = n;
+  }
+  constexpr int WM = TW * TH / 64;
+  const size_t lds = (size_t)NBUF * (TH + 2) * (TW + 2) * 128 + (MASK ? WM * 2 * 4096 : 0) + 256;
+  const int per_cu = (int)(163840 / lds) < 8 / (WM * 2) ? (int)(163840 / lds) : 8 / (WM * 2);   // LDS- and register-limited
+  static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
+  if (!granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<TW, TH, MASK, NBUF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return ASR_ELAUNCH;
+    granted = true;
+  }
+  const int64_t slots = (int64_t)cus * (per_cu > 0 ? per_cu : 1);
+  const unsigned grid = (unsigned)(nt < slots ? nt : slots);
+  hipLaunchKernelGGL((conv3x3_c64_kernel<TW, TH, MASK, NBUF>), dim3(grid), dim3(WM * 128), lds, s, p);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+}  // namespace
+
+int asr_conv3x3_c64_launch(const C64Args& a_, hipStream_t s) {
+  C64Args a = a_;
+  { const char* ab = getenv("ASR_C64_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+  // shape (ASR_C64_SHAPE, tuning): 0 = two 4-wave workgroups per CU on 8 x 16 pixel tiles (default: the two workgroups are not in
+  // phase, so one's address / epilogue VALU work overlaps the other's MFMAs); 1 / 2 = one 8-wave workgroup on 16 x 16 / 8 x 32 tiles
+  const char* sh = getenv("ASR_C64_SHAPE");
+  const int shape = sh ? atoi(sh) : 0;
+  if (shape == 1) return a.mask ? launch_t<16, 16, true, 3>(a, s) : launch_t<16, 16, false, 3>(a, s);
+  if (shape == 2) return a.mask ? launch_t<32, 8, true, 3>(a, s) : launch_t<32, 8, false, 3>(a, s);
+  return a.mask ? launch_t<16, 8, true, 2>(a, s) : launch_t<16, 8, false, 3>(a, s);
+}

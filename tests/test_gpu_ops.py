@@ -466,6 +466,32 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     close("conv3x3 wgrad accumulates", dwn, 2 * wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
 
 
+@pytest.mark.parametrize("tw", ["0", "1", "2"])
+@pytest.mark.parametrize("cfg", [(3, 161, 232, True), (5, 97, 401, False), (1, 5, 7, True)])
+def test_conv3x3_c64_persistent(ops, tw, cfg, monkeypatch):
+    """64 -> 64 channel bf16 layer on the persistent kernel (conv_c64.hip): more tiles than workgroups, so that the three-deep
+    patch pipeline, both tile shapes, image borders and the masked (dgrad) epilogue all run; reference = fp32 conv of the same
+    bf16-rounded operands."""
+    B, H, W, masked = cfg
+    monkeypatch.setenv("ASR_C64_SHAPE", tw)
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H * W)
+    x = q(torch.randn(B, 64, H, W, generator=g).relu(), dtype)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g) / 3
+    D = dev()
+    wk = torch.empty(64, 9, 64, device=D, dtype=dtype); wd = torch.empty(64, 9, 64, device=D, dtype=dtype)
+    ops.conv_pack_weight(w.to(D), wk, wd)
+    ref = F.conv2d(x, q(w, dtype), b, padding=1)
+    if masked:
+        m = q(torch.randn(B, 64, H, W, generator=g), dtype)
+        y = ops.conv3x3(nhwc(x).to(D, dtype), wk, b.to(D), 64, relu=False, mask_src=nhwc(m).to(D, dtype))
+        close("c64 masked", y, nhwc(ref * (m > 0)), dtype, scale=2)
+    else:
+        y = ops.conv3x3(nhwc(x).to(D, dtype), wk, b.to(D), 64, relu=True)
+        close("c64 relu", y, nhwc(F.relu(ref)), dtype, scale=2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(2, 21, 38, 64), (1, 161, 16, 64), (2, 40, 16, 128)])
 def test_maxpool_fwd_bwd_both_layouts(ops, dtype, shape):
