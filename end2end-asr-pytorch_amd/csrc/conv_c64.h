@@ -10,6 +10,7 @@ struct C64Args {
   bf16_t* y;            // (B, H, W, 64)
   int B, H, W, relu;
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
+  long long* dbg;                 // tuning only (-DC64_TIMING builds): per-section cycle totals of workgroup 0
   int ablate;                     // tuning only (ASR_C64_ABLATE): 1 = no patch DMA, 2 = no operand reads / MFMAs, 4 = no stores
 };
 

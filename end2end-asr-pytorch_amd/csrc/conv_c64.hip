@@ -16,6 +16,7 @@
 #include "common.h"
 #include "conv_c64.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <utility>
@@ -32,6 +33,11 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {      // one v_
 }
 
 #define C64_COMPILER_FENCE() asm volatile("" ::: "memory")
+#ifdef C64_TIMING      // tuning builds only: s_memtime stamps at section boundaries (each one drains lgkmcnt)
+#define C64_STAMP(K) { const long long now_ = clock64(); tsec[K] += now_ - tlast; tlast = now_; }
+#else
+#define C64_STAMP(K)
+#endif
 
 __device__ __forceinline__ void lds_read16(u32x4_t& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
@@ -51,9 +57,12 @@ __device__ __forceinline__ void c64_issue(u32x4_t (&dst)[4], const unsigned (&pb
 
 template <int S, int PW, int CB>
 __device__ __forceinline__ void c64_step(f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4], const u32x4_t (&wB)[9][2][2],
-                                         const unsigned (&pbd)[3][2], const f32x4_t (&bv)[2]) {
+                                         const unsigned (&pbd)[3][2], u32x4_t (&bq)[2]) {
   u32x4_t(&cur)[4] = a[S & 1];
-  if constexpr (S + 1 < 18) {
+  if constexpr (S == 0) {
+    c64_issue<S + 1, PW, CB>(a[(S + 1) & 1], pbd);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(bq[0]), "+v"(bq[1]));
+  } else if constexpr (S + 1 < 18) {
     c64_issue<S + 1, PW, CB>(a[(S + 1) & 1], pbd);           // next step's operands in flight under this step's MFMAs
     asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
   } else {
@@ -65,13 +74,14 @@ __device__ __forceinline__ void c64_step(f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4
 #pragma unroll
     for (int j = 0; j < 2; ++j)      // the first step starts every accumulator from the bias of its 4 output channels
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wB[tap][ms][j]),
-                                                          __builtin_bit_cast(bf16x8_t, cur[i]), S == 0 ? bv[j] : acc[i][j], 0, 0, 0);
+                                                          __builtin_bit_cast(bf16x8_t, cur[i]),
+                                                          S == 0 ? __builtin_bit_cast(f32x4_t, bq[j]) : acc[i][j], 0, 0, 0);
 }
 
 template <int PW, int CB, int... S>
 __device__ __forceinline__ void c64_steps(std::integer_sequence<int, S...>, f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4],
-                                          const u32x4_t (&wB)[9][2][2], const unsigned (&pbd)[3][2], const f32x4_t (&bv)[2]) {
-  (c64_step<S, PW, CB>(acc, a, wB, pbd, bv), ...);
+                                          const u32x4_t (&wB)[9][2][2], const unsigned (&pbd)[3][2], u32x4_t (&bq)[2]) {
+  (c64_step<S, PW, CB>(acc, a, wB, pbd, bq), ...);
 }
 
 // 2 bf16 of `o` zeroed where the mask element is not > 0 (packed 16-bit integer ops: a bf16 is > 0 iff its bits are > 0 as int16;
@@ -118,12 +128,28 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
   if (tid < 64) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = p.bias ? p.bias[tid] : 0.f;
   __syncthreads();
 
-  auto origin = [&](int n, int& b, int& h0, int& w0) __attribute__((always_inline)) {
-    int t = vid + n * nwg;
-    const int tw = t % p.tiles_w; t /= p.tiles_w;
-    const int th = t % p.tiles_h;
-    b = t / p.tiles_h; h0 = th * TH; w0 = tw * TW;
+  // tile origins (image, first row, first column) without per-tile integer divisions: the walk advances by gridDim.x tiles per
+  // iteration, i.e. by a fixed (images, tile rows, tile columns) step with carries; org[k] = origin of tile n + k
+  struct Org { int b, h0, w0; };
+  const int dtw = (nwg % p.tiles_w) * TW, q1 = nwg / p.tiles_w, dth = (q1 % p.tiles_h) * TH, db = q1 / p.tiles_h;
+  const int wlim = p.tiles_w * TW, hlim = p.tiles_h * TH;
+  auto advance = [&](Org& o) __attribute__((always_inline)) {
+    o.w0 += dtw;
+    const bool c1 = o.w0 >= wlim;
+    o.w0 -= c1 ? wlim : 0;
+    o.h0 += dth + (c1 ? TH : 0);
+    const bool c2 = o.h0 >= hlim;
+    o.h0 -= c2 ? hlim : 0;
+    o.b += db + (c2 ? 1 : 0);
   };
+  Org org[DIST + 1];
+  {
+    int t = vid;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    org[0].w0 = tw * TW; org[0].h0 = (t % p.tiles_h) * TH; org[0].b = t / p.tiles_h;
+#pragma unroll
+    for (int k = 1; k <= DIST; ++k) { org[k] = org[k - 1]; advance(org[k]); }
+  }
   // per-thread byte offsets relative to the tile's first pixel: rel = the thread's PIT patch chunks, relo = its 4 output chunks
   // (pixel of fragment f = 4 wm + i: row f / CB, column block f % CB, column lr; channels co0 .. co0 + 7)
   const int co0 = wn * 32 + (g & 1) * 16 + (g & 2) * 4;
@@ -141,9 +167,8 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
   // halo patch of tile n -> buffer n % NBUF.  Tiles whose halo lies inside the image: one add per chunk.  Border tiles: per-chunk
   // bounds test, outside pixels come from the zero page (`t_` = the thread index, laundered per tile by the caller so that this
   // arithmetic is redone every tile instead of being hoisted out of the tile loop into registers that the weights leave no room for)
-  auto stage = [&](int n, int t_) __attribute__((always_inline)) {
-    int b, h0, w0;
-    origin(n, b, h0, w0);
+  auto stage = [&](int n, const Org& o_, int t_) __attribute__((always_inline)) {
+    const int b = o_.b, h0 = o_.h0, w0 = o_.w0;
     unsigned char* buf = smem + (n % NBUF) * PBYTES;
     const unsigned base = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * 128u;   // < 4 GB (launcher)
     const bool inside = h0 >= 1 && w0 >= 1 && h0 + TH + 1 <= p.H && w0 + TW + 1 <= p.W;
@@ -175,7 +200,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
 
 #pragma unroll
   for (int d = 0; d < DIST; ++d)
-    if (cnt > d) stage(d, tid);
+    if (cnt > d) stage(d, org[d], tid);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // per-lane operand addressing: LDS byte address of the lane's chunk of (fragment 0, tap row 0) for column shift dx and channel half
@@ -190,40 +215,49 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
   const unsigned bias_addr = smem_base + (unsigned)(BIAS_OFF + (wn * 32 + 4 * g) * 4);
   const unsigned stash_addr = smem_base + (unsigned)(NBUF * PBYTES + (wave * 4 * 64 + lane) * 16);
 
+#ifdef C64_TIMING
+  long long tsec[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
   for (int n = 0; n < cnt; ++n) {
+    C64_STAMP(5)
     C64_COMPILER_FENCE();
     __builtin_amdgcn_s_barrier();       // patch n landed for every wave; everybody is done with tile n-1 (its buffer is free)
     C64_COMPILER_FENCE();
+    C64_STAMP(0)
     const bool more = n + DIST < cnt;
     int tl = tid;
     asm volatile("" : "+v"(tl));
-    int b, h0, w0;
-    origin(n, b, h0, w0);
+    const int b = org[0].b, h0 = org[0].h0, w0 = org[0].w0;
     const unsigned obase = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * 128u;
     const bool whole = h0 + TH <= p.H && w0 + TW <= p.W;          // every output pixel of the tile is inside the image
     if (MASK) {                        // this tile's mask chunks -> the lane's private stash (pixels outside the image: clamped)
       const unsigned char* Mk = reinterpret_cast<const unsigned char*>(p.mask);
+      unsigned moff[4];
+      if (whole) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        unsigned off = obase + (unsigned)relo[i];
-        if (!whole) {
+        for (int i = 0; i < 4; ++i) moff[i] = obase + (unsigned)relo[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
           const int f = (tl >> 7) * 4 + i;
           const int gy = min(h0 + f / CB, p.H - 1), gx = min(w0 + (f % CB) * 16 + (tl & 15), p.W - 1);
-          off = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * 128u + (unsigned)co0 * 2u;
+          moff[i] = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * 128u + (unsigned)co0 * 2u;
         }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
         unsigned char* dst = stash + ((wave * 4 + i) * 64) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Mk + off),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Mk + moff[i]),
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     }
-    if (more && !(p.ablate & 1)) stage(n + DIST, tl);
+    if (more && !(p.ablate & 1)) stage(n + DIST, org[DIST], tl);
     C64_COMPILER_FENCE();
 
-    u32x4_t bq[2];
+    C64_STAMP(1)
+    u32x4_t bq[2];                       // bias: issued ahead of the first operand reads, covered by the first step's wait (in order)
     lds_read16(bq[0], bias_addr);
     lds_read16(bq[1], bias_addr + 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]));
-    const f32x4_t bv[2] = {__builtin_bit_cast(f32x4_t, bq[0]), __builtin_bit_cast(f32x4_t, bq[1])};
     f32x4_t acc[4][2];
     unsigned pbd[3][2];
 #pragma unroll
@@ -233,18 +267,21 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
     u32x4_t a[2][4];
     if (!(p.ablate & 2)) {
       c64_issue<0, PW, CB>(a[0], pbd);
-      c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bv);
+      c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);
     } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = bv[0];
+      for (int i = 0; i < 4; ++i) acc[i][0] = acc[i][1] = __builtin_bit_cast(f32x4_t, bq[0]);
     }
 
+    C64_STAMP(2)
     // patch n+1 (and this tile's mask chunks) must have landed before the next barrier; with NBUF = 3, patch n+2 (just issued) may
     // stay in flight: loads complete in order, so "at most PIT-1 outstanding" implies that everything older than it is done
     C64_COMPILER_FENCE();
     if (DIST == 2 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIT - 1) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    C64_STAMP(3)
     // ---- epilogue: bf16 pairs, ReLU / mask on the packed halves, lane-group exchange, one 16-byte store per fragment
     u32x4_t mk[4];
     if (MASK) {
@@ -252,6 +289,9 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
       for (int i = 0; i < 4; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(mk[i]) : "v"(stash_addr), "n"(i * 1024));
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk[0]), "+v"(mk[1]), "+v"(mk[2]), "+v"(mk[3]));
     }
+    // (branch-free: ReLU = packed signed max with 0, "no ReLU" = max with the most negative int16; validity of a pixel by compares)
+    const uint32_t floor2 = p.relu ? 0u : 0x80008000u;
+    const int rows_ok = p.H - h0, cols_ok = p.W - w0 - (tl & 15);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint32_t lo[2], hi[2];
@@ -259,10 +299,8 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
       for (int d = 0; d < 2; ++d) {
         uint32_t pa = pack_bf16(acc[i][0][2 * d], acc[i][0][2 * d + 1]);
         uint32_t pb2 = pack_bf16(acc[i][1][2 * d], acc[i][1][2 * d + 1]);
-        if (p.relu) {               // max(x, 0) on bf16 bits = signed 16-bit max with 0 (rounding keeps the sign)
-          asm("v_pk_max_i16 %0, %0, 0" : "+v"(pa));
-          asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb2));
-        }
+        asm("v_pk_max_i16 %0, %0, %1" : "+v"(pa) : "s"(floor2));     // max(x, 0) on bf16 bits = signed 16-bit max (rounding keeps the sign)
+        asm("v_pk_max_i16 %0, %0, %1" : "+v"(pb2) : "s"(floor2));
         // (a, b) -> a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3}
         auto sw = __builtin_amdgcn_permlane16_swap(pa, pb2, false, false);
         lo[d] = sw[0]; hi[d] = sw[1];
@@ -272,15 +310,20 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
         o.x = c64_mask2(o.x, mk[i][0]); o.y = c64_mask2(o.y, mk[i][1]);
         o.z = c64_mask2(o.z, mk[i][2]); o.w = c64_mask2(o.w, mk[i][3]);
       }
-      bool ok = true;
-      if (!whole) {
-        const int f = (tl >> 7) * 4 + i;
-        ok = h0 + f / CB < p.H && w0 + (f % CB) * 16 + (tl & 15) < p.W;
-      }
-      if (ok && !(p.ablate & 4))
-        *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
+      const int f = (tl >> 7) * 4 + i;
+      const bool ok = (f / CB < rows_ok) & ((f % CB) * 16 < cols_ok) & !(p.ablate & 4);
+      if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
     }
+    C64_STAMP(4)
+#pragma unroll
+    for (int k = 0; k < DIST; ++k) org[k] = org[k + 1];
+    advance(org[DIST]);
   }
+#ifdef C64_TIMING
+  if (p.dbg && blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 6; ++k) p.dbg[wave * 8 + k] = tsec[k];
+  if (p.dbg && blockIdx.x == 0 && tid == 0) p.dbg[7] = cnt;
+#endif
 }
 
 template <int TW, int TH, bool MASK, int NBUF>
@@ -307,10 +350,29 @@ int launch_t(C64Args p, hipStream_t s) {
       return ASR_ELAUNCH;
     granted = true;
   }
-  const int64_t slots = (int64_t)cus * (per_cu > 0 ? per_cu : 1);
+  const char* pc = getenv("ASR_C64_PER_CU");          // tuning: workgroups per CU
+  const int64_t slots = (int64_t)cus * (pc ? atoi(pc) : (per_cu > 0 ? per_cu : 1));
   const unsigned grid = (unsigned)(nt < slots ? nt : slots);
+#ifdef C64_TIMING
+  static long long* dbg = nullptr;
+  if (!dbg) { (void)hipMalloc(&dbg, 64 * 8); }
+  (void)hipMemset(dbg, 0, 64 * 8);
+  p.dbg = dbg;
+#endif
   hipLaunchKernelGGL((conv3x3_c64_kernel<TW, TH, MASK, NBUF>), dim3(grid), dim3(WM * 128), lds, s, p);
   ASR_LAUNCH_CHECK();
+#ifdef C64_TIMING
+  {
+    long long h[64];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    static int shown = 0;
+    if (shown++ < 2)
+      for (int w = 0; w < WM * 2; ++w)
+        fprintf(stderr, "c64 timing wave %d tiles %lld: barrier %lld stage %lld mfma %lld dmawait %lld epilogue %lld looptop %lld (100 MHz ticks)\n", w,
+                h[7], h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+  }
+#endif
   return ASR_OK;
 }
 

@@ -14,13 +14,24 @@ template <int K, bool SPLIT> __global__ __launch_bounds__(512) void k(float* out
   u32x4_t a = {seed, seed + 1, seed + 2, seed + 3}, b = {seed * 3, seed * 5, seed * 7, seed * 11};
   uint32_t v[8];
   for (int i = 0; i < 8; ++i) { acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f}; v[i] = threadIdx.x + i; }
-  const bool mf = !SPLIT || ((threadIdx.x >> 6) & 4) == 0;      // waves w and w+4 share a SIMD: waves 0-3 MFMA, 4-7 VALU
-  const bool va = !SPLIT || !mf;
-  for (int it = 0; it < N_IT; ++it) {
+  if (!SPLIT) {
+    for (int it = 0; it < N_IT; ++it) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if (mf) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
-      if (va) {
+      for (int i = 0; i < 8; ++i) {
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+#pragma unroll
+        for (int j = 0; j < K; ++j) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[(i + j) & 7]) : "v"(seed));
+      }
+    }
+  } else if (((threadIdx.x >> 6) & 4) == 0) {      // waves w and w+4 share a SIMD: waves 0-3 MFMA only ...
+    for (int it = 0; it < N_IT; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+  } else {                                         // ... waves 4-7 VALU only (8 K v_add per iteration)
+    for (int it = 0; it < N_IT; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
 #pragma unroll
         for (int j = 0; j < K; ++j) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[(i + j) & 7]) : "v"(seed));
       }
