@@ -16,6 +16,14 @@
 
 namespace {
 
+// Ablation hooks (ASR_IGEMM_ABLATE / ASR_WGRAD_ABLATE) exist only in -DASR_TUNE_ABLATE builds: a run-time test inside the MFMA
+// loops costs scalar branches per step and blocks unrolling.
+#ifdef ASR_TUNE_ABLATE
+#define ASR_ABL(P, BIT) (((P).ablate & (BIT)) != 0)
+#else
+#define ASR_ABL(P, BIT) false
+#endif
+
 // ================================================================================================ conv1 (Cin = 1)
 // Direct convolution on the vector ALU, HBM bound (528 MB of bf16 activations written / read at B = 32).  A thread owns EPC
 // output channels (taps + bias in registers) and walks QUADS of 4 horizontally adjacent pixels: the 3 x 6 input window of a
@@ -171,6 +179,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 }
 
 // ================================================================================================ implicit GEMM 3x3
+__device__ const uint4 conv_zero_page = {0u, 0u, 0u, 0u};      // source of halo pixels outside the image
+
 struct ConvArgs {
   const void* x; const void* wk; const float* bias; const void* mask_src; void* y;
   int B, H, W, Cin, Cout, relu, tiles_h, tiles_w;
@@ -242,10 +252,8 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     }                                                                                                         \
   }
   // halo patch of one 64-channel slice, HBM -> LDS by the LDS-DMA (no registers, one round trip): chunk c = (pixel hp, slot) of the
-  // lane-linear image takes source chunk slot ^ (hp & 7).  The DMA cannot zero-fill: pixels outside the image are read from a
-  // clamped (valid) address and zeroed afterwards -- only workgroups on the image border have any.
+  // lane-linear image takes source chunk slot ^ (hp & 7); pixels outside the image are read from a 16-byte zero page.
   constexpr int PIT = (NHALO * CPP + 255) / 256;
-  const bool border = h0 == 0 || w0 == 0 || h0 + TH + 1 > p.H || w0 + 17 > p.W;
   auto pstage = [&](int cc) __attribute__((always_inline)) {
 #pragma unroll 1                         // rolled on purpose: a DMA is fire-and-forget, unrolling only pins 2 address registers per pass
     for (int it = 0; it < PIT; ++it) {
@@ -253,19 +261,13 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
       if (c < NHALO * CPP) {
         const int hp = c / CPP, slot = c % CPP, ch = SWZ ? (slot ^ (hp & 7)) : slot;
         const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
-        const int cy = gy < 0 ? 0 : (gy < p.H ? gy : p.H - 1), cx = gx < 0 ? 0 : (gx < p.W ? gx : p.W - 1);
-        const T* src = X + (((int64_t)b * p.H + cy) * p.W + cx) * p.Cin + cc * 64 + ch * EPC;
+        const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const T* src = in ? X + (((int64_t)b * p.H + gy) * p.W + gx) * p.Cin + cc * 64 + ch * EPC
+                          : reinterpret_cast<const T*>(&conv_zero_page);       // the DMA cannot zero-fill: outside pixels read zeros
         unsigned char* dst = sP + (it * 256 + (tid & ~63)) * 16;      // wave-uniform; the DMA adds lane * 16
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
-    }
-  };
-  auto pzero = [&]() __attribute__((always_inline)) {
-    for (int c = tid; c < NHALO * CPP; c += 256) {
-      const int hp = c / CPP;
-      const int gy = h0 + hp / 18 - 1, gx = w0 + hp % 18 - 1;
-      if (gy < 0 || gy >= p.H || gx < 0 || gx >= p.W) *reinterpret_cast<u32x4_t*>(sP + c * 16) = u32x4_t{0u, 0u, 0u, 0u};
     }
   };
   {
@@ -280,19 +282,15 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
     const int sstep = step % SPS;
     if (sstep == 0) {
       if (step > 0) __syncthreads();      // everybody is done with the previous channel slice of the patch
-      if (!(p.ablate & 1)) pstage(step / SPS);
+      if (!ASR_ABL(p, 1)) pstage(step / SPS);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                     // patch + weight buffer (step&1) visible
-      if (border) {                        // (workgroup-uniform)
-        pzero();
-        __syncthreads();
-      }
     }
     const bool has_next = step + 1 < nsteps;
     u32x4_t rw[WCH];
 #pragma unroll
     for (int i = 0; i < WCH; ++i) rw[i] = u32x4_t{0u, 0u, 0u, 0u};
-    if (has_next && !(p.ablate & 2)) ASR_WLOAD(rw, step + 1)
+    if (has_next && !ASR_ABL(p, 2)) ASR_WLOAD(rw, step + 1)
     const unsigned char* sW = (step & 1) ? sW1 : sW0;
 #pragma unroll
     for (int tt = 0; tt < TPS; ++tt) {
@@ -312,7 +310,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
           const int row = tt * NCO + wn * (NCO / WN) + j * 16 + lr;
           bfr[j] = *reinterpret_cast<const uint4*>(sW + row * PP + ASR_SLOT(row, ms * 4 + g));
         }
-        if (!(p.ablate & 8)) {
+        if (!ASR_ABL(p, 8)) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -401,7 +399,7 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
         for (int e = 0; e < EPC; ++e)
           if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<T>::to(0.f);
       }
-      if (ok && !(p.ablate & 4)) *reinterpret_cast<uint4*>(yrow + cho[q]) = o.v;
+      if (ok && !ASR_ABL(p, 4)) *reinterpret_cast<uint4*>(yrow + cho[q]) = o.v;
     }
   }
 }
@@ -654,9 +652,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
   for (int patch = p_beg; patch < p_end; ++patch) {
     swrite();
     __syncthreads();
-    if (patch + 1 < p_end && !(p.ablate & 1)) gload(patch + 1);          // next patch's HBM latency hides under this patch's MFMAs
+    if (patch + 1 < p_end && !ASR_ABL(p, 1)) gload(patch + 1);          // next patch's HBM latency hides under this patch's MFMAs
 #pragma unroll 1
-    for (int ms = 0; ms < ((p.ablate & 2) ? 0 : WgPack<T>::NMS); ++ms) {
+    for (int ms = 0; ms < (ASR_ABL(p, 2) ? 0 : WgPack<T>::NMS); ++ms) {
       uint4 a[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = WgPack<T>::template load<PP>(sD, ms, lr, g, i * 16, 16, 0, 0);
@@ -696,7 +694,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = co0 + i * 16 + g * 4 + r, ci = ci0 + wave * 16 + lr;
-          if (!(p.ablate & 4) || acc[t][i][r] == 12345.f) atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + t, acc[t][i][r]);
+          if (!ASR_ABL(p, 4) || acc[t][i][r] == 12345.f) atomicAdd(p.dw + ((int64_t)co * p.Cin + ci) * 9 + t, acc[t][i][r]);
         }
   }
   if (do_bias) {

@@ -497,9 +497,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
   // column chunk (16 B) this tile may read: clamp to the operand's last whole chunk (columns past N / K are never stored)
   const int a_chunks = (int)(p.lda * ESZ / 16), b_chunks = (int)(p.ldb * ESZ / 16);
 
+  // per-thread byte offsets of its DMA chunks relative to the first row of a stage (the stage base is workgroup-uniform: the
+  // loads of a whole stage then cost one scalar base update instead of ~12 vector ops of address arithmetic per chunk)
+  constexpr int NIT = P::RM * P::CPR / 256;
+  unsigned offA[NIT], offB[NIT];
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
+    int ca = n0 * ESZ / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;
+    int cb = k0 * ESZ / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+    offA[i] = (unsigned)(row * (int)p.lda * ESZ + ca * 16);
+    offB[i] = (unsigned)(row * (int)p.ldb * ESZ + cb * 16);
+  }
   auto stage = [&](int st, int buf) __attribute__((always_inline)) {
     unsigned char* s = smem + buf * STAGE;
     const int64_t mrow = m_beg + (int64_t)st * P::RM;
+    if (mrow + P::RM <= p.M) {            // every row of the stage exists
+      const unsigned char* ba = A + mrow * p.lda * ESZ;
+      const unsigned char* bb = B + mrow * p.ldb * ESZ;
+#pragma unroll
+      for (int i = 0; i < NIT; ++i) {
+        unsigned char* d = s + (i * 256 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ba + offA[i]),
+                                         (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bb + offB[i]),
+                                         (__attribute__((address_space(3))) void*)(d + P::RM * P::ROWB), 16, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < P::RM * P::CPR / 256; ++i) {
       const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
@@ -1154,7 +1179,8 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   const int esz = dtype == ASR_F32 ? 4 : 2, epc = 16 / esz;
   const int rm = dtype == ASR_F32 ? 64 : 128;
   // 16-byte aligned rows; a partial last stage of m is zero-filled in LDS by the kernel
-  if (lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K)
+  if (lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K ||
+      lda >= ((int64_t)1 << 22) || ldb >= ((int64_t)1 << 22))      // (32-bit byte offsets inside one stage of rows)
     return ASR_EUNSUPPORTED;
   {
     const int s128 = tn128_splits(M, N, K, splits, dtype);
