@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "conv_c64.h"
+#include "conv_wgrad_dma.h"
 
 namespace {
 
@@ -935,6 +936,17 @@ extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, 
   const int esz = dtype == ASR_F32 ? 4 : 2;
   const size_t lds = (size_t)(180 + 128) * (64 * esz + 16);
   AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
+  // bf16 with a workspace: the LDS-DMA pipelined kernel (conv_wgrad_dma.hip); same grid, same partial-block layout
+  static const bool dma = !(getenv("ASR_WGRAD_DMA") && atoi(getenv("ASR_WGRAD_DMA")) == 0);
+  const int64_t cmax = Cin > Cout ? Cin : Cout;
+  if (dma && dtype == ASR_BF16 && p.ws && (int64_t)B * H * W * cmax * 2 < ((int64_t)1 << 32)) {
+    WgdArgs q{};
+    q.x = static_cast<const bf16_t*>(x); q.dy = static_cast<const bf16_t*>(dy); q.db = db; q.ws = p.ws;
+    q.B = B; q.H = H; q.W = W; q.Cin = Cin; q.Cout = Cout; q.tiles_h = p.tiles_h; q.tiles_w = p.tiles_w;
+    q.npatch = p.npatch; q.patches_per_wg = p.patches_per_wg; q.nci = p.nci;
+    const int rc = asr_conv3x3_wgrad_dma_launch(q, (unsigned)wgx, (unsigned)blocks_y, s);
+    if (rc != ASR_OK) return rc;
+  } else
   if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_nhwc_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<float>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   else { allow_big_lds(conv3x3_wgrad_nhwc_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<bf16_t>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   ASR_LAUNCH_CHECK();

@@ -1,0 +1,210 @@
+// 3x3 convolution weight gradient, bf16 NHWC, LDS-DMA pipelined variant of conv3x3_wgrad_nhwc_kernel (conv.hip; reference:
+// the autograd of models/asr/transformer.py:44-52).  Same decomposition -- a workgroup owns a 64 co x 64 ci x 9 tap block of dW
+// and walks 8 x 16 pixel patches, wave w holds the 9 x 4 accumulator fragments of ci slice w -- but the operands no longer pass
+// through registers on their way to LDS and the vector ALU no longer does per-patch address arithmetic:
+//   * halo patch of X (10 x 18 px x 64 ci) and dY tile (8 x 16 px x 64 co) of patch n+1 travel HBM -> LDS by the LDS-DMA (two
+//     stages) while patch n is contracted; per-thread source offsets are computed once, a patch costs one scalar base update
+//     (patches on the image border take a slower path: per-chunk bounds test, outside pixels from a 16-byte zero page);
+//   * LDS image = unpadded 128-byte pixel rows, 16-B chunk c of the pixel in patch column x in slot c ^ (x & 7); the MFMA operands
+//     (8 CONSECUTIVE PIXELS per lane) are built by ds_read_b64_tr_b16 (see common.h), issued by hand two k steps ahead -- the
+//     compiler would drain the DMA counter before every LDS read it can see -- with the (macro step, tap) part of the address in
+//     the instruction's immediate offset;
+//   * two 4-wave workgroups per CU, out of phase: one's DMA issue / epilogue overlaps the other's MFMAs.
+// Per-workgroup partial dW blocks go to the caller's workspace and are folded by wgrad_reduce_kernel (conv.hip).
+#include "common.h"
+#include "conv_wgrad_dma.h"
+
+#include <utility>
+
+namespace {
+
+__device__ const uint4 wgd_zero_page = {0u, 0u, 0u, 0u};
+
+#define WGD_FENCE() asm volatile("" ::: "memory")
+
+constexpr int XB = 180 * 128;          // halo patch bytes
+constexpr int DB = 128 * 128;          // dY tile bytes
+constexpr int STAGE = XB + DB;
+
+// One 16-byte-per-lane LDS-DMA piece, issued by hand: the compiler must not know that a DMA is in flight, or it drains the
+// VMEM counter before every LDS read of the patch being contracted.  (It then also cannot count these loads: the kernel has no
+// compiler-visible vector memory loads while a DMA is outstanding, and the patch loop waits for vmcnt(0) by hand.  M0 is written
+// without being declared: the compiler sets M0 itself before each of its own uses, and this kernel has none.)
+__device__ __forceinline__ void wgd_dma(unsigned lds_wave_base, const unsigned char* base, unsigned off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void wgd_dma(unsigned lds_wave_base, const unsigned char* src) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(src) : "memory");
+}
+
+// transposed 8-pixel operand: two ds_read_b64_tr_b16 (pixels 0..3 and 4..7 of the lane group's 8)
+__device__ __forceinline__ bf16x8_t wgd_read(const unsigned char* lo, const unsigned char* hi) {
+  const uint2 a = asr_lds_read_tr16(lo), b = asr_lds_read_tr16(hi);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
+  constexpr int NXC = 180 * 8, NDC = 128 * 8;          // 16-byte chunks of the X patch / dY tile
+  constexpr int RX = (NXC + 255) / 256, RD = NDC / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int co0 = (blockIdx.y / p.nci) * 64, ci0 = (blockIdx.y % p.nci) * 64;
+  const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x) + ci0 * 2;
+  const unsigned char* DY = reinterpret_cast<const unsigned char*>(p.dy) + co0 * 2;
+  const int p_beg = blockIdx.x * p.patches_per_wg, p_end = min(p.npatch, p_beg + p.patches_per_wg);
+  const int xrow = p.Cin * 2, drow = p.Cout * 2;       // bytes per pixel
+
+  // ---- per-thread DMA source offsets relative to the patch's first pixel
+  int relx[RX], reld[RD];
+#pragma unroll
+  for (int i = 0; i < RX; ++i) {
+    const int c = tid + i * 256, hp = c >> 3, col = hp % 18;
+    relx[i] = ((hp / 18 - 1) * p.W + col - 1) * xrow + (((c & 7) ^ (col & 7)) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < RD; ++i) {
+    const int c = tid + i * 256, px = c >> 3, col = px & 15;
+    reld[i] = ((px >> 4) * p.W + col) * drow + (((c & 7) ^ (col & 7)) << 4);
+  }
+  // patch origin, advanced without divisions
+  int b, h0, w0;
+  {
+    int t = p_beg;
+    const int tw = t % p.tiles_w; t /= p.tiles_w;
+    w0 = tw * 16; h0 = (t % p.tiles_h) * 8; b = t / p.tiles_h;
+  }
+  auto advance = [&]() __attribute__((always_inline)) {
+    w0 += 16;
+    if (w0 >= p.tiles_w * 16) { w0 = 0; h0 += 8; if (h0 >= p.tiles_h * 8) { h0 = 0; ++b; } }
+  };
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wave_lds = smem_base + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;      // + piece * 4096 + stage
+  auto stage = [&](int buf, int t_) __attribute__((always_inline)) {
+    const unsigned sx = wave_lds + (unsigned)(buf * STAGE);
+    const unsigned pix = ((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0;
+    const unsigned bx = pix * (unsigned)xrow, bd = pix * (unsigned)drow;            // < 4 GB (launcher)
+    const bool inside = h0 >= 1 && w0 >= 1 && h0 + 9 <= p.H && w0 + 17 <= p.W;
+    if (inside) {
+#pragma unroll
+      for (int i = 0; i < RX; ++i)
+        if (i < RX - 1 || tid + i * 256 < NXC) wgd_dma(sx + i * 4096, X, bx + (unsigned)relx[i]);
+#pragma unroll
+      for (int i = 0; i < RD; ++i) wgd_dma(sx + XB + i * 4096, DY, bd + (unsigned)reld[i]);
+    } else {
+      // (everything from the laundered thread index `t_`: this arithmetic must stay inside the patch loop, not in 20 hoisted registers)
+      const unsigned char* zero = reinterpret_cast<const unsigned char*>(&wgd_zero_page);
+#pragma unroll
+      for (int i = 0; i < RX; ++i) {
+        const int c = t_ + i * 256;
+        if (i < RX - 1 || c < NXC) {
+          const int hp = c >> 3, col = hp % 18, gy = h0 + hp / 18 - 1, gx = w0 + col - 1;
+          const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+          const unsigned off = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * (unsigned)xrow +
+                               (unsigned)(((c & 7) ^ (col & 7)) << 4);
+          wgd_dma(sx + i * 4096, in ? X + off : zero);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RD; ++i) {
+        const int c = t_ + i * 256, px = c >> 3, col = px & 15, gy = h0 + (px >> 4), gx = w0 + col;
+        const bool in = gy < p.H && gx < p.W;
+        const unsigned off = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * (unsigned)drow +
+                             (unsigned)(((c & 7) ^ (col & 7)) << 4);
+        wgd_dma(sx + XB + i * 4096, in ? DY + off : zero);
+      }
+    }
+  };
+
+  // ---- per-lane operand offsets inside a stage (k = 8 g + j <-> patch row 2 ms + (g >> 1), column 8 (g & 1) + j); the
+  // (macro step, tap) part of an address is a compile-time constant that lands in the read's immediate offset
+  const int colb = 8 * (g & 1) + (lr >> 2), rowb = g >> 1, sub = 8 * (lr & 1), cpair = (lr & 3) >> 1;
+  int xlo[3], xhi[3], dlo[4], dhi[4];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int c = colb + dx, ch = wave * 2 + cpair;
+    xlo[dx] = (rowb * 18 + c) * 128 + ((ch ^ (c & 7)) << 4) + sub;
+    xhi[dx] = (rowb * 18 + c + 4) * 128 + ((ch ^ ((c + 4) & 7)) << 4) + sub;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = 2 * i + cpair;
+    dlo[i] = XB + (rowb * 16 + colb) * 128 + ((ch ^ (colb & 7)) << 4) + sub;
+    dhi[i] = XB + (rowb * 16 + colb + 4) * 128 + ((ch ^ ((colb + 4) & 7)) << 4) + sub;
+  }
+
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.db != nullptr && ci0 == 0 && wave == 0;
+
+  if (p_beg < p_end) stage(0, tid);
+  for (int patch = p_beg; patch < p_end; ++patch) {
+    const int buf = (patch - p_beg) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the patch have landed (the compiler does not count them)
+    __syncthreads();          // the patch is complete for every wave; everybody is done with the other stage
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    advance();
+    if (patch + 1 < p_end) stage(buf ^ 1, tl);
+    const unsigned char* sb = smem + buf * STAGE;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      bf16x8_t a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = wgd_read(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
+      if (do_bias) {          // db: sum of dY over the pixels (wave 0 of the ci block 0 workgroups)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4_t u = __builtin_bit_cast(u32x4_t, a[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int off = ((2 * ms + t / 3) * 18) * 128;
+        const bf16x8_t bb = wgd_read(sb + xlo[t % 3] + off, sb + xhi[t % 3] + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb, acc[t][i], 0, 0, 0);
+        if (t % 3 == 2) WGD_FENCE();      // bounds how far ahead the scheduler hoists operand reads (and their registers): one tap row
+      }
+    }
+  }
+
+  // ---- partial dW block -> workspace [blockIdx.y][blockIdx.x][tap][co][ci]
+  float* part = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(t * 64 + i * 16 + g * 4 + r) * 64 + wave * 16 + lr] = acc[t][i][r];
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) atomicAdd(p.db + co0 + i * 16 + lr, v);
+    }
+  }
+}
+
+}  // namespace
+
+int asr_conv3x3_wgrad_dma_launch(const WgdArgs& p, unsigned wgx, unsigned blocks_y, hipStream_t s) {
+  const size_t lds = 2 * (size_t)STAGE;
+  static bool granted = false;          // the first (eager / warm-up) launch does it, never a captured one
+  if (!granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+        hipSuccess)
+      return ASR_ELAUNCH;
+    granted = true;
+  }
+  hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(wgx, blocks_y), dim3(256), lds, s, p);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}

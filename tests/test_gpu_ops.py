@@ -466,6 +466,25 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     close("conv3x3 wgrad accumulates", dwn, 2 * wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
 
 
+@pytest.mark.parametrize("cfg", [(3, 97, 130, 64, 128), (2, 50, 200, 128, 64)])
+def test_conv3x3_wgrad_dma_pipeline(ops, cfg):
+    """bf16 weight gradient on the LDS-DMA pipelined kernel (conv_wgrad_dma.hip) at sizes with interior AND border patches, several
+    patches per workgroup and more than one dW block; reference = fp32 autograd of the same bf16-rounded operands."""
+    B, H, W, Cin, Cout = cfg
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H + W)
+    x = q(torch.randn(B, Cin, H, W, generator=g), dtype)
+    dy = q(torch.randn(B, Cout, H, W, generator=g) / 8, dtype)
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    bias = torch.zeros(Cout, requires_grad=True)
+    F.conv2d(x, w, bias, padding=1).backward(dy)
+    D = dev()
+    dw = torch.zeros(Cout, Cin, 3, 3, device=D); db = torch.zeros(Cout, device=D)
+    ops.conv3x3_wgrad_nhwc(nhwc(x).to(D, dtype), nhwc(dy).to(D, dtype), dw, db)
+    close("wgrad dma dW", dw, w.grad, dtype)
+    close("wgrad dma db", db, bias.grad, torch.float32, scale=64)
+
+
 @pytest.mark.parametrize("tw", ["0", "1", "2"])
 @pytest.mark.parametrize("cfg", [(3, 161, 232, True), (5, 97, 401, False), (1, 5, 7, True)])
 def test_conv3x3_c64_persistent(ops, tw, cfg, monkeypatch):
