@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "conv1_wgrad_mfma.h"
 #include "conv_c64.h"
 #include "conv_wgrad_dma.h"
 
@@ -801,6 +802,9 @@ extern "C" int asr_conv1_wgrad(const float* x, const void* dy, float* dw, float*
   if (blocks < 1) blocks = 1;
   const size_t lds = (size_t)C0 * 10 * sizeof(float);
   AsrProfScope prof(ASR_OP_CONV1, s);
+  // bf16 storage, 64 channels: matrix-core kernel with the pixel as contraction index (conv1_wgrad_mfma.hip)
+  static const bool mfma = !(getenv("ASR_CONV1_WGRAD_MFMA") && atoi(getenv("ASR_CONV1_WGRAD_MFMA")) == 0);
+  if (mfma && dtype == ASR_BF16 && C0 == 64) return asr_conv1_wgrad_mfma_launch(x, (const bf16_t*)dy, dw, db, B, H, W, s);
   if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_wgrad_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, s, x, (const float*)dy, dw, db, B, H, W, C0);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, s, x, (const bf16_t*)dy, dw, db, B, H, W, C0);
   ASR_LAUNCH_CHECK();

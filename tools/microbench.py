@@ -140,6 +140,9 @@ def misc():
     src = torch.randn(32, 1, 161, 800, device=D); w = torch.randn(64, 1, 3, 3, device=D); bb = torch.randn(64, device=D)
     us = timeit(lambda: ops.conv1_fwd(src, w, bb, torch.bfloat16), iters=10)
     print("  conv1_fwd %7.1f us  %.0f GB/s" % (us, x1.numel() * 2 / us / 1e3))
+    dw = torch.zeros(64, 1, 3, 3, device=D); db = torch.zeros(64, device=D)
+    us = timeit(lambda: ops.conv1_wgrad(src, x1, dw, db), iters=10)
+    print("  conv1_wgrad %7.1f us  %.0f GB/s" % (us, x1.numel() * 2 / us / 1e3))
 
 
 def decode():
