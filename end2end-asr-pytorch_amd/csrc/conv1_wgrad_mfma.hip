@@ -2,7 +2,7 @@
 // on the matrix cores, bf16 storage mode.  dW[co][tap] = sum_px dY[px][co] * x[px + tap] is a GEMM whose contraction index is the
 // PIXEL: M = 64 channels, N = taps, K = B*H*W.  The vector-ALU kernel of conv.hip spends 9 FMA per (pixel, channel) and runs at
 // 2.1 TB/s of dY; here:
-//   * dY tiles (128 consecutive pixels of one image row = 16 KB) travel HBM -> LDS by hand-issued LDS-DMA, one stage, 16-byte
+//   * dY tiles (128 consecutive pixels of one image row = 16 KB) travel HBM -> LDS by hand-issued LDS-DMA, four stages, 16-byte
 //     chunk c of pixel p in slot c ^ (p & 7); the A operands (8 consecutive pixels per lane) are built by ds_read_b64_tr_b16;
 //   * the fp32 input keeps (almost) its precision: x = xh + xl, two bf16 -- the B operand has the 9 taps of xh in columns 0..8 of
 //     one fragment and the 9 taps of xl in columns 0..8 of a second one; column 9 of the first is the constant 1, so the bias
@@ -31,11 +31,17 @@ __device__ __forceinline__ void c1w_dma(unsigned lds_wave_base, const unsigned c
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(src) : "memory");
 }
 
+// 4 bytes per lane (the fp32 input rows: only dword alignment is guaranteed)
+__device__ __forceinline__ void c1w_dma4(unsigned lds_wave_base, const unsigned char* src) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_wave_base), "v"(src) : "memory");
+}
+
 constexpr int TILE = 128;              // pixels per tile (one image row segment)
 constexpr int DYB = TILE * 128;        // dY tile bytes
 constexpr int XW = TILE + 8;           // staged input row: columns x0 - 4 .. x0 + TILE + 3 (16-byte aligned start)
-constexpr int XB = 3 * XW * 4;         // three input rows, fp32
+constexpr int XB = 2048;               // three input rows, fp32 (3 x 136 x 4 = 1632 B) padded to the 512 DMA lanes
 constexpr int STAGE = DYB + XB;
+constexpr int C1W_STAGES = 4;          // LDS stages (3 tiles ahead)
 
 __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __restrict__ x, const bf16_t* __restrict__ dy,
                                                                float* dw, float* db, int B, int H, int W, int tiles_w, int ntiles) {
@@ -65,25 +71,20 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __re
       c1w_dma(wave_lds + (unsigned)(buf * STAGE + i * 4096), src);
     }
   };
-  auto load_x = [&](int tile, float (&v)[2]) __attribute__((always_inline)) {
+  // the three input rows of the tile (columns x0 - 4 .. x0 + TILE + 3, fp32) by 4-byte DMA pieces: element e of the 3 x XW block sits
+  // at LDS offset 4 e; rows / columns outside the image come from the zero page
+  const unsigned wave_lds4 = smem_base + (unsigned)__builtin_amdgcn_readfirstlane(wave) * 256u;
+  auto stage_x = [&](int tile, int buf) __attribute__((always_inline)) {
     int64_t rowpix, img; int yy, x0;
     origin(tile, rowpix, yy, img, x0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256;                 // element of the 3 x XW block
+      const int e = tid + i * 256;                 // (e >= 3 XW: lands in the unused tail of the block, XB is padded to 2 KB)
       const int r = e / XW, c = e - r * XW;
       const int ry = yy + r - 1, cx = x0 - 4 + c;
       const bool ok = e < 3 * XW && ry >= 0 && ry < H && cx >= 0 && cx < W;
-      const float t = x[(img * H + (ok ? ry : yy)) * (int64_t)W + (ok ? cx : 0)];
-      v[i] = ok ? t : 0.f;
-    }
-  };
-  auto store_x = [&](int buf, const float (&v)[2]) __attribute__((always_inline)) {
-    float* sx = reinterpret_cast<float*>(smem + buf * STAGE + DYB);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int e = tid + i * 256;
-      if (e < 3 * XW) sx[e] = v[i];
+      const unsigned char* src = ok ? reinterpret_cast<const unsigned char*>(x + ((img * H + ry) * (int64_t)W + cx)) : zero;
+      c1w_dma4(wave_lds4 + (unsigned)(buf * STAGE + DYB + i * 1024), src);
     }
   };
 
@@ -98,17 +99,24 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __re
   // A-operand addressing inside a stage: pixels ms*32 + 8 g + j, channels 16 i + lr
   const int prow = 8 * g + (lr >> 2), sub = 8 * (lr & 1), cpair = (lr & 3) >> 1;
 
-  // ONE stage per workgroup, four workgroups per CU: the tiles in flight that cover the HBM latency belong to the OTHER workgroups
-  // (a private two-stage pipeline measured the same 171 us; 6 / 8 workgroups per CU 211 / 240 us: every workgroup ends with 640
-  // atomics on the same 640 addresses)
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int buf = 0;
-    float xr[2];
-    stage_dy(tile, 0);
-    load_x(tile, xr);
-    store_x(0, xr);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the tile have landed (the compiler does not count them)
-    __syncthreads();
+  // NS stages per workgroup, everything staged by hand-issued DMA (no compiler-visible loads in the loop): reading at HBM speed
+  // needs ~80 KB in flight per CU (21 KB/us per CU x 3-4 us of latency) = 2 workgroups x 3 tiles of 18 KB ahead.  Every wave issues
+  // exactly 6 pieces per tile and loads retire in order, so "at most 6 k outstanding" means the k newest tiles may still be in flight.
+  constexpr int NS = C1W_STAGES;
+  const int step = gridDim.x;
+  int tile = blockIdx.x;
+#pragma unroll
+  for (int d = 0; d < NS - 1; ++d)
+    if (tile + d * step < ntiles) { stage_dy(tile + d * step, d); stage_x(tile + d * step, d); }
+  for (int n = 0; tile < ntiles; tile += step, ++n) {
+    const int buf = n % NS;
+    const int ahead = min(NS - 2, (ntiles - 1 - tile) / step);        // tiles after this one that are already in flight
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                      // the tile is complete for every wave; everybody is done with tile n-1's stage
+    const int next = tile + (NS - 1) * step;
+    if (next < ntiles) { stage_dy(next, (n + NS - 1) % NS); stage_x(next, (n + NS - 1) % NS); }
     const unsigned char* sd = smem + buf * STAGE;
     const float* sx = reinterpret_cast<const float*>(sd + DYB);
     // ---- this wave's macro step: pixels wave*32 .. +31 of the tile
@@ -141,7 +149,6 @@ __global__ __launch_bounds__(256) void conv1_wgrad_mfma_kernel(const float* __re
       acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bhv, acc[i][0], 0, 0, 0);
       acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], blv, acc[i][1], 0, 0, 0);
     }
-    __syncthreads();          // everybody is done with the stage before the next tile overwrites it
   }
 
   // ---- fold the 4 waves in LDS, then one atomic per (workgroup, element): dw[co][tap] (n < 9), db[co] (n == 9)
@@ -167,7 +174,7 @@ int asr_conv1_wgrad_mfma_launch(const float* x, const bf16_t* dy, float* dw, flo
   const int tiles_w = (W + TILE - 1) / TILE;
   const int64_t nt = (int64_t)B * H * tiles_w;
   if (nt >= ((int64_t)1 << 31)) return ASR_EUNSUPPORTED;
-  const size_t lds = (size_t)STAGE;
+  const size_t lds = (size_t)C1W_STAGES * STAGE;
   static bool granted = false;          // the first (eager / warm-up) launch does it, never a captured one
   if (!granted) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_wgrad_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -175,7 +182,7 @@ int asr_conv1_wgrad_mfma_launch(const float* x, const bf16_t* dy, float* dw, flo
       return ASR_ELAUNCH;
     granted = true;
   }
-  const int per_cu = getenv("ASR_CONV1_WGRAD_WGS") ? atoi(getenv("ASR_CONV1_WGRAD_WGS")) : 4;
+  const int per_cu = getenv("ASR_CONV1_WGRAD_WGS") ? atoi(getenv("ASR_CONV1_WGRAD_WGS")) : 2;
   const unsigned grid = (unsigned)(nt < 256 * per_cu ? nt : 256 * per_cu);     // every workgroup ends with 640 atomics
   hipLaunchKernelGGL(conv1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, x, dy, dw, db, B, H, W, tiles_w, (int)nt);
   ASR_LAUNCH_CHECK();

@@ -413,9 +413,10 @@ def nchw(x):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_conv1_fwd_wgrad(ops, dtype):
+@pytest.mark.parametrize("shape", [(2, 21, 37), (5, 161, 331)])     # the second: several tiles per workgroup (4-stage DMA pipeline)
+def test_conv1_fwd_wgrad(ops, dtype, shape):
     g = torch.Generator().manual_seed(4)
-    B, H, W, C0 = 2, 21, 37, 64
+    (B, H, W), C0 = shape, 64
     x = torch.randn(B, 1, H, W, generator=g)
     w = torch.randn(C0, 1, 3, 3, generator=g) / 3
     b = torch.randn(C0, generator=g) / 3
