@@ -11,7 +11,7 @@ struct C64Args {
   int B, H, W, relu;
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
   long long* dbg;                 // tuning only (-DC64_TIMING builds): per-section cycle totals of workgroup 0
-  int ablate;                     // tuning only (ASR_C64_ABLATE): 1 = no patch DMA, 2 = no operand reads / MFMAs, 4 = no stores
+  int ablate;                     // tuning only (ASR_C64_ABLATE in -DASR_TUNE_ABLATE builds)
 };
 
 int asr_conv3x3_c64_launch(const C64Args& a, hipStream_t s);

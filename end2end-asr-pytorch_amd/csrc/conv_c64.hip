@@ -33,6 +33,12 @@ __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {      // one v_
 }
 
 #define C64_COMPILER_FENCE() asm volatile("" ::: "memory")
+// ablation hooks (ASR_C64_ABLATE: 1 = no patch DMA, 2 = no operand reads / MFMAs, 4 = no stores) exist in -DASR_TUNE_ABLATE builds only
+#ifdef ASR_TUNE_ABLATE
+#define C64_ABL(P, BIT) (((P).ablate & (BIT)) != 0)
+#else
+#define C64_ABL(P, BIT) false
+#endif
 #ifdef C64_TIMING      // tuning builds only: s_memtime stamps at section boundaries (each one drains lgkmcnt)
 #define C64_STAMP(K) { const long long now_ = clock64(); tsec[K] += now_ - tlast; tlast = now_; }
 #else
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     }
-    if (more && !(p.ablate & 1)) stage(n + DIST, org[DIST], tl);
+    if (more && !C64_ABL(p, 1)) stage(n + DIST, org[DIST], tl);
     C64_COMPILER_FENCE();
 
     C64_STAMP(1)
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n % NBUF) * PBYTES);
     u32x4_t a[2][4];
-    if (!(p.ablate & 2)) {
+    if (!C64_ABL(p, 2)) {
       c64_issue<0, PW, CB>(a[0], pbd);
       c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);
     } else {
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
         o.z = c64_mask2(o.z, mk[i][2]); o.w = c64_mask2(o.w, mk[i][3]);
       }
       const int f = (tl >> 7) * 4 + i;
-      const bool ok = (f / CB < rows_ok) & ((f % CB) * 16 < cols_ok) & !(p.ablate & 4);
+      const bool ok = (f / CB < rows_ok) & ((f % CB) * 16 < cols_ok) & !C64_ABL(p, 4);
       if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
     }
     C64_STAMP(4)
