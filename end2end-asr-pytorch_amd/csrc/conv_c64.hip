@@ -1,18 +1,24 @@
 // 3x3 convolution, 64 -> 64 channels, bf16 NHWC: the full-resolution layer of vgg_cnn (reference: models/asr/transformer.py:44-47,
 // conv2 forward and its dgrad), the largest single kernel of the training step.  A persistent, software-pipelined variant of the
 // implicit GEMM of conv.hip, possible because ALL of the layer's weights (64 co x 9 taps x 64 ci = 72 KB) fit in the register
-// files of one 8-wave workgroup:
-//   * one workgroup per CU walks tiles of 256 output pixels (TH x TW, TW = 16 or 32) x 64 co; wave (wm, wn) owns 4 pixel
-//     fragments x 2 co fragments and keeps its 32 co x 576 k weights in 144 VGPRs for the whole kernel: no weight traffic, no
-//     per-tap barrier;
-//   * the halo patch of tile n+2 travels HBM -> LDS by the LDS-DMA into one of THREE patch buffers while tile n is contracted:
-//     one s_barrier per tile, and the wait on the DMA counter sits after the MFMAs of a whole tile;
+// files of a workgroup:
+//   * persistent workgroups (default: TWO 4-wave workgroups per CU, which run out of phase so that one's address / epilogue work
+//     overlaps the other's MFMAs) walk tiles of 128 output pixels (8 x 16) x 64 co; wave (wm, wn) owns 4 pixel fragments x 2 co
+//     fragments and keeps its 32 co x 576 k weights in 144 VGPRs for the whole kernel: no weight traffic, no per-tap barrier
+//     (8-wave workgroups on 16 x 16 / 8 x 32 tiles remain as ASR_C64_SHAPE=1/2);
+//   * the halo patch of tile n+2 travels HBM -> LDS by the LDS-DMA into one of THREE patch buffers (two in the masked variant, where
+//     the mask stash needs the LDS) while tile n is contracted: one s_barrier per tile, the wait on the DMA counter sits after the
+//     MFMAs of a whole tile and is COUNTED (loads retire in order: "at most N outstanding" proves everything older has landed);
+//   * the vector ALU does almost nothing per tile (an MFMA leaves room for about two other vector instructions): operand
+//     addresses = 6 per-lane registers + instruction immediates (swizzle keyed on the patch COLUMN), per-thread DMA offsets computed
+//     once + a scalar tile base, tile origins advanced with carries, branch-free epilogue;
 //   * pixels outside the image are DMA'd from a 16-byte zero page (no zero-fill pass);
 //   * operand reads are hand-issued ds_read_b128 (inline asm, double buffered per k step) -- the compiler would otherwise drain
 //     the DMA counter before every LDS read it can see;
 //   * epilogue from the accumulators (co rows x pixel columns): bias / ReLU / bf16 / v_permlane16_swap -> one 16-byte chunk of a
 //     pixel's NHWC row per lane; the dgrad's ReLU-mask chunks are prefetched per lane through a private LDS stash by the same DMA.
-// MFMA-bound: 2*9*64*64 flop per output pixel; HBM bytes per pixel = 2 * 64 * 2 (+ halo overlap on the read side).
+// MFMA ~ HBM bound: 2*9*64*64 flop per output pixel; HBM bytes per pixel = 2 * 64 * 2 (+ halo overlap on the read side).
+// Measured (MI355X, B=32 161x800): 270 us forward / 310 us dgrad+mask; the MFMAs alone 144 us, the memory side alone 219 us.
 #include "common.h"
 #include "conv_c64.h"
 
