@@ -171,13 +171,15 @@ int asr_clip_coef(const float* sumsq, float max_norm, float* coef, asr_stream_t 
 /* conv.0: 1->C0 3x3 pad 1 + ReLU from the raw fp32 spectrogram (B,1,F,T); weight (C0,1,3,3), bias fp32          */
 int asr_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int H, int W, int C0,
                   int dtype, asr_stream_t stream);
-/* dw (C0*9) += , db (C0) += ; dy already masked by ReLU                                                          */
+/* dw (C0*9) += , db (C0) += ; dy already masked by ReLU.  bf16, C0 = 64: MFMA kernel with the pixel as contraction index
+ * (x split into two bf16, conv1_wgrad_mfma.hip); otherwise the direct vector-ALU kernel.                            */
 int asr_conv1_wgrad(const float* x, const void* dy, float* dw_acc, float* db_acc, int B, int H, int W, int C0,
                     int dtype, asr_stream_t stream);
 /* master (Cout,Cin,3,3) fp32 -> wk (Cout,9,Cin) for forward and wd (Cin,9,Cout) tap-flipped for dgrad            */
 int asr_conv_pack_weight(const float* w, void* wk, void* wd, int Cout, int Cin, int dtype, asr_stream_t stream);
 /* y = act(conv3x3_pad1(x; wk) + bias): relu=1 -> ReLU.  If mask_src != NULL: y *= (mask_src > 0) (dgrad through
- * the ReLU that produced this conv's input).  Cin, Cout multiples of 64, Cout <= 128.                           */
+ * the ReLU that produced this conv's input).  Cin, Cout multiples of 64, Cout <= 128.  bf16 64 -> 64 runs the persistent
+ * register-resident-weights kernel of conv_c64.hip, everything else the generic implicit GEMM of conv.hip.        */
 int asr_conv3x3_igemm(const void* x, const void* wk, const float* bias, const void* mask_src, void* y, int B,
                       int H, int W, int Cin, int Cout, int relu, int dtype, asr_stream_t stream);
 /* 2x2/2 floor max-pool NHWC; if out_tcf != 0 writes (B, W/2, C, H/2) i.e. the encoder layout (B,T',C*F')        */
@@ -186,7 +188,8 @@ int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_
 int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
                     asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
- * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip).                          */
+ * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip; bf16 with a workspace: the LDS-DMA
+ * pipelined kernel of conv_wgrad_dma.hip).                                                                      */
 /* workspace (fp32, >= asr_conv3x3_wgrad_workspace(...) elements, optional): per-workgroup partial dW blocks for a two-stage
  * reduction; without it every workgroup adds its 36,864 partial sums with fp32 atomics (more than half of the kernel time) */
 int64_t asr_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
