@@ -343,8 +343,7 @@ class VGGFn(Function):
         src = src.contiguous().float()
         y1 = ops.conv1_fwd(src, w0.data, b0.data, cd)
         wk2, _ = P.conv_shadow(w2)
-        y2 = ops.conv3x3(y1, wk2, b2.data, w2.shape[0], relu=True)
-        p1 = ops.maxpool_fwd(y2)
+        y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])      # conv.2 + ReLU + MaxPool2d in one epilogue
         wk5, _ = P.conv_shadow(w5)
         y3 = ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True)
         wk7, _ = P.conv_shadow(w7)

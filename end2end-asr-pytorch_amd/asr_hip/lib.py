@@ -15,6 +15,7 @@ HEADER = os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "asr_hi
 
 F32, BF16 = 0, 1
 GEMM_RELU, GEMM_ACCUMULATE = 1, 2
+EUNSUPPORTED = -3
 ATTN_DELTA, ATTN_DQ, ATTN_DKV, ATTN_ALL = 1, 2, 4, 7
 OP_GEMM, OP_CONV_IGEMM, OP_CONV_WGRAD, OP_ATTN_FWD, OP_ATTN_BWD, OP_ADD_LN, OP_CE, OP_ADAM, OP_CONV1, OP_POOL, \
     OP_LAYOUT = range(11)
@@ -58,6 +59,7 @@ _SIGS = {
     "asr_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_conv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "asr_conv3x3_igemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_conv3x3_relu_pool": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),

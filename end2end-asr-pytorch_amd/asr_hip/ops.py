@@ -411,6 +411,22 @@ def conv3x3(x, wk, bias, Cout, relu, mask_src=None):
     return y
 
 
+def conv3x3_relu_pool(x, wk, bias, Cout):
+    """(y, pool): y = ReLU(conv3x3(x) + bias) and its 2x2/2 max-pool.  One kernel where the library has the fused epilogue
+    (bf16, 64 -> 64 channels), otherwise the convolution followed by the pooling kernel -- both are HIP paths."""
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, H, W, Cout), device=x.device, dtype=x.dtype)
+    pool = torch.empty((B, H // 2, W // 2, Cout), device=x.device, dtype=x.dtype)
+    rc = L.load().asr_conv3x3_relu_pool(L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(y), L.ptr(pool), B, H, W, Cin, Cout, L.dt(x),
+                                        L.stream())
+    if rc == L.EUNSUPPORTED:
+        y = conv3x3(x, wk, bias, Cout, relu=True)
+        return y, maxpool_fwd(y)
+    L.check(rc, "asr_conv3x3_relu_pool")
+    return y, pool
+
+
 def maxpool_fwd(x, tcf=False):
     B, H, W, C = x.shape
     if tcf:

@@ -846,6 +846,25 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);
 }
 
+extern "C" int asr_conv3x3_relu_pool(const void* x, const void* wk, const float* bias, void* y, void* pool, int B, int H, int W,
+                                     int Cin, int Cout, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && wk && y && pool && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  // only the layer that has it in the model: bf16, 64 -> 64 channels (conv_c64.hip); callers fall back to conv + asr_maxpool_fwd
+  if (dtype != ASR_BF16 || Cin != 64 || Cout != 64 || !aligned16(x) || !aligned16(wk) || !aligned16(y) || !aligned16(pool) ||
+      (int64_t)B * H * W * 128 >= ((int64_t)1 << 32))
+    return ASR_EUNSUPPORTED;
+  static const bool fused = !(getenv("ASR_CONV_POOL") && atoi(getenv("ASR_CONV_POOL")) == 0);
+  if (!fused) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  C64Args a{};
+  a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
+  a.y = static_cast<bf16_t*>(y); a.pool = static_cast<bf16_t*>(pool);
+  a.B = B; a.H = H; a.W = W; a.relu = 1;
+  return asr_conv3x3_c64_launch(a, s);
+}
+
 extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && y && B >= 0 && H >= 2 && W >= 2 && C > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);

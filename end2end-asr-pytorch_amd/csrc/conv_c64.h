@@ -8,6 +8,7 @@ struct C64Args {
   const float* bias;    // (64) or null
   const bf16_t* mask;   // (B, H, W, 64) or null: output zeroed where mask <= 0 (ReLU mask of the consumer's input, dgrad)
   bf16_t* y;            // (B, H, W, 64)
+  bf16_t* pool;         // optional (forward, ReLU, no mask): (B, H/2, W/2, 64) = 2x2/2 floor max-pool of y, written by the same epilogue
   int B, H, W, relu;
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
   long long* dbg;                 // tuning only (-DC64_TIMING builds): per-section cycle totals of workgroup 0

@@ -104,7 +104,7 @@ __device__ __forceinline__ uint32_t c64_mask2(uint32_t o, uint32_t m) {
   return o & t;
 }
 
-template <int TW, int TH, bool MASK, int NBUF>
+template <int TW, int TH, bool MASK, int NBUF, bool POOL = false>
 __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) {
   constexpr int CB = TW / 16;                         // 16-pixel column blocks per tile row
   constexpr int WM = TW * TH / 64;                    // wave rows (4 pixel fragments each); waves = WM x 2 (32 co each)
@@ -304,6 +304,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
     // (branch-free: ReLU = packed signed max with 0, "no ReLU" = max with the most negative int16; validity of a pixel by compares)
     const uint32_t floor2 = p.relu ? 0u : 0x80008000u;
     const int rows_ok = p.H - h0, cols_ok = p.W - w0 - (tl & 15);
+    uint32_t keep[POOL ? 4 : 1][2][2];        // POOL: the fragments' packed (ReLU'd) channel pairs, [row][channel fragment][pair]
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       uint32_t lo[2], hi[2];
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
         uint32_t pb2 = pack_bf16(acc[i][1][2 * d], acc[i][1][2 * d + 1]);
         asm("v_pk_max_i16 %0, %0, %1" : "+v"(pa) : "s"(floor2));     // max(x, 0) on bf16 bits = signed 16-bit max (rounding keeps the sign)
         asm("v_pk_max_i16 %0, %0, %1" : "+v"(pb2) : "s"(floor2));
+        if (POOL) { keep[i][0][d] = pa; keep[i][1][d] = pb2; }
         // (a, b) -> a' = {a.row0, b.row0, a.row2, b.row2}, b' = {a.row1, b.row1, a.row3, b.row3}
         auto sw = __builtin_amdgcn_permlane16_swap(pa, pb2, false, false);
         lo[d] = sw[0]; hi[d] = sw[1];
@@ -326,6 +328,32 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
       const bool ok = (f / CB < rows_ok) & ((f % CB) * 16 < cols_ok) & !C64_ABL(p, 4);
       if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
     }
+    if (POOL) {
+      // 2x2 / stride 2 max-pool of the tile (8 x 16 -> 4 x 8 pixels) from the packed halves: the values are ReLU outputs (>= 0), so
+      // the signed 16-bit maximum IS the bf16 maximum.  Rows: fragments (0,1) and (2,3) of this wave; columns: lane pairs (lr, lr^1)
+      // by a quad-permute DPP move; the even lanes then own a pooled pixel and the usual lane-group exchange builds its 16-byte chunk.
+      static_assert(!POOL || (CB == 1 && TH == 8), "pooled epilogue: 8 x 16 tiles");
+      const int H2 = p.H >> 1, W2 = p.W >> 1;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        uint32_t lo[2], hi[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          uint32_t va = keep[2 * pr][0][d], vb = keep[2 * pr][1][d];
+          asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(keep[2 * pr + 1][0][d]));
+          asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(keep[2 * pr + 1][1][d]));
+          const uint32_t na = (uint32_t)__builtin_amdgcn_mov_dpp((int)va, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: lane ^ 1
+          const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)vb, 0xB1, 0xf, 0xf, true);
+          asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(na));
+          asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(nb));
+          auto sw = __builtin_amdgcn_permlane16_swap(va, vb, false, false);
+          lo[d] = sw[0]; hi[d] = sw[1];
+        }
+        const int prow = (h0 >> 1) + (tl >> 7) * 2 + pr, pcol = (w0 >> 1) + ((tl & 15) >> 1);
+        if (!(tl & 1) && prow < H2 && pcol < W2)
+          *reinterpret_cast<uint4*>(p.pool + ((((int64_t)b * H2 + prow) * W2 + pcol) * 64 + co0)) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+      }
+    }
     C64_STAMP(4)
 #pragma unroll
     for (int k = 0; k < DIST; ++k) org[k] = org[k + 1];
@@ -338,7 +366,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
 #endif
 }
 
-template <int TW, int TH, bool MASK, int NBUF>
+template <int TW, int TH, bool MASK, int NBUF, bool POOL = false>
 int launch_t(C64Args p, hipStream_t s) {
   p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + TW - 1) / TW;
@@ -357,7 +385,7 @@ int launch_t(C64Args p, hipStream_t s) {
   const int per_cu = (int)(163840 / lds) < 8 / (WM * 2) ? (int)(163840 / lds) : 8 / (WM * 2);   // LDS- and register-limited
   static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
   if (!granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<TW, TH, MASK, NBUF>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_c64_kernel<TW, TH, MASK, NBUF, POOL>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ASR_ELAUNCH;
     granted = true;
@@ -371,7 +399,7 @@ int launch_t(C64Args p, hipStream_t s) {
   (void)hipMemset(dbg, 0, 64 * 8);
   p.dbg = dbg;
 #endif
-  hipLaunchKernelGGL((conv3x3_c64_kernel<TW, TH, MASK, NBUF>), dim3(grid), dim3(WM * 128), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_c64_kernel<TW, TH, MASK, NBUF, POOL>), dim3(grid), dim3(WM * 128), lds, s, p);
   ASR_LAUNCH_CHECK();
 #ifdef C64_TIMING
   {
@@ -397,6 +425,10 @@ int asr_conv3x3_c64_launch(const C64Args& a_, hipStream_t s) {
   // phase, so one's address / epilogue VALU work overlaps the other's MFMAs); 1 / 2 = one 8-wave workgroup on 16 x 16 / 8 x 32 tiles
   const char* sh = getenv("ASR_C64_SHAPE");
   const int shape = sh ? atoi(sh) : 0;
+  if (a.pool) {                      // pooled epilogue: forward with ReLU on the default shape only
+    if (a.mask || !a.relu) return ASR_EUNSUPPORTED;
+    return launch_t<16, 8, false, 3, true>(a, s);
+  }
   if (shape == 1) return a.mask ? launch_t<16, 16, true, 3>(a, s) : launch_t<16, 16, false, 3>(a, s);
   if (shape == 2) return a.mask ? launch_t<32, 8, true, 3>(a, s) : launch_t<32, 8, false, 3>(a, s);
   return a.mask ? launch_t<16, 8, true, 2>(a, s) : launch_t<16, 8, false, 3>(a, s);

@@ -182,6 +182,11 @@ int asr_conv_pack_weight(const float* w, void* wk, void* wd, int Cout, int Cin, 
  * register-resident-weights kernel of conv_c64.hip, everything else the generic implicit GEMM of conv.hip.        */
 int asr_conv3x3_igemm(const void* x, const void* wk, const float* bias, const void* mask_src, void* y, int B,
                       int H, int W, int Cin, int Cout, int relu, int dtype, asr_stream_t stream);
+/* y = ReLU(conv3x3_pad1(x; wk) + bias) AND pool = 2x2/2 floor max-pool of y (B, H/2, W/2, Cout) from the same epilogue
+ * (transformer.py:45-47: conv.2, ReLU, MaxPool2d): the pool no longer re-reads y.  ASR_EUNSUPPORTED unless bf16 and
+ * Cin = Cout = 64 (the layer that has this shape in the model) -- callers then use asr_conv3x3_igemm + asr_maxpool_fwd.  */
+int asr_conv3x3_relu_pool(const void* x, const void* wk, const float* bias, void* y, void* pool, int B, int H, int W,
+                          int Cin, int Cout, int dtype, asr_stream_t stream);
 /* 2x2/2 floor max-pool NHWC; if out_tcf != 0 writes (B, W/2, C, H/2) i.e. the encoder layout (B,T',C*F')        */
 int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, asr_stream_t stream);
 /* dx = scatter of dy to the first maximum of each window, times (x > 0); dy layout per in_tcf                   */

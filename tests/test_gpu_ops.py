@@ -467,6 +467,27 @@ def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     close("conv3x3 wgrad accumulates", dwn, 2 * wr.grad, torch.float32 if dtype == torch.float32 else dtype, scale=16 if dtype == torch.float32 else 1)
 
 
+@pytest.mark.parametrize("shape", [(3, 161, 232), (2, 21, 37), (1, 8, 16), (2, 9, 50)])
+def test_conv3x3_relu_pool_fused(ops, shape):
+    """conv.2 + ReLU + MaxPool2d from one epilogue (asr_conv3x3_relu_pool) == the convolution followed by asr_maxpool_fwd, bit for
+    bit (same accumulators, same rounding; the pooled maximum is taken on the rounded bf16 values in both)."""
+    B, H, W = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = q(torch.randn(B, H, W, 64, generator=g).relu(), dtype)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g) / 3
+    D = dev()
+    wk = torch.empty(64, 9, 64, device=D, dtype=dtype); wd = torch.empty(64, 9, 64, device=D, dtype=dtype)
+    ops.conv_pack_weight(w.to(D), wk, wd)
+    xd = x.to(D, dtype)
+    y_ref = ops.conv3x3(xd, wk, b.to(D), 64, relu=True)
+    p_ref = ops.maxpool_fwd(y_ref)
+    y, pool = ops.conv3x3_relu_pool(xd, wk, b.to(D), 64)
+    assert torch.equal(y, y_ref)
+    assert pool.shape == p_ref.shape and torch.equal(pool, p_ref)
+
+
 @pytest.mark.parametrize("cfg", [(3, 97, 130, 64, 128), (2, 50, 200, 128, 64)])
 def test_conv3x3_wgrad_dma_pipeline(ops, cfg):
     """bf16 weight gradient on the LDS-DMA pipelined kernel (conv_wgrad_dma.hip) at sizes with interior AND border patches, several
