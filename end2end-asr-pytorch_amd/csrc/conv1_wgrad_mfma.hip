@@ -28,12 +28,20 @@ __device__ __forceinline__ uint32_t c1w_pack(float a, float b) {      // one v_c
 
 // hand-issued LDS-DMA piece (see conv_wgrad_dma.hip: the compiler must not see a DMA in flight, and does not count it)
 __device__ __forceinline__ void c1w_dma(unsigned lds_wave_base, const unsigned char* src) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(src) : "memory");
+  unsigned keep;      // M0 is saved and restored: the statement is neutral for whatever the compiler keeps there
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
 }
 
 // 4 bytes per lane (the fp32 input rows: only dword alignment is guaranteed)
 __device__ __forceinline__ void c1w_dma4(unsigned lds_wave_base, const unsigned char* src) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_wave_base), "v"(src) : "memory");
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
 }
 
 constexpr int TILE = 128;              // pixels per tile (one image row segment)

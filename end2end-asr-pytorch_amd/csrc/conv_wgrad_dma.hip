@@ -28,13 +28,20 @@ constexpr int STAGE = XB + DB;
 
 // One 16-byte-per-lane LDS-DMA piece, issued by hand: the compiler must not know that a DMA is in flight, or it drains the
 // VMEM counter before every LDS read of the patch being contracted.  (It then also cannot count these loads: the kernel has no
-// compiler-visible vector memory loads while a DMA is outstanding, and the patch loop waits for vmcnt(0) by hand.  M0 is written
-// without being declared: the compiler sets M0 itself before each of its own uses, and this kernel has none.)
+// compiler-visible vector memory loads while a DMA is outstanding, and the patch loop waits for vmcnt(0) by hand.)
 __device__ __forceinline__ void wgd_dma(unsigned lds_wave_base, const unsigned char* base, unsigned off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_wave_base), "v"(off), "s"(base) : "memory");
+  unsigned keep;      // M0 is saved and restored: the statement is neutral for whatever the compiler keeps there
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(off), "s"(base)
+               : "memory");
 }
 __device__ __forceinline__ void wgd_dma(unsigned lds_wave_base, const unsigned char* src) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_wave_base), "v"(src) : "memory");
+  unsigned keep;      // M0 is saved and restored: the statement is neutral for whatever the compiler keeps there
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
 }
 
 // transposed 8-pixel operand: two ds_read_b64_tr_b16 (pixels 0..3 and 4..7 of the lane group's 8)
