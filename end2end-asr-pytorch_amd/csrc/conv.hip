@@ -186,14 +186,15 @@ __device__ const uint4 conv_zero_page = {0u, 0u, 0u, 0u};      // source of halo
 struct ConvArgs {
   const void* x; const void* wk; const float* bias; const void* mask_src; void* y;
   int B, H, W, Cin, Cout, relu, tiles_h, tiles_w;
-  int ablate;   // tuning only (ASR_IGEMM_ABLATE): 1 = no patch loads, 2 = no weight loads, 4 = no stores, 8 = no MFMAs
+  int ablate;   // tuning only (ASR_IGEMM_ABLATE in -DASR_TUNE_ABLATE builds): 1 = no patch loads, 2 = no weight loads, 4 = no stores, 8 = no MFMAs
 };
 
 // Workgroup tile = TH x 16 pixels x NCO output channels, K step = (tap, 64-channel slice).  The TH+2 x 18 halo patch of a
 // channel slice is staged once and read at 9 shifted positions; the tap's weight rows are double buffered (register
 // prefetch).  Waves: (TH/4) along pixel rows x WN along Cout, each wave 4 pixel-row fragments x FN = NCO/(16 WN) Cout
 // fragments.  TH = 16 gives 4 x 4 (NCO 64) / 4 x 8 (NCO 128) fragments per wave: 2 / 2.7 MFMAs per LDS operand read
-// instead of 1.3 / 2 with TH = 8 -- the kernel is bound by LDS read bandwidth, not by the matrix cores.
+// instead of 1.3 / 2 with TH = 8.  What bounds the loop is instruction issue around the MFMAs (an MFMA leaves room for about two
+// other vector instructions, tools/probes/mfma_valu_probe.hip; this loop carries 1.8 - 3.4) and the two barriers per tap.
 template <typename T, int NCO, int TH, int TPS, int WBUF>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
@@ -211,7 +212,6 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int WCH = WROWS * CPP / 256;   // weight chunks per thread
   constexpr int SPS = (9 + TPS - 1) / TPS; // steps per 64-channel slice
   constexpr int NHALO = (TH + 2) * 18;     // halo pixels
-  constexpr int NPX = TH * 16;             // output pixels
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sP = smem;
   unsigned char* sW0 = smem + NHALO * PP;         // weight tile, buffer 0
