@@ -321,3 +321,104 @@ def edit_distance(a, b):
             cur.append(min(prev[j] + 1, cur[j - 1] + 1, prev[j - 1] + (ca != cb)))
         prev = cur
     return prev[-1]
+
+
+# ------------------------------------------------------------------------------------------------ decoding
+def decode_logits(w, cfg, ys, enc_out):
+    """One pass of the decode-time decoder over the prefix ys (B,t): models/asr/transformer.py:336-350 (greedy) and
+    :437-455 (beam) -- non_pad_mask of ones, causal self-attention mask only, dec_enc_attn_mask=None, dropout in eval
+    mode.  Returns logits (B,t,V)."""
+    B, t = ys.shape
+    D = enc_out.shape[2]
+    causal = torch.triu(torch.ones(t, t, dtype=torch.bool), diagonal=1)[None].expand(B, t, t)        # common_layers.py:66-74
+    scale = (D ** -0.5) if cfg.emb_trg_sharing else 1.0
+    emb_w = w["decoder.trg_embedding.weight"]
+    d = emb_w[ys] * scale + w["decoder.positional_encoding.pe"][:, :t]
+    for l in range(cfg.num_dec_layers):
+        p = "decoder.layers.%d." % l
+        d = multi_head_attention(w, p + "self_attn.", d, d, causal, cfg.num_heads, cfg.dim_key, cfg.dim_value)
+        d = multi_head_attention(w, p + "encoder_attn.", d, enc_out, None, cfg.num_heads, cfg.dim_key, cfg.dim_value)
+        d = pos_ffn(w, p + "pos_ffn.", d)
+    out_w = emb_w if cfg.emb_trg_sharing else w["decoder.output_linear.weight"]
+    return d @ out_w.t()
+
+
+def greedy_search(w, cfg, enc_out, id2label, steps=300):
+    """models/asr/transformer.py:316-394 without LM rescoring: 300 arg-max steps for the whole batch, then every row is
+    cut at its first EOS (:385-393).  Returns the list of strings."""
+    B = enc_out.shape[0]
+    ys = torch.full((B, 1), SOS, dtype=torch.int64)
+    toks = []
+    with torch.no_grad():
+        for _ in range(steps):
+            nxt = decode_logits(w, cfg, ys, enc_out)[:, -1].argmax(dim=1)          # torch.max(prob[:, -1], dim=1) :373
+            toks.append(nxt)
+            ys = torch.cat([ys, nxt[:, None]], dim=1)
+    sents = []
+    for row in torch.stack(toks, dim=1).tolist():
+        st = ""
+        for t in row:
+            if t == EOS:
+                break
+            st += id2label[t]
+        sents.append(st)
+    return sents
+
+
+def beam_search(w, cfg, enc_out, id2label, beam_width, nbest=1, c_weight=1.0, pad_char="¶", sos_char="§",
+                eos_char="¤", steps=300):
+    """models/asr/transformer.py:396-517 without the LM branch.  Per utterance: every live hypothesis is extended by its
+    beam_width best tokens, the candidate list is re-sorted and cut INSIDE the hypothesis loop (:460), hypotheses ending in
+    EOS are retired with final_score = score + sqrt(#words) * c_weight (:487-490), EOS is forced at step T_enc-1 (:465-467).
+    Returns (ids, strings) of the nbest retired hypotheses per utterance; strings keep the EOS char (post_process_hyp)."""
+    ids_out, strs_out = [], []
+    max_len = enc_out.shape[1]
+    with torch.no_grad():
+        for b in range(enc_out.shape[0]):
+            enc = enc_out[b:b + 1]
+            hyps = [{"score": 0.0, "yseq": [SOS]}]
+            ended = []
+            for i in range(steps):
+                kept = []
+                for hyp in hyps:
+                    ys = torch.tensor([hyp["yseq"]], dtype=torch.int64)
+                    lp = torch.log_softmax(decode_logits(w, cfg, ys, enc)[:, -1], dim=1)
+                    best, idx = torch.topk(lp, beam_width, dim=1)
+                    for j in range(beam_width):
+                        kept.append({"score": hyp["score"] + float(best[0, j]), "yseq": hyp["yseq"] + [int(idx[0, j])]})
+                    kept = sorted(kept, key=lambda h: h["score"], reverse=True)[:beam_width]
+                hyps = kept
+                if i == max_len - 1:
+                    for hyp in hyps:
+                        hyp["yseq"] = hyp["yseq"] + [EOS]
+                alive = []
+                for hyp in hyps:
+                    if hyp["yseq"][-1] == EOS:
+                        s = "".join(id2label[t] for t in hyp["yseq"])
+                        for ch in (pad_char, sos_char, eos_char):
+                            s = s.replace(ch, "")
+                        s = s.replace("  ", " ")
+                        hyp["final_score"] = hyp["score"] + math.sqrt(len(s.split())) * c_weight
+                        ended.append(hyp)
+                    else:
+                        alive.append(hyp)
+                hyps = alive
+                if not hyps:
+                    break
+            for hyp in sorted(ended, key=lambda h: h["final_score"], reverse=True)[:min(len(ended), nbest)]:
+                ids_out.append(hyp["yseq"])
+                strs_out.append("".join(id2label[t] for t in hyp["yseq"][1:]))
+    return ids_out, strs_out
+
+
+def eval_error_counts(strs_hyps, strs_gold, pad_char="¶", sos_char="§", eos_char="¤"):
+    """test.py:42-58: (total_cer, total_char, total_wer, total_word) over a batch of hypothesis / gold strings."""
+    tc = tch = tw = twd = 0
+    for h, g in zip(strs_hyps, strs_gold):
+        for ch in (eos_char, sos_char, pad_char):
+            h, g = h.replace(ch, ""), g.replace(ch, "")
+        tw += edit_distance(h.split(), g.split())                     # utils/metrics.py:58-76
+        tc += edit_distance(h.strip(), g.strip())                     # utils/metrics.py:48-56
+        twd += len(g.split(" "))
+        tch += len(g)
+    return tc, tch, tw, twd

@@ -8,8 +8,18 @@ Recipe follows SURVEY.md Appendix A: stub Levenshtein/torchaudio, preset sys.arg
 reference import (utils/constant.py:99 parses argv at import time), never write bytecode into the
 reference tree.  One interpreter per configuration (the reference Namespace is a process global).
 
-usage:  python oracle/gen_golden.py <case>      case in: vgg_tiny | emb_tiny | raw_tiny
-        python oracle/gen_golden.py all         (spawns one subprocess per case)
+usage:  python oracle/gen_golden.py <case>      case in: vgg_tiny | emb_tiny | raw_tiny            (full tensors)
+                                                         cfg0 | cfg1_b2 | cfg3_shape                (BASELINE shapes, summaries)
+                                                         dec_tiny                                   (greedy / beam strings, CER)
+                                                         ref_ckpt                                   (reference-written checkpoints)
+        python oracle/gen_golden.py all         (spawns one subprocess per tiny case)
+        python oracle/gen_golden.py round2      (spawns one subprocess per round-2 case)
+
+BASELINE-shape cases keep the fixtures small: the weights are NOT stored -- the product's constructors consume torch's
+CPU RNG exactly like the reference's (checked: identical state_dict from torch.manual_seed(123456)), so a test rebuilds
+them from the seed (+ the same perturbation of the 1-D parameters) and the fixture only holds a checksum, the loss, the
+arg-max rows with their margins, a column sample of the logits and, per parameter, the gradient's norm, a random
+projection and a strided sample.
 """
 import os
 import subprocess
@@ -138,11 +148,331 @@ def run_case(name):
           "%.2f MB" % (os.path.getsize(path) / 1e6))
 
 
+# ====================================================================================================== round 2 cases
+def _boot(flags):
+    """Stub the absent third-party modules, preset argv, import the reference.  Returns its `constant` module."""
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    sys.argv = ["train.py"] + list(flags)
+    lev = types.ModuleType("Levenshtein"); lev.distance = edit_distance
+    sys.modules["Levenshtein"] = lev
+    sys.modules["torchaudio"] = types.ModuleType("torchaudio")
+    import torch
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    from utils import constant
+    return constant
+
+
+def synth_labels(V, constant):
+    """The bench / test vocabulary: PAD, SOS, EOS + (V-3) CJK code points (bench.py:labels)."""
+    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(V - 3)]
+    l2i = {c: i for i, c in enumerate(chars)}
+    return l2i, {i: c for c, i in l2i.items()}
+
+
+def perturb_1d(model):
+    """Biases / LayerNorm / BatchNorm affine made non-trivial, in SORTED name order (order independent of registration)."""
+    import torch
+    g = torch.Generator().manual_seed(4321)
+    named = dict(model.named_parameters())
+    with torch.no_grad():
+        for n in sorted(named):
+            if named[n].dim() == 1:
+                named[n].add_(0.1 * torch.randn(named[n].shape, generator=g))
+
+
+def synth_batch(B, T, V, src_len, tgt_len):
+    import torch
+    g = torch.Generator().manual_seed(1234)
+    src = torch.randn(B, 1, 161, T, generator=g)
+    src_len = torch.tensor(src_len, dtype=torch.int32)
+    for b in range(B):
+        src[b, :, :, int(src_len[b]):] = 0.0
+    tgt = torch.zeros(B, max(tgt_len), dtype=torch.int64)
+    for b, L in enumerate(tgt_len):
+        tgt[b, :L] = torch.randint(3, V, (L,), generator=g)
+    return src, src_len, tgt
+
+
+def weight_checksum(sd):
+    import numpy as np
+    s1 = s2 = 0.0
+    for k in sorted(sd):
+        if k.endswith("num_batches_tracked"):
+            continue
+        a = sd[k].detach().double().numpy()
+        s1 += float(a.sum()); s2 += float((a * a).sum())
+    return np.array([s1, s2])
+
+
+def name_seed(name):
+    import zlib
+    return zlib.crc32(name.encode()) & 0x7FFFFFFF
+
+
+def grad_summary(out, name, g):
+    """norm, projection on a seeded +-1 vector, and either the full tensor (<= 8192 elements) or 1024 strided samples."""
+    import numpy as np
+    import torch
+    f = g.detach().reshape(-1).double()
+    out["gn/" + name] = np.float64(f.norm().item())
+    sign = (torch.randint(0, 2, (f.numel(),), generator=torch.Generator().manual_seed(name_seed(name))).double() * 2 - 1)
+    out["gp/" + name] = np.float64((f * sign).sum().item())
+    if f.numel() <= 8192:
+        out["g0/" + name] = g.detach().numpy().copy()
+    else:
+        stride = f.numel() // 1024
+        out["gs/" + name] = g.detach().reshape(-1)[::stride][:1024].numpy().copy()
+
+
+BIG = {
+    # BASELINE.json configs[0] exactly: 2-layer d256 h4 dk64 (Dff = the CLI default 1024) vgg_cnn, B=4, T=800, Td=100, V=4364
+    "cfg0": dict(flags=["--num-layers", "2", "--num-heads", "4", "--dim-model", "256", "--dim-key", "64", "--dim-value", "64",
+                        "--dim-inner", "1024", "--dim-emb", "256", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "100",
+                        "--src-max-len", "800", "--label-smoothing", "0.1", "--dropout", "0.0"],
+                 V=4364, B=4, T=800, src_len=[800, 640, 150, 97], tgt_len=[99, 60, 23, 5], smoothing=0.1),
+    # configs[1] (the benched model) at batch 2
+    "cfg1_b2": dict(flags=["--num-layers", "4", "--num-heads", "8", "--dim-model", "512", "--dim-key", "64", "--dim-value", "64",
+                           "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "100",
+                           "--src-max-len", "800", "--label-smoothing", "0.1", "--dropout", "0.0"],
+                    V=4364, B=2, T=800, src_len=[800, 170], tgt_len=[99, 31], smoothing=0.1),
+    # configs[3]-shaped: emb_cnn, T=1600 -> T'=795, d512 h8 dk64, V=32, 2 encoder / 1 decoder layers (constructors: the CLI has
+    # one --num-layers for both, reference utils/functions.py:148-151)
+    "cfg3_shape": dict(flags=["--num-layers", "2", "--num-heads", "8", "--dim-model", "512", "--dim-key", "64", "--dim-value", "64",
+                              "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "emb_cnn", "--tgt-max-len", "100",
+                              "--src-max-len", "1600", "--label-smoothing", "0.1", "--dropout", "0.0"],
+                       V=32, B=2, T=1600, src_len=[1600, 700], tgt_len=[99, 40], smoothing=0.1, enc_layers=2, dec_layers=1),
+}
+
+
+def build_reference_model(constant, cfg, l2i, i2l):
+    import torch
+    from utils.functions import init_transformer_model
+    torch.manual_seed(123456)
+    if "enc_layers" not in cfg:
+        return init_transformer_model(constant.args, l2i, i2l)
+    from models.asr.transformer import Decoder, Encoder, Transformer
+    a = constant.args
+    a.dim_input = 32 * 21
+    enc = Encoder(cfg["enc_layers"], a.num_heads, a.dim_model, a.dim_key, a.dim_value, a.dim_input, a.dim_inner,
+                  dropout=a.dropout, src_max_length=a.src_max_len)
+    dec = Decoder(i2l, len(l2i), len(l2i), cfg["dec_layers"], a.num_heads, a.dim_emb, a.dim_model, a.dim_inner, a.dim_key,
+                  a.dim_value, dropout=a.dropout, trg_max_length=a.tgt_max_len, emb_trg_sharing=False)
+    return Transformer(enc, dec, feat_extractor="emb_cnn")
+
+
+def run_big(name):
+    import numpy as np
+    cfg = BIG[name]
+    constant = _boot(cfg["flags"])
+    import torch
+    from utils.functions import init_optimizer
+    from utils.metrics import calculate_metrics
+    l2i, i2l = synth_labels(cfg["V"], constant)
+    model = build_reference_model(constant, cfg, l2i, i2l)
+    opt = init_optimizer(constant.args, model, "noam")
+    model.train()
+    perturb_1d(model)
+    src, src_len, tgt = synth_batch(cfg["B"], cfg["T"], cfg["V"], cfg["src_len"], cfg["tgt_len"])
+    out = {"V": np.int64(cfg["V"]), "B": np.int64(cfg["B"]), "T": np.int64(cfg["T"]), "src_len": np.array(cfg["src_len"], np.int32),
+           "tgt_len": np.array(cfg["tgt_len"], np.int32), "smoothing": np.float64(cfg["smoothing"]),
+           "flags": np.array(" ".join(cfg["flags"])), "dim_input": np.int64(constant.args.dim_input),
+           "enc_layers": np.int64(cfg.get("enc_layers", 0)), "dec_layers": np.int64(cfg.get("dec_layers", 0)),
+           "wsum": weight_checksum(model.state_dict()), "src_sum": np.float64(src.double().sum().item()),
+           "tgt": tgt.numpy()}
+    opt.zero_grad()
+    pred, gold, hyp_seq, _ = model(src, src_len, tgt)
+    loss, ncorrect = calculate_metrics(pred, gold, smoothing=cfg["smoothing"], loss_type="ce")
+    loss.backward()
+    p = pred.detach()
+    top2 = torch.topk(p, 2, dim=2).values
+    out["margin"] = (top2[..., 0] - top2[..., 1]).numpy().astype(np.float32)
+    out["hyp"] = p.argmax(2).numpy().astype(np.int32)
+    out["gold"] = gold.numpy().astype(np.int32)
+    idx = torch.randperm(cfg["V"], generator=torch.Generator().manual_seed(99))[:64].sort().values
+    out["pred_idx"] = idx.numpy()
+    out["pred_sub"] = p[:, :, idx].numpy().copy()
+    out["pred_lse"] = torch.logsumexp(p, dim=2).numpy().copy()
+    out["pred_absmax"] = np.float64(p.abs().max().item())
+    out["loss"] = np.float64(loss.item())
+    out["num_correct"] = np.int64(ncorrect)
+    for k, q in model.named_parameters():
+        grad_summary(out, k, q.grad)
+    opt.step()
+    out["lr1"] = np.float64(opt._rate)
+    opt.zero_grad()
+    pred2, gold2, _, _ = model(src, src_len, tgt)
+    loss2, _ = calculate_metrics(pred2, gold2, smoothing=cfg["smoothing"], loss_type="ce")
+    out["loss2"] = np.float64(loss2.item())
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(name, "loss", out["loss"], "loss2", out["loss2"], "ncorrect", ncorrect, "->", path,
+          "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+# ---------------------------------------------------------------------------------------------------- decode / CER
+DEC = dict(flags=["--num-layers", "2", "--num-heads", "2", "--dim-model", "32", "--dim-key", "16", "--dim-value", "16",
+                  "--dim-inner", "64", "--dim-emb", "32", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "301",
+                  "--src-max-len", "64", "--label-smoothing", "0.1", "--dropout", "0.0", "--warmup", "40", "--k-lr", "6"],
+           B=4, T=64, src_len=[64, 52, 40, 33], tgt_len=[14, 10, 7, 3], smoothing=0.1, train_steps=170, beam_width=4)
+
+
+def reference_eval_cer(constant, strs_hyps, strs_gold):
+    """The accumulation of reference test.py:42-58."""
+    from utils.metrics import calculate_cer, calculate_wer
+    total_cer = total_wer = total_char = total_word = 0
+    for h, g in zip(strs_hyps, strs_gold):
+        for ch in (constant.EOS_CHAR, constant.SOS_CHAR, constant.PAD_CHAR):
+            h, g = h.replace(ch, ""), g.replace(ch, "")
+        total_wer += calculate_wer(h, g)
+        total_cer += calculate_cer(h.strip(), g.strip())
+        total_word += len(g.split(" "))
+        total_char += len(g)
+    return total_cer, total_char, total_wer, total_word
+
+
+def run_dec(name="dec_tiny"):
+    """Train the tiny vgg model for a few Noam/Adam steps on one batch WITH THE REFERENCE (so that it emits EOS and the
+    strings mean something), then run the reference's own Transformer.evaluate(): greedy and beam search."""
+    import json
+    import numpy as np
+    cfg = DEC
+    constant = _boot(cfg["flags"])
+    import torch
+    import models.asr.transformer as T
+    from utils.functions import init_optimizer, init_transformer_model
+    from utils.metrics import calculate_metrics
+    # torch >= 1.2 refuses uint8 masks in masked_fill: the decode loops build theirs with get_subsequent_mask (uint8).
+    _orig = T.get_subsequent_mask
+    T.get_subsequent_mask = lambda seq: _orig(seq).bool()
+    labels = json.load(open(os.path.join(REF, "data/labels/labels.json")))
+    labels = constant.PAD_CHAR + constant.SOS_CHAR + constant.EOS_CHAR + "".join(labels)
+    l2i = {c: i for i, c in enumerate(labels)}
+    i2l = {i: c for c, i in l2i.items()}
+    V = len(l2i)
+    torch.manual_seed(123456)
+    model = init_transformer_model(constant.args, l2i, i2l)
+    opt = init_optimizer(constant.args, model, "noam")
+    model.train()
+    perturb_1d(model)
+    src, src_len, tgt = synth_batch(cfg["B"], cfg["T"], V, cfg["src_len"], cfg["tgt_len"])
+    # distinguishable utterances: a per-utterance spectral tilt on top of the noise (random noise alone is not learnable)
+    g = torch.Generator().manual_seed(77)
+    for b in range(cfg["B"]):
+        src[b, 0, :, :int(src_len[b])] += 1.5 * torch.randn(161, 1, generator=g)
+    tgt[tgt == l2i[" "]] = l2i["a"]                       # keep strings free of blanks at the edges (test.py strips them)
+    tgt[0, 5] = l2i[" "]                                  # ... but one interior blank so that WER sees two words
+    losses = []
+    for _ in range(cfg["train_steps"]):
+        opt.zero_grad()
+        pred, gold, _, _ = model(src, src_len, tgt)
+        loss, _ = calculate_metrics(pred, gold, smoothing=cfg["smoothing"], loss_type="ce")
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    print("train loss %.4f -> %.4f" % (losses[0], losses[-1]))
+    model.eval()
+    out = {"src": src.numpy(), "src_len": src_len.numpy(), "tgt": tgt.numpy(), "V": np.int64(V),
+           "flags": np.array(" ".join(cfg["flags"])), "beam_width": np.int64(cfg["beam_width"]),
+           "train_loss_first": np.float64(losses[0]), "train_loss_last": np.float64(losses[-1])}
+    for k, v in model.state_dict().items():
+        out["w/" + k] = v.detach().numpy().copy()
+    with torch.no_grad():
+        _, g_hyps, g_gold = model.evaluate(src, src_len, tgt, beam_search=False)
+        _, b_hyps, b_gold = model.evaluate(src, src_len, tgt, beam_search=True, beam_width=cfg["beam_width"], beam_nbest=1,
+                                           c_weight=constant.args.c_weight)
+        # per-step margins of the greedy path (teacher-forced on the greedy output): how decisive each argmax was
+        enc_in = model.conv(src)
+        s = enc_in.size()
+        enc_out, _ = model.encoder(enc_in.view(s[0], s[1] * s[2], s[3]).transpose(1, 2).contiguous(), src_len)
+    out["greedy"] = np.array(g_hyps)
+    out["beam"] = np.array(b_hyps)
+    out["gold_strs"] = np.array(g_gold)
+    out["enc_out"] = enc_out.numpy().copy()
+    gc = reference_eval_cer(constant, g_hyps, g_gold)
+    bc = reference_eval_cer(constant, b_hyps, b_gold)
+    out["greedy_cer"] = np.array(gc, dtype=np.int64)
+    out["beam_cer"] = np.array(bc, dtype=np.int64)
+    print("greedy", g_hyps, gc)
+    print("beam  ", b_hyps, bc)
+    print("gold  ", g_gold)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("->", path, "%.2f MB" % (os.path.getsize(path) / 1e6))
+
+
+# ---------------------------------------------------------------------------------------------------- checkpoints
+CKPT = dict(flags=["--num-layers", "1", "--num-heads", "2", "--dim-model", "32", "--dim-key", "16", "--dim-value", "16",
+                   "--dim-inner", "64", "--dim-emb", "32", "--feat_extractor", "", "--tgt-max-len", "16", "--src-max-len", "50",
+                   "--label-smoothing", "0.1", "--dropout", "0.0", "--name", "ref_ckpt"],
+            B=3, T=50, src_len=[50, 31, 12], tgt_len=[12, 8, 2], smoothing=0.1)
+
+
+def run_ckpt(parallel):
+    """Two steps with the reference, checkpoint written by the reference's OWN save_model (plain, or wrapped in
+    nn.DataParallel so that every key carries the `module.` prefix), then a third step: the resume target."""
+    import json
+    import shutil
+    import tempfile
+    import numpy as np
+    cfg = CKPT
+    flags = cfg["flags"] + (["--parallel"] if parallel else [])
+    tmp = tempfile.mkdtemp()
+    constant = _boot(flags + ["--save-folder", tmp])
+    import torch
+    from utils.functions import init_optimizer, init_transformer_model, save_model
+    from utils.metrics import calculate_metrics
+    labels = json.load(open(os.path.join(REF, "data/labels/labels.json")))
+    labels = constant.PAD_CHAR + constant.SOS_CHAR + constant.EOS_CHAR + "".join(labels)
+    l2i = {c: i for i, c in enumerate(labels)}
+    i2l = {i: c for c, i in l2i.items()}
+    torch.manual_seed(123456)
+    model = init_transformer_model(constant.args, l2i, i2l)       # nn.DataParallel(model) under --parallel (CPU: pass-through)
+    opt = init_optimizer(constant.args, model, "noam")
+    model.train()
+    perturb_1d(model)
+    src, src_len, tgt = synth_batch(cfg["B"], cfg["T"], len(l2i), cfg["src_len"], cfg["tgt_len"])
+
+    def one():
+        opt.zero_grad()
+        pred, gold, _, _ = model(src, src_len, tgt)
+        loss, _ = calculate_metrics(pred, gold, smoothing=cfg["smoothing"], loss_type="ce")
+        loss.backward()
+        opt.step()
+        return loss.item()
+
+    l1, l2 = one(), one()
+    save_model(model, 7, opt, {"valid_loss": 1.25, "train_loss": l2}, l2i, i2l, best_model=False)
+    tag = "parallel" if parallel else "plain"
+    dst = os.path.join(OUT, "ref_ckpt_%s.th" % tag)
+    shutil.copyfile(os.path.join(tmp, "ref_ckpt", "epoch_7.th"), dst)
+    shutil.rmtree(tmp)
+    l3 = one()
+    out = {"src": src.numpy(), "src_len": src_len.numpy(), "tgt": tgt.numpy(), "loss1": np.float64(l1), "loss2": np.float64(l2),
+           "loss3": np.float64(l3), "lr3": np.float64(opt._rate), "smoothing": np.float64(cfg["smoothing"])}
+    for k, v in model.state_dict().items():
+        if not k.endswith(".pe"):
+            out["w3/" + k] = v.detach().numpy().copy()
+    path = os.path.join(OUT, "ref_ckpt_%s.npz" % tag)
+    np.savez_compressed(path, **out)
+    print(tag, "losses", l1, l2, l3, "->", dst, "%.2f MB" % (os.path.getsize(dst) / 1e6), path)
+
+
+ROUND2 = ["cfg0", "cfg1_b2", "cfg3_shape", "dec_tiny", "ref_ckpt_plain", "ref_ckpt_parallel"]
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
-    if which == "all":
-        for c in CASES:
+    if which in ("all", "round2"):
+        for c in (CASES if which == "all" else ROUND2):
             subprocess.check_call([sys.executable, os.path.abspath(__file__), c],
                                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    elif which in BIG:
+        run_big(which)
+    elif which == "dec_tiny":
+        run_dec()
+    elif which in ("ref_ckpt_plain", "ref_ckpt_parallel"):
+        run_ckpt(which.endswith("parallel"))
     else:
         run_case(which)
