@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Throughput of the Transformer-ASR TRAINING STEP on MI355X (BASELINE.json metric: input spectrogram frames/s).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N ...`: WORLD_SIZE is in the environment and must equal N) or bench.py re-executes
+itself under torch.distributed.run with N ranks.  Fewer than N visible GPUs is an error, never a silent 1-GPU run.
 
 Workload (BASELINE.json configs[1]): 4-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Transformer,
 synthetic spectrogram batch (B=32 per GPU, 1, 161, T_src=800) fp32, targets (B, 99) int64 padded to T_tgt=100,
@@ -12,6 +16,8 @@ HBM before the timed region.  One JSON line on stdout (rank 0).
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -31,25 +37,42 @@ MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm
 LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0, "enc_layers": 12, "dec_layers": 6}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
+TRAFFIC_FILE = os.path.join("profiles", "r02_roofline_traffic.json")
 
 
-def conv_igemm_flops(B):
-    """Algorithmic FLOPs of all asr_conv3x3_igemm launches in ONE step: 3 forward convs + 3 dgrads (2*9*Cin*Cout/pixel)."""
-    px1, px2 = B * 161 * 800, B * 80 * 400
-    fwd = 2 * 9 * (64 * 64 * px1 + 64 * 128 * px2 + 128 * 128 * px2)
-    return 2 * fwd, 6
+# ------------------------------------------------------------------------------------------------ algorithmic work
+def family_flops(B, L=4, D=512, H=8, dk=64, Dff=2048, vocab=V, t_src=T_SRC, t_tgt=T_TGT):
+    """Algorithmic FLOPs (2*MAC) of ONE training step of configs[1], by kernel family -> {family: (flop, launches)}.
+    conv: 3 forward + 3 data-gradient implicit GEMMs (2*9*Cin*Cout per pixel); conv weight gradients the same flop once more;
+    linear: every nn.Linear / Conv1d(k=1): forward + data gradient + weight gradient = 3 * 2*M*N*K;
+    attention: forward 4*B*H*Tq*Tk*d, backward 2.5 x forward."""
+    px1, px2 = B * 161 * t_src, B * 80 * (t_src // 2)
+    conv_fwd = 2 * 9 * (64 * 64 * px1 + 64 * 128 * px2 + 128 * 128 * px2)
+    Te, Td = t_src // 4, t_tgt
+    Me, Md = B * Te, B * Td
+    HD = H * dk
+    lin = Me * D * (5120)                                             # encoder input linear (D_in = 128 * 40)
+    lin += L * (Me * 3 * HD * D + Me * D * HD + 2 * Me * Dff * D)     # encoder layers
+    lin += L * (Md * 3 * HD * D + Md * D * HD + Md * HD * D + Me * 2 * HD * D + Md * D * HD + 2 * Md * Dff * D)
+    lin += Md * vocab * D
+    att = L * 4 * B * H * dk * (Te * Te + Td * Td + Td * Te)
+    return {"conv3x3_igemm (3 fwd + 3 dgrad)": (2 * conv_fwd, 6), "conv3x3_wgrad": (conv_fwd, 3),
+            "linear GEMMs (fwd + dgrad + wgrad)": (3 * 2 * lin, None), "attention fwd": (att, 3 * L),
+            "attention bwd": (2.5 * att, None)}
 
 
 def measured_traffic(a):
-    """HBM bytes per igemm launch from the committed rocprofv3 PMC passes (profiles/r01_roofline_traffic.json: separate
-    FETCH_SIZE / WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
+    """HBM bytes per launch of the conv igemm family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
+    WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
     if a.batch != 32 or a.precision != "bf16":
         return None
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_roofline_traffic.json")) as f:
-            return json.load(f)["traffic_bytes_per_launch_avg"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for f in (TRAFFIC_FILE, os.path.join("profiles", "r01_roofline_traffic.json")):
+        try:
+            with open(os.path.join(ROOT, f)) as fh:
+                return json.load(fh)["traffic_bytes_per_launch_avg"], f
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def labels(vocab=V):
@@ -78,30 +101,78 @@ def build_librispeech_model(args, l2i, i2l):
     return Transformer(enc, dec, feat_extractor="emb_cnn")
 
 
-def cpu_baseline(state_dict, dropout_free_flags, seconds_budget=25.0):
-    """The CPU oracle (port of the reference step, oracle/asr_oracle.py) timed on this box's host cores on a bounded
-    sample of the same workload: same model, same T_src/T_tgt/V, batch 8 instead of 32."""
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(state_dict, flags, batch, seconds_budget=150.0):
+    """the reference step (zero_grad, forward, label-smoothed CE, backward, Noam/Adam) on this box's
+    host cores, fp32, the SAME synthetic tensors as the GPU run (B = 32, T_src = 800, T_tgt = 100, V = 4364), 1 warm-up + 3
+    timed steps, best and median.  kind "reference": the unmodified reference imported from /root/reference in a subprocess
+    (oracle/time_reference.py); kind "port": oracle/asr_oracle.py (the restatement pinned to the reference by tests/) when the
+    reference tree is absent, as on the GPU box.  Data loading and the trainer's string / CER bookkeeping are excluded."""
     import torch
+    common = {"unit": "frames/s", "cores": torch.get_num_threads(), "nproc": os.cpu_count(), "cpu_model": cpu_model_name(),
+              "dtype": "f32", "batch": batch}
+    ref_dir = os.environ.get("ASR_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref_dir, "models")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--batch", str(batch),
+                            "--budget", str(seconds_budget)], capture_output=True, text=True, timeout=seconds_budget * 4 + 300)
+        if r.returncode == 0:
+            t = json.loads(r.stdout.strip().splitlines()[-1])
+            times = t["times"]
+            return dict(common, value=batch * T_SRC / min(times), median=batch * T_SRC / statistics.median(times), kind="reference",
+                        cores=t["threads"], step_s_best=min(times), step_s_median=statistics.median(times),
+                        sample="the unmodified reference train step (models/asr/transformer.py:59-85, utils/metrics.py:78-130, "
+                               "utils/optimizer.py:15-22) imported from /root/reference, fp32, dropout 0.1, 4-layer d512 vgg_cnn, "
+                               "batch %d x T_src 800, 1 warm-up + %d timed steps (best / median); data loading and CER "
+                               "bookkeeping excluded" % (batch, len(times)))
     from oracle import asr_oracle as O
-    Bc = 8
-    cfg = O.Cfg.from_flags(dropout_free_flags)
+    cfg = O.Cfg.from_flags(flags)
     w = {k: v.detach().float().cpu() for k, v in state_dict.items()}
-    src, src_len, tgt = synthetic_batch(Bc, torch)
+    src, src_len, tgt = synthetic_batch(batch, torch)
     names = O.trainable_names(w, cfg)
     opt = O.NoamAdam({k: w[k] for k in names}, model_size=5120)
     times = []
     t_start = time.time()
-    for i in range(3):
+    for i in range(4):
         t0 = time.time()
         O.train_step(w, cfg, src, src_len, tgt, 0.1, opt=opt)
-        times.append(time.time() - t0)
+        if i > 0:
+            times.append(time.time() - t0)
+        elif time.time() - t0 > seconds_budget / 2:                # a very slow host: keep the warm-up as the only sample
+            times.append(time.time() - t0)
+            break
         if time.time() - t_start > seconds_budget:
             break
-    best = min(times[1:]) if len(times) > 1 else times[0]
-    return {"value": Bc * T_SRC / best, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/asr_oracle.py train_step (fwd+CE+bwd+Noam/Adam, fp32, dropout off), same 4-layer d512 vgg_cnn "
-                      "model and shapes at batch %d, best of %d timed steps after 1 warm-up; data loading and CER "
-                      "bookkeeping excluded" % (Bc, max(1, len(times) - 1))}
+    return dict(common, value=batch * T_SRC / min(times), median=batch * T_SRC / statistics.median(times), kind="port",
+                step_s_best=min(times), step_s_median=statistics.median(times),
+                sample="oracle/asr_oracle.py train_step (restatement of the reference step pinned to it by tests/: forward + "
+                       "label-smoothed CE + backward + Noam/Adam, fp32, dropout off), same 4-layer d512 vgg_cnn model, same "
+                       "synthetic tensors, batch %d x T_src 800, 1 warm-up + %d timed steps (best / median); data loading and CER "
+                       "bookkeeping excluded" % (batch, len(times)))
+
+
+# ------------------------------------------------------------------------------------------------ launch
+def respawn(a):
+    """--gpus N > 1 without a launcher: re-exec under torch.distributed.run, one rank per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to run a smaller job under that label"
+                         % (a.gpus, have))
+    port = 29500 + os.getpid() % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
 
 
 def main():
@@ -116,8 +187,17 @@ def main():
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
+    ap.add_argument("--no-exposure", action="store_true", help="N > 1: skip the extra no-collective steps that measure how much "
+                    "of the gradient all-reduce is exposed")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     a = ap.parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        respawn(a)
+    world = int(env_world or "1")
+    force_ddp = os.environ.get("ASR_FORCE_DDP") == "1"
+    if world != a.gpus:
+        raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world))
     libri = a.workload == "librispeech"
     if a.batch is None:
         a.batch = LIBRI["B"] if libri else 32
@@ -126,15 +206,17 @@ def main():
 
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-    force_ddp = os.environ.get("ASR_FORCE_DDP") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < 1 or (world > 1 and ndev < world and os.environ.get("ASR_DIST_BACKEND", "nccl") == "nccl"):
+        raise SystemExit("bench.py: %d rank(s) need %d GPU(s), %d visible" % (world, world, ndev))
+    torch.cuda.set_device(local % ndev)
+    backend = os.environ.get("ASR_DIST_BACKEND", "nccl")
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(os.environ.get("ASR_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     from asr_hip import lib as L
     from asr_hip import ops
@@ -161,6 +243,9 @@ def main():
         model = init_transformer_model(args, l2i, i2l).cuda()
     model.train()
     opt = init_optimizer(args, model, "noam")
+    red = opt.optimizer.reducer
+    if world > 1 and (red is None or not red.active):
+        raise SystemExit("bench.py: %d ranks but no active gradient reducer" % world)
     src, src_len, tgt = synthetic_batch(a.batch, torch, t_src, t_tgt, vocab)
     src, tgt = src.cuda(), tgt.cuda()
     sd_cpu = None
@@ -176,10 +261,10 @@ def main():
         opt.step()
         return loss
 
-    # N = 1: the whole step is one captured hipGraph (same kernels, no per-launch host cost).  N > 1 stays eager: RCCL
-    # collectives inside a capture could not be validated on the single-GPU development box.
-    use_graph = not a.eager and (world == 1 or os.environ.get("ASR_GRAPH_DDP") == "1")
-    if use_graph:
+    # The step is replayed from captured hipGraphs (same kernels, no per-launch host cost): one graph on one GPU; under data
+    # parallelism three graphs with the RCCL all-reduces between them (asr_hip/graph.py).
+    gs = None
+    if not a.eager:
         from asr_hip.graph import GraphedTrainStep
         gs = GraphedTrainStep(model, opt, 0.1, src, src_len, tgt, warmup_steps=max(1, a.warmup))
         step = lambda: gs()[0]
@@ -187,48 +272,69 @@ def main():
         step = eager_step
         for _ in range(a.warmup):
             step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    final_loss = float(loss.item())
 
-    # roofline pass: the dominant kernel family bracketed by HIP events on its own stream, over `prof_steps` eager steps of
-    # the same workload (events cannot be recorded inside a graph replay).  Every rank takes part: the steps contain the
-    # gradient all-reduce.
+    def timed(n):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item()), dt, loss
+
+    dt, dt_local, loss = timed(a.steps)
+    final_loss = gs.global_loss() if gs is not None else float(loss.item())
+
+    # Exposed part of the gradient exchange: the same steps with the collectives switched off (ranks then drift apart -- this
+    # runs after the timed region and nothing is measured afterwards that depends on the weights).
+    exposure = None
+    if red is not None and red.active and not a.no_exposure:
+        red.active = False
+        dt_nc, _, _ = timed(a.steps)
+        red.active = True
+        exposure = {"ms_per_step_without_allreduce": dt_nc / a.steps * 1e3,
+                    "exposed_ms_per_step": (dt - dt_nc) / a.steps * 1e3}
+
+    # Roofline pass: every launch of the MFMA kernel families bracketed by HIP events on the stream it is launched on, over
+    # `prof_steps` EAGER steps of the same workload right after the timed region (events cannot be recorded inside a graph
+    # replay).  Every rank takes part: the steps contain the gradient all-reduce.
     prof = None
+    fam_ops = {"conv3x3_igemm (3 fwd + 3 dgrad)": L.OP_CONV_IGEMM, "conv3x3_wgrad": L.OP_CONV_WGRAD,
+               "linear GEMMs (fwd + dgrad + wgrad)": L.OP_GEMM, "attention fwd": L.OP_ATTN_FWD, "attention bwd": L.OP_ATTN_BWD}
     if not a.no_roofline and not libri:
         prof_steps = min(a.steps, 3)
-        ops.prof_enable(L.OP_CONV_IGEMM, True)
+        for op in fam_ops.values():
+            ops.prof_enable(op, True)
         for _ in range(prof_steps):
-            eager_step()
+            if gs is not None:
+                gs._eager_step()
+                gs._host_after()
+            else:
+                eager_step()
         torch.cuda.synchronize()
-        tot_ms, n = ops.prof_collect(L.OP_CONV_IGEMM)
-        ops.prof_enable(L.OP_CONV_IGEMM, False)
-        prof = (tot_ms, n, prof_steps)
+        prof = {k: ops.prof_collect(op) for k, op in fam_ops.items()}
+        for op in fam_ops.values():
+            ops.prof_enable(op, False)
     if world > 1:
         dist.barrier()
 
-    out = None
     if rank == 0:
         ms = dt / a.steps * 1e3
         frames = a.batch * world * t_src * a.steps
         value = frames / dt
         peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        mode = "eager" if a.eager else ("hipGraph replay" if red is None or not red.active else
+                                        "3 hipGraphs per step, RCCL all-reduces between them")
         out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-               "launch_mode": "hipGraph replay" if use_graph else "eager",
+               "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic", "launch_mode": mode,
                "config": {"workload": ("configs[3]: 12-enc/6-dec-layer d_model=512 heads=8 dim-inner=2048 emb_cnn Transformer ASR "
                                        "training step, synthetic (B=%d/GPU,1,161,T_src=1600) -> T_tgt=100, V=32, label "
                                        "smoothing 0.1, dropout %.2f, random init" if libri else
@@ -236,22 +342,45 @@ def main():
                                        "step, synthetic (B=%d/GPU,1,161,T_src=800) -> T_tgt=100, V=4364, label smoothing 0.1, "
                                        "dropout %.2f, random init") % (a.batch, a.dropout),
                           "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                          "per_gpu_frames_per_s": value / world,
+                          "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
+                          "collective_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+                          "rank0_ms_per_step": dt_local / a.steps * 1e3,
                           "step_tflops_whole_model": value * mflop_per_frame * 1e6 / 1e12,
                           "frac_of_mfma_peak_whole_step": value * mflop_per_frame * 1e6 / 1e12 / (peak * world),
                           "final_loss": final_loss}}
+        if exposure is not None:
+            out["config"]["gradient_allreduce"] = dict(exposure, bytes=4 * red.flat.total_all,
+                                                       note="147 MB fp32 gradients + stats slot; the encoder/decoder slice is in "
+                                                            "flight during the conv backward graph")
         if prof is not None:
-            tot_ms, n, prof_steps = prof
-            fl, per_step = conv_igemm_flops(a.batch)
-            if n > 0 and tot_ms > 0:
-                ach = fl * prof_steps / (tot_ms * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_igemm_kernel (3 fwd + 3 dgrad launches per step)",
-                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                                   "traffic": measured_traffic(a),
-                                   "launches": n, "avg_launch_ms": tot_ms / n,
-                                   "algorithmic_flop_per_launch_avg": fl / per_step}
+            fl = family_flops(a.batch)
+            fams = {}
+            for k, (tot_ms, n) in prof.items():
+                if n > 0 and tot_ms > 0:
+                    ach = fl[k][0] * prof_steps / (tot_ms * 1e-3) / 1e12
+                    fams[k] = {"achieved": ach, "frac": ach / peak, "ms_per_step": tot_ms / prof_steps, "launches_per_step": n / prof_steps,
+                               "algorithmic_gflop_per_step": fl[k][0] / 1e9}
+            key = "conv3x3_igemm (3 fwd + 3 dgrad)"
+            if key in fams:
+                f = fams[key]
+                tr = measured_traffic(a)
+                n_launch = prof[key][1]
+                out["roofline"] = {"bound": "mfma", "kernel": "asr_conv3x3_igemm: conv3x3_c64_kernel / conv3x3_igemm_kernel, 3 forward "
+                                   "+ 3 data-gradient launches per step (45 % of the step's algorithmic FLOPs)",
+                                   "achieved": f["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": f["frac"],
+                                   "traffic": tr[0] if tr else None,
+                                   "traffic_source": ("constant read from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                                      "command, committed; NOT measured by this run)" % tr[1]) if tr else None,
+                                   "timing": "HIP events around every launch on its own stream during %d EAGER steps right after the "
+                                             "timed (graph-replayed) region" % prof_steps,
+                                   "launches": n_launch, "avg_launch_ms": prof[key][0] / n_launch,
+                                   "algorithmic_flop_per_launch_avg": fl[key][0] / fl[key][1],
+                                   "families": fams,
+                                   "largest_family_by_time": max(fams, key=lambda k: fams[k]["ms_per_step"])}
         if sd_cpu is not None:
             try:
-                out["cpu_baseline"] = cpu_baseline(sd_cpu, " ".join(MODEL_FLAGS))
+                out["cpu_baseline"] = cpu_baseline(sd_cpu, " ".join(MODEL_FLAGS), a.batch)
             except Exception as e:           # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -1,11 +1,21 @@
 """Data-parallel gradient reduction for one-process-per-GPU training: replaces the reference's single-process
 nn.DataParallel (reference: utils/functions.py:154-160; scatter / replicate / gather / reduce_add_coalesced every step,
-SURVEY.md 2c) with bucketed all-reduce(SUM) over RCCL, launched from inside backward as soon as a bucket's last
-gradient has been enqueued (asr_hip.params.grad_ready), i.e. overlapped with the rest of backward.
+SURVEY.md 2c) with all-reduce(SUM) over RCCL of slices of the ONE flat fp32 gradient buffer.
 
-The backend is whatever torch.distributed was initialised with: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU
-tests.  Gradients are SUMMED, not averaged: the loss of each rank is local_sum / GLOBAL token count (CEFn), which is
-exactly the reference's loss over the gathered global batch (loss-normalisation note).
+Two launch modes share this class:
+  * eager (trainer, variable shapes): buckets of ~32 MiB are all-reduced from inside backward as soon as the last
+    gradient of a bucket has been enqueued (asr_hip.params.grad_ready), i.e. overlapped with the rest of backward;
+  * graph replay (asr_hip/graph.py, fixed shapes): the collectives stay OUTSIDE the captured hipGraphs -- `hold` is set,
+    mark_ready does nothing and GraphedTrainStep issues `all_reduce_range` between graph segments.
+
+The backend is whatever torch.distributed was initialised with: "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the tests.
+
+Loss normalisation: the reference's loss is the mean over the non-PAD tokens of the GATHERED
+batch.  Every rank back-propagates its un-normalised local SUM; the three CE statistics [loss_sum, token count,
+num_correct] live in a 64-float `stats` slot at the end of the flat gradient buffer, so they are summed over ranks by
+the same all-reduce as the gradients, and the optimiser kernel multiplies every gradient by 1 / global count
+(asr_grad_coef).  No collective of its own, no host synchronisation, exact equivalence with one process on the
+concatenated batch.
 """
 import os
 
@@ -18,40 +28,55 @@ class GradReducer:
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        # ASR_FORCE_DDP=1: issue the collectives even with a single rank (exercises the RCCL + hipGraph path on one GPU)
+        # ASR_FORCE_DDP=1: issue the collectives even with a single rank (exercises the whole path on one GPU)
         self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("ASR_FORCE_DDP") == "1")
-        # buckets are contiguous slices of the flat gradient buffer, filled from the END of the buffer backwards
-        # because backward produces gradients roughly in reverse registration order (decoder first, conv stack last)
+        self.hold = False          # graph-replay mode: GraphedTrainStep owns the collectives
+        # Buckets are contiguous slices of the flat gradient buffer.  Backward produces gradients roughly in reverse
+        # registration order, so slices are grown from the END of the buffer; the 4-D convolution weights (and their
+        # biases) form buckets of their own because their gradients arrive LAST (the conv stack is the first layer) even
+        # though nn.Module registers them after the encoder / decoder.  The last bucket carries the stats slot.
         n = len(flat.params)
+        is_conv = [False] * n
+        for i, p in enumerate(flat.params):      # conv weights and the 1-D parameters that follow them (biases, BatchNorm affine)
+            is_conv[i] = p.dim() == 4 or (p.dim() == 1 and i > 0 and is_conv[i - 1])
         self.bucket_of = [0] * n
         self.buckets = []          # dicts: lo, hi, members(set of param indices)
         cap = max(1, int(bucket_bytes) // 4)
-        hi = flat.total
+        hi = flat.total_all
         members = set()
-        size = 0
         for i in range(n - 1, -1, -1):
             lo = flat.offsets[i]
             members.add(i)
-            size = hi - lo
-            if size >= cap or i == 0:
+            boundary = i == 0 or is_conv[i - 1] != is_conv[i]
+            if hi - lo >= cap or boundary:
                 self.buckets.append({"lo": lo, "hi": hi, "members": members})
                 hi = lo
                 members = set()
         for b, bk in enumerate(self.buckets):
             for i in bk["members"]:
                 self.bucket_of[i] = b
+        self.done = False
         self._reset()
 
     def _reset(self):
         self.pending = [set(b["members"]) for b in self.buckets]
         self.launched = [False] * len(self.buckets)
         self.works = []
+        self.done = False
+
+    def begin_step(self):
+        """Called by zero_grad(): a new backward is about to fill the gradient buffer."""
+        self._reset()
 
     def broadcast_parameters(self, src=0):
         if self.active:
             dist.broadcast(self.flat.data, src, group=self.group)
 
     def mark_ready(self, p):
+        if self.hold:
+            return
+        if self.done:              # a backward without zero_grad() in between: start a new round
+            self._reset()
         i = self.flat.index.get(id(p))
         if i is None:
             return
@@ -62,24 +87,29 @@ class GradReducer:
 
     def _launch(self, b):
         self.launched[b] = True
-        if self.active:
-            bk = self.buckets[b]
-            self.works.append(dist.all_reduce(self.flat.grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.group,
-                                              async_op=True))
+        bk = self.buckets[b]
+        w = self.all_reduce_range(bk["lo"], bk["hi"])
+        if w is not None:
+            self.works.append(w)
+
+    def all_reduce_range(self, lo, hi, async_op=True):
+        """SUM-all-reduce flat.grad_all[lo:hi] (gradients and, when the range reaches the end, the stats slot)."""
+        if not self.active or hi <= lo:
+            return None
+        return dist.all_reduce(self.flat.grad_all[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def finish(self):
-        """Reduce whatever has not been reduced yet and make the current stream wait for every bucket."""
+        """Reduce whatever has not been reduced yet and make the current stream wait for every bucket.  Idempotent within a
+        step: clip_grad_norm_() and step() both call it, the gradients are reduced once."""
+        if self.done or self.hold:
+            return
         for b in range(len(self.buckets)):
             if not self.launched[b]:
                 self._launch(b)
         for w in self.works:
             w.wait()
-        self._reset()
-
-    def all_reduce_scalar_(self, t):
-        if self.active:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return t
+        self.works = []
+        self.done = True
 
 
 class HipDataParallel(torch.nn.Module):
@@ -97,7 +127,15 @@ class HipDataParallel(torch.nn.Module):
 
 
 def rank_shard(bins, rank, world):
-    """Deterministic disjoint split of the BucketingSampler's bins over ranks; every rank gets the same number of bins
-    (the tail that does not divide evenly is dropped so that collectives never deadlock)."""
-    n = (len(bins) // world) * world
-    return [bins[i] for i in range(rank, n, world)]
+    """Split every BucketingSampler bin over the ranks: rank r takes utterances r, r+world, ... of each bin, so the GLOBAL
+    batch stays --batch-size utterances and an epoch has as many optimiser steps as in the reference, whose nn.DataParallel
+    scatters one batch over the GPUs (reference: utils/functions.py:154-160).  Every rank gets the same number of utterances
+    per bin (the remainder of a bin that does not divide evenly is dropped; bins smaller than the world size are skipped), so
+    collectives never deadlock."""
+    out = []
+    for b in bins:
+        n = (len(b) // world) * world
+        if n == 0:
+            continue
+        out.append([b[i] for i in range(rank, n, world)])
+    return out

@@ -160,6 +160,28 @@ class LinearFn(Function):
         return dx, None, None, None, None
 
 
+# ================================================================================================ encoder output fan-out
+class FanOutFn(Function):
+    """The encoder output feeds the cross-attention of EVERY decoder layer (reference: transformer.py:296-299).  Autograd
+    would sum the per-layer gradients with one elementwise add per layer; here the layers' backward GEMMs accumulate into
+    ONE buffer (`box['buf']`: the first to run allocates it, the others use the GEMM's accumulate epilogue, MHAFn.backward)
+    and this node hands that buffer on."""
+
+    @staticmethod
+    def forward(ctx, x, n, box):
+        ctx.box = box
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g = ctx.box.pop("buf", None)
+        for x in grads:                      # layers that did not use the shared buffer (un-fused K/V projections)
+            if x is not None:
+                g = x if g is None else g + x
+        return g, None, None
+
+
 # ================================================================================================ attention sub-layer
 class MHAFn(Function):
     @staticmethod
@@ -236,7 +258,14 @@ class MHAFn(Function):
             fused.bwd(dqkv.view(B * Tq, 3 * HD), q2, dx_out=d_res, accumulate=True)
         elif fused.ok:
             _linear_bwd(dQ.view(B * Tq, HD), q2, Wq, bq, dx_out=d_res, accumulate=True)
-            d_kv = fused.bwd(dkv.view(B * Tk, 2 * HD), kv2, need_dx=ctx.need_dkv)
+            box = cfg.get("kv_grad_box") if ctx.need_dkv else None
+            if box is not None and box.get("buf") is not None:     # a later decoder layer already produced d(enc_out)
+                fused.bwd(dkv.view(B * Tk, 2 * HD), kv2, dx_out=box["buf"].view(B * Tk, D), accumulate=True)
+            else:
+                d_kv = fused.bwd(dkv.view(B * Tk, 2 * HD), kv2, need_dx=ctx.need_dkv)
+                if box is not None:
+                    box["buf"] = d_kv.view(B, Tk, D)
+                    d_kv = None
         else:
             dQ2, dK2, dV2 = dQ.view(B * Tq, HD), dK.view(B * Tk, HD), dV.view(B * Tk, HD)
             _linear_bwd(dQ2, q2, Wq, bq, dx_out=d_res, accumulate=True)
@@ -412,6 +441,9 @@ def _bn_stats(bn, y, M, C, training):
     return mean.contiguous(), torch.rsqrt(var + bn.eps).contiguous()
 
 
+_emb_generation = [0]
+
+
 class EmbCNNFn(Function):
     """Conv2d(1,32,(41,11),(2,2),(0,10)) -> BN -> Hardtanh(0,20) -> Conv2d(32,32,(21,11),(2,1)) -> BN -> Hardtanh(0,20)
     -> (B, T', 32*F')   (reference: transformer.py:33-40, :70-76)."""
@@ -433,12 +465,18 @@ class EmbCNNFn(Function):
         out = torch.empty((B, gB[11], C2 * gB[10]), device=src.device, dtype=cd)
         ops.bn_act_fwd(yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, out, tH=gB[10], tW=gB[11])
         ctx.t = (colA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB)
+        # colA / yA / colB / yB are SHARED grow-only workspaces (ops.workspace): a later forward overwrites them
+        _emb_generation[0] += 1
+        ctx.generation = _emb_generation[0]
         ctx.geo = (gA, gB, MA, KA, MB, KB)
         ctx.params = (w0, b0, g1, be1, w3, b3, g4, be4)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.generation != _emb_generation[0]:
+            raise RuntimeError("emb_cnn backward after a later emb_cnn forward: the im2col workspaces of this forward were "
+                               "overwritten (run backward before the next forward)")
         colA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB = ctx.t
         gA, gB, MA, KA, MB, KB = ctx.geo
         w0, b0, g1, be1, w3, b3, g4, be4 = ctx.params
@@ -471,9 +509,14 @@ class EmbCNNFn(Function):
 
 # ================================================================================================ loss
 class CEFn(Function):
-    """loss = sum over non-PAD rows of the (label smoothed) row loss / count.  `count` is this rank's non-PAD count
-    unless `global_count` (a device scalar, e.g. all-reduced over data-parallel ranks) is given (SURVEY.md section 5:
-    exact DP -> DDP equivalence needs local_sum / global_count with SUMMED gradients)."""
+    """loss = sum over non-PAD rows of the (label smoothed) row loss / count        (reference: utils/metrics.py:102-132).
+
+    Single process: `count` is the batch's non-PAD count (or `global_count`, a device scalar, when given).
+    Data parallel (a GradReducer is active and gradients are enabled): the reference's loss is the mean over the GATHERED
+    batch, so the three statistics [loss_sum, count, num_correct] are written into FlatParams.stats -- the tail of the flat
+    gradient buffer, summed over ranks by the gradient all-reduce itself -- and backward propagates the UN-normalised local
+    sum; FusedAdam multiplies the reduced gradients by 1 / global count (asr_grad_coef).  The value returned here is the
+    LOCAL mean (a per-rank progress figure); the exact global loss is FusedAdam.global_loss() after the step."""
 
     @staticmethod
     def forward(ctx, pred, gold, smoothing, pad_id, global_count):
@@ -483,19 +526,25 @@ class CEFn(Function):
             logits = logits.float()
         logits = logits.contiguous()
         g = gold.reshape(-1).contiguous()
-        lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id)
         red = P._state["reducer"]
-        if global_count is None and red is not None and red.active:
-            global_count = red.all_reduce_scalar_(sums[1:2].clone())      # one scalar all-reduce per step
-        count = global_count if global_count is not None else sums[1:2]
+        deferred = (global_count is None and red is not None and red.active and torch.is_grad_enabled()
+                    and red.flat.stats.device == logits.device)
+        lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id, sums=red.flat.stats if deferred else None)
+        if deferred:
+            count = None                                               # backward: un-normalised sum
+            sums = sums[:3]
+        else:
+            count = global_count if global_count is not None else sums[1:2]
         ctx.t = (logits, g, lse, count)
         ctx.smoothing, ctx.pad_id, ctx.shape = smoothing, pad_id, pred.shape
+        loss = ops.ratio(sums[0:1], global_count if global_count is not None else sums[1:2]).reshape(())
         ctx.mark_non_differentiable(sums, am)
-        loss = sums[0] / count.reshape(())
         return loss, sums, am
 
     @staticmethod
     def backward(ctx, dloss, *unused):
         logits, g, lse, count = ctx.t
+        if count is None:
+            count = ops.ones_scalar(logits.device)
         dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, dloss.reshape(1).float().contiguous(), count)
         return dl.view(ctx.shape), None, None, None, None

@@ -1,10 +1,23 @@
 """Whole-step hipGraph: step_advance, zero_grad, forward, label-smoothed CE, backward, (clip), Noam/Adam captured ONCE and
-replayed per batch.  A training step of the 4-layer model is ~450 small launches; eagerly they cost ~13 ms of host time
-per step on top of ~30 ms of GPU time, replayed they cost none (MI355X guide: "capture launch-bound inner loops in
-hipGraphs").  Everything that changes between steps lives in device memory: the batch (static buffers), the dropout
-seed counter and the optimiser step (ops.step_state()).
+replayed per batch.  A training step of the 4-layer model is ~400 small launches; eagerly they cost more host time than
+GPU time, replayed they cost none (MI355X guide: "capture launch-bound inner loops in hipGraphs").  Everything that
+changes between steps lives in device memory: the batch (static buffers), the dropout seed counter and the optimiser
+step (ops.step_state()).
 
-Shapes are static per graph: one GraphedTrainStep per (B, T_src, L_tgt) bucket.
+Single GPU: ONE graph.
+
+Data parallel (a GradReducer is attached to the optimiser): THREE graphs with the RCCL collectives BETWEEN them -- a
+collective inside a capture ties the graph to the communicator's internal streams and could not be validated on a
+one-GPU box, while graph -> all-reduce -> graph is ordinary stream ordering:
+
+    graph A   step_advance, zero_grad, conv front end forward, encoder, decoder, CE, backward down to the conv output
+      -> all-reduce (async, RCCL's stream) of the encoder + decoder slice of the flat gradient buffer (99 % of the bytes)
+    graph B   conv front end backward                      (runs WHILE the all-reduce above is in flight)
+      -> all-reduce of the conv slice + the stats slot [loss sum, token count, num_correct]; wait for both
+    graph C   (clip) + Noam/Adam with 1 / global token count folded into the gradient scale
+
+The three graphs share one memory pool (activations saved by A are read by B) and are always replayed in this order.
+Shapes are static per instance: one GraphedTrainStep per (B, T_src, L_tgt) bucket.
 """
 import torch
 
@@ -17,6 +30,7 @@ class GraphedTrainStep:
         from utils.metrics import calculate_metrics
         self._metrics = calculate_metrics
         self.model, self.opt, self.smoothing, self.clip = model, opt, float(smoothing), clip_max_norm
+        self.core = model.module if hasattr(model, "module") else model
         dev = src.device
         self.src = src.clone()
         self.tgt = tgt.clone()
@@ -24,44 +38,131 @@ class GraphedTrainStep:
         self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
         adam = opt.optimizer
         adam._ensure_flat()
+        self.red = adam.reducer if (adam.reducer is not None and adam.reducer.active) else None
         # the device-side step counter continues from the optimiser's host-side count
         st = ops.step_state(dev)
         st[1] = int(opt._step)
         self.factor_ms = float(opt.factor) * float(opt.model_size) ** -0.5
+        if self.red is not None:
+            self._split = self._conv_split(adam.flat)
+            self.red.hold = True                      # the collectives are issued here, between the graphs
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup_steps)):       # eager warm-up: allocates workspaces, shadows, big-LDS attributes
-                self._body()
+            for _ in range(max(1, warmup_steps)):       # eager warm-up: allocates workspaces, shadows, big-LDS attributes,
+                self._eager_step()                      # and (data parallel) creates / warms the communicator
                 self._host_after()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-            self.loss, self.sums = self._body()
+        if self.red is None:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss, self.sums = self._body_single()
+            self.graphs = [self.graph]
+        else:
+            self.graph_a, self.graph_b, self.graph_c = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
+                self.loss, self.sums, feats, dfeats = self._body_a()
+            pool = self.graph_a.pool()
+            with torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode="thread_local"):
+                self._body_b(feats, dfeats)
+            with torch.cuda.graph(self.graph_c, pool=pool, capture_error_mode="thread_local"):
+                self._body_c()
+            del feats, dfeats
+            self.graphs = [self.graph_a, self.graph_b, self.graph_c]
         self._host_after()                               # capture does not execute; replay below does
-        self.graph.replay()
+        self._replay()
 
-    def _body(self):
+    # ------------------------------------------------------------------------------------------------ single GPU
+    def _body_single(self):
         ops.step_advance()
         self.opt.zero_grad()
         pred, gold, _, _ = self.model(self.src, self.src_len, self.tgt)
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
         loss.backward()
+        self._body_c()
+        return loss.detach(), sums
+
+    # ------------------------------------------------------------------------------------------------ data parallel
+    @staticmethod
+    def _conv_split(flat):
+        """Offset separating the conv front end's parameters from the rest of the flat buffer.  nn.Module registers
+        `conv` after encoder / decoder (models/asr/transformer.py), so the conv slice is the tail, next to the stats slot."""
+        conv = [i for i, p in enumerate(flat.params) if p.dim() == 4]
+        if not conv:
+            return flat.total                          # no CNN: everything is "transformer", the tail is the stats slot
+        first = min(conv)
+        tail = all(p.dim() in (1, 4) for p in flat.params[first:])
+        if not tail:
+            raise RuntimeError("the conv parameters are expected at the end of the flat parameter buffer")
+        return flat.offsets[first]
+
+    def _body_a(self):
+        ops.step_advance()
+        self.opt.zero_grad()
+        core = self.core
+        feats = core._features(self.src)
+        leaf = feats.detach().requires_grad_(feats.requires_grad)
+        enc_out, _ = core.encoder(leaf, self.src_len)
+        pred, gold, *_ = core.decoder(self.tgt, enc_out, self.src_len)
+        loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
+        loss.backward()
+        return loss.detach(), sums, feats, leaf.grad
+
+    def _body_b(self, feats, dfeats):
+        if feats.requires_grad:
+            feats.backward(dfeats)
+
+    def _body_c(self):
         adam = self.opt.optimizer
         if self.clip is not None:
             adam.clip_grad_norm_(self.clip)
         adam.step_device(self.factor_ms, float(self.opt.warmup), float(self.opt.min_lr), self.lr_dev)
-        return loss.detach(), sums
+
+    def _exchange_a(self):
+        return self.red.all_reduce_range(0, self._split)
+
+    def _exchange_b(self, wa):
+        wb = self.red.all_reduce_range(self._split, self.red.flat.total_all)
+        for w in (wa, wb):
+            if w is not None:
+                w.wait()
+
+    def _eager_step(self):
+        if self.red is None:
+            return self._body_single()
+        loss, sums, feats, dfeats = self._body_a()
+        wa = self._exchange_a()
+        self._body_b(feats, dfeats)
+        self._exchange_b(wa)
+        self._body_c()
+        return loss, sums
+
+    def _replay(self):
+        if self.red is None:
+            self.graph.replay()
+            return
+        self.graph_a.replay()
+        wa = self._exchange_a()
+        self.graph_b.replay()
+        self._exchange_b(wa)
+        self.graph_c.replay()
 
     def _host_after(self):
         self.opt._step += 1
         self.opt._rate = self.opt.rate()
         self.opt.optimizer.after_replay(1)
 
+    def global_loss(self):
+        """Data parallel: loss over the gathered batch (host float; one D2H copy).  Single GPU: the step's loss."""
+        if self.red is None:
+            return float(self.loss.item())
+        return self.opt.optimizer.global_loss()
+
     def __call__(self, src=None, src_len=None, tgt=None):
         """Copy the batch into the static buffers (skip arguments that are already there) and replay.
-        Returns (loss, sums) device tensors: sums = [loss_sum, non-PAD count, num_correct]."""
+        Returns (loss, sums) device tensors: sums = [loss_sum, non-PAD count, num_correct] (data parallel: `loss` is this
+        rank's local mean and `sums` holds the GLOBAL sums once the step has run)."""
         if src is not None and src.data_ptr() != self.src.data_ptr():
             self.src.copy_(src, non_blocking=True)
         if tgt is not None and tgt.data_ptr() != self.tgt.data_ptr():
@@ -70,6 +171,6 @@ class GraphedTrainStep:
             sl = torch.as_tensor(src_len)
             if not (sl.is_cuda and sl.data_ptr() == self.src_len.data_ptr()):
                 self.src_len.copy_(sl.to(torch.int32), non_blocking=True)
-        self.graph.replay()
+        self._replay()
         self._host_after()
         return self.loss, self.sums

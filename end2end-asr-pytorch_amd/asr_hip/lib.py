@@ -55,6 +55,9 @@ _SIGS = {
     "asr_adam_noam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P]),
     "asr_sumsq_acc": (_I, [_P, _L, _P, _P]),
     "asr_clip_coef": (_I, [_P, _F, _P, _P]),
+    "asr_grad_coef": (_I, [_P, _F, _P, _P, _P]),
+    "asr_length_mask": (_I, [_P, _I, _I, _P, _P]),
+    "asr_ratio": (_I, [_P, _P, _P, _P]),
     "asr_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_conv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),

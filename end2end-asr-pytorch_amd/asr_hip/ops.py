@@ -328,13 +328,16 @@ def embed_bwd(tok, dout, dtable, scale, p, seed, pad_id):
 
 
 # ------------------------------------------------------------------------------------------------ loss
-def ce_fwd(logits, gold, smoothing, pad_id):
-    """logits (M,V) fp32 -> (row_lse (M), argmax (M) int64, sums (3) fp32 = [loss_sum, count, num_correct])."""
+def ce_fwd(logits, gold, smoothing, pad_id, sums=None):
+    """logits (M,V) fp32 -> (row_lse (M), argmax (M) int64, sums (3) fp32 = [loss_sum, count, num_correct]).
+    sums: optional ZEROED fp32 destination (>= 3 elements) the kernel adds into, e.g. FlatParams.stats."""
     M, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1 and gold.is_contiguous()
     lse = torch.empty(M, device=logits.device, dtype=torch.float32)
     am = torch.empty(M, device=logits.device, dtype=torch.int64)
-    sums = torch.zeros(3, device=logits.device, dtype=torch.float32)
+    if sums is None:
+        sums = torch.zeros(3, device=logits.device, dtype=torch.float32)
+    assert sums.dtype == torch.float32 and sums.numel() >= 3 and sums.is_contiguous()
     L.call("asr_ce_fwd", L.ptr(logits), logits.stride(0), L.ptr(gold), M, V, float(smoothing), int(pad_id), L.ptr(lse),
            L.ptr(am), L.ptr(sums), L.stream())
     return lse, am, sums
@@ -379,6 +382,37 @@ def sumsq_acc(g, acc):
 
 def clip_coef(sumsq, max_norm, coef):
     L.call("asr_clip_coef", L.ptr(sumsq), float(max_norm), L.ptr(coef), L.stream())
+
+
+def length_mask(lengths, T):
+    """lengths (B) int32 on the device -> row_keep (B*T) uint8, 1 where t < length."""
+    B = lengths.shape[0]
+    out = torch.empty(B * T, device=lengths.device, dtype=torch.uint8)
+    L.call("asr_length_mask", L.ptr(lengths), B, int(T), L.ptr(out), L.stream())
+    return out
+
+
+def ratio(num, den):
+    """(1,) fp32 num / den on the device."""
+    out = torch.empty(1, device=num.device, dtype=torch.float32)
+    L.call("asr_ratio", L.ptr(num), L.ptr(den), L.ptr(out), L.stream())
+    return out
+
+
+_ones = {}
+
+
+def ones_scalar(device):
+    t = _ones.get(str(device))
+    if t is None:
+        t = torch.ones(1, device=device, dtype=torch.float32)
+        _ones[str(device)] = t
+    return t
+
+
+def grad_coef(sumsq, max_norm, denom, coef):
+    """coef = (1/denom) * clip coefficient of the (1/denom)-scaled gradients; sumsq None = no clipping."""
+    L.call("asr_grad_coef", L.ptr(sumsq), float(max_norm), L.ptr(denom), L.ptr(coef), L.stream())
 
 
 # ------------------------------------------------------------------------------------------------ conv front end
@@ -462,13 +496,22 @@ _ws = {}
 
 
 def workspace(tag, shape, dtype, device):
-    """Persistent zero-initialised buffer: kernels rewrite the live region only, padding rows/columns stay zero."""
-    key = (tag, tuple(shape), dtype, str(device))
-    buf = _ws.get(key)
-    if buf is None:
-        buf = torch.zeros(tuple(shape), device=device, dtype=dtype)
-        _ws[key] = buf
-    return buf
+    """Persistent zero-initialised buffer: kernels rewrite the live region only, padding rows/columns stay zero.
+    ONE grow-only allocation per tag (variable-length batches do not leak a buffer per shape): a request that fits is a view
+    of it, re-zeroed only when the shape differs from the previous request (the padding moves)."""
+    key = (tag, dtype, str(device))
+    shape = tuple(int(x) for x in shape)
+    n = 1
+    for x in shape:
+        n *= x
+    ent = _ws.get(key)
+    if ent is None or ent[0].numel() < n:
+        ent = [torch.zeros(n, device=device, dtype=dtype), shape]
+        _ws[key] = ent
+    elif ent[1] != shape:
+        ent[0][:n].zero_()
+        ent[1] = shape
+    return ent[0][:n].view(shape)
 
 
 def conv_geom(B, H, W, C, KH, KW, SH, SW, PH, PW):

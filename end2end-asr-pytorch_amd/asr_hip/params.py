@@ -128,6 +128,7 @@ class FlatParams:
     `p.data` / `p.grad` become views; names, shapes and values are unchanged."""
 
     ALIGN = 64
+    STATS = 64
 
     def __init__(self, module_or_params, order=None):
         params = []
@@ -151,7 +152,12 @@ class FlatParams:
         self.total = off
         self.params = params
         self.data = torch.zeros(off, device=dev, dtype=torch.float32)
-        self.grad = torch.zeros(off, device=dev, dtype=torch.float32)
+        # gradient buffer + a 64-float statistics slot behind it: [CE loss sum, non-PAD token count, num_correct, ...].
+        # Under data parallelism the slot is summed over ranks by the same all-reduce as the gradients (asr_hip/ddp.py).
+        self.total_all = off + self.STATS
+        self.grad_all = torch.zeros(self.total_all, device=dev, dtype=torch.float32)
+        self.grad = self.grad_all[:off]
+        self.stats = self.grad_all[off:]
         for p, o in zip(params, self.offsets):
             n = p.numel()
             self.data[o:o + n].copy_(p.data.reshape(-1))
@@ -191,4 +197,4 @@ class FlatParams:
         return ent[0][off:off + p.numel()]
 
     def zero_grad(self):
-        self.grad.zero_()
+        self.grad_all.zero_()

@@ -128,6 +128,14 @@ __global__ __launch_bounds__(64) void preprocess_kernel(const int64_t* __restric
   }
 }
 
+// row_keep[b, t] = t < len[b]   (get_non_pad_mask with input_lengths, common_layers.py:33-38)
+__global__ __launch_bounds__(256) void length_mask_kernel(const int32_t* __restrict__ len, int T, uint8_t* __restrict__ out) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t < T) out[(int64_t)b * T + t] = t < len[b] ? 1 : 0;
+}
+__global__ void ratio_kernel(const float* num, const float* den, float* out) { *out = *num / *den; }
+
 // ------------------------------------------------------------------------------------------------ Adam
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, int64_t n4, int64_t n, float lr, float b1,
@@ -228,10 +236,16 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(acc, red[0] + red[1] + red[2] + red[3]);
 }
-__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef) {
-  const float nrm = sqrtf(*sumsq);
-  const float c = max_norm / (nrm + 1e-6f);     // torch.nn.utils.clip_grad_norm_
-  *coef = c < 1.f ? c : 1.f;
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, const float* denom, float* coef) {
+  // gradients in the buffer are `denom` times the true ones (un-normalised loss sum, see asr_grad_coef)
+  const float s = denom ? 1.f / fmaxf(*denom, 1.f) : 1.f;
+  float c = 1.f;
+  if (sumsq) {
+    const float nrm = sqrtf(*sumsq) * s;
+    c = max_norm / (nrm + 1e-6f);               // torch.nn.utils.clip_grad_norm_
+    c = c < 1.f ? c : 1.f;
+  }
+  *coef = s * c;
 }
 
 }  // namespace
@@ -317,6 +331,20 @@ extern "C" int asr_decoder_preprocess(const int64_t* tgt, int B, int L, int Td, 
   return ASR_OK;
 }
 
+extern "C" int asr_length_mask(const int32_t* lengths, int B, int T, uint8_t* row_keep, hipStream_t s) {
+  ASR_CHECK_ARG(lengths && row_keep && B >= 0 && T >= 0);
+  if (B == 0 || T == 0) return ASR_OK;
+  hipLaunchKernelGGL(length_mask_kernel, dim3((T + 255) / 256, B), dim3(256), 0, s, lengths, T, row_keep);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+extern "C" int asr_ratio(const float* num, const float* den, float* out, hipStream_t s) {
+  ASR_CHECK_ARG(num && den && out);
+  hipLaunchKernelGGL(ratio_kernel, dim3(1), dim3(1), 0, s, num, den, out);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 extern "C" int asr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                              float eps, float bc1, float bc2, const float* gscale, hipStream_t s) {
   ASR_CHECK_ARG(p && g && m && v && n >= 0 && bc1 > 0.f && bc2 > 0.f);
@@ -343,7 +371,13 @@ extern "C" int asr_sumsq_acc(const float* g, int64_t n, float* acc, hipStream_t 
 }
 extern "C" int asr_clip_coef(const float* sumsq, float max_norm, float* coef, hipStream_t s) {
   ASR_CHECK_ARG(sumsq && coef);
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, coef);
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, (const float*)nullptr, coef);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+extern "C" int asr_grad_coef(const float* sumsq, float max_norm, const float* denom, float* coef, hipStream_t s) {
+  ASR_CHECK_ARG(coef && (sumsq || denom));
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq, max_norm, denom, coef);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

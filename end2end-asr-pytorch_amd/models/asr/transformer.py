@@ -114,7 +114,7 @@ class Encoder(nn.Module):
         dev = padded_input.device
         lens = _lengths_to_device(input_lengths, dev)
         # row_keep[b,t] = t < len[b]   (reference: common_layers.py:33-38 via transformer.py:168)
-        row_keep = (torch.arange(T, device=dev, dtype=torch.int32)[None, :] < lens[:, None]).to(torch.uint8).reshape(-1)
+        row_keep = ops.length_mask(lens, T)
         x = F_.EncInFn.apply(padded_input, self.input_linear.weight, self.input_linear.bias, self.layer_norm_input.weight,
                              self.layer_norm_input.bias, self.positional_encoding.pe[0])
         attns = []
@@ -190,9 +190,15 @@ class Decoder(nn.Module):
         x = F_.EmbedFn.apply(seq_in, self.trg_embedding.weight, self.positional_encoding.pe[0], self.x_logit_scale, p,
                              constant.PAD_TOKEN, True)
         self_attns, enc_attns = [], []
-        for layer in self.layers:
-            x, sa, ea = layer(x, encoder_padded_outputs, row_keep=row_keep, self_key_pad=key_pad, enc_key_len=enc_len,
-                              need_attn=need_attn)
+        # one gradient buffer for the encoder output: the layers' cross-attention backward GEMMs accumulate into it
+        box = None
+        enc_views = [encoder_padded_outputs] * len(self.layers)
+        if torch.is_grad_enabled() and encoder_padded_outputs.requires_grad and len(self.layers) > 1:
+            box = {}
+            enc_views = F_.FanOutFn.apply(encoder_padded_outputs, len(self.layers), box)
+        for li, layer in enumerate(self.layers):
+            x, sa, ea = layer(x, enc_views[li], row_keep=row_keep, self_key_pad=key_pad, enc_key_len=enc_len,
+                              need_attn=need_attn, kv_grad_box=box)
             self_attns.append(sa)
             enc_attns.append(ea)
         # with --emb_trg_sharing the embedding backward (which runs last) reports the shared weight as ready
@@ -318,7 +324,7 @@ class DecoderLayer(nn.Module):
         self.pos_ffn = PositionwiseFeedForwardWithConv(dim_model, dim_inner, dropout=dropout)
 
     def forward(self, decoder_input, encoder_output, non_pad_mask=None, self_attn_mask=None, dec_enc_attn_mask=None,
-                row_keep=None, self_key_pad=None, enc_key_len=None, causal_only=False, need_attn=False):
+                row_keep=None, self_key_pad=None, enc_key_len=None, causal_only=False, need_attn=False, kv_grad_box=None):
         if causal_only:
             x, sa = self.self_attn(decoder_input, decoder_input, decoder_input, causal=True, need_attn=need_attn)
             x, ea = self.encoder_attn(x, encoder_output, encoder_output, need_attn=need_attn)
@@ -329,6 +335,6 @@ class DecoderLayer(nn.Module):
         x, sa = self.self_attn(decoder_input, decoder_input, decoder_input, mask=self_attn_mask if generic else None,
                                key_pad=self_key_pad, causal=not generic, row_keep=row_keep, need_attn=need_attn)
         x, ea = self.encoder_attn(x, encoder_output, encoder_output, mask=dec_enc_attn_mask, key_len=enc_key_len,
-                                  row_keep=row_keep, need_attn=need_attn)
+                                  row_keep=row_keep, need_attn=need_attn, kv_grad_box=kv_grad_box)
         x = self.pos_ffn(x, row_keep=row_keep)
         return x, sa, ea

@@ -107,12 +107,12 @@ class MultiHeadAttention(nn.Module):
         self.query_linear.weight._asr_qkv = True      # hint for the flat-parameter layout: q/k/v weights adjacent
 
     def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
-                need_attn=True):
+                need_attn=True, kv_grad_box=None):
         if key is not value:
             raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
         cfg = dict(H=self.num_heads, dk=self.dim_key, p=self.dropout.p if self.training else 0.0, key_len=key_len,
                    key_pad=key_pad if key_pad is not None else _mask_to_u8(mask), causal=causal, row_keep=row_keep,
-                   want_attn=need_attn)
+                   want_attn=need_attn, kv_grad_box=kv_grad_box)
         q = _to_compute(query)
         kv = None if key is query else _to_compute(key)
         res = F_.MHAFn.apply(q, kv, self.query_linear.weight, self.query_linear.bias, self.key_linear.weight,

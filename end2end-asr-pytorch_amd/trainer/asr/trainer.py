@@ -1,9 +1,12 @@
 """Training / validation loop with the reference's Trainer().train(...) signature (reference: trainer/asr/trainer.py).
 
 Differences that keep the semantics: token ids reach the host in ONE copy per step (the reference calls int() on every
-element of two (B,T) device tensors, trainer.py:62-75); the loss value is read once; under data parallelism the loss is
-local_sum / global token count with summed gradients (= the reference's loss over the gathered batch) and the decision
-to skip a batch with an infinite loss is taken collectively so that ranks never diverge.
+element of two (B,T) device tensors, trainer.py:62-75); the loss value is read once; under data parallelism every rank
+back-propagates its local loss SUM, the gradients and the [loss sum, token count] statistics are summed by one all-reduce and
+the optimiser divides by the global token count (= the reference's loss over the gathered batch, for the update AND for the
+logged train loss); validation runs un-sharded on every rank with the local normalisation, so `valid_loss` and the best-model
+choice are identical on every rank and to a single-GPU run; the decision to skip a batch with an infinite loss is taken
+collectively so that ranks never diverge.
 """
 import logging
 import sys
@@ -56,11 +59,17 @@ class Trainer():
         if finite.item() == 0:
             logging.info("Found infinity loss, masking")
             return None
+        loss_value = None
         if opt is not None:
             loss.backward()
             if constant.args.clip:
                 opt.optimizer.clip_grad_norm_(constant.args.max_norm)
             opt.step()
+            red = getattr(opt.optimizer, "reducer", None)
+            if red is not None and red.active:
+                # data parallel: `loss` is this rank's local mean; the reference's number is the mean over the gathered
+                # batch = all-reduced loss sum / all-reduced token count (the stats slot of the gradient buffer)
+                loss_value = opt.optimizer.global_loss()
         ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()   # one D2H copy
         strs_gold, strs_hyps = _strings(ids[0], id2label), _strings(ids[1], id2label)
         cer = wer = chars = words = 0
@@ -70,7 +79,7 @@ class Trainer():
             wer += calculate_wer(h, g)
             chars += len(g.replace(' ', ''))
             words += len(g.split(" "))
-        return loss.item(), cer, wer, chars, words
+        return (loss.item() if loss_value is None else loss_value), cer, wer, chars, words
 
     def train(self, model, train_loader, train_sampler, valid_loader_list, opt, loss_type, start_epoch, num_epochs, label2id,
               id2label, last_metrics=None):

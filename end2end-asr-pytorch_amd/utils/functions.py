@@ -43,6 +43,16 @@ def load_model(load_path):
     """-> (model, opt, epoch, metrics, args, label2id, id2label)   (reference: functions.py:62-98)"""
     ckpt = torch.load(load_path, map_location="cpu", weights_only=False)
     args = ckpt.get('args', constant.args)
+    cur = constant.args
+    if args is not cur:
+        # What describes THIS run, not the run that wrote the file, comes from the current command line: how the job is
+        # laid out over GPUs (the reference re-wraps according to the current --parallel, train.py:92-99; a checkpoint saved
+        # without it must not silently train un-synchronised replicas), where it runs, and the MI355X-path switches a
+        # reference-written checkpoint does not carry at all.
+        for k in ("parallel", "device_ids", "precision", "dist_backend", "bucket_mb", "gpu_frontend"):
+            if hasattr(cur, k):
+                setattr(args, k, getattr(cur, k))
+        args.cuda = bool(getattr(args, "cuda", False) or getattr(cur, "cuda", False))
     label2id, id2label = ckpt['label2id'], ckpt['id2label']
     model = init_transformer_model(args, label2id, id2label)
     sd = ckpt['model_state_dict']
@@ -56,6 +66,8 @@ def load_model(load_path):
     if getattr(args, "cuda", False):
         model = model.cuda()
     opt = init_optimizer(args, model)
+    if getattr(args, "parallel", False) and dist.is_initialized() and dist.get_world_size() > 1:
+        assert opt.optimizer.reducer is not None, "--parallel with world_size > 1 needs the gradient reducer"
     if opt is not None:
         opt.optimizer.load_state_dict(ckpt['optimizer_state_dict'])
         op = ckpt['optimizer_params']

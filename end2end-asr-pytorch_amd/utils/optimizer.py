@@ -78,6 +78,8 @@ class FusedAdam(torch.optim.Adam):
     def zero_grad(self, set_to_none=False):
         """Gradients are accumulation targets of the kernels: zero them, never drop them."""
         self._ensure_flat()
+        if self.reducer is not None:
+            self.reducer.begin_step()
         if self.flat is not None:
             self.flat.zero_grad()
             return
@@ -101,14 +103,36 @@ class FusedAdam(torch.optim.Adam):
                     if p.grad is not None:
                         ops.sumsq_acc(p.grad.reshape(-1), acc)
         self.grad_scale = torch.empty(1, device=dev, dtype=torch.float32)
-        ops.clip_coef(acc, max_norm, self.grad_scale)
+        # data parallel: the buffer holds gradients of the un-normalised loss SUM; 1 / global token count is folded in here
+        ops.grad_coef(acc, max_norm, self._denominator(), self.grad_scale)
         return acc
+
+    def _denominator(self):
+        """Device scalar the gradients still have to be divided by (the all-reduced non-PAD token count under data
+        parallelism, asr_hip/ddp.py), or None."""
+        if self.reducer is not None and self.reducer.active and self.flat is not None:
+            return self.flat.stats[1:2]
+        return None
+
+    def _pre_step(self):
+        """Finish the gradient exchange; make sure grad_scale carries 1 / global count when it is owed."""
+        if self.reducer is not None:
+            self.reducer.finish()
+        den = self._denominator()
+        if den is not None and self.grad_scale is None:
+            self.grad_scale = torch.empty(1, device=den.device, dtype=torch.float32)
+            ops.grad_coef(None, 0.0, den, self.grad_scale)
+
+    def global_loss(self):
+        """Data parallel: the reference's loss over the gathered batch = all-reduced loss sum / all-reduced token count
+        (valid after clip_grad_norm_() / step() of the current step, i.e. once the stats slot has been reduced).  Host float."""
+        st = self.flat.stats[:2].tolist()
+        return st[0] / max(st[1], 1.0)
 
     @torch.no_grad()
     def step(self, closure=None):
         self._ensure_flat()
-        if self.reducer is not None:
-            self.reducer.finish()
+        self._pre_step()
         self._t += 1
         for group in self.param_groups:
             b1, b2 = group['betas']
@@ -139,8 +163,7 @@ class FusedAdam(torch.optim.Adam):
         self._ensure_flat()
         if self.flat is None:
             raise RuntimeError("step_device needs the parameters on a GPU")
-        if self.reducer is not None:
-            self.reducer.finish()
+        self._pre_step()
         b1, b2 = self.param_groups[0]['betas']
         ops.adam_noam_step(self.flat.data, self.flat.grad, self._m, self._v, b1, b2, self.param_groups[0]['eps'], factor_ms,
                            warmup, min_lr, self.grad_scale, lr_out)

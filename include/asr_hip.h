@@ -161,10 +161,19 @@ int asr_step_advance(uint64_t* state, asr_stream_t stream);
 int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
                        float beta2, float eps, float factor_ms, float warmup, float min_lr,
                        const float* grad_scale_dev, float* lr_out, asr_stream_t stream);
+/* row_keep[b*T + t] = t < lengths[b]: the encoder's non_pad_mask (common_layers.py:33-38 via transformer.py:168)     */
+int asr_length_mask(const int32_t* lengths, int B, int T, uint8_t* row_keep, asr_stream_t stream);
+/* out[0] = num[0] / den[0]: the mean over non-PAD tokens (utils/metrics.py:127-130) from asr_ce_fwd's sums            */
+int asr_ratio(const float* num, const float* den, float* out, asr_stream_t stream);
 /* acc[0] += sum(g^2)  (clip_grad_norm_, trainer.py:108-109)                                                     */
 int asr_sumsq_acc(const float* g, int64_t n, float* acc, asr_stream_t stream);
 /* coef[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6))                                                          */
 int asr_clip_coef(const float* sumsq, float max_norm, float* coef, asr_stream_t stream);
+/* Data-parallel form (replaces nn.DataParallel's gather + one loss over the whole batch, utils/functions.py:154-160 with
+ * utils/metrics.py:127-130): every rank back-propagates its UN-normalised loss sum, `denom[0]` is the all-reduced
+ * non-PAD token count; coef[0] = s * min(1, max_norm / (s * sqrt(sumsq[0]) + 1e-6)) with s = 1 / max(denom[0], 1).
+ * sumsq == NULL: no clipping (coef = s).  denom == NULL: s = 1 (== asr_clip_coef).                                   */
+int asr_grad_coef(const float* sumsq, float max_norm, const float* denom, float* coef, asr_stream_t stream);
 
 /* ---- vgg_cnn front end (transformer.py:42-53, :70-76) -----------------------------------------------------------
  * Activations are NHWC: (B, H=F, W=T, C), C contiguous, in `dtype`.                                             */

@@ -1,0 +1,134 @@
+"""Data-parallel equivalence on the GPU: TWO ranks, each with its share of a
+golden batch, must reproduce the reference's SINGLE-process numbers -- loss over the gathered batch, every gradient,
+the weights after two Noam/Adam steps -- both with the eager bucketed reducer (trainer path) and with the
+three-graphs-per-step replay (bench path).  The ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device); the product code path is the same, only the backend string differs.  Also: clip_grad_norm_() followed by
+step() reduces the gradients once."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys
+root = sys.argv[3]
+for p in (root, os.path.join(root, "end2end-asr-pytorch_amd"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch, torch.distributed as dist
+rank, world, name, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[5], sys.argv[6]
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[4]
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=rank, world_size=world)
+from utils import constant
+from utils.functions import init_optimizer, init_transformer_model
+from utils.metrics import calculate_metrics
+z = np.load(os.path.join(root, "tests", "golden", name + ".npz"))
+flags = str(z["flags"]).split()
+if "--feat_extractor" in flags and (flags.index("--feat_extractor") + 1 >= len(flags) or flags[flags.index("--feat_extractor") + 1].startswith("--")):
+    flags.insert(flags.index("--feat_extractor") + 1, "")
+args = constant.parse(flags + ["--precision", "fp32", "--cuda", "--parallel", "--bucket-mb", "0.05"])
+V = int(z["V"])
+chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(V - 3)]
+l2i = {c: i for i, c in enumerate(chars)}; i2l = {i: c for c, i in l2i.items()}
+model = init_transformer_model(args, l2i, i2l)
+assert type(model).__name__ == "HipDataParallel"
+sd = {"module." + k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w0/")}
+if rank == 1:                                   # a different start on rank 1: the broadcast from rank 0 must equalise
+    sd = {k: (v + 0.01 if v.dtype.is_floating_point and not k.endswith(".pe") else v) for k, v in sd.items()}
+model.load_state_dict(sd, strict=True)
+model = model.cuda().train()
+opt = init_optimizer(args, model, "noam")
+adam = opt.optimizer
+red = adam.reducer
+assert red is not None and red.active and red.world == 2 and len(red.buckets) >= 2
+B = z["src"].shape[0]
+mine = [i for i in range(B) if (i < (B + 1) // 2) == (rank == 0)]
+src = torch.from_numpy(z["src"][mine]).cuda(); tgt = torch.from_numpy(z["tgt"][mine]).cuda()
+src_len = torch.from_numpy(z["src_len"][mine])
+sm = float(z["smoothing"])
+core = model.module
+noise = lambda k: k.endswith("key_linear.bias")
+
+def check_grads():
+    cnt = float(adam.flat.stats[1])
+    for k, p in core.named_parameters():
+        ref = z["g0/" + k]
+        tol = 1e-6 + 2e-4 * np.abs(ref).max()
+        np.testing.assert_allclose(p.grad.cpu().numpy() / cnt, ref, rtol=0, atol=tol, err_msg=k)
+
+if mode == "eager":
+    for it in range(2):
+        opt.zero_grad()
+        pred, gold, hyp, _ = model(src, src_len, tgt)
+        loss, sums = calculate_metrics(pred, gold, smoothing=sm, loss_type="ce", sync=False)
+        loss.backward()
+        adam.clip_grad_norm_(1e9)               # finish() here AND in step(): the gradients must be reduced once
+        if it == 0:
+            check_grads()
+        g_before = adam.flat.grad.clone()
+        opt.step()
+        assert torch.equal(g_before, adam.flat.grad), "step() reduced the gradients a second time"
+        gl = adam.global_loss()
+        assert abs(gl - float(z["loss" if it == 0 else "loss2"])) < 5e-5, (it, gl)
+        assert int(adam.flat.stats[2]) == (int(z["num_correct"]) if it == 0 else int(adam.flat.stats[2]))
+    assert abs(opt._rate - float(z["lr2"])) < 1e-12
+else:
+    from asr_hip.graph import GraphedTrainStep
+    gs = GraphedTrainStep(model, opt, sm, src, src_len, tgt, clip_max_norm=1e9, warmup_steps=1)   # 1 eager + 1 replayed step
+    assert len(gs.graphs) == 3 and opt._step == 2
+    assert abs(gs.global_loss() - float(z["loss2"])) < 5e-5, gs.global_loss()
+    assert abs(gs.lr_dev.item() - float(z["lr2"])) < 1e-11
+lr_sum = float(z["lr1"]) + float(z["lr2"])
+for k, v in core.state_dict().items():
+    if k.endswith(".pe") or k.endswith("num_batches_tracked"):
+        continue
+    np.testing.assert_allclose(v.cpu().numpy(), z["w2/" + k], rtol=0, atol=2.1 * lr_sum if noise(k) else 2e-5, err_msg=k)
+if mode == "graph":                              # a third step from the graphs keeps the ranks identical
+    gs(src, src_len, tgt)
+    torch.cuda.synchronize()
+    mine_w = adam.flat.data.clone()
+    other = [torch.zeros_like(mine_w) for _ in range(world)]
+    dist.all_gather(other, mine_w)
+    assert torch.equal(other[0], other[1])
+dist.barrier()
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+@pytest.mark.parametrize("name", ["raw_tiny", "vgg_tiny"])
+def test_two_ranks_equal_the_single_process_reference(tmp_path, name, mode):
+    script = tmp_path / "w.py"
+    script.write_text(WORKER)
+    port = str(29500 + (os.getpid() * 7 + hash((name, mode))) % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", ROOT, port, name, mode], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("ok %d" % r) in o, o[-4000:]
+
+
+def test_bench_gpus_flag_refuses_a_smaller_machine():
+    """`bench.py --gpus 8` on a box with fewer GPUs must fail loudly instead of printing a 1-GPU number."""
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1), "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)

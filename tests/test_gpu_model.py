@@ -179,3 +179,33 @@ def test_eval_mode_and_checkpoint_roundtrip(golden_dir, tmp_path):
         if k.endswith("key_linear.bias"):
             continue            # zero-gradient parameters: atomics-order noise is amplified to +-lr by Adam
         assert torch.allclose(a.cpu(), b.cpu(), atol=2e-6), k
+
+
+@pytest.mark.parametrize("tag", ["plain", "parallel"])
+@pytest.mark.parametrize("run_parallel", [False, True])
+def test_reference_written_checkpoint_resumes(golden_dir, tag, run_parallel):
+    """A checkpoint written by the REFERENCE's own save_model (tests/golden/ref_ckpt_{plain,parallel}.th: pickled argparse
+    Namespace without any of this build's flags, torch Adam per-parameter state, `module.`-prefixed keys when the reference
+    ran under --parallel) loads through utils.functions.load_model -- whichever way THIS run is launched -- and the resumed
+    third step equals the reference's third step (loss, lr, every weight)."""
+    from utils import constant
+    from utils.functions import load_model
+    from asr_hip.ddp import HipDataParallel
+    z = np.load(os.path.join(golden_dir, "ref_ckpt_%s.npz" % tag))
+    constant.parse(["--cuda", "--precision", "fp32", "--tgt-max-len", "16"] + (["--parallel"] if run_parallel else []))
+    model, opt, epoch, metrics, args, l2i, i2l = load_model(os.path.join(golden_dir, "ref_ckpt_%s.th" % tag))
+    constant.set_args(args)
+    assert epoch == 7 and metrics["valid_loss"] == 1.25 and opt._step == 2
+    assert isinstance(model, HipDataParallel) == run_parallel and args.precision == "fp32" and args.parallel == run_parallel
+    assert abs(metrics["train_loss"] - float(z["loss2"])) < 1e-12 and len(l2i) == 32
+    model.train()
+    pred, gold, hyp, loss, _ = step(model, opt, z, float(z["smoothing"]))
+    opt.step()
+    assert abs(loss.item() - float(z["loss3"])) < 2e-5 and abs(opt._rate - float(z["lr3"])) < 1e-12
+    core = model.module if run_parallel else model
+    for k, v in core.state_dict().items():
+        if k.endswith(".pe"):
+            continue
+        name = ("module." + k) if tag == "parallel" else k
+        atol = 2.1 * float(z["lr3"]) if k.endswith("key_linear.bias") else 2e-5
+        np.testing.assert_allclose(v.cpu().numpy(), z["w3/" + name], rtol=0, atol=atol, err_msg=k)

@@ -246,6 +246,12 @@ CASES = [
     dict(B=2, H=8, Tq=100, Tk=200, d=64, key_len=[200, 37], causal=False),
     dict(B=2, H=2, Tq=130, Tk=75, d=32, key_len=[75, 60], causal=False),
     dict(B=1, H=2, Tq=70, Tk=70, d=64, full=True, causal=False),
+    # the headline shapes: encoder self-attention of configs[1] (T'=... the north-star microbench T=800) and the
+    # ragged T'=795 of configs[3]; decoder cross-attention Tq=100 over 795 keys; causal + key-pad decoder self-attention at Td=100
+    dict(B=2, H=8, Tq=800, Tk=800, d=64, key_len=[800, 613], causal=False),
+    dict(B=2, H=8, Tq=795, Tk=795, d=64, key_len=[795, 402], causal=False),
+    dict(B=2, H=8, Tq=100, Tk=795, d=64, key_len=[700, 795], causal=False),
+    dict(B=2, H=8, Tq=100, Tk=100, d=64, pad=True, causal=True),
 ]
 
 
@@ -433,7 +439,8 @@ def test_conv1_fwd_wgrad(ops, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cfg", [(2, 21, 37, 64, 64), (1, 16, 32, 64, 128), (2, 9, 50, 128, 128), (1, 11, 19, 128, 64)])
+@pytest.mark.parametrize("cfg", [(2, 21, 37, 64, 64), (1, 16, 32, 64, 128), (2, 9, 50, 128, 128), (1, 11, 19, 128, 64),
+                                 (1, 80, 400, 64, 128), (1, 80, 400, 128, 128)])       # the last two: configs[1] image size
 def test_conv3x3_fwd_dgrad_wgrad(ops, dtype, cfg):
     B, H, W, Cin, Cout = cfg
     g = torch.Generator().manual_seed(H * W + Cin)

@@ -98,13 +98,18 @@ def test_noam_and_text_metrics_match_oracle():
     assert calculate_wer("a b c", "c b a") == 2
 
 
-def test_rank_shard_is_disjoint_and_balanced():
+def test_rank_shard_splits_every_bin_over_the_ranks():
+    """The GLOBAL batch stays --batch-size (the reference's nn.DataParallel scatters one batch over the GPUs): every rank takes
+    an equal, disjoint share of every bin; bins smaller than the world size are skipped on every rank."""
     from asr_hip.ddp import rank_shard
-    bins = [[i] for i in range(11)]
+    bins = [list(range(0, 8)), list(range(8, 16)), list(range(16, 22)), [22, 23, 24]]
     parts = [rank_shard(bins, r, 4) for r in range(4)]
-    assert all(len(p) == 2 for p in parts)
-    flat = [b[0] for p in parts for b in p]
-    assert len(set(flat)) == len(flat) == 8
+    assert all(len(p) == 3 for p in parts)                              # the 3-utterance bin is dropped everywhere
+    assert all([len(b) for b in p] == [2, 2, 1] for p in parts)         # 8, 8, 6 -> 2, 2, 1 per rank (6 % 4 dropped)
+    for j in range(3):
+        seen = [u for p in parts for u in p[j]]
+        assert len(set(seen)) == len(seen) and set(seen) <= set(bins[j])
+    assert rank_shard(bins, 0, 1) == bins
 
 
 WORKER = r'''
@@ -121,25 +126,41 @@ m = torch.nn.Sequential(torch.nn.Linear(40, 70), torch.nn.Linear(70, 30), torch.
 flat = FlatParams(m)
 red = GradReducer(flat, bucket_bytes=4 * 2000)     # several buckets
 assert len(red.buckets) >= 2
+assert red.buckets[0]["hi"] == flat.total_all and red.buckets[-1]["lo"] == 0       # the first bucket carries the stats slot
+assert sum(b["hi"] - b["lo"] for b in red.buckets) == flat.total_all
 red.broadcast_parameters(0)
 ref = [torch.zeros_like(flat.data) for _ in range(world)]
 dist.all_gather(ref, flat.data)
 assert all(torch.equal(r, ref[0]) for r in ref)
-for step in range(2):
+for step in range(3):
+    if step < 2:
+        red.begin_step()                            # what FusedAdam.zero_grad() does; step 2 relies on the automatic restart
     flat.zero_grad()
+    flat.stats[0] = 10.0 * (rank + 1) + step        # [loss sum, token count] ride in the tail of the gradient buffer
+    flat.stats[1] = 3.0 + rank
     params = list(m.parameters())
     for i, p in reversed(list(enumerate(params))):  # backward order
         p.grad.add_(float(rank + 1) * (i + 1 + step))
-        red.mark_ready(p)
-    if step == 1:                                   # leave the last bucket to finish()
-        pass
+        if not (step == 1 and i == 0):              # step 1: the last bucket is left to finish()
+            red.mark_ready(p)
     red.finish()
+    red.finish()                                    # clip_grad_norm_() and step() both call it: reduced ONCE (ADVICE r1)
     for i, p in enumerate(params):
         want = sum(float(r + 1) for r in range(world)) * (i + 1 + step)
         assert torch.allclose(p.grad, torch.full_like(p.grad, want)), (step, i)
-t = torch.tensor([float(rank + 3)])
-red.all_reduce_scalar_(t)
-assert t.item() == sum(r + 3 for r in range(world))
+    assert flat.stats[0].item() == sum(10.0 * (r + 1) + step for r in range(world))
+    assert flat.stats[1].item() == sum(3.0 + r for r in range(world))
+# graph-replay mode: mark_ready / finish are inert, the caller reduces explicit ranges
+red.begin_step(); red.hold = True
+flat.zero_grad(); flat.grad_all.add_(float(rank + 1))
+for p in m.parameters():
+    red.mark_ready(p)
+red.finish()
+assert torch.all(flat.grad_all == float(rank + 1))
+cut = flat.offsets[2]
+wa = red.all_reduce_range(0, cut); wb = red.all_reduce_range(cut, flat.total_all)
+wa.wait(); wb.wait()
+assert torch.all(flat.grad_all == float(sum(r + 1 for r in range(world))))
 dist.destroy_process_group()
 print("ok", rank)
 '''
