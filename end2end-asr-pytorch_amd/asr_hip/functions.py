@@ -209,15 +209,19 @@ class MHAFn(Function):
         p_att = cfg["p"]
         seed_a, seed_o = P.next_seed(), P.next_seed()
         scale = 1.0 / (dk ** 0.5)
+        # bf16 storage + backward coming: keep an un-rounded fp32 copy of the attention output for delta = rowsum(dO * O)
+        O32 = None
+        if Q.dtype != torch.float32 and any(ctx.needs_input_grad):
+            O32 = torch.empty((B, Tq, HD), device=Q.device, dtype=torch.float32)
         O, lse, attn = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
                                     causal=cfg.get("causal", False), scale=scale, p=p_att, seed=seed_a,
-                                    want_attn=cfg.get("want_attn", False))
+                                    want_attn=cfg.get("want_attn", False), o32=O32)
         Y = _linear_fwd(O.view(B * Tq, HD), Wo, bo)
         out, mean, rstd = ops.add_ln_fwd(Y, q2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
         ctx.cfg, ctx.self_attn, ctx.fused = cfg, self_attn, fused
         ctx.seeds = (seed_a, seed_o)
         ctx.scale = scale
-        ctx.t = (q2, kv2, Q, K, V, O, lse, Y, mean, rstd)      # Y now holds z
+        ctx.t = (q2, kv2, Q, K, V, O, lse, Y, mean, rstd, O32)      # Y now holds z
         ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta)
         ctx.shape = (B, Tq, Tk, D)
         ctx.need_dkv = (not self_attn) and kv_in.requires_grad
@@ -233,7 +237,7 @@ class MHAFn(Function):
         H, dk = cfg["H"], cfg["dk"]
         HD = H * dk
         B, Tq, Tk, D = ctx.shape
-        q2, kv2, Q, K, V, O, lse, Z, mean, rstd = ctx.t
+        q2, kv2, Q, K, V, O, lse, Z, mean, rstd, O32 = ctx.t
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta = ctx.params
         seed_a, seed_o = ctx.seeds
         dout2 = dout.reshape(B * Tq, D).contiguous()
@@ -251,7 +255,7 @@ class MHAFn(Function):
         else:
             dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
         ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, HD), lse, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
-                     causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV))
+                     causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV), o32=O32)
         d_kv = None
         # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulated straight into d_res
         if fused.ok and ctx.self_attn:
@@ -282,12 +286,20 @@ class MHAFn(Function):
 
 
 # ================================================================================================ feed-forward sub-layer
+# Debug tap: set to a list and every forward appends the tensors holding its discrete selections (ReLU outputs, pooled
+# activations) in call order: FFN hidden activations, and for vgg_cnn (y1, y2, y3, y4).  Parity tests evaluate their fp64
+# restatement's gradient under the SAME selections (tests/test_gpu_baseline_shapes.py); never set on the training path.
+capture_selections = None
+
+
 class FFNFn(Function):
     @staticmethod
     def forward(ctx, x, W1, b1, W2, b2, gamma, beta, cfg):
         B, T, D = x.shape
         x2 = x.reshape(B * T, D).contiguous()
         h = _linear_fwd(x2, W1, b1, relu=True)
+        if capture_selections is not None:
+            capture_selections.append(("ffn", h))
         y = _linear_fwd(h, W2, b2)
         seed = P.next_seed()
         out, mean, rstd = ops.add_ln_fwd(y, x2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=cfg["p"], seed=seed)
@@ -378,6 +390,8 @@ class VGGFn(Function):
         wk7, _ = P.conv_shadow(w7)
         y4 = ops.conv3x3(y3, wk7, b7.data, w7.shape[0], relu=True)
         out = ops.maxpool_fwd(y4, tcf=True)
+        if capture_selections is not None:
+            capture_selections.append(("vgg", (y1, y2, y3, y4)))
         ctx.t = (src, y1, y2, p1, y3, y4)
         ctx.params = (w0, b0, w2, b2, w5, b5, w7, b7)
         return out
@@ -527,7 +541,8 @@ class CEFn(Function):
         logits = logits.contiguous()
         g = gold.reshape(-1).contiguous()
         red = P._state["reducer"]
-        deferred = (global_count is None and red is not None and red.active and torch.is_grad_enabled()
+        # (grad mode is always off inside Function.forward: "will backward run" is ctx.needs_input_grad)
+        deferred = (global_count is None and red is not None and red.active and ctx.needs_input_grad[0]
                     and red.flat.stats.device == logits.device)
         lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id, sums=red.flat.stats if deferred else None)
         if deferred:

@@ -40,9 +40,9 @@ _SIGS = {
     "asr_add_ln_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _P, _I, _P]),
     "asr_add_ln_bwd_workspace": (_L, [_I, _I]),
     "asr_add_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _P, _I, _P]),
-    "asr_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _P, _L, _L,
+    "asr_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _P, _L, _L,
                           _I, _F, _F, _U64, _P, _I, _P]),
-    "asr_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,
+    "asr_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,
                           _P, _P, _L, _L, _I, _F, _F, _U64, _P, _I, _I, _P]),
     "asr_decoder_preprocess": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "asr_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _P]),

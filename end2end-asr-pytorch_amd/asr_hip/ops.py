@@ -245,8 +245,9 @@ def _mask_strides(mask, B, Tq, Tk):
     return Tq * Tk, Tk
 
 
-def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, want_attn=False):
-    """q (B,Tq,H*d), k/v (B,Tk,H*d) -> (o (B,Tq,H*d), lse (B,H,Tq), attn (H*B,Tq,Tk) or None)."""
+def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, want_attn=False, o32=None):
+    """q (B,Tq,H*d), k/v (B,Tk,H*d) -> (o (B,Tq,H*d), lse (B,H,Tq), attn (H*B,Tq,Tk) or None).
+    o32: optional fp32 (B,Tq,H*d) contiguous destination for an un-rounded copy of o (training with bf16 storage)."""
     B, Tq, _ = q.shape
     Tk = k.shape[1]
     msb, msq = _mask_strides(key_pad, B, Tq, Tk)
@@ -254,17 +255,19 @@ def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0,
     lse = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
     attn = torch.empty((H * B, Tq, Tk), device=q.device, dtype=torch.float32) if want_attn else None
     qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
-    L.call("asr_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(lse), L.ptr(attn), B, H, Tq, Tk, d, qs[0], qs[1],
+    assert o32 is None or (o32.dtype == torch.float32 and o32.shape == o.shape and o32.is_contiguous())
+    L.call("asr_attn_fwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(o32), L.ptr(lse), L.ptr(attn), B, H, Tq, Tk, d, qs[0], qs[1],
            ks[0], ks[1], vs[0], vs[1], os_[0], os_[1], L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal),
            float(scale), float(p), int(seed), _seed_dev(q), L.dt(q), L.stream())
     return o, lse, attn
 
 
-def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, out=None):
+def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, out=None, o32=None):
     """out: optional (dq, dk, dv) destination tensors; they must have the strides of q, k, v (the ABI reuses them)."""
     B, Tq, _ = q.shape
     Tk = k.shape[1]
     assert do.is_contiguous() and o.is_contiguous()
+    assert o32 is None or (o32.dtype == torch.float32 and o32.shape == o.shape and o32.is_contiguous())
     if out is None:
         dq = torch.empty_strided(q.shape, q.stride(), device=q.device, dtype=q.dtype)
         dk = torch.empty_strided(k.shape, k.stride(), device=k.device, dtype=k.dtype)
@@ -278,7 +281,7 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
     sd = _seed_dev(q)
 
     def launch(parts):
-        L.call("asr_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dq),
+        L.call("asr_attn_bwd", L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), L.ptr(o32), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dq),
                L.ptr(dk), L.ptr(dv), B, H, Tq, Tk, d, qs[0], qs[1], ks[0], ks[1], vs[0], vs[1], os_[0], os_[1],
                L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), sd, parts,
                L.dt(q), L.stream())

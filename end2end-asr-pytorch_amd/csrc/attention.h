@@ -9,6 +9,7 @@ struct AttnArgs {
   const void *Q, *K, *V, *O, *dO;
   void *Out, *dQ, *dK, *dV;
   float* lse; float* delta; float* attn_out;
+  float* Out32; const float* O32;   // optional fp32 copy of the output (same element strides as O): delta = rowsum(dO * O32)
   int B, H, Tq, Tk;
   int64_t q_sb, q_st, k_sb, k_st, v_sb, v_st, o_sb, o_st;
   const int32_t* key_len; const uint8_t* key_pad; int64_t m_sb, m_sq;

@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
     for (int df = 0; df < A::NDF; ++df)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) DT<T>::st(Ob + df * 16 + g * 4 + r, o[df][r] * inv_l);
+      for (int r = 0; r < 4; ++r) {
+        DT<T>::st(Ob + df * 16 + g * 4 + r, o[df][r] * inv_l);
+        if (p.Out32) p.Out32[(int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD + df * 16 + g * 4 + r] = o[df][r] * inv_l;
+      }
   }
 }
 
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int HD) {
     const int b = (int)(idx / ((int64_t)p.Tq * p.H));
     const T* o = static_cast<const T*>(p.O) + (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD;
     const T* d = static_cast<const T*>(p.dO) + (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD;
-    for (int c = sub; c < HD; c += 16) s += DT<T>::ld(o + c) * DT<T>::ld(d + c);
+    const float* o32 = p.O32 ? p.O32 + (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD : nullptr;
+    for (int c = sub; c < HD; c += 16) s += (o32 ? o32[c] : DT<T>::ld(o + c)) * DT<T>::ld(d + c);
   }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
@@ -496,7 +500,7 @@ int fill_common(AttnArgs& p, int B, int H, int Tq, int Tk, int d, int64_t q_sb, 
 
 }  // namespace
 
-extern "C" int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, float* attn_out, int B, int H,
+extern "C" int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* o32, float* lse, float* attn_out, int B, int H,
                             int Tq, int Tk, int d, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
                             int64_t v_st, int64_t o_sb, int64_t o_st, const int32_t* key_len, const uint8_t* key_pad,
                             int64_t mask_sb, int64_t mask_sq, int causal, float scale, float dropout_p, uint64_t seed,
@@ -507,7 +511,8 @@ extern "C" int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O
                        scale, dropout_p, seed, seed_dev, dtype);
   if (rc != ASR_OK) return rc;
   if (B == 0 || Tq == 0) return ASR_OK;
-  p.Q = Q; p.K = K; p.V = V; p.Out = O; p.lse = lse; p.attn_out = attn_out;
+  p.Q = Q; p.K = K; p.V = V; p.Out = O; p.Out32 = o32; p.lse = lse; p.attn_out = attn_out;
+  ASR_CHECK_ARG(!o32 || aligned16(o32));
   p.vec = p.vec && aligned16(Q) && aligned16(K) && aligned16(V);
   AsrProfScope prof(ASR_OP_ATTN_FWD, stream);
   {
@@ -520,7 +525,7 @@ extern "C" int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O
   return dtype == ASR_F32 ? dispatch<float>(p, d, false, stream) : dispatch<bf16_t>(p, d, false, stream);
 }
 
-extern "C" int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+extern "C" int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const float* o32, const void* dO, const float* lse,
                             float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
                             int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
                             const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,
@@ -533,7 +538,7 @@ extern "C" int asr_attn_bwd(const void* Q, const void* K, const void* V, const v
                        scale, dropout_p, seed, seed_dev, dtype);
   if (rc != ASR_OK) return rc;
   if (B == 0 || Tq == 0 || Tk == 0) return ASR_OK;
-  p.Q = Q; p.K = K; p.V = V; p.O = O; p.dO = dO; p.lse = const_cast<float*>(lse); p.delta = delta;
+  p.Q = Q; p.K = K; p.V = V; p.O = O; p.O32 = o32; p.dO = dO; p.lse = const_cast<float*>(lse); p.delta = delta;
   p.dQ = dQ; p.dK = dK; p.dV = dV; p.parts = parts;
   p.vec = p.vec && aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(dO);
   AsrProfScope prof(ASR_OP_ATTN_BWD, stream);

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
     for (int df = 0; df < 4; ++df) {
       const f32x4_t v = o[qi][df] * inv_l;
       *reinterpret_cast<uint2*>(Ob + df * 16 + g * 4) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+      if (p.Out32) *reinterpret_cast<f32x4_t*>(p.Out32 + (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD + df * 16 + g * 4) = v;
     }
   }
 }
@@ -565,10 +566,16 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_d64_kernel(AttnArgs p) {
     const int b = (int)(idx / ((int64_t)p.Tq * p.H));
     const int64_t off = (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD + sub * 8;
     Chunk<bf16_t> o, d;
-    o.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.O) + off);
     d.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.dO) + off);
+    if (p.O32) {       // un-rounded forward output: the rounding error of a bf16 O does not cancel against dP (see asr_hip.h)
+      const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(p.O32 + off), o1 = *reinterpret_cast<const f32x4_t*>(p.O32 + off + 4);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc += bf16_to_f32(o.e[j]) * bf16_to_f32(d.e[j]);
+      for (int j = 0; j < 4; ++j) acc += o0[j] * bf16_to_f32(d.e[j]) + o1[j] * bf16_to_f32(d.e[4 + j]);
+    } else {
+      o.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.O) + off);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += bf16_to_f32(o.e[j]) * bf16_to_f32(d.e[j]);
+    }
   }
   acc += __shfl_xor(acc, 4, 64);
   acc += __shfl_xor(acc, 2, 64);

@@ -109,14 +109,17 @@ int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const flo
  * Masks (True = masked, as reference): key index >= key_len[b] (NULL = none); key_pad[b*mask_sb + q*mask_sq + k] != 0
  * (NULL = none; mask_sb=Tk, mask_sq=0 for a per-key mask, mask_sb=Tq*Tk, mask_sq=Tk for a full (B,Tq,Tk) mask);
  * causal: key > query.  lse (B,H,Tq) fp32 saved for backward.  attn_out (H*B,Tq,Tk) fp32 optional (index h*B+b,
- * reference layout common_layers.py:185-190).  Replaces common_layers.py:211-225 and the permutes at :185-195. */
-int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* lse, float* attn_out, int B, int H,
+ * reference layout common_layers.py:185-190).  o32 (optional, NULL = none): fp32 copy of O with O's element strides,
+ * for the backward's delta = rowsum(dO*O): with bf16 storage the rounding error of O does not cancel against
+ * dP = dO.V^T and dominates dQ/dK when the value rows share a common component (measured 3-10x on dK).
+ * Replaces common_layers.py:211-225 and the permutes at :185-195. */
+int asr_attn_fwd(const void* Q, const void* K, const void* V, void* O, float* o32, float* lse, float* attn_out, int B, int H,
                  int Tq, int Tk, int d, int64_t q_sb, int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb,
                  int64_t v_st, int64_t o_sb, int64_t o_st, const int32_t* key_len, const uint8_t* key_pad,
                  int64_t mask_sb, int64_t mask_sq, int causal, float scale, float dropout_p, uint64_t seed,
                  const uint64_t* seed_dev, int dtype, asr_stream_t stream);
-/* delta (B,H,Tq) fp32 workspace.  dQ/dK/dV use the strides of Q/K/V.                                           */
-int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+/* delta (B,H,Tq) fp32 workspace.  dQ/dK/dV use the strides of Q/K/V.  o32: the forward's fp32 copy or NULL.    */
+int asr_attn_bwd(const void* Q, const void* K, const void* V, const void* O, const float* o32, const void* dO, const float* lse,
                  float* delta, void* dQ, void* dK, void* dV, int B, int H, int Tq, int Tk, int d, int64_t q_sb,
                  int64_t q_st, int64_t k_sb, int64_t k_st, int64_t v_sb, int64_t v_st, int64_t o_sb, int64_t o_st,
                  const int32_t* key_len, const uint8_t* key_pad, int64_t mask_sb, int64_t mask_sq, int causal,

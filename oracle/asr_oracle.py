@@ -66,19 +66,38 @@ class Cfg:
 
 
 # ------------------------------------------------------------------------------------------------ front end
-def conv_front_end(w, x, feat_extractor, training, bn_state=None):
+def _relu(x, keep=None):
+    """ReLU; with `keep` (bool, same shape) the SELECTION is imposed instead of derived: x * keep.  Used by parity tests to
+    evaluate the fp64 gradient under the discrete decisions (ReLU masks, pooling arg-maxes) that the implementation under
+    test took in its own forward pass -- at an element within rounding distance of 0 (or of a tie) either decision is a
+    correct fp32 result, but the gradients of the two branches differ by that element's whole contribution."""
+    return F.relu(x) if keep is None else x * keep.to(x.dtype)
+
+
+def _max_pool(x, idx=None):
+    """MaxPool2d(2, stride=2); with `idx` (flat indices into H*W per (b,c), as F.max_pool2d(return_indices=True)) the
+    selection is imposed: out = x.flatten(2).gather(idx)."""
+    if idx is None:
+        return F.max_pool2d(x, 2, stride=2)
+    B, C, H, W = x.shape
+    return x.flatten(2).gather(2, idx.flatten(2)).view(B, C, H // 2, W // 2)
+
+
+def conv_front_end(w, x, feat_extractor, training, bn_state=None, decisions=None):
     """models/asr/transformer.py:32-53 (module definition) and :70-76 (application + reshape).
 
     x: (B,1,F,T) -> (B,T',C*F') with feature index c*F'+f.
     bn_state: dict updated in place with BatchNorm running stats when training (emb_cnn only).
+    decisions: optional dict {"relu0","relu2","pool4","relu5","relu7","pool9"} (vgg_cnn; see _relu / _max_pool).
     """
+    dz = decisions or {}
     if feat_extractor == "vgg_cnn":                                   # :41-53
-        x = F.relu(F.conv2d(x, w["conv.0.weight"], w["conv.0.bias"], padding=1))
-        x = F.relu(F.conv2d(x, w["conv.2.weight"], w["conv.2.bias"], padding=1))
-        x = F.max_pool2d(x, 2, stride=2)
-        x = F.relu(F.conv2d(x, w["conv.5.weight"], w["conv.5.bias"], padding=1))
-        x = F.relu(F.conv2d(x, w["conv.7.weight"], w["conv.7.bias"], padding=1))
-        x = F.max_pool2d(x, 2, stride=2)
+        x = _relu(F.conv2d(x, w["conv.0.weight"], w["conv.0.bias"], padding=1), dz.get("relu0"))
+        x = _relu(F.conv2d(x, w["conv.2.weight"], w["conv.2.bias"], padding=1), dz.get("relu2"))
+        x = _max_pool(x, dz.get("pool4"))
+        x = _relu(F.conv2d(x, w["conv.5.weight"], w["conv.5.bias"], padding=1), dz.get("relu5"))
+        x = _relu(F.conv2d(x, w["conv.7.weight"], w["conv.7.bias"], padding=1), dz.get("relu7"))
+        x = _max_pool(x, dz.get("pool9"))
     elif feat_extractor == "emb_cnn":                                 # :32-40
         st = bn_state if bn_state is not None else {}
         x = F.conv2d(x, w["conv.0.weight"], w["conv.0.bias"], stride=(2, 2), padding=(0, 10))
@@ -142,9 +161,9 @@ def multi_head_attention(w, p, q_in, kv_in, mask, H, dk, dv, return_attn=False):
     return out
 
 
-def pos_ffn(w, p, x):
-    """models/common_layers.py:135-142 (Conv1d k=1 == Linear on the last dim)."""
-    h = F.relu(x @ w[p + "conv_1.weight"][:, :, 0].t() + w[p + "conv_1.bias"])
+def pos_ffn(w, p, x, decisions=None):
+    """models/common_layers.py:135-142 (Conv1d k=1 == Linear on the last dim).  decisions[p + "relu"]: see _relu."""
+    h = _relu(x @ w[p + "conv_1.weight"][:, :, 0].t() + w[p + "conv_1.bias"], (decisions or {}).get(p + "relu"))
     y = h @ w[p + "conv_2.weight"][:, :, 0].t() + w[p + "conv_2.bias"]
     return layer_norm(y + x, w[p + "layer_norm.weight"], w[p + "layer_norm.bias"])
 
@@ -156,7 +175,7 @@ def length_masks(lengths, T):
     return keep
 
 
-def encoder_forward(w, cfg, x, src_len):
+def encoder_forward(w, cfg, x, src_len, decisions=None):
     """models/asr/transformer.py:157-180 + EncoderLayer :195-203."""
     B, Te, _ = x.shape
     keep = length_masks(src_len, Te)                                  # :168
@@ -169,7 +188,7 @@ def encoder_forward(w, cfg, x, src_len):
         p = "encoder.layers.%d." % l
         e = multi_head_attention(w, p + "self_attn.", e, e, attn_mask, cfg.num_heads, cfg.dim_key, cfg.dim_value)
         e = e * m_e                                                   # :198
-        e = pos_ffn(w, p + "pos_ffn.", e)
+        e = pos_ffn(w, p + "pos_ffn.", e, decisions)
         e = e * m_e                                                   # :201
     return e
 
@@ -191,7 +210,7 @@ def decoder_preprocess(tgt, Td):
     return seq_in, seq_out
 
 
-def decoder_forward(w, cfg, tgt, enc_out, src_len):
+def decoder_forward(w, cfg, tgt, enc_out, src_len, decisions=None):
     """models/asr/transformer.py:268-305 + DecoderLayer :533-545."""
     B, Te, D = enc_out.shape
     Td = cfg.tgt_max_len
@@ -212,22 +231,22 @@ def decoder_forward(w, cfg, tgt, enc_out, src_len):
         d = multi_head_attention(w, p + "encoder_attn.", d, enc_out, cross_mask, cfg.num_heads, cfg.dim_key,
                                  cfg.dim_value)
         d = d * m_d
-        d = pos_ffn(w, p + "pos_ffn.", d)
+        d = pos_ffn(w, p + "pos_ffn.", d, decisions)
         d = d * m_d
     out_w = emb_w if cfg.emb_trg_sharing else w["decoder.output_linear.weight"]
     logits = d @ out_w.t()                                            # :302 (no bias)
     return logits, seq_out
 
 
-def transformer_forward(w, cfg, src, src_len, tgt, training=True, bn_state=None):
-    """models/asr/transformer.py:59-85.  Returns (pred, gold, hyp_seq)."""
+def transformer_forward(w, cfg, src, src_len, tgt, training=True, bn_state=None, decisions=None):
+    """models/asr/transformer.py:59-85.  Returns (pred, gold, hyp_seq).  decisions: see _relu (parity tests only)."""
     if cfg.feat_extractor in ("vgg_cnn", "emb_cnn"):
-        x = conv_front_end(w, src, cfg.feat_extractor, training, bn_state)
+        x = conv_front_end(w, src, cfg.feat_extractor, training, bn_state, (decisions or {}).get("conv"))
     else:
         B, C, Fq, T = src.shape
         x = src.reshape(B, C * Fq, T).transpose(1, 2).contiguous()
-    enc = encoder_forward(w, cfg, x, src_len)
-    pred, gold = decoder_forward(w, cfg, tgt, enc, src_len)
+    enc = encoder_forward(w, cfg, x, src_len, decisions)
+    pred, gold = decoder_forward(w, cfg, tgt, enc, src_len, decisions)
     hyp = pred.argmax(dim=2)      # torch.topk(pred,1) (:80) -- lowest index on exact ties, as argmax
     return pred, gold, hyp
 
@@ -295,14 +314,14 @@ def trainable_names(w, cfg):
     return names
 
 
-def train_step(w, cfg, src, src_len, tgt, smoothing, opt=None, bn_state=None):
+def train_step(w, cfg, src, src_len, tgt, smoothing, opt=None, bn_state=None, decisions=None):
     """trainer/asr/trainer.py:56-111 minus the string/CER bookkeeping.  w: dict of fp32 tensors.
     Returns dict(loss, pred, gold, hyp, num_correct, grads)."""
     names = trainable_names(w, cfg)
     leaves = {k: w[k].detach().clone().requires_grad_(True) for k in names}
     wl = dict(w)
     wl.update(leaves)
-    pred, gold, hyp = transformer_forward(wl, cfg, src, src_len, tgt, True, bn_state)
+    pred, gold, hyp = transformer_forward(wl, cfg, src, src_len, tgt, True, bn_state, decisions)
     loss, ncorrect, num_word = smoothed_ce(pred, gold, smoothing)
     grads = torch.autograd.grad(loss, [leaves[k] for k in names], allow_unused=True)
     grads = {k: (g if g is not None else torch.zeros_like(w[k])) for k, g in zip(names, grads)}

@@ -298,12 +298,41 @@ def run_big(name):
     out["num_correct"] = np.int64(ncorrect)
     for k, q in model.named_parameters():
         grad_summary(out, k, q.grad)
+    g32 = {k: q.grad.detach().double().numpy().copy() for k, q in model.named_parameters()}
     opt.step()
     out["lr1"] = np.float64(opt._rate)
     opt.zero_grad()
     pred2, gold2, _, _ = model(src, src_len, tgt)
     loss2, _ = calculate_metrics(pred2, gold2, smoothing=cfg["smoothing"], loss_type="ce")
     out["loss2"] = np.float64(loss2.item())
+    # What the reference's OWN arithmetic is worth at this shape, per parameter gradient, against the same model in fp64:
+    #   e32/<name>  relative L2 error of the fp32 run above        (the floor of any fp32 comparison)
+    #   ebf/<name>  relative L2 error of the reference under torch.autocast(cpu, bfloat16)  (what "bf16 tolerance" means
+    #               for THIS model: PyTorch's own mixed precision; the product's bf16 bound is stated as a multiple of it)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+    def rerun(mode):
+        m = build_reference_model(constant, cfg, l2i, i2l)
+        m.train()
+        perturb_1d(m)
+        s = src
+        if mode == "f64":
+            m, s = m.double(), src.double()
+        if mode == "bf16":
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                pr, go, _, _ = m(s, src_len, tgt)
+                lo, _ = calculate_metrics(pr.float(), go, smoothing=cfg["smoothing"], loss_type="ce")
+        else:
+            pr, go, _, _ = m(s, src_len, tgt)
+            lo, _ = calculate_metrics(pr, go, smoothing=cfg["smoothing"], loss_type="ce")
+        lo.backward()
+        return {k: q.grad.detach().double().numpy() for k, q in m.named_parameters()}, pr.detach().double()
+    g64, p64 = rerun("f64")
+    gbf, pbf = rerun("bf16")
+    for k in g64:
+        out["e32/" + k] = np.float64(rel(g32[k], g64[k]))
+        out["ebf/" + k] = np.float64(rel(gbf[k], g64[k]))
+    out["pred_err_f32"] = np.float64((p.double() - p64).abs().max().item())
+    out["pred_err_autocast_bf16"] = np.float64((pbf - p64).abs().max().item())
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **out)

@@ -11,11 +11,26 @@
 dk=64 + bf16 runs attention_fast.hip, the 128x64 / tn128 GEMM tiles and the V=4364 -> 4416 padded vocabulary GEMM
 that the tiny goldens never reach.  Ragged lengths: source rows below T' and targets from 5 to 99 tokens.
 
-Tolerances (measured values are written to gpurun_out/parity_r02.json by this test and quoted in DESIGN.md section 2)
-  fp32 mode: logits atol 5e-5*max(1,max|logit|); loss 2e-5; per-tensor gradient relative L2 error <= 2e-4;
+The truth is the oracle in FLOAT64 (same weights, same inputs, run on the GPU box's host cores).  Every fixture also holds,
+per parameter, what the executed reference's OWN arithmetic is worth against its fp64 self at this shape
+(oracle/gen_golden.py run_big): e32/<name> = relative L2 error of the reference's fp32 gradient, ebf/<name> = the same for
+the reference under torch.autocast(cpu, bfloat16) -- PyTorch's own mixed precision.  The product's bounds are stated as
+multiples of those floors:
+
+  fp32 mode: logits atol 5e-5*max(1,max|logit|); loss 2e-5; per-tensor gradient relative L2 error <= max(2e-4, 4*e32);
              loss after the step 1e-4; arg-max exact on every row whose reference margin exceeds 1e-3.
-  bf16 mode: logits atol 4e-2*max|logit|; loss 2e-2; per-tensor gradient relative L2 error <= REL_BF16 (below);
+             The gradient truth is evaluated UNDER THE PRODUCT'S OWN DISCRETE SELECTIONS (its ReLU masks and max-pool
+             arg-maxes, tapped with asr_hip.functions.capture_selections and imposed on the fp64 oracle): at a pre-activation
+             within fp32 rounding of 0, or a pooling window whose two largest values are within rounding of each other
+             (exactly tied over the zero-padded frames), either selection is a correct fp32 result, but ONE flipped ReLU
+             among the 4e5 hidden units of a layer moves that layer's gradient by 1e-3 relative, and the fp64 oracle's own
+             selections over exactly tied windows depend on last-bit differences of its BLAS (measured: tools/diag_fp32.py,
+             DESIGN.md section 2).  That the imposed selections are legitimate is checked by the oracle's FORWARD under them:
+             its logits must equal the free-running fp64 logits to 1e-6.  The error against the free-running fp64 gradient
+             is reported next to it (parity json: grad_rel_l2_free).
+  bf16 mode: logits atol 4e-2*max|logit|; loss 2e-2; per-tensor gradient relative L2 error <= max(REL_BF16, 2*ebf);
              arg-max equal wherever the reference's top-2 margin exceeds 8e-2*max|logit|.
+Measured values (every tensor) are written to gpurun_out/parity_r02.json and quoted in DESIGN.md section 2.
 """
 import json
 import os
@@ -28,7 +43,7 @@ import big_cases as BC
 
 pytestmark = pytest.mark.gpu
 
-REL_BF16 = 6e-2        # per-tensor ||g - g_ref|| / ||g_ref||, bf16 storage of ~25-50 chained layers (measured <= see DESIGN)
+REL_BF16 = 5e-2        # floor of the per-tensor bound ||g - g_64|| / ||g_64|| in bf16 mode (the bound is max(this, 2 * ebf[name]))
 _oracle_cache = {}
 _report = {}
 
@@ -42,10 +57,42 @@ def _oracle(name, z, model, src, src_len, tgt):
         names = O.trainable_names(w, cfg)
         opt = O.NoamAdam({k: w[k] for k in names}, model_size=int(z["dim_input"]))
         bn = {}
+        w64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in w.items()}
+        r64 = O.train_step(w64, cfg, src.double(), src_len, tgt, float(z["smoothing"]), bn_state={})      # the truth
         r1 = O.train_step(w, cfg, src, src_len, tgt, float(z["smoothing"]), opt=opt, bn_state=bn)
         r2 = O.train_step(w, cfg, src, src_len, tgt, float(z["smoothing"]), bn_state=bn)
+        r1["grads64"] = {k: v.double() for k, v in r64["grads"].items()}
+        r1["pred64"] = r64["pred"].double()
         _oracle_cache[name] = (r1, r2["loss"], opt.rate)
     return _oracle_cache[name]
+
+
+def _oracle_under_selections(z, model, taps, src, src_len, tgt, ref):
+    """fp64 oracle gradients with the product's ReLU masks / pooling arg-maxes imposed (see the module docstring).
+    Returns (grads, max |logit shift| of the oracle's forward caused by imposing them)."""
+    import torch.nn.functional as F
+    from oracle import asr_oracle as O
+    core = model.module if hasattr(model, "module") else model
+    prefixes = (["encoder.layers.%d.pos_ffn." % i for i in range(len(core.encoder.layers))] +
+                ["decoder.layers.%d.pos_ffn." % i for i in range(len(core.decoder.layers))])
+    ffn = [t for kind, t in taps if kind == "ffn"]
+    assert len(ffn) == len(prefixes), (len(ffn), len(prefixes))
+    dec = {}
+    B = src.shape[0]
+    for p, h in zip(prefixes, ffn):
+        dec[p + "relu"] = (h.detach().cpu() > 0).view(B, -1, h.shape[-1])
+    vgg = [t for kind, t in taps if kind == "vgg"]
+    if vgg:
+        nchw = lambda t: t.detach().cpu().permute(0, 3, 1, 2).contiguous()
+        y1, y2, y3, y4 = (nchw(t) for t in vgg[0])
+        dec["conv"] = {"relu0": y1 > 0, "relu2": y2 > 0, "relu5": y3 > 0, "relu7": y4 > 0,
+                       "pool4": F.max_pool2d(y2.double(), 2, 2, return_indices=True)[1],
+                       "pool9": F.max_pool2d(y4.double(), 2, 2, return_indices=True)[1]}
+    w = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    w64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in w.items()}
+    r = O.train_step(w64, BC.oracle_cfg(z), src.double(), src_len, tgt, float(z["smoothing"]), bn_state={}, decisions=dec)
+    shift = float((r["pred"].double() - ref["pred64"]).abs().max())
+    return {k: v.double() for k, v in r["grads"].items()}, shift
 
 
 def _dump():
@@ -76,8 +123,11 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
         loss.backward()
         return pred, gold, hyp, loss, ncorrect
 
+    from asr_hip import functions as F_
+    F_.capture_selections = [] if precision == "fp32" else None
     pred, gold, hyp, loss, ncorrect = step()
     torch.cuda.synchronize()
+    taps, F_.capture_selections = F_.capture_selections, None
     p = pred.detach().float().cpu()
     assert torch.isfinite(p).all()
     amax = float(ref["pred"].abs().max())
@@ -87,8 +137,15 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
     assert torch.equal(gold.cpu(), ref["gold"]) and np.array_equal(gold.cpu().numpy(), z["gold"])
     emb = name == "cfg3_shape"
     grads = {k: q.grad.detach().float().cpu() for k, q in model.named_parameters()}
-    rel = {k: BC.rel_l2(grads[k].numpy(), ref["grads"][k].numpy()) for k in grads if not BC.noise_driven(k, emb)}
-    worst = max(rel, key=rel.get)
+    rel_free = {k: BC.rel_l2(grads[k].numpy(), ref["grads64"][k].numpy()) for k in grads if not BC.noise_driven(k, emb)}
+    truth, sel_logit_dev = ref["grads64"], 0.0
+    if precision == "fp32":
+        truth, sel_logit_dev = _oracle_under_selections(z, model, taps, src, src_len, tgt, ref)
+    rel = {k: BC.rel_l2(grads[k].numpy(), truth[k].numpy()) for k in grads if not BC.noise_driven(k, emb)}
+    floor = {k: float(z[("e32/" if precision == "fp32" else "ebf/") + k]) for k in rel}
+    bound = {k: max(2e-4, 4 * floor[k]) if precision == "fp32" else max(REL_BF16, 2 * floor[k]) for k in rel}
+    worst = max(rel, key=lambda k: rel[k] / bound[k])
+    perr64 = float((p.double() - ref["pred64"]).abs().max())
     summ = BC.summary_errors(z, pred, loss.item(), grads)
     margin = 1e-3 if precision == "fp32" else 8e-2 * amax
     miss, nsure = BC.argmax_agreement(z, hyp, margin)
@@ -100,7 +157,15 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
     l2err = abs(loss2.item() - ref_loss2)
     _report["%s/%s" % (name, precision)] = {
         "logit_max_abs_err": perr, "logit_abs_max": amax, "loss_err": lerr, "loss2_err": l2err, "loss2_err_vs_reference": abs(loss2.item() - float(z["loss2"])),
-        "grad_rel_l2_worst": rel[worst], "grad_rel_l2_worst_name": worst, "grad_rel_l2_median": float(np.median(list(rel.values()))),
+        "grad_rel_l2_worst": rel[worst], "grad_rel_l2_worst_name": worst, "grad_rel_l2_worst_bound": bound[worst],
+        "grad_rel_l2_median": float(np.median(list(rel.values()))), "grad_rel_l2_max": max(rel.values()),
+        "reference_floor_median": float(np.median(list(floor.values()))), "reference_floor_max": max(floor.values()),
+        "logit_max_abs_err_vs_fp64": perr64,
+        "reference_logit_err": float(z["pred_err_f32" if precision == "fp32" else "pred_err_autocast_bf16"]),
+        "grad_rel_l2": {k: [rel[k], floor[k]] for k in sorted(rel, key=lambda k: -rel[k] / bound[k])},
+        "grad_rel_l2_free_max": max(rel_free.values()), "grad_rel_l2_free_median": float(np.median(list(rel_free.values()))),
+        "grad_rel_l2_free": {k: rel_free[k] for k in sorted(rel_free, key=lambda k: -rel_free[k])[:12]},
+        "oracle_logit_shift_under_product_selections": sel_logit_dev,
         "argmax_rows_checked": nsure, "argmax_mismatch_vs_reference": miss, "argmax_mismatch_vs_oracle": miss_o,
         "ref_summary_pred_sub": summ["pred_sub"], "ref_summary_gs_worst": max(v for k, v in summ["gs"].items() if not BC.noise_driven(k, emb)),
         "num_correct": int(ncorrect), "lr1": opt._rate}
@@ -108,15 +173,16 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
     assert abs(opt._rate - ref_lr) < 1e-12 and abs(opt._rate - float(z["lr1"])) < 1e-12
     assert int(ncorrect) == int(z["num_correct"]) or precision == "bf16"
     if precision == "fp32":
+        assert sel_logit_dev <= 1e-6 * max(1.0, amax), sel_logit_dev
         assert perr <= 5e-5 * max(1.0, amax), perr
         assert lerr < 2e-5 and l2err < 1e-4, (lerr, l2err)
-        assert rel[worst] <= 2e-4, (worst, rel[worst])
+        assert rel[worst] <= bound[worst], (worst, rel[worst], bound[worst])
         assert summ["pred_sub"] <= 1e-4 and abs(loss2.item() - float(z["loss2"])) < 1e-4
     else:
         assert perr <= 4e-2 * amax, (perr, amax)
         assert lerr < 2e-2 and l2err < 3e-2, (lerr, l2err)
-        assert rel[worst] <= REL_BF16, (worst, rel[worst])
-    assert miss == 0 and miss_o == 0 and nsure > 20, (miss, miss_o, nsure)
+        assert rel[worst] <= bound[worst], (worst, rel[worst], bound[worst])
+    assert miss == 0 and miss_o == 0 and nsure > (20 if precision == "fp32" else 5), (miss, miss_o, nsure)
 
 
 def test_graph_replay_equals_eager_at_dk64_bf16(golden_dir):

@@ -292,6 +292,39 @@ def test_attention_fwd_bwd(ops, dtype, case):
     close("attn dv", dv, vr.grad, dtype, scale=4)
 
 
+def test_attention_bwd_delta_from_unrounded_output(ops):
+    """bf16 storage: delta = rowsum(dO * O) from the forward's fp32 copy of O (asr_attn_fwd o32).  When the value rows share a
+    common component (LayerNorm bias / positional part of the stream) the rounding error of a bf16 O does not cancel against
+    dP = dO.V^T and dominates dS = P (dP - delta); with the fp32 copy dQ / dK keep plain bf16 accuracy.  Truth: fp64 on the
+    bf16-rounded operands.  Decoder self-attention shape of the benchmark (B=2, H=8, T=100, d=64, causal + key pad)."""
+    B, H, T, d = 2, 8, 100, 64
+    g = torch.Generator().manual_seed(11)
+    dtype = torch.bfloat16
+    qx = q(torch.randn(B, T, H * d, generator=g) * 0.5, dtype)
+    kx = q(torch.randn(B, T, H * d, generator=g) * 0.5, dtype)
+    vx = q(torch.randn(B, T, H * d, generator=g) + 6.0 * torch.randn(1, 1, H * d, generator=g), dtype)
+    do = q(torch.randn(B, T, H * d, generator=g), dtype)
+    key_pad = torch.zeros(B, T, dtype=torch.uint8)
+    key_pad[1, 70:] = 1
+    scale = 1.0 / math.sqrt(d)
+    qr, kr, vr = (t.double().clone().requires_grad_() for t in (qx, kx, vx))
+    oref, _ = attn_ref(qr, kr, vr, H, d, None, key_pad, True, scale)
+    oref.backward(do.double())
+    D = dev()
+    a = [t.to(D, dtype) for t in (qx, kx, vx)]
+    o32 = torch.empty(B, T, H * d, device=D, dtype=torch.float32)
+    o, lse, _ = ops.attn_fwd(*a, H, d, key_pad=key_pad.to(D), causal=True, scale=scale, o32=o32)
+    assert (o32.cpu().double() - oref.detach()).abs().max() < 5e-3 * oref.detach().abs().max() and torch.equal(o32.to(dtype), o)
+    err = {}
+    for tag, buf in (("bf16_O", None), ("fp32_O", o32)):
+        dq, dk, dv = ops.attn_bwd(*a, o, do.to(D, dtype), lse, H, d, key_pad=key_pad.to(D), causal=True, scale=scale, o32=buf)
+        rel = lambda x, r: float((x.double().cpu() - r).norm() / r.norm())
+        err[tag] = (rel(dq, qr.grad), rel(dk, kr.grad), rel(dv, vr.grad))
+    print("attention backward relative L2 error (dq, dk, dv):", err)
+    assert max(err["fp32_O"]) < 1e-2, err
+    assert err["fp32_O"][0] < 0.6 * err["bf16_O"][0] and err["fp32_O"][1] < 0.6 * err["bf16_O"][1], err
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("d,T", [(32, 96), (64, 200)])
 def test_attention_dropout_consistency(ops, dtype, d, T):
@@ -436,6 +469,29 @@ def test_conv1_fwd_wgrad(ops, dtype, shape):
     ops.conv1_wgrad(x.to(dev()), dy.to(dev(), dtype), dw, db)
     close("conv1 dw", dw, wr.grad, torch.float32, scale=16)
     close("conv1 db", db, br.grad, torch.float32, scale=16)
+
+
+def test_conv1_wgrad_fp32_accuracy_at_the_benchmark_image(ops):
+    """fp32 parity mode at 161 x 800 (the benchmark's spectrogram): the first layer's weight gradient is a sum of ~10^5
+    uncorrelated products per batch element (|g| ~ sqrt(N) |term|), so accumulation order matters.  Truth: fp64; the bound is
+    a small multiple of what torch's own fp32 convolution backward loses on the same tensors."""
+    g = torch.Generator().manual_seed(8)
+    B, H, W, C0 = 2, 161, 800, 64
+    x = torch.randn(B, 1, H, W, generator=g)
+    x[1, :, :, 170:] = 0
+    dy = torch.randn(B, H, W, C0, generator=g) * (torch.rand(B, H, W, C0, generator=g) > 0.5)
+    w64 = torch.zeros(C0, 1, 3, 3, dtype=torch.float64, requires_grad=True)
+    b64 = torch.zeros(C0, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w64, b64, padding=1).backward(nchw(dy).double())
+    w32 = torch.zeros(C0, 1, 3, 3, requires_grad=True)
+    b32 = torch.zeros(C0, requires_grad=True)
+    F.conv2d(x, w32, b32, padding=1).backward(nchw(dy))
+    dw = torch.zeros(C0, 1, 3, 3, device=dev()); db = torch.zeros(C0, device=dev())
+    ops.conv1_wgrad(x.to(dev()), dy.to(dev()), dw, db)
+    rel = lambda a, r: float((a.double().cpu() - r).norm() / r.norm())
+    e = dict(ours_dw=rel(dw, w64.grad), torch_dw=rel(w32.grad, w64.grad), ours_db=rel(db, b64.grad), torch_db=rel(b32.grad, b64.grad))
+    print("conv1 wgrad fp32 relative L2 error vs fp64:", e)
+    assert e["ours_dw"] <= max(2e-5, 4 * e["torch_dw"]) and e["ours_db"] <= max(2e-5, 4 * e["torch_db"]), e
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
