@@ -10,6 +10,7 @@ rm -rf $out
 db=$(find $out -name "*.db" | head -1)
 if [ -n "$db" ]; then
   python $root/tools/prof_summary.py "$db" $steps "rocprofv3 --kernel-trace --stats -- $* ($steps steps in the trace: eager warm-up + capture + replays)" > $root/gpurun_out/${tag}_kernel_stats.txt 2>&1
+  python $root/tools/prof_timeline.py "$db" "timeline of the last 3 replayed steps: rocprofv3 --kernel-trace -- $*" > $root/gpurun_out/${tag}_timeline.txt 2>&1
 else
   echo "no rocpd database produced" > $root/gpurun_out/${tag}_kernel_stats.txt; ls -R $out | head -30 >> $root/gpurun_out/${tag}_kernel_stats.txt
 fi
