@@ -27,6 +27,8 @@ _P, _I, _L, _F, _U64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_f
 _SIGS = {
     "asr_strerror": (ctypes.c_char_p, [_I]),
     "asr_abi_version": (_I, []),
+    "asr_set_tuning": (_I, [ctypes.c_char_p, _L]),
+    "asr_clear_tuning": (_I, [ctypes.c_char_p]),
     "asr_prof_enable": (_I, [_I, _I]),
     "asr_prof_collect": (_I, [_I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64)]),
     "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
@@ -98,7 +100,36 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    _forward_env_tuning(lib)
     return lib
+
+
+# A/B switches of the library.  The library itself reads no environment variables: the ASR_<NAME>
+# variables present when the library is loaded are forwarded ONCE through asr_set_tuning(); set_tuning() changes them later.
+TUNING_NAMES = ("ATTN_GENERIC", "IGEMM_TH", "IGEMM_TPS", "IGEMM_WBUF", "CONV1_WGRAD_MFMA", "IGEMM_ABLATE", "C64", "CONV_POOL",
+                "WGRAD_ABLATE", "WGRAD_DMA", "CONV1_WGRAD_WGS", "C64_PER_CU", "C64_ABLATE", "C64_SHAPE", "GEMM_NS", "GEMM_TILE",
+                "GEMM_GENERIC", "TN_WGS", "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG")
+
+
+def _forward_env_tuning(lib):
+    for name in TUNING_NAMES:
+        v = os.environ.get("ASR_" + name)
+        if v is None:
+            continue
+        try:
+            iv = int(v)
+        except ValueError:
+            iv = 1                      # presence switches (ASR_ATTN_GENERIC=yes)
+        rc = lib.asr_set_tuning(name.encode(), iv)
+        if rc != 0:
+            raise RuntimeError("asr_set_tuning(%s) refused" % name)
+
+
+def set_tuning(name, value):
+    """Set (value is not None) or clear a tuning switch of the library, e.g. set_tuning("GEMM_TILE", 2)."""
+    lib = load()
+    rc = lib.asr_clear_tuning(name.encode()) if value is None else lib.asr_set_tuning(name.encode(), int(value))
+    check(rc, "asr_set_tuning(%s)" % name)
 
 
 class AsrHipError(RuntimeError):

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_d64_kernel(AttnArgs p) {
 }
 
 bool fast_ok(const AttnArgs& p, int d, int dtype) {
-  return dtype == ASR_BF16 && d == HD && p.vec && p.Tq > 0 && p.Tk > 0 && getenv("ASR_ATTN_GENERIC") == nullptr;
+  return dtype == ASR_BF16 && d == HD && p.vec && p.Tq > 0 && p.Tk > 0 && asr_tuning("ATTN_GENERIC", 0) == 0;
 }
 
 }  // namespace

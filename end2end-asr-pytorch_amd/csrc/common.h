@@ -127,6 +127,9 @@ static inline uint32_t asr_drop_threshold(float p) {
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// tuning switch set through asr_set_tuning (prof.hip), or `dflt`; the library itself reads no environment variables
+int64_t asr_tuning(const char* name, int64_t dflt);
+
 // profiling hook (prof.hip): brackets one launch with hipEvents when profiling of `op` is enabled.
 struct AsrProfScope {
   int op;

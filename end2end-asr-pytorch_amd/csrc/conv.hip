@@ -753,9 +753,9 @@ int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
 // +9 % (Cout 64) to +23 % (Cout 128) measured; ASR_IGEMM_WBUF=2 restores the double buffer.
 template <typename T, int NCO>
 int launch_igemm(const ConvArgs& a, hipStream_t s) {
-  static const int th = getenv("ASR_IGEMM_TH") ? atoi(getenv("ASR_IGEMM_TH")) : 16;
-  static const int tps = getenv("ASR_IGEMM_TPS") ? atoi(getenv("ASR_IGEMM_TPS")) : 1;
-  static const int wbuf = getenv("ASR_IGEMM_WBUF") ? atoi(getenv("ASR_IGEMM_WBUF")) : 1;
+  const int th = (int)asr_tuning("IGEMM_TH", 16);
+  const int tps = (int)asr_tuning("IGEMM_TPS", 1);
+  const int wbuf = (int)asr_tuning("IGEMM_WBUF", 1);
   if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1, 1>(a, s);
   if (sizeof(T) == 2 && NCO == 64 && tps == 2) return launch_igemm_t<T, NCO, 8, 2, 2>(a, s);
   if (wbuf == 1) return launch_igemm_t<T, NCO, 8, 1, 1>(a, s);
@@ -803,7 +803,7 @@ extern "C" int asr_conv1_wgrad(const float* x, const void* dy, float* dw, float*
   const size_t lds = (size_t)C0 * 10 * sizeof(float);
   AsrProfScope prof(ASR_OP_CONV1, s);
   // bf16 storage, 64 channels: matrix-core kernel with the pixel as contraction index (conv1_wgrad_mfma.hip)
-  static const bool mfma = !(getenv("ASR_CONV1_WGRAD_MFMA") && atoi(getenv("ASR_CONV1_WGRAD_MFMA")) == 0);
+  const bool mfma = asr_tuning("CONV1_WGRAD_MFMA", 1) != 0;
   if (mfma && dtype == ASR_BF16 && C0 == 64) return asr_conv1_wgrad_mfma_launch(x, (const bf16_t*)dy, dw, db, B, H, W, s);
   if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_wgrad_kernel<float>), dim3((unsigned)blocks), dim3(256), lds, s, x, (const float*)dy, dw, db, B, H, W, C0);
   else hipLaunchKernelGGL((conv1_wgrad_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), lds, s, x, (const bf16_t*)dy, dw, db, B, H, W, C0);
@@ -831,10 +831,10 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   ConvArgs p{};
   p.x = x; p.wk = wk; p.bias = bias; p.mask_src = mask_src; p.y = y;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = relu;
-  { const char* ab = getenv("ASR_IGEMM_ABLATE"); p.ablate = ab ? atoi(ab) : 0; }
+  p.ablate = (int)asr_tuning("IGEMM_ABLATE", 0);
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
   // the 64 -> 64 channel bf16 layer (full-resolution conv2 and its dgrad) has a persistent kernel with register-resident weights
-  static const bool c64 = !(getenv("ASR_C64") && atoi(getenv("ASR_C64")) == 0);
+  const bool c64 = asr_tuning("C64", 1) != 0;
   if (c64 && dtype == ASR_BF16 && Cin == 64 && Cout == 64 && (int64_t)B * H * W * 128 < ((int64_t)1 << 32) && !p.ablate) {
     C64Args a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
@@ -854,7 +854,7 @@ extern "C" int asr_conv3x3_relu_pool(const void* x, const void* wk, const float*
   if (dtype != ASR_BF16 || Cin != 64 || Cout != 64 || !aligned16(x) || !aligned16(wk) || !aligned16(y) || !aligned16(pool) ||
       (int64_t)B * H * W * 128 >= ((int64_t)1 << 32))
     return ASR_EUNSUPPORTED;
-  static const bool fused = !(getenv("ASR_CONV_POOL") && atoi(getenv("ASR_CONV_POOL")) == 0);
+  const bool fused = asr_tuning("CONV_POOL", 1) != 0;
   if (!fused) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
@@ -951,7 +951,7 @@ extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, 
   p.tiles_h = (H + 7) / 8; p.tiles_w = (W + 15) / 16;
   p.npatch = B * p.tiles_h * p.tiles_w;
   p.nci = Cin / 64;
-  static const int ablate = getenv("ASR_WGRAD_ABLATE") ? atoi(getenv("ASR_WGRAD_ABLATE")) : 0;
+  const int ablate = (int)asr_tuning("WGRAD_ABLATE", 0);
   p.ablate = ablate;
   int wgx, blocks_y;
   wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &p.patches_per_wg);
@@ -960,7 +960,7 @@ extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, 
   const size_t lds = (size_t)(180 + 128) * (64 * esz + 16);
   AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
   // bf16 with a workspace: the LDS-DMA pipelined kernel (conv_wgrad_dma.hip); same grid, same partial-block layout
-  static const bool dma = !(getenv("ASR_WGRAD_DMA") && atoi(getenv("ASR_WGRAD_DMA")) == 0);
+  const bool dma = asr_tuning("WGRAD_DMA", 1) != 0;
   const int64_t cmax = Cin > Cout ? Cin : Cout;
   if (dma && dtype == ASR_BF16 && p.ws && (int64_t)B * H * W * cmax * 2 < ((int64_t)1 << 32)) {
     WgdArgs q{};

@@ -190,7 +190,7 @@ int asr_conv1_wgrad_mfma_launch(const float* x, const bf16_t* dy, float* dw, flo
       return ASR_ELAUNCH;
     granted = true;
   }
-  const int per_cu = getenv("ASR_CONV1_WGRAD_WGS") ? atoi(getenv("ASR_CONV1_WGRAD_WGS")) : 2;
+  const int per_cu = (int)asr_tuning("CONV1_WGRAD_WGS", 2);
   const unsigned grid = (unsigned)(nt < 256 * per_cu ? nt : 256 * per_cu);     // every workgroup ends with 640 atomics
   hipLaunchKernelGGL(conv1_wgrad_mfma_kernel, dim3(grid), dim3(256), lds, s, x, dy, dw, db, B, H, W, tiles_w, (int)nt);
   ASR_LAUNCH_CHECK();

@@ -390,8 +390,8 @@ int launch_t(C64Args p, hipStream_t s) {
       return ASR_ELAUNCH;
     granted = true;
   }
-  const char* pc = getenv("ASR_C64_PER_CU");          // tuning: workgroups per CU
-  const int64_t slots = (int64_t)cus * (pc ? atoi(pc) : (per_cu > 0 ? per_cu : 1));
+  const int pc = (int)asr_tuning("C64_PER_CU", 0);    // tuning: workgroups per CU (0 = what the occupancy query says)
+  const int64_t slots = (int64_t)cus * (pc > 0 ? pc : (per_cu > 0 ? per_cu : 1));
   const unsigned grid = (unsigned)(nt < slots ? nt : slots);
 #ifdef C64_TIMING
   static long long* dbg = nullptr;
@@ -420,11 +420,10 @@ int launch_t(C64Args p, hipStream_t s) {
 
 int asr_conv3x3_c64_launch(const C64Args& a_, hipStream_t s) {
   C64Args a = a_;
-  { const char* ab = getenv("ASR_C64_ABLATE"); a.ablate = ab ? atoi(ab) : 0; }
+  a.ablate = (int)asr_tuning("C64_ABLATE", 0);
   // shape (ASR_C64_SHAPE, tuning): 0 = two 4-wave workgroups per CU on 8 x 16 pixel tiles (default: the two workgroups are not in
   // phase, so one's address / epilogue VALU work overlaps the other's MFMAs); 1 / 2 = one 8-wave workgroup on 16 x 16 / 8 x 32 tiles
-  const char* sh = getenv("ASR_C64_SHAPE");
-  const int shape = sh ? atoi(sh) : 0;
+  const int shape = (int)asr_tuning("C64_SHAPE", 0);
   if (a.pool) {                      // pooled epilogue: forward with ReLU on the default shape only
     if (a.mask || !a.relu) return ASR_EUNSUPPORTED;
     return launch_t<16, 8, false, 3, true>(a, s);

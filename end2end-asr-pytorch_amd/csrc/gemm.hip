@@ -408,7 +408,7 @@ int launch_fast_ns(const GemmArgs& a, int splits, hipStream_t s) {
 }
 template <typename T, typename TO, int BM, int BN>
 int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
-  static const int ns = getenv("ASR_GEMM_NS") ? atoi(getenv("ASR_GEMM_NS")) : 1;      // LDS stages (tuning hook)
+  const int ns = (int)asr_tuning("GEMM_NS", 1);      // LDS stages (tuning hook)
   if (ns == 2) return launch_fast_ns<T, TO, BM, BN, 2>(a, splits, s);
   if (ns == 3) return launch_fast_ns<T, TO, BM, BN, 3>(a, splits, s);
   if (ns == 4) return launch_fast_ns<T, TO, BM, BN, 4>(a, splits, s);
@@ -417,10 +417,11 @@ int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
 
 template <typename T, typename TO>
 int dispatch_fast(const GemmArgs& a, int splits, hipStream_t s) {
-  if (const char* force = getenv("ASR_GEMM_TILE")) {          // tuning hook (tools/microbench.py)
-    if (force[0] == '0') return launch_fast<T, TO, 128, 128>(a, splits, s);
-    if (force[0] == '1') return launch_fast<T, TO, 128, 64>(a, splits, s);
-    if (force[0] == '2') return launch_fast<T, TO, 64, 64>(a, splits, s);
+  {                                                            // tuning hook (tools/microbench.py): -1 = automatic
+    const int force = (int)asr_tuning("GEMM_TILE", -1);
+    if (force == 0) return launch_fast<T, TO, 128, 128>(a, splits, s);
+    if (force == 1) return launch_fast<T, TO, 128, 64>(a, splits, s);
+    if (force == 2) return launch_fast<T, TO, 64, 64>(a, splits, s);
   }
   // Measured on MI355X (tools/microbench.py, profiles/r01_microbench_v5.txt): 64x64 tiles (8 workgroups per CU) win while the
   // grid is small; once 128x64 tiles still give >= ~1200 workgroups they tie or win (half the B-operand traffic through L2):
@@ -1107,7 +1108,7 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   AsrProfScope prof(ASR_OP_GEMM, stream);
   // fast path: LDS-DMA staging needs whole 16-B chunks everywhere and whole 128-byte K steps
   const bool fast = p.vecA && p.vecB && K > 0 && (K % bk == 0) && (kps % bk == 0) &&
-                    getenv("ASR_GEMM_GENERIC") == nullptr;
+                    asr_tuning("GEMM_GENERIC", 0) == 0;
   if (fast) {
     if (in_dtype == ASR_F32) return dispatch_fast<float, float>(p, splits, stream);
     if (out_dtype == ASR_BF16) return dispatch_fast<bf16_t, bf16_t>(p, splits, stream);
@@ -1122,7 +1123,7 @@ namespace {
 // slices over m: explicit, or automatic.  With a workspace the split costs one extra pass over splits*N*K floats, so the grid is
 // filled to ~2 workgroups per CU; without one the slices meet in fp32 atomics and are kept to the measured optimum (<= 4).
 int tn_splits(int M, int N, int K, int splits, int dtype, bool have_ws) {
-  static const int ASR_TN_TARGET_WGS = getenv("ASR_TN_WGS") ? atoi(getenv("ASR_TN_WGS")) : 512;
+  const int ASR_TN_TARGET_WGS = (int)asr_tuning("TN_WGS", 512);
   const int rm = dtype == ASR_F32 ? 64 : 128;
   const int ntiles = ((N + 63) / 64) * ((K + 63) / 64);
   const int stages = (M + rm - 1) / rm;
@@ -1147,8 +1148,8 @@ namespace {
 // 128 x 128-tile kernel: bf16, automatic split, a workspace, and enough 128-blocks that ~512 workgroups of >= 4 stages exist.
 // Returns the number of m-slices (0 = use the 64 x 64-tile kernel).
 int tn128_splits(int M, int N, int K, int splits, int dtype) {
-  static const int enabled = getenv("ASR_TN_128") ? atoi(getenv("ASR_TN_128")) : 1;
-  static const int min_tiles = getenv("ASR_TN_128_MIN") ? atoi(getenv("ASR_TN_128_MIN")) : 128;      // measured: wins for 512x5120 (160 blocks), loses for 64-block outputs
+  const int enabled = (int)asr_tuning("TN_128", 1);
+  const int min_tiles = (int)asr_tuning("TN_128_MIN", 128);      // measured: wins for 512x5120 (160 blocks), loses for 64-block outputs
   if (!enabled || dtype != ASR_BF16 || splits > 0 || N < 128 || K < 128) return 0;
   const int nt = ((N + 127) / 128) * ((K + 127) / 128);
   if (nt < min_tiles) return 0;
@@ -1194,7 +1195,7 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
       const int stages = (M + 63) / 64;
       q.m_per_split = ((stages + s128 - 1) / s128) * 64;
       AsrProfScope prof(ASR_OP_GEMM, stream);
-      static const int rm128 = getenv("ASR_TN_128_RM") ? atoi(getenv("ASR_TN_128_RM")) : 64;
+      const int rm128 = (int)asr_tuning("TN_128_RM", 64);
       if (rm128 == 128) {
         static bool granted = false;
         if (!granted) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 256); granted = true; }
@@ -1226,7 +1227,7 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   const int sps = (stages + splits - 1) / splits;
   p.m_per_split = sps * rm;
   p.ws = (have_ws && splits > 1) ? workspace : nullptr;
-  static const int nbuf = getenv("ASR_TN_NBUF") ? atoi(getenv("ASR_TN_NBUF")) : 1;       // LDS stages (tuning hook)
+  const int nbuf = (int)asr_tuning("TN_NBUF", 1);       // LDS stages (tuning hook)
   const size_t lds_stage = (size_t)(nbuf == 2 ? 2 : 1) * 2 * rm * (64 * esz);
   const size_t lds_epi = (size_t)2 * 64 * 64 * 4 + 4 * 64 * sizeof(float);
   const size_t lds = lds_stage > lds_epi ? lds_stage : lds_epi;
@@ -1267,7 +1268,7 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
   const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
-  static const int64_t nn_big = getenv("ASR_NN_BIG") ? atoll(getenv("ASR_NN_BIG")) : 800;      // 128x64 tiles from this many 64x64 tiles on
+  const int64_t nn_big = asr_tuning("NN_BIG", 800);      // 128x64 tiles from this many 64x64 tiles on
   const bool big = t64 >= nn_big && M > 64;
   if (in_dtype == ASR_F32) return big ? launch_nn<float, float, 128>(p, stream) : launch_nn<float, float, 64>(p, stream);
   if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);

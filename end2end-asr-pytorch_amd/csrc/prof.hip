@@ -4,6 +4,8 @@
 #include <vector>
 
 #include "common.h"
+#include <atomic>
+#include <string.h>
 
 namespace {
 struct Pair { hipEvent_t a, b; };
@@ -71,5 +73,44 @@ extern "C" int asr_prof_collect(int op, double* total_ms, int64_t* launches) {
   }
   *total_ms = tot;
   *launches = (int64_t)P.used;
+  return ASR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ tuning switches
+// The library reads NO environment variables: A/B switches are set through the ABI (asr_set_tuning) by the host layer
+// (asr_hip/lib.py forwards ASR_<NAME> variables once, at load).  Unknown names are refused.
+namespace {
+const char* const kTuningNames[] = {
+    "ATTN_GENERIC", "IGEMM_TH", "IGEMM_TPS", "IGEMM_WBUF", "CONV1_WGRAD_MFMA", "IGEMM_ABLATE", "C64", "CONV_POOL", "WGRAD_ABLATE",
+    "WGRAD_DMA", "CONV1_WGRAD_WGS", "C64_PER_CU", "C64_ABLATE", "C64_SHAPE", "GEMM_NS", "GEMM_TILE", "GEMM_GENERIC", "TN_WGS",
+    "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG"};
+constexpr int kNumTuning = (int)(sizeof(kTuningNames) / sizeof(kTuningNames[0]));
+std::atomic<int64_t> g_tuning_value[kNumTuning];
+std::atomic<bool> g_tuning_set[kNumTuning];
+int tuning_index(const char* name) {
+  for (int i = 0; i < kNumTuning; ++i)
+    if (strcmp(name, kTuningNames[i]) == 0) return i;
+  return -1;
+}
+}  // namespace
+
+int64_t asr_tuning(const char* name, int64_t dflt) {
+  const int i = tuning_index(name);
+  return (i >= 0 && g_tuning_set[i].load(std::memory_order_acquire)) ? g_tuning_value[i].load(std::memory_order_relaxed) : dflt;
+}
+
+extern "C" int asr_set_tuning(const char* name, int64_t value) {
+  if (!name) return ASR_EINVAL;
+  const int i = tuning_index(name);
+  if (i < 0) return ASR_EINVAL;
+  g_tuning_value[i].store(value, std::memory_order_relaxed);
+  g_tuning_set[i].store(true, std::memory_order_release);
+  return ASR_OK;
+}
+extern "C" int asr_clear_tuning(const char* name) {
+  if (!name) { for (int i = 0; i < kNumTuning; ++i) g_tuning_set[i].store(false, std::memory_order_release); return ASR_OK; }
+  const int i = tuning_index(name);
+  if (i < 0) return ASR_EINVAL;
+  g_tuning_set[i].store(false, std::memory_order_release);
   return ASR_OK;
 }

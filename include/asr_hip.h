@@ -42,6 +42,13 @@ enum {
 const char* asr_strerror(int code);
 int asr_abi_version(void);
 
+/* ---- tuning / A-B switches.  The library reads no environment variables and has no other mutable global state than
+ * this table and the profiling slots below: a switch (names: the ASR_* list of DESIGN.md section 4 without the prefix,
+ * e.g. "C64", "GEMM_TILE", "ATTN_GENERIC") keeps its built-in default until set here.  ASR_EINVAL for an unknown name.
+ * asr_clear_tuning(NULL) restores every default.                                                                */
+int asr_set_tuning(const char* name, int64_t value);
+int asr_clear_tuning(const char* name);
+
 /* ---- profiling: bracket every launch of one op id with hipEvents on its own stream ------------------------- */
 int asr_prof_enable(int op_id, int enable);           /* enable=1 starts a fresh capture for op_id            */
 int asr_prof_collect(int op_id, double* total_ms, int64_t* launches); /* synchronises the recorded events      */

@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "end2end-asr-pytorch_amd"))
 import torch
 
+from asr_hip import lib as L
 from asr_hip import ops
 
 D = torch.device("cuda:0")
@@ -38,10 +39,10 @@ def gemm():
         out = torch.empty(M, N, device=D, dtype=od)
         res = []
         for tile in "012":
-            os.environ["ASR_GEMM_TILE"] = tile
+            L.set_tuning("GEMM_TILE", int(tile))
             us = timeit(lambda: ops.gemm_nt(A, B, out=out, bias=bias))
             res.append("%s %6.1fus %5.0fTF" % (["128x128", "128x64", "64x64"][int(tile)], us, 2 * M * N * K / us / 1e6))
-        os.environ.pop("ASR_GEMM_TILE", None)
+        L.set_tuning("GEMM_TILE", None)
         print("  fwd   %5d %5d %5d -> %-8s %s" % (M, N, K, str(od)[6:], " | ".join(res)))
     print("== wgrad TN (natural layouts, tr reads)  dW(N,K) over M")
     for N, K, M in [(512, 512, 6400), (2048, 512, 6400), (512, 2048, 6400), (512, 5120, 6400), (4364, 512, 3200), (512, 512, 3200)]:
@@ -60,13 +61,13 @@ def gemm():
         g = torch.zeros(N, K, device=D)
         tiles = ((N + 127) // 128) * ((K + 127) // 128)
         for tile in "012":
-            os.environ["ASR_GEMM_TILE"] = tile
+            L.set_tuning("GEMM_TILE", int(tile))
             res = []
             for sp in (1, 2, 4, 8):
                 us = timeit(lambda: ops.gemm_nt(dyt, xt, out=g, accumulate=True, splits=sp))
                 res.append("s%d %6.1fus %5.0fTF" % (sp, us, 2 * M * N * K / us / 1e6))
             print("  wgrad %5d %5d %5d tile %s : %s" % (N, K, M, ["128x128", "128x64", "64x64"][int(tile)], " | ".join(res)))
-        os.environ.pop("ASR_GEMM_TILE", None)
+        L.set_tuning("GEMM_TILE", None)
 
 
 def conv():
