@@ -18,6 +18,7 @@ from tqdm import tqdm
 
 from utils import constant
 from utils.audio import gpu_front_end
+from utils.data_loader import DevicePrefetcher
 from utils.functions import save_model
 from utils.metrics import calculate_cer, calculate_metrics, calculate_wer
 
@@ -95,7 +96,9 @@ class Trainer():
             t0 = time.time()
             logging.info("TRAIN")
             model.train()
-            pbar = tqdm(iter(train_loader), leave=True, total=len(train_loader), disable=not rank0)
+            # batches arrive on the device one step ahead (pinned staging + copy stream, utils/data_loader.py)
+            feed = DevicePrefetcher(train_loader, torch.device("cuda", torch.cuda.current_device()) if constant.USE_CUDA else None)
+            pbar = tqdm(iter(feed), leave=True, total=len(train_loader), disable=not rank0)
             for i, data in enumerate(pbar):
                 r = self._run_batch(model, data, smoothing, loss_type, id2label, opt)
                 if r is None:

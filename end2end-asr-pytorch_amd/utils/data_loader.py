@@ -94,6 +94,56 @@ class AudioDataLoader(DataLoader):
         self.collate_fn = _collate_fn
 
 
+class DevicePrefetcher:
+    """Iterates a loader one batch AHEAD: while the model works on batch i, batch i+1 is collated by the loader's workers,
+    staged in pinned host memory and copied to the device on a copy stream of its own; the compute stream only waits for
+    the copy's event.  The reference blocks on `src.cuda()` inside the step (trainer.py:63-66) -- at (32,1,161,800) fp32 that
+    is 16.5 MB = 0.26 ms over PCIe Gen5 per step, 3 % of the accelerated step.  Yields the loader's tuples unchanged except
+    that the tensors (inputs, targets) already live on `device`.  device=None: plain pass-through (CPU runs, tests)."""
+
+    def __init__(self, loader, device=None, tensor_slots=(0, 1)):
+        self.loader, self.device, self.slots = loader, device, tuple(tensor_slots)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _stage(self, batch, stream):
+        out = list(batch)
+        with torch.cuda.stream(stream):
+            for i in self.slots:
+                t = out[i]
+                if torch.is_tensor(t) and not t.is_cuda:
+                    if not t.is_pinned():
+                        t = t.pin_memory()
+                    out[i] = t.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return out, ev
+
+    def __iter__(self):
+        if self.device is None or not torch.cuda.is_available():
+            for batch in self.loader:
+                yield batch
+            return
+        stream = torch.cuda.Stream(device=self.device)
+        it = iter(self.loader)
+        try:
+            nxt = self._stage(next(it), stream)
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._stage(next(it), stream)         # batch i+1: H2D in flight while batch i computes
+            except StopIteration:
+                nxt = None
+            torch.cuda.current_stream().wait_event(ev)
+            for i in self.slots:
+                if torch.is_tensor(cur[i]) and cur[i].is_cuda:
+                    cur[i].record_stream(torch.cuda.current_stream())
+            yield tuple(cur)
+
+
 class BucketingSampler(Sampler):
     """Consecutive bins of `batch_size` indices (data is assumed sorted by length), shuffled inside a bin at iteration
     time and across bins by shuffle().  With rank/world given (or torch.distributed initialised) every rank iterates a

@@ -655,3 +655,15 @@ def test_gpu_spectrogram_matches_host_convention(ops):
     raw, _ = ops.log_spectrogram(torch.from_numpy(wav[:2]).to(D), torch.tensor(lens[:2], dtype=torch.int32, device=D), normalize=False)
     ref = log_spectrogram(wav[1, :lens[1]], normalize=False)
     np.testing.assert_allclose(raw[1, 0, :, :ref.shape[1]].cpu().numpy(), ref, rtol=0, atol=1e-4)
+
+
+def test_device_prefetcher_delivers_device_batches():
+    from utils.data_loader import DevicePrefetcher
+    batches = [(torch.randn(4, 1, 161, 50 + i), torch.randint(0, 9, (4, 7)), torch.ones(4), torch.full((4,), 50 + i), None) for i in range(6)]
+    out = []
+    for b in DevicePrefetcher(batches, device=dev()):
+        assert b[0].is_cuda and b[1].is_cuda and not b[2].is_cuda
+        out.append((b[0] * 2).sum().item())          # consume on the compute stream
+    assert len(out) == 6
+    for i, v in enumerate(out):
+        assert abs(v - float((batches[i][0] * 2).sum())) < 1e-2 * max(1.0, abs(v))

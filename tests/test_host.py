@@ -239,3 +239,14 @@ def test_library_reads_no_environment_and_tuning_goes_through_the_abi():
     assert h.asr_set_tuning(b"GEMM_TILE", 2) == 0 and h.asr_clear_tuning(b"GEMM_TILE") == 0
     assert h.asr_set_tuning(b"NO_SUCH_SWITCH", 1) != 0
     assert h.asr_clear_tuning(None) == 0
+
+
+def test_device_prefetcher_passes_batches_through_in_order():
+    """utils/data_loader.DevicePrefetcher: same tuples in the same order (host path: pass-through; the H2D overlap itself is
+    exercised by tests/test_gpu_train_cli.py, which trains through it)."""
+    import torch
+    from utils.data_loader import DevicePrefetcher
+    batches = [(torch.full((2, 3), float(i)), torch.full((2,), i, dtype=torch.int64), i, "x%d" % i, None) for i in range(5)]
+    got = list(DevicePrefetcher(batches, device=None))
+    assert len(got) == 5 and all(g[2] == i and torch.equal(g[0], batches[i][0]) for i, g in enumerate(got))
+    assert list(DevicePrefetcher([], device=None)) == []
