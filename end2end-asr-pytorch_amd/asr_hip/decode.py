@@ -109,6 +109,97 @@ class DecoderKVCache:
         return F_._linear_fwd(x, dec.output_linear.weight, None, out_dtype=torch.float32)
 
 
+class GraphedGreedyDecoder:
+    """The greedy loop as ONE captured hipGraph replayed per token.  Everything that changes between steps lives on the
+    device: the position (state[0]), the token buffer (argmax written in place), the caches.  Fixed shapes: the
+    self-attention always addresses the whole (B, max_len, H*d) cache and masks positions > t with a device-side key_len
+    (asr_decode_prepare), this position's key / value rows are appended by asr_kv_append at the device-side row.  A step is
+    ~15 launches per layer; replayed they cost no host time (the eager cached loop is bound by ~60 Python-issued launches per
+    token)."""
+
+    def __init__(self, decoder, encoder_padded_outputs, max_len):
+        self.dec = decoder
+        self.cache = DecoderKVCache(decoder, encoder_padded_outputs, max_len)
+        c = self.cache
+        dev = encoder_padded_outputs.device
+        self.B, self.max_len = c.B, max_len
+        self.state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.key_len = torch.zeros(c.B, dtype=torch.int32, device=dev)
+        pe = decoder.positional_encoding.pe[0]
+        self.pe = pe[:max_len].float().contiguous()
+        self.pe_cur = torch.zeros((1, pe.shape[1]), dtype=torch.float32, device=dev)
+        self.tok = torch.full((c.B,), constant.SOS_TOKEN, dtype=torch.int64, device=dev)
+        self.done = torch.zeros(c.B, dtype=torch.bool, device=dev)
+        self.out = torch.zeros((max_len, c.B), dtype=torch.int64, device=dev)
+        for i in range(len(c.self_k)):               # positions > t are masked, but must hold finite numbers
+            c.self_k[i].zero_()
+            c.self_v[i].zero_()
+        self.graph = None
+
+    def _attend(self, attn_mod, x, q_in, k, v, key_len):
+        c = self.cache
+        B = x.shape[0]
+        HD = c.H * c.dk
+        o, _, _ = ops.attn_fwd(q_in.view(B, 1, HD), k, v, c.H, c.dk, key_len=key_len, scale=1.0 / (c.dk ** 0.5))
+        y = F_._linear_fwd(o.view(B, HD), attn_mod.output_linear.weight, attn_mod.output_linear.bias)
+        out, _, _ = ops.add_ln_fwd(y, x, attn_mod.layer_norm.weight.data, attn_mod.layer_norm.bias.data)
+        return out
+
+    def _step(self):
+        dec, c = self.dec, self.cache
+        B = self.B
+        ops.decode_prepare(self.pe, self.pe_cur, self.key_len, self.state)
+        x = ops.embed_fwd(self.tok.view(B, 1), dec.trg_embedding.weight.data, self.pe_cur, dec.x_logit_scale, 0.0, 0,
+                          ops.compute_dtype()).view(B, -1)
+        for i, layer in enumerate(dec.layers):
+            sa = layer.self_attn
+            q = F_._linear_fwd(x, sa.query_linear.weight, sa.query_linear.bias)
+            kt = F_._linear_fwd(x, sa.key_linear.weight, sa.key_linear.bias)
+            vt = F_._linear_fwd(x, sa.value_linear.weight, sa.value_linear.bias)
+            ops.kv_append(kt, vt, c.self_k[i], c.self_v[i], self.state)
+            x = self._attend(sa, x, q, c.self_k[i], c.self_v[i], self.key_len)
+            ca = layer.encoder_attn
+            q = F_._linear_fwd(x, ca.query_linear.weight, ca.query_linear.bias)
+            x = self._attend(ca, x, q, c.cross[i][0], c.cross[i][1], None)
+            ff = layer.pos_ffn
+            w1, w2 = (ff.conv_1, ff.conv_2) if hasattr(ff, "conv_1") else (ff.linear_1, ff.linear_2)
+            h = F_._linear_fwd(x, w1.weight, w1.bias, relu=True)
+            y = F_._linear_fwd(h, w2.weight, w2.bias)
+            x, _, _ = ops.add_ln_fwd(y, x, ff.layer_norm.weight.data, ff.layer_norm.bias.data)
+        logits = F_._linear_fwd(x, dec.output_linear.weight, None, out_dtype=torch.float32)
+        ops.argmax_rows(logits, out=self.tok)
+        self.done |= self.tok.eq(constant.EOS_TOKEN)
+        ops.decode_advance(self.state)
+
+    @torch.no_grad()
+    def run(self, steps, check_every=32):
+        """-> token ids (B, n <= steps).  Two eager steps (warm-up: shadows, workspaces), capture, then replays."""
+        n = 0
+        for _ in range(min(2, steps)):
+            self._step()
+            self.out[n].copy_(self.tok)
+            n += 1
+        if n < steps:
+            torch.cuda.synchronize()
+            if self.graph is None:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self._step()
+            while n < steps:
+                self.graph.replay()
+                self.out[n].copy_(self.tok)
+                n += 1
+                if n % check_every == 0 and bool(self.done.all()):
+                    break
+        return self.out[:n].t().contiguous()
+
+
+@torch.no_grad()
+def greedy_search_graphed(decoder, encoder_padded_outputs, steps=300):
+    """Same tokens as greedy_search below, one hipGraph replay per token."""
+    return GraphedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps).run(steps)
+
+
 @torch.no_grad()
 def greedy_search(decoder, encoder_padded_outputs, steps=300, check_every=16):
     """Token ids (B, n<=steps) of the reference's greedy loop (transformer.py:316-394): argmax fed back for `steps`

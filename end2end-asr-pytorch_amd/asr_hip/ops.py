@@ -346,10 +346,31 @@ def ce_fwd(logits, gold, smoothing, pad_id, sums=None):
     return lse, am, sums
 
 
-def argmax_rows(logits):
+def decode_prepare(pe, pe_cur, key_len, state):
+    """pe (T,D) fp32, state (>=1) int64 on the device: pe_cur = pe[state[0]], key_len[:] = state[0] + 1."""
+    assert pe.dtype == torch.float32 and pe.is_contiguous() and pe_cur.dtype == torch.float32 and key_len.dtype == torch.int32
+    L.call("asr_decode_prepare", L.ptr(pe), pe.shape[1], L.ptr(pe_cur), L.ptr(key_len), key_len.numel(), L.ptr(state), 0, L.stream())
+
+
+def decode_advance(state):
+    L.call("asr_decode_prepare", None, 0, None, None, 0, L.ptr(state), 1, L.stream())
+
+
+def kv_append(k_src, v_src, k_cache, v_cache, state):
+    """k_src / v_src (B, ncols) (row stride free) -> k_cache / v_cache (B, max_len, ncols) at row state[0]."""
+    B, ncols = k_src.shape
+    assert k_src.stride(1) == 1 and v_src.stride(1) == 1 and k_src.stride(0) == v_src.stride(0)
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == (B, k_cache.shape[1], ncols)
+    L.call("asr_kv_append", L.ptr(k_src), L.ptr(v_src), k_src.stride(0), L.ptr(k_cache), L.ptr(v_cache), B, ncols,
+           k_cache.shape[1], L.ptr(state), L.dt(k_src), L.stream())
+
+
+def argmax_rows(logits, out=None):
     M, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1
-    out = torch.empty(M, device=logits.device, dtype=torch.int64)
+    if out is None:
+        out = torch.empty(M, device=logits.device, dtype=torch.int64)
+    assert out.dtype == torch.int64 and out.numel() == M and out.is_contiguous()
     L.call("asr_argmax_rows", L.ptr(logits), logits.stride(0), M, V, L.ptr(out), L.stream())
     return out
 

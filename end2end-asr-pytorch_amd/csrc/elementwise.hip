@@ -309,6 +309,51 @@ extern "C" int asr_embed_fwd(const int64_t* tok, const float* table, const float
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
+// ---- incremental decoding with a device-side position (one captured hipGraph serves every step) -----------------------
+// state[0] = position t of the token being fed.  pe_cur = pe[t]; key_len[b] = t + 1 (the self-attention of this step sees the
+// cache rows 0..t); `advance` != 0: afterwards state[0] = t + 1 (issued as the LAST launch of a step).
+__global__ __launch_bounds__(256) void decode_prepare_kernel(const float* __restrict__ pe, int D, float* __restrict__ pe_cur,
+                                                             int32_t* __restrict__ key_len, int B, int64_t* state, int advance) {
+  const int64_t t = state[0];
+  if (advance) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[0] = t + 1;
+    return;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < D; i += gridDim.x * 256) pe_cur[i] = pe[t * D + i];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < B; i += gridDim.x * 256) key_len[i] = (int32_t)(t + 1);
+}
+// rows (B, ncols) with row stride `src_ld` -> cache[b][t][0..ncols) for two caches (this position's key and value rows)
+template <typename T>
+__global__ __launch_bounds__(256) void kv_append_kernel(const T* __restrict__ k_src, const T* __restrict__ v_src, int64_t src_ld,
+                                                        T* __restrict__ k_cache, T* __restrict__ v_cache, int ncols, int max_len,
+                                                        const int64_t* __restrict__ state) {
+  const int64_t t = state[0];
+  if (t >= max_len) return;
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < ncols; c += 256) {
+    k_cache[((int64_t)b * max_len + t) * ncols + c] = k_src[(int64_t)b * src_ld + c];
+    v_cache[((int64_t)b * max_len + t) * ncols + c] = v_src[(int64_t)b * src_ld + c];
+  }
+}
+
+extern "C" int asr_decode_prepare(const float* pe, int D, float* pe_cur, int32_t* key_len, int B, int64_t* state, int advance,
+                                  hipStream_t s) {
+  ASR_CHECK_ARG(state && (advance || (pe && pe_cur && key_len && D > 0 && B >= 0)));
+  hipLaunchKernelGGL(decode_prepare_kernel, dim3(advance ? 1 : 4), dim3(256), 0, s, pe, D, pe_cur, key_len, B, state, advance);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+extern "C" int asr_kv_append(const void* k_src, const void* v_src, int64_t src_ld, void* k_cache, void* v_cache, int B, int ncols,
+                             int max_len, const int64_t* state, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(k_src && v_src && k_cache && v_cache && state && B >= 0 && ncols > 0 && max_len > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (B == 0) return ASR_OK;
+  if (dtype == ASR_F32) hipLaunchKernelGGL((kv_append_kernel<float>), dim3(B), dim3(256), 0, s, (const float*)k_src, (const float*)v_src, src_ld, (float*)k_cache, (float*)v_cache, ncols, max_len, state);
+  else hipLaunchKernelGGL((kv_append_kernel<bf16_t>), dim3(B), dim3(256), 0, s, (const bf16_t*)k_src, (const bf16_t*)v_src, src_ld, (bf16_t*)k_cache, (bf16_t*)v_cache, ncols, max_len, state);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 extern "C" int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable, int B, int T, int D, float scale,
                              float p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(tok && dout && dtable && B >= 0 && T > 0 && D > 0 && p >= 0.f && p < 1.f);

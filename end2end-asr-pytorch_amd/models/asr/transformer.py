@@ -223,13 +223,17 @@ class Decoder(nn.Module):
     def greedy_search(self, encoder_padded_outputs, beam_width=2, lm_rescoring=False, lm=None, lm_weight=0.1, c_weight=1,
                       use_cache=True):
         """1-best strings of the reference's 300-step greedy loop (transformer.py:316-394).  Needs --tgt-max-len >= 301.
-        use_cache=True decodes incrementally with per-layer key/value caches (asr_hip/decode.py); False re-runs the full
-        decoder over the prefix at every step like the reference -- same tokens either way (tests/test_gpu_decode.py)."""
+        use_cache=True decodes incrementally with per-layer key/value caches, one captured hipGraph replayed per token
+        (asr_hip/decode.py); "eager" the same without the graph; False re-runs the full decoder over the prefix at every step
+        like the reference -- same tokens every way (tests/test_gpu_decode.py)."""
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
-        if use_cache:
+        if use_cache == "eager":                      # cached, launches issued from Python per token
             from asr_hip.decode import greedy_search as cached_greedy
             toks = cached_greedy(self, encoder_padded_outputs, steps=300).cpu().tolist()
+        elif use_cache:                               # cached + one hipGraph replay per token (device-side position)
+            from asr_hip.decode import greedy_search_graphed
+            toks = greedy_search_graphed(self, encoder_padded_outputs, steps=300).cpu().tolist()
         else:
             B = encoder_padded_outputs.size(0)
             ys = torch.full((B, 1), constant.SOS_TOKEN, dtype=torch.int64, device=encoder_padded_outputs.device)

@@ -144,6 +144,15 @@ int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void*
 int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable_acc, int B, int T, int D, float scale,
                   float dropout_p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, asr_stream_t stream);
 
+/* ---- incremental (KV-cached) decoding with the position on the device: one captured hipGraph serves all 300 steps of
+ * the reference's greedy loop (models/asr/transformer.py:316-394).  state[0] = position t of the token being fed.
+ * asr_decode_prepare(advance=0): pe_cur[0..D) = pe[t], key_len[0..B) = t+1;  (advance=1): state[0] = t+1.
+ * asr_kv_append: k_src / v_src (B, ncols) rows (row stride src_ld) -> k_cache / v_cache (B, max_len, ncols) at row t.     */
+int asr_decode_prepare(const float* pe, int D, float* pe_cur, int32_t* key_len, int B, int64_t* state, int advance,
+                       asr_stream_t stream);
+int asr_kv_append(const void* k_src, const void* v_src, int64_t src_ld, void* k_cache, void* v_cache, int B, int ncols,
+                  int max_len, const int64_t* state, int dtype, asr_stream_t stream);
+
 /* ---- label-smoothed cross entropy + argmax + num_correct (utils/metrics.py:78-132, transformer.py:80) ---------
  * logits (M, ld) fp32.  sums[0] += sum of row losses over non-PAD rows, sums[1] += #non-PAD rows,
  * sums[2] += #(argmax == gold) over non-PAD rows.  argmax = lowest index among maxima.                        */

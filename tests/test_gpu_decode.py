@@ -53,9 +53,10 @@ def test_greedy_and_beam_cached_match_uncached(precision):
     dec = model.decoder
     g = torch.Generator().manual_seed(5)
     enc = torch.randn(2, 12, 512, generator=g).cuda()
-    a = dec.greedy_search(enc, use_cache=True)
+    a = dec.greedy_search(enc, use_cache=True)           # one hipGraph replay per token
     b = dec.greedy_search(enc, use_cache=False)
-    assert a == b and len(a) == 2
+    c = dec.greedy_search(enc, use_cache="eager")
+    assert a == b == c and len(a) == 2
     ia, sa = dec.beam_search(enc, beam_width=3, nbest=2, use_cache=True)
     ib, sb = dec.beam_search(enc, beam_width=3, nbest=2, use_cache=False)
     assert sa == sb and ia == ib
@@ -91,7 +92,7 @@ def _error_counts(strs_hyps, strs_gold):
     return [tc, tch, tw, twd]
 
 
-@pytest.mark.parametrize("use_cache", [True, False])
+@pytest.mark.parametrize("use_cache", [True, "eager", False])
 def test_decode_strings_and_cer_match_the_reference(golden_dir, use_cache):
     """fp32 mode: Transformer.evaluate() greedy and beam-4 produce the REFERENCE's strings (tests/golden/dec_tiny.npz: the
     reference's own evaluate() on a model the reference trained for 170 steps; greedy CER 17/34, beam CER 30/34) and
@@ -112,7 +113,7 @@ def test_decode_strings_and_cer_match_the_reference(golden_dir, use_cache):
     assert beam == [str(s) for s in z["beam"]]
     assert _error_counts(greedy, strs_gold) == [int(v) for v in z["greedy_cer"]]
     assert _error_counts(beam, strs_gold) == [int(v) for v in z["beam_cer"]]
-    if use_cache:       # the public entry point (reference transformer.py:87-124)
+    if use_cache is True:       # the public entry point (reference transformer.py:87-124)
         _, hyps, golds = model.evaluate(src, src_len, tgt, beam_search=True, beam_width=int(z["beam_width"]), beam_nbest=1,
                                         c_weight=0.1)
         assert hyps == beam and golds == strs_gold
