@@ -581,3 +581,27 @@ class CEFn(Function):
             count = ops.ones_scalar(logits.device)
         dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, dloss.reshape(1).float().contiguous(), count)
         return dl.view(ctx.shape), None, None, None, None
+
+
+class CTCFn(Function):
+    """loss = F.ctc_loss(F.log_softmax(pred, 2).transpose(0, 1), gold, input_lengths, target_lengths, reduction="mean")
+    (reference: utils/metrics.py:133-154; blank = PAD = 0)."""
+
+    @staticmethod
+    def forward(ctx, pred, gold, input_lengths, target_lengths, blank):
+        logits = pred if pred.dtype == torch.float32 else pred.float()
+        logits = logits.contiguous()
+        dev = logits.device
+        tg = gold.to(device=dev, dtype=torch.int64).contiguous()
+        il = torch.as_tensor(input_lengths).to(device=dev, dtype=torch.int32).contiguous()
+        tl = torch.as_tensor(target_lengths).to(device=dev, dtype=torch.int32).contiguous()
+        loss, ws = ops.ctc_fwd(logits, tg, il, tl, blank)
+        ctx.t = (logits, tg, il, tl, ws)
+        ctx.blank = blank
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, tg, il, tl, ws = ctx.t
+        dl = ops.ctc_bwd(logits, tg, il, tl, ws, dloss.reshape(1).float().contiguous(), ctx.blank)
+        return dl, None, None, None, None

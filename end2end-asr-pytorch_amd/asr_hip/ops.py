@@ -346,6 +346,29 @@ def ce_fwd(logits, gold, smoothing, pad_id, sums=None):
     return lse, am, sums
 
 
+def ctc_fwd(logits, targets, input_lengths, target_lengths, blank=0):
+    """logits (B,T,V) fp32, targets (B,Lmax) int64, lengths (B) int32 on the device -> (loss (1,), workspace)."""
+    B, T, V = logits.shape
+    Lmax = max(1, targets.shape[1])
+    assert logits.dtype == torch.float32 and logits.is_contiguous() and targets.dtype == torch.int64 and targets.is_contiguous()
+    assert input_lengths.dtype == torch.int32 and target_lengths.dtype == torch.int32 and targets.shape[1] >= 1
+    n = L.load().asr_ctc_workspace(B, T, Lmax)
+    ws = torch.empty(n, device=logits.device, dtype=torch.float32)
+    loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+    L.call("asr_ctc_fwd", L.ptr(logits), V, L.ptr(targets), L.ptr(input_lengths), L.ptr(target_lengths), B, T, V, Lmax, int(blank),
+           L.ptr(ws), n, L.ptr(loss), L.stream())
+    return loss, ws
+
+
+def ctc_bwd(logits, targets, input_lengths, target_lengths, ws, grad_out, blank=0):
+    B, T, V = logits.shape
+    Lmax = max(1, targets.shape[1])
+    dl = torch.empty((B, T, V), device=logits.device, dtype=torch.float32)
+    L.call("asr_ctc_bwd", L.ptr(logits), V, L.ptr(targets), L.ptr(input_lengths), L.ptr(target_lengths), B, T, V, Lmax, int(blank),
+           L.ptr(ws), L.ptr(grad_out), L.ptr(dl), V, L.stream())
+    return dl
+
+
 def decode_prepare(pe, pe_cur, key_len, state):
     """pe (T,D) fp32, state (>=1) int64 on the device: pe_cur = pe[state[0]], key_len[:] = state[0] + 1."""
     assert pe.dtype == torch.float32 and pe.is_contiguous() and pe_cur.dtype == torch.float32 and key_len.dtype == torch.int32

@@ -53,7 +53,16 @@ class Trainer():
         if opt is not None:
             opt.zero_grad()
         pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)
-        loss, sums = calculate_metrics(pred, gold, smoothing=smoothing, loss_type=loss_type, sync=False)
+        if loss_type == "ctc":
+            red = getattr(getattr(opt, "optimizer", None), "reducer", None) if opt is not None else None
+            if red is not None and red.active:
+                raise RuntimeError("--loss ctc is single-GPU here: the data-parallel loss normalisation (global token count in "
+                                   "the gradient buffer's stats slot) is implemented for the cross-entropy path only")
+            # reference trainer.py:81-85: input lengths = source percentages x decoder positions, targets' true lengths
+            sizes = (src_percentages.float() * int(pred.size(1))).int()
+            loss, sums = calculate_metrics(pred, gold, input_lengths=sizes, target_lengths=tgt_lengths, loss_type="ctc")
+        else:
+            loss, sums = calculate_metrics(pred, gold, smoothing=smoothing, loss_type=loss_type, sync=False)
         finite = torch.isfinite(loss.detach()).float()
         if dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(finite, op=dist.ReduceOp.MIN)        # skip on every rank or on none

@@ -43,8 +43,13 @@ def calculate_loss(pred, gold, input_lengths=None, target_lengths=None, smoothin
     """pred (B,T,V), gold (B,T) -> scalar loss (reference: metrics.py:102-132).
     ce: mean over non-PAD tokens of the label-smoothed row loss, smoothing mass eps/V on every class (metrics.py:124).
     global_count: optional device scalar replacing the local non-PAD count (exact loss under data parallelism)."""
+    if loss_type == "ctc":
+        # F.log_softmax + F.ctc_loss(reduction="mean") with blank = PAD (reference: metrics.py:133-154), one fused HIP path
+        if input_lengths is None or target_lengths is None:
+            raise ValueError("loss_type='ctc' needs input_lengths and target_lengths")
+        return F_.CTCFn.apply(pred, gold, input_lengths, target_lengths, constant.PAD_TOKEN)
     if loss_type != "ce":
-        raise NotImplementedError("only loss_type='ce' is on the accelerated path (CTC: SURVEY.md 8(f) #4)")
+        raise NotImplementedError("loss_type must be 'ce' or 'ctc'")
     loss, _, _ = F_.CEFn.apply(pred, gold, float(smoothing), constant.PAD_TOKEN, global_count)
     return loss
 
@@ -53,8 +58,10 @@ def calculate_metrics(pred, gold, input_lengths=None, target_lengths=None, smoot
                       global_count=None):
     """-> (loss, num_correct)  (reference: metrics.py:78-100).  num_correct is a Python int as in the reference
     (one device sync); pass sync=False to get the fp32 device tensor [loss_sum, count, num_correct] instead."""
+    if loss_type == "ctc":              # the reference returns (loss, None) (metrics.py:96-97)
+        return calculate_loss(pred, gold, input_lengths, target_lengths, smoothing, "ctc"), None
     if loss_type != "ce":
-        raise NotImplementedError("only loss_type='ce' is on the accelerated path (CTC: SURVEY.md 8(f) #4)")
+        raise NotImplementedError("loss_type must be 'ce' or 'ctc'")
     loss, sums, _ = F_.CEFn.apply(pred, gold, float(smoothing), constant.PAD_TOKEN, global_count)
     if sync:
         return loss, int(sums[2].item())

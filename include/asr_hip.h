@@ -144,6 +144,20 @@ int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void*
 int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable_acc, int B, int T, int D, float scale,
                   float dropout_p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, asr_stream_t stream);
 
+/* ---- CTC loss (utils/metrics.py:133-154: F.log_softmax over the vocabulary + F.ctc_loss(reduction="mean"), blank 0,
+ * zero_infinity=False) and its gradient w.r.t. the LOGITS (log-softmax included).  logits (B,T,ld) fp32, targets
+ * (B,Lmax) int64 (row b holds target_lengths[b] labels), lengths int32 on the device.  loss[0] = mean_b(nll_b /
+ * max(len_b,1)); an unreachable target gives +inf (the reference skips such a batch, trainer.py:87-90).  The workspace
+ * (asr_ctc_workspace floats) carries the lattice from asr_ctc_fwd to asr_ctc_bwd.  dlogits (B,T,ldo) fp32, columns
+ * >= V zeroed; grad_out: device scalar d(loss).                                                                  */
+int64_t asr_ctc_workspace(int B, int T, int Lmax);
+int asr_ctc_fwd(const float* logits, int64_t ld, const int64_t* targets, const int32_t* input_lengths,
+                const int32_t* target_lengths, int B, int T, int V, int Lmax, int blank, float* workspace,
+                int64_t workspace_floats, float* loss, asr_stream_t stream);
+int asr_ctc_bwd(const float* logits, int64_t ld, const int64_t* targets, const int32_t* input_lengths,
+                const int32_t* target_lengths, int B, int T, int V, int Lmax, int blank, const float* workspace,
+                const float* grad_out, float* dlogits, int64_t ldo, asr_stream_t stream);
+
 /* ---- incremental (KV-cached) decoding with the position on the device: one captured hipGraph serves all 300 steps of
  * the reference's greedy loop (models/asr/transformer.py:316-394).  state[0] = position t of the token being fed.
  * asr_decode_prepare(advance=0): pe_cur[0..D) = pe[t], key_len[0..B) = t+1;  (advance=1): state[0] = t+1.

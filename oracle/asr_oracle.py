@@ -272,6 +272,13 @@ def smoothed_ce(pred, gold, smoothing):
 
 
 # ------------------------------------------------------------------------------------------------ optimiser
+def ctc_loss(pred, gold, input_lengths, target_lengths):
+    """utils/metrics.py:133-154: log-softmax over the vocabulary, then torch's ctc_loss with blank = 0, reduction="mean"
+    (per-utterance negative log-likelihood / target length, averaged over the batch), zero_infinity=False."""
+    log_probs = F.log_softmax(pred.transpose(0, 1), dim=2)            # T x B x C  (:134, :153)
+    return F.ctc_loss(log_probs, gold, input_lengths, target_lengths, reduction="mean")        # :154
+
+
 def noam_rate(step, model_size, factor, warmup, min_lr):
     """utils/optimizer.py:27-32."""
     return max(min_lr, factor * (model_size ** (-0.5) * min(step ** (-0.5), step * warmup ** (-1.5))))

@@ -63,3 +63,28 @@ def test_oracle_decode_matches_reference_strings_and_cer(golden_dir):
     assert beam == [str(s) for s in z["beam"]]
     assert list(O.eval_error_counts(greedy, strs_gold)) == [int(v) for v in z["greedy_cer"]]
     assert list(O.eval_error_counts(beam, strs_gold)) == [int(v) for v in z["beam_cer"]]
+
+
+def test_oracle_ctc_is_the_reference_expression():
+    """oracle.ctc_loss restates utils/metrics.py:133-154 (log_softmax + F.ctc_loss(mean)); pinned by a brute-force sum over all
+    alignments of a tiny case: p(l|x) = sum over paths that collapse to l."""
+    import itertools
+    import torch
+    from oracle import asr_oracle as O
+    g = torch.Generator().manual_seed(0)
+    T, V = 4, 3
+    pred = torch.randn(1, T, V, generator=g).double()
+    tgt = torch.tensor([[1, 2]])
+    lp = torch.log_softmax(pred[0], dim=1)
+    total = 0.0
+    for path in itertools.product(range(V), repeat=T):
+        col, prev = [], None
+        for s in path:
+            if s != prev and s != 0:
+                col.append(s)
+            prev = s
+        if col == [1, 2]:
+            total += float(torch.exp(sum(lp[t, s] for t, s in enumerate(path))))
+    ref = -torch.log(torch.tensor(total, dtype=torch.float64)) / 2          # reduction="mean": / target length, mean over the batch of 1
+    got = O.ctc_loss(pred, tgt, torch.tensor([T]), torch.tensor([2]))
+    assert abs(float(got) - float(ref)) < 1e-12
