@@ -605,3 +605,89 @@ class CTCFn(Function):
         logits, tg, il, tl, ws = ctx.t
         dl = ops.ctc_bwd(logits, tg, il, tl, ws, dloss.reshape(1).float().contiguous(), ctx.blank)
         return dl, None, None, None, None
+
+
+# ================================================================================================ composable pieces
+# The fused sub-layer Functions above cover the reference's layers.  The low-rank variant (BASELINE configs[4]) factorises
+# every projection W (out, in) into V (out, r) . U (r, in); its sub-layers are assembled from LinearFn plus these two.
+class SDPAFn(Function):
+    """Scaled-dot-product attention on projected (B,T,H*d) tensors: softmax(Q K^T / sqrt(d) + masks) V with in-kernel
+    dropout (reference: models/common_layers.py:211-225, head split / merge at :185-195)."""
+
+    @staticmethod
+    def forward(ctx, Q, K, V, cfg):
+        H, dk = cfg["H"], cfg["dk"]
+        B, Tq, HD = Q.shape
+        seed = P.next_seed()
+        scale = 1.0 / (dk ** 0.5)
+        O32 = torch.empty((B, Tq, HD), device=Q.device, dtype=torch.float32) if (Q.dtype != torch.float32 and any(ctx.needs_input_grad)) else None
+        O, lse, _ = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
+                                 causal=cfg.get("causal", False), scale=scale, p=cfg["p"], seed=seed, o32=O32)
+        ctx.t = (Q, K, V, O, lse, O32)
+        ctx.cfg, ctx.seed, ctx.scale = cfg, seed, scale
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        Q, K, V, O, lse, O32 = ctx.t
+        cfg = ctx.cfg
+        dQ, dK, dV = ops.attn_bwd(Q, K, V, O, dO.contiguous(), lse, cfg["H"], cfg["dk"], key_len=cfg.get("key_len"),
+                                  key_pad=cfg.get("key_pad"), causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"],
+                                  seed=ctx.seed, o32=O32)
+        return dQ, dK, dV, None
+
+
+class AddLNFn(Function):
+    """out = LayerNorm(dropout(y) + residual) * row_keep   (reference: common_layers.py:140-141, :197-198 and the
+    `*= non_pad_mask` after every sub-layer)."""
+
+    @staticmethod
+    def forward(ctx, y, residual, gamma, beta, cfg):
+        shape = y.shape
+        D = shape[-1]
+        y2 = y.reshape(-1, D).clone() if y.requires_grad or y.data_ptr() == residual.data_ptr() else y.reshape(-1, D).contiguous()
+        r2 = residual.reshape(-1, D).contiguous()
+        seed = P.next_seed()
+        out, mean, rstd = ops.add_ln_fwd(y2, r2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=cfg["p"], seed=seed)
+        ctx.t = (y2, mean, rstd)                       # y2 now holds z = dropout(y) + residual
+        ctx.params, ctx.cfg, ctx.seed, ctx.shape = (gamma, beta), cfg, seed, shape
+        return out.view(shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, mean, rstd = ctx.t
+        gamma, beta = ctx.params
+        D = ctx.shape[-1]
+        d_res, d_y = ops.add_ln_bwd(dout.reshape(-1, D).contiguous(), z, mean, rstd, gamma.data, ctx.cfg.get("row_keep"),
+                                    P.grad_of(gamma), P.grad_of(beta), p=ctx.cfg["p"], seed=ctx.seed)
+        P.grad_ready(gamma, beta)
+        return d_y.view(ctx.shape), d_res.view(ctx.shape), None, None, None
+
+
+class LinearActFn(Function):
+    """y = act(x W^T + b) with act = ReLU or identity, for chains of projections: `relu` fuses the ReLU into this GEMM's
+    epilogue; `input_is_relu` says x is the ReLU output of the previous projection, whose mask (x > 0) is then applied in
+    THIS layer's data-gradient epilogue (the same fusion FFNFn uses), so no stand-alone activation kernel exists."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, input_is_relu):
+        cd = ops.compute_dtype()
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != cd:
+            x2 = x2.to(cd)
+        x2 = x2.contiguous()
+        y = _linear_fwd(x2, weight, bias, relu=relu)
+        ctx.x2, ctx.weight, ctx.bias = x2, weight, bias
+        ctx.in_shape, ctx.input_is_relu, ctx.need_dx = x.shape, input_is_relu, x.requires_grad
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        N = ctx.weight.shape[0]
+        dy_c = _as_compute(dy.reshape(-1, N))
+        dx = _linear_bwd(dy_c, ctx.x2, ctx.weight, ctx.bias, need_dx=ctx.need_dx,
+                         relu_mask=ctx.x2 if (ctx.input_is_relu and ctx.need_dx) else None)
+        P.grad_ready(*[p for p in (ctx.weight, ctx.bias) if p is not None])
+        if dx is not None:
+            dx = dx.view(ctx.in_shape)
+        return dx, None, None, None, None

@@ -12,7 +12,8 @@ import torch.nn as nn
 
 from asr_hip import functions as F_
 from asr_hip import ops
-from models.common_layers import MultiHeadAttention, PositionalEncoding, PositionwiseFeedForwardWithConv
+from models.common_layers import (LowRankMultiHeadAttention, LowRankPositionwiseFeedForward, MultiHeadAttention,
+                                  PositionalEncoding, PositionwiseFeedForwardWithConv)
 from utils import constant
 
 
@@ -95,7 +96,7 @@ class Encoder(nn.Module):
     src_max_length=2500)   (reference: transformer.py:126-180)"""
 
     def __init__(self, num_layers, num_heads, dim_model, dim_key, dim_value, dim_input, dim_inner, dropout=0.1,
-                 src_max_length=2500):
+                 src_max_length=2500, rank=0):
         super().__init__()
         self.dim_input, self.num_layers, self.num_heads = dim_input, num_layers, num_heads
         self.dim_model, self.dim_key, self.dim_value, self.dim_inner = dim_model, dim_key, dim_value, dim_inner
@@ -105,7 +106,7 @@ class Encoder(nn.Module):
         self.input_linear = nn.Linear(dim_input, dim_model)
         self.layer_norm_input = nn.LayerNorm(dim_model)
         self.positional_encoding = PositionalEncoding(dim_model, src_max_length)
-        self.layers = nn.ModuleList([EncoderLayer(num_heads, dim_model, dim_inner, dim_key, dim_value, dropout=dropout)
+        self.layers = nn.ModuleList([EncoderLayer(num_heads, dim_model, dim_inner, dim_key, dim_value, dropout=dropout, rank=rank)
                                      for _ in range(num_layers)])
 
     def forward(self, padded_input, input_lengths, need_attn=False):
@@ -127,8 +128,12 @@ class Encoder(nn.Module):
 class EncoderLayer(nn.Module):
     """EncoderLayer(num_heads, dim_model, dim_inner, dim_key, dim_value, dropout=0.1)   (reference: transformer.py:183-203)"""
 
-    def __init__(self, num_heads, dim_model, dim_inner, dim_key, dim_value, dropout=0.1):
+    def __init__(self, num_heads, dim_model, dim_inner, dim_key, dim_value, dropout=0.1, rank=0):
         super().__init__()
+        if rank > 0:          # Low-Rank Transformer (BASELINE configs[4]): every projection is V (out,r) . U (r,in)
+            self.self_attn = LowRankMultiHeadAttention(num_heads, dim_model, dim_key, dim_value, rank, dropout=dropout)
+            self.pos_ffn = LowRankPositionwiseFeedForward(dim_model, dim_inner, rank, dropout=dropout)
+            return
         self.self_attn = MultiHeadAttention(num_heads, dim_model, dim_key, dim_value, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForwardWithConv(dim_model, dim_inner, dropout=dropout)
 
@@ -146,7 +151,7 @@ class Decoder(nn.Module):
     dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False)   (reference: transformer.py:206-305)"""
 
     def __init__(self, id2label, num_src_vocab, num_trg_vocab, num_layers, num_heads, dim_emb, dim_model, dim_inner, dim_key,
-                 dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False):
+                 dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False, rank=0):
         super().__init__()
         self.sos_id, self.eos_id = constant.SOS_TOKEN, constant.EOS_TOKEN
         self.id2label = id2label
@@ -158,7 +163,7 @@ class Decoder(nn.Module):
         self.trg_embedding = nn.Embedding(num_trg_vocab, dim_emb, padding_idx=constant.PAD_TOKEN)
         self.positional_encoding = PositionalEncoding(dim_model, max_length=trg_max_length)
         self.dropout = nn.Dropout(dropout)
-        self.layers = nn.ModuleList([DecoderLayer(dim_model, dim_inner, num_heads, dim_key, dim_value, dropout=dropout)
+        self.layers = nn.ModuleList([DecoderLayer(dim_model, dim_inner, num_heads, dim_key, dim_value, dropout=dropout, rank=rank)
                                      for _ in range(num_layers)])
         self.output_linear = nn.Linear(dim_model, num_trg_vocab, bias=False)
         nn.init.xavier_normal_(self.output_linear.weight)
@@ -321,8 +326,13 @@ class Decoder(nn.Module):
 class DecoderLayer(nn.Module):
     """DecoderLayer(dim_model, dim_inner, num_heads, dim_key, dim_value, dropout=0.1)   (reference: transformer.py:519-545)"""
 
-    def __init__(self, dim_model, dim_inner, num_heads, dim_key, dim_value, dropout=0.1):
+    def __init__(self, dim_model, dim_inner, num_heads, dim_key, dim_value, dropout=0.1, rank=0):
         super().__init__()
+        if rank > 0:
+            self.self_attn = LowRankMultiHeadAttention(num_heads, dim_model, dim_key, dim_value, rank, dropout=dropout)
+            self.encoder_attn = LowRankMultiHeadAttention(num_heads, dim_model, dim_key, dim_value, rank, dropout=dropout)
+            self.pos_ffn = LowRankPositionwiseFeedForward(dim_model, dim_inner, rank, dropout=dropout)
+            return
         self.self_attn = MultiHeadAttention(num_heads, dim_model, dim_key, dim_value, dropout=dropout)
         self.encoder_attn = MultiHeadAttention(num_heads, dim_model, dim_key, dim_value, dropout=dropout)
         self.pos_ffn = PositionwiseFeedForwardWithConv(dim_model, dim_inner, dropout=dropout)

@@ -173,3 +173,69 @@ class PositionwiseFeedForward(nn.Module):
         cfg = dict(p=self.dropout.p if self.training else 0.0, row_keep=row_keep)
         return F_.FFNFn.apply(_to_compute(x), self.linear_1.weight, self.linear_1.bias, self.linear_2.weight,
                               self.linear_2.bias, self.layer_norm.weight, self.layer_norm.bias, cfg)
+
+
+# ================================================================================================ low-rank variant
+# BASELINE configs[4] / SURVEY 8(f) #4: the Low-Rank Transformer of the reference's authors (arXiv:1910.13923, cited in the
+# reference README; the reference tree holds no code for it -- parity unpinned, checked against the test suite's CPU
+# restatement).  Every projection W (out, in) of the attention and feed-forward sub-layers is replaced by a linear
+# encoder-decoder unit V (out, r) . U (r, in) with no non-linearity in between: 2 r (in + out) instead of in * out weights.
+class LowRankLinear(nn.Module):
+    """y = V (U x) + b.  state_dict keys: <name>.u.weight (rank, in), <name>.v.weight (out, rank), <name>.v.bias."""
+
+    def __init__(self, dim_in, dim_out, rank, bias=True):
+        super().__init__()
+        self.u = nn.Linear(dim_in, rank, bias=False)
+        self.v = nn.Linear(rank, dim_out, bias=bias)
+        nn.init.xavier_normal_(self.u.weight)
+        nn.init.xavier_normal_(self.v.weight)
+
+    def forward(self, x, relu=False, input_is_relu=False):
+        h = F_.LinearActFn.apply(_to_compute(x), self.u.weight, None, False, input_is_relu)
+        return F_.LinearActFn.apply(h, self.v.weight, self.v.bias, relu, False)
+
+
+class LowRankMultiHeadAttention(nn.Module):
+    """MultiHeadAttention (reference: common_layers.py:170-200) with low-rank query / key / value / output projections."""
+
+    def __init__(self, num_heads, dim_model, dim_key, dim_value, rank, dropout=0.1):
+        super().__init__()
+        self.num_heads, self.dim_model, self.dim_key, self.dim_value, self.rank = num_heads, dim_model, dim_key, dim_value, rank
+        self.query_linear = LowRankLinear(dim_model, num_heads * dim_key, rank)
+        self.key_linear = LowRankLinear(dim_model, num_heads * dim_key, rank)
+        self.value_linear = LowRankLinear(dim_model, num_heads * dim_value, rank)
+        self.output_linear = LowRankLinear(num_heads * dim_value, dim_model, rank)
+        self.layer_norm = nn.LayerNorm(dim_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
+                need_attn=False, kv_grad_box=None):
+        if key is not value:
+            raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
+        p = self.dropout.p if self.training else 0.0
+        q_in, kv_in = _to_compute(query), _to_compute(key)
+        cfg = dict(H=self.num_heads, dk=self.dim_key, p=p, key_len=key_len,
+                   key_pad=key_pad if key_pad is not None else _mask_to_u8(mask), causal=causal)
+        Q, K, V = self.query_linear(q_in), self.key_linear(kv_in), self.value_linear(kv_in)
+        O = F_.SDPAFn.apply(Q.contiguous(), K.contiguous(), V.contiguous(), cfg)
+        y = self.output_linear(O)
+        out = F_.AddLNFn.apply(y, q_in, self.layer_norm.weight, self.layer_norm.bias, dict(p=p, row_keep=row_keep))
+        return out, None
+
+
+class LowRankPositionwiseFeedForward(nn.Module):
+    """LN(dropout(W2 relu(W1 x)) + x) (reference: common_layers.py:124-142) with W1, W2 low rank."""
+
+    def __init__(self, dim_model, dim_hidden, rank, dropout=0.1):
+        super().__init__()
+        self.linear_1 = LowRankLinear(dim_model, dim_hidden, rank)
+        self.linear_2 = LowRankLinear(dim_hidden, dim_model, rank)
+        self.dropout = nn.Dropout(dropout)
+        self.layer_norm = nn.LayerNorm(dim_model)
+
+    def forward(self, x, row_keep=None):
+        p = self.dropout.p if self.training else 0.0
+        xc = _to_compute(x)
+        h = self.linear_1(xc, relu=True)
+        y = self.linear_2(h, input_is_relu=True)
+        return F_.AddLNFn.apply(y, xc, self.layer_norm.weight, self.layer_norm.bias, dict(p=p, row_keep=row_keep))

@@ -64,6 +64,8 @@ _FLAGS = [
     (("--precision",), dict(default="bf16", choices=["bf16", "fp32"])),
     (("--dist-backend",), dict(default="nccl")), (("--bucket-mb",), dict(default=32.0, type=_F)),
     (("--gpu-frontend",), dict(action="store_true")),
+    # Low-Rank Transformer (arXiv:1910.13923, BASELINE configs[4]): rank of every attention / feed-forward projection, 0 = full rank
+    (("--rank",), dict(default=0, type=_I)),
 ]
 
 parser = argparse.ArgumentParser(description="Transformer ASR on MI355X")

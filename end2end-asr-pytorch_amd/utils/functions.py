@@ -107,11 +107,11 @@ def init_transformer_model(args, label2id, id2label):
     ops.set_compute_dtype(torch.float32 if getattr(args, "precision", "bf16") == "fp32" else torch.bfloat16)
     encoder = Encoder(args.num_layers, num_heads=args.num_heads, dim_model=args.dim_model, dim_key=args.dim_key,
                       dim_value=args.dim_value, dim_input=args.dim_input, dim_inner=args.dim_inner,
-                      src_max_length=args.src_max_len, dropout=args.dropout)
+                      src_max_length=args.src_max_len, dropout=args.dropout, rank=getattr(args, "rank", 0))
     decoder = Decoder(id2label, num_src_vocab=len(label2id), num_trg_vocab=len(label2id), num_layers=args.num_layers,
                       num_heads=args.num_heads, dim_emb=args.dim_emb, dim_model=args.dim_model, dim_inner=args.dim_inner,
                       dim_key=args.dim_key, dim_value=args.dim_value, trg_max_length=args.tgt_max_len, dropout=args.dropout,
-                      emb_trg_sharing=args.emb_trg_sharing)
+                      emb_trg_sharing=args.emb_trg_sharing, rank=getattr(args, "rank", 0))
     model = Transformer(encoder, decoder, feat_extractor=args.feat_extractor)
     if args.parallel:
         model = HipDataParallel(model, device_ids=args.device_ids)

@@ -138,13 +138,25 @@ def layer_norm(x, g, b):
     return (x - mu) / torch.sqrt(var + 1e-5) * g + b
 
 
+def proj(w, name, x):
+    """x W^T + b for the projection `name`; the Low-Rank Transformer variant (arXiv:1910.13923 -- cited by the reference
+    README, no code in the reference tree: PARITY UNPINNED for this branch) stores it as a linear encoder-decoder unit
+    <name>.u.weight (r, in) / <name>.v.weight (out, r) / <name>.v.bias: y = V (U x) + b."""
+    if name + ".u.weight" in w:
+        return (x @ w[name + ".u.weight"].t()) @ w[name + ".v.weight"].t() + w[name + ".v.bias"]
+    W = w[name + ".weight"]
+    if W.dim() == 3:                     # Conv1d(k=1) storage of the feed-forward weights
+        W = W[:, :, 0]
+    return x @ W.t() + w[name + ".bias"]
+
+
 def multi_head_attention(w, p, q_in, kv_in, mask, H, dk, dv, return_attn=False):
     """models/common_layers.py:170-225.  mask: (B,Tq,Tk) bool, True = masked, or None."""
     B, Tq, _ = q_in.shape
     Tk = kv_in.shape[1]
-    q = (q_in @ w[p + "query_linear.weight"].t() + w[p + "query_linear.bias"]).view(B, Tq, H, dk)   # :181
-    k = (kv_in @ w[p + "key_linear.weight"].t() + w[p + "key_linear.bias"]).view(B, Tk, H, dk)       # :182
-    v = (kv_in @ w[p + "value_linear.weight"].t() + w[p + "value_linear.bias"]).view(B, Tk, H, dv)   # :183
+    q = proj(w, p + "query_linear", q_in).view(B, Tq, H, dk)         # :181
+    k = proj(w, p + "key_linear", kv_in).view(B, Tk, H, dk)           # :182
+    v = proj(w, p + "value_linear", kv_in).view(B, Tk, H, dv)         # :183
     q = q.permute(2, 0, 1, 3)                                        # (H,B,Tq,dk)  :185
     k = k.permute(2, 0, 1, 3)
     v = v.permute(2, 0, 1, 3)
@@ -154,7 +166,7 @@ def multi_head_attention(w, p, q_in, kv_in, mask, H, dk, dv, return_attn=False):
     a = torch.softmax(s, dim=-1)                                     # :221
     o = torch.matmul(a, v)                                           # :223  (H,B,Tq,dv)
     o = o.permute(1, 2, 0, 3).reshape(B, Tq, H * dv)                 # :194-195
-    o = o @ w[p + "output_linear.weight"].t() + w[p + "output_linear.bias"]                          # :197
+    o = proj(w, p + "output_linear", o)                              # :197
     out = layer_norm(o + q_in, w[p + "layer_norm.weight"], w[p + "layer_norm.bias"])                 # :198
     if return_attn:
         return out, a.reshape(H * B, Tq, Tk)
@@ -163,8 +175,9 @@ def multi_head_attention(w, p, q_in, kv_in, mask, H, dk, dv, return_attn=False):
 
 def pos_ffn(w, p, x, decisions=None):
     """models/common_layers.py:135-142 (Conv1d k=1 == Linear on the last dim).  decisions[p + "relu"]: see _relu."""
-    h = _relu(x @ w[p + "conv_1.weight"][:, :, 0].t() + w[p + "conv_1.bias"], (decisions or {}).get(p + "relu"))
-    y = h @ w[p + "conv_2.weight"][:, :, 0].t() + w[p + "conv_2.bias"]
+    n1, n2 = ("linear_1", "linear_2") if (p + "linear_1.u.weight") in w else ("conv_1", "conv_2")
+    h = _relu(proj(w, p + n1, x), (decisions or {}).get(p + "relu"))
+    y = proj(w, p + n2, h)
     return layer_norm(y + x, w[p + "layer_norm.weight"], w[p + "layer_norm.bias"])
 
 
