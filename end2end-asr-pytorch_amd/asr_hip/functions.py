@@ -676,7 +676,14 @@ class LinearActFn(Function):
         if x2.dtype != cd:
             x2 = x2.to(cd)
         x2 = x2.contiguous()
-        y = _linear_fwd(x2, weight, bias, relu=relu)
+        if ops.fp8_enabled() and cd == torch.bfloat16:
+            # fp8 forward (e4m3, one scale per tensor, fp32 accumulation on the K = 128 block-scaled MFMA); the backward pass
+            # below differentiates the bf16 expression (straight-through), from the bf16 operands
+            qa, sa = ops.quant_fp8(x2)
+            qb, sb = ops.quant_fp8(weight.data.view(weight.shape[0], -1))
+            y = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias.data if bias is not None else None, relu=relu)
+        else:
+            y = _linear_fwd(x2, weight, bias, relu=relu)
         ctx.x2, ctx.weight, ctx.bias = x2, weight, bias
         ctx.in_shape, ctx.input_is_relu, ctx.need_dx = x.shape, input_is_relu, x.requires_grad
         return y.view(*x.shape[:-1], weight.shape[0])

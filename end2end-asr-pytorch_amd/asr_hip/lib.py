@@ -49,6 +49,8 @@ _SIGS = {
     "asr_decoder_preprocess": (_I, [_P, _I, _I, _I, _P, _P, _P, _P, _P, _P]),
     "asr_embed_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _P]),
     "asr_embed_bwd": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _I, _P]),
+    "asr_quant_fp8": (_I, [_P, _L, _I, _I, _I, _P, _L, _P, _P]),
+    "asr_gemm_nt_fp8": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _P, _I, _I, _I, _I, _I, _P]),
     "asr_ctc_workspace": (_L, [_I, _I, _I]),
     "asr_ctc_fwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P]),
     "asr_ctc_bwd": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _L, _P]),

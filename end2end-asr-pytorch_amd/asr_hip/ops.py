@@ -346,6 +346,40 @@ def ce_fwd(logits, gold, smoothing, pad_id, sums=None):
     return lse, am, sums
 
 
+# ------------------------------------------------------------------------------------------------ fp8 projections
+_fp8 = {"on": False}
+
+
+def set_fp8(on):
+    """--precision fp8: the low-rank projections run their forward GEMMs on the fp8 MFMA (storage stays bf16)."""
+    _fp8["on"] = bool(on)
+
+
+def fp8_enabled():
+    return _fp8["on"]
+
+
+def quant_fp8(x):
+    """x (M,K) bf16/fp32 -> (q (M, Kp) uint8 e4m3 bytes, scale (2,) fp32 [amax, amax/448])."""
+    M, K = x.shape
+    assert x.stride(1) == 1
+    Kp = (K + 15) // 16 * 16
+    q = torch.empty((M, Kp), device=x.device, dtype=torch.uint8)
+    scale = torch.empty(2, device=x.device, dtype=torch.float32)
+    L.call("asr_quant_fp8", L.ptr(x), x.stride(0), M, K, L.dt(x), L.ptr(q), Kp, L.ptr(scale), L.stream())
+    return q, scale
+
+
+def gemm_nt_fp8(qa, sa, qb, sb, bias=None, relu=False, out_dtype=torch.bfloat16, K=None):
+    """C (M,N) = sa sb qa . qb^T (+ bias)(ReLU): qa (M,Kp), qb (N,Kp) e4m3 bytes from quant_fp8."""
+    M, N = qa.shape[0], qb.shape[0]
+    K = qa.shape[1] if K is None else K
+    out = torch.empty((M, N), device=qa.device, dtype=out_dtype)
+    L.call("asr_gemm_nt_fp8", L.ptr(qa), qa.stride(0), L.ptr(sa), L.ptr(qb), qb.stride(0), L.ptr(sb), L.ptr(out), out.stride(0),
+           L.ptr(bias), M, N, K, int(relu), L.dt_of(out_dtype), L.stream())
+    return out
+
+
 def ctc_fwd(logits, targets, input_lengths, target_lengths, blank=0):
     """logits (B,T,V) fp32, targets (B,Lmax) int64, lengths (B) int32 on the device -> (loss (1,), workspace)."""
     B, T, V = logits.shape

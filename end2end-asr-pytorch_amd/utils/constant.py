@@ -61,7 +61,7 @@ _FLAGS = [
     (("--max-norm",), dict(default=400, type=_F)), (("--dropout",), dict(default=0.1, type=_F)),
     (("--parallel",), dict(action="store_true")), (("--shuffle",), dict(action="store_true")),
     # MI355X path (additions)
-    (("--precision",), dict(default="bf16", choices=["bf16", "fp32"])),
+    (("--precision",), dict(default="bf16", choices=["bf16", "fp32", "fp8"])),     # fp8: bf16 storage, fp8 MFMA for the --rank projections
     (("--dist-backend",), dict(default="nccl")), (("--bucket-mb",), dict(default=32.0, type=_F)),
     (("--gpu-frontend",), dict(action="store_true")),
     # Low-Rank Transformer (arXiv:1910.13923, BASELINE configs[4]): rank of every attention / feed-forward projection, 0 = full rank

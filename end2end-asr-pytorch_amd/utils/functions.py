@@ -105,6 +105,7 @@ def init_transformer_model(args, label2id, id2label):
     else:
         print("the model is initialized without feature extractor")
     ops.set_compute_dtype(torch.float32 if getattr(args, "precision", "bf16") == "fp32" else torch.bfloat16)
+    ops.set_fp8(getattr(args, "precision", "bf16") == "fp8")
     encoder = Encoder(args.num_layers, num_heads=args.num_heads, dim_model=args.dim_model, dim_key=args.dim_key,
                       dim_value=args.dim_value, dim_input=args.dim_input, dim_inner=args.dim_inner,
                       src_max_length=args.src_max_len, dropout=args.dropout, rank=getattr(args, "rank", 0))

@@ -144,6 +144,16 @@ int asr_embed_fwd(const int64_t* tok, const float* table, const float* pe, void*
 int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable_acc, int B, int T, int D, float scale,
                   float dropout_p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, asr_stream_t stream);
 
+/* ---- fp8 (OCP e4m3fn) projections of the Low-Rank Transformer variant (BASELINE configs[4]).
+ * asr_quant_fp8: x (M,K) bf16/fp32 -> q (M, ldq >= K rounded up to 16; pad bytes zero) with ONE scale per tensor;
+ *   scale[0] = amax (workspace), scale[1] = amax / 448 (the dequantisation factor the GEMM multiplies in).
+ * asr_gemm_nt_fp8: C[M,N] = scale_a[1] * scale_b[1] * sum_k A[m,k] B[n,k] (+ bias[n]) (ReLU) on the K = 128 block-scaled
+ *   fp8 MFMA with unit block scales (fp32 accumulators; measured 3e-5 of the largest output off the exact product
+ *   of the decoded operands: the matrix core aligns a block's products before adding).  K multiple of 16.        */
+int asr_quant_fp8(const void* x, int64_t ld, int M, int K, int dtype, uint8_t* q, int64_t ldq, float* scale, asr_stream_t stream);
+int asr_gemm_nt_fp8(const uint8_t* A, int64_t lda, const float* scale_a, const uint8_t* B, int64_t ldb, const float* scale_b,
+                    void* C, int64_t ldc, const float* bias, int M, int N, int K, int relu, int out_dtype, asr_stream_t stream);
+
 /* ---- CTC loss (utils/metrics.py:133-154: F.log_softmax over the vocabulary + F.ctc_loss(reduction="mean"), blank 0,
  * zero_infinity=False) and its gradient w.r.t. the LOGITS (log-softmax included).  logits (B,T,ld) fp32, targets
  * (B,Lmax) int64 (row b holds target_lengths[b] labels), lengths int32 on the device.  loss[0] = mean_b(nll_b /

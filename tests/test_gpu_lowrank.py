@@ -78,3 +78,75 @@ def test_lowrank_model_matches_oracle(precision):
         assert perr <= 6e-2 * amax and abs(loss.item() - ref["loss"]) < 3e-2
         assert float(np.median(list(rel.values()))) <= 6e-2 and rel[worst] <= 0.25, (worst, rel[worst])
     opt.step()
+
+
+def _e4m3_decode(b):
+    """OCP e4m3fn byte -> float (CPU restatement of the format: 1-4-3, bias 7, no infinities, 0x7f/0xff = NaN)."""
+    b = b.to(torch.int32)
+    s = torch.where((b & 0x80) != 0, -1.0, 1.0).double()
+    e = ((b >> 3) & 0xF).double()
+    m = (b & 7).double()
+    v = torch.where(e == 0, m / 8.0 * 2.0 ** -6, (1 + m / 8.0) * 2.0 ** (e - 7))
+    return s * v
+
+
+@pytest.mark.parametrize("shape", [(200, 64, 512), (6400, 512, 64), (130, 70, 128), (64, 2048, 64), (333, 64, 2048)])
+def test_fp8_gemm_is_exact_on_its_quantised_operands(shape):
+    """asr_quant_fp8 + asr_gemm_nt_fp8: (1) the bytes decode (OCP e4m3fn) to within half an fp8 step of x * 448 / amax;
+    (2) the GEMM equals the float64 product of the DECODED operands to 1e-4 of the largest output (measured 3e-5: the
+    block-scaled matrix core aligns the 32 products of a block to their largest before adding -- about 2^-15 relative -- so it
+    is not bit-exact fp32 accumulation, but any operand-layout error of v_mfma_scale_f32_16x16x128_f8f6f4 would be O(1)); (3) against the un-quantised product the
+    relative L2 error is the e4m3 quantisation noise (3 mantissa bits: <= 4e-2 stated tolerance)."""
+    from asr_hip import ops
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16()
+    B = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, generator=g)
+    qa, sa = ops.quant_fp8(A.cuda())
+    qb, sb = ops.quant_fp8(B.cuda())
+    da, db = _e4m3_decode(qa.cpu())[:, :K], _e4m3_decode(qb.cpu())[:, :K]
+    assert abs(sa[1].item() - A.float().abs().max().item() / 448) < 1e-6 * sa[1].item() + 1e-12
+    xs = A.double() / sa[1].item()
+    step = torch.clamp(2.0 ** (torch.floor(torch.log2(xs.abs().clamp_min(2.0 ** -6))) - 3), min=2.0 ** -9)
+    assert ((da - xs).abs() <= 0.5 * step + 1e-9).all()
+    out = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias.cuda(), out_dtype=torch.float32, K=qa.shape[1])
+    exact = (da @ db.t()) * (sa[1].item() * sb[1].item()) + bias.double()
+    err = (out.double().cpu() - exact).abs().max().item()
+    assert err <= 1e-4 * exact.abs().max().item(), err
+    full = A.double() @ B.double().t() + bias.double()
+    rel = float((out.double().cpu() - full).norm() / full.norm())
+    print("fp8 gemm %s: rel L2 vs the unquantised product %.3e" % (shape, rel))
+    assert rel <= 4e-2, rel
+    relu = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias.cuda(), relu=True, out_dtype=torch.bfloat16, K=qa.shape[1])
+    assert (relu.float().cpu() - exact.clamp_min(0).float()).abs().max().item() <= 1.6e-2 * exact.abs().max().item()
+
+
+def test_lowrank_fp8_forward_close_to_bf16():
+    """--precision fp8: the r-rank projections' forward GEMMs on the fp8 MFMA.  Stated tolerance against the bf16 run of the
+    same model: logits within 0.15 * max|logit| and loss within 5e-2 (e4m3 has 3 mantissa bits; ~20 chained projections); the
+    backward pass is the bf16 straight-through one and must stay finite."""
+    from utils import constant
+    from utils.functions import init_optimizer
+    from utils.metrics import calculate_metrics
+    args, model, V = _build("bf16")
+    src, src_len, tgt = _batch(V)
+    model = model.cuda().train()
+    from asr_hip import ops
+    outs = {}
+    for mode in ("bf16", "fp8"):
+        ops.set_fp8(mode == "fp8")
+        opt = init_optimizer(args, model, "noam")
+        opt.zero_grad()
+        pred, gold, _, _ = model(src.cuda(), src_len, tgt.cuda())
+        loss, _ = calculate_metrics(pred, gold, smoothing=0.1, loss_type="ce")
+        loss.backward()
+        gn = float(sum(p.grad.float().pow(2).sum() for p in model.parameters()).sqrt())
+        outs[mode] = (pred.detach().float().cpu(), loss.item(), gn)
+    ops.set_fp8(False)
+    amax = outs["bf16"][0].abs().max().item()
+    d = (outs["fp8"][0] - outs["bf16"][0]).abs().max().item()
+    print("fp8 vs bf16 low-rank model: max |dlogit| %.3e (max |logit| %.2f), loss %.4f vs %.4f, |grad| %.3e vs %.3e"
+          % (d, amax, outs["fp8"][1], outs["bf16"][1], outs["fp8"][2], outs["bf16"][2]))
+    assert d > 0 and d <= 0.15 * amax and abs(outs["fp8"][1] - outs["bf16"][1]) < 5e-2
+    assert np.isfinite(outs["fp8"][2]) and abs(outs["fp8"][2] - outs["bf16"][2]) < 0.3 * outs["bf16"][2]
