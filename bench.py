@@ -181,9 +181,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 16 for --workload librispeech)")
-    ap.add_argument("--workload", default="headline", choices=["headline", "librispeech"],
-                    help="headline = BASELINE configs[1] (the judged metric); librispeech = configs[3] (12/6 layers, emb_cnn)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "librispeech", "lowrank"],
+                    help="headline = BASELINE configs[1] (the judged metric); librispeech = configs[3] (12/6 layers, emb_cnn); "
+                         "lowrank = configs[4] (12-layer d512 Low-Rank Transformer, r = 64; use --precision fp8 for its fp8 path)")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp8"])
     ap.add_argument("--dropout", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -199,10 +200,13 @@ def main():
     if world != a.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world))
     libri = a.workload == "librispeech"
+    lowrank = a.workload == "lowrank"
+    if a.precision == "fp8" and not lowrank:
+        raise SystemExit("bench.py: --precision fp8 is the fp8 path of the low-rank projections: use --workload lowrank")
     if a.batch is None:
         a.batch = LIBRI["B"] if libri else 32
     t_src, t_tgt, vocab = (LIBRI["T_SRC"], LIBRI["T_TGT"], LIBRI["V"]) if libri else (T_SRC, T_TGT, V)
-    mflop_per_frame = LIBRI["MFLOP_PER_FRAME"] if libri else MFLOP_PER_FRAME
+    mflop_per_frame = LIBRI["MFLOP_PER_FRAME"] if libri else (None if a.workload == "lowrank" else MFLOP_PER_FRAME)
 
     import torch
     import torch.distributed as dist
@@ -227,6 +231,8 @@ def main():
     flags = MODEL_FLAGS + ["--dropout", str(a.dropout), "--precision", a.precision, "--cuda", "--batch-size", str(a.batch)]
     if libri:
         flags += ["--feat_extractor", "emb_cnn", "--src-max-len", str(t_src)]
+    if lowrank:                              # argparse: the later --num-layers wins
+        flags += ["--num-layers", "12", "--rank", "64"]
     if world > 1 or force_ddp:
         flags.append("--parallel")
     args = constant.parse(flags)
@@ -249,7 +255,7 @@ def main():
     src, src_len, tgt = synthetic_batch(a.batch, torch, t_src, t_tgt, vocab)
     src, tgt = src.cuda(), tgt.cuda()
     sd_cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and not libri:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and not libri and not lowrank:
         core = model.module if hasattr(model, "module") else model
         sd_cpu = {k: v.detach().cpu().clone() for k, v in core.state_dict().items()}
 
@@ -308,7 +314,7 @@ def main():
     prof = None
     fam_ops = {"conv3x3_igemm (3 fwd + 3 dgrad)": L.OP_CONV_IGEMM, "conv3x3_wgrad": L.OP_CONV_WGRAD,
                "linear GEMMs (fwd + dgrad + wgrad)": L.OP_GEMM, "attention fwd": L.OP_ATTN_FWD, "attention bwd": L.OP_ATTN_BWD}
-    if not a.no_roofline and not libri:
+    if not a.no_roofline and not libri and not lowrank:
         prof_steps = min(a.steps, 3)
         for op in fam_ops.values():
             ops.prof_enable(op, True)
@@ -329,13 +335,17 @@ def main():
         ms = dt / a.steps * 1e3
         frames = a.batch * world * t_src * a.steps
         value = frames / dt
-        peak = PEAK_BF16_TFLOPS if a.precision == "bf16" else PEAK_F32_TFLOPS
+        peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         mode = "eager" if a.eager else ("hipGraph replay" if red is None or not red.active else
                                         "3 hipGraphs per step, RCCL all-reduces between them")
         out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic", "launch_mode": mode,
-               "config": {"workload": ("configs[3]: 12-enc/6-dec-layer d_model=512 heads=8 dim-inner=2048 emb_cnn Transformer ASR "
+               "config": {"workload": ("configs[4]: 12-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Low-Rank Transformer (every attention / "
+                                       "feed-forward projection rank 64) training step%s, synthetic (B=%%d/GPU,1,161,T_src=800) -> T_tgt=100, "
+                                       "V=4364, label smoothing 0.1, dropout %%.2f, random init" % (", fp8 (e4m3) forward projections" if a.precision == "fp8" else "")
+                                       if lowrank else
+                                       "configs[3]: 12-enc/6-dec-layer d_model=512 heads=8 dim-inner=2048 emb_cnn Transformer ASR "
                                        "training step, synthetic (B=%d/GPU,1,161,T_src=1600) -> T_tgt=100, V=32, label "
                                        "smoothing 0.1, dropout %.2f, random init" if libri else
                                        "configs[1]: 4-layer d_model=512 heads=8 dim-inner=2048 vgg_cnn Transformer ASR training "
@@ -346,8 +356,8 @@ def main():
                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                           "collective_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
                           "rank0_ms_per_step": dt_local / a.steps * 1e3,
-                          "step_tflops_whole_model": value * mflop_per_frame * 1e6 / 1e12,
-                          "frac_of_mfma_peak_whole_step": value * mflop_per_frame * 1e6 / 1e12 / (peak * world),
+                          "step_tflops_whole_model": (value * mflop_per_frame * 1e6 / 1e12) if mflop_per_frame else None,
+                          "frac_of_mfma_peak_whole_step": (value * mflop_per_frame * 1e6 / 1e12 / (peak * world)) if mflop_per_frame else None,
                           "final_loss": final_loss}}
         if exposure is not None:
             out["config"]["gradient_allreduce"] = dict(exposure, bytes=4 * red.flat.total_all,

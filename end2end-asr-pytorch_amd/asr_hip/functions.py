@@ -664,6 +664,17 @@ class AddLNFn(Function):
         return d_y.view(ctx.shape), d_res.view(ctx.shape), None, None, None
 
 
+def _fp8_weight(weight):
+    """e4m3 bytes + row scales of a weight, re-quantised when the optimiser stepped or the parameter was modified."""
+    key = (P._state["generation"], weight._version)
+    ent = weight.__dict__.get("_asr_fp8")
+    if ent is None or ent[0] != key:
+        q, sc = ops.quant_fp8(weight.data.view(weight.shape[0], -1))
+        ent = (key, q, sc)
+        weight.__dict__["_asr_fp8"] = ent
+    return ent[1], ent[2]
+
+
 class LinearActFn(Function):
     """y = act(x W^T + b) with act = ReLU or identity, for chains of projections: `relu` fuses the ReLU into this GEMM's
     epilogue; `input_is_relu` says x is the ReLU output of the previous projection, whose mask (x > 0) is then applied in
@@ -677,10 +688,10 @@ class LinearActFn(Function):
             x2 = x2.to(cd)
         x2 = x2.contiguous()
         if ops.fp8_enabled() and cd == torch.bfloat16:
-            # fp8 forward (e4m3, one scale per tensor, fp32 accumulation on the K = 128 block-scaled MFMA); the backward pass
+            # fp8 forward (e4m3, one scale per row of either operand, fp32 accumulation on the K = 128 block-scaled MFMA); the backward pass
             # below differentiates the bf16 expression (straight-through), from the bf16 operands
             qa, sa = ops.quant_fp8(x2)
-            qb, sb = ops.quant_fp8(weight.data.view(weight.shape[0], -1))
+            qb, sb = _fp8_weight(weight)
             y = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias.data if bias is not None else None, relu=relu)
         else:
             y = _linear_fwd(x2, weight, bias, relu=relu)

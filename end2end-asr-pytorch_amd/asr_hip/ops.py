@@ -360,18 +360,18 @@ def fp8_enabled():
 
 
 def quant_fp8(x):
-    """x (M,K) bf16/fp32 -> (q (M, Kp) uint8 e4m3 bytes, scale (2,) fp32 [amax, amax/448])."""
+    """x (M,K) bf16/fp32 -> (q (M, Kp) uint8 e4m3 bytes, scale (M,) fp32: row amax / 448)."""
     M, K = x.shape
     assert x.stride(1) == 1
     Kp = (K + 15) // 16 * 16
     q = torch.empty((M, Kp), device=x.device, dtype=torch.uint8)
-    scale = torch.empty(2, device=x.device, dtype=torch.float32)
+    scale = torch.empty(M, device=x.device, dtype=torch.float32)
     L.call("asr_quant_fp8", L.ptr(x), x.stride(0), M, K, L.dt(x), L.ptr(q), Kp, L.ptr(scale), L.stream())
     return q, scale
 
 
 def gemm_nt_fp8(qa, sa, qb, sb, bias=None, relu=False, out_dtype=torch.bfloat16, K=None):
-    """C (M,N) = sa sb qa . qb^T (+ bias)(ReLU): qa (M,Kp), qb (N,Kp) e4m3 bytes from quant_fp8."""
+    """C[m,n] = sa[m] sb[n] (qa . qb^T)[m,n] (+ bias)(ReLU): qa (M,Kp), qb (N,Kp) e4m3 bytes and row scales from quant_fp8."""
     M, N = qa.shape[0], qb.shape[0]
     K = qa.shape[1] if K is None else K
     out = torch.empty((M, N), device=qa.device, dtype=out_dtype)

@@ -145,9 +145,9 @@ int asr_embed_bwd(const int64_t* tok, const void* dout, float* dtable_acc, int B
                   float dropout_p, uint64_t seed, const uint64_t* seed_dev, int pad_id, int dtype, asr_stream_t stream);
 
 /* ---- fp8 (OCP e4m3fn) projections of the Low-Rank Transformer variant (BASELINE configs[4]).
- * asr_quant_fp8: x (M,K) bf16/fp32 -> q (M, ldq >= K rounded up to 16; pad bytes zero) with ONE scale per tensor;
- *   scale[0] = amax (workspace), scale[1] = amax / 448 (the dequantisation factor the GEMM multiplies in).
- * asr_gemm_nt_fp8: C[M,N] = scale_a[1] * scale_b[1] * sum_k A[m,k] B[n,k] (+ bias[n]) (ReLU) on the K = 128 block-scaled
+ * asr_quant_fp8: x (M,K) bf16/fp32 -> q (M, ldq >= K rounded up to 16; pad bytes zero) with one scale PER ROW:
+ *   scale[m] = amax of row m / 448 (the dequantisation factor the GEMM multiplies in).  One launch.
+ * asr_gemm_nt_fp8: C[m,n] = scale_a[m] * scale_b[n] * sum_k A[m,k] B[n,k] (+ bias[n]) (ReLU) on the K = 128 block-scaled
  *   fp8 MFMA with unit block scales (fp32 accumulators; measured 3e-5 of the largest output off the exact product
  *   of the decoded operands: the matrix core aligns a block's products before adding).  K multiple of 16.        */
 int asr_quant_fp8(const void* x, int64_t ld, int M, int K, int dtype, uint8_t* q, int64_t ldq, float* scale, asr_stream_t stream);
