@@ -821,6 +821,156 @@ __global__ __launch_bounds__(256) void gemm_tn128_kernel(Tn128Args p) {
   }
 }
 
+// ---- pipelined variant: the same 128 x 128 block and wave layout, but RM = 32 rows of m per stage in an NST-deep LDS ring filled
+// by HAND-ISSUED LDS-DMA (inline asm: the compiler must not know a DMA is in flight, or it drains the VMEM counter in front of
+// every transposing read it can see -- the reason the single-stage kernel above cannot overlap its loads), counted
+// s_waitcnt vmcnt, raw s_barrier.  One barrier per stage; the DMA of stage st + NST - 1 is issued right behind the barrier of
+// stage st (the ring slot it overwrites was read at stage st - 1, which every wave has left).  A partial last stage reads the
+// missing rows of A from a 16-byte zero page (the DMA cannot zero fill).  64 KB of LDS at NST = 4: two workgroups per CU.
+__device__ const uint4 tn_zero_page = {0u, 0u, 0u, 0u};
+
+__device__ __forceinline__ void tn_dma(unsigned lds_wave_base, const unsigned char* src) {
+  unsigned keep;      // M0 saved and restored: neutral for whatever the compiler keeps there
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
+}
+__device__ __forceinline__ uint4 tn32_pack(const unsigned char* tile, int lr, int g, int c0) {
+  // 8 consecutive rows 8g .. 8g+7 of column c0 + lr of a [32][128] bf16 tile (256-byte rows, chunk c of row r in slot c ^ (r & 7))
+  const int row = 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);
+  const int chunk = col >> 3, half = (col >> 2) & 1;
+  const uint2 lo = asr_lds_read_tr16(tile + row * 256 + ((chunk ^ (row & 7)) << 4) + half * 8);
+  const uint2 hi = asr_lds_read_tr16(tile + (row + 4) * 256 + ((chunk ^ ((row + 4) & 7)) << 4) + half * 8);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int NST>
+__global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
+  constexpr int RM = 32, ROWB = 256, TILEB = RM * ROWB, STAGEB = 2 * TILEB;       // 8 KB per operand, 16 KB per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int split = wid / p.ntiles, tile = wid % p.ntiles;
+  const int n0 = (tile / p.tiles_k) * 128, k0 = (tile % p.tiles_k) * 128;
+  const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+  const int nstage = (m_end - m_beg + RM - 1) / RM;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)(p.ldb * 2 / 16);
+
+  // per-thread DMA pieces: 512 chunks per operand tile = 2 per thread; chunk c = (row, slot), source chunk slot ^ (row & 7)
+  int64_t offA[2], offB[2];
+  int rowi[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 256 + tid, row = c >> 4, slot = (c & 15) ^ (row & 7);
+    int ca = n0 * 2 / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;       // columns past N / K are never stored
+    int cb = k0 * 2 / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+    offA[i] = (int64_t)row * p.lda * 2 + (int64_t)ca * 16;
+    offB[i] = (int64_t)row * p.ldb * 2 + (int64_t)cb * 16;
+    rowi[i] = row;
+  }
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(&tn_zero_page);
+  auto stage = [&](int st) __attribute__((always_inline)) {
+    const unsigned sl = wave_lds + (unsigned)((st % NST) * STAGEB);
+    const int64_t mrow = m_beg + (int64_t)st * RM;
+    const unsigned char* ba = A + mrow * p.lda * 2;
+    const unsigned char* bb = B + mrow * p.ldb * 2;
+    const int valid = m_end - (int)mrow;                  // rows of this stage that exist (uniform)
+    if (valid >= RM) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        tn_dma(sl + i * 4096, ba + offA[i]);
+        tn_dma(sl + TILEB + i * 4096, bb + offB[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool in = rowi[i] < valid;
+        tn_dma(sl + i * 4096, in ? ba + offA[i] : zero);
+        tn_dma(sl + TILEB + i * 4096, in ? bb + offB[i] : zero);
+      }
+    }
+  };
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = p.colsum != nullptr && k0 == 0 && wk == 0;
+
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nstage) stage(st);
+  for (int st = 0; st < nstage; ++st) {
+    // stage st has landed once at most the DMA pieces of the later stages are outstanding (4 pieces per stage and thread, in order)
+    const int ahead = min(NST - 2, nstage - 1 - st);
+    if (ahead >= 2) wait_vmcnt<8>();
+    else if (ahead == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();              // stage st visible to every wave; every wave is done reading stage st - 1
+    asm volatile("" ::: "memory");
+    if (st + NST - 1 < nstage) stage(st + NST - 1);
+    const unsigned char* sA = smem + (st % NST) * STAGEB;
+    const unsigned char* sB = sA + TILEB;
+    uint4 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = tn32_pack(sA, lr, g, wn * 64 + i * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = tn32_pack(sB, lr, g, wk * 64 + j * 16);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Chunk<bf16_t> c; c.v = a[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mma16<bf16_t>(acc[i][j], a[i], b[j]);
+  }
+
+  // ---- the wave's 64 x 64 quadrant: lane (lr, g) holds rows 4g..4g+3 of column lr of every fragment
+  const bool single = gridDim.x == (unsigned)p.ntiles;
+  float* part = p.ws ? p.ws + ((int64_t)split * p.ntiles + tile) * 16384 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wn * 64 + i * 16 + g * 4 + r, gn = n0 + row;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wk * 64 + j * 16 + lr, gk = k0 + col;
+        const float v = acc[i][j][r];
+        if (!single && part) part[row * 128 + col] = v;
+        else if (gn < p.N && gk < p.K) {
+          float* dst = p.C + (int64_t)gn * p.ldc + gk;
+          if (single) *dst += v; else atomicAdd(dst, v);
+        }
+      }
+    }
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int gn = n0 + wn * 64 + i * 16 + lr;
+      if (g == 0 && gn < p.N) atomicAdd(p.colsum + gn, v);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void tn128_reduce_kernel(const float* __restrict__ ws, float* C, int64_t ldc, int N, int K,
                                                            int ntiles, int tiles_k, int splits) {
   const int tile = blockIdx.x >> 4;
@@ -1147,15 +1297,26 @@ int tn_splits(int M, int N, int K, int splits, int dtype, bool have_ws) {
 namespace {
 // 128 x 128-tile kernel: bf16, automatic split, a workspace, and enough 128-blocks that ~512 workgroups of >= 4 stages exist.
 // Returns the number of m-slices (0 = use the 64 x 64-tile kernel).
+// LDS stages of the pipelined 128 x 128 kernel for an output of `nt` blocks, 0 = use the single-stage kernels.  Measured
+// (tools/microbench.py tn, profiles/r02_microbench_tn.txt): from 64 blocks on (2048 x 512 and larger) the pipelined kernel wins
+// (512 x 2048 over 6400 rows: 38.9 -> 33.8 us; 2048 x 512 over 12720 rows: 58.8 -> 47.6 us), below that its m-slices are too
+// short to fill the ring and the 64 x 64 kernel's 8 workgroups per CU win (512 x 512: 19 vs 30 us).  3 stages (48 KB, 3
+// workgroups per CU) tie or beat 4.
+int tn_pipe_stages(int nt) {
+  const int pipe = (int)asr_tuning("TN_PIPE", 3);
+  return (pipe > 0 && nt >= (int)asr_tuning("TN_PIPE_MIN", 64)) ? pipe : 0;
+}
+
 int tn128_splits(int M, int N, int K, int splits, int dtype) {
   const int enabled = (int)asr_tuning("TN_128", 1);
   const int min_tiles = (int)asr_tuning("TN_128_MIN", 128);      // measured: wins for 512x5120 (160 blocks), loses for 64-block outputs
   if (!enabled || dtype != ASR_BF16 || splits > 0 || N < 128 || K < 128) return 0;
   const int nt = ((N + 127) / 128) * ((K + 127) / 128);
-  if (nt < min_tiles) return 0;
-  const int stages = (M + 63) / 64;
+  const int pipe = tn_pipe_stages(nt);
+  if (!pipe && nt < min_tiles) return 0;
+  const int stages = pipe ? (M + 31) / 32 : (M + 63) / 64;
   int sp = (512 + nt / 2) / nt;
-  if (sp > 16) sp = 16;
+  if (sp > (pipe ? 32 : 16)) sp = pipe ? 32 : 16;
   while (sp > 1 && stages / sp < 4) --sp;
   if (sp < 1) sp = 1;
   const int sps = (stages + sp - 1) / sp;
@@ -1192,11 +1353,21 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
       q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.M = M; q.N = N; q.K = K;
       q.tiles_k = (K + 127) / 128;
       q.ntiles = ((N + 127) / 128) * q.tiles_k;
-      const int stages = (M + 63) / 64;
-      q.m_per_split = ((stages + s128 - 1) / s128) * 64;
+      const int pipe = tn_pipe_stages(q.ntiles);
+      const int stages = pipe ? (M + 31) / 32 : (M + 63) / 64;
+      q.m_per_split = ((stages + s128 - 1) / s128) * (pipe ? 32 : 64);
       AsrProfScope prof(ASR_OP_GEMM, stream);
       const int rm128 = (int)asr_tuning("TN_128_RM", 64);
-      if (rm128 == 128) {
+      if (pipe) {
+        static bool granted = false;
+        if (!granted) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128p_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384);
+          granted = true;
+        }
+        if (pipe == 3) hipLaunchKernelGGL(gemm_tn128p_kernel<3>, dim3((unsigned)(q.ntiles * s128)), dim3(256), 3 * 16384, stream, q);
+        else hipLaunchKernelGGL(gemm_tn128p_kernel<4>, dim3((unsigned)(q.ntiles * s128)), dim3(256), 4 * 16384, stream, q);
+      } else if (rm128 == 128) {
         static bool granted = false;
         if (!granted) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 128 * 256); granted = true; }
         hipLaunchKernelGGL(gemm_tn128_kernel<128>, dim3((unsigned)(q.ntiles * s128)), dim3(256), 2 * 128 * 256, stream, q);

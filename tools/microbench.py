@@ -117,6 +117,24 @@ def attn(cases=None):
               ((B, H, Tq, Tk, d, causal), pd, us, fl / us / 1e6, fl / us / 25e6, usb, 2.5 * fl / usb / 1e6, 2.5 * fl / usb / 25e6))
 
 
+def tn_ab():
+    """Weight-gradient GEMM dW(N,K) = dY^T X over M rows, automatic split: single-stage kernels (TN_PIPE=0) vs the pipelined
+    128 x 128 kernel with 3 / 4 LDS stages."""
+    print("== wgrad TN, automatic split: TN_PIPE = 0 (single-stage 64x64 / 128x128 kernels) | 3 | 4 stages")
+    for N, K, M in [(512, 512, 6400), (1536, 512, 6400), (2048, 512, 6400), (512, 2048, 6400), (512, 5120, 6400), (4364, 512, 3200),
+                    (512, 512, 3200), (1024, 512, 6400), (512, 512, 12720), (2048, 512, 12720), (512, 2048, 12720), (1536, 512, 12720)]:
+        dy = torch.randn(M, (N + 63) // 64 * 64, device=D).bfloat16()
+        x = torch.randn(M, K, device=D).bfloat16()
+        g = torch.zeros(N, K, device=D); gb = torch.zeros(N, device=D)
+        res = []
+        for pipe in (0, 3, 4):
+            L.set_tuning("TN_PIPE", pipe)
+            us = timeit(lambda: ops.gemm_tn(dy, x, g, colsum_acc=gb, N=N, K=K))
+            res.append("pipe%d %6.1fus %5.0fTF" % (pipe, us, 2 * M * N * K / us / 1e6))
+        L.set_tuning("TN_PIPE", None)
+        print("  tn    %5d %5d %5d : %s" % (N, K, M, " | ".join(res)))
+
+
 def misc():
     print("== streaming kernels")
     M, Dm = 6400, 512
@@ -181,5 +199,7 @@ if __name__ == "__main__":
             fn()
     if which == "decode":
         decode()
+    if which == "tn":
+        tn_ab()
     if which == "attn800":          # the north-star shape only (encoder self-attention, T = 800, bs 32, dropout 0.1)
         attn([ATTN_CASES[5]])
