@@ -77,11 +77,15 @@ def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_d
     if not need_dx:
         _wgrad_bias(dy2d, x2d, wparam, bparam)
         return None
+    ops.join_if_pending_reads(dx_out)
     f = ops.fork()
     with f:                                   # dW / db on the second stream, next to dX on this one
         _wgrad_bias(dy2d, x2d, wparam, bparam)
     dx = _dgrad(dy2d, wparam, dx_out, accumulate, relu_mask)
-    f.join()
+    if ops._side["defer"]:
+        f.defer(dy2d, x2d)                    # nobody reads dW before the optimiser: no join here (ops.join_deferred)
+    else:
+        f.join()
     return dx
 
 
@@ -113,6 +117,7 @@ class _Fused:
 
     def bwd(self, dy2d, x2d, dx_out=None, accumulate=False, need_dx=True):
         g = self.w_grad.view(self.N, self.K)
+        ops.join_if_pending_reads(dx_out)
         f = ops.fork() if need_dx else None
         if f is not None:
             f.__enter__()
@@ -131,7 +136,10 @@ class _Fused:
         else:
             wt = ops.transpose_padded(self.W)
             dx = ops.gemm_nt(_pad_cols(dy2d), wt, out=dx_out, accumulate=accumulate)
-        f.join()
+        if ops._side["defer"]:
+            f.defer(dy2d, x2d)
+        else:
+            f.join()
         return dx
 
 

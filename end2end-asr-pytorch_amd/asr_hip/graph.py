@@ -107,11 +107,13 @@ class GraphedTrainStep:
         pred, gold, *_ = core.decoder(self.tgt, enc_out, self.src_len)
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
         loss.backward()
+        ops.join_deferred()                     # every forked stream must have re-joined before this graph ends
         return loss.detach(), sums, feats, leaf.grad
 
     def _body_b(self, feats, dfeats):
         if feats.requires_grad:
             feats.backward(dfeats)
+        ops.join_deferred()
 
     def _body_c(self):
         adam = self.opt.optimizer

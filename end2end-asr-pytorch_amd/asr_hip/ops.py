@@ -52,7 +52,8 @@ def _pad8(n):
 
 
 # ------------------------------------------------------------------------------------------------ second stream
-_side = {"stream": None, "enabled": os.environ.get("ASR_OVERLAP", "1") != "0"}
+_side = {"stream": None, "enabled": os.environ.get("ASR_OVERLAP", "1") != "0", "pending": [],
+         "defer": os.environ.get("ASR_DEFER_JOIN", "0") == "1"}
 
 
 class fork:
@@ -86,6 +87,38 @@ class fork:
     def join(self):
         if self.on:
             self.main.wait_stream(self.side)
+
+    def defer(self, *tensors):
+        """Instead of join(): leave the side-stream work running and keep `tensors` (its operands) referenced until the next
+        join_deferred() -- the main stream does not wait at this point.  Used for weight gradients: nothing on the main stream
+        reads dW before the optimiser, so a layer's backward need not wait for them (a join is a cross-stream graph edge and an
+        idle gap on the main stream: 44 of them per step)."""
+        if self.on:
+            _side["pending"].append(tensors)
+
+
+def join_if_pending_reads(t):
+    """A main-stream kernel is about to WRITE tensor `t` in place (accumulate epilogue): if a deferred side-stream kernel still
+    reads memory that overlaps it (dropout 0: LayerNorm's d_y IS d_res, read by a weight gradient and accumulated into by the
+    next data gradient), wait for the second stream first."""
+    if t is None or not _side["pending"]:
+        return
+    lo = t.data_ptr()
+    hi = lo + t.numel() * t.element_size()
+    for group in _side["pending"]:
+        for x in group:
+            a = x.data_ptr()
+            if a < hi and lo < a + x.numel() * x.element_size():
+                join_deferred()
+                return
+
+
+def join_deferred():
+    """Main stream waits for everything deferred on the second stream (called before anything reads the weight gradients
+    and at the end of every captured graph body)."""
+    if _side["pending"] and _side["stream"] is not None:
+        torch.cuda.current_stream().wait_stream(_side["stream"])
+    _side["pending"] = []
 
 
 # ------------------------------------------------------------------------------------------------ dense

@@ -91,6 +91,7 @@ class FusedAdam(torch.optim.Adam):
     def clip_grad_norm_(self, max_norm):
         """torch.nn.utils.clip_grad_norm_ (reference: trainer.py:108-109) without a host sync: the coefficient stays on
         the device and is folded into the next step()."""
+        ops.join_deferred()                     # weight gradients still running on the second stream
         if self.reducer is not None:
             self.reducer.finish()
         dev = self.param_groups[0]['params'][0].device
@@ -116,6 +117,7 @@ class FusedAdam(torch.optim.Adam):
 
     def _pre_step(self):
         """Finish the gradient exchange; make sure grad_scale carries 1 / global count when it is owed."""
+        ops.join_deferred()                     # weight gradients still running on the second stream
         if self.reducer is not None:
             self.reducer.finish()
         den = self._denominator()
