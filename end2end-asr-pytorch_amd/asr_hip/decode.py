@@ -194,9 +194,148 @@ class GraphedGreedyDecoder:
         return self.out[:n].t().contiguous()
 
 
+def _dec_pack(decoder):
+    """bf16 weights of the decode-step GEMMs, Q/K/V of the self attention concatenated; cached on the decoder until a weight
+    changes (optimiser step / load_state_dict)."""
+    ws = [p for p in decoder.parameters()]
+    key = (F_.P._state["generation"], tuple(p._version for p in ws), tuple(p.data_ptr() for p in ws))
+    hit = getattr(decoder, "_asr_dec_pack", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    bf = torch.bfloat16
+
+    def w2(lin):
+        w = lin.weight.data
+        return w.reshape(w.shape[0], -1).to(bf).contiguous()
+
+    def b1(lin):
+        return lin.bias.data.float().contiguous() if lin.bias is not None else None
+
+    layers = []
+    for layer in decoder.layers:
+        sa, ca, ff = layer.self_attn, layer.encoder_attn, layer.pos_ffn
+        w1, w2_ = (ff.conv_1, ff.conv_2) if hasattr(ff, "conv_1") else (ff.linear_1, ff.linear_2)
+        layers.append(dict(
+            wqkv=torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0).contiguous(),
+            bqkv=torch.cat([b1(sa.query_linear), b1(sa.key_linear), b1(sa.value_linear)], 0).contiguous(),
+            wo_s=w2(sa.output_linear), bo_s=b1(sa.output_linear),
+            ln_s=(sa.layer_norm.weight.data.float().contiguous(), sa.layer_norm.bias.data.float().contiguous(), sa.layer_norm.eps),
+            wq_c=w2(ca.query_linear), bq_c=b1(ca.query_linear), wo_c=w2(ca.output_linear), bo_c=b1(ca.output_linear),
+            ln_c=(ca.layer_norm.weight.data.float().contiguous(), ca.layer_norm.bias.data.float().contiguous(), ca.layer_norm.eps),
+            w1=w2(w1), b1=b1(w1), w2=w2(w2_), b2=b1(w2_),
+            ln_f=(ff.layer_norm.weight.data.float().contiguous(), ff.layer_norm.bias.data.float().contiguous(), ff.layer_norm.eps)))
+    pack = dict(layers=layers, wout=w2(decoder.output_linear), table=decoder.trg_embedding.weight.data.float().contiguous())
+    decoder._asr_dec_pack = (key, pack)
+    return pack
+
+
+def fused_decode_supported(decoder, encoder_padded_outputs, max_len):
+    """The 34-launch step (csrc/decode.hip): bf16, <= 32 sequences, d_model <= 512 and a multiple of 64, dk = dv = 64,
+    inner dimension a multiple of 64, at most 512 cached positions / encoder frames, plain (full-rank) projections."""
+    if ops.compute_dtype() != torch.bfloat16 or not hasattr(decoder.layers[0].self_attn, "query_linear"):
+        return False
+    sa = decoder.layers[0].self_attn
+    if not isinstance(getattr(sa.query_linear, "weight", None), torch.Tensor):
+        return False
+    D = decoder.dim_model
+    B, Te, _ = encoder_padded_outputs.shape
+    ff = decoder.layers[0].pos_ffn
+    w1 = ff.conv_1 if hasattr(ff, "conv_1") else ff.linear_1
+    return (B <= 32 and D % 64 == 0 and D <= 512 and decoder.dim_key == 64 and getattr(decoder, "dim_value", 64) == 64 and
+            w1.weight.shape[0] % 64 == 0 and max_len <= 512 and Te <= 512 and (decoder.num_heads * decoder.dim_key) % 64 == 0)
+
+
+class FusedGreedyDecoder:
+    """Greedy loop on the decode-step kernels of csrc/decode.hip: per layer 8 launches (Q/K/V GEMM with the previous LayerNorm or
+    the embedding as its prologue, self attention that appends its own key / value rows, output GEMM, cross-attention query GEMM
+    with LayerNorm prologue, cross attention, output GEMM, two feed-forward GEMMs), then the vocabulary GEMM and asr_dec_finish:
+    34 launches per token for the 4-layer model instead of 62, captured once and replayed."""
+
+    def __init__(self, decoder, encoder_padded_outputs, max_len):
+        self.dec = decoder
+        self.cache = DecoderKVCache(decoder, encoder_padded_outputs, max_len)
+        c = self.cache
+        dev = encoder_padded_outputs.device
+        bf = torch.bfloat16
+        self.B, self.max_len = c.B, max_len
+        B, D, HD = c.B, decoder.dim_model, c.H * c.dk
+        self.pack = _dec_pack(decoder)
+        self.state = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.pe = decoder.positional_encoding.pe[0][:max_len].float().contiguous()
+        self.tok = torch.full((B,), constant.SOS_TOKEN, dtype=torch.int64, device=dev)
+        self.done = torch.zeros(B, dtype=torch.bool, device=dev)
+        self.out = torch.zeros((max_len, B), dtype=torch.int64, device=dev)
+        dff = self.pack["layers"][0]["w1"].shape[0]
+        V = self.pack["wout"].shape[0]
+        z = lambda *shape: torch.zeros(shape, dtype=bf, device=dev)
+        self.xs = [z(B, D), z(B, D), z(B, D)]          # sub-layer inputs (residuals): x0 -> self attention, x1 -> cross, x2 -> ffn
+        self.qkv, self.o, self.y, self.qc, self.h = z(B, 3 * HD), z(B, HD), z(B, D), z(B, HD), z(B, dff)
+        self.y2, self.y3 = z(B, D), z(B, D)
+        self.logits = torch.zeros((B, (V + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :V]
+        self.graph = None
+
+    def _step(self):
+        dec, c, P_ = self.dec, self.cache, self.pack
+        HD = c.H * c.dk
+        scale = 1.0 / (c.dk ** 0.5)
+        x0, x1, x2 = self.xs
+        prev = None                                                   # (Y, R, gamma, beta, eps) of the pending LayerNorm
+        for i, Lw in enumerate(P_["layers"]):
+            if prev is None:
+                ops.dec_gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0,
+                             embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
+            else:
+                ops.dec_gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
+            ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
+                         k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state)
+            ops.dec_gemm(Lw["wo_s"], Lw["bo_s"], self.y, x=self.o)
+            ops.dec_gemm(Lw["wq_c"], Lw["bq_c"], self.qc, ln=(self.y, x0) + Lw["ln_s"], x_out=x1)
+            ops.dec_attn(self.qc, c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale)
+            ops.dec_gemm(Lw["wo_c"], Lw["bo_c"], self.y2, x=self.o)
+            ops.dec_gemm(Lw["w1"], Lw["b1"], self.h, ln=(self.y2, x1) + Lw["ln_c"], x_out=x2, relu=True)
+            ops.dec_gemm(Lw["w2"], Lw["b2"], self.y3, x=self.h)
+            prev = (self.y3, x2) + Lw["ln_f"]
+        ops.dec_gemm(P_["wout"], None, self.logits, ln=prev)
+        ops.dec_finish(self.logits, self.tok, self.done, self.out, constant.EOS_TOKEN, self.state, self.ticket)
+
+    @torch.no_grad()
+    def step_logits(self, tokens):
+        """Teacher-forced step (tests): feed `tokens` (B,) at the current position -> fp32 logits (B, V) (a view, overwritten by
+        the next step)."""
+        self.tok.copy_(tokens)
+        self._step()
+        return self.logits
+
+    @torch.no_grad()
+    def run(self, steps, check_every=32):
+        """-> token ids (B, n <= steps).  Two eager steps (warm-up), capture, then one replay per token."""
+        n = 0
+        for _ in range(min(2, steps)):
+            self._step()
+            n += 1
+        if n < steps:
+            torch.cuda.synchronize()
+            if self.graph is None:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    self._step()
+            while n < steps:
+                self.graph.replay()
+                n += 1
+                if n % check_every == 0 and bool(self.done.all()):
+                    break
+        return self.out[:n].t().contiguous()
+
+
 @torch.no_grad()
-def greedy_search_graphed(decoder, encoder_padded_outputs, steps=300):
-    """Same tokens as greedy_search below, one hipGraph replay per token."""
+def greedy_search_graphed(decoder, encoder_padded_outputs, steps=300, fused=None):
+    """Same tokens as greedy_search below, one hipGraph replay per token.  fused: None = the 34-launch step when the shapes
+    allow it (bf16), False = the kernel-per-op step."""
+    if fused is None:
+        fused = fused_decode_supported(decoder, encoder_padded_outputs, steps)
+    if fused:
+        return FusedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps).run(steps)
     return GraphedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps).run(steps)
 
 

@@ -455,6 +455,59 @@ def kv_append(k_src, v_src, k_cache, v_cache, state):
            k_cache.shape[1], L.ptr(state), L.dt(k_src), L.stream())
 
 
+def dec_gemm(W, bias, out, x=None, ln=None, embed=None, x_out=None, relu=False):
+    """out (B, N) = act(x W^T + bias) for B <= 32 decode rows (asr_dec_gemm).  W (N, K) bf16.  Exactly one input:
+    x (B, K) bf16;  ln = (Y, R, gamma, beta, eps): x = LayerNorm(Y + R);  embed = (tok, table, pe, scale, state):
+    x = table[tok] * scale + pe[state[0]].  x_out (B, K): the prologue's x is also stored there."""
+    N, K = W.shape
+    B = out.shape[0]
+    assert W.dtype == torch.bfloat16 and W.stride(1) == 1 and out.stride(1) == 1 and out.shape[1] == N
+    pro = 0 if x is not None else (1 if ln is not None else 2)
+    X = Y = R = g = bt = tok = table = pe = state = None
+    eps, scale, ldx = 0.0, 1.0, 0
+    if pro == 0:
+        assert x.dtype == torch.bfloat16 and x.shape == (B, K) and x.stride(1) == 1
+        X, ldx = x, x.stride(0)
+    elif pro == 1:
+        Y, R, g, bt, eps = ln
+        assert Y.dtype == R.dtype == torch.bfloat16 and Y.shape == R.shape == (B, K) and Y.is_contiguous() and R.is_contiguous()
+        assert g.dtype == bt.dtype == torch.float32
+    else:
+        tok, table, pe, scale, state = embed
+        assert tok.dtype == torch.int64 and table.dtype == pe.dtype == torch.float32 and table.shape[1] == K == pe.shape[1]
+        assert table.is_contiguous() and pe.is_contiguous()
+    if x_out is not None:
+        assert x_out.dtype == torch.bfloat16 and x_out.shape == (B, K) and x_out.is_contiguous()
+    L.call("asr_dec_gemm", L.ptr(W), W.stride(0), L.ptr(bias), L.ptr(out), out.stride(0), B, N, K, int(relu), L.dt(out), pro,
+           L.ptr(X), ldx, L.ptr(Y), L.ptr(R), L.ptr(g), L.ptr(bt), float(eps), L.ptr(x_out), L.ptr(tok), L.ptr(table), L.ptr(pe),
+           float(scale), L.ptr(state), L.stream())
+    return out
+
+
+def dec_attn(q, k_cache, v_cache, out, H, dk, scale, k_new=None, v_new=None, state=None):
+    """One query row per sequence and head (asr_dec_attn).  q (B, H*dk) (row stride free); k_cache / v_cache (B, rows, H*dk)
+    (batch stride may be 0).  state given: self attention at t = state[0] with k_new / v_new (B, H*dk) appended at row t."""
+    B = q.shape[0]
+    assert q.dtype == torch.bfloat16 and q.stride(1) == 1 and k_cache.stride(2) == 1 and k_cache.stride() == v_cache.stride()
+    assert out.stride(1) == 1 and out.shape == (B, H * dk)
+    ldn = 0
+    if k_new is not None:
+        assert k_new.stride(1) == 1 and v_new.stride(1) == 1 and k_new.stride(0) == v_new.stride(0)
+        ldn = k_new.stride(0)
+    L.call("asr_dec_attn", L.ptr(q), q.stride(0), L.ptr(k_new), L.ptr(v_new), ldn, L.ptr(k_cache), L.ptr(v_cache), k_cache.stride(0),
+           k_cache.stride(1), k_cache.shape[1], L.ptr(out), out.stride(0), B, H, dk, float(scale), L.ptr(state), L.stream())
+    return out
+
+
+def dec_finish(logits, tok, done, out, eos, state, ticket):
+    """tok = argmax(logits) per row, done |= tok == eos, out[state[0]] = tok, state[0] += 1 (asr_dec_finish)."""
+    B, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and tok.dtype == torch.int64 and done.dtype == torch.bool
+    assert out.dtype == torch.int64 and out.is_contiguous() and out.shape[1] == B and ticket.dtype == torch.int32
+    L.call("asr_dec_finish", L.ptr(logits), logits.stride(0), V, L.ptr(tok), L.ptr(done), L.ptr(out), B, out.shape[0], int(eos),
+           L.ptr(state), L.ptr(ticket), L.stream())
+
+
 def argmax_rows(logits, out=None):
     M, V = logits.shape
     assert logits.dtype == torch.float32 and logits.stride(1) == 1

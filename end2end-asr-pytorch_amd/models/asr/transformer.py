@@ -229,8 +229,10 @@ class Decoder(nn.Module):
                       use_cache=True):
         """1-best strings of the reference's 300-step greedy loop (transformer.py:316-394).  Needs --tgt-max-len >= 301.
         use_cache=True decodes incrementally with per-layer key/value caches, one captured hipGraph replayed per token
-        (asr_hip/decode.py); "eager" the same without the graph; False re-runs the full decoder over the prefix at every step
-        like the reference -- same tokens every way (tests/test_gpu_decode.py)."""
+        (asr_hip/decode.py; in bf16 the step is the 34-launch one of csrc/decode.hip when the shapes allow it); "graph" the same
+        with the kernel-per-op step; "eager" that step without the graph; False re-runs the full decoder over the prefix at
+        every step like the reference -- "graph" / "eager" / False give the same tokens (tests/test_gpu_decode.py), the fused
+        step the same within the bf16 tolerance (tests/test_gpu_decode_fused.py)."""
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
         if use_cache == "eager":                      # cached, launches issued from Python per token
@@ -238,7 +240,8 @@ class Decoder(nn.Module):
             toks = cached_greedy(self, encoder_padded_outputs, steps=300).cpu().tolist()
         elif use_cache:                               # cached + one hipGraph replay per token (device-side position)
             from asr_hip.decode import greedy_search_graphed
-            toks = greedy_search_graphed(self, encoder_padded_outputs, steps=300).cpu().tolist()
+            fused = False if use_cache == "graph" else None      # "graph": the kernel-per-op step; True: 34-launch step in bf16
+            toks = greedy_search_graphed(self, encoder_padded_outputs, steps=300, fused=fused).cpu().tolist()
         else:
             B = encoder_padded_outputs.size(0)
             ys = torch.full((B, 1), constant.SOS_TOKEN, dtype=torch.int64, device=encoder_padded_outputs.device)

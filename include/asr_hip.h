@@ -177,6 +177,30 @@ int asr_decode_prepare(const float* pe, int D, float* pe_cur, int32_t* key_len, 
 int asr_kv_append(const void* k_src, const void* v_src, int64_t src_ld, void* k_cache, void* v_cache, int B, int ncols,
                   int max_len, const int64_t* state, int dtype, asr_stream_t stream);
 
+/* ---- the same greedy step in 34 launches instead of 62 (bf16; B <= 32 rows; csrc/decode.hip).  Replaces, per decoder layer of
+ * models/asr/transformer.py:533-545 run on ONE position: the Q/K/V, output, feed-forward projections (common_layers.py:170-200,
+ * :135-142) and -- as a prologue of the GEMM that consumes it -- the sub-layer epilogue LayerNorm(dropout(y) + residual)
+ * (common_layers.py:140-141, :197-198) or the embedding + positional encoding of transformer.py:292-293.
+ * asr_dec_gemm: out (B, ldo) = act(x W^T + bias), W (N, ldw) bf16, K % 64 == 0.  prologue 0: x = X (B, ldx) bf16;
+ *   1: x = LN(Y + R) * gamma + beta (Y, R (B, K) bf16 contiguous, K <= 512; z = Y + R rounded to bf16 before the statistics,
+ *      like asr_add_ln_fwd), x also stored to x_out (B, K) when given;  2: x = table[tok[b]] * scale + pe[state[0]] (fp32
+ *      table / pe), stored to x_out.  out_dtype ASR_BF16 or ASR_F32.  ASR_EUNSUPPORTED outside these shapes.
+ * asr_dec_attn: one query row per sequence and head (dk = 64): q (B, ldq); keys / values (B, rows, H*64) with the given
+ *   batch / row strides.  state != NULL: self attention at position t = state[0]: k_new / v_new (B, ld_new) are this
+ *   position's rows -- stored to row t of both caches by this launch -- and the keys are rows 0..t; state == NULL: all
+ *   `rows` keys (cross attention, no mask: transformer.py:336-350 passes none at decode time).  out (B, ldo) bf16.
+ * asr_dec_finish: tok[b] = argmax of logits row b (lowest index on ties), done[b] |= tok == eos, out[t * B + b] = tok
+ *   (t = state[0] < max_len), then state[0] = t + 1 (by the last workgroup; *ticket must be 0 before the first call).      */
+int asr_dec_gemm(const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int B, int N, int K, int relu,
+                 int out_dtype, int prologue, const void* X, int64_t ldx, const void* Y, const void* R, const float* gamma,
+                 const float* beta, float eps, void* x_out, const int64_t* tok, const float* table, const float* pe,
+                 float scale, const int64_t* state, asr_stream_t stream);
+int asr_dec_attn(const void* q, int64_t ldq, const void* k_new, const void* v_new, int64_t ld_new, void* k_cache,
+                 void* v_cache, int64_t cache_batch_stride, int64_t cache_row_stride, int rows, void* out, int64_t ldo,
+                 int B, int H, int dk, float scale, const int64_t* state, asr_stream_t stream);
+int asr_dec_finish(const float* logits, int64_t ld, int V, int64_t* tok, uint8_t* done, int64_t* out, int B, int max_len,
+                   int eos, int64_t* state, int32_t* ticket, asr_stream_t stream);
+
 /* ---- label-smoothed cross entropy + argmax + num_correct (utils/metrics.py:78-132, transformer.py:80) ---------
  * logits (M, ld) fp32.  sums[0] += sum of row losses over non-PAD rows, sums[1] += #non-PAD rows,
  * sums[2] += #(argmax == gold) over non-PAD rows.  argmax = lowest index among maxima.                        */

@@ -53,7 +53,7 @@ def test_greedy_and_beam_cached_match_uncached(precision):
     dec = model.decoder
     g = torch.Generator().manual_seed(5)
     enc = torch.randn(2, 12, 512, generator=g).cuda()
-    a = dec.greedy_search(enc, use_cache=True)           # one hipGraph replay per token
+    a = dec.greedy_search(enc, use_cache="graph")        # one hipGraph replay per token, kernel-per-op step
     b = dec.greedy_search(enc, use_cache=False)
     c = dec.greedy_search(enc, use_cache="eager")
     assert a == b == c and len(a) == 2

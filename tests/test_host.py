@@ -25,7 +25,8 @@ def test_library_loads_and_exports_header_symbols():
     # pure host helpers of the ABI (no device needed): workspace sizes
     assert h.asr_add_ln_bwd_workspace(6400, 512) == 800 * 1024
     assert h.asr_conv3x3_wgrad_workspace(32, 161, 800, 64, 64) == 510 * 9 * 64 * 64      # 33600 patches, 66 per workgroup
-    assert h.asr_gemm_tn_workspace(6400, 2048, 512, 0, 1) == 2 * 256 * 4096
+    assert h.asr_gemm_tn_workspace(6400, 2048, 512, 0, 1) == 8 * 64 * 16384      # pipelined 128 x 128 blocks: 64 blocks x 8 m-slices
+    assert h.asr_gemm_tn_workspace(6400, 512, 512, 0, 1) == 8 * 64 * 4096         # 64 x 64 tiles: 64 tiles x 8 m-slices
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -180,14 +180,15 @@ def decode():
     model = init_transformer_model(args, l2i, {i: c for c, i in l2i.items()}).cuda().eval()
     enc = torch.randn(32, 200, 512, device=D)
     print("== greedy decode, 32 utterances x 300 steps, 4-layer d512 decoder over 200 encoder frames (bf16)")
-    for mode in (True, "eager", False):
+    modes = (True,) if os.environ.get("MICRO_DECODE_GRAPH_ONLY") == "1" else (True, "graph", "eager", False)
+    for mode in modes:
         with torch.no_grad():
             model.decoder.greedy_search(enc, use_cache=mode)
             torch.cuda.synchronize()
             t0 = time.time()
             model.decoder.greedy_search(enc, use_cache=mode)
             torch.cuda.synchronize()
-        print("  %-28s %8.1f ms" % ({True: "KV cache + hipGraph replay", "eager": "KV cache, eager launches", False: "full re-run (reference)"}[mode],
+        print("  %-36s %8.1f ms" % ({True: "KV cache + hipGraph, 34-launch step", "graph": "KV cache + hipGraph, op per launch", "eager": "KV cache, eager launches", False: "full re-run (reference)"}[mode],
                                       (time.time() - t0) * 1e3))
 
 
