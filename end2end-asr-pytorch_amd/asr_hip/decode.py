@@ -194,11 +194,15 @@ class GraphedGreedyDecoder:
         return self.out[:n].t().contiguous()
 
 
+def _weights_key(decoder):
+    ws = list(decoder.parameters())
+    return (F_.P._state["generation"], tuple(p._version for p in ws), tuple(p.data_ptr() for p in ws))
+
+
 def _dec_pack(decoder):
     """bf16 weights of the decode-step GEMMs, Q/K/V of the self attention concatenated; cached on the decoder until a weight
     changes (optimiser step / load_state_dict)."""
-    ws = [p for p in decoder.parameters()]
-    key = (F_.P._state["generation"], tuple(p._version for p in ws), tuple(p.data_ptr() for p in ws))
+    key = _weights_key(decoder)
     hit = getattr(decoder, "_asr_dec_pack", None)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -208,6 +212,9 @@ def _dec_pack(decoder):
         w = lin.weight.data
         return w.reshape(w.shape[0], -1).to(bf).contiguous()
 
+    def fr(w):                                  # (flat fragment-major weight, (N, K)): 1 KB per wave-wide load (include/asr_hip.h)
+        return ops.frag_pack(w), tuple(w.shape)
+
     def b1(lin):
         return lin.bias.data.float().contiguous() if lin.bias is not None else None
 
@@ -216,15 +223,15 @@ def _dec_pack(decoder):
         sa, ca, ff = layer.self_attn, layer.encoder_attn, layer.pos_ffn
         w1, w2_ = (ff.conv_1, ff.conv_2) if hasattr(ff, "conv_1") else (ff.linear_1, ff.linear_2)
         layers.append(dict(
-            wqkv=torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0).contiguous(),
+            wqkv=fr(torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0)),
             bqkv=torch.cat([b1(sa.query_linear), b1(sa.key_linear), b1(sa.value_linear)], 0).contiguous(),
-            wo_s=w2(sa.output_linear), bo_s=b1(sa.output_linear),
+            wo_s=fr(w2(sa.output_linear)), bo_s=b1(sa.output_linear),
             ln_s=(sa.layer_norm.weight.data.float().contiguous(), sa.layer_norm.bias.data.float().contiguous(), sa.layer_norm.eps),
-            wq_c=w2(ca.query_linear), bq_c=b1(ca.query_linear), wo_c=w2(ca.output_linear), bo_c=b1(ca.output_linear),
+            wq_c=fr(w2(ca.query_linear)), bq_c=b1(ca.query_linear), wo_c=fr(w2(ca.output_linear)), bo_c=b1(ca.output_linear),
             ln_c=(ca.layer_norm.weight.data.float().contiguous(), ca.layer_norm.bias.data.float().contiguous(), ca.layer_norm.eps),
-            w1=w2(w1), b1=b1(w1), w2=w2(w2_), b2=b1(w2_),
+            w1=fr(w2(w1)), b1=b1(w1), w2=fr(w2(w2_)), b2=b1(w2_),
             ln_f=(ff.layer_norm.weight.data.float().contiguous(), ff.layer_norm.bias.data.float().contiguous(), ff.layer_norm.eps)))
-    pack = dict(layers=layers, wout=w2(decoder.output_linear), table=decoder.trg_embedding.weight.data.float().contiguous())
+    pack = dict(layers=layers, wout=fr(w2(decoder.output_linear)), table=decoder.trg_embedding.weight.data.float().contiguous())
     decoder._asr_dec_pack = (key, pack)
     return pack
 
@@ -249,10 +256,15 @@ class FusedGreedyDecoder:
     """Greedy loop on the decode-step kernels of csrc/decode.hip: per layer 8 launches (Q/K/V GEMM with the previous LayerNorm or
     the embedding as its prologue, self attention that appends its own key / value rows, output GEMM, cross-attention query GEMM
     with LayerNorm prologue, cross attention, output GEMM, two feed-forward GEMMs), then the vocabulary GEMM and asr_dec_finish:
-    34 launches per token for the 4-layer model instead of 62, captured once and replayed."""
+    34 launches per token for the 4-layer model instead of 62, captured once (TOKENS_PER_GRAPH steps per graph: the host's
+    replay gap is paid once per graph) and replayed; the object -- buffers and graph -- is kept on the decoder and reused by
+    later calls with the same shapes (greedy_search_graphed), only the cross-attention keys / values are recomputed."""
+
+    TOKENS_PER_GRAPH = 4
 
     def __init__(self, decoder, encoder_padded_outputs, max_len):
         self.dec = decoder
+        self.key = _weights_key(decoder)
         self.cache = DecoderKVCache(decoder, encoder_padded_outputs, max_len)
         c = self.cache
         dev = encoder_padded_outputs.device
@@ -266,11 +278,12 @@ class FusedGreedyDecoder:
         self.tok = torch.full((B,), constant.SOS_TOKEN, dtype=torch.int64, device=dev)
         self.done = torch.zeros(B, dtype=torch.bool, device=dev)
         self.out = torch.zeros((max_len, B), dtype=torch.int64, device=dev)
-        dff = self.pack["layers"][0]["w1"].shape[0]
-        V = self.pack["wout"].shape[0]
+        dff = self.pack["layers"][0]["w1"][1][0]
+        V = self.pack["wout"][1][0]
         z = lambda *shape: torch.zeros(shape, dtype=bf, device=dev)
         self.xs = [z(B, D), z(B, D), z(B, D)]          # sub-layer inputs (residuals): x0 -> self attention, x1 -> cross, x2 -> ffn
-        self.qkv, self.o, self.y, self.qc, self.h = z(B, 3 * HD), z(B, HD), z(B, D), z(B, HD), z(B, dff)
+        self.qkv, self.y, self.qc = z(B, 3 * HD), z(B, D), z(B, HD)
+        self.o, self.h = z(32 * HD), z(32 * dff)             # fragment-major: what the next GEMM's wave-wide loads want
         self.y2, self.y3 = z(B, D), z(B, D)
         self.logits = torch.zeros((B, (V + 3) // 4 * 4), dtype=torch.float32, device=dev)[:, :V]
         self.graph = None
@@ -281,23 +294,47 @@ class FusedGreedyDecoder:
         scale = 1.0 / (c.dk ** 0.5)
         x0, x1, x2 = self.xs
         prev = None                                                   # (Y, R, gamma, beta, eps) of the pending LayerNorm
+        B = self.B
+
+        def gemm(w, bias, out, **kw):
+            return ops.dec_gemm(w[0], bias, out, w_frag=w[1], **kw)
+
         for i, Lw in enumerate(P_["layers"]):
             if prev is None:
-                ops.dec_gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0,
-                             embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
+                gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0, embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
             else:
-                ops.dec_gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
+                gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
             ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
-                         k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state)
-            ops.dec_gemm(Lw["wo_s"], Lw["bo_s"], self.y, x=self.o)
-            ops.dec_gemm(Lw["wq_c"], Lw["bq_c"], self.qc, ln=(self.y, x0) + Lw["ln_s"], x_out=x1)
-            ops.dec_attn(self.qc, c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale)
-            ops.dec_gemm(Lw["wo_c"], Lw["bo_c"], self.y2, x=self.o)
-            ops.dec_gemm(Lw["w1"], Lw["b1"], self.h, ln=(self.y2, x1) + Lw["ln_c"], x_out=x2, relu=True)
-            ops.dec_gemm(Lw["w2"], Lw["b2"], self.y3, x=self.h)
+                         k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state, out_frag=True)
+            gemm(Lw["wo_s"], Lw["bo_s"], self.y, x=self.o, x_frag=True)
+            gemm(Lw["wq_c"], Lw["bq_c"], self.qc, ln=(self.y, x0) + Lw["ln_s"], x_out=x1)
+            ops.dec_attn(self.qc, c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale, out_frag=True)
+            gemm(Lw["wo_c"], Lw["bo_c"], self.y2, x=self.o, x_frag=True)
+            gemm(Lw["w1"], Lw["b1"], self.h, ln=(self.y2, x1) + Lw["ln_c"], x_out=x2, relu=True, out_frag=True, B=B)
+            gemm(Lw["w2"], Lw["b2"], self.y3, x=self.h, x_frag=True)
             prev = (self.y3, x2) + Lw["ln_f"]
-        ops.dec_gemm(P_["wout"], None, self.logits, ln=prev)
+        gemm(P_["wout"], None, self.logits, ln=prev)
         ops.dec_finish(self.logits, self.tok, self.done, self.out, constant.EOS_TOKEN, self.state, self.ticket)
+
+    @torch.no_grad()
+    def reset(self, encoder_padded_outputs):
+        """Start a new batch of the same shape: position 0, SOS tokens, fresh cross-attention keys / values (in place: the
+        captured graph keeps its addresses)."""
+        c = self.cache
+        cd = ops.compute_dtype()
+        enc = encoder_padded_outputs.to(cd).contiguous()
+        Be, Te, D = enc.shape
+        assert (Be, Te) == tuple(c.cross[0][0].shape[:2])
+        enc2 = enc.view(Be * Te, D)
+        for i, layer in enumerate(self.dec.layers):
+            a = layer.encoder_attn
+            c.cross[i][0].copy_(F_._linear_fwd(enc2, a.key_linear.weight, a.key_linear.bias).view(Be, Te, -1))
+            c.cross[i][1].copy_(F_._linear_fwd(enc2, a.value_linear.weight, a.value_linear.bias).view(Be, Te, -1))
+        self.state.zero_()
+        self.ticket.zero_()
+        self.tok.fill_(constant.SOS_TOKEN)
+        self.done.zero_()
+        self.out.zero_()
 
     @torch.no_grad()
     def step_logits(self, tokens):
@@ -309,21 +346,31 @@ class FusedGreedyDecoder:
 
     @torch.no_grad()
     def run(self, steps, check_every=32):
-        """-> token ids (B, n <= steps).  Two eager steps (warm-up), capture, then one replay per token."""
-        n = 0
-        for _ in range(min(2, steps)):
-            self._step()
-            n += 1
-        if n < steps:
-            torch.cuda.synchronize()
-            if self.graph is None:
+        """-> token ids (B, n <= steps).  First use: two eager steps (warm-up) and the capture; then one replay per
+        TOKENS_PER_GRAPH tokens, the remainder eagerly."""
+        assert steps <= self.max_len
+        n, G = 0, self.TOKENS_PER_GRAPH
+        if self.graph is None:
+            for _ in range(min(2, steps)):
+                self._step()
+                n += 1
+            if steps - n >= G:
+                torch.cuda.synchronize()
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
-                    self._step()
-            while n < steps:
+                    for _ in range(G):
+                        self._step()
+        nxt = check_every
+        while n < steps:
+            if self.graph is not None and steps - n >= G:
                 self.graph.replay()
+                n += G
+            else:
+                self._step()
                 n += 1
-                if n % check_every == 0 and bool(self.done.all()):
+            if n >= nxt:
+                nxt += check_every
+                if bool(self.done.all()):
                     break
         return self.out[:n].t().contiguous()
 
@@ -335,7 +382,18 @@ def greedy_search_graphed(decoder, encoder_padded_outputs, steps=300, fused=None
     if fused is None:
         fused = fused_decode_supported(decoder, encoder_padded_outputs, steps)
     if fused:
-        return FusedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps).run(steps)
+        B, Te, _ = encoder_padded_outputs.shape
+        slot = (B, Te, steps, str(encoder_padded_outputs.device))
+        held = getattr(decoder, "_asr_fused_decoders", None)
+        if held is None:
+            held = decoder._asr_fused_decoders = {}
+        obj = held.get(slot)
+        if obj is not None and obj.key == _weights_key(decoder):
+            obj.reset(encoder_padded_outputs)
+        else:
+            held.clear()                                      # one shape at a time: the buffers of a 32 x 300 decode are ~80 MB
+            obj = held[slot] = FusedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps)
+        return obj.run(steps)
     return GraphedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps).run(steps)
 
 

@@ -455,17 +455,54 @@ def kv_append(k_src, v_src, k_cache, v_cache, state):
            k_cache.shape[1], L.ptr(state), L.dt(k_src), L.stream())
 
 
-def dec_gemm(W, bias, out, x=None, ln=None, embed=None, x_out=None, relu=False):
-    """out (B, N) = act(x W^T + bias) for B <= 32 decode rows (asr_dec_gemm).  W (N, K) bf16.  Exactly one input:
-    x (B, K) bf16;  ln = (Y, R, gamma, beta, eps): x = LayerNorm(Y + R);  embed = (tok, table, pe, scale, state):
-    x = table[tok] * scale + pe[state[0]].  x_out (B, K): the prologue's x is also stored there."""
-    N, K = W.shape
-    B = out.shape[0]
-    assert W.dtype == torch.bfloat16 and W.stride(1) == 1 and out.stride(1) == 1 and out.shape[1] == N
+def frag_pack(w):
+    """(rows, K) -> the fragment-major order of asr_dec_gemm (include/asr_hip.h): rows padded with zeros to a multiple of 32,
+    blocks of 32 rows x 16 columns, lane 32 h + i of a block holds [i][8 h .. 8 h + 7].  Returns a flat tensor."""
+    rows, K = w.shape
+    assert K % 16 == 0
+    rp = (rows + 31) // 32 * 32
+    if rp != rows:
+        w = torch.cat([w, w.new_zeros(rp - rows, K)], 0)
+    return w.view(rp // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def frag_unpack(f, rows, K):
+    """Inverse of frag_pack (tests)."""
+    rp = (rows + 31) // 32 * 32
+    return f.view(rp // 32, K // 16, 2, 32, 8).permute(0, 3, 1, 2, 4).contiguous().view(rp, K)[:rows]
+
+
+def dec_gemm(W, bias, out, x=None, ln=None, embed=None, x_out=None, relu=False, w_frag=None, x_frag=False, out_frag=False, B=None):
+    """out (B, N) = act(x W^T + bias) for B <= 32 decode rows (asr_dec_gemm).  W (N, K) bf16, or w_frag = (N, K) with W the
+    flat frag_pack()ed weight.  Exactly one input: x (B, K) bf16 (x_frag: flat fragment-major, 32 rows);
+    ln = (Y, R, gamma, beta, eps): x = LayerNorm(Y + R);  embed = (tok, table, pe, scale, state):
+    x = table[tok] * scale + pe[state[0]].  x_out (B, K): the prologue's x is also stored there.  out_frag: out is a flat
+    fragment-major (32, N) bf16 buffer and B is taken from x / Y / tok."""
+    if w_frag is not None:
+        N, K = w_frag
+        ldw = K
+        assert W.dtype == torch.bfloat16 and W.is_contiguous() and W.numel() == (N + 31) // 32 * 32 * K
+    else:
+        N, K = W.shape
+        ldw = W.stride(0)
+        assert W.dtype == torch.bfloat16 and W.stride(1) == 1
+    layout = (1 if w_frag is not None else 0) | (2 if x_frag else 0) | (4 if out_frag else 0)
+    if out_frag:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == 32 * N
+        if B is None:
+            B = (x if x is not None and not x_frag else (ln[0] if ln is not None else embed[0])).shape[0]
+        ldo = N
+    else:
+        B = out.shape[0]
+        assert out.stride(1) == 1 and out.shape[1] == N
+        ldo = out.stride(0)
     pro = 0 if x is not None else (1 if ln is not None else 2)
     X = Y = R = g = bt = tok = table = pe = state = None
     eps, scale, ldx = 0.0, 1.0, 0
-    if pro == 0:
+    if pro == 0 and x_frag:
+        assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() == 32 * K
+        X, ldx = x, K
+    elif pro == 0:
         assert x.dtype == torch.bfloat16 and x.shape == (B, K) and x.stride(1) == 1
         X, ldx = x, x.stride(0)
     elif pro == 1:
@@ -478,24 +515,29 @@ def dec_gemm(W, bias, out, x=None, ln=None, embed=None, x_out=None, relu=False):
         assert table.is_contiguous() and pe.is_contiguous()
     if x_out is not None:
         assert x_out.dtype == torch.bfloat16 and x_out.shape == (B, K) and x_out.is_contiguous()
-    L.call("asr_dec_gemm", L.ptr(W), W.stride(0), L.ptr(bias), L.ptr(out), out.stride(0), B, N, K, int(relu), L.dt(out), pro,
+    L.call("asr_dec_gemm", L.ptr(W), ldw, L.ptr(bias), L.ptr(out), ldo, B, N, K, int(relu), L.dt(out), layout, pro,
            L.ptr(X), ldx, L.ptr(Y), L.ptr(R), L.ptr(g), L.ptr(bt), float(eps), L.ptr(x_out), L.ptr(tok), L.ptr(table), L.ptr(pe),
            float(scale), L.ptr(state), L.stream())
     return out
 
 
-def dec_attn(q, k_cache, v_cache, out, H, dk, scale, k_new=None, v_new=None, state=None):
+def dec_attn(q, k_cache, v_cache, out, H, dk, scale, k_new=None, v_new=None, state=None, out_frag=False):
     """One query row per sequence and head (asr_dec_attn).  q (B, H*dk) (row stride free); k_cache / v_cache (B, rows, H*dk)
     (batch stride may be 0).  state given: self attention at t = state[0] with k_new / v_new (B, H*dk) appended at row t."""
     B = q.shape[0]
     assert q.dtype == torch.bfloat16 and q.stride(1) == 1 and k_cache.stride(2) == 1 and k_cache.stride() == v_cache.stride()
-    assert out.stride(1) == 1 and out.shape == (B, H * dk)
+    if out_frag:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == 32 * H * dk
+        ldo = H * dk
+    else:
+        assert out.stride(1) == 1 and out.shape == (B, H * dk)
+        ldo = out.stride(0)
     ldn = 0
     if k_new is not None:
         assert k_new.stride(1) == 1 and v_new.stride(1) == 1 and k_new.stride(0) == v_new.stride(0)
         ldn = k_new.stride(0)
     L.call("asr_dec_attn", L.ptr(q), q.stride(0), L.ptr(k_new), L.ptr(v_new), ldn, L.ptr(k_cache), L.ptr(v_cache), k_cache.stride(0),
-           k_cache.stride(1), k_cache.shape[1], L.ptr(out), out.stride(0), B, H, dk, float(scale), L.ptr(state), L.stream())
+           k_cache.stride(1), k_cache.shape[1], L.ptr(out), ldo, B, H, dk, float(scale), int(out_frag), L.ptr(state), L.stream())
     return out
 
 

@@ -24,126 +24,141 @@ struct DecGemmArgs {
   const bf16_t* W; const float* bias; void* out;
   int64_t ldw, ldo;
   int B, N, K, relu;
+  int w_frag, x_frag, out_frag;                                   // fragment-major operands (see asr_hip.h)
   const bf16_t* X; int64_t ldx;                                   // prologue 0: the input rows
   const bf16_t* Y; const bf16_t* R; const float* gamma; const float* beta; float eps;   // prologue 1: x = LN(Y + R) gamma + beta
   bf16_t* x_out;                                                   // prologue 1 / 2: workgroup 0 stores x (B, K)
   const int64_t* tok; const float* table; const float* pe; float scale; const int64_t* state;   // prologue 2
 };
 
-// PRO 0: x read from memory; 1: LayerNorm(Y + R); 2: embedding row * scale + pe[t].   GS = K steps whose loads are issued together.
-template <int PRO, typename TO, int GS>
-__global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs p) {
+// PRO 0: x read from memory; 1: LayerNorm(Y + R); 2: embedding row * scale + pe[t].  NW waves split K (4, or 8 when K > 512);
+// GS = K steps per wave whose loads are issued together (all of them).
+template <int PRO, typename TO, int NW, int GS>
+__global__ __launch_bounds__(NW * 64) void dec_gemm_kernel(DecGemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, half = lane >> 5;
   const int n0 = blockIdx.x * 32;
   const int K = p.K;
   const int XP = K * 2 + 16;                                       // LDS row pitch of the x tile: rows 4 banks apart
-  float* red = reinterpret_cast<float*>(smem);                     // [3][16][64] partial accumulators of waves 1..3
-  unsigned char* xs = smem + 3 * 16 * 64 * 4;                      // PRO != 0: x tile [32][XP]
+  float* red = reinterpret_cast<float*>(smem);                     // [NW - 1][16][64] partial accumulators of waves 1..
+  unsigned char* xs = smem + (NW - 1) * 16 * 64 * 4;               // PRO != 0: x tile [32][XP]
+  float* gb = red;                                                 // PRO 1: gamma | beta [2][K] fp32, dead before `red` is written
+
+  // ---- the weight fragments do not depend on the prologue: their loads go out first and fly while x is produced
+  const int kper = K / NW;                                         // k range of a wave (a multiple of 16)
+  const int kw = wave * kper;
+  const int ksteps = kper >> 4;
+  const int nrow = n0 + lr < p.N ? n0 + lr : p.N - 1;
+  // row-major: lane (row lr, k half) reads 16 bytes of its row per step; fragment-major: the 64 lanes of a step read 1 KB in a row
+  const bf16_t* wp = p.w_frag ? p.W + (((int64_t)blockIdx.x * (K >> 4) + (kw >> 4)) * 64 + lane) * 8
+                              : p.W + (int64_t)nrow * p.ldw + kw + 8 * half;
+  const int wstep = p.w_frag ? 512 : 16;
+  uint4 a[GS], b[GS];
+#pragma unroll
+  for (int i = 0; i < GS; ++i)
+    if (i < ksteps) a[i] = *reinterpret_cast<const uint4*>(wp + i * wstep);
 
   if (PRO != 0) {
-    const int c0 = lane * 8;                                       // K <= 512: one 16-byte chunk per lane and row
-    const bool live = c0 < K;
-    float gm[8], bt[8];
+    // thread = (row m = tid / 8, sub = tid % 8): the row's 16-byte chunks sub, sub + 8, ... (8 lanes read 128 contiguous bytes);
+    // statistics over the 8 lanes of a row by three xor shuffles -- all 32 rows at once, one memory round trip
+    static_assert(PRO == 0 || NW == 4, "prologues: 256 threads = 32 rows x 8 lanes");
+    const int m = tid >> 3, sub = tid & 7;
+    const int nch = K >> 3;                                        // chunks per row (<= 64)
+    const int mm = m < p.B ? m : p.B - 1;
+    Chunk<bf16_t> z[8];
     if (PRO == 1) {
-      const int cc = live ? c0 : 0;
+      Chunk<bf16_t> cy[8], cr[8];
 #pragma unroll
-      for (int j = 0; j < 8; j += 4) {
-        const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + cc + j);
-        const float4 b4 = *reinterpret_cast<const float4*>(p.beta + cc + j);
-        gm[j] = g4.x; gm[j + 1] = g4.y; gm[j + 2] = g4.z; gm[j + 3] = g4.w;
-        bt[j] = b4.x; bt[j + 1] = b4.y; bt[j + 2] = b4.z; bt[j + 3] = b4.w;
+      for (int j = 0; j < 8; ++j) {
+        const int c = j * 8 + sub, cc = c < nch ? c : 0;
+        cy[j].v = *reinterpret_cast<const uint4*>(p.Y + (int64_t)mm * K + cc * 8);
+        cr[j].v = *reinterpret_cast<const uint4*>(p.R + (int64_t)mm * K + cc * 8);
       }
-    }
-    const int64_t t = PRO == 2 ? p.state[0] : 0;
-    // all loads of the wave's 8 rows first (one memory round trip), then the arithmetic
-    Chunk<bf16_t> cy[8], cr[8];
-    float ev[PRO == 2 ? 8 : 1][8];
-    float pv[8];
-    if (PRO == 2) {
-      const int cc = live ? c0 : 0;
-#pragma unroll
-      for (int j = 0; j < 8; j += 4) {
-        const float4 q4 = *reinterpret_cast<const float4*>(p.pe + t * K + cc + j);
-        pv[j] = q4.x; pv[j + 1] = q4.y; pv[j + 2] = q4.z; pv[j + 3] = q4.w;
+      for (int c = tid; c < K / 4; c += 256) {                     // gamma | beta -> LDS (read after the barrier below)
+        *reinterpret_cast<float4*>(gb + c * 4) = *reinterpret_cast<const float4*>(p.gamma + c * 4);
+        *reinterpret_cast<float4*>(gb + K + c * 4) = *reinterpret_cast<const float4*>(p.beta + c * 4);
       }
-    }
+      // z = y + residual rounded to the storage type first (what asr_add_ln_fwd stores and normalises), fp32 statistics
+      float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = wave * 8 + i;
-      const int mm = m < p.B ? m : p.B - 1, cc = live ? c0 : 0;
-      if (PRO == 1) {
-        cy[i].v = *reinterpret_cast<const uint4*>(p.Y + (int64_t)mm * K + cc);
-        cr[i].v = *reinterpret_cast<const uint4*>(p.R + (int64_t)mm * K + cc);
-      } else {
-        const float* e = p.table + p.tok[mm] * (int64_t)K + cc;
+      for (int j = 0; j < 8; ++j) {
+        const bool live = j * 8 + sub < nch;
 #pragma unroll
-        for (int j = 0; j < 8; j += 4) {
-          const float4 e4 = *reinterpret_cast<const float4*>(e + j);
-          ev[PRO == 2 ? i : 0][j] = e4.x; ev[PRO == 2 ? i : 0][j + 1] = e4.y; ev[PRO == 2 ? i : 0][j + 2] = e4.z; ev[PRO == 2 ? i : 0][j + 3] = e4.w;
+        for (int e = 0; e < 8; ++e) {
+          z[j].e[e] = f32_to_bf16(bf16_to_f32(cy[j].e[e]) + bf16_to_f32(cr[j].e[e]));
+          s += live ? bf16_to_f32(z[j].e[e]) : 0.f;
         }
       }
-    }
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      const float mu = s / (float)K;
+      float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = wave * 8 + i;
-      Chunk<bf16_t> o;
-      o.v = make_uint4(0u, 0u, 0u, 0u);
-      if (PRO == 1) {
-        // z = y + residual rounded to the storage type first (what asr_add_ln_fwd stores and normalises), fp32 statistics
-        float z[8], s = 0.f;
+      for (int j = 0; j < 8; ++j) {
+        const bool live = j * 8 + sub < nch;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          z[j] = live ? bf16_to_f32(f32_to_bf16(bf16_to_f32(cy[i].e[j]) + bf16_to_f32(cr[i].e[j]))) : 0.f;
-          s += z[j];
-        }
-        const float mu = wave_sum(s) / (float)K;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = live ? z[j] - mu : 0.f; q += d * d; }
-        const float rs = rsqrtf(wave_sum(q) / (float)K + p.eps);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f32_to_bf16((z[j] - mu) * rs * gm[j] + bt[j]);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o.e[j] = f32_to_bf16(ev[PRO == 2 ? i : 0][j] * p.scale + pv[j]);
+        for (int e = 0; e < 8; ++e) { const float d = live ? bf16_to_f32(z[j].e[e]) - mu : 0.f; q += d * d; }
       }
-      if (m >= p.B) o.v = make_uint4(0u, 0u, 0u, 0u);
-      if (live) {
-        *reinterpret_cast<uint4*>(xs + m * XP + c0 * 2) = o.v;
-        if (blockIdx.x == 0 && p.x_out && m < p.B) *reinterpret_cast<uint4*>(p.x_out + (int64_t)m * K + c0) = o.v;
+      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+      const float rs = rsqrtf(q / (float)K + p.eps);
+      __syncthreads();                                             // gamma / beta are in LDS
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = j * 8 + sub;
+        if (c < nch) {
+          Chunk<bf16_t> o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            o.e[e] = f32_to_bf16((bf16_to_f32(z[j].e[e]) - mu) * rs * gb[c * 8 + e] + gb[K + c * 8 + e]);
+          if (m >= p.B) o.v = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(xs + m * XP + c * 16) = o.v;
+          if (blockIdx.x == 0 && p.x_out && m < p.B) *reinterpret_cast<uint4*>(p.x_out + (int64_t)m * K + c * 8) = o.v;
+        }
+      }
+    } else {
+      const int64_t t = p.state[0];
+      const float* erow = p.table + p.tok[mm] * (int64_t)K;
+      const float* prow = p.pe + t * K;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = j * 8 + sub;
+        if (c < nch) {
+          const float4 e0 = *reinterpret_cast<const float4*>(erow + c * 8), e1 = *reinterpret_cast<const float4*>(erow + c * 8 + 4);
+          const float4 q0 = *reinterpret_cast<const float4*>(prow + c * 8), q1 = *reinterpret_cast<const float4*>(prow + c * 8 + 4);
+          Chunk<bf16_t> o;
+          o.e[0] = f32_to_bf16(e0.x * p.scale + q0.x); o.e[1] = f32_to_bf16(e0.y * p.scale + q0.y);
+          o.e[2] = f32_to_bf16(e0.z * p.scale + q0.z); o.e[3] = f32_to_bf16(e0.w * p.scale + q0.w);
+          o.e[4] = f32_to_bf16(e1.x * p.scale + q1.x); o.e[5] = f32_to_bf16(e1.y * p.scale + q1.y);
+          o.e[6] = f32_to_bf16(e1.z * p.scale + q1.z); o.e[7] = f32_to_bf16(e1.w * p.scale + q1.w);
+          if (m >= p.B) o.v = make_uint4(0u, 0u, 0u, 0u);
+          *reinterpret_cast<uint4*>(xs + m * XP + c * 16) = o.v;
+          if (blockIdx.x == 0 && p.x_out && m < p.B) *reinterpret_cast<uint4*>(p.x_out + (int64_t)m * K + c * 8) = o.v;
+        }
       }
     }
     __syncthreads();
   }
 
-  // ---- K loop: wave w contracts k in [w K/4, (w+1) K/4); A = 32 weight rows (output columns), B = the 32 input rows
-  const int kw = wave * (K >> 2);
-  const int ksteps = K >> 6;
+  // ---- K loop: wave w contracts its k range; A = 32 weight rows (output columns), B = the 32 input rows
   f32x16_t acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  const int nrow = n0 + lr < p.N ? n0 + lr : p.N - 1;
-  const bf16_t* wp = p.W + (int64_t)nrow * p.ldw + kw + 8 * half;
-  const bf16_t* xp = PRO == 0 ? p.X + (int64_t)(lr < p.B ? lr : p.B - 1) * p.ldx + kw + 8 * half : nullptr;
+  const bf16_t* xp = PRO != 0 ? nullptr
+                     : (p.x_frag ? p.X + ((int64_t)(kw >> 4) * 64 + lane) * 8 : p.X + (int64_t)(lr < p.B ? lr : p.B - 1) * p.ldx + kw + 8 * half);
+  const int xstep = p.x_frag ? 512 : 16;
   const unsigned char* xl = xs + lr * XP + (kw + 8 * half) * 2;
-  for (int s0 = 0; s0 < ksteps; s0 += GS) {
-    uint4 a[GS], b[GS];
 #pragma unroll
-    for (int i = 0; i < GS; ++i)
-      if (s0 + i < ksteps) {
-        a[i] = *reinterpret_cast<const uint4*>(wp + (s0 + i) * 16);
-        if (PRO == 0) b[i] = *reinterpret_cast<const uint4*>(xp + (s0 + i) * 16);
-        else b[i] = *reinterpret_cast<const uint4*>(xl + (s0 + i) * 32);
-      }
+  for (int i = 0; i < GS; ++i)
+    if (i < ksteps) {
+      if (PRO == 0) b[i] = *reinterpret_cast<const uint4*>(xp + i * xstep);
+      else b[i] = *reinterpret_cast<const uint4*>(xl + i * 32);
+    }
 #pragma unroll
-    for (int i = 0; i < GS; ++i)
-      if (s0 + i < ksteps)
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[i]), acc, 0, 0, 0);
-  }
+  for (int i = 0; i < GS; ++i)
+    if (i < ksteps)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[i]), __builtin_bit_cast(bf16x8_t, b[i]), acc, 0, 0, 0);
 
-  // ---- the four waves' partial tiles meet in LDS (fragment layout: lane-private slots)
+  // ---- the waves' partial tiles meet in LDS (fragment layout: lane-private slots)
   if (wave > 0) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
@@ -151,7 +166,9 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs p) {
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane];
+  for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
   // D fragment: column (input row m) = lane & 31, row (output column) = 8 (r / 4) + 4 (lane >> 5) + (r & 3)
   const int m = lr;
   if (m >= p.B) return;
@@ -164,6 +181,17 @@ __global__ __launch_bounds__(256) void dec_gemm_kernel(DecGemmArgs p) {
     for (int e = 0; e < 4; ++e) {
       v[e] = acc[4 * q + e] + ((p.bias && n + e < p.N) ? p.bias[n + e] : 0.f);
       if (p.relu) v[e] = fmaxf(v[e], 0.f);
+    }
+    if constexpr (sizeof(TO) == 2) {
+      if (p.out_frag) {                 // chunk n / 8 of row m in the layout the next GEMM reads: ((chunk/2) 64 + (chunk%2) 32 + m) 8
+        const int ch = n >> 3;
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        if (n + 3 < p.N)
+          *reinterpret_cast<uint2*>(static_cast<bf16_t*>(p.out) + ((int64_t)(ch >> 1) * 64 + (ch & 1) * 32 + m) * 8 + (n & 7)) = o;
+        continue;
+      }
     }
     if (n + 3 < p.N) {
       if constexpr (sizeof(TO) == 4) {
@@ -189,18 +217,22 @@ struct DecAttnArgs {
   bf16_t* kc; bf16_t* vc; int64_t cbs, cld;              // caches / encoder keys and values: (B, rows, H * 64), batch and row strides
   int rows;                                              // cache length (self attention) or number of keys (cross attention)
   bf16_t* out; int64_t ldo;
-  int B, H; float scale;
+  int B, H; float scale; int out_frag;
   const int64_t* state;                                  // self attention: state[0] = position t (keys 0..t); null: all `rows` keys
 };
 
-constexpr int DEC_NI = 8;                                // keys per lane: up to 512 keys
+constexpr int DEC_MAX_KEYS = 512;
 
+// One workgroup per (sequence, head).  thread = (16-byte channel chunk c = tid % 8, key group jg = tid / 8): keys jg, jg + 32, ...
+// -- the 8 lanes of a key read its 128-byte row as ONE contiguous access, for the scores (partial dot products over 8 channels,
+// three xor shuffles) and for P V alike; all <= 16 + 16 loads of a thread are issued before the first use (the values do not
+// depend on the softmax), the softmax statistics go through LDS.
 __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs p) {
-  __shared__ float pbuf[4][DEC_NI * 64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.x * 4 + wave;
-  if (bh >= p.B * p.H) return;                           // waves are independent: no workgroup barrier below
-  const int b = bh / p.H, h = bh % p.H;
+  constexpr int NI = DEC_MAX_KEYS / 32;
+  __shared__ float wred[2][4];
+  __shared__ float ored[4][8][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   int t = -1, L = p.rows;
   if (p.state) {
     const int64_t ts = p.state[0];
@@ -211,83 +243,82 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs p) {
   const bf16_t* kn = p.kn ? p.kn + (int64_t)b * p.ldn + h * 64 : kc;
   const bf16_t* vn = p.vn ? p.vn + (int64_t)b * p.ldn + h * 64 : vc;
   const int tsel = p.kn ? t : -1;                        // row t comes from the source rows when it is appended by this launch
-  if (tsel >= 0 && lane < 16) {                          // append: row t of both caches (read below from the source rows)
-    const int c = (lane & 7) * 8;
-    const uint4 v = *reinterpret_cast<const uint4*>((lane < 8 ? kn : vn) + c);
-    *reinterpret_cast<uint4*>((lane < 8 ? p.kc : p.vc) + b * p.cbs + (int64_t)t * p.cld + h * 64 + c) = v;
+  if (tsel >= 0 && tid < 16) {                           // append: row t of both caches (read below from the source rows)
+    const int c = (tid & 7) * 8;
+    const uint4 v = *reinterpret_cast<const uint4*>((tid < 8 ? kn : vn) + c);
+    *reinterpret_cast<uint4*>((tid < 8 ? p.kc : p.vc) + b * p.cbs + (int64_t)t * p.cld + h * 64 + c) = v;
   }
-  float qf[64];
-  {
-    const bf16_t* q = p.q + (int64_t)b * p.ldq + h * 64;
+  const int c = (tid & 7) * 8, jg = tid >> 3;
+  Chunk<bf16_t> kq, kk[NI], vv[NI];
+  kq.v = *reinterpret_cast<const uint4*>(p.q + (int64_t)b * p.ldq + h * 64 + c);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      Chunk<bf16_t> ch;
-      ch.v = *reinterpret_cast<const uint4*>(q + c * 8);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[c * 8 + e] = bf16_to_f32(ch.e[e]) * p.scale;
+  for (int i = 0; i < NI; ++i)
+    if (i * 32 < L) {                                    // uniform
+      const int j = jg + 32 * i, jj = j < L ? j : L - 1;
+      kk[i].v = *reinterpret_cast<const uint4*>((jj == tsel ? kn : kc + (int64_t)jj * p.cld) + c);
     }
-  }
-  float s[DEC_NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (i * 32 < L) {
+      const int j = jg + 32 * i, jj = j < L ? j : L - 1;
+      vv[i].v = *reinterpret_cast<const uint4*>((jj == tsel ? vn : vc + (int64_t)jj * p.cld) + c);
+    }
+  // ---- scores
+  float qf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] = bf16_to_f32(kq.e[e]);
+  float sc[NI];
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < DEC_NI; ++i) {
-    s[i] = -INFINITY;
-    if (i * 64 < L) {
-      const int j = lane + 64 * i;
-      const int jj = j < L ? j : L - 1;
-      const bf16_t* kr = jj == tsel ? kn : kc + (int64_t)jj * p.cld;
-      Chunk<bf16_t> ch[8];
+  for (int i = 0; i < NI; ++i) {
+    sc[i] = -INFINITY;
+    if (i * 32 < L) {
+      float d = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ch[c].v = *reinterpret_cast<const uint4*>(kr + c * 8);
-      float d0 = 0.f, d1 = 0.f;
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-          d0 += qf[c * 8 + e] * bf16_to_f32(ch[c].e[e]);
-          d1 += qf[c * 8 + e + 1] * bf16_to_f32(ch[c].e[e + 1]);
-        }
-      if (j < L) s[i] = d0 + d1;
-      mx = fmaxf(mx, s[i]);
+      for (int e = 0; e < 8; ++e) d += qf[e] * bf16_to_f32(kk[i].e[e]);
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      if (jg + 32 * i < L) sc[i] = d * p.scale;
+      mx = fmaxf(mx, sc[i]);
     }
   }
   mx = wave_max(mx);
-  float l = 0.f;
-#pragma unroll
-  for (int i = 0; i < DEC_NI; ++i)
-    if (i * 64 < L) {
-      const float pr = s[i] == -INFINITY ? 0.f : __expf(s[i] - mx);
-      l += pr;
-      pbuf[wave][lane + 64 * i] = bf16_to_f32(f32_to_bf16(pr));      // the probabilities enter P V in the storage type
-    }
-  l = wave_sum(l);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  // P V: lane = (8-channel chunk c, key group jg): keys jg, jg + 8, ...; the 8 groups meet by three xor shuffles
-  const int c = (lane & 7) * 8, jg = lane >> 3;
-  float acc[8];
+  if (lane == 0) wred[0][wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
+  // ---- probabilities (every lane of a key group holds the same value) and P V
+  float l = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-#pragma unroll 4
-  for (int j = jg; j < L; j += 8) {
-    const float pj = pbuf[wave][j];
-    const bf16_t* vr = j == tsel ? vn : vc + (int64_t)j * p.cld;
-    Chunk<bf16_t> ch;
-    ch.v = *reinterpret_cast<const uint4*>(vr + c);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] += pj * bf16_to_f32(ch.e[e]);
-  }
+  for (int i = 0; i < NI; ++i)
+    if (i * 32 < L) {
+      const float pr = sc[i] == -INFINITY ? 0.f : __expf(sc[i] - mx);
+      l += pr;
+      const float pj = bf16_to_f32(f32_to_bf16(pr));     // the probabilities enter P V in the storage type
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pj * bf16_to_f32(vv[i].e[e]);
+    }
+  // sums over the 8 key groups of a wave (lane bits 3..5), then over the 4 waves through LDS; l is replicated 8 x per key
+  l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
-  if (jg == 0) {
-    const float inv = l > 0.f ? 1.f / l : 0.f;
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ored[wave][lane][e] = acc[e];
+    if (lane == 0) wred[1][wave] = l;
+  }
+  __syncthreads();
+  if (tid < 8) {
+    const float lt = wred[1][0] + wred[1][1] + wred[1][2] + wred[1][3];
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
     Chunk<bf16_t> o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o.e[e] = f32_to_bf16(acc[e] * inv);
-    *reinterpret_cast<uint4*>(p.out + (int64_t)b * p.ldo + h * 64 + c) = o.v;
+    for (int e = 0; e < 8; ++e) o.e[e] = f32_to_bf16((ored[0][tid][e] + ored[1][tid][e] + ored[2][tid][e] + ored[3][tid][e]) * inv);
+    const int ch = h * 8 + tid;
+    if (p.out_frag) *reinterpret_cast<uint4*>(p.out + ((int64_t)(ch >> 1) * 64 + (ch & 1) * 32 + b) * 8) = o.v;
+    else *reinterpret_cast<uint4*>(p.out + (int64_t)b * p.ldo + h * 64 + tid * 8) = o.v;
   }
 }
 
@@ -332,15 +363,18 @@ __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int asr_dec_gemm(const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int B, int N, int K, int relu,
-                            int out_dtype, int prologue, const void* X, int64_t ldx, const void* Y, const void* R, const float* gamma,
+                            int out_dtype, int layout, int prologue, const void* X, int64_t ldx, const void* Y, const void* R, const float* gamma,
                             const float* beta, float eps, void* x_out, const int64_t* tok, const float* table, const float* pe,
                             float scale, const int64_t* state, hipStream_t s) {
   ASR_CHECK_ARG(W && out && B >= 0 && N > 0 && K > 0 && prologue >= 0 && prologue <= 2);
   ASR_CHECK_ARG(out_dtype == ASR_F32 || out_dtype == ASR_BF16);
+  ASR_CHECK_ARG(layout >= 0 && layout < 8 && !((layout & ASR_DEC_X_FRAG) && prologue != 0) && !((layout & ASR_DEC_OUT_FRAG) && out_dtype != ASR_BF16));
   if (B > 32 || K % 64 != 0 || ldw % 8 != 0 || !aligned16(W) || ldo % 4 != 0 || !aligned16(out)) return ASR_EUNSUPPORTED;
+  if ((layout & ASR_DEC_OUT_FRAG) && N % 16 != 0) return ASR_EUNSUPPORTED;
   if (prologue != 0 && K > 512) return ASR_EUNSUPPORTED;
   if (prologue == 0) ASR_CHECK_ARG(X && ldx >= K);
-  if (prologue == 0 && (ldx % 8 != 0 || !aligned16(X))) return ASR_EUNSUPPORTED;
+  if (prologue == 0 && !(layout & ASR_DEC_X_FRAG) && ldx % 8 != 0) return ASR_EUNSUPPORTED;
+  if (prologue == 0 && !aligned16(X)) return ASR_EUNSUPPORTED;
   if (prologue == 1) ASR_CHECK_ARG(Y && R && gamma && beta && aligned16(Y) && aligned16(R) && aligned16(gamma) && aligned16(beta));
   if (prologue == 2) ASR_CHECK_ARG(tok && table && pe && state && aligned16(table) && aligned16(pe));
   if (x_out) ASR_CHECK_ARG(aligned16(x_out));
@@ -348,23 +382,27 @@ extern "C" int asr_dec_gemm(const void* W, int64_t ldw, const float* bias, void*
   DecGemmArgs p{};
   p.W = static_cast<const bf16_t*>(W); p.bias = bias; p.out = out; p.ldw = ldw; p.ldo = ldo;
   p.B = B; p.N = N; p.K = K; p.relu = relu;
+  p.w_frag = (layout & ASR_DEC_W_FRAG) != 0; p.x_frag = (layout & ASR_DEC_X_FRAG) != 0; p.out_frag = (layout & ASR_DEC_OUT_FRAG) != 0;
   p.X = static_cast<const bf16_t*>(X); p.ldx = ldx;
   p.Y = static_cast<const bf16_t*>(Y); p.R = static_cast<const bf16_t*>(R); p.gamma = gamma; p.beta = beta; p.eps = eps;
   p.x_out = static_cast<bf16_t*>(x_out);
   p.tok = tok; p.table = table; p.pe = pe; p.scale = scale; p.state = state;
   const unsigned grid = (unsigned)((N + 31) / 32);
-  const size_t lds = 3 * 16 * 64 * 4 + (prologue ? (size_t)32 * (K * 2 + 16) : 0);
   const bool f32 = out_dtype == ASR_F32;
-  const bool deep = (K >> 6) > 8;                        // more than 8 K steps per wave: 16 loads per operand in flight
+  const int nw = (prologue == 0 && K > 512 && K % 128 == 0) ? 8 : 4;            // waves that split K
+  const int ksteps = K / nw / 16;
+  if (ksteps > 16) return ASR_EUNSUPPORTED;                                  // K <= 1024 (4 waves) / 2048 (8 waves)
+  const size_t lds = (size_t)(nw - 1) * 16 * 64 * 4 + (prologue ? (size_t)32 * (K * 2 + 16) : 0);
   AsrProfScope prof(ASR_OP_GEMM, s);
-#define ASR_DEC_LAUNCH(PRO_, TO_, GS_) hipLaunchKernelGGL((dec_gemm_kernel<PRO_, TO_, GS_>), dim3(grid), dim3(256), lds, s, p)
+#define ASR_DEC_LAUNCH(PRO_, TO_, NW_, GS_) hipLaunchKernelGGL((dec_gemm_kernel<PRO_, TO_, NW_, GS_>), dim3(grid), dim3(NW_ * 64), lds, s, p)
   if (prologue == 0) {
-    if (f32) { if (deep) ASR_DEC_LAUNCH(0, float, 16); else ASR_DEC_LAUNCH(0, float, 8); }
-    else { if (deep) ASR_DEC_LAUNCH(0, bf16_t, 16); else ASR_DEC_LAUNCH(0, bf16_t, 8); }
+    if (nw == 8) { if (f32) ASR_DEC_LAUNCH(0, float, 8, 16); else ASR_DEC_LAUNCH(0, bf16_t, 8, 16); }
+    else if (ksteps > 8) { if (f32) ASR_DEC_LAUNCH(0, float, 4, 16); else ASR_DEC_LAUNCH(0, bf16_t, 4, 16); }
+    else { if (f32) ASR_DEC_LAUNCH(0, float, 4, 8); else ASR_DEC_LAUNCH(0, bf16_t, 4, 8); }
   } else if (prologue == 1) {
-    if (f32) ASR_DEC_LAUNCH(1, float, 8); else ASR_DEC_LAUNCH(1, bf16_t, 8);
+    if (f32) ASR_DEC_LAUNCH(1, float, 4, 8); else ASR_DEC_LAUNCH(1, bf16_t, 4, 8);
   } else {
-    if (f32) ASR_DEC_LAUNCH(2, float, 8); else ASR_DEC_LAUNCH(2, bf16_t, 8);
+    if (f32) ASR_DEC_LAUNCH(2, float, 4, 8); else ASR_DEC_LAUNCH(2, bf16_t, 4, 8);
   }
 #undef ASR_DEC_LAUNCH
   ASR_LAUNCH_CHECK();
@@ -373,11 +411,11 @@ extern "C" int asr_dec_gemm(const void* W, int64_t ldw, const float* bias, void*
 
 extern "C" int asr_dec_attn(const void* q, int64_t ldq, const void* k_new, const void* v_new, int64_t ld_new, void* k_cache,
                             void* v_cache, int64_t cache_batch_stride, int64_t cache_row_stride, int rows, void* out, int64_t ldo,
-                            int B, int H, int dk, float scale, const int64_t* state, hipStream_t s) {
+                            int B, int H, int dk, float scale, int out_frag, const int64_t* state, hipStream_t s) {
   ASR_CHECK_ARG(q && k_cache && v_cache && out && B >= 0 && H > 0 && rows > 0);
   ASR_CHECK_ARG((k_new == nullptr) == (v_new == nullptr));
   ASR_CHECK_ARG(!k_new || state);                        // an appended row needs its position
-  if (dk != 64 || rows > DEC_NI * 64) return ASR_EUNSUPPORTED;
+  if (dk != 64 || rows > DEC_MAX_KEYS) return ASR_EUNSUPPORTED;
   if (ldq % 8 != 0 || ldo % 8 != 0 || cache_row_stride % 8 != 0 || cache_batch_stride % 8 != 0 || (k_new && ld_new % 8 != 0) ||
       !aligned16(q) || !aligned16(out) || !aligned16(k_cache) || !aligned16(v_cache) || (k_new && (!aligned16(k_new) || !aligned16(v_new))))
     return ASR_EUNSUPPORTED;
@@ -387,8 +425,10 @@ extern "C" int asr_dec_attn(const void* q, int64_t ldq, const void* k_new, const
   p.kn = static_cast<const bf16_t*>(k_new); p.vn = static_cast<const bf16_t*>(v_new); p.ldn = ld_new;
   p.kc = static_cast<bf16_t*>(k_cache); p.vc = static_cast<bf16_t*>(v_cache); p.cbs = cache_batch_stride; p.cld = cache_row_stride;
   p.rows = rows; p.out = static_cast<bf16_t*>(out); p.ldo = ldo; p.B = B; p.H = H; p.scale = scale; p.state = state;
+  p.out_frag = out_frag;
+  if (out_frag && B > 32) return ASR_EUNSUPPORTED;
   AsrProfScope prof(ASR_OP_ATTN_FWD, s);
-  hipLaunchKernelGGL(dec_attn_kernel, dim3((unsigned)((B * H + 3) / 4)), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(dec_attn_kernel, dim3((unsigned)(B * H)), dim3(256), 0, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

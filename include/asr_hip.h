@@ -185,19 +185,27 @@ int asr_kv_append(const void* k_src, const void* v_src, int64_t src_ld, void* k_
  *   1: x = LN(Y + R) * gamma + beta (Y, R (B, K) bf16 contiguous, K <= 512; z = Y + R rounded to bf16 before the statistics,
  *      like asr_add_ln_fwd), x also stored to x_out (B, K) when given;  2: x = table[tok[b]] * scale + pe[state[0]] (fp32
  *      table / pe), stored to x_out.  out_dtype ASR_BF16 or ASR_F32.  ASR_EUNSUPPORTED outside these shapes.
+ *   Fragment-major order (`layout` flags; every wave-wide operand load of the kernel is then 1 KB of consecutive bytes): a
+ *   (rows, K) matrix is cut into blocks of 32 rows x 16 columns; block (r, s) holds, for lane = 32 * h + i (h = 0, 1; i < 32),
+ *   the 8 elements [32 r + i][16 s + 8 h .. + 7] at element offset ((r * K / 16 + s) * 64 + lane) * 8.  Weights: rows padded
+ *   with zeros to a multiple of 32.  Activations (<= 32 rows): r = 0, rows >= B are never used.
  * asr_dec_attn: one query row per sequence and head (dk = 64): q (B, ldq); keys / values (B, rows, H*64) with the given
  *   batch / row strides.  state != NULL: self attention at position t = state[0]: k_new / v_new (B, ld_new) are this
  *   position's rows -- stored to row t of both caches by this launch -- and the keys are rows 0..t; state == NULL: all
- *   `rows` keys (cross attention, no mask: transformer.py:336-350 passes none at decode time).  out (B, ldo) bf16.
+ *   `rows` keys (cross attention, no mask: transformer.py:336-350 passes none at decode time).  out (B, ldo) bf16, or
+ *   fragment-major (out_frag != 0, B <= 32).
  * asr_dec_finish: tok[b] = argmax of logits row b (lowest index on ties), done[b] |= tok == eos, out[t * B + b] = tok
  *   (t = state[0] < max_len), then state[0] = t + 1 (by the last workgroup; *ticket must be 0 before the first call).      */
+#define ASR_DEC_W_FRAG 1    /* W in fragment-major order (below)                                   */
+#define ASR_DEC_X_FRAG 2    /* prologue 0: X in fragment-major order (written by a producer with ..._OUT_FRAG) */
+#define ASR_DEC_OUT_FRAG 4  /* bf16 out in fragment-major order, N % 16 == 0                        */
 int asr_dec_gemm(const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int B, int N, int K, int relu,
-                 int out_dtype, int prologue, const void* X, int64_t ldx, const void* Y, const void* R, const float* gamma,
+                 int out_dtype, int layout, int prologue, const void* X, int64_t ldx, const void* Y, const void* R, const float* gamma,
                  const float* beta, float eps, void* x_out, const int64_t* tok, const float* table, const float* pe,
                  float scale, const int64_t* state, asr_stream_t stream);
 int asr_dec_attn(const void* q, int64_t ldq, const void* k_new, const void* v_new, int64_t ld_new, void* k_cache,
                  void* v_cache, int64_t cache_batch_stride, int64_t cache_row_stride, int rows, void* out, int64_t ldo,
-                 int B, int H, int dk, float scale, const int64_t* state, asr_stream_t stream);
+                 int B, int H, int dk, float scale, int out_frag, const int64_t* state, asr_stream_t stream);
 int asr_dec_finish(const float* logits, int64_t ld, int V, int64_t* tok, uint8_t* done, int64_t* out, int B, int max_len,
                    int eos, int64_t* state, int32_t* ticket, asr_stream_t stream);
 

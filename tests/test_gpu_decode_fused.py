@@ -40,6 +40,28 @@ def test_dec_gemm_plain(B, N, K, relu, f32out):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B,N,K", [(32, 512, 2048), (9, 2048, 512), (5, 4364, 512)])
+def test_dec_gemm_fragment_major_operands(B, N, K):
+    """Packed weight, packed input rows and packed output are the same numbers in the order of include/asr_hip.h."""
+    from asr_hip import ops
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(B, K, generator=g).to(bf).cuda()
+    W = (torch.randn(N, K, generator=g) * K ** -0.5).to(bf).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    plain = torch.zeros(B, N, dtype=bf, device="cuda")
+    ops.dec_gemm(W, bias, plain, x=x, relu=True)
+    Wf = ops.frag_pack(W)
+    assert torch.equal(ops.frag_unpack(Wf, N, K), W)
+    xf = ops.frag_pack(x)                                  # rows >= B: zeros
+    a = torch.zeros(B, N, dtype=bf, device="cuda")
+    ops.dec_gemm(Wf, bias, a, x=xf, relu=True, w_frag=(N, K), x_frag=True)
+    assert torch.equal(a, plain)
+    if N % 16 == 0:
+        of = torch.zeros(32 * N, dtype=bf, device="cuda")
+        ops.dec_gemm(Wf, bias, of, x=x, relu=True, w_frag=(N, K), out_frag=True)
+        assert torch.equal(ops.frag_unpack(of, 32, N)[:B], plain)
+
+
 @pytest.mark.parametrize("B,K", [(32, 512), (7, 256), (3, 64)])
 def test_dec_gemm_layernorm_prologue_equals_add_ln_then_gemm(B, K):
     from asr_hip import ops
@@ -129,6 +151,9 @@ def test_dec_attn_cross(rows, shared):
     ops.dec_attn(q, K, V, out, H, d, d ** -0.5)
     ref = _attn_ref(q, K, V, H, d ** -0.5)
     assert (out.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    of = torch.zeros(32 * HD, dtype=bf, device="cuda")
+    ops.dec_attn(q, K, V, of, H, d, d ** -0.5, out_frag=True)
+    assert torch.equal(ops.frag_unpack(of, 32, HD)[:B], out)
 
 
 def test_dec_finish_argmax_done_output_and_position():
@@ -201,7 +226,8 @@ def test_fused_greedy_graph_replay_equals_eager_and_follows_the_per_op_argmax():
     g = torch.Generator().manual_seed(5)
     B, steps = 4, 40
     enc = torch.randn(B, 50, 512, generator=g).cuda()
-    toks = FusedGreedyDecoder(dec, enc, max_len=steps).run(steps, check_every=1000)          # 2 eager steps + 38 replays
+    B, steps = 4, 41
+    toks = FusedGreedyDecoder(dec, enc, max_len=steps).run(steps, check_every=1000)          # 2 eager steps + 9 replays of 4 + 3 eager
     eager = FusedGreedyDecoder(dec, enc, max_len=steps)
     for _ in range(steps):
         eager._step()
@@ -215,6 +241,18 @@ def test_fused_greedy_graph_replay_equals_eager_and_follows_the_per_op_argmax():
         got = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
         assert ((top - got) <= 3e-2 * lg.abs().max()).all(), t
         prev = toks[:, t].contiguous()
-    # the public entry point picks this path for bf16 at these shapes
+    # the public entry point picks this path for bf16 at these shapes, and a second call with the same shapes reuses the
+    # captured graph with fresh encoder keys / values
+    from asr_hip.decode import greedy_search_graphed
+    a1 = greedy_search_graphed(dec, enc, steps=steps)
+    assert a1.shape[1] <= steps and torch.equal(a1, toks[:, :a1.shape[1]])      # (stops once every row has emitted EOS)
+    enc2 = torch.randn(B, 50, 512, generator=g).cuda()
+    held = dec._asr_fused_decoders[(B, 50, steps, str(enc.device))]
+    a2 = greedy_search_graphed(dec, enc2, steps=steps)
+    assert dec._asr_fused_decoders[(B, 50, steps, str(enc.device))] is held
+    fresh = FusedGreedyDecoder(dec, enc2, max_len=steps)
+    for _ in range(steps):
+        fresh._step()
+    assert torch.equal(a2, fresh.out.t()[:, :a2.shape[1]]) and not torch.equal(a2[:, :8], a1[:, :8])
     strs = dec.greedy_search(enc[:2], use_cache=True)
     assert len(strs) == 2

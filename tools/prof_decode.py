@@ -9,7 +9,7 @@ from collections import defaultdict
 
 c = sqlite3.connect(sys.argv[1])
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
-marks = [i for i, r in enumerate(rows) if "decode_prepare" in r[0]]
+marks = [i for i, r in enumerate(rows) if "decode_prepare" in r[0] or "dec_finish" in r[0]]
 if len(sys.argv) > 2:
     print("# " + sys.argv[2])
 print("# %d kernels, %d tokens" % (len(rows), len(marks)))
