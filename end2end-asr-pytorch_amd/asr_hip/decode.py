@@ -224,6 +224,7 @@ def _dec_pack(decoder):
         w1, w2_ = (ff.conv_1, ff.conv_2) if hasattr(ff, "conv_1") else (ff.linear_1, ff.linear_2)
         layers.append(dict(
             wqkv=fr(torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0)),
+            wqkv_rm=torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0).contiguous(), wq_c_rm=w2(ca.query_linear),
             bqkv=torch.cat([b1(sa.query_linear), b1(sa.key_linear), b1(sa.value_linear)], 0).contiguous(),
             wo_s=fr(w2(sa.output_linear)), bo_s=b1(sa.output_linear),
             ln_s=(sa.layer_norm.weight.data.float().contiguous(), sa.layer_norm.bias.data.float().contiguous(), sa.layer_norm.eps),
@@ -256,11 +257,17 @@ class FusedGreedyDecoder:
     """Greedy loop on the decode-step kernels of csrc/decode.hip: per layer 8 launches (Q/K/V GEMM with the previous LayerNorm or
     the embedding as its prologue, self attention that appends its own key / value rows, output GEMM, cross-attention query GEMM
     with LayerNorm prologue, cross attention, output GEMM, two feed-forward GEMMs), then the vocabulary GEMM and asr_dec_finish:
-    34 launches per token for the 4-layer model instead of 62, captured once (TOKENS_PER_GRAPH steps per graph: the host's
+    34 launches per token for the 4-layer model instead of 62 (30 with the cross-attention query projection inside the attention
+    launch, asr_dec_attn_fused), captured once (TOKENS_PER_GRAPH steps per graph: the host's
     replay gap is paid once per graph) and replayed; the object -- buffers and graph -- is kept on the decoder and reused by
     later calls with the same shapes (greedy_search_graphed), only the cross-attention keys / values are recomputed."""
 
-    TOKENS_PER_GRAPH = 4
+    TOKENS_PER_GRAPH = 8
+    # projections inside the attention launches (asr_dec_attn_fused).  Measured at B = 32, t = 300 (profiles/r02_decode_trace.txt):
+    # cross attention 11.0 us fused vs 6.7 + 8.6 us as two launches -- on; self attention 19.9 us fused vs 7.0 + 10.8 us: every
+    # (sequence, head) workgroup re-reads the head's 192 KB of Q/K/V rows, 48 MB through L2 per layer against 1.5 MB in the GEMM -- off
+    FUSE_CROSS = True
+    FUSE_SELF = False
 
     def __init__(self, decoder, encoder_padded_outputs, max_len):
         self.dec = decoder
@@ -300,15 +307,24 @@ class FusedGreedyDecoder:
             return ops.dec_gemm(w[0], bias, out, w_frag=w[1], **kw)
 
         for i, Lw in enumerate(P_["layers"]):
-            if prev is None:
-                gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0, embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
+            if self.FUSE_SELF:
+                src = dict(embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale)) if prev is None else dict(ln=prev)
+                ops.dec_attn_fused(Lw["wqkv_rm"], Lw["bqkv"], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale, x_out=x0,
+                                   state=self.state, self_attention=True, out_frag=True, **src)
             else:
-                gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
-            ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
-                         k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state, out_frag=True)
+                if prev is None:
+                    gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0, embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
+                else:
+                    gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
+                ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
+                             k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state, out_frag=True)
             gemm(Lw["wo_s"], Lw["bo_s"], self.y, x=self.o, x_frag=True)
-            gemm(Lw["wq_c"], Lw["bq_c"], self.qc, ln=(self.y, x0) + Lw["ln_s"], x_out=x1)
-            ops.dec_attn(self.qc, c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale, out_frag=True)
+            if self.FUSE_CROSS:
+                ops.dec_attn_fused(Lw["wq_c_rm"], Lw["bq_c"], c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale,
+                                   ln=(self.y, x0) + Lw["ln_s"], x_out=x1, out_frag=True)
+            else:
+                gemm(Lw["wq_c"], Lw["bq_c"], self.qc, ln=(self.y, x0) + Lw["ln_s"], x_out=x1)
+                ops.dec_attn(self.qc, c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale, out_frag=True)
             gemm(Lw["wo_c"], Lw["bo_c"], self.y2, x=self.o, x_frag=True)
             gemm(Lw["w1"], Lw["b1"], self.h, ln=(self.y2, x1) + Lw["ln_c"], x_out=x2, relu=True, out_frag=True, B=B)
             gemm(Lw["w2"], Lw["b2"], self.y3, x=self.h, x_frag=True)

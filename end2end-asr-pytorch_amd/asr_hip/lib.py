@@ -60,6 +60,8 @@ _SIGS = {
     "asr_argmax_rows": (_I, [_P, _L, _I, _I, _P, _P]),
     "asr_dec_gemm": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P]),
     "asr_dec_attn": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _L, _I, _P, _L, _I, _I, _I, _F, _I, _P, _P]),
+    "asr_dec_attn_fused": (_I, [_P, _P, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _F, _P, _P, _P, _L, _L, _I, _P, _L, _I, _I, _I, _F, _I,
+                                _P, _P]),
     "asr_dec_finish": (_I, [_P, _L, _I, _P, _P, _P, _I, _I, _I, _P, _P, _P]),
     "asr_ce_bwd": (_I, [_P, _L, _P, _P, _I, _I, _F, _I, _P, _P, _P, _L, _I, _P]),
     "asr_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P]),

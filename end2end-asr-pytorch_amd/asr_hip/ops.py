@@ -541,6 +541,37 @@ def dec_attn(q, k_cache, v_cache, out, H, dk, scale, k_new=None, v_new=None, sta
     return out
 
 
+def dec_attn_fused(W, bias, k_cache, v_cache, out, H, dk, scale, ln=None, embed=None, x_out=None, state=None, self_attention=False,
+                   out_frag=False):
+    """LayerNorm / embedding prologue + this head's projections + single-query attention in one launch (asr_dec_attn_fused).
+    W ((3 if self_attention else 1) * H*dk, D) bf16 row-major; ln = (Y, R, gamma, beta, eps) or embed = (tok, table, pe, scale)."""
+    NW, D = W.shape
+    assert W.dtype == torch.bfloat16 and W.is_contiguous() and NW == (3 if self_attention else 1) * H * dk
+    assert k_cache.stride(2) == 1 and k_cache.stride() == v_cache.stride()
+    Y = R = g = bt = tok = table = pe = None
+    eps, es = 0.0, 1.0
+    if ln is not None:
+        Y, R, g, bt, eps = ln
+        B = Y.shape[0]
+        assert Y.dtype == R.dtype == torch.bfloat16 and Y.shape == R.shape == (B, D) and Y.is_contiguous() and R.is_contiguous()
+    else:
+        tok, table, pe, es = embed
+        B = tok.shape[0]
+        assert tok.dtype == torch.int64 and table.dtype == pe.dtype == torch.float32 and table.shape[1] == D == pe.shape[1]
+    if out_frag:
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.numel() == 32 * H * dk
+        ldo = H * dk
+    else:
+        assert out.stride(1) == 1 and out.shape == (B, H * dk)
+        ldo = out.stride(0)
+    if x_out is not None:
+        assert x_out.dtype == torch.bfloat16 and x_out.shape == (B, D) and x_out.is_contiguous()
+    L.call("asr_dec_attn_fused", L.ptr(W), L.ptr(bias), D, int(self_attention), L.ptr(Y), L.ptr(R), L.ptr(g), L.ptr(bt), float(eps),
+           L.ptr(tok), L.ptr(table), L.ptr(pe), float(es), L.ptr(x_out), L.ptr(k_cache), L.ptr(v_cache), k_cache.stride(0),
+           k_cache.stride(1), k_cache.shape[1], L.ptr(out), ldo, B, H, dk, float(scale), int(out_frag), L.ptr(state), L.stream())
+    return out
+
+
 def dec_finish(logits, tok, done, out, eos, state, ticket):
     """tok = argmax(logits) per row, done |= tok == eos, out[state[0]] = tok, state[0] += 1 (asr_dec_finish)."""
     B, V = logits.shape

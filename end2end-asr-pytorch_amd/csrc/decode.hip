@@ -322,6 +322,242 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ projections + attention
+// The sub-layer input row AND this head's projections inside the attention launch: workgroup (sequence b, head h), 512 threads,
+//   1. every load is issued first: the head's 64 (cross: query) or 192 (self: query, key, value) weight rows -- thread (output o =
+//      tid / 8, k eighth tid % 8) reads 128 consecutive bytes per row, 8 lanes a whole 1 KB row --, the cached keys / values (thread =
+//      (16-byte chunk, key group of 64)), and the two rows of the prologue;
+//   2. wave 0: x = LayerNorm(Y[b] + R[b]) (or embedding[tok[b]] scale + pe[t]) -> LDS, head 0 stores it for the next residual;
+//   3. 64 / 192 dot products of length D from registers x LDS, 8-lane xor reduction, bias, rounded to bf16 like the GEMM's output;
+//   4. self attention: key / value row t -> cache, and taken from LDS for the scores; then softmax and P V as in dec_attn_kernel.
+// Replaces two launches (the LayerNorm-prologue GEMM and the attention) by one: 34 -> 26 launches per token.
+struct DecFusedArgs {
+  const bf16_t* Y; const bf16_t* R; const float* gamma; const float* beta; float eps;
+  const int64_t* tok; const float* table; const float* pe; float emb_scale;
+  bf16_t* x_out;
+  const bf16_t* W; const float* bias; int D;
+  bf16_t* kc; bf16_t* vc; int64_t cbs, cld; int rows;
+  bf16_t* out; int64_t ldo; int B, H; float scale; int out_frag;
+  const int64_t* state;
+};
+
+template <bool SELF, bool EMBED>
+__global__ __launch_bounds__(512) void dec_attn_fused_kernel(DecFusedArgs p) {
+  constexpr int NP = SELF ? 2 : 1;                       // projections of the first pass (the value rows' weights are loaded
+  constexpr int NI = DEC_MAX_KEYS / 64;                  // once the query / key dot products have freed their registers)
+  __shared__ float xs[512];                              // the sub-layer input row (bf16 values as fp32)
+  __shared__ float pr[SELF ? 3 : 1][64];                 // this head's query (, key, value) row
+  __shared__ float wred[2][8];
+  __shared__ float ored[8][8][8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int D = p.D, HD = p.H * 64;
+  int t = -1, L = p.rows;
+  if (SELF || EMBED) {
+    const int64_t ts = p.state[0];
+    if (SELF && ts < p.rows) { t = (int)ts; L = t + 1; }
+  }
+  // ---- 1. loads
+  const int o = tid >> 3, ke = tid & 7;
+  const int nck = D >> 6;                                // 16-byte chunks of a weight row per thread (<= 8)
+  Chunk<bf16_t> wq[NP][8];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const bf16_t* wr = p.W + ((int64_t)j * HD + h * 64 + o) * D + ke * 8;      // chunks ke, ke + 8, ...: 8 lanes read 128 consecutive bytes
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nck) wq[j][c].v = *reinterpret_cast<const uint4*>(wr + c * 64);
+  }
+  const bf16_t* kc = p.kc + b * p.cbs + h * 64;
+  const bf16_t* vc = p.vc + b * p.cbs + h * 64;
+  const int c8 = (tid & 7) * 8, jg = tid >> 3;
+  Chunk<bf16_t> kk[NI], vv[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (i * 64 < L) {                                    // uniform
+      const int j = jg + 64 * i, jj = j < L ? j : L - 1;
+      kk[i].v = *reinterpret_cast<const uint4*>(kc + (int64_t)jj * p.cld + c8);
+    }
+  // ---- 2. the input row (wave 0; D <= 512: one 16-byte chunk per lane)
+  if (wave == 0) {
+    const int c0 = lane * 8;
+    const bool live = c0 < D;
+    const int cc = live ? c0 : 0;
+    Chunk<bf16_t> xo;
+    if (EMBED) {
+      const int64_t tt = p.state[0];
+      const float* e = p.table + p.tok[b] * (int64_t)D + cc;
+      const float* q = p.pe + tt * D + cc;
+      const float4 e0 = *reinterpret_cast<const float4*>(e), e1 = *reinterpret_cast<const float4*>(e + 4);
+      const float4 q0 = *reinterpret_cast<const float4*>(q), q1 = *reinterpret_cast<const float4*>(q + 4);
+      xo.e[0] = f32_to_bf16(e0.x * p.emb_scale + q0.x); xo.e[1] = f32_to_bf16(e0.y * p.emb_scale + q0.y);
+      xo.e[2] = f32_to_bf16(e0.z * p.emb_scale + q0.z); xo.e[3] = f32_to_bf16(e0.w * p.emb_scale + q0.w);
+      xo.e[4] = f32_to_bf16(e1.x * p.emb_scale + q1.x); xo.e[5] = f32_to_bf16(e1.y * p.emb_scale + q1.y);
+      xo.e[6] = f32_to_bf16(e1.z * p.emb_scale + q1.z); xo.e[7] = f32_to_bf16(e1.w * p.emb_scale + q1.w);
+    } else {
+      Chunk<bf16_t> cy, cr;
+      cy.v = *reinterpret_cast<const uint4*>(p.Y + (int64_t)b * D + cc);
+      cr.v = *reinterpret_cast<const uint4*>(p.R + (int64_t)b * D + cc);
+      float gm[8], bt[8];
+#pragma unroll
+      for (int j = 0; j < 8; j += 4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(p.gamma + cc + j), b4 = *reinterpret_cast<const float4*>(p.beta + cc + j);
+        gm[j] = g4.x; gm[j + 1] = g4.y; gm[j + 2] = g4.z; gm[j + 3] = g4.w;
+        bt[j] = b4.x; bt[j + 1] = b4.y; bt[j + 2] = b4.z; bt[j + 3] = b4.w;
+      }
+      float z[8], sum = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        z[e] = live ? bf16_to_f32(f32_to_bf16(bf16_to_f32(cy.e[e]) + bf16_to_f32(cr.e[e]))) : 0.f;
+        sum += z[e];
+      }
+      const float mu = wave_sum(sum) / (float)D;
+      float q = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = live ? z[e] - mu : 0.f; q += d * d; }
+      const float rs = rsqrtf(wave_sum(q) / (float)D + p.eps);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xo.e[e] = f32_to_bf16((z[e] - mu) * rs * gm[e] + bt[e]);
+    }
+    if (live) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xs[c0 + e] = bf16_to_f32(xo.e[e]);
+      if (h == 0 && p.x_out) *reinterpret_cast<uint4*>(p.x_out + (int64_t)b * D + c0) = xo.v;
+    }
+  }
+  __syncthreads();
+  // ---- 3. projections
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nck) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += bf16_to_f32(wq[j][c].e[e]) * xs[c * 64 + ke * 8 + e];
+      }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    if (ke == 0) pr[j][o] = bf16_to_f32(f32_to_bf16(d + (p.bias ? p.bias[j * HD + h * 64 + o] : 0.f)));
+  }
+  // the cached values (and the value rows' weights) go out now, into the registers the first-pass weights have freed, and land
+  // under the scores and the softmax
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (i * 64 < L) {
+      const int j = jg + 64 * i, jj = j < L ? j : L - 1;
+      vv[i].v = *reinterpret_cast<const uint4*>(vc + (int64_t)jj * p.cld + c8);
+    }
+  Chunk<bf16_t> wv[8];
+  if (SELF) {
+    const bf16_t* wr = p.W + ((int64_t)2 * HD + h * 64 + o) * D + ke * 8;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nck) wv[c].v = *reinterpret_cast<const uint4*>(wr + c * 64);
+  }
+  __syncthreads();
+  // ---- 4. attention
+  if (SELF && t >= 0 && tid < 8) {                       // this position's key row -> cache
+    const int c = tid * 8;
+    Chunk<bf16_t> ch;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ch.e[e] = f32_to_bf16(pr[1][c + e]);
+    *reinterpret_cast<uint4*>(p.kc + b * p.cbs + (int64_t)t * p.cld + h * 64 + c) = ch.v;
+  }
+  float qf[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) qf[e] = pr[0][c8 + e];
+  float sc[NI];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    sc[i] = -INFINITY;
+    if (i * 64 < L) {
+      const int j = jg + 64 * i;
+      float d = 0.f;
+      if (SELF && j == t) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qf[e] * pr[1][c8 + e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qf[e] * bf16_to_f32(kk[i].e[e]);
+      }
+      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+      if (j < L) sc[i] = d * p.scale;
+      mx = fmaxf(mx, sc[i]);
+    }
+  }
+  mx = wave_max(mx);
+  if (lane == 0) wred[0][wave] = mx;
+  if (SELF) {                                            // value projection, then its row -> LDS and cache
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < nck) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += bf16_to_f32(wv[c].e[e]) * xs[c * 64 + ke * 8 + e];
+      }
+    d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+    if (ke == 0) pr[2][o] = bf16_to_f32(f32_to_bf16(d + (p.bias ? p.bias[2 * HD + h * 64 + o] : 0.f)));
+  }
+  __syncthreads();
+  if (SELF && t >= 0 && tid < 8) {
+    const int c = tid * 8;
+    Chunk<bf16_t> ch;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ch.e[e] = f32_to_bf16(pr[2][c + e]);
+    *reinterpret_cast<uint4*>(p.vc + b * p.cbs + (int64_t)t * p.cld + h * 64 + c) = ch.v;
+  }
+  mx = wred[0][0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) mx = fmaxf(mx, wred[0][w]);
+  float l = 0.f, acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+    if (i * 64 < L) {
+      const int j = jg + 64 * i;
+      const float prb = sc[i] == -INFINITY ? 0.f : __expf(sc[i] - mx);
+      l += prb;
+      const float pj = bf16_to_f32(f32_to_bf16(prb));
+      if (SELF && j == t) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * pr[2][c8 + e];
+      } else if (j < L) {                                // (the clamped row of a lane past L may be the not yet written row t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * bf16_to_f32(vv[i].e[e]);
+      }
+    }
+  l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
+#pragma unroll
+  for (int of = 8; of < 64; of <<= 1)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], of, 64);
+  if (lane < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ored[wave][lane][e] = acc[e];
+    if (lane == 0) wred[1][wave] = l;
+  }
+  __syncthreads();
+  if (tid < 8) {
+    float lt = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) lt += wred[1][w];
+    const float inv = lt > 0.f ? 1.f / lt : 0.f;
+    Chunk<bf16_t> oc;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) a += ored[w][tid][e];
+      oc.e[e] = f32_to_bf16(a * inv);
+    }
+    const int ch = h * 8 + tid;
+    if (p.out_frag) *reinterpret_cast<uint4*>(p.out + ((int64_t)(ch >> 1) * 64 + (ch & 1) * 32 + b) * 8) = oc.v;
+    else *reinterpret_cast<uint4*>(p.out + (int64_t)b * p.ldo + h * 64 + tid * 8) = oc.v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ next token
 __global__ __launch_bounds__(256) void dec_finish_kernel(const float* __restrict__ logits, int64_t ld, int V, int64_t* __restrict__ tok,
                                                          uint8_t* __restrict__ done, int64_t* __restrict__ out, int B, int max_len,
@@ -438,6 +674,39 @@ extern "C" int asr_dec_finish(const float* logits, int64_t ld, int V, int64_t* t
   ASR_CHECK_ARG(logits && tok && done && state && ticket && B >= 0 && V > 0 && ld >= V && max_len > 0);
   if (B == 0) return ASR_OK;
   hipLaunchKernelGGL(dec_finish_kernel, dim3((unsigned)B), dim3(256), 0, s, logits, ld, V, tok, done, out, B, max_len, eos, state, ticket);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_dec_attn_fused(const void* W, const float* bias, int D, int self_attention, const void* Y, const void* R,
+                                  const float* gamma, const float* beta, float eps, const int64_t* tok, const float* table,
+                                  const float* pe, float emb_scale, void* x_out, void* k_cache, void* v_cache,
+                                  int64_t cache_batch_stride, int64_t cache_row_stride, int rows, void* out, int64_t ldo, int B, int H,
+                                  int dk, float scale, int out_frag, const int64_t* state, hipStream_t s) {
+  ASR_CHECK_ARG(W && k_cache && v_cache && out && B >= 0 && H > 0 && rows > 0 && D > 0);
+  const bool embed = tok != nullptr;
+  ASR_CHECK_ARG(embed ? (table && pe && state && self_attention) : (Y && R && gamma && beta));
+  ASR_CHECK_ARG(!self_attention || state);
+  if (dk != 64 || rows > DEC_MAX_KEYS || D % 64 != 0 || D > 512 || (out_frag && B > 32)) return ASR_EUNSUPPORTED;
+  if (ldo % 8 != 0 || cache_row_stride % 8 != 0 || cache_batch_stride % 8 != 0 || !aligned16(W) || !aligned16(out) || !aligned16(k_cache) ||
+      !aligned16(v_cache) || (x_out && !aligned16(x_out)) || (!embed && (!aligned16(Y) || !aligned16(R) || !aligned16(gamma) || !aligned16(beta))) ||
+      (embed && (!aligned16(table) || !aligned16(pe))))
+    return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  DecFusedArgs p{};
+  p.Y = static_cast<const bf16_t*>(Y); p.R = static_cast<const bf16_t*>(R); p.gamma = gamma; p.beta = beta; p.eps = eps;
+  p.tok = tok; p.table = table; p.pe = pe; p.emb_scale = emb_scale; p.x_out = static_cast<bf16_t*>(x_out);
+  p.W = static_cast<const bf16_t*>(W); p.bias = bias; p.D = D;
+  p.kc = static_cast<bf16_t*>(k_cache); p.vc = static_cast<bf16_t*>(v_cache); p.cbs = cache_batch_stride; p.cld = cache_row_stride;
+  p.rows = rows; p.out = static_cast<bf16_t*>(out); p.ldo = ldo; p.B = B; p.H = H; p.scale = scale; p.out_frag = out_frag; p.state = state;
+  AsrProfScope prof(ASR_OP_ATTN_FWD, s);
+  const dim3 grid((unsigned)(B * H)), block(512);
+  if (self_attention) {
+    if (embed) hipLaunchKernelGGL((dec_attn_fused_kernel<true, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((dec_attn_fused_kernel<true, false>), grid, block, 0, s, p);
+  } else {
+    hipLaunchKernelGGL((dec_attn_fused_kernel<false, false>), grid, block, 0, s, p);
+  }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

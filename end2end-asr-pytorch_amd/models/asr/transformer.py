@@ -229,7 +229,7 @@ class Decoder(nn.Module):
                       use_cache=True):
         """1-best strings of the reference's 300-step greedy loop (transformer.py:316-394).  Needs --tgt-max-len >= 301.
         use_cache=True decodes incrementally with per-layer key/value caches, one captured hipGraph replayed per token
-        (asr_hip/decode.py; in bf16 the step is the 34-launch one of csrc/decode.hip when the shapes allow it); "graph" the same
+        (asr_hip/decode.py; in bf16 the step is the 30-launch one of csrc/decode.hip when the shapes allow it); "graph" the same
         with the kernel-per-op step; "eager" that step without the graph; False re-runs the full decoder over the prefix at
         every step like the reference -- "graph" / "eager" / False give the same tokens (tests/test_gpu_decode.py), the fused
         step the same within the bf16 tolerance (tests/test_gpu_decode_fused.py)."""
@@ -240,7 +240,7 @@ class Decoder(nn.Module):
             toks = cached_greedy(self, encoder_padded_outputs, steps=300).cpu().tolist()
         elif use_cache:                               # cached + one hipGraph replay per token (device-side position)
             from asr_hip.decode import greedy_search_graphed
-            fused = False if use_cache == "graph" else None      # "graph": the kernel-per-op step; True: 34-launch step in bf16
+            fused = False if use_cache == "graph" else None      # "graph": the kernel-per-op step; True: 30-launch step in bf16
             toks = greedy_search_graphed(self, encoder_padded_outputs, steps=300, fused=fused).cpu().tolist()
         else:
             B = encoder_padded_outputs.size(0)

@@ -206,6 +206,16 @@ int asr_dec_gemm(const void* W, int64_t ldw, const float* bias, void* out, int64
 int asr_dec_attn(const void* q, int64_t ldq, const void* k_new, const void* v_new, int64_t ld_new, void* k_cache,
                  void* v_cache, int64_t cache_batch_stride, int64_t cache_row_stride, int rows, void* out, int64_t ldo,
                  int B, int H, int dk, float scale, int out_frag, const int64_t* state, asr_stream_t stream);
+/* asr_dec_attn_fused: asr_dec_gemm(prologue 1 or 2) + asr_dec_attn in ONE launch: per (sequence, head) the sub-layer input row
+ *   x = LN(Y + R) gamma + beta (tok == NULL) or table[tok] emb_scale + pe[state[0]] (self attention of the first layer), the
+ *   head's projections from W ((3 H 64, D) = [query | key | value] rows for self_attention != 0, (H 64, D) query rows otherwise;
+ *   row-major bf16, bias fp32 or NULL), then the attention of asr_dec_attn (self: key / value row appended at t = state[0]).
+ *   x (B, D) is stored to x_out by the head-0 workgroups.  D % 64 == 0, D <= 512, dk = 64, rows <= 512.                    */
+int asr_dec_attn_fused(const void* W, const float* bias, int D, int self_attention, const void* Y, const void* R,
+                       const float* gamma, const float* beta, float eps, const int64_t* tok, const float* table, const float* pe,
+                       float emb_scale, void* x_out, void* k_cache, void* v_cache, int64_t cache_batch_stride,
+                       int64_t cache_row_stride, int rows, void* out, int64_t ldo, int B, int H, int dk, float scale, int out_frag,
+                       const int64_t* state, asr_stream_t stream);
 int asr_dec_finish(const float* logits, int64_t ld, int V, int64_t* tok, uint8_t* done, int64_t* out, int B, int max_len,
                    int eos, int64_t* state, int32_t* ticket, asr_stream_t stream);
 

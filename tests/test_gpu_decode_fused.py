@@ -156,6 +156,60 @@ def test_dec_attn_cross(rows, shared):
     assert torch.equal(ops.frag_unpack(of, 32, HD)[:B], out)
 
 
+@pytest.mark.parametrize("mode,t,D", [("ln", 17, 512), ("ln", 0, 512), ("embed", 5, 512), ("ln", 299, 256), ("cross", -1, 512), ("cross", -1, 128)])
+def test_dec_attn_fused_equals_prologue_gemm_then_attention(mode, t, D):
+    """asr_dec_attn_fused against asr_dec_gemm (LayerNorm / embedding prologue) followed by asr_dec_attn: the same input row, the
+    same cache rows, the attention output within 2 bf16 ulp (the projections are fp32 dot products in another order)."""
+    from asr_hip import ops
+    g = torch.Generator().manual_seed(t + D)
+    B, H, d, rows = 6, 8, 64, 300
+    HD = H * d
+    self_attn = mode != "cross"
+    NP = 3 if self_attn else 1
+    W = (torch.randn(NP * HD, D, generator=g) * D ** -0.5).to(bf).cuda()
+    bias = torch.randn(NP * HD, generator=g).cuda()
+    kc = torch.randn(B, rows, HD, generator=g).to(bf).cuda()
+    vc = torch.randn(B, rows, HD, generator=g).to(bf).cuda()
+    if self_attn:                                    # rows >= t are uninitialised memory in a real decode: poison them
+        kc[:, t:], vc[:, t:] = float("nan"), float("nan")
+    kc2, vc2 = kc.clone(), vc.clone()
+    state = torch.tensor([max(t, 0), 0], dtype=torch.int64, device="cuda")
+    src = {}
+    if mode == "embed":
+        table, pe = torch.randn(50, D, generator=g).cuda(), torch.randn(rows, D, generator=g).cuda()
+        tok = torch.randint(0, 50, (B,), generator=g).cuda()
+        src_f, src_g = dict(embed=(tok, table, pe, 0.7)), dict(embed=(tok, table, pe, 0.7, state))
+    else:
+        Y, R = torch.randn(B, D, generator=g).to(bf).cuda(), (2 * torch.randn(B, D, generator=g)).to(bf).cuda()
+        gamma, beta = (1 + 0.2 * torch.randn(D, generator=g)).cuda(), (0.3 * torch.randn(D, generator=g)).cuda()
+        src_f = src_g = dict(ln=(Y, R, gamma, beta, 1e-5))
+    # two launches
+    qkv = torch.zeros(B, NP * HD, dtype=bf, device="cuda")
+    x_ref = torch.zeros(B, D, dtype=bf, device="cuda")
+    ops.dec_gemm(W, bias, qkv, x_out=x_ref, **src_g)
+    o_ref = torch.zeros(B, HD, dtype=bf, device="cuda")
+    if self_attn:
+        ops.dec_attn(qkv[:, :HD], kc, vc, o_ref, H, d, d ** -0.5, k_new=qkv[:, HD:2 * HD], v_new=qkv[:, 2 * HD:], state=state)
+    else:
+        ops.dec_attn(qkv, kc, vc, o_ref, H, d, d ** -0.5)
+    # one launch
+    o = torch.zeros(B, HD, dtype=bf, device="cuda")
+    x = torch.zeros(B, D, dtype=bf, device="cuda")
+    ops.dec_attn_fused(W, bias, kc2, vc2, o, H, d, d ** -0.5, x_out=x, state=state if self_attn else None, self_attention=self_attn,
+                       **src_f)
+    assert torch.equal(x, x_ref)
+    if self_attn:
+        _ulp_close(kc2[:, t], kc[:, t])
+        _ulp_close(vc2[:, t], vc[:, t])
+        assert torch.equal(kc2[:, :t], kc[:, :t]) and torch.equal(vc2[:, :t], vc[:, :t]) and torch.isnan(kc2[:, t + 1:].float()).all()
+    assert torch.isfinite(o.float()).all() and torch.isfinite(o_ref.float()).all()
+    assert (o.float() - o_ref.float()).abs().max().item() <= 2e-2 * o_ref.float().abs().max().item()
+    of = torch.zeros(32 * HD, dtype=bf, device="cuda")
+    ops.dec_attn_fused(W, bias, kc2, vc2, of, H, d, d ** -0.5, state=state if self_attn else None, self_attention=self_attn, out_frag=True,
+                       **src_f)
+    assert torch.equal(ops.frag_unpack(of, 32, HD)[:B], o)
+
+
 def test_dec_finish_argmax_done_output_and_position():
     from asr_hip import ops
     B, V, max_len = 6, 4364, 10
@@ -193,9 +247,12 @@ def _model(layers=2, inner=256, V=40):
     return model
 
 
-def test_fused_step_logits_match_kernel_per_op_step():
+@pytest.mark.parametrize("fuse_self,fuse_cross", [(False, True), (True, True), (False, False)])
+def test_fused_step_logits_match_kernel_per_op_step(fuse_self, fuse_cross, monkeypatch):
     """Teacher forcing: the same tokens through both steps -> logits within 3e-2 of the logit range at every position."""
     from asr_hip.decode import DecoderKVCache, FusedGreedyDecoder, fused_decode_supported
+    monkeypatch.setattr(FusedGreedyDecoder, "FUSE_SELF", fuse_self)
+    monkeypatch.setattr(FusedGreedyDecoder, "FUSE_CROSS", fuse_cross)
     model = _model()
     dec = model.decoder
     g = torch.Generator().manual_seed(3)
@@ -226,8 +283,8 @@ def test_fused_greedy_graph_replay_equals_eager_and_follows_the_per_op_argmax():
     g = torch.Generator().manual_seed(5)
     B, steps = 4, 40
     enc = torch.randn(B, 50, 512, generator=g).cuda()
-    B, steps = 4, 41
-    toks = FusedGreedyDecoder(dec, enc, max_len=steps).run(steps, check_every=1000)          # 2 eager steps + 9 replays of 4 + 3 eager
+    B, steps = 4, 45
+    toks = FusedGreedyDecoder(dec, enc, max_len=steps).run(steps, check_every=1000)          # 2 eager steps + 5 replays of 8 + 3 eager
     eager = FusedGreedyDecoder(dec, enc, max_len=steps)
     for _ in range(steps):
         eager._step()
