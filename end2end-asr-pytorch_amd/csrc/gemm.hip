@@ -496,7 +496,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs p) {
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
   // column chunk (16 B) this tile may read: clamp to the operand's last whole chunk (columns past N / K are never stored)
-  const int a_chunks = (int)(p.lda * ESZ / 16), b_chunks = (int)(p.ldb * ESZ / 16);
+  // (ldb < K: the rows of B are overlapping windows over one longer buffer -- the clamp is then the window's own width)
+  const int a_chunks = (int)(p.lda * ESZ / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * ESZ / 16);
 
   // per-thread byte offsets of its DMA chunks relative to the first row of a stage (the stage base is workgroup-uniform: the
   // loads of a whole stage then cost one scalar base update instead of ~12 vector ops of address arithmetic per chunk)
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(256) void gemm_tn128_kernel(Tn128Args p) {
   const int nstage = (m_end - m_beg + RM - 1) / RM;
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
-  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)(p.ldb * 2 / 16);
+  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * 2 / 16);
 
   f32x4_t acc[4][4];
 #pragma unroll
@@ -860,7 +861,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
   const int nstage = (m_end - m_beg + RM - 1) / RM;
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
-  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)(p.ldb * 2 / 16);
+  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * 2 / 16);
 
   // per-thread DMA pieces: 512 chunks per operand tile = 2 per thread; chunk c = (row, slot), source chunk slot ^ (row & 7)
   int64_t offA[2], offB[2];
@@ -1341,7 +1342,7 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   const int esz = dtype == ASR_F32 ? 4 : 2, epc = 16 / esz;
   const int rm = dtype == ASR_F32 ? 64 : 128;
   // 16-byte aligned rows; a partial last stage of m is zero-filled in LDS by the kernel
-  if (lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N || ldb < K ||
+  if (lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || lda < N ||
       lda >= ((int64_t)1 << 22) || ldb >= ((int64_t)1 << 22))      // (32-bit byte offsets inside one stage of rows)
     return ASR_EUNSUPPORTED;
   {

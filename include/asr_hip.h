@@ -68,7 +68,9 @@ int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
  * rows, else ASR_EUNSUPPORTED (callers fall back to asr_transpose + asr_gemm_nt); any M (a partial last stage is
  * zero-filled in LDS).  splits <= 0: automatic split over m.  workspace (fp32, >= asr_gemm_tn_workspace(...) elements,
  * optional): the m-slices write partial tiles there and a second kernel folds them into C; without it they meet in fp32
- * atomics on C (slower, and limited to 4 slices).                                                                  */
+ * atomics on C (slower, and limited to 4 slices).  ldb < K is allowed: the rows of B are then overlapping windows of K
+ * elements, ldb apart, over one longer buffer (a convolution along the contiguous axis without im2col: asr_hip/functions.py,
+ * EmbCNNFn); the caller guarantees that (M - 1) * ldb + K rounded up to 8 elements are readable.                     */
 int64_t asr_gemm_tn_workspace(int M, int N, int K, int splits, int dtype);
 int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, float* colsum_acc,
                 float* workspace, int64_t workspace_floats, int M, int N, int K, int splits, int dtype,
