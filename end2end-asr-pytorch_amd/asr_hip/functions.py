@@ -471,68 +471,80 @@ _emb_window = os.environ.get("ASR_EMB_WINDOW", "1") != "0"
 
 
 def _window_ok(g):
-    """The time-window formulation below applies to a convolution with unit stride and no padding along the contiguous (time)
-    axis whose per-position block KH * C is a whole number of 16-byte chunks and of 128-byte K steps' halves (the 32 -> 32,
-    21 x 11, stride (2,1) layer of emb_cnn: 672 elements)."""
+    """The time-window formulation below applies to a convolution without padding along the frequency axis whose padded time
+    extent is a whole number of strides (both emb_cnn layers: 1 -> 32, 41 x 11, stride (2,2), time padding 10, and 32 -> 32,
+    21 x 11, stride (2,1)); bf16 operands."""
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
-    return _emb_window and SW == 1 and PW == 0 and PH == 0 and KW > 1 and (KH * C) % 8 == 0 and ops.compute_dtype() == torch.bfloat16
+    return _emb_window and PH == 0 and KW > 1 and (W + 2 * PW) % SW == 0 and ops.compute_dtype() == torch.bfloat16
+
+
+def _window_geom(g):
+    """-> (g1: the KW = 1, stride-1 im2col geometry, blk: elements of one time step's (ky, c) block padded to 16 bytes,
+    Wg: GEMM rows per (b, oh) group, R: GEMM rows)"""
+    B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
+    g1 = ops.conv_geom(B, H, W, C, KH, 1, SH, 1, 0, PW)              # OH x (W + 2 PW) positions, one (padded) time step per row
+    blk = (KH * C + 7) // 8 * 8
+    Wg = g1[11] // SW
+    return g1, blk, Wg, B * OH * Wg
 
 
 def _conv_window_fwd(x_nhwc, g, w, b, tag):
-    """The same convolution WITHOUT the kx axis in im2col: X2[(b, oh, t), (ky, c)] = x[b, SH*oh + ky, t, c] for every input time
-    step t (KW times fewer bytes than the full im2col), and the GEMM's A operand is the overlapping-rows view
-    A[(b, oh, t)] = X2 flat[row * KH*C : row * KH*C + KW * KH*C] -- KW consecutive X2 rows ARE the patch in column order
-    (kx, ky, c).  Rows t >= OW of a (b, oh) group mix in the next group and are dropped when y is compacted.
-    Returns (X2, A view, Ws, y fp32 (Mp, 64) compact, M, K, R)."""
+    """The same convolution WITHOUT the kx axis in im2col: X2[(b, oh, t), (ky, c)] = x[b, SH*oh + ky, t - PW, c] for every
+    (padded) input time step t (about KW / SW times fewer bytes than the full im2col), and the GEMM's A operand is the
+    overlapping-rows view A[(b, oh, j)] = X2 flat[row * SW * blk : ... + KW * blk] -- KW consecutive X2 rows ARE the patch of
+    output step j, in column order (kx, ky, c).  Rows j >= OW of a (b, oh) group run into the next group and are dropped when y
+    is compacted.  Returns (X2, A view, y fp32 (Mp, 64) compact, M)."""
     cd = ops.compute_dtype()
     dev = x_nhwc.device
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
     Cout = w.shape[0]
-    blk = KH * C
-    g1 = ops.conv_geom(B, H, W, C, KH, 1, SH, 1, 0, 0)              # OH x W output positions, one time step per row
-    R, M, K = B * OH * W, B * OH * OW, KW * blk
+    g1, blk, Wg, R = _window_geom(g)
+    M, K = B * OH * OW, KW * blk
     Kp = ops._pad8(K)
-    slack = (Kp + blk - 1) // blk + 1                                # rows the last window reads past R
-    X2 = ops.im2col(x_nhwc, g1, ops.workspace(tag + "_x2", (R + slack, blk), cd, dev))
-    A = torch.as_strided(X2, (R, Kp), (blk, 1))
-    Ws = ops.workspace(tag + "_w", (64, Kp), cd, dev)                # rows >= Cout and columns >= K stay zero
-    Ws[:Cout, :K].copy_(w.data.permute(0, 3, 2, 1).reshape(Cout, K)) # (co, kx, ky, ci): the window's column order
+    rows1 = B * OH * g1[11]
+    slack = (Kp + blk - 1) // blk + SW                               # rows the last window reads past the last group
+    X2 = ops.im2col(x_nhwc, g1, ops.workspace(tag + "_x2", (rows1 + slack, blk), cd, dev))
+    A = torch.as_strided(X2, (R, Kp), (SW * blk, 1))
+    Ws = ops.workspace(tag + "_w", (64, Kp), cd, dev)                # rows >= Cout, columns >= K and the ky padding stay zero
+    Ws[:Cout, :K].view(Cout, KW, blk)[:, :, :KH * C].copy_(w.data.permute(0, 3, 2, 1).reshape(Cout, KW, KH * C))   # (co, kx, ky, ci)
     bias = ops.workspace(tag + "_b", (64,), torch.float32, dev)
     bias[:Cout].copy_(b.data)
-    Rp, Mp = (R + 127) // 128 * 128, (M + 127) // 128 * 128
+    Mp = (M + 127) // 128 * 128
     yf = ops.gemm_nt(A, Ws, bias=bias, out=ops.workspace(tag + "_yf", (R, 64), torch.float32, dev))
     y = ops.workspace(tag + "_y", (Mp, 64), torch.float32, dev)
-    y[:M].view(B * OH, OW, 64).copy_(yf.view(B * OH, W, 64)[:, :OW])
-    return X2, A, Ws, y, M, K, R
+    y[:M].view(B * OH, OW, 64).copy_(yf.view(B * OH, Wg, 64)[:, :OW])
+    return X2, A, y, M
 
 
-def _conv_window_bwd(dy, X2, A, w, b_grad, g, R, tag):
-    """dy (Mp, 64) compact rows -> weight gradient (Cout, Cin, KH, KW) fp32 (returned), bias gradient (accumulated), data
-    gradient dx (B, H, W, C).  D holds dy's Cout columns densely, one row per INPUT time step (rows t >= OW zero) with KW - 1
-    zero rows in front, so that D flat[r * Cout : r * Cout + KW * Cout] = dy rows r - (KW - 1) .. r: the data gradient of X2 is
-    ONE GEMM against the weights in (kx reversed, co) order, and the weight gradient one TN GEMM against the window view A."""
+def _conv_window_bwd(dy, A, w, b_grad, g, tag, need_dx):
+    """dy (Mp, 64) compact rows -> weight gradient (Cout, Cin, KH, KW) fp32 (returned), bias gradient (accumulated) and, for a
+    unit time stride, the data gradient dx (B, H, W, C).  D holds dy's Cout columns densely on the GEMM's row grid (rows j >= OW
+    of a group zero) with KW - 1 zero rows in front, so that D flat[r * Cout : r * Cout + KW * Cout] = dy rows r - (KW - 1) .. r:
+    the data gradient of X2 is ONE GEMM against the weights in (kx reversed, co) order, and the weight gradient one TN GEMM
+    against the window view A (asr_gemm_tn with ldb < K)."""
     cd = ops.compute_dtype()
     dev = dy.device
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
     Cout = w.shape[0]
-    blk, M = KH * C, B * OH * OW
+    g1, blk, Wg, R = _window_geom(g)
+    M = B * OH * OW
     Kd = KW * Cout
     Kdp = ops._pad8(Kd)
     lead = KW - 1
     tail = (Kdp + Cout - 1) // Cout + 1
     D = ops.workspace(tag + "_d", (lead + R + tail, Cout), cd, dev)
-    D[lead:lead + R].view(B * OH, W, Cout)[:, :OW].copy_(dy[:M].view(B * OH, OW, dy.shape[1])[:, :, :Cout])
-    # weight gradient: (Cout, K) += dy^T . windows
+    D[lead:lead + R].view(B * OH, Wg, Cout)[:, :OW].copy_(dy[:M].view(B * OH, OW, dy.shape[1])[:, :, :Cout])
     K = KW * blk
     dw = torch.zeros((Cout, K), device=dev, dtype=torch.float32)
     ops.gemm_tn(D[lead:lead + R], A, dw, colsum_acc=b_grad, N=Cout, K=K)
-    dw = dw.view(Cout, KW, KH, C).permute(0, 3, 2, 1)                # (co, kx, ky, ci) -> (co, ci, ky, kx)
-    # data gradient of X2: rows r, columns (ky, ci)
+    dw = dw.view(Cout, KW, blk)[:, :, :KH * C].reshape(Cout, KW, KH, C).permute(0, 3, 2, 1)      # (co, kx, ky, ci) -> (co, ci, ky, kx)
+    if not need_dx:
+        return dw, None
+    assert SW == 1 and PW == 0
     Wd = ops.workspace(tag + "_wd", ((blk + 63) // 64 * 64, Kdp), cd, dev)
-    Wd[:blk, :Kd].copy_(w.data.flip(3).permute(2, 1, 3, 0).reshape(blk, Kd))   # [(ky, ci), (j = KW-1-kx, co)]
+    Wd[:KH * C, :Kd].copy_(w.data.flip(3).permute(2, 1, 3, 0).reshape(KH * C, Kd))     # [(ky, ci), (j = KW-1-kx, co)]
     Ad = torch.as_strided(D, (R, Kdp), (Cout, 1))
     dX2 = ops.gemm_nt(Ad, Wd[:blk], out=ops.workspace(tag + "_dx2", (R, blk), cd, dev))
-    g1 = ops.conv_geom(B, H, W, C, KH, 1, SH, 1, 0, 0)
     return dw, ops.col2im(dX2, g1)
 
 
@@ -564,26 +576,31 @@ class EmbCNNFn(Function):
         B, _, Fq, T = src.shape
         C1, C2 = w0.shape[0], w3.shape[0]
         gA = ops.conv_geom(B, Fq, T, 1, w0.shape[2], w0.shape[3], 2, 2, 0, 10)
-        colA, WsA, yA, MA, KA = _conv_gemm_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embA")
+        winA = _window_ok(gA)
+        if winA:
+            colA, WsA, yA, MA = _conv_window_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embV")      # colA = X2, WsA = the window view
+            KA = gA[3] * gA[4] * gA[5]
+        else:
+            colA, WsA, yA, MA, KA = _conv_gemm_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embA")
         meanA, rstdA = _bn_stats(bn1, yA, MA, C1, training)
         a1 = torch.empty((B, gA[10], gA[11], C1), device=src.device, dtype=cd)
         ops.bn_act_fwd(yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, a1.view(MA, C1))
         gB = ops.conv_geom(B, gA[10], gA[11], C1, w3.shape[2], w3.shape[3], 2, 1, 0, 0)
         win = _window_ok(gB)
         if win:
-            colB, WsB, _, yB, MB, KB, RB = _conv_window_fwd(a1, gB, w3, b3, "embW")      # colB = X2, WsB = the window view
+            colB, WsB, yB, MB = _conv_window_fwd(a1, gB, w3, b3, "embW")       # colB = X2, WsB = the window view
+            KB = gB[3] * gB[4] * gB[5]
         else:
             colB, WsB, yB, MB, KB = _conv_gemm_fwd(a1, gB, w3, b3, "embB")
-            RB = 0
         meanB, rstdB = _bn_stats(bn4, yB, MB, C2, training)
         out = torch.empty((B, gB[11], C2 * gB[10]), device=src.device, dtype=cd)
         ops.bn_act_fwd(yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, out, tH=gB[10], tW=gB[11])
-        ctx.t = (colA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB)
+        ctx.t = (colA, WsA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB)
         # colA / yA / colB / yB are SHARED grow-only workspaces (ops.workspace): a later forward overwrites them
         _emb_generation[0] += 1
         ctx.generation = _emb_generation[0]
         ctx.geo = (gA, gB, MA, KA, MB, KB)
-        ctx.win, ctx.RB = win, RB
+        ctx.win, ctx.winA = win, winA
         ctx.params = (w0, b0, g1, be1, w3, b3, g4, be4)
         return out
 
@@ -592,7 +609,7 @@ class EmbCNNFn(Function):
         if ctx.generation != _emb_generation[0]:
             raise RuntimeError("emb_cnn backward after a later emb_cnn forward: the im2col workspaces of this forward were "
                                "overwritten (run backward before the next forward)")
-        colA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB = ctx.t
+        colA, WsA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB = ctx.t
         gA, gB, MA, KA, MB, KB = ctx.geo
         w0, b0, g1, be1, w3, b3, g4, be4 = ctx.params
         cd = ops.compute_dtype()
@@ -607,7 +624,7 @@ class EmbCNNFn(Function):
         P.grad_of(be4).add_(sB[:C2])
         P.grad_of(g4).add_(sB[C2:])
         if ctx.win:
-            dwB, da1 = _conv_window_bwd(dyB, colB, WsB, w3, P.grad_of(b3), gB, ctx.RB, "embW")
+            dwB, da1 = _conv_window_bwd(dyB, WsB, w3, P.grad_of(b3), gB, "embW", True)
             P.grad_of(w3).add_(dwB)
             P.grad_ready(w3, b3, g4, be4)
         else:
@@ -618,11 +635,15 @@ class EmbCNNFn(Function):
             dcolB = ops.gemm_nn(dyB, WsB, out=colB)          # colB is dead after the weight gradient: reuse its storage
             da1 = ops.col2im(dcolB, gB)
         # ---- first conv block (no data gradient: the input is the spectrogram)
-        dyA = ops.workspace("embA_dy", (colA.shape[0], 64), cd, dev)
+        dyA = ops.workspace("embA_dy", (yA.shape[0], 64), cd, dev)
         sA = ops.bn_act_bwd(da1.view(MA, C1), yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, dyA)
         P.grad_of(be1).add_(sA[:C1])
         P.grad_of(g1).add_(sA[C1:])
-        ops.gemm_tn(dyA, colA, P.grad_of(w0).view(C1, KA), colsum_acc=P.grad_of(b0), N=C1, K=KA)
+        if ctx.winA:
+            dwA, _ = _conv_window_bwd(dyA, WsA, w0, P.grad_of(b0), gA, "embV", False)
+            P.grad_of(w0).add_(dwA)
+        else:
+            ops.gemm_tn(dyA, colA, P.grad_of(w0).view(C1, KA), colsum_acc=P.grad_of(b0), N=C1, K=KA)
         P.grad_ready(w0, b0, g1, be1)
         return (None,) * 12
 
