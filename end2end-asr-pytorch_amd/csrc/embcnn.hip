@@ -140,7 +140,8 @@ __device__ __forceinline__ int64_t act_index(const BnArgs& a, int64_t m, int c) 
   return m * a.ldo + c;
 }
 
-constexpr int BN_ROWS = 2048;      // rows per workgroup
+constexpr int BN_ROWS = 512;       // rows per workgroup (the streaming reductions keep 4 independent row loads per thread in flight:
+                                   // one load per iteration ran at 1.5 TB/s on the 200 MB fp32 conv output)
 
 // out[0:C] += sum (y - center), out[C:2C] += sum (y - center)^2   (center == nullptr: 0)
 __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __restrict__ center, float* __restrict__ out) {
@@ -150,7 +151,14 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __
   const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
   const int64_t r1 = r0 + BN_ROWS < a.M ? r0 + BN_ROWS : a.M;
   float s = 0.f, q = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+  int64_t r = r0 + rl;
+  for (; r + 3 * nrl < r1; r += 4 * nrl) {
+    const float v0 = a.y[r * a.ldy + c] - ctr, v1 = a.y[(r + nrl) * a.ldy + c] - ctr;
+    const float v2 = a.y[(r + 2 * nrl) * a.ldy + c] - ctr, v3 = a.y[(r + 3 * nrl) * a.ldy + c] - ctr;
+    s += (v0 + v1) + (v2 + v3);
+    q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+  }
+  for (; r < r1; r += nrl) {
     const float v = a.y[r * a.ldy + c] - ctr;
     s += v;
     q += v * v;
@@ -189,7 +197,24 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
   const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
   const int64_t r1 = r0 + BN_ROWS < a.M ? r0 + BN_ROWS : a.M;
   float s = 0.f, q = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += nrl) {
+  int64_t r = r0 + rl;
+  for (; r + 3 * nrl < r1; r += 4 * nrl) {          // all 8 loads of four rows first; rows outside the Hardtanh window contribute 0
+    float yv[4], dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      yv[u] = a.y[(r + u * nrl) * a.ldy + c];
+      dv[u] = DT<T>::ld(dout + act_index(a, r + u * nrl, c));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float xh = (yv[u] - mu) * rs;
+      const float z = xh * g + be;
+      const float d = (z > a.lo && z < a.hi) ? dv[u] : 0.f;
+      s += d;
+      q += d * xh;
+    }
+  }
+  for (; r < r1; r += nrl) {
     const float xh = (a.y[r * a.ldy + c] - mu) * rs;
     const float z = xh * g + be;
     if (z > a.lo && z < a.hi) {
