@@ -777,11 +777,13 @@ def col2im(dcol, g, dtype=None):
 def bn_batch_stats(y, M, C):
     """Training-mode BatchNorm statistics of the fp32 conv output y (rows, ld) over its first M rows / C columns:
     (mean, biased var), two passes (mean, then centred second moment)."""
-    s1 = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-    L.call("asr_bn_stats", L.ptr(y), y.stride(0), M, C, None, L.ptr(s1), L.stream())
+    nb = L.load().asr_bn_stats_blocks(M)
+    part = torch.empty((nb, 2 * C), device=y.device, dtype=torch.float32)       # per-workgroup sums, added in a fixed order:
+    s1 = torch.empty(2 * C, device=y.device, dtype=torch.float32)               # reproducible statistics (no atomics)
+    L.call("asr_bn_stats_partial", L.ptr(y), y.stride(0), M, C, None, L.ptr(part), L.ptr(s1), L.stream())
     mean = s1[:C] / M
-    s2 = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-    L.call("asr_bn_stats", L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(s2), L.stream())
+    s2 = torch.empty(2 * C, device=y.device, dtype=torch.float32)
+    L.call("asr_bn_stats_partial", L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(part), L.ptr(s2), L.stream())
     return mean, s2[C:] / M
 
 

@@ -144,7 +144,10 @@ constexpr int BN_ROWS = 512;       // rows per workgroup (the streaming reductio
                                    // one load per iteration ran at 1.5 TB/s on the 200 MB fp32 conv output)
 
 // out[0:C] += sum (y - center), out[C:2C] += sum (y - center)^2   (center == nullptr: 0)
-__global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __restrict__ center, float* __restrict__ out) {
+// (partial != nullptr: the workgroup's sums go to partial[blockIdx.x][2C] instead -- summed in a fixed order by the caller, so
+//  the batch statistics, and with them the forward pass, are bit-reproducible from run to run)
+__global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __restrict__ center, float* __restrict__ out,
+                                                       float* __restrict__ partial) {
   __shared__ float red[2][256];
   const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
   const float ctr = center ? center[c] : 0.f;
@@ -171,8 +174,29 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __
       s += red[0][i * C + c];
       q += red[1][i * C + c];
     }
-    atomicAdd(out + c, s);
-    atomicAdd(out + C + c, q);
+    if (partial) {
+      partial[(int64_t)blockIdx.x * 2 * C + c] = s;
+      partial[(int64_t)blockIdx.x * 2 * C + C + c] = q;
+    } else {
+      atomicAdd(out + c, s);
+      atomicAdd(out + C + c, q);
+    }
+  }
+}
+
+// out[c] = sum over the workgroups' partial rows in a FIXED order: 1024 / C2 row groups (rows g, g + G, ...) per column, each a
+// serial chain, then the groups in index order (C2 <= 512)
+__global__ void __launch_bounds__(1024) bn_partial_sum_kernel(const float* __restrict__ partial, int64_t nblk, int C2, float* __restrict__ out) {
+  __shared__ float red[1024];
+  const int G = 1024 / C2, c = threadIdx.x % C2, g = threadIdx.x / C2;
+  float s = 0.f;
+  if (g < G)
+    for (int64_t b = g; b < nblk; b += G) s += partial[b * C2 + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0) {
+    for (int i = 1; i < G; ++i) s += red[i * C2 + c];
+    out[c] = s;
   }
 }
 
@@ -308,7 +332,22 @@ extern "C" int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const
   BnArgs a{};
   a.y = y; a.ldy = ldy; a.M = M; a.C = C;
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
-  bn_stats_kernel<<<(unsigned)ceil_div64(M, BN_ROWS), 256, 0, stream>>>(a, center, sums);
+  bn_stats_kernel<<<(unsigned)ceil_div64(M, BN_ROWS), 256, 0, stream>>>(a, center, sums, nullptr);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int64_t asr_bn_stats_blocks(int64_t M) { return M > 0 ? ceil_div64(M, BN_ROWS) : 0; }
+
+extern "C" int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* partial, float* sums,
+                                    hipStream_t stream) {
+  ASR_CHECK_ARG(y && partial && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C);
+  BnArgs a{};
+  a.y = y; a.ldy = ldy; a.M = M; a.C = C;
+  AsrProfScope prof(ASR_OP_ADD_LN, stream);
+  const int64_t nblk = ceil_div64(M, BN_ROWS);
+  bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, center, nullptr, partial);
+  bn_partial_sum_kernel<<<1, 1024, 0, stream>>>(partial, nblk, 2 * C, sums);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

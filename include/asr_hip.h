@@ -309,6 +309,11 @@ int asr_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, i
 /* nn.BatchNorm2d statistics over the rows of the fp32 conv output y (M, ldy), channel = column:
  * sums[0:C] += sum(y - center), sums[C:2C] += sum((y - center)^2); center may be NULL (two-pass mean / variance).     */
 int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, asr_stream_t stream);
+/* the same sums WITHOUT atomics: per-workgroup sums into the workspace partial (asr_bn_stats_blocks(M), 2C), then added in a
+ * fixed order into sums (2C, overwritten): the batch statistics, and with them the forward pass, are reproducible bit for bit  */
+int64_t asr_bn_stats_blocks(int64_t M);
+int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* partial, float* sums,
+                         asr_stream_t stream);
 /* out = clamp(gamma * (y - mean) * rstd + beta, lo, hi)   (BatchNorm2d + Hardtanh, transformer.py:35-36,38-39).
  * tH > 0: rows are (b,h,w) over (B,tH,tW) and out is the encoder input (B, tW, C*tH), feature c*tH + h (:74-76).     */
 int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,

@@ -64,3 +64,44 @@ def test_graph_replay_changes_dropout_masks(golden_dir):
     gs()
     for k, v in m.state_dict().items():
         assert torch.equal(v, w[k]), k            # lr = 0: nothing moves
+
+
+@pytest.mark.parametrize("case", ["vgg_tiny", "emb_tiny"])
+def test_graph_replay_with_dropout_equals_eager_at_the_same_seed_counter(golden_dir, case):
+    """The benched path -- dropout > 0 under hipGraph replay -- against the eager launch sequence: the dropout masks are a pure
+    function of (host-side site seed, device-side step counter, element index), so with both set to the same values a replayed
+    step and an eagerly issued step draw the SAME masks in forward and backward and must produce the same loss and the same
+    gradients (weights frozen through lr = 0 so that both start from the same point)."""
+    from asr_hip import ops
+    from asr_hip.graph import GraphedTrainStep
+    z, args, m, o = build(golden_dir, case, "bf16")
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.25
+    o.factor, o.min_lr = 0.0, 0.0
+    from asr_hip import params as P
+    src, src_len, tgt = _batch(z)
+    P._state["seed_ctr"] = 0
+    gs = GraphedTrainStep(m, o, float(z["smoothing"]), src, src_len, tgt, warmup_steps=1)
+    # every dropout site draws one host-side seed per issued step: the warm-up step took 1..n, the captured launches carry n+1..2n
+    n_sites = P._state["seed_ctr"] // 2
+    assert n_sites > 0 and P._state["seed_ctr"] == 2 * n_sites
+    st = ops.step_state(src.device)
+    flat = o.optimizer.flat
+    st[0] = 1000
+    loss_a = gs()[0].item()
+    g_a = flat.grad.detach().clone()
+    st[0] = 1000
+    P._state["seed_ctr"] = n_sites                # the eager step re-draws the seeds the capture baked in
+    loss_b = gs._eager_step()[0].item()
+    gs._host_after()
+    g_b = flat.grad.detach().clone()
+    st[0] = 1001
+    loss_c = gs()[0].item()
+    # different masks move the loss by 1e-2 .. 1e-1 (loss_c below).  Forward: bit-reproducible (the BatchNorm batch statistics are
+    # summed in a fixed order, asr_bn_stats_partial); gradients: equal up to the summation order of the fp32 atomics behind the
+    # bias / LayerNorm / BatchNorm parameter gradients
+    tol_l, tol_g = 1e-6, (1e-5 if case == "vgg_tiny" else 1e-3)
+    assert abs(loss_a - loss_b) <= tol_l * abs(loss_a) and abs(loss_a - loss_c) > 5e-3 * abs(loss_a)
+    assert g_a.abs().max().item() > 0
+    assert ((g_a - g_b).norm() / g_a.norm()).item() <= tol_g
