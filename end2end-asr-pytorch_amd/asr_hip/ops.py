@@ -591,6 +591,16 @@ def argmax_rows(logits, out=None):
     return out
 
 
+def logsoftmax_topk(logits, k):
+    """(values (M,k) fp32, indices (M,k) int64) of the k largest log-softmax entries per row, best first (beam-search scoring)."""
+    M, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1
+    vals = torch.empty((M, k), device=logits.device, dtype=torch.float32)
+    idx = torch.empty((M, k), device=logits.device, dtype=torch.int64)
+    L.call("asr_logsoftmax_topk", L.ptr(logits), logits.stride(0), M, V, k, L.ptr(vals), L.ptr(idx), L.stream())
+    return vals, idx
+
+
 def ce_bwd(logits, gold, lse, smoothing, pad_id, grad_out, count):
     """Returns fp32 dlogits as an (M,V) view of an (M, pad8(V)) buffer whose pad columns are zero."""
     M, V = logits.shape

@@ -110,6 +110,57 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   }
 }
 
+// Beam-search scoring (reference: transformer.py:446-449, F.log_softmax + torch.topk per hypothesis): the k best log-probabilities
+// of a logits row and their indices, best first (equal values: lowest index first).  One workgroup per row: row max and
+// sum of exponentials, then k block-wide arg-max passes over the row (L2 resident), each excluding the indices already taken.
+constexpr int TOPK_MAX = 16;
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ logits, int64_t ld, int V, int k,
+                                                              float* __restrict__ vals, int64_t* __restrict__ idx) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  __shared__ float s_red[2][4];
+  __shared__ int taken[TOPK_MAX];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* l = logits + (int64_t)row * ld;
+  float mx = -INFINITY;
+  for (int v = tid; v < V; v += 256) mx = fmaxf(mx, l[v]);
+  mx = wave_max(mx);
+  if (lane == 0) s_red[0][wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(s_red[0][0], s_red[0][1]), fmaxf(s_red[0][2], s_red[0][3]));
+  float se = 0.f;
+  for (int v = tid; v < V; v += 256) se += expf(l[v] - mx);
+  se = wave_sum(se);
+  if (lane == 0) s_red[1][wave] = se;
+  __syncthreads();
+  const float lse = mx + logf(s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3]);
+  for (int j = 0; j < k; ++j) {
+    MaxIdx mi{-INFINITY, 0x7fffffff};
+    for (int v = tid; v < V; v += 256) {
+      bool used = false;
+      for (int t = 0; t < j; ++t) used |= taken[t] == v;
+      const float x = l[v];
+      if (!used && (x > mi.v || (x == mi.v && v < mi.i))) { mi.v = x; mi.i = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      MaxIdx t{__shfl_xor(mi.v, o, 64), __shfl_xor(mi.i, o, 64)};
+      mi = better(mi, t);
+    }
+    if (lane == 0) { s_v[wave] = mi.v; s_i[wave] = mi.i; }
+    __syncthreads();
+    if (tid == 0) {
+      MaxIdx m{s_v[0], s_i[0]};
+#pragma unroll
+      for (int w = 1; w < 4; ++w) m = better(m, MaxIdx{s_v[w], s_i[w]});
+      taken[j] = m.i;
+      vals[(int64_t)row * k + j] = m.v - lse;
+      idx[(int64_t)row * k + j] = m.i == 0x7fffffff ? 0 : m.i;
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* __restrict__ logits, int64_t ld,
                                                      const int64_t* __restrict__ gold, const float* __restrict__ row_lse,
@@ -169,6 +220,15 @@ extern "C" int asr_argmax_rows(const float* logits, int64_t ld, int M, int V, in
   ASR_CHECK_ARG(logits && out && M >= 0 && V > 0 && ld >= V);
   if (M == 0) return ASR_OK;
   hipLaunchKernelGGL(argmax_rows_kernel, dim3(M), dim3(256), 0, s, logits, ld, V, out);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_logsoftmax_topk(const float* logits, int64_t ld, int M, int V, int k, float* vals, int64_t* idx, hipStream_t s) {
+  ASR_CHECK_ARG(logits && vals && idx && M >= 0 && V > 0 && ld >= V && k > 0 && k <= V);
+  if (k > TOPK_MAX) return ASR_EUNSUPPORTED;
+  if (M == 0) return ASR_OK;
+  hipLaunchKernelGGL(logsoftmax_topk_kernel, dim3(M), dim3(256), 0, s, logits, ld, V, k, vals, idx);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

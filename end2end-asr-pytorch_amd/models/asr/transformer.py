@@ -283,8 +283,7 @@ class Decoder(nn.Module):
             for i in range(300):
                 if use_cache:
                     last = torch.tensor([h['yseq'][-1] for h in hyps], dtype=torch.int64, device=dev)
-                    lp_all = torch.log_softmax(cache.step(last).float(), dim=1)
-                    best_all, idx_all = torch.topk(lp_all, beam_width, dim=1)
+                    best_all, idx_all = ops.logsoftmax_topk(cache.step(last).float().contiguous(), beam_width)
                     best_all, idx_all = best_all.tolist(), idx_all.tolist()
                 cand = []
                 for hi, hyp in enumerate(hyps):
@@ -293,8 +292,7 @@ class Decoder(nn.Module):
                     else:
                         ys = torch.tensor([hyp['yseq']], dtype=torch.int64, device=dev)
                         logits = self._step_logits(ys, enc)[:, -1]
-                        lp = torch.log_softmax(logits.float(), dim=1)
-                        best, idx = torch.topk(lp, beam_width, dim=1)
+                        best, idx = ops.logsoftmax_topk(logits.float().contiguous(), beam_width)
                         best, idx = best[0].tolist(), idx[0].tolist()
                     for j in range(beam_width):
                         cand.append({'score': hyp['score'] + best[j], 'yseq': hyp['yseq'] + [idx[j]], 'parent': hi})

@@ -228,6 +228,9 @@ int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, int M, int 
                float* row_lse, int64_t* argmax, float* sums, asr_stream_t stream);
 /* out[m] = lowest index of the row maximum (torch.topk(pred,1) at transformer.py:80, metrics.py:89)            */
 int asr_argmax_rows(const float* logits, int64_t ld, int M, int V, int64_t* out, asr_stream_t stream);
+/* beam-search scoring (F.log_softmax + torch.topk per hypothesis, transformer.py:446-449): vals (M,k) = the k largest
+ * log-probabilities of each row, best first, idx (M,k) their indices (lowest index first among equal values); k <= 16   */
+int asr_logsoftmax_topk(const float* logits, int64_t ld, int M, int V, int k, float* vals, int64_t* idx, asr_stream_t stream);
 /* dlogits[m,v] = coef * (softmax*sum_q - q), coef = *grad_out / *count (device scalars), 0 for PAD rows.
  * dlogits has leading dimension ldd >= V and dtype `out_dtype`; columns V..ldd-1 are zero-filled.              */
 int asr_ce_bwd(const float* logits, int64_t ld, const int64_t* gold, const float* row_lse, int M, int V,

@@ -667,3 +667,21 @@ def test_device_prefetcher_delivers_device_batches():
     assert len(out) == 6
     for i, v in enumerate(out):
         assert abs(v - float((batches[i][0] * 2).sum())) < 1e-2 * max(1.0, abs(v))
+
+
+@pytest.mark.parametrize("M,V,k", [(5, 4364, 4), (1, 35, 2), (32, 4364, 8), (3, 17, 16)])
+def test_logsoftmax_topk_matches_torch(M, V, k):
+    """asr_logsoftmax_topk against the reference's two calls (F.log_softmax + torch.topk, transformer.py:446-449)."""
+    from asr_hip import ops
+    g = torch.Generator().manual_seed(M * 7 + V)
+    x = (3 * torch.randn(M, V + 5, generator=g)).cuda()[:, :V]          # a row stride larger than V
+    x[0, 3] = x[0, 11] = x.max() + 1.0                                  # a tie at the top: lowest index first
+    vals, idx = ops.logsoftmax_topk(x, k)
+    ref = torch.log_softmax(x.float().cpu(), dim=1)
+    rv, ri = torch.topk(ref, k, dim=1)
+    assert (vals.cpu() - rv).abs().max().item() <= 2e-6 * max(1.0, rv.abs().max().item())
+    assert idx[0, 0].item() == 3 and idx[0, 1].item() == 11
+    # same index sets, and the same order wherever the values are distinct
+    assert torch.equal(torch.sort(idx.cpu(), 1).values, torch.sort(ri, 1).values)
+    distinct = (rv[:, 1:] != rv[:, :-1]).all(1)
+    assert torch.equal(idx.cpu()[distinct], ri[distinct])
