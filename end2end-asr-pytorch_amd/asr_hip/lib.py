@@ -58,6 +58,7 @@ _SIGS = {
     "asr_kv_append": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _P, _I, _P]),
     "asr_ce_fwd": (_I, [_P, _L, _P, _I, _I, _F, _I, _P, _P, _P, _P]),
     "asr_argmax_rows": (_I, [_P, _L, _I, _I, _P, _P]),
+    "asr_edit_distance_batch": (_I, [_P, _P, _P, _P, _I, _P]),
     "asr_logsoftmax_topk": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),
     "asr_dec_gemm": (_I, [_P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P, _F, _P, _P, _P, _P, _F, _P, _P]),
     "asr_dec_attn": (_I, [_P, _L, _P, _P, _L, _P, _P, _L, _L, _I, _P, _L, _I, _I, _I, _F, _I, _P, _P]),

@@ -20,7 +20,8 @@ from utils import constant
 from utils.audio import gpu_front_end
 from utils.data_loader import DevicePrefetcher
 from utils.functions import save_model
-from utils.metrics import calculate_cer, calculate_metrics, calculate_wer
+from asr_hip.text import edit_distance_batch
+from utils.metrics import calculate_metrics
 
 
 def _strings(id_rows, id2label):
@@ -82,13 +83,13 @@ class Trainer():
                 loss_value = opt.optimizer.global_loss()
         ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()   # one D2H copy
         strs_gold, strs_hyps = _strings(ids[0], id2label), _strings(ids[1], id2label)
-        cer = wer = chars = words = 0
-        for g, h in zip(strs_gold, strs_hyps):
-            g, h = _strip(g), _strip(h)
-            cer += calculate_cer(h.replace(' ', ''), g.replace(' ', ''))
-            wer += calculate_wer(h, g)
-            chars += len(g.replace(' ', ''))
-            words += len(g.split(" "))
+        # CER / WER of the whole batch in two calls of the native Levenshtein (asr_hip/text.py; per utterance it is
+        # calculate_cer(h without spaces, g without spaces) and calculate_wer(h, g) of utils/metrics.py)
+        golds, hyps = [_strip(g) for g in strs_gold], [_strip(h) for h in strs_hyps]
+        cer = sum(edit_distance_batch([(h.replace(' ', ''), g.replace(' ', '')) for g, h in zip(golds, hyps)]))
+        wer = sum(edit_distance_batch([(h.split(), g.split()) for g, h in zip(golds, hyps)]))
+        chars = sum(len(g.replace(' ', '')) for g in golds)
+        words = sum(len(g.split(" ")) for g in golds)
         return (loss.item() if loss_value is None else loss_value), cer, wer, chars, words
 
     def train(self, model, train_loader, train_sampler, valid_loader_list, opt, loss_type, start_epoch, num_epochs, label2id,

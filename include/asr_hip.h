@@ -228,6 +228,10 @@ int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, int M, int 
                float* row_lse, int64_t* argmax, float* sums, asr_stream_t stream);
 /* out[m] = lowest index of the row maximum (torch.topk(pred,1) at transformer.py:80, metrics.py:89)            */
 int asr_argmax_rows(const float* logits, int64_t ld, int M, int V, int64_t* out, asr_stream_t stream);
+/* HOST function (no device work): Levenshtein distances of n sequence pairs of int32 symbols (UTF-32 code points for CER, word
+ * ids for WER; utils/metrics.py:48-76, trainer.py:62-75).  Pair p = a[a_off[p] .. a_off[p+1]) vs b[b_off[p] .. b_off[p+1]).   */
+int asr_edit_distance_batch(const int32_t* a, const int64_t* a_off, const int32_t* b, const int64_t* b_off, int n, int32_t* out);
+
 /* beam-search scoring (F.log_softmax + torch.topk per hypothesis, transformer.py:446-449): vals (M,k) = the k largest
  * log-probabilities of each row, best first, idx (M,k) their indices (lowest index first among equal values); k <= 16   */
 int asr_logsoftmax_topk(const float* logits, int64_t ld, int M, int V, int k, float* vals, int64_t* idx, asr_stream_t stream);

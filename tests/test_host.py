@@ -251,3 +251,21 @@ def test_device_prefetcher_passes_batches_through_in_order():
     got = list(DevicePrefetcher(batches, device=None))
     assert len(got) == 5 and all(g[2] == i and torch.equal(g[0], batches[i][0]) for i, g in enumerate(got))
     assert list(DevicePrefetcher([], device=None)) == []
+
+
+def test_native_edit_distance_matches_python_and_oracle():
+    """asr_edit_distance_batch (host C++ in libasr_hip.so) against the pure-Python distance it replaces and the oracle's, on
+    random strings incl. empty ones and CJK code points, and on word lists (WER)."""
+    import random
+    from asr_hip.text import edit_distance, edit_distance_batch, edit_distance_py
+    from oracle import asr_oracle as O
+    rnd = random.Random(7)
+    alphabet = "abcdefghij 的一是不了"
+    pairs = [("".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 90))),
+              "".join(rnd.choice(alphabet) for _ in range(rnd.randint(0, 90)))) for _ in range(48)]
+    pairs += [("", ""), ("abc", ""), ("", "xy"), ("kitten", "sitting")]
+    got = edit_distance_batch(pairs)
+    assert got == [edit_distance_py(a, b) for a, b in pairs] == [O.edit_distance(a, b) for a, b in pairs]
+    words = [(a.split(), b.split()) for a, b in pairs]
+    assert edit_distance_batch(words) == [edit_distance_py(a, b) for a, b in words]
+    assert edit_distance("flaw", "lawn") == 2 and edit_distance_batch([]) == []
