@@ -26,7 +26,9 @@ from . import params as P
 
 
 class GraphedTrainStep:
-    def __init__(self, model, opt, smoothing, src, src_len, tgt, clip_max_norm=None, warmup_steps=2):
+    def __init__(self, model, opt, smoothing, src, src_len, tgt, clip_max_norm=None, warmup_steps=2, replay_after_capture=True):
+        """Runs `warmup_steps` REAL steps eagerly on the given batch, captures, and (replay_after_capture) one more by replay.
+        A trainer that must apply each batch exactly once passes warmup_steps=1, replay_after_capture=False."""
         from utils.metrics import calculate_metrics
         self._metrics = calculate_metrics
         self.model, self.opt, self.smoothing, self.clip = model, opt, float(smoothing), clip_max_norm
@@ -50,8 +52,10 @@ class GraphedTrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup_steps)):       # eager warm-up: allocates workspaces, shadows, big-LDS attributes,
-                self._eager_step()                      # and (data parallel) creates / warms the communicator
+                res = self._eager_step()                # and (data parallel) creates / warms the communicator
                 self._host_after()
+            # results of the last eager step (the capture below re-binds loss / hyp_seq to tensors that only a replay fills)
+            self.warm = (res[0], getattr(self, "gold_seq", None), getattr(self, "hyp_seq", None))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.red is None:
@@ -70,14 +74,15 @@ class GraphedTrainStep:
                 self._body_c()
             del feats, dfeats
             self.graphs = [self.graph_a, self.graph_b, self.graph_c]
-        self._host_after()                               # capture does not execute; replay below does
-        self._replay()
+        if replay_after_capture:
+            self._host_after()                           # capture does not execute; replay below does
+            self._replay()
 
     # ------------------------------------------------------------------------------------------------ single GPU
     def _body_single(self):
         ops.step_advance()
         self.opt.zero_grad()
-        pred, gold, _, _ = self.model(self.src, self.src_len, self.tgt)
+        pred, gold, self.hyp_seq, self.gold_seq = self.model(self.src, self.src_len, self.tgt)
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
         loss.backward()
         self._body_c()
@@ -160,6 +165,11 @@ class GraphedTrainStep:
         if self.red is None:
             return float(self.loss.item())
         return self.opt.optimizer.global_loss()
+
+    def sync_step_counter(self):
+        """Several graphs (one per shape bucket) and eager steps may alternate on one optimiser: the device-side step counter
+        every replay reads is set from the optimiser's host-side count first."""
+        ops.step_state(self.src.device)[1] = int(self.opt._step)
 
     def __call__(self, src=None, src_len=None, tgt=None):
         """Copy the batch into the static buffers (skip arguments that are already there) and replay.

@@ -44,6 +44,45 @@ class Trainer():
     def __init__(self):
         logging.info("Trainer is initialized")
 
+    def _graph_step(self, model, opt, src, src_lengths, tgt, smoothing):
+        """--graph-buckets N: the training step as a captured hipGraph per (batch, padded frames) shape.  The batch is copied
+        into the graph's static buffers -- time axis zero-padded to a multiple of N frames, targets PAD-padded to --tgt-max-len - 1
+        columns (Decoder.preprocess strips PAD, so the targets are unchanged; the extra zero frames are seen by the model exactly
+        like the collate function's own padding of shorter utterances) -- and the graph is replayed.  The first batch of a new
+        shape runs eagerly (that IS its training step) and captures.  Returns (loss value, gold_seq, hyp_seq) or None when the
+        shapes do not fit (falls back to eager launches)."""
+        from asr_hip.graph import GraphedTrainStep
+        a = constant.args
+        red = getattr(opt.optimizer, "reducer", None)
+        L = int(a.tgt_max_len) - 1
+        if (red is not None and red.active) or tgt.shape[1] > L or src.dim() != 4:
+            return None
+        N = int(a.graph_buckets)
+        B, C, F, T = src.shape
+        Tb = (T + N - 1) // N * N
+        key = (B, C, F, Tb, L, src.dtype)
+        graphs = self.__dict__.setdefault("_graphs", {})
+        gs = graphs.get(key)
+        lens = torch.as_tensor(src_lengths).to(torch.int32)
+        if gs is None:
+            src_b = torch.zeros((B, C, F, Tb), device=src.device, dtype=src.dtype)
+            src_b[..., :T].copy_(src)
+            tgt_b = torch.zeros((B, L), device=tgt.device, dtype=tgt.dtype)
+            tgt_b[:, :tgt.shape[1]].copy_(tgt)
+            gs = graphs[key] = GraphedTrainStep(model, opt, smoothing, src_b, lens, tgt_b,
+                                                clip_max_norm=a.max_norm if a.clip else None, warmup_steps=1,
+                                                replay_after_capture=False)
+            return gs.warm                              # the eager step the constructor ran IS this batch's training step
+        else:
+            gs.src[..., :T].copy_(src, non_blocking=True)
+            if Tb > T:
+                gs.src[..., T:].zero_()
+            gs.tgt.zero_()
+            gs.tgt[:, :tgt.shape[1]].copy_(tgt, non_blocking=True)
+            gs.sync_step_counter()
+            gs(src_len=lens)
+        return gs.loss, gs.gold_seq, gs.hyp_seq
+
     def _run_batch(self, model, data, smoothing, loss_type, id2label, opt=None):
         src, tgt, src_percentages, src_lengths, tgt_lengths = data
         if constant.USE_CUDA:
@@ -51,6 +90,15 @@ class Trainer():
         if getattr(constant.args, "gpu_frontend", False):
             a = constant.args
             src, src_lengths = gpu_front_end(src, src_lengths, a.sample_rate, a.window_size, a.window_stride, a.src_max_len)
+        if opt is not None and loss_type == "ce" and getattr(constant.args, "graph_buckets", 0) > 0 and src.is_cuda:
+            r = self._graph_step(model, opt, src, src_lengths, tgt, smoothing)
+            if r is not None:
+                loss, gold_seq, hyp_seq = r
+                ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()      # one D2H copy (also the step's only sync)
+                loss_value = loss.item()
+                if loss_value != loss_value or loss_value in (float("inf"), float("-inf")):
+                    logging.info("non-finite loss under --graph-buckets: the replayed step has already been applied")
+                return (loss_value,) + self._text_metrics(ids, id2label)
         if opt is not None:
             opt.zero_grad()
         pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)
@@ -82,6 +130,11 @@ class Trainer():
                 # batch = all-reduced loss sum / all-reduced token count (the stats slot of the gradient buffer)
                 loss_value = opt.optimizer.global_loss()
         ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()   # one D2H copy
+        return ((loss.item() if loss_value is None else loss_value),) + self._text_metrics(ids, id2label)
+
+    @staticmethod
+    def _text_metrics(ids, id2label):
+        """(gold ids, hypothesis ids) of a batch -> (CER distance, WER distance, #characters, #words) (reference trainer.py:62-75)"""
         strs_gold, strs_hyps = _strings(ids[0], id2label), _strings(ids[1], id2label)
         # CER / WER of the whole batch in two calls of the native Levenshtein (asr_hip/text.py; per utterance it is
         # calculate_cer(h without spaces, g without spaces) and calculate_wer(h, g) of utils/metrics.py)
@@ -90,7 +143,7 @@ class Trainer():
         wer = sum(edit_distance_batch([(h.split(), g.split()) for g, h in zip(golds, hyps)]))
         chars = sum(len(g.replace(' ', '')) for g in golds)
         words = sum(len(g.split(" ")) for g in golds)
-        return (loss.item() if loss_value is None else loss_value), cer, wer, chars, words
+        return cer, wer, chars, words
 
     def train(self, model, train_loader, train_sampler, valid_loader_list, opt, loss_type, start_epoch, num_epochs, label2id,
               id2label, last_metrics=None):

@@ -64,6 +64,10 @@ _FLAGS = [
     (("--precision",), dict(default="bf16", choices=["bf16", "fp32", "fp8"])),     # fp8: bf16 storage, fp8 MFMA for the --rank projections
     (("--dist-backend",), dict(default="nccl")), (("--bucket-mb",), dict(default=32.0, type=_F)),
     (("--gpu-frontend",), dict(action="store_true")),
+    # 0: eager launches on the batch exactly as collated.  N > 0: training batches are zero-padded along time to a multiple of N
+    # frames (the way the collate function pads shorter utterances) and to --tgt-max-len - 1 target columns, and the step is a
+    # captured hipGraph per (batch, frames) shape, replayed (trainer/asr/trainer.py)
+    (("--graph-buckets",), dict(default=0, type=_I)),
     # Low-Rank Transformer (arXiv:1910.13923, BASELINE configs[4]): rank of every attention / feed-forward projection, 0 = full rank
     (("--rank",), dict(default=0, type=_I)),
 ]

@@ -105,3 +105,35 @@ def test_graph_replay_with_dropout_equals_eager_at_the_same_seed_counter(golden_
     assert abs(loss_a - loss_b) <= tol_l * abs(loss_a) and abs(loss_a - loss_c) > 5e-3 * abs(loss_a)
     assert g_a.abs().max().item() > 0
     assert ((g_a - g_b).norm() / g_a.norm()).item() <= tol_g
+
+
+def test_trainer_graph_buckets_equal_eager_on_whole_buckets(golden_dir, monkeypatch):
+    """Trainer._run_batch with --graph-buckets N: when the batch already fills its bucket (T a multiple of N, targets
+    --tgt-max-len - 1 wide) the replayed steps are the eager steps -- same losses, same hypothesis ids, same weights (fp32 mode,
+    dropout 0); the first batch of a shape is applied exactly once (eagerly, by the constructor).  With a bucket that pads the
+    time axis (N = 48: 64 -> 96 frames) the step still trains (finite, decreasing loss) on the zero-extended batch."""
+    from trainer.asr.trainer import Trainer
+    from utils import constant
+
+    def run(buckets, steps=4):
+        z, args, m, o = build(golden_dir, "vgg_tiny", "fp32")
+        monkeypatch.setattr(constant.args, "graph_buckets", buckets, raising=False)
+        monkeypatch.setattr(constant, "USE_CUDA", True, raising=False)
+        i2l = {i: chr(0x61 + i % 26) for i in range(int(z["V"]))}
+        src, tgt = torch.from_numpy(z["src"]), torch.from_numpy(z["tgt"])
+        data = (src, tgt, torch.ones(src.shape[0]), torch.from_numpy(z["src_len"]), torch.full((src.shape[0],), tgt.shape[1], dtype=torch.int32))
+        tr = Trainer()
+        out = [tr._run_batch(m, data, float(z["smoothing"]), "ce", i2l, o) for _ in range(steps)]
+        return out, {k: v.detach().clone() for k, v in m.state_dict().items()}, o, tr
+
+    eager, w_e, o_e, _ = run(0)
+    graph, w_g, o_g, tr = run(16)
+    assert len(tr._graphs) == 1 and o_g._step == o_e._step == 4
+    for a, b in zip(eager, graph):
+        assert abs(a[0] - b[0]) <= 2e-5 and a[1:] == b[1:], (a, b)          # loss; CER / WER / character / word counts
+    for k in w_e:
+        if not k.endswith("key_linear.bias"):
+            assert torch.allclose(w_e[k], w_g[k], atol=1e-5), k
+    padded, _, o_p, trp = run(48)
+    assert list(trp._graphs)[0][3] == 96 and o_p._step == 4
+    assert all(r[0] == r[0] and abs(r[0]) < 1e3 for r in padded) and padded[-1][0] < padded[0][0]

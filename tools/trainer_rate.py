@@ -2,7 +2,7 @@
 """Steps per second of the TRAINER's step body (trainer/asr/trainer.py:_run_batch: H2D through the prefetcher, zero_grad, forward,
 loss, backward, optimiser, one D2H copy of the token ids, strings, CER / WER) on the benchmark's workload -- configs[1], B = 32,
 synthetic batches that arrive as host tensors like the collate function's -- next to bench.py's graph-replayed step.
-usage: python tools/trainer_rate.py [steps]"""
+usage: [RATE_MODE=prefetch|resident|pinned] [RATE_BUCKETS=N] python tools/trainer_rate.py [steps]"""
 import os
 import sys
 import time
@@ -20,7 +20,8 @@ from trainer.asr.trainer import Trainer              # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = 32
-args = constant.parse(Bn.MODEL_FLAGS + ["--dropout", "0.1", "--precision", "bf16", "--cuda", "--batch-size", str(B)])
+args = constant.parse(Bn.MODEL_FLAGS + ["--dropout", "0.1", "--precision", "bf16", "--cuda", "--batch-size", str(B),
+                                        "--graph-buckets", os.environ.get("RATE_BUCKETS", "0")])
 l2i, i2l = Bn.labels(Bn.V)
 model = init_transformer_model(args, l2i, i2l).cuda()
 opt = init_optimizer(args, model, "noam")
@@ -41,4 +42,4 @@ for name, n in (("warm-up", 5), ("timed", steps)):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / n
     if name == "timed":
-        print(mode, "trainer step body: %.2f ms/step = %.2f M frames/s (loss %.4f)" % (dt * 1e3, B * Bn.T_SRC / dt / 1e6, r[0]))
+        print(mode, "graph-buckets", args.graph_buckets, "trainer step body: %.2f ms/step = %.2f M frames/s (loss %.4f)" % (dt * 1e3, B * Bn.T_SRC / dt / 1e6, r[0]))
