@@ -40,6 +40,35 @@ def _strip(s):
     return s.replace(constant.SOS_CHAR, '').replace(constant.EOS_CHAR, '')
 
 
+class _Pending:
+    """Results of a training step that are still on their way to the host: the token ids (gold, hypothesis) and the loss are
+    copied into pinned memory asynchronously; .result() waits for that copy only -- the trainer asks for it AFTER it has
+    enqueued the next step, so the strings / CER / WER of step i are computed while the GPU runs step i + 1."""
+    _pool = {}
+
+    def __init__(self, gold_seq, hyp_seq, loss, id2label):
+        turn = _Pending._pool["turn"] = (_Pending._pool.get("turn", 0) + 1) & 1        # two buffers per shape: one pending, one filling
+        key = (tuple(gold_seq.shape), turn)
+        buf = _Pending._pool.get(key)
+        if buf is None:
+            buf = _Pending._pool[key] = (torch.empty((2,) + tuple(gold_seq.shape), dtype=torch.int64).pin_memory(),
+                                         torch.empty(1, dtype=torch.float32).pin_memory())
+        self.ids, self.loss = buf
+        self.ids[0].copy_(gold_seq, non_blocking=True)
+        self.ids[1].copy_(hyp_seq, non_blocking=True)
+        self.loss.copy_(loss.detach().reshape(1).float(), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self.id2label = id2label
+
+    def result(self):
+        self.event.synchronize()
+        loss_value = float(self.loss[0])
+        if loss_value != loss_value or loss_value in (float("inf"), float("-inf")):
+            logging.info("non-finite loss: the step has already been applied")
+        return (loss_value,) + Trainer._text_metrics(self.ids.tolist(), self.id2label)
+
+
 class Trainer():
     def __init__(self):
         logging.info("Trainer is initialized")
@@ -94,11 +123,7 @@ class Trainer():
             r = self._graph_step(model, opt, src, src_lengths, tgt, smoothing)
             if r is not None:
                 loss, gold_seq, hyp_seq = r
-                ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()      # one D2H copy (also the step's only sync)
-                loss_value = loss.item()
-                if loss_value != loss_value or loss_value in (float("inf"), float("-inf")):
-                    logging.info("non-finite loss under --graph-buckets: the replayed step has already been applied")
-                return (loss_value,) + self._text_metrics(ids, id2label)
+                return _Pending(gold_seq, hyp_seq, loss, id2label)         # asynchronous D2H; no sync in this step
         if opt is not None:
             opt.zero_grad()
         pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)
@@ -129,6 +154,8 @@ class Trainer():
                 # data parallel: `loss` is this rank's local mean; the reference's number is the mean over the gathered
                 # batch = all-reduced loss sum / all-reduced token count (the stats slot of the gradient buffer)
                 loss_value = opt.optimizer.global_loss()
+        if opt is not None and loss_value is None and gold_seq.is_cuda:
+            return _Pending(gold_seq, hyp_seq, loss, id2label)  # training: the ids / loss reach the host under the next step
         ids = torch.stack([gold_seq, hyp_seq]).cpu().tolist()   # one D2H copy
         return ((loss.item() if loss_value is None else loss_value),) + self._text_metrics(ids, id2label)
 
@@ -162,16 +189,29 @@ class Trainer():
             # batches arrive on the device one step ahead (pinned staging + copy stream, utils/data_loader.py)
             feed = DevicePrefetcher(train_loader, torch.device("cuda", torch.cuda.current_device()) if constant.USE_CUDA else None)
             pbar = tqdm(iter(feed), leave=True, total=len(train_loader), disable=not rank0)
-            for i, data in enumerate(pbar):
-                r = self._run_batch(model, data, smoothing, loss_type, id2label, opt)
-                if r is None:
-                    continue
+            def account(r, i):
+                nonlocal total_loss, total_cer, total_wer, total_char, total_word, n_batches
                 loss, cer, wer, chars, words = r
                 total_loss += loss; total_cer += cer; total_wer += wer; total_char += chars; total_word += words
                 n_batches += 1
-                frames += int(data[3].sum())
                 pbar.set_description("(Epoch {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f} {:.0f} frames/s".format(
                     epoch + 1, total_loss / (i + 1), total_cer * 100 / max(1, total_char), opt._rate, frames / (time.time() - t0)))
+
+            pending = None                       # (--graph-buckets) the previous step's results, still in flight to the host
+            for i, data in enumerate(pbar):
+                r = self._run_batch(model, data, smoothing, loss_type, id2label, opt)
+                if pending is not None:
+                    account(pending[0].result(), pending[1])
+                    pending = None
+                if r is None:
+                    continue
+                frames += int(data[3].sum())
+                if isinstance(r, _Pending):
+                    pending = (r, i)
+                else:
+                    account(r, i)
+            if pending is not None:
+                account(pending[0].result(), pending[1])
             logging.info("(Epoch {}) TRAIN LOSS:{:.4f} CER:{:.2f}% LR:{:.7f}".format(
                 epoch + 1, total_loss / max(1, len(train_loader)), total_cer * 100 / max(1, total_char), opt._rate))
 

@@ -123,7 +123,16 @@ def test_trainer_graph_buckets_equal_eager_on_whole_buckets(golden_dir, monkeypa
         src, tgt = torch.from_numpy(z["src"]), torch.from_numpy(z["tgt"])
         data = (src, tgt, torch.ones(src.shape[0]), torch.from_numpy(z["src_len"]), torch.full((src.shape[0],), tgt.shape[1], dtype=torch.int32))
         tr = Trainer()
-        out = [tr._run_batch(m, data, float(z["smoothing"]), "ce", i2l, o) for _ in range(steps)]
+        out, pending = [], None
+        for _ in range(steps):                 # like Trainer.train: a step's results are fetched after the next step is enqueued
+            r = tr._run_batch(m, data, float(z["smoothing"]), "ce", i2l, o)
+            if pending is not None:
+                out.append(pending.result())
+            pending = r if hasattr(r, "result") else None
+            if pending is None:
+                out.append(r)
+        if pending is not None:
+            out.append(pending.result())
         return out, {k: v.detach().clone() for k, v in m.state_dict().items()}, o, tr
 
     eager, w_e, o_e, _ = run(0)

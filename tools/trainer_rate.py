@@ -37,8 +37,17 @@ for name, n in (("warm-up", 5), ("timed", steps)):
     feed = [resident] * n if mode == "resident" else DevicePrefetcher([batch] * n, torch.device("cuda", 0))
     torch.cuda.synchronize()
     t0 = time.time()
+    pending = None
     for data in feed:
         r = tr._run_batch(model, data, 0.1, "ce", i2l, opt)
+        if pending is not None:                       # like Trainer.train: the previous step's results after this step's launches
+            last = pending.result()
+        pending = r if hasattr(r, "result") else None
+        if pending is None:
+            last = r
+    if pending is not None:
+        last = pending.result()
+    r = last
     torch.cuda.synchronize()
     dt = (time.time() - t0) / n
     if name == "timed":
