@@ -13,7 +13,7 @@ OBJ = os.path.join(HERE, "_obj")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in architectural VGPRs (gfx950 has a unified file); without it the
 # softmax / epilogue code pays a v_accvgpr_read/write pair for every accumulator element it touches.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
-         "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("ASR_HIPCC_EXTRA", "").split()    # e.g. -DASR_TUNE_ABLATE (tuning builds)
 
 
 def _hipcc():

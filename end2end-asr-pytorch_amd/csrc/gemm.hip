@@ -20,6 +20,7 @@ struct GemmArgs {
   float alpha;
   int relu, accumulate, atomic, vecA, vecB, vecC;
   int tiles_n, ntiles;
+  int ablate;          // -DASR_TUNE_ABLATE builds only (tuning "GEMM_ABLATE"): 1 = stage A once, 2 = stage B once (stale operands: timing only)
 };
 
 constexpr int kPitch = 144;   // bytes per LDS tile row: 128 data + 16 pad (keeps 16-B alignment, breaks the 128-B stride)
@@ -217,8 +218,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   auto stage = [&](int kt, int buf) __attribute__((always_inline)) {
     unsigned char* s = smem + buf * STAGE;
     const int64_t kb = (kbeg * ESZ) + (int64_t)kt * BKB;
+#ifdef ASR_TUNE_ABLATE
+    if (!(p.ablate & 1) || kt == 0) stage_glds<BM>(s, A, p.lda * ESZ, m0, p.M, kb, tid, wave);
+    if (!(p.ablate & 2) || kt == 0) stage_glds<BN>(s + BM * BKB, B, p.ldb * ESZ, n0, p.N, kb, tid, wave);
+#else
     stage_glds<BM>(s, A, p.lda * ESZ, m0, p.M, kb, tid, wave);
     stage_glds<BN>(s + BM * BKB, B, p.ldb * ESZ, n0, p.N, kb, tid, wave);
+#endif
   };
 
 #pragma unroll
@@ -1257,6 +1263,9 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
   const int oesz = out_dtype == ASR_F32 ? 4 : 2;
   p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0) && (oesz == 4 || ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
+#ifdef ASR_TUNE_ABLATE
+  p.ablate = (int)asr_tuning("GEMM_ABLATE", 0);
+#endif
   // fast path: LDS-DMA staging needs whole 16-B chunks everywhere and whole 128-byte K steps
   const bool fast = p.vecA && p.vecB && K > 0 && (K % bk == 0) && (kps % bk == 0) &&
                     asr_tuning("GEMM_GENERIC", 0) == 0;
