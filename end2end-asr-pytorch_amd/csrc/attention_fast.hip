@@ -93,10 +93,10 @@ __device__ __forceinline__ uint4 load_row16(const bf16_t* base, int64_t st, int 
 
 // Mask NKF key fragments of raw scores s[qi][kf][r] (key = kbase + 16 kf + 4 g + r, query = q_lane + 16 qi): straight-line
 // selects, mask bytes read with clamped (always valid) addresses.
-template <int NKF>
+template <int NKF, int NQ = 2>
 __device__ __forceinline__ void mask_scores(const AttnArgs& p, f32x4_t (*s)[NKF], int b, int kbase, int g, int q_lane, int kend) {
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
     const int q = q_lane + qi * 16;
     const uint8_t* mrow = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (int64_t)(q < p.Tq ? q : p.Tq - 1) * p.m_sq : nullptr;
 #pragma unroll
@@ -113,36 +113,41 @@ __device__ __forceinline__ void mask_scores(const AttnArgs& p, f32x4_t (*s)[NKF]
 }
 
 // ================================================================================================ forward
-// workgroup = 4 waves x 32 queries; grid = ceil(Tq / 128) * B * H (1-D, XCD-aware).
+// workgroup = 4 waves x 16 NQ queries; grid = ceil(Tq / (64 NQ)) * B * H (1-D, XCD-aware).  NQ = 2 (32 queries per wave) for long
+// sequences; NQ = 1 for short ones (Tq <= 256, every attention of the benchmark model at T' = 200): measured at (32, 8, 200, 200)
+// the tile loop costs 2.1 us per 64-key tile with two waves per SIMD -- one wave's S -> softmax -> P V chain cannot overlap its own
+// phases -- against 2.7 us for everything else in the launch; half the queries per wave doubles the waves per SIMD.
 constexpr int FQ = 128;
 
+template <int NQ>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
+  constexpr int FQW = 64 * NQ;                               // queries per workgroup
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];      // [buffer][K | V]
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (p.Tq + FQ - 1) / FQ;
+  const int nqb = (p.Tq + FQW - 1) / FQW;
   const int vid = xcd_linear_id();
   const int bh = vid / nqb, qb = vid - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int qw = qb * FQ + wave * 32;                       // first query of this wave
+  const int qw = qb * FQW + wave * 16 * NQ;                 // first query of this wave
   const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
   const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
   const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
   const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   const float c2 = p.scale * LOG2E;
 
-  uint4 qf[2][2];
-  uint32_t rkey[2];
+  uint4 qf[NQ][2];
+  uint32_t rkey[NQ];
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) qf[qi][ds] = load_row16(Qb, p.q_st, qw + qi * 16 + lr, p.Tq, ds * 32 + g * 8);
     rkey[qi] = drop_row_key(seed, drop_row(p, b, h, qw + qi * 16 + lr));
   }
-  f32x4_t o[2][4];
-  float m[2], l[2];
+  f32x4_t o[NQ][4];
+  float m[NQ], l[NQ];
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
     m[qi] = -INFINITY;
     l[qi] = 0.f;
 #pragma unroll
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
   }
   const int kend = key_end(p, b);
   int kstop = kend;
-  if (p.causal) kstop = min(kend, qb * FQ + FQ);
+  if (p.causal) kstop = min(kend, qb * FQW + FQW);
   const int ntile = (kstop + 63) >> 6;
 
   if (ntile > 0) {
@@ -164,21 +169,21 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
     const unsigned char* sK = smem + (t & 1) * 2 * TILE;
     const unsigned char* sV = sK + TILE;
     // ---- S^T[key][q] = K . Q^T
-    f32x4_t s[2][4];
+    f32x4_t s[NQ][4];
 #pragma unroll
     for (int kf = 0; kf < 4; ++kf) {
-      s[0][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      s[1][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int qi = 0; qi < NQ; ++qi) s[qi][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) {
         const uint4 a = frag_rows(sK, kf * 16 + lr, ds, g);
-        mma(s[0][kf], a, qf[0][ds]);
-        mma(s[1][kf], a, qf[1][ds]);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) mma(s[qi][kf], a, qf[qi][ds]);
       }
     }
     // ---- masks only where a boundary crosses this tile (wave-uniform test)
     const bool need_mask = (k0 + 64 > kend) || p.key_pad != nullptr || (p.causal && k0 + 63 > qw);
-    if (need_mask) mask_scores<4>(p, s, b, k0, g, qw + lr, kend);
+    if (need_mask) mask_scores<4, NQ>(p, s, b, k0, g, qw + lr, kend);
     // next tile: HBM -> LDS in flight under the softmax and the second contraction.  Issued AFTER the mask bytes were
     // consumed: ordinary loads and LDS-DMA loads share vmcnt, and waiting for the former with the latter in flight
     // was observed to return stale mask bytes.
@@ -190,9 +195,9 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- online softmax (base 2), dropout, pack P^T as the B operand
-    uint4 pb[2][2];
+    uint4 pb[NQ][2];
 #pragma unroll
-    for (int qi = 0; qi < 2; ++qi) {
+    for (int qi = 0; qi < NQ; ++qi) {
       float mx = -INFINITY;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
@@ -236,15 +241,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const uint4 vt = frag_cols(sV, df * 16, ms, lr, g);
-        mma(o[0][df], vt, pb[0][ms]);
-        mma(o[1][df], vt, pb[1][ms]);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) mma(o[qi][df], vt, pb[qi][ms]);
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
     const int q = qw + qi * 16 + lr;
     if (q >= p.Tq) continue;
     const float inv_l = l[qi] > 0.f ? p.inv_keep / l[qi] : 0.f;      // the dropout rescale is a constant: applied once here
@@ -264,15 +269,18 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
 //   S^T = K Q^T, dP^T = V dO^T (A operands: K / V rows from LDS; B: Q / dO rows in registers)
 //   P = exp2(S c - lse c'), dS = P (keep/(1-p) dP - delta)
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (A: transposing reads of the natural K tile; B: dS from the accumulators)
+// NQ as in the forward kernel: 16 NQ queries per wave (NQ = 1 for Tq <= 256).
+template <int NQ>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
+  constexpr int FQW = 64 * NQ;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (p.Tq + FQ - 1) / FQ;
+  const int nqb = (p.Tq + FQW - 1) / FQW;
   const int vid = xcd_linear_id();
   const int bh = vid / nqb, qb = vid - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int qw = qb * FQ + wave * 32;
+  const int qw = qb * FQW + wave * 16 * NQ;
   const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
   const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
   const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
@@ -280,11 +288,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
   const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   const float c2 = p.scale * LOG2E;
 
-  uint4 qf[2][2], dof[2][2];
-  uint32_t rkey[2];
-  float lse2[2], dlt[2];
+  uint4 qf[NQ][2], dof[NQ][2];
+  uint32_t rkey[NQ];
+  float lse2[NQ], dlt[NQ];
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
     const int q = qw + qi * 16 + lr;
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) {
@@ -296,14 +304,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
     lse2[qi] = p.lse[si] * LOG2E;                 // +inf for fully masked rows: exp2(-inf) = 0
     dlt[qi] = p.delta[si];
   }
-  f32x4_t dq[2][4];
+  f32x4_t dq[NQ][4];
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi)
+  for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
     for (int df = 0; df < 4; ++df) dq[qi][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int kend = key_end(p, b);
   int kstop = kend;
-  if (p.causal) kstop = min(kend, qb * FQ + FQ);
+  if (p.causal) kstop = min(kend, qb * FQW + FQW);
   const int ntile = (kstop + 63) >> 6;
 
   if (ntile > 0) {
@@ -320,24 +328,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
     // the tile is consumed in two halves of 32 keys (one macro step of the dQ contraction each): half the live accumulators
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-      f32x4_t s[2][2], dp[2][2];
+      f32x4_t s[NQ][2], dp[NQ][2];
 #pragma unroll
       for (int k2 = 0; k2 < 2; ++k2) {
-        s[0][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        s[1][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[0][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[1][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) {
+          s[qi][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          dp[qi][k2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
           const uint4 ak = frag_rows(sK, (2 * ms + k2) * 16 + lr, ds, g);
           const uint4 av = frag_rows(sV, (2 * ms + k2) * 16 + lr, ds, g);
-          mma(s[0][k2], ak, qf[0][ds]);
-          mma(s[1][k2], ak, qf[1][ds]);
-          mma(dp[0][k2], av, dof[0][ds]);
-          mma(dp[1][k2], av, dof[1][ds]);
+#pragma unroll
+          for (int qi = 0; qi < NQ; ++qi) {
+            mma(s[qi][k2], ak, qf[qi][ds]);
+            mma(dp[qi][k2], av, dof[qi][ds]);
+          }
         }
       }
-      if (need_mask) mask_scores<2>(p, s, b, k0 + 32 * ms, g, qw + lr, kend);
+      if (need_mask) mask_scores<2, NQ>(p, s, b, k0 + 32 * ms, g, qw + lr, kend);
       if (ms == 0) {
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntile) {
@@ -347,9 +357,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      uint4 pb[2];
+      uint4 pb[NQ];
 #pragma unroll
-      for (int qi = 0; qi < 2; ++qi) {
+      for (int qi = 0; qi < NQ; ++qi) {
         if (p.thr) {
 #pragma unroll
           for (int k2 = 0; k2 < 2; ++k2)
@@ -372,15 +382,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
         const uint4 kt = frag_cols(sK, df * 16, ms, lr, g);
-        mma(dq[0][df], kt, pb[0]);
-        mma(dq[1][df], kt, pb[1]);
+#pragma unroll
+        for (int qi = 0; qi < NQ; ++qi) mma(dq[qi][df], kt, pb[qi]);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 #pragma unroll
-  for (int qi = 0; qi < 2; ++qi) {
+  for (int qi = 0; qi < NQ; ++qi) {
     const int q = qw + qi * 16 + lr;
     if (q >= p.Tq) continue;
     bf16_t* o = static_cast<bf16_t*>(p.dQ) + (int64_t)b * p.q_sb + (int64_t)q * p.q_st + (int64_t)h * HD;
@@ -396,16 +406,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
 // wave = 32 keys (two B fragments, K / V rows in registers); 64-query Q / dO tiles double buffered in LDS with their
 // lse / delta rows.   S = Q K^T, dP = dO V^T (A: Q / dO rows from LDS), P, dS as above, then
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]   (A: transposing reads of dO / Q tiles)
+// NK: 16 NK keys per wave (NK = 1 for Tk <= 256, as in the other two kernels).
+template <int NK>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) {
+  constexpr int FKW = 64 * NK;                               // keys per workgroup
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   __shared__ float s_stat[2][2][64];                                              // [buffer][lse*log2e | delta][q]
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nkb = (p.Tk + FQ - 1) / FQ;
+  const int nkb = (p.Tk + FKW - 1) / FKW;
   const int vid = xcd_linear_id();
   const int bh = vid / nkb, kb = vid - bh * nkb;
   const int b = bh / p.H, h = bh - b * p.H;
-  const int kw = kb * FQ + wave * 32;                       // first key of this wave
+  const int kw = kb * FKW + wave * 16 * NK;                 // first key of this wave
   const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
   const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
   const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
@@ -415,21 +428,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
   const int kend = key_end(p, b);
   const int64_t stat0 = ((int64_t)b * p.H + h) * p.Tq;
 
-  uint4 kfr[2][2], vfr[2][2];
+  uint4 kfr[NK][2], vfr[NK][2];
 #pragma unroll
-  for (int ki = 0; ki < 2; ++ki)
+  for (int ki = 0; ki < NK; ++ki)
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) {
       kfr[ki][ds] = load_row16(Kb, p.k_st, kw + ki * 16 + lr, p.Tk, ds * 32 + g * 8);
       vfr[ki][ds] = load_row16(Vb, p.v_st, kw + ki * 16 + lr, p.Tk, ds * 32 + g * 8);
     }
-  f32x4_t dk[2][4], dv[2][4];
+  f32x4_t dk[NK][4], dv[NK][4];
 #pragma unroll
-  for (int ki = 0; ki < 2; ++ki)
+  for (int ki = 0; ki < NK; ++ki)
 #pragma unroll
     for (int df = 0; df < 4; ++df) { dk[ki][df] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[ki][df] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   // causal: query tiles that end before the first key of this workgroup never see it
-  const int t0 = p.causal ? (kb * FQ) >> 6 : 0;
+  const int t0 = p.causal ? (kb * FKW) >> 6 : 0;
   const int ntile = (p.Tq + 63) >> 6;
 
   auto stage_stats = [&](int t, int buf) __attribute__((always_inline)) {
@@ -454,25 +467,27 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
     const unsigned char* sdO = sQ + TILE;
     const float* st_lse = s_stat[t & 1][0];
     const float* st_dlt = s_stat[t & 1][1];
-    const bool need_mask = p.key_pad != nullptr || (p.causal && kw + 31 > q0) || (kw + 32 > kend);
+    const bool need_mask = p.key_pad != nullptr || (p.causal && kw + 16 * NK - 1 > q0) || (kw + 16 * NK > kend);
     // the query tile is consumed in two halves of 32 queries (one macro step of the dV / dK contractions each)
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-      f32x4_t s[2][2], dp[2][2];
+      f32x4_t s[NK][2], dp[NK][2];
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
-        s[0][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        s[1][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[0][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        dp[1][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ki = 0; ki < NK; ++ki) {
+          s[ki][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          dp[ki][q2] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
           const uint4 aq = frag_rows(sQ, (2 * ms + q2) * 16 + lr, ds, g);
           const uint4 ao = frag_rows(sdO, (2 * ms + q2) * 16 + lr, ds, g);
-          mma(s[0][q2], aq, kfr[0][ds]);
-          mma(s[1][q2], aq, kfr[1][ds]);
-          mma(dp[0][q2], ao, vfr[0][ds]);
-          mma(dp[1][q2], ao, vfr[1][ds]);
+#pragma unroll
+          for (int ki = 0; ki < NK; ++ki) {
+            mma(s[ki][q2], aq, kfr[ki][ds]);
+            mma(dp[ki][q2], ao, vfr[ki][ds]);
+          }
         }
       }
       // per-row statistics of the 8 queries this lane sees in this half: q = q0 + 32 ms + 16 q2 + 4 g + r
@@ -492,9 +507,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      uint4 pa[2], pd[2];
+      uint4 pa[NK], pd[NK];
 #pragma unroll
-      for (int ki = 0; ki < 2; ++ki) {
+      for (int ki = 0; ki < NK; ++ki) {
         const int key = kw + ki * 16 + lr;
         if (need_mask) {
           const uint8_t* mcol = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (key < p.Tk ? key : p.Tk - 1) : nullptr;
@@ -530,17 +545,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
       for (int df = 0; df < 4; ++df) {
         const uint4 aot = frag_cols(sdO, df * 16, ms, lr, g);
         const uint4 aqt = frag_cols(sQ, df * 16, ms, lr, g);
-        mma(dv[0][df], aot, pa[0]);
-        mma(dv[1][df], aot, pa[1]);
-        mma(dk[0][df], aqt, pd[0]);
-        mma(dk[1][df], aqt, pd[1]);
+#pragma unroll
+        for (int ki = 0; ki < NK; ++ki) {
+          mma(dv[ki][df], aot, pa[ki]);
+          mma(dk[ki][df], aqt, pd[ki]);
+        }
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 #pragma unroll
-  for (int ki = 0; ki < 2; ++ki) {
+  for (int ki = 0; ki < NK; ++ki) {
     const int key = kw + ki * 16 + lr;
     if (key >= p.Tk) continue;
     bf16_t* ok = static_cast<bf16_t*>(p.dK) + (int64_t)b * p.k_sb + (int64_t)key * p.k_st + (int64_t)h * HD;
@@ -591,8 +607,11 @@ bool fast_ok(const AttnArgs& p, int d, int dtype) {
 
 int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   if (!fast_ok(p, d, dtype) || (((uintptr_t)p.Out) & 7) != 0 || p.o_st % 4 != 0 || p.o_sb % 4 != 0) return ASR_EUNSUPPORTED;
-  const int nqb = (p.Tq + FQ - 1) / FQ;
-  attn_fwd_bf16_d64_kernel<<<dim3((unsigned)(nqb * p.B * p.H)), dim3(256), 0, s>>>(p);
+  if (p.Tq <= 256 && asr_tuning("ATTN_SHORT", 1) != 0) {
+    attn_fwd_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tq + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
+  } else {
+    attn_fwd_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+  }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -607,11 +626,17 @@ int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
     ASR_LAUNCH_CHECK();
   }
   if (p.parts & ASR_ATTN_DQ) {
-    attn_bwd_dq_bf16_d64_kernel<<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    if (p.Tq <= 256 && asr_tuning("ATTN_SHORT", 1) != 0)
+      attn_bwd_dq_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tq + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    else
+      attn_bwd_dq_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
     ASR_LAUNCH_CHECK();
   }
   if (p.parts & ASR_ATTN_DKV) {
-    attn_bwd_dkv_bf16_d64_kernel<<<dim3((unsigned)(((p.Tk + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    if (p.Tk <= 256 && asr_tuning("ATTN_SHORT", 1) != 0)
+      attn_bwd_dkv_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tk + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    else
+      attn_bwd_dkv_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tk + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
     ASR_LAUNCH_CHECK();
   }
   return ASR_OK;
