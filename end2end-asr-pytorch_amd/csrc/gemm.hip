@@ -207,7 +207,10 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
   const int64_t kend = min((int64_t)p.K, kbeg + p.k_per_split);
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
-  const int nk = (int)((kend - kbeg) * ESZ / BKB);
+  int nk = (int)((kend - kbeg) * ESZ / BKB);
+#ifdef ASR_TUNE_ABLATE
+  if (p.ablate & 16) nk = 0;
+#endif
 
   f32x4_t acc[FM][FN];
 #pragma unroll
@@ -286,6 +289,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
           const int r = wn * WN + j * 16 + lr;
           b[j] = *reinterpret_cast<const uint4*>(sB + r * BKB + (((ms * 4 + g) ^ (r & 7)) << 4));
         }
+#ifdef ASR_TUNE_ABLATE
+        if (p.ablate & 8) {
+#pragma unroll
+          for (int i = 0; i < FM; ++i) asm volatile("" :: "v"(a[i].x));
+#pragma unroll
+          for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(b[j].x));
+          continue;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -335,6 +347,9 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(GemmArgs p) {
           for (int e = 0; e < EPCO; ++e)
             if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<TO>::to(0.f);
         }
+#ifdef ASR_TUNE_ABLATE
+        if (p.ablate & 4) continue;
+#endif
         *reinterpret_cast<uint4*>(dst) = o.v;
       }
       return;
