@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
 //   S^T = K Q^T, dP^T = V dO^T (A operands: K / V rows from LDS; B: Q / dO rows in registers)
 //   P = exp2(S c - lse c'), dS = P (keep/(1-p) dP - delta)
 //   dQ^T[d][q] += K^T[d][key] dS^T[key][q]   (A: transposing reads of the natural K tile; B: dS from the accumulators)
-// NQ as in the forward kernel: 16 NQ queries per wave (NQ = 1 for Tq <= 256).
+// NQ as in the forward kernel: 16 NQ queries per wave.  In the two backward kernels 16-row waves win at every length (measured:
+// (32, 8, 800, 800) p = 0.1 backward 324 -> 301 us, (16, 8, 795, 795) 185 -> 166 us; the forward loses 4 - 9 % there), so they are the default.
 template <int NQ>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
   constexpr int FQW = 64 * NQ;
@@ -607,7 +608,7 @@ bool fast_ok(const AttnArgs& p, int d, int dtype) {
 
 int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   if (!fast_ok(p, d, dtype) || (((uintptr_t)p.Out) & 7) != 0 || p.o_st % 4 != 0 || p.o_sb % 4 != 0) return ASR_EUNSUPPORTED;
-  if (p.Tq <= 256 && asr_tuning("ATTN_SHORT", 1) != 0) {
+  if (p.Tq <= asr_tuning("ATTN_SHORT", 256)) {
     attn_fwd_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tq + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
   } else {
     attn_fwd_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
@@ -626,14 +627,14 @@ int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
     ASR_LAUNCH_CHECK();
   }
   if (p.parts & ASR_ATTN_DQ) {
-    if (p.Tq <= 256 && asr_tuning("ATTN_SHORT", 1) != 0)
+    if (p.Tq <= asr_tuning("ATTN_SHORT_BWD", 1 << 30))
       attn_bwd_dq_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tq + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
     else
       attn_bwd_dq_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
     ASR_LAUNCH_CHECK();
   }
   if (p.parts & ASR_ATTN_DKV) {
-    if (p.Tk <= 256 && asr_tuning("ATTN_SHORT", 1) != 0)
+    if (p.Tk <= asr_tuning("ATTN_SHORT_BWD", 1 << 30))
       attn_bwd_dkv_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tk + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
     else
       attn_bwd_dkv_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tk + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
