@@ -42,6 +42,8 @@ _SIGS = {
     "asr_add_ln_fwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _F, _F, _U64, _P, _I, _P]),
     "asr_add_ln_bwd_workspace": (_L, [_I, _I]),
     "asr_add_ln_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _P, _I, _P]),
+    "asr_add_ln_bwd_partials": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _F, _U64, _P, _I, _P]),
+    "asr_ln_reduce_multi": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "asr_attn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L, _P, _P, _L, _L,
                           _I, _F, _F, _U64, _P, _I, _P]),
     "asr_attn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _L, _L, _L, _L, _L, _L, _L,

@@ -119,6 +119,7 @@ def join_deferred():
     if _side["pending"] and _side["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_side["stream"])
     _side["pending"] = []
+    flush_ln_reduces()
 
 
 # ------------------------------------------------------------------------------------------------ dense
@@ -254,10 +255,33 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     d_y = torch.empty_like(z) if p > 0 else d_res
     n_ws = L.load().asr_add_ln_bwd_workspace(M, D)
     ws = torch.empty(n_ws, device=z.device, dtype=torch.float32)       # caching allocator: no cost after the first step
+    if _ln_multi and torch.cuda.is_current_stream_capturing():
+        # graph capture: the dgamma / dbeta sums of all layers in one launch at the end of backward (flush_ln_reduces)
+        L.call("asr_add_ln_bwd_partials", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
+               L.ptr(d_res), L.ptr(d_y), L.ptr(ws), n_ws, M, D, float(p), int(seed), _seed_dev(z), L.dt(z), L.stream())
+        _ln_pending.append((ws, M, D, dgamma, dbeta))
+        return d_res, d_y
     L.call("asr_add_ln_bwd", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
            L.ptr(d_res), L.ptr(d_y), L.ptr(dgamma), L.ptr(dbeta), L.ptr(ws), n_ws, M, D, float(p), int(seed), _seed_dev(z),
            L.dt(z), L.stream())
     return d_res, d_y
+
+
+_ln_multi = os.environ.get("ASR_LN_MULTI", "1") != "0"
+_ln_pending = []
+
+
+def flush_ln_reduces():
+    """Second stage of every LayerNorm backward issued since the last flush (same hidden size: one launch)."""
+    import ctypes
+    while _ln_pending:
+        D = _ln_pending[0][2]
+        grp = [e for e in _ln_pending if e[2] == D]
+        _ln_pending[:] = [e for e in _ln_pending if e[2] != D]
+        n = len(grp)
+        P_, I_ = ctypes.c_void_p * n, ctypes.c_int * n
+        L.call("asr_ln_reduce_multi", P_(*[e[0].data_ptr() for e in grp]), I_(*[e[1] for e in grp]),
+               P_(*[e[3].data_ptr() for e in grp]), P_(*[e[4].data_ptr() for e in grp]), n, D, L.stream())
 
 
 # ------------------------------------------------------------------------------------------------ attention

@@ -228,6 +228,26 @@ __global__ __launch_bounds__(256) void ln_partial_reduce_kernel(const float* __r
   atomicAdd(c < D ? dgamma + c : dbeta + (c - D), acc);
 }
 
+// the same for up to LN_MULTI layers in ONE launch (blockIdx.z = layer): the parameter-gradient sums are not on the critical
+// path of backward, so the per-layer second stages are collected and run together (asr_ln_reduce_multi)
+constexpr int LN_MULTI = 24;
+struct LnMultiArgs {
+  const float* ws[LN_MULTI]; float* dgamma[LN_MULTI]; float* dbeta[LN_MULTI]; int nblk[LN_MULTI];
+  int D2;
+};
+__global__ __launch_bounds__(256) void ln_partial_reduce_multi_kernel(LnMultiArgs a) {
+  const int L = blockIdx.z, c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.D2) return;
+  const int nblk = a.nblk[L];
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  const float* partial = a.ws[L];
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) acc += partial[(int64_t)b * a.D2 + c];
+  const int D = a.D2 / 2;
+  if (b0 < b1) atomicAdd(c < D ? a.dgamma[L] + c : a.dbeta[L] + (c - D), acc);
+}
+
 }  // namespace
 
 namespace {
@@ -241,14 +261,14 @@ void launch_fwd(T* y_z, const T* res, const float* gamma, const float* beta, con
 template <typename T, int NCH>
 void launch_bwd(const T* dout, const T* z, const float* mean, const float* rstd, const float* gamma, const uint8_t* keep, T* d_res,
                 T* d_y, float* dgamma, float* dbeta, float* ws, int64_t ws_floats, int M, int D, uint32_t thr, float inv, uint64_t seed,
-                const uint64_t* seed_dev, hipStream_t s) {
+                const uint64_t* seed_dev, hipStream_t s, bool reduce = true) {
   // with a workspace: 8 rows per block (fills the chip) and a two-stage column reduction; without: 32 rows + atomics
   int rpb = 8;
   int nblk = (M + rpb - 1) / rpb;
   if (!ws || ws_floats < (int64_t)nblk * 2 * D) { rpb = 32; nblk = (M + rpb - 1) / rpb; ws = nullptr; }
   hipLaunchKernelGGL((add_ln_bwd_kernel<T, NCH>), dim3(nblk), dim3(256), (size_t)3 * 2 * D * sizeof(float), s, dout, z,
                      mean, rstd, gamma, keep, d_res, d_y, dgamma, dbeta, ws, M, D, rpb, thr, inv, seed, seed_dev);
-  if (ws) {
+  if (ws && reduce) {
     const int slices = nblk >= 512 ? 64 : (nblk >= 64 ? 16 : 1);      // ~13 partial rows per thread
     hipLaunchKernelGGL(ln_partial_reduce_kernel, dim3((2 * D + 255) / 256, slices), dim3(256), 0, s, ws, nblk, 2 * D, dgamma, dbeta);
   }
@@ -304,6 +324,52 @@ extern "C" int asr_add_ln_bwd(const void* dout, const void* z, const float* mean
 #define ASR_CALL_B(T_, N_) launch_bwd<T_, N_>((const T_*)dout, (const T_*)z, mean, rstd, gamma, row_keep, (T_*)d_res, (T_*)d_y, dgamma, dbeta, workspace, workspace_floats, M, D, thr, inv, seed, seed_dev, s)
   if (dtype == ASR_F32) { ASR_LN_DISPATCH(float, ASR_CALL_B) } else { ASR_LN_DISPATCH(bf16_t, ASR_CALL_B) }
 #undef ASR_CALL_B
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+/* asr_add_ln_bwd without its second stage: the per-block column partials stay in `workspace` (required) until
+ * asr_ln_reduce_multi adds them into dgamma / dbeta. */
+extern "C" int asr_add_ln_bwd_partials(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
+                                       const uint8_t* row_keep, void* d_res, void* d_y, float* workspace, int64_t workspace_floats,
+                                       int M, int D, float p, uint64_t seed, const uint64_t* seed_dev, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(dout && z && mean && rstd && gamma && d_res && workspace && M >= 0 && D > 0 && p >= 0.f && p < 1.f);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  ASR_CHECK_ARG(workspace_floats >= asr_add_ln_bwd_workspace(M, D));
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  if (D % epc != 0 || D > 64 * 8 * epc) return ASR_EUNSUPPORTED;
+  ASR_CHECK_ARG(aligned16(dout) && aligned16(z) && aligned16(d_res) && (!d_y || aligned16(d_y)));
+  if (p > 0.f) ASR_CHECK_ARG(d_y && d_y != d_res);
+  if (M == 0) return ASR_OK;
+  const uint32_t thr = asr_drop_threshold(p);
+  const float inv = 1.f / (1.f - p);
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+  AsrProfScope prof(ASR_OP_ADD_LN, s);
+#define ASR_CALL_P(T_, N_) launch_bwd<T_, N_>((const T_*)dout, (const T_*)z, mean, rstd, gamma, row_keep, (T_*)d_res, (T_*)d_y, dgamma, dbeta, workspace, workspace_floats, M, D, thr, inv, seed, seed_dev, s, false)
+  if (dtype == ASR_F32) { ASR_LN_DISPATCH(float, ASR_CALL_P) } else { ASR_LN_DISPATCH(bf16_t, ASR_CALL_P) }
+#undef ASR_CALL_P
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_ln_reduce_multi(const float* const* workspaces, const int* rows, float* const* dgamma, float* const* dbeta, int n,
+                                   int D, hipStream_t s) {
+  ASR_CHECK_ARG(n >= 0 && D > 0 && (n == 0 || (workspaces && rows && dgamma && dbeta)));
+  for (int i0 = 0; i0 < n; i0 += LN_MULTI) {
+    LnMultiArgs a{};
+    const int cnt = n - i0 < LN_MULTI ? n - i0 : LN_MULTI;
+    int max_blk = 0;
+    for (int i = 0; i < cnt; ++i) {
+      ASR_CHECK_ARG(workspaces[i0 + i] && dgamma[i0 + i] && dbeta[i0 + i] && rows[i0 + i] >= 0);
+      a.ws[i] = workspaces[i0 + i]; a.dgamma[i] = dgamma[i0 + i]; a.dbeta[i] = dbeta[i0 + i];
+      a.nblk[i] = (rows[i0 + i] + 7) / 8;                   // the first stage's 8 rows per block
+      if (a.nblk[i] > max_blk) max_blk = a.nblk[i];
+    }
+    a.D2 = 2 * D;
+    const int slices = max_blk >= 512 ? 64 : (max_blk >= 64 ? 16 : 1);
+    hipLaunchKernelGGL(ln_partial_reduce_multi_kernel, dim3((2 * D + 255) / 256, slices, cnt), dim3(256), 0, s, a);
+  }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -112,6 +112,15 @@ int asr_add_ln_bwd(const void* dout, const void* z, const float* mean, const flo
                    const uint8_t* row_keep, void* d_res, void* d_y, float* dgamma_acc, float* dbeta_acc,
                    float* workspace, int64_t workspace_floats, int M, int D, float dropout_p, uint64_t seed,
                    const uint64_t* seed_dev, int dtype, asr_stream_t stream);
+/* The same with the second stage postponed: asr_add_ln_bwd_partials leaves the per-block column partials in `workspace`
+ * (required, asr_add_ln_bwd_workspace(M, D) floats, alive until the reduction), asr_ln_reduce_multi adds the partials of n layers
+ * (rows[i] = that layer's M) into their dgamma / dbeta in ONE launch -- the parameter gradients are not on backward's critical
+ * path, 21 seven-microsecond launches per step are (host arrays of n pointers; the kernel arguments carry them by value).   */
+int asr_add_ln_bwd_partials(const void* dout, const void* z, const float* mean, const float* rstd, const float* gamma,
+                            const uint8_t* row_keep, void* d_res, void* d_y, float* workspace, int64_t workspace_floats, int M,
+                            int D, float dropout_p, uint64_t seed, const uint64_t* seed_dev, int dtype, asr_stream_t stream);
+int asr_ln_reduce_multi(const float* const* workspaces, const int* rows, float* const* dgamma, float* const* dbeta, int n, int D,
+                        asr_stream_t stream);
 
 /* ---- fused multi-head attention core: softmax(mask(Q K^T * scale)) (dropout) V -------------------------------
  * Q (B,Tq,H,d) with element strides (q_sb, q_st) and head h at offset h*d; same for K,V (B,Tk,H,d), O (B,Tq,H,d).
