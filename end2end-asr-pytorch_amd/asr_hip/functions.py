@@ -387,7 +387,10 @@ class EmbedFn(Function):
 
 
 # ================================================================================================ vgg front end
-_conv_overlap = os.environ.get("ASR_CONV_OVERLAP", "0") == "1"      # A/B switch, default OFF: conv weight gradients on the second stream next to the
+_conv_overlap = os.environ.get("ASR_CONV_OVERLAP", "0") == "1"
+# fold of the conv weight-gradient partial blocks on the second stream, under the next data-gradient convolution: measured SLOWER
+# (7.44 -> 7.50 / 7.59 ms per step: the data-gradient convolutions are as much HBM- as MFMA-bound), default off
+_conv_reduce_side = os.environ.get("ASR_CONV_REDUCE_SIDE", "0") == "1"      # A/B switch, default OFF: conv weight gradients on the second stream next to the
 # following data gradient measured 7.82-7.94 vs 7.70 ms/step (both kernels are MFMA bound: sharing the CUs only slows both)
 
 
@@ -425,6 +428,15 @@ class VGGFn(Function):
             if f is not None and f.on:
                 with f:
                     ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
+                forks.append(f)
+                return
+            f = ops.fork() if (_conv_reduce_side and ops.compute_dtype() == torch.bfloat16) else None
+            if f is not None and f.on:
+                # MFMA-bound first stage here; its HBM-bound fold (75 MB of partial blocks) on the second stream, under the data-gradient
+                # convolution that follows on this one
+                fold = ops.conv3x3_wgrad_split(x, dy, P.grad_of(w), P.grad_of(b), tag)
+                with f:
+                    fold()
                 forks.append(f)
             else:
                 ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))

@@ -85,6 +85,8 @@ _SIGS = {
     "asr_maxpool_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "asr_conv3x3_wgrad_nhwc": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_conv3x3_wgrad_partials": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_conv3x3_wgrad_reduce": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_stft_frames": (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _P]),
     "asr_spect_finish": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_im2col": (_I, [_P, _P] + [_I] * 12 + [_L, _L, _I, _I, _P]),

@@ -765,6 +765,18 @@ def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
 
 
 
+def conv3x3_wgrad_split(x, dy, dw, db, tag):
+    """The same in two launches: partial blocks into a workspace of this layer's own (tag), then the HBM-bound fold -- returned as a
+    closure so that the caller can run it on its second stream next to the data-gradient convolution that follows."""
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3]
+    n_ws = L.load().asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout)
+    ws = workspace("wgrad_ws_" + tag, (n_ws,), torch.float32, x.device)
+    L.call("asr_conv3x3_wgrad_partials", L.ptr(x), L.ptr(dy), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x), L.stream())
+    return lambda: L.call("asr_conv3x3_wgrad_reduce", L.ptr(ws), L.ptr(dw), B, H, W, Cin, Cout, L.stream())
+
+
 # ------------------------------------------------------------------------------------------------ emb_cnn front end
 _ws = {}
 

@@ -939,8 +939,39 @@ extern "C" int64_t asr_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int
   return (int64_t)wgx * by * 9 * 64 * 64;
 }
 
+namespace {
+int conv3x3_wgrad_impl(const void* x, const void* dy, float* dw, float* db, float* workspace, int64_t workspace_floats, int B, int H,
+                       int W, int Cin, int Cout, int dtype, bool reduce, hipStream_t s);
+}
 extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, float* db, float* workspace,
                                       int64_t workspace_floats, int B, int H, int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  return conv3x3_wgrad_impl(x, dy, dw, db, workspace, workspace_floats, B, H, W, Cin, Cout, dtype, true, s);
+}
+// first stage only: the per-workgroup partial dW blocks stay in `workspace` (required) until asr_conv3x3_wgrad_reduce
+extern "C" int asr_conv3x3_wgrad_partials(const void* x, const void* dy, float* db, float* workspace, int64_t workspace_floats, int B,
+                                          int H, int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(workspace && workspace_floats >= asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout));
+  if (asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout) == 0) return ASR_EUNSUPPORTED;
+  return conv3x3_wgrad_impl(x, dy, workspace /* dw is not touched without the reduction */, db, workspace, workspace_floats, B, H, W,
+                            Cin, Cout, dtype, false, s);
+}
+// second stage: dw += the partial blocks of asr_conv3x3_wgrad_partials (same geometry arguments)
+extern "C" int asr_conv3x3_wgrad_reduce(const float* workspace, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t s) {
+  ASR_CHECK_ARG(workspace && dw && B >= 0 && H > 0 && W > 0);
+  if (Cin % 64 != 0 || Cout % 64 != 0) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  int wgx, blocks_y, ppw;
+  wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &ppw);
+  const int slices = wgx >= 32 ? 8 : 1;
+  AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y, (unsigned)slices), dim3(256), 0, s, workspace, dw, wgx,
+                     Cin / 64, Cin);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+namespace {
+int conv3x3_wgrad_impl(const void* x, const void* dy, float* dw, float* db, float* workspace, int64_t workspace_floats, int B, int H,
+                       int W, int Cin, int Cout, int dtype, bool reduce, hipStream_t s) {
   ASR_CHECK_ARG(x && dy && dw && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   if (Cin % 64 != 0 || Cout % 64 != 0 || !aligned16(x) || !aligned16(dy)) return ASR_EUNSUPPORTED;
@@ -973,7 +1004,7 @@ extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, 
   if (dtype == ASR_F32) { allow_big_lds(conv3x3_wgrad_nhwc_kernel<float>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<float>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   else { allow_big_lds(conv3x3_wgrad_nhwc_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<bf16_t>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   ASR_LAUNCH_CHECK();
-  if (p.ws) {
+  if (p.ws && reduce) {
     const int slices = wgx >= 32 ? 8 : 1;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y, (unsigned)slices), dim3(256), 0, s, p.ws, dw, wgx,
                        p.nci, Cin);
@@ -981,3 +1012,4 @@ extern "C" int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw, 
   }
   return ASR_OK;
 }
+}  // namespace

@@ -312,6 +312,12 @@ int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W
 int64_t asr_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout);
 int asr_conv3x3_wgrad_nhwc(const void* x, const void* dy, float* dw_acc, float* db_acc, float* workspace,
                            int64_t workspace_floats, int B, int H, int W, int Cin, int Cout, int dtype, asr_stream_t stream);
+/* The two stages separately: asr_conv3x3_wgrad_partials leaves the per-workgroup partial dW blocks in `workspace` (required; db is
+ * accumulated as usual), asr_conv3x3_wgrad_reduce adds them into dw -- an HBM-bound pass that a caller with a second stream runs
+ * next to the MFMA-bound data-gradient convolution that follows (asr_hip/functions.py: VGGFn.backward).                    */
+int asr_conv3x3_wgrad_partials(const void* x, const void* dy, float* db, float* workspace, int64_t workspace_floats, int B, int H,
+                               int W, int Cin, int Cout, int dtype, asr_stream_t stream);
+int asr_conv3x3_wgrad_reduce(const float* workspace, float* dw, int B, int H, int W, int Cin, int Cout, asr_stream_t stream);
 
 /* ---- emb_cnn front end (reference: models/asr/transformer.py:33-40: Conv2d(1,32,(41,11),(2,2),(0,10)) / BatchNorm2d /
  * Hardtanh(0,20) / Conv2d(32,32,(21,11),(2,1)) / BatchNorm2d / Hardtanh(0,20)), embcnn.hip.  The strided big-window
