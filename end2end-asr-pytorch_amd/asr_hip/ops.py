@@ -759,7 +759,7 @@ def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
     Cout = dy.shape[3]
     assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3]
     n_ws = L.load().asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout)
-    ws = workspace("wgrad_ws", (n_ws,), torch.float32, x.device)      # 75 MB, shared by the three conv layers
+    ws = workspace("wgrad_ws", (n_ws,), torch.float32, x.device, zero=False)      # 75 MB, shared by the three conv layers
     L.call("asr_conv3x3_wgrad_nhwc", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x),
            L.stream())
 
@@ -772,7 +772,7 @@ def conv3x3_wgrad_split(x, dy, dw, db, tag):
     Cout = dy.shape[3]
     assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3]
     n_ws = L.load().asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout)
-    ws = workspace("wgrad_ws_" + tag, (n_ws,), torch.float32, x.device)
+    ws = workspace("wgrad_ws_" + tag, (n_ws,), torch.float32, x.device, zero=False)
     L.call("asr_conv3x3_wgrad_partials", L.ptr(x), L.ptr(dy), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x), L.stream())
     return lambda: L.call("asr_conv3x3_wgrad_reduce", L.ptr(ws), L.ptr(dw), B, H, W, Cin, Cout, L.stream())
 
@@ -781,10 +781,11 @@ def conv3x3_wgrad_split(x, dy, dw, db, tag):
 _ws = {}
 
 
-def workspace(tag, shape, dtype, device):
+def workspace(tag, shape, dtype, device, zero=True):
     """Persistent zero-initialised buffer: kernels rewrite the live region only, padding rows/columns stay zero.
     ONE grow-only allocation per tag (variable-length batches do not leak a buffer per shape): a request that fits is a view
-    of it, re-zeroed only when the shape differs from the previous request (the padding moves)."""
+    of it, re-zeroed only when the shape differs from the previous request (the padding moves).  zero=False: scratch that its
+    user overwrites completely (never re-zeroed: three layers sharing one tag cost three 75 MB fills per step otherwise)."""
     key = (tag, dtype, str(device))
     shape = tuple(int(x) for x in shape)
     n = 1
@@ -795,7 +796,8 @@ def workspace(tag, shape, dtype, device):
         ent = [torch.zeros(n, device=device, dtype=dtype), shape]
         _ws[key] = ent
     elif ent[1] != shape:
-        ent[0][:n].zero_()
+        if zero:
+            ent[0][:n].zero_()
         ent[1] = shape
     return ent[0][:n].view(shape)
 
