@@ -90,8 +90,8 @@ def test_gradients_are_additive_over_the_batch_and_equivariant_under_permutation
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_graph_replay_equals_eager_at_the_benchmark_shape(precision):
-    """One eager + one replayed step against two eager steps from the same start: the same second-step loss (1e-5 relative:
-    a replay on stale weights would move it by 1e-3) and the same second-step gradient over the whole flat buffer -- relative
+    """One eager + one replayed step against two eager steps from the same start: the same second-step loss (1e-4 relative:
+    a replay on stale weights would move it by 1e-3; the two paths sum LayerNorm's parameter gradients in different groupings) and the same second-step gradient over the whole flat buffer -- relative
     L2 <= 1e-3 in fp32 mode and <= 5e-2 in bf16 mode.  The gradient bound is loose on purpose: measured on this shape, two
     IDENTICAL eager runs already differ by 2e-4 (fp32) / 3e-3 (bf16) in their second-step gradient, and the device-side
     optimiser step (1 ulp apart from the host-side one in 0.1 % of the fp32 masters) by 2.5e-2 in bf16: Adam's first step turns
@@ -116,7 +116,7 @@ def test_graph_replay_equals_eager_at_the_benchmark_shape(precision):
         loss.backward()
         g_eager = opt2.optimizer.flat.grad.detach().clone()
         opt2.step()
-    assert abs(float(loss.item()) - loss_graph) <= 1e-5 * abs(loss_graph)
+    assert abs(float(loss.item()) - loss_graph) <= 1e-4 * abs(loss_graph)
     assert _rel(g_graph.double(), g_eager.double()) <= (1e-3 if precision == "fp32" else 5e-2)
     lr = 1e-5                                                        # Noam's floor (min_lr) during the first steps
     for k, v in model2.state_dict().items():
