@@ -77,6 +77,11 @@ def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_d
     if not need_dx:
         _wgrad_bias(dy2d, x2d, wparam, bparam)
         return None
+    W = P.linear_weight(wparam)
+    N, K = wparam.shape[0], wparam.numel() // wparam.shape[0]
+    if W.shape[1] == K and ops.gemm_nn_tn_supported(dy2d, W, x2d):      # graph capture, bf16: dX and dW workgroups in ONE launch
+        return ops.gemm_nn_tn(dy2d, W, x2d, P.grad_of(wparam).view(N, K), P.grad_of(bparam) if bparam is not None else None,
+                              out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
     ops.join_if_pending_reads(dx_out)
     f = ops.fork()
     with f:                                   # dW / db on the second stream, next to dX on this one
@@ -117,6 +122,8 @@ class _Fused:
 
     def bwd(self, dy2d, x2d, dx_out=None, accumulate=False, need_dx=True):
         g = self.w_grad.view(self.N, self.K)
+        if need_dx and ops.gemm_nn_tn_supported(dy2d, self.W, x2d):
+            return ops.gemm_nn_tn(dy2d, self.W, x2d, g, self.b_grad, out=dx_out, accumulate=accumulate)
         ops.join_if_pending_reads(dx_out)
         f = ops.fork() if need_dx else None
         if f is not None:

@@ -35,6 +35,10 @@ _SIGS = {
     "asr_gemm_tn_workspace": (_L, [_I, _I, _I, _I, _I]),
     "asr_gemm_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "asr_gemm_nn": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _I, _I, _I, _P]),
+    "asr_gemm_nn_tn_splits": (_I, [_I, _I]),
+    "asr_gemm_nn_tn_workspace": (_L, [_I, _I, _I, _I]),
+    "asr_gemm_nn_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
+    "asr_tn_reduce_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "asr_cast_flat": (_I, [_P, _P, _L, _I, _P]),
     "asr_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "asr_cast_weight": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
@@ -128,7 +132,7 @@ def load():
 # variables present when the library is loaded are forwarded ONCE through asr_set_tuning(); set_tuning() changes them later.
 TUNING_NAMES = ("ATTN_GENERIC", "IGEMM_TH", "IGEMM_TPS", "IGEMM_WBUF", "CONV1_WGRAD_MFMA", "IGEMM_ABLATE", "C64", "CONV_POOL",
                 "WGRAD_ABLATE", "WGRAD_DMA", "CONV1_WGRAD_WGS", "C64_PER_CU", "C64_ABLATE", "C64_SHAPE", "GEMM_NS", "GEMM_TILE",
-                "GEMM_GENERIC", "TN_WGS", "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG", "TN_PIPE", "TN_PIPE_MIN", "GEMM_ABLATE", "ATTN_SHORT", "ATTN_SHORT_BWD")
+                "GEMM_GENERIC", "TN_WGS", "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG", "TN_PIPE", "TN_PIPE_MIN", "GEMM_ABLATE", "ATTN_SHORT", "ATTN_SHORT_BWD", "ATTN_BOTH", "NNTN_STAGES")
 
 
 def _forward_env_tuning(lib):

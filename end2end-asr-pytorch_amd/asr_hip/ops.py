@@ -120,6 +120,7 @@ def join_deferred():
         torch.cuda.current_stream().wait_stream(_side["stream"])
     _side["pending"] = []
     flush_ln_reduces()
+    flush_tn_reduces()
 
 
 # ------------------------------------------------------------------------------------------------ dense
@@ -182,6 +183,58 @@ def gemm_nn(dy, w, out=None, accumulate=False, relu_mask=None, alpha=1.0):
     L.call("asr_gemm_nn", L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(out), out.stride(0), L.ptr(relu_mask), M, K, N,
            float(alpha), L.GEMM_ACCUMULATE if accumulate else 0, L.dt(dy), L.dt(out), L.stream())
     return out
+
+
+_nn_tn = os.environ.get("ASR_NN_TN", "1") != "0"
+# larger weights keep the two-stream pair: their 128 x 128-tile weight-gradient kernel moves half the operand bytes per flop, which
+# is worth more than the fork / join it costs (512 x 5120 over 6400 rows: 112 us as a pair, 141 us as one launch)
+_nn_tn_max = int(os.environ.get("ASR_NN_TN_MAX", str(1 << 21)))
+_tn_fold_next = os.environ.get("ASR_TN_FOLD_NEXT", "1") != "0"
+_tn_pending = []
+
+
+def gemm_nn_tn_supported(dy, w, x):
+    """True when a linear layer's dX and dW can be ONE launch (asr_gemm_nn_tn): bf16, inside a graph capture (the weight
+    gradient is then complete only after flush_tn_reduces(), which join_deferred() issues at the end of backward)."""
+    return (_nn_tn and dy.dtype == torch.bfloat16 and torch.cuda.is_current_stream_capturing() and gemm_nn_supported(dy, w) and
+            gemm_tn_supported(dy, x) and w.shape[0] % 64 == 0 and x.dtype == dy.dtype and w.shape[0] * w.shape[1] <= _nn_tn_max)
+
+
+def gemm_nn_tn(dy, w, x, dw, db=None, out=None, accumulate=False, relu_mask=None):
+    """out (M,K) (+)= dy[:, :N] @ w (N,K) and, in the same launch, the partial sums of dw (N,K) fp32 += dy^T @ x[:, :K] (folded
+    into dw by flush_tn_reduces()) and db (N) += column sums of dy."""
+    M, (N, K) = dy.shape[0], w.shape
+    if out is None:
+        out = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+        assert not accumulate
+    assert out.shape == (M, K) and out.stride(1) == 1 and out.dtype == dy.dtype
+    assert dw.dtype == torch.float32 and dw.stride(1) == 1 and dw.shape == (N, K) and x.shape[0] == M and x.shape[1] >= K
+    if relu_mask is not None:
+        assert relu_mask.dtype == dy.dtype and relu_mask.stride(0) == out.stride(0)
+    lib = L.load()
+    n_ws = lib.asr_gemm_nn_tn_workspace(M, N, K, 0)
+    ws = torch.empty(n_ws, device=dy.device, dtype=torch.float32)       # stays referenced until it has been folded
+    # the previous layer's partial tiles are folded by extra workgroups of THIS launch (same stream: they are complete)
+    prev = _tn_pending.pop() if (_tn_fold_next and _tn_pending) else None
+    fold = (L.ptr(prev[0]), L.ptr(prev[1]), prev[1].stride(0), prev[2], prev[3], prev[4]) if prev else (None, None, 0, 0, 0, 0)
+    L.call("asr_gemm_nn_tn", L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(x), x.stride(0), L.ptr(out), out.stride(0),
+           L.ptr(relu_mask), L.ptr(db), L.ptr(ws), n_ws, M, N, K, L.GEMM_ACCUMULATE if accumulate else 0, 0, L.dt(dy), *fold,
+           L.stream())
+    _tn_pending.append((ws, dw, N, K, lib.asr_gemm_nn_tn_splits(M, 0)))
+    return out
+
+
+def flush_tn_reduces():
+    """Second stage of every gemm_nn_tn() issued since the last flush: one launch (per 48 layers) folds all partial tiles."""
+    import ctypes
+    if not _tn_pending:
+        return
+    n = len(_tn_pending)
+    P_, I_, L_ = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+    L.call("asr_tn_reduce_multi", P_(*[e[0].data_ptr() for e in _tn_pending]), P_(*[e[1].data_ptr() for e in _tn_pending]),
+           L_(*[e[1].stride(0) for e in _tn_pending]), I_(*[e[2] for e in _tn_pending]), I_(*[e[3] for e in _tn_pending]),
+           I_(*[e[4] for e in _tn_pending]), n, L.stream())
+    del _tn_pending[:]
 
 
 def cast_flat(src, dst):
@@ -344,7 +397,7 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
                L.dt(q), L.stream())
 
     f = fork()
-    if f.on and os.environ.get('ASR_ATTN_SPLIT', '1') != '0':   # inside a captured graph: dK/dV on the second stream next to dQ (both only need delta)
+    if f.on and os.environ.get('ASR_ATTN_SPLIT', '0') == '1':   # (A/B) dK/dV on the second stream next to dQ: the default is ONE launch for both
         launch(L.ATTN_DELTA)
         with f:
             launch(L.ATTN_DKV)

@@ -44,10 +44,11 @@ __device__ __forceinline__ float group_sum4(float v) {
 }
 
 // XCD-aware linear workgroup id: consecutive ids run on the same XCD (hardware deals blockIdx round-robin over 8 XCDs)
-__device__ __forceinline__ int xcd_linear_id() {
-  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+__device__ __forceinline__ int xcd_linear_id(int bid, int nwg) {
+  const int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
   return (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
 }
+__device__ __forceinline__ int xcd_linear_id() { return xcd_linear_id((int)blockIdx.x, (int)gridDim.x); }
 
 // 64 rows x 128 B of a (rows, 64) bf16 slice -> LDS, chunk c of row r stored at slot c ^ (r & 7).  Rows past `nrows`
 // re-read the last valid row (the LDS-DMA cannot zero-fill; such rows are masked / never stored by the callers).
@@ -272,13 +273,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
 // NQ as in the forward kernel: 16 NQ queries per wave.  In the two backward kernels 16-row waves win at every length (measured:
 // (32, 8, 800, 800) p = 0.1 backward 324 -> 301 us, (16, 8, 795, 795) 185 -> 166 us; the forward loses 4 - 9 % there), so they are the default.
 template <int NQ>
-__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
+__device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vid, unsigned char* smem) {
   constexpr int FQW = 64 * NQ;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nqb = (p.Tq + FQW - 1) / FQW;
-  const int vid = xcd_linear_id();
   const int bh = vid / nqb, qb = vid - bh * nqb;
   const int b = bh / p.H, h = bh - b * p.H;
   const int qw = qb * FQW + wave * 16 * NQ;
@@ -409,14 +408,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
 //   dV^T[d][key] += dO^T[d][q] Pd[q][key],  dK^T[d][key] += Q^T[d][q] dS[q][key]   (A: transposing reads of dO / Q tiles)
 // NK: 16 NK keys per wave (NK = 1 for Tk <= 256, as in the other two kernels).
 template <int NK>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) {
-  constexpr int FKW = 64 * NK;                               // keys per workgroup
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
-  __shared__ float s_stat[2][2][64];                                              // [buffer][lse*log2e | delta][q]
+__device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int vid, unsigned char* smem, float (*s_stat)[2][64]) {
+  constexpr int FKW = 64 * NK;                               // keys per workgroup;  s_stat: [buffer][lse*log2e | delta][q]
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nkb = (p.Tk + FKW - 1) / FKW;
-  const int vid = xcd_linear_id();
   const int bh = vid / nkb, kb = vid - bh * nkb;
   const int b = bh / p.H, h = bh - b * p.H;
   const int kw = kb * FKW + wave * 16 * NK;                 // first key of this wave
@@ -571,6 +567,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
   }
 }
 
+template <int NQ>
+__global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  attn_bwd_dq_body<NQ>(p, xcd_linear_id(), smem);
+}
+template <int NK>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  __shared__ float s_stat[2][2][64];
+  attn_bwd_dkv_body<NK>(p, xcd_linear_id(), smem, s_stat);
+}
+// Both halves of the backward in ONE launch: the first n_dq workgroups are dQ workgroups, the others dK / dV workgroups (they are
+// independent; both only need delta).  Two launches on two streams cost a fork and a join -- 0.16 ms of idle time per step over the
+// 12 attention blocks of the benchmark model -- for the same overlap.
+template <int N>
+__global__ __launch_bounds__(256) void attn_bwd_both_bf16_d64_kernel(AttnArgs p, int n_dq) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+  __shared__ float s_stat[2][2][64];
+  const int bid = (int)blockIdx.x;
+  if (bid < n_dq) attn_bwd_dq_body<N>(p, xcd_linear_id(bid, n_dq), smem);
+  else attn_bwd_dkv_body<N>(p, xcd_linear_id(bid - n_dq, (int)gridDim.x - n_dq), smem, s_stat);
+}
+
 __global__ __launch_bounds__(256) void attn_delta_bf16_d64_kernel(AttnArgs p) {
   // delta[b,h,q] = sum_d dO * O : one 8-lane group per row (8 x 16 B = one 128-byte head row)
   const int64_t idx = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
@@ -625,6 +644,17 @@ int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   if (p.parts & ASR_ATTN_DELTA) {
     attn_delta_bf16_d64_kernel<<<dim3((unsigned)ceil_div64(rows, 32)), dim3(256), 0, s>>>(p);
     ASR_LAUNCH_CHECK();
+  }
+  if ((p.parts & ASR_ATTN_DQ) && (p.parts & ASR_ATTN_DKV) && asr_tuning("ATTN_BOTH", 1) != 0) {
+    const bool short_q = p.Tq <= asr_tuning("ATTN_SHORT_BWD", 1 << 30), short_k = p.Tk <= asr_tuning("ATTN_SHORT_BWD", 1 << 30);
+    if (short_q == short_k) {
+      const int rows = short_q ? 64 : FQ;
+      const int n_dq = ((p.Tq + rows - 1) / rows) * p.B * p.H, n_dkv = ((p.Tk + rows - 1) / rows) * p.B * p.H;
+      if (short_q) attn_bwd_both_bf16_d64_kernel<1><<<dim3((unsigned)(n_dq + n_dkv)), dim3(256), 0, s>>>(p, n_dq);
+      else attn_bwd_both_bf16_d64_kernel<2><<<dim3((unsigned)(n_dq + n_dkv)), dim3(256), 0, s>>>(p, n_dq);
+      ASR_LAUNCH_CHECK();
+      return ASR_OK;
+    }
   }
   if (p.parts & ASR_ATTN_DQ) {
     if (p.Tq <= asr_tuning("ATTN_SHORT_BWD", 1 << 30))

@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(256) void tn128_reduce_kernel(const float* __restri
 // contraction index as W's slow axis, so the B operand is built with the transposing LDS read (bf16) / 4-byte reads (fp32)
 // exactly like gemm_tn -- no transposed weight shadows.  A staging, pipeline and epilogue are those of gemm_glds (BN = 64).
 template <typename T, typename TO, int BM>
-__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
+__device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, const int nwg, unsigned char* smem) {
   using P = TnPack<T>;
   constexpr int ESZ = (int)sizeof(T);
   constexpr int BN = 64, BKB = 128;
@@ -1025,11 +1025,10 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
   constexpr int STAGE = BM * BKB + BKR * P::ROWB;
   constexpr int CPITCH = BN * 4 + 16;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1, lr = lane & 15, g = lane >> 4;
-  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
   const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
   const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
@@ -1191,6 +1190,185 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
         if (e < nvalid) store_out<TO>(dst + e, v[e], p.accumulate, 0);
     }
   }
+}
+
+template <typename T, typename TO, int BM>
+__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  gemm_nn_body<T, TO, BM>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+// ------------------------------------------------------------------------------------------------ TN on quadrant waves (bf16)
+// The weight-gradient contraction again, with the FOOTPRINT of the data-gradient kernel (64 x 64 tile of dW, waves in a 2 x 2
+// grid of 32 x 32 quadrants, every wave contracts every row of a 64-row stage: 16 accumulator registers, one 16 KB LDS stage,
+// no cross-wave reduction) so that both can be workgroups of ONE launch (gemm_nn_tnq_kernel below): a layer's dX and dW used to
+// be two launches on two streams, and every fork / join of a replayed graph is a 5-10 us hole on the main stream (88 of them
+// per step).  Partial tiles go to the workspace [split][tile][64][64]; asr_tn_reduce_multi folds all layers at once.
+__device__ __forceinline__ void gemm_tnq_body(const TnArgs& p, const int bid, const int nwg, unsigned char* smem) {
+  using P = TnPack<bf16_t>;
+  constexpr int RM = 64, TILEB = RM * P::ROWB;                    // 8 KB per operand
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int split = wid / p.ntiles, tile = wid % p.ntiles;
+  const int n0 = (tile / p.tiles_k) * 64, k0 = (tile % p.tiles_k) * 64;
+  const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+  const int nstage = (m_end - m_beg + RM - 1) / RM;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * 2 / 16);
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(&tn_zero_page);
+
+  unsigned offA[2], offB[2];
+  int rowi[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 256 + tid, row = c >> 3, slot = (c & 7) ^ (row & 7);
+    int ca = n0 * 2 / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;       // columns past N / K are never stored
+    int cb = k0 * 2 / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+    offA[i] = (unsigned)(row * (int)p.lda * 2 + ca * 16);
+    offB[i] = (unsigned)(row * (int)p.ldb * 2 + cb * 16);
+    rowi[i] = row;
+  }
+
+  f32x4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const bool do_colsum = p.colsum != nullptr && k0 == 0 && wk == 0;
+
+  for (int st = 0; st < nstage; ++st) {
+    if (st > 0) __syncthreads();                 // everybody is done reading stage st-1
+    const int64_t mrow = m_beg + (int64_t)st * RM;
+    const unsigned char* ba = A + mrow * p.lda * 2;
+    const unsigned char* bb = B + mrow * p.ldb * 2;
+    const int valid = m_end - (int)mrow;         // rows of this stage that exist (uniform); the others come from a page of zeros
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool in = rowi[i] < valid;
+      unsigned char* d = smem + (i * 256 + wave * 64) * 16;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in ? ba + offA[i] : zero),
+                                       (__attribute__((address_space(3))) void*)d, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(in ? bb + offB[i] : zero),
+                                       (__attribute__((address_space(3))) void*)(d + TILEB), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned char* sA = smem;
+    const unsigned char* sB = smem + TILEB;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      uint4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = P::load(sA, ms * 32, lr, g, wn * 32 + i * 16);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = P::load(sB, ms * 32, lr, g, wk * 32 + j * 16);
+      if (do_colsum) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          Chunk<bf16_t> c; c.v = a[i];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16<bf16_t>(acc[i][j], a[i], b[j]);
+    }
+  }
+
+  // ---- the wave's 32 x 32 quadrant: lane (lr, g) holds rows 4g..4g+3 of column lr of every fragment
+  const bool single = nwg == p.ntiles;
+  float* part = p.ws ? p.ws + ((int64_t)split * p.ntiles + tile) * 4096 : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wn * 32 + i * 16 + g * 4 + r, gn = n0 + row;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = wk * 32 + j * 16 + lr, gk = k0 + col;
+        const float v = acc[i][j][r];
+        if (part) part[row * 64 + col] = v;
+        else if (gn < p.N && gk < p.K) {
+          float* dst = p.C + (int64_t)gn * p.ldc + gk;
+          if (single) *dst += v; else atomicAdd(dst, v);
+        }
+      }
+    }
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int gn = n0 + wn * 32 + i * 16 + lr;
+      if (g == 0 && gn < p.N) atomicAdd(p.colsum + gn, v);
+    }
+  }
+}
+
+// C tile += the m-slices of its partial tiles [split][tile][64][64]: one workgroup folds a quarter tile (fixed order).
+__device__ __forceinline__ void tn_fold_block(const float* __restrict__ ws, float* C, const int64_t ldc, const int N, const int K,
+                                              const int splits, const int bid) {
+  const int tiles_k = (K + 63) / 64, ntiles = ((N + 63) / 64) * tiles_k;
+  const int tile = bid >> 2;
+  if (tile >= ntiles) return;
+  const int e = ((bid & 3) * 256 + threadIdx.x) * 4;               // 4 consecutive columns of one row of the tile
+  const int row = e >> 6, col = e & 63;
+  const int gn = (tile / tiles_k) * 64 + row, gk = (tile % tiles_k) * 64 + col;
+  if (gn >= N || gk >= K) return;
+  const float* src = ws + (int64_t)tile * 4096 + e;
+  const int64_t step = (int64_t)ntiles * 4096;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int sp = 0; sp < splits; ++sp) {
+    const float4 t = *reinterpret_cast<const float4*>(src + sp * step);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  float* dst = C + (int64_t)gn * ldc + gk;
+  if (gk + 3 < K && ((((uintptr_t)dst) & 15) == 0)) {
+    float4 o = *reinterpret_cast<float4*>(dst);
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *reinterpret_cast<float4*>(dst) = o;
+  } else {
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (gk + i < K) dst[i] += vv[i];
+  }
+}
+
+// dX workgroups and dW workgroups of one linear layer in ONE launch: the first n_tn workgroups are the (longer) weight-gradient
+// tiles, then the n_nn data-gradient tiles, then -- software pipelining across launches -- the workgroups that fold the partial
+// tiles the PREVIOUS layer's launch left behind (HBM-bound, they ride under the MFMA-bound tiles of this one).
+struct TnFoldArgs {
+  const float* ws; float* C; int64_t ldc; int N, K, splits;
+};
+template <int BM>
+__global__ __launch_bounds__(256) void gemm_nn_tnq_kernel(GemmArgs pn, TnArgs pt, TnFoldArgs pf, int n_tn, int n_nn) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int bid = (int)blockIdx.x;
+  if (bid < n_tn) gemm_tnq_body(pt, bid, n_tn, smem);
+  else if (bid < n_tn + n_nn) gemm_nn_body<bf16_t, bf16_t, BM>(pn, bid - n_tn, n_nn, smem);
+  else tn_fold_block(pf.ws, pf.C, pf.ldc, pf.N, pf.K, pf.splits, bid - n_tn - n_nn);
+}
+
+// Second stage for up to TN_MULTI layers in one launch (blockIdx.y = layer).
+constexpr int TN_MULTI = 48;
+struct TnMultiArgs {
+  const float* ws[TN_MULTI];
+  float* C[TN_MULTI];
+  int ldc[TN_MULTI], N[TN_MULTI], K[TN_MULTI], splits[TN_MULTI];
+};
+__global__ __launch_bounds__(256) void tn_reduce_multi_kernel(TnMultiArgs q) {
+  const int l = blockIdx.y;
+  tn_fold_block(q.ws[l], q.C[l], q.ldc[l], q.N[l], q.K[l], q.splits[l], (int)blockIdx.x);
 }
 
 template <typename T, typename TO, int BM>
@@ -1469,4 +1647,95 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   if (in_dtype == ASR_F32) return big ? launch_nn<float, float, 128>(p, stream) : launch_nn<float, float, 64>(p, stream);
   if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);
   return big ? launch_nn<bf16_t, float, 128>(p, stream) : launch_nn<bf16_t, float, 64>(p, stream);
+}
+
+// ---- one launch for a linear layer's backward: dx (M,K) (+)= dy (M,N) . w (N,K) [ReLU mask]  AND  the partial sums of
+// dw (N,K) += dy^T . x (M,K), db (N) += column sums of dy.  bf16 operands.  splits = 0: chosen here.
+static int nn_tn_splits(int M, int splits, int* m_per_split) {
+  const int stages = (M + 63) / 64;
+  if (splits <= 0) {
+    const int per = (int)asr_tuning("NNTN_STAGES", 16);           // 64-row stages of one weight-gradient workgroup
+    splits = (stages + per - 1) / (per > 0 ? per : 16);
+  }
+  splits = splits < 1 ? 1 : (splits > stages ? stages : splits);
+  const int mps = ((stages + splits - 1) / splits) * 64;
+  if (m_per_split) *m_per_split = mps;
+  return (M + mps - 1) / mps;                                      // no empty slice
+}
+
+extern "C" int asr_gemm_nn_tn_splits(int M, int splits) { return M > 0 ? nn_tn_splits(M, splits, nullptr) : 0; }
+
+extern "C" int64_t asr_gemm_nn_tn_workspace(int M, int N, int K, int splits) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (int64_t)nn_tn_splits(M, splits, nullptr) * ((N + 63) / 64) * ((K + 63) / 64) * 4096;
+}
+
+extern "C" int asr_gemm_nn_tn(const void* dy, int64_t ld_dy, const void* w, int64_t ldw, const void* x, int64_t ldx, void* dx,
+                              int64_t ld_dx, const void* relu_mask, float* db, float* workspace, int64_t workspace_floats, int M,
+                              int N, int K, int flags, int splits, int dtype, const float* fold_ws, float* fold_dw,
+                              int64_t fold_ld, int fold_N, int fold_K, int fold_splits, hipStream_t stream) {
+  ASR_CHECK_ARG(dy && w && x && dx && workspace && M > 0 && N > 0 && K > 0);
+  if (dtype != ASR_BF16) return ASR_EUNSUPPORTED;
+  if (N % 64 != 0 || ld_dy % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0 || !aligned16(dy) || !aligned16(w) || !aligned16(x) || ldw < K ||
+      ld_dy < N || ld_dy >= ((int64_t)1 << 22) || ldx >= ((int64_t)1 << 22))
+    return ASR_EUNSUPPORTED;
+  int m_per_split = 0;
+  splits = nn_tn_splits(M, splits, &m_per_split);
+  TnArgs t{};
+  t.A = dy; t.B = x; t.C = nullptr; t.colsum = db; t.ws = workspace;
+  t.lda = ld_dy; t.ldb = ldx; t.ldc = 0;
+  t.M = M; t.N = N; t.K = K;
+  t.tiles_k = (K + 63) / 64;
+  t.ntiles = ((N + 63) / 64) * t.tiles_k;
+  t.m_per_split = m_per_split;
+  if (workspace_floats < (int64_t)splits * t.ntiles * 4096) return ASR_EINVAL;
+  GemmArgs p{};
+  p.A = dy; p.B = w; p.C = dx; p.mask = relu_mask;
+  p.lda = ld_dy; p.ldb = ldw; p.ldc = ld_dx;
+  p.M = M; p.N = K; p.K = N; p.alpha = 1.f;
+  p.accumulate = (flags & ASR_GEMM_ACCUMULATE) != 0;
+  p.vecC = ((((uintptr_t)dx) & 15) == 0) && (ld_dx % 4 == 0);
+  p.tiles_n = (K + 63) / 64;
+  const int64_t t64 = ceil_div64(M, 64) * p.tiles_n;
+  const bool big = t64 >= asr_tuning("NN_BIG", 800) && M > 64;
+  const int bm = big ? 128 : 64;
+  p.ntiles = ((M + bm - 1) / bm) * p.tiles_n;
+  const int n_tn = t.ntiles * splits;
+  size_t lds = (size_t)(bm * 128 + 64 * 128);
+  const size_t cl = (size_t)bm * (64 * 4 + 16);
+  if (cl > lds) lds = cl;
+  AsrProfScope prof(ASR_OP_GEMM, stream);
+  TnFoldArgs f{};
+  int n_fold = 0;
+  if (fold_ws) {
+    ASR_CHECK_ARG(fold_dw && fold_N > 0 && fold_K > 0 && fold_splits > 0);
+    f.ws = fold_ws; f.C = fold_dw; f.ldc = fold_ld; f.N = fold_N; f.K = fold_K; f.splits = fold_splits;
+    n_fold = ((fold_N + 63) / 64) * ((fold_K + 63) / 64) * 4;
+  }
+  const dim3 grid((unsigned)(n_tn + p.ntiles + n_fold));
+  if (big) hipLaunchKernelGGL(gemm_nn_tnq_kernel<128>, grid, dim3(256), lds, stream, p, t, f, n_tn, p.ntiles);
+  else hipLaunchKernelGGL(gemm_nn_tnq_kernel<64>, grid, dim3(256), lds, stream, p, t, f, n_tn, p.ntiles);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_tn_reduce_multi(const float* const* workspaces, float* const* dw, const int64_t* ld_dw, const int* N, const int* K,
+                                   const int* splits, int count, hipStream_t stream) {
+  ASR_CHECK_ARG(count >= 0 && (count == 0 || (workspaces && dw && ld_dw && N && K && splits)));
+  for (int base = 0; base < count; base += TN_MULTI) {
+    const int n = count - base < TN_MULTI ? count - base : TN_MULTI;
+    TnMultiArgs q{};
+    int max_tiles = 0;
+    for (int i = 0; i < n; ++i) {
+      ASR_CHECK_ARG(workspaces[base + i] && dw[base + i] && N[base + i] > 0 && K[base + i] > 0 && splits[base + i] > 0);
+      q.ws[i] = workspaces[base + i]; q.C[i] = dw[base + i]; q.ldc[i] = (int)ld_dw[base + i];
+      q.N[i] = N[base + i]; q.K[i] = K[base + i]; q.splits[i] = splits[base + i];
+      const int nt = ((q.N[i] + 63) / 64) * ((q.K[i] + 63) / 64);
+      if (nt > max_tiles) max_tiles = nt;
+    }
+    AsrProfScope prof(ASR_OP_GEMM, stream);
+    hipLaunchKernelGGL(tn_reduce_multi_kernel, dim3((unsigned)(max_tiles * 4), (unsigned)n), dim3(256), 0, stream, q);
+    ASR_LAUNCH_CHECK();
+  }
+  return ASR_OK;
 }

@@ -81,6 +81,25 @@ int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C
  * multiple of 64 (bf16) / 32 (fp32) and 16-byte aligned rows, else ASR_EUNSUPPORTED.                              */
 int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask, int M,
                 int N, int K, float alpha, int flags, int in_dtype, int out_dtype, asr_stream_t stream);
+/* A linear layer's whole backward in ONE launch (every nn.Linear / Conv1d(k=1) of models/common_layers.py:136-142,181-197 under
+ * autograd): dx (M,K) (+)= dy (M,N) . w (N,K) [flags: ASR_GEMM_ACCUMULATE; relu_mask as in asr_gemm_nt] from the data-gradient
+ * workgroups of asr_gemm_nn, and next to them in the same grid the weight-gradient workgroups: the partial 64 x 64 tiles of
+ * dy^T . x over `splits` slices of the M rows go to workspace [split][tile][64][64] (asr_gemm_nn_tn_workspace floats), the bias
+ * gradient db (N, may be NULL) += column sums of dy.  asr_tn_reduce_multi then folds the slices of up to any number of layers
+ * into their dw (N,K; fp32; += semantics) in one launch per 48 layers, slices added in a fixed order.  Two launches on two streams
+ * cost a fork and a join (5-10 us each on the critical path of a replayed graph) per layer.  bf16 only; N a multiple of 64 and
+ * 16-byte aligned rows, else ASR_EUNSUPPORTED.  splits = 0: chosen by the library (asr_gemm_nn_tn_splits tells the number).
+ * fold_ws != NULL: extra workgroups of the same launch fold the partial tiles an EARLIER asr_gemm_nn_tn call on this stream left
+ * in fold_ws into fold_dw (fold_N x fold_K, row stride fold_ld, fold_splits slices) -- the HBM-bound second stage of layer i
+ * rides under the MFMA-bound tiles of layer i+1 instead of being a launch of its own.                                         */
+int asr_gemm_nn_tn_splits(int M, int splits);
+int64_t asr_gemm_nn_tn_workspace(int M, int N, int K, int splits);
+int asr_gemm_nn_tn(const void* dy, int64_t ld_dy, const void* w, int64_t ldw, const void* x, int64_t ldx, void* dx, int64_t ld_dx,
+                   const void* relu_mask, float* db, float* workspace, int64_t workspace_floats, int M, int N, int K, int flags,
+                   int splits, int dtype, const float* fold_ws, float* fold_dw, int64_t fold_ld, int fold_N, int fold_K,
+                   int fold_splits, asr_stream_t stream);
+int asr_tn_reduce_multi(const float* const* workspaces, float* const* dw, const int64_t* ld_dw, const int* N, const int* K,
+                        const int* splits, int count, asr_stream_t stream);
 /* dst[i] = (dtype) src[i] : the one-launch refresh of the flat compute-dtype weight shadow after an optimiser step  */
 int asr_cast_flat(const float* src, void* dst, int64_t n, int dtype, asr_stream_t stream);
 

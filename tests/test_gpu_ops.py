@@ -137,6 +137,44 @@ def test_gemm_nn_data_gradient(ops, dtype, shape):
     close("nn relu mask", out, (dy @ w) * (mask > 0), dtype)
 
 
+@pytest.mark.parametrize("shape", [(6400, 512, 512), (3200, 512, 2048), (3200, 2048, 512), (200, 64, 64), (130, 192, 72),
+                                   (37, 64, 200), (1000, 1536, 512)])
+def test_gemm_nn_tn_one_launch(ops, shape):
+    """A linear layer's dX and dW from ONE launch (asr_gemm_nn_tn) + the multi-layer fold (asr_tn_reduce_multi): dX bit-identical
+    to asr_gemm_nn (the same workgroup code), dW / db against fp32 torch and against asr_gemm_tn."""
+    M, N, K = shape
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N + K)
+    D = dev()
+    ldx = (K + 7) // 8 * 8
+    dy = q(torch.randn(M, N, generator=g), dtype)
+    w = q(torch.randn(N, K, generator=g) / math.sqrt(N), dtype)
+    x = torch.zeros(M, ldx); x[:, :K] = q(torch.randn(M, K, generator=g), dtype)
+    dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    dyd, wd, xd = dy.to(D, dtype), w.to(D, dtype), x.to(D, dtype)
+    ref_dw = dw0 + dy.t() @ x[:, :K]
+    # two "layers" pending at once: plain store, and accumulate + ReLU mask
+    dw_a, db_a = dw0.clone().to(D), db0.clone().to(D)
+    out_a = ops.gemm_nn_tn(dyd, wd, xd, dw_a, db_a)
+    base, mask = q(torch.randn(M, K, generator=g), dtype), q(torch.randn(M, K, generator=g), dtype)
+    dw_b = dw0.clone().to(D)
+    out_b = base.to(D, dtype)
+    ops.gemm_nn_tn(dyd, wd, xd, dw_b, None, out=out_b, accumulate=True, relu_mask=mask.to(D, dtype))
+    assert torch.equal(dw_b.cpu(), dw0)                       # the second layer's slices are still pending ...
+    assert len(ops._tn_pending) == 1                           # ... the first layer's were folded by the second launch
+    ops.flush_tn_reduces()
+    assert torch.equal(out_a, ops.gemm_nn(dyd, wd))
+    chk = base.to(D, dtype)
+    ops.gemm_nn(dyd, wd, out=chk, accumulate=True, relu_mask=mask.to(D, dtype))
+    assert torch.equal(out_b, chk)
+    close("nn_tn dW", dw_a, ref_dw, dtype, scale=0.2)
+    assert torch.equal(dw_a, dw_b)                            # fixed summation order: reproducible
+    close("nn_tn db", db_a, db0 + dy.sum(0), torch.float32, scale=8)
+    dw_c = dw0.clone().to(D)
+    ops.gemm_tn(dyd, xd, dw_c, N=N, K=K)
+    close("nn_tn dW vs gemm_tn", dw_a, dw_c.cpu(), torch.float32, scale=64)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_cast_colsum(ops, dtype):
     g = torch.Generator().manual_seed(3)

@@ -66,3 +66,12 @@ for n, v in sorted(exposed.items(), key=lambda kv: -kv[1])[:32]:
 print("idle gaps by preceding kernel (ms/step):")
 for n, v in sorted(gap_after.items(), key=lambda kv: -kv[1])[:16]:
     print("  %8.3f  %s" % (v / 1e6 / nsteps, clean(n)))
+# the launch sequence of the last complete step: start offset, duration, gap since the latest end of anything before it
+lo2 = marks[-2]
+seq = rows[lo2:marks[-1]]
+print("sequence of the last step (t_us, dur_us, idle_before_us, name):")
+base = seq[0][1]
+latest = seq[0][1]
+for n, s, e in seq:
+    print("  %9.1f %7.1f %6.1f  %s" % ((s - base) / 1e3, (e - s) / 1e3, max(0.0, (s - latest) / 1e3), clean(n)[:70]))
+    latest = max(latest, e)
