@@ -711,17 +711,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_nhwc_kernel(WgradNArgs p
 }
 
 // dW[co0+co][ci0+ci][t] += sum over this slice of the workgroup partials ws[by][wg][t][co][ci]
+// No atomics (1.2 M same-line fp32 atomics were most of this kernel's time: 8 slices x 147 K elements x 4 blocks at the ~40 / ns the
+// chip sustains) and a fixed summation order: a workgroup owns 256 consecutive elements, its four waves each add a quarter of the
+// partial blocks with 16-byte loads (eight in flight), the quarters meet in LDS and wave 0 does the plain dw += .
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* dw, int wgx, int nci, int Cin) {
-  const int e = blockIdx.x * 256 + threadIdx.x;          // element of the 9 x 64 x 64 block: (t, co, ci), ci fastest
-  const int by = blockIdx.y, slices = gridDim.z, sl = blockIdx.z;
-  const int per = (wgx + slices - 1) / slices;
-  const int w0 = sl * per, w1 = min(wgx, w0 + per);
+  __shared__ float4 red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int e = (blockIdx.x * 64 + col) * 4;             // 4 elements of the 9 x 64 x 64 block: (t, co, ci .. ci+3), ci fastest
+  const int by = blockIdx.y;
+  const int per = (wgx + 3) / 4;
+  const int w0 = grp * per, w1 = min(wgx, w0 + per);
   const float* src = ws + ((int64_t)by * wgx) * (9 * 64 * 64) + e;
-  float acc = 0.f;
-  for (int w = w0; w < w1; ++w) acc += src[(int64_t)w * (9 * 64 * 64)];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+  for (int w = w0; w < w1; ++w) {
+    const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)w * (9 * 64 * 64));
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[grp][col] = acc;
+  __syncthreads();
+  if (grp != 0) return;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const float4 v = red[k][col];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
   const int ci = e & 63, co = (e >> 6) & 63, t = e >> 12;
   const int co0 = (by / nci) * 64, ci0 = (by % nci) * 64;
-  atomicAdd(dw + ((int64_t)(co0 + co) * Cin + ci0 + ci) * 9 + t, acc);
+  float* dst = dw + ((int64_t)(co0 + co) * Cin + ci0 + ci) * 9 + t;
+  dst[0] += acc.x; dst[9] += acc.y; dst[18] += acc.z; dst[27] += acc.w;
 }
 
 // once per kernel instantiation (never during a stream capture: the first eager/warm-up launch does it)
@@ -962,9 +980,8 @@ extern "C" int asr_conv3x3_wgrad_reduce(const float* workspace, float* dw, int B
   if (B == 0) return ASR_OK;
   int wgx, blocks_y, ppw;
   wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &ppw);
-  const int slices = wgx >= 32 ? 8 : 1;
   AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y, (unsigned)slices), dim3(256), 0, s, workspace, dw, wgx,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y), dim3(256), 0, s, workspace, dw, wgx,
                      Cin / 64, Cin);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -1005,8 +1022,7 @@ int conv3x3_wgrad_impl(const void* x, const void* dy, float* dw, float* db, floa
   else { allow_big_lds(conv3x3_wgrad_nhwc_kernel<bf16_t>, lds); hipLaunchKernelGGL((conv3x3_wgrad_nhwc_kernel<bf16_t>), dim3((unsigned)wgx, (unsigned)blocks_y), dim3(256), lds, s, p); }
   ASR_LAUNCH_CHECK();
   if (p.ws && reduce) {
-    const int slices = wgx >= 32 ? 8 : 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y, (unsigned)slices), dim3(256), 0, s, p.ws, dw, wgx,
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y), dim3(256), 0, s, p.ws, dw, wgx,
                        p.nci, Cin);
     ASR_LAUNCH_CHECK();
   }
