@@ -37,21 +37,23 @@ def _wgrad_bias(dy2d, x2d, wparam, bparam):
 
 
 def _as_compute(dy2d):
-    """(M,N) gradient in any float dtype -> (M,Np) zero padded copy in the compute dtype (contiguous rows)."""
+    """(M,N) gradient in any float dtype -> (M,Np) zero padded copy in the compute dtype (contiguous rows).  Np = N rounded up
+    to 64: the data-gradient kernel contracts N in stages of 64 and relies on the zero columns (vocabulary projection: 4364)."""
     cd = ops.compute_dtype()
     if dy2d.dtype == torch.float32 and cd != torch.float32:
-        return ops.cast_and_transpose(dy2d, cd, want_t=False)[0]
+        return ops.cast_and_transpose(dy2d, cd, want_t=False, pad=64)[0]
     if dy2d.dtype != cd:
         dy2d = dy2d.to(cd)
-    return _pad_cols(dy2d)
+    return _pad_cols(dy2d, 64)
 
 
-def _pad_cols(x2d):
+def _pad_cols(x2d, pad=8):
     """(M,K) -> itself if rows are contiguous and K is already padded, else a zero padded copy (M, pad(K))."""
     K = x2d.shape[1]
-    if K == ops._pad8(K) and x2d.is_contiguous():
+    Kp = (K + pad - 1) // pad * pad
+    if K == Kp and x2d.is_contiguous():
         return x2d
-    out = torch.zeros((x2d.shape[0], ops._pad8(K)), device=x2d.device, dtype=x2d.dtype)
+    out = torch.zeros((x2d.shape[0], Kp), device=x2d.device, dtype=x2d.dtype)
     out[:, :K].copy_(x2d)
     return out
 

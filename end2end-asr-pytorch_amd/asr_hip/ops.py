@@ -163,10 +163,12 @@ def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0, use_ws=True):
 
 
 def gemm_nn_supported(dy, w):
-    """True when dx = dy (M,N) @ w (N,K) can run on the transpose-free data-gradient kernel."""
+    """True when dx = dy (M,N) @ w (N,K) can run on the transpose-free data-gradient kernel.  N not a multiple of the kernel's
+    reduction stage: dy must carry zero columns up to the next multiple (functions._as_compute / _pad_cols(x, 64) make them)."""
     bkr = 32 if dy.dtype == torch.float32 else 64
     epc = 4 if dy.dtype == torch.float32 else 8
-    return (dy.dtype == w.dtype and w.shape[0] % bkr == 0 and dy.shape[1] >= w.shape[0] and dy.stride(1) == 1 and
+    return (dy.dtype == w.dtype and dy.stride(0) >= (w.shape[0] + bkr - 1) // bkr * bkr and dy.shape[1] >= w.shape[0] and
+            dy.stride(1) == 1 and
             w.stride(1) == 1 and dy.stride(0) % epc == 0 and w.stride(0) % epc == 0 and dy.data_ptr() % 16 == 0 and
             w.data_ptr() % 16 == 0)
 
@@ -197,7 +199,7 @@ def gemm_nn_tn_supported(dy, w, x):
     """True when a linear layer's dX and dW can be ONE launch (asr_gemm_nn_tn): bf16, inside a graph capture (the weight
     gradient is then complete only after flush_tn_reduces(), which join_deferred() issues at the end of backward)."""
     return (_nn_tn and dy.dtype == torch.bfloat16 and torch.cuda.is_current_stream_capturing() and gemm_nn_supported(dy, w) and
-            gemm_tn_supported(dy, x) and w.shape[0] % 64 == 0 and x.dtype == dy.dtype and w.shape[0] * w.shape[1] <= _nn_tn_max)
+            gemm_tn_supported(dy, x) and x.dtype == dy.dtype and w.shape[0] * w.shape[1] <= _nn_tn_max)
 
 
 def gemm_nn_tn(dy, w, x, dw, db=None, out=None, accumulate=False, relu_mask=None):
@@ -257,14 +259,14 @@ def transpose(x):
     return transpose_padded(x)[:, :x.shape[0]]
 
 
-def cast_and_transpose(src, dtype, want_same=True, want_t=True):
-    """fp32 (rows, cols) -> (copy in dtype with ld padded to 8, transpose in dtype with ld padded to 8).
+def cast_and_transpose(src, dtype, want_same=True, want_t=True, pad=8):
+    """fp32 (rows, cols) -> (copy in dtype with ld padded to `pad`, transpose in dtype with ld padded to 8).
     Pad columns are zero so a contraction may run over the padded K."""
     assert src.dim() == 2 and src.stride(1) == 1 and src.dtype == torch.float32
     rows, cols = src.shape
     same = t = None
     if want_same:
-        same = torch.zeros((rows, _pad8(cols)), device=src.device, dtype=dtype)
+        same = torch.zeros((rows, (cols + pad - 1) // pad * pad), device=src.device, dtype=dtype)
     if want_t:
         t = torch.zeros((cols, _pad8(rows)), device=src.device, dtype=dtype)
     L.call("asr_cast_weight", L.ptr(src), src.stride(0), L.ptr(same), same.stride(0) if same is not None else 0,

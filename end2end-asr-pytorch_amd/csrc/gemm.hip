@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, c
   const int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
-  const int nk = p.K / BKR;
+  const int nk = (p.K + BKR - 1) / BKR;          // a partial last stage: A's columns past K are zero (caller), B's rows are clamped
   const int b_chunks = (int)(p.ldb * ESZ / 16);
 
   f32x4_t acc[FM][FN];
@@ -1050,7 +1050,8 @@ __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, c
     for (int i = 0; i < BKR * P::CPR / 256; ++i) {
       const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
       int cb = n0 * ESZ / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
-      const unsigned char* src = B + ((int64_t)kt * BKR + row) * p.ldb * ESZ + (int64_t)cb * 16;
+      const int br = min(kt * BKR + row, p.K - 1);
+      const unsigned char* src = B + (int64_t)br * p.ldb * ESZ + (int64_t)cb * 16;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(sb + (i * 256 + wave * 64) * 16), 16, 0, 0);
     }
@@ -1632,7 +1633,7 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   ASR_CHECK_ARG(out_dtype == in_dtype || (in_dtype == ASR_BF16 && out_dtype == ASR_F32));
   if (M == 0 || N == 0) return ASR_OK;
   const int esz = in_dtype == ASR_F32 ? 4 : 2, epc = 16 / esz, bkr = 128 / esz;
-  if (K <= 0 || K % bkr != 0 || lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || ldb < N || lda < K)
+  if (K <= 0 || lda % epc != 0 || ldb % epc != 0 || !aligned16(A) || !aligned16(B) || ldb < N || lda < (K + bkr - 1) / bkr * bkr)
     return ASR_EUNSUPPORTED;
   GemmArgs p{};
   p.A = A; p.B = B; p.C = C; p.mask = relu_mask;
@@ -1676,8 +1677,8 @@ extern "C" int asr_gemm_nn_tn(const void* dy, int64_t ld_dy, const void* w, int6
                               int64_t fold_ld, int fold_N, int fold_K, int fold_splits, hipStream_t stream) {
   ASR_CHECK_ARG(dy && w && x && dx && workspace && M > 0 && N > 0 && K > 0);
   if (dtype != ASR_BF16) return ASR_EUNSUPPORTED;
-  if (N % 64 != 0 || ld_dy % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0 || !aligned16(dy) || !aligned16(w) || !aligned16(x) || ldw < K ||
-      ld_dy < N || ld_dy >= ((int64_t)1 << 22) || ldx >= ((int64_t)1 << 22))
+  if (ld_dy % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0 || !aligned16(dy) || !aligned16(w) || !aligned16(x) || ldw < K ||
+      ld_dy < (N + 63) / 64 * 64 || ld_dy >= ((int64_t)1 << 22) || ldx >= ((int64_t)1 << 22))
     return ASR_EUNSUPPORTED;
   int m_per_split = 0;
   splits = nn_tn_splits(M, splits, &m_per_split);

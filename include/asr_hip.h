@@ -77,8 +77,9 @@ int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C
                 asr_stream_t stream);
 
 /* Data gradient without transposed weights: C[M,N] (op)= alpha * sum_k A[m*lda+k] * B[k*ldb+n] with B = W (K,N) in its
- * master layout (transposing LDS reads).  flags: ASR_GEMM_ACCUMULATE; relu_mask as in asr_gemm_nt.  Needs K to be a
- * multiple of 64 (bf16) / 32 (fp32) and 16-byte aligned rows, else ASR_EUNSUPPORTED.                              */
+ * master layout (transposing LDS reads).  flags: ASR_GEMM_ACCUMULATE; relu_mask as in asr_gemm_nt.  Needs 16-byte aligned
+ * rows; K is contracted in stages of 64 (bf16) / 32 (fp32): when K is not a multiple of that, lda must cover K rounded up to a
+ * whole stage and the caller guarantees A[:, K:] == 0 there (B's rows are clamped), else ASR_EUNSUPPORTED.              */
 int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask, int M,
                 int N, int K, float alpha, int flags, int in_dtype, int out_dtype, asr_stream_t stream);
 /* A linear layer's whole backward in ONE launch (every nn.Linear / Conv1d(k=1) of models/common_layers.py:136-142,181-197 under
@@ -87,8 +88,8 @@ int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C,
  * dy^T . x over `splits` slices of the M rows go to workspace [split][tile][64][64] (asr_gemm_nn_tn_workspace floats), the bias
  * gradient db (N, may be NULL) += column sums of dy.  asr_tn_reduce_multi then folds the slices of up to any number of layers
  * into their dw (N,K; fp32; += semantics) in one launch per 48 layers, slices added in a fixed order.  Two launches on two streams
- * cost a fork and a join (5-10 us each on the critical path of a replayed graph) per layer.  bf16 only; N a multiple of 64 and
- * 16-byte aligned rows, else ASR_EUNSUPPORTED.  splits = 0: chosen by the library (asr_gemm_nn_tn_splits tells the number).
+ * cost a fork and a join (5-10 us each on the critical path of a replayed graph) per layer.  bf16 only; 16-byte aligned rows;
+ * ld_dy >= N rounded up to 64 with dy[:, N:] == 0 there (as asr_gemm_nn), else ASR_EUNSUPPORTED.  splits = 0: chosen by the library (asr_gemm_nn_tn_splits tells the number).
  * fold_ws != NULL: extra workgroups of the same launch fold the partial tiles an EARLIER asr_gemm_nn_tn call on this stream left
  * in fold_ws into fold_dw (fold_N x fold_K, row stride fold_ld, fold_splits slices) -- the HBM-bound second stage of layer i
  * rides under the MFMA-bound tiles of layer i+1 instead of being a launch of its own.                                         */

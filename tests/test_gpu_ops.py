@@ -176,6 +176,36 @@ def test_gemm_nn_tn_one_launch(ops, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(300, 4364, 512), (130, 100, 72), (64, 32, 512)])
+def test_gemm_nn_partial_reduction_stage(ops, dtype, shape):
+    """dx = dy @ W when N (the contracted axis) is not a multiple of the kernel's stage: dy carries zero columns up to the next
+    multiple of 64, W's rows are clamped (vocabulary projection, V = 4364 / 32); same for the one-launch dX + dW (bf16)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(N)
+    D = dev()
+    Np = (N + 63) // 64 * 64
+    dy = torch.zeros(M, Np); dy[:, :N] = q(torch.randn(M, N, generator=g), dtype)
+    # W sits inside a larger buffer whose following rows are NOT zero: they must not leak into the result
+    wbuf = q(torch.randn(N + 64, K, generator=g) / math.sqrt(N), dtype)
+    w = wbuf[:N]
+    dyd, wd = dy.to(D, dtype), wbuf.to(D, dtype)[:N]
+    assert ops.gemm_nn_supported(dyd, wd)
+    if N % 64 != 0 and N % 8 == 0 and dtype == torch.bfloat16:
+        assert not ops.gemm_nn_supported(dyd[:, :N].contiguous(), wd)      # no room for the zero columns
+    out = ops.gemm_nn(dyd, wd)
+    close("nn partial stage", out, dy[:, :N] @ w, dtype)
+    if dtype == torch.bfloat16:
+        x = q(torch.randn(M, K, generator=g), dtype)
+        dw0, db0 = torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+        dw, db = dw0.clone().to(D), db0.clone().to(D)
+        out2 = ops.gemm_nn_tn(dyd, wd, x.to(D, dtype), dw, db)
+        ops.flush_tn_reduces()
+        assert torch.equal(out2, out)
+        close("nn_tn dW partial tile", dw, dw0 + dy[:, :N].t() @ x, dtype, scale=0.2)
+        close("nn_tn db partial tile", db, db0 + dy[:, :N].sum(0), torch.float32, scale=8)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_cast_colsum(ops, dtype):
     g = torch.Generator().manual_seed(3)
     x = q(torch.randn(203, 77, generator=g), dtype)
