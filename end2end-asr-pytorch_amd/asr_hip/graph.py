@@ -58,6 +58,7 @@ class GraphedTrainStep:
             self.warm = (res[0], getattr(self, "gold_seq", None), getattr(self, "hyp_seq", None))
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ops.reset_pending()
         if self.red is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):

@@ -226,6 +226,13 @@ def gemm_nn_tn(dy, w, x, dw, db=None, out=None, accumulate=False, relu_mask=None
     return out
 
 
+def reset_pending():
+    """Forget second stages that were never issued (a capture that raised half way): their workspaces are gone."""
+    del _tn_pending[:]
+    del _ln_pending[:]
+    _side["pending"] = []
+
+
 def flush_tn_reduces():
     """Second stage of every gemm_nn_tn() issued since the last flush: one launch (per 48 layers) folds all partial tiles."""
     import ctypes

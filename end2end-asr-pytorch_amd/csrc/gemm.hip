@@ -1643,7 +1643,7 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
   const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
-  const int64_t nn_big = asr_tuning("NN_BIG", 800);      // 128x64 tiles from this many 64x64 tiles on
+  const int64_t nn_big = asr_tuning("NN_BIG", 1700);      // 128x64 tiles from this many 64x64 tiles on
   const bool big = t64 >= nn_big && M > 64;
   if (in_dtype == ASR_F32) return big ? launch_nn<float, float, 128>(p, stream) : launch_nn<float, float, 64>(p, stream);
   if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);
@@ -1698,7 +1698,7 @@ extern "C" int asr_gemm_nn_tn(const void* dy, int64_t ld_dy, const void* w, int6
   p.vecC = ((((uintptr_t)dx) & 15) == 0) && (ld_dx % 4 == 0);
   p.tiles_n = (K + 63) / 64;
   const int64_t t64 = ceil_div64(M, 64) * p.tiles_n;
-  const bool big = t64 >= asr_tuning("NN_BIG", 800) && M > 64;
+  const bool big = t64 >= asr_tuning("NN_BIG", 1700) && M > 64;
   const int bm = big ? 128 : 64;
   p.ntiles = ((M + bm - 1) / bm) * p.tiles_n;
   const int n_tn = t.ntiles * splits;
