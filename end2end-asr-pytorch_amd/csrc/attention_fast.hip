@@ -52,16 +52,29 @@ __device__ __forceinline__ int xcd_linear_id() { return xcd_linear_id((int)block
 
 // 64 rows x 128 B of a (rows, 64) bf16 slice -> LDS, chunk c of row r stored at slot c ^ (r & 7).  Rows past `nrows`
 // re-read the last valid row (the LDS-DMA cannot zero-fill; such rows are masked / never stored by the callers).
+//
+// The LDS-DMA is issued BY HAND (inline asm).  Through the builtin the compiler counts these loads itself, and its waitcnt pass
+// cannot tell a DMA's LDS write from the tile a later ds_read wants: it put s_waitcnt vmcnt(0) in front of the first LDS read that
+// followed the prefetch of the next tile (the P.V operand reads) -- the "double buffering" only ever overlapped the softmax, and
+// every tile exposed most of a global-memory round trip.  Hand-issued, nothing waits until the explicit s_waitcnt vmcnt(0) in front
+// of the barrier at the end of the tile (every loop below has one); ordinary global loads issued while a DMA is in flight still
+// wait for it (vmcnt retires in order), so the loops issue those BEFORE the prefetch.
+__device__ __forceinline__ void lds_dma16(unsigned lds_wave_base, const void* src) {
+  unsigned keep;      // M0 saved and restored: neutral for whatever the compiler keeps there
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
+}
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* g, int64_t st, int r0, int nrows, int tid, int wave) {
+  const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = i * 256 + tid, row = c >> 3, slot = c & 7;
     int gr = r0 + row;
     gr = gr < nrows ? gr : nrows - 1;
     const bf16_t* src = g + (int64_t)gr * st + ((slot ^ (row & 7)) << 3);
-    unsigned char* dst = lds + (i * 256 + wave * 64) * 16;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    lds_dma16(base + (unsigned)((i * 256 + wave * 64) * 16), src);
   }
 }
 // A-operand pack (one row, 8 consecutive d) from a natural tile: row, macro step ds over d, lane group g
@@ -92,6 +105,13 @@ __device__ __forceinline__ uint4 load_row16(const bf16_t* base, int64_t st, int 
   return *reinterpret_cast<const uint4*>(base + (int64_t)r * st + col0);
 }
 
+// Buffer resource over the whole key-padding mask ((B, Tk) or (B, Tq, Tk) bytes; fast_ok() guarantees < 2^31): raw buffer, stride 0,
+// out-of-range reads return 0.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mask_rsrc(const AttnArgs& p) {
+  const int64_t n = (int64_t)(p.B - 1) * p.m_sb + (int64_t)(p.Tq - 1) * p.m_sq + p.Tk;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.key_pad), 0, (int)n, 0x00020000);
+}
+
 // Mask NKF key fragments of raw scores s[qi][kf][r] (key = kbase + 16 kf + 4 g + r, query = q_lane + 16 qi): straight-line
 // selects, mask bytes read with clamped (always valid) addresses.
 template <int NKF, int NQ = 2>
@@ -99,15 +119,23 @@ __device__ __forceinline__ void mask_scores(const AttnArgs& p, f32x4_t (*s)[NKF]
 #pragma unroll
   for (int qi = 0; qi < NQ; ++qi) {
     const int q = q_lane + qi * 16;
-    const uint8_t* mrow = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (int64_t)(q < p.Tq ? q : p.Tq - 1) * p.m_sq : nullptr;
+    // every mask byte of this lane is loaded up front, unconditionally (a short-circuit `dead || byte` compiled to one branch, one
+    // load and one s_waitcnt vmcnt(0) PER ELEMENT: 16 NQ serialised global round trips per tile) -- as BUFFER loads: one 32-bit
+    // offset register + immediates instead of a 64-bit address per byte, and the hardware's range check (bytes past the end of
+    // the mask read as 0) instead of per-element clamps; keys >= Tk are dead by kend anyway.
+    uint32_t mbits = 0u;
+    if (p.key_pad) {
+      const int off = (int)((int64_t)b * p.m_sb + (int64_t)(q < p.Tq ? q : p.Tq - 1) * p.m_sq) + kbase + g * 4;
+#pragma unroll
+      for (int i = 0; i < NKF * 4; ++i)
+        mbits |= (uint32_t)(__builtin_amdgcn_raw_buffer_load_b8(mask_rsrc(p), off + (i >> 2) * 16 + (i & 3), 0, 0) != 0) << i;
+    }
 #pragma unroll
     for (int kf = 0; kf < NKF; ++kf)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int kg = kbase + kf * 16 + g * 4 + r;
-        bool dead = kg >= kend;
-        if (p.causal) dead = dead || kg > q;
-        if (mrow) dead = dead || mrow[kg < p.Tk ? kg : p.Tk - 1] != 0;
+        const bool dead = (kg >= kend) | (p.causal != 0 & kg > q) | (((mbits >> (kf * 4 + r)) & 1u) != 0u);
         s[qi][kf][r] = dead ? -INFINITY : s[qi][kf][r];
       }
   }
@@ -442,19 +470,22 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   const int t0 = p.causal ? (kb * FKW) >> 6 : 0;
   const int ntile = (p.Tq + 63) >> 6;
 
+  // lse (x log2 e) / delta of query tile t for threads 0..63 / 64..127.  An ordinary load: it must have been CONSUMED before the
+  // hand-issued DMA of that tile goes out (vmcnt retires in order: waiting for it later would wait for the DMA as well), so the
+  // loop loads it at the top of tile t - 1 and stores it to LDS right before the prefetch.
+  auto load_stat = [&](int t) __attribute__((always_inline)) -> float {
+    const int ql = tid & 63, qq = (t << 6) + ql;
+    if (tid < 64) return qq < p.Tq ? p.lse[stat0 + qq] * LOG2E : INFINITY;        // rows past Tq: P = exp2(-inf) = 0
+    return (tid < 128 && qq < p.Tq) ? p.delta[stat0 + qq] : 0.f;
+  };
   auto stage_stats = [&](int t, int buf) __attribute__((always_inline)) {
-    if (tid < 128) {
-      const int ql = tid & 63, qq = (t << 6) + ql;
-      float v;
-      if (tid < 64) v = qq < p.Tq ? p.lse[stat0 + qq] * LOG2E : INFINITY;        // rows past Tq: P = exp2(-inf) = 0
-      else v = qq < p.Tq ? p.delta[stat0 + qq] : 0.f;
-      s_stat[buf][tid >> 6][ql] = v;
-    }
+    const float v = load_stat(t);
+    if (tid < 128) s_stat[buf][tid >> 6][tid & 63] = v;
   };
   if (t0 < ntile) {
+    stage_stats(t0, t0 & 1);
     stage_tile(smem, Qb, p.q_st, t0 << 6, p.Tq, tid, wave);
     stage_tile(smem + TILE, dOb, p.o_st, t0 << 6, p.Tq, tid, wave);
-    stage_stats(t0, t0 & 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -465,6 +496,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
     const float* st_lse = s_stat[t & 1][0];
     const float* st_dlt = s_stat[t & 1][1];
     const bool need_mask = p.key_pad != nullptr || (p.causal && kw + 16 * NK - 1 > q0) || (kw + 16 * NK > kend);
+    const float next_stat = t + 1 < ntile ? load_stat(t + 1) : 0.f;
     // the query tile is consumed in two halves of 32 queries (one macro step of the dV / dK contractions each)
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -498,9 +530,9 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntile) {
           unsigned char* nb = smem + ((t + 1 - t0) & 1) * 2 * TILE;
+          if (tid < 128) s_stat[(t + 1) & 1][tid >> 6][tid & 63] = next_stat;
           stage_tile(nb, Qb, p.q_st, q0 + 64, p.Tq, tid, wave);
           stage_tile(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, tid, wave);
-          stage_stats(t + 1, (t + 1) & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -509,15 +541,21 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
       for (int ki = 0; ki < NK; ++ki) {
         const int key = kw + ki * 16 + lr;
         if (need_mask) {
-          const uint8_t* mcol = p.key_pad ? p.key_pad + (int64_t)b * p.m_sb + (key < p.Tk ? key : p.Tk - 1) : nullptr;
+          uint32_t mbits = 0u;                      // mask bytes loaded up front, unconditionally (see mask_scores)
+          if (p.key_pad) {
+            const int col = (int)((int64_t)b * p.m_sb) + (key < p.Tk ? key : p.Tk - 1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const int qq = q0 + (2 * ms + (i >> 2)) * 16 + g * 4 + (i & 3);
+              mbits |= (uint32_t)(__builtin_amdgcn_raw_buffer_load_b8(mask_rsrc(p), col + (qq < p.Tq ? qq : p.Tq - 1) * (int)p.m_sq, 0, 0) != 0) << i;
+            }
+          }
 #pragma unroll
           for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               const int qq = q0 + (2 * ms + q2) * 16 + g * 4 + r;
-              bool dead = key >= kend;
-              if (p.causal) dead = dead || key > qq;
-              if (mcol) dead = dead || mcol[(int64_t)(qq < p.Tq ? qq : p.Tq - 1) * p.m_sq] != 0;
+              const bool dead = (key >= kend) | (p.causal != 0 & key > qq) | (((mbits >> (q2 * 4 + r)) & 1u) != 0u);
               s[ki][q2][r] = dead ? -INFINITY : s[ki][q2][r];
             }
         }
@@ -620,6 +658,7 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_d64_kernel(AttnArgs p) {
 }
 
 bool fast_ok(const AttnArgs& p, int d, int dtype) {
+  if (p.key_pad && (int64_t)(p.B - 1) * p.m_sb + (int64_t)(p.Tq - 1) * p.m_sq + p.Tk >= ((int64_t)1 << 31)) return false;   // 32-bit mask offsets
   return dtype == ASR_BF16 && d == HD && p.vec && p.Tq > 0 && p.Tk > 0 && asr_tuning("ATTN_GENERIC", 0) == 0;
 }
 
