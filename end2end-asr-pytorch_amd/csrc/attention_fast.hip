@@ -66,6 +66,34 @@ __device__ __forceinline__ void lds_dma16(unsigned lds_wave_base, const void* sr
                : "s"(lds_wave_base), "v"(src)
                : "memory");
 }
+// The same with a wave-uniform base address (SGPR pair) + a per-thread 32-bit byte offset that does not change from tile to tile:
+// the loops of the forward kernel hoist the offsets (tile_voff) and pay no vector instruction per prefetch (the per-tile 64-bit
+// row * stride arithmetic was 24 of the 245 vector instructions of a forward tile).
+__device__ __forceinline__ void lds_dma16_s(unsigned lds_wave_base, unsigned voff, const void* sbase) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(voff), "s"(sbase)
+               : "memory");
+}
+// byte offset of this thread's i-th chunk of a tile relative to the tile's first row (row stride st elements; fast_ok(): < 2^22)
+__device__ __forceinline__ unsigned tile_voff(int64_t st, int tid, int i) {
+  const int c = i * 256 + tid, row = c >> 3, slot = c & 7;
+  return (unsigned)(row * (int)st * 2 + ((slot ^ (row & 7)) << 4));
+}
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* g, int64_t st, int r0, int nrows, int tid, int wave);
+// full tiles (r0 + 64 <= nrows) go by base + hoisted offsets, the ragged last tile by the clamped per-row addresses
+__device__ __forceinline__ void stage_tile_h(unsigned char* lds, const bf16_t* g, int64_t st, int r0, int nrows, const unsigned (&voff)[2],
+                                             int tid, int wave) {
+  if (r0 + 64 <= nrows) {
+    const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const bf16_t* gb = g + (int64_t)r0 * st;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) lds_dma16_s(base + (unsigned)((i * 256 + wave * 64) * 16), voff[i], gb);
+  } else {
+    stage_tile(lds, g, st, r0, nrows, tid, wave);
+  }
+}
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* g, int64_t st, int r0, int nrows, int tid, int wave) {
   const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
 #pragma unroll
@@ -148,7 +176,7 @@ __device__ __forceinline__ void mask_scores(const AttnArgs& p, f32x4_t (*s)[NKF]
 // phases -- against 2.7 us for everything else in the launch; half the queries per wave doubles the waves per SIMD.
 constexpr int FQ = 128;
 
-template <int NQ>
+template <int NQ, bool DROP>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
   constexpr int FQW = 64 * NQ;                               // queries per workgroup
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];      // [buffer][K | V]
@@ -187,9 +215,11 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
   if (p.causal) kstop = min(kend, qb * FQW + FQW);
   const int ntile = (kstop + 63) >> 6;
 
+  const unsigned voK[2] = {tile_voff(p.k_st, tid, 0), tile_voff(p.k_st, tid, 1)};
+  const unsigned voV[2] = {tile_voff(p.v_st, tid, 0), tile_voff(p.v_st, tid, 1)};
   if (ntile > 0) {
-    stage_tile(smem, Kb, p.k_st, 0, p.Tk, tid, wave);
-    stage_tile(smem + TILE, Vb, p.v_st, 0, p.Tk, tid, wave);
+    stage_tile_h(smem, Kb, p.k_st, 0, p.Tk, voK, tid, wave);
+    stage_tile_h(smem + TILE, Vb, p.v_st, 0, p.Tk, voV, tid, wave);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -219,8 +249,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     if (t + 1 < ntile) {
       unsigned char* nb = smem + ((t + 1) & 1) * 2 * TILE;
-      stage_tile(nb, Kb, p.k_st, k0 + 64, p.Tk, tid, wave);
-      stage_tile(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, tid, wave);
+      stage_tile_h(nb, Kb, p.k_st, k0 + 64, p.Tk, voK, tid, wave);
+      stage_tile_h(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, voV, tid, wave);
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- online softmax (base 2), dropout, pack P^T as the B operand
@@ -246,7 +276,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
           psum += pv;
           s[qi][kf][r] = pv;
         }
-      if (p.thr) {
+      if (DROP) {                    // compile time: a run-time `if (p.thr)` here cost 8 register moves per query fragment even at p = 0
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -658,6 +688,7 @@ __global__ __launch_bounds__(256) void attn_delta_bf16_d64_kernel(AttnArgs p) {
 }
 
 bool fast_ok(const AttnArgs& p, int d, int dtype) {
+  if (p.q_st >= (1 << 22) || p.k_st >= (1 << 22) || p.v_st >= (1 << 22) || p.o_st >= (1 << 22)) return false;   // 32-bit in-tile byte offsets
   if (p.key_pad && (int64_t)(p.B - 1) * p.m_sb + (int64_t)(p.Tq - 1) * p.m_sq + p.Tk >= ((int64_t)1 << 31)) return false;   // 32-bit mask offsets
   return dtype == ASR_BF16 && d == HD && p.vec && p.Tq > 0 && p.Tk > 0 && asr_tuning("ATTN_GENERIC", 0) == 0;
 }
@@ -667,9 +698,13 @@ bool fast_ok(const AttnArgs& p, int d, int dtype) {
 int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   if (!fast_ok(p, d, dtype) || (((uintptr_t)p.Out) & 7) != 0 || p.o_st % 4 != 0 || p.o_sb % 4 != 0) return ASR_EUNSUPPORTED;
   if (p.Tq <= asr_tuning("ATTN_SHORT", 256)) {
-    attn_fwd_bf16_d64_kernel<1><<<dim3((unsigned)(((p.Tq + 63) / 64) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    const dim3 grid((unsigned)(((p.Tq + 63) / 64) * p.B * p.H));
+    if (p.thr) attn_fwd_bf16_d64_kernel<1, true><<<grid, dim3(256), 0, s>>>(p);
+    else attn_fwd_bf16_d64_kernel<1, false><<<grid, dim3(256), 0, s>>>(p);
   } else {
-    attn_fwd_bf16_d64_kernel<2><<<dim3((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H)), dim3(256), 0, s>>>(p);
+    const dim3 grid((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H));
+    if (p.thr) attn_fwd_bf16_d64_kernel<2, true><<<grid, dim3(256), 0, s>>>(p);
+    else attn_fwd_bf16_d64_kernel<2, false><<<grid, dim3(256), 0, s>>>(p);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
