@@ -6,7 +6,7 @@ cat > /tmp/ab.py <<'PY'
 import sys, os
 sys.path.insert(0, "tools")
 import microbench as M
-M.attn([(32, 8, 800, 800, 64, False, 0.0)])
+M.attn([(32, 8, 800, 800, 64, False, 0.0), (32, 8, 800, 800, 64, False, 0.1)])
 PY
 : > gpurun_out/${tag}.txt
 i=0
@@ -16,6 +16,6 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   i=$((i+1)); out=/tmp/pmc_${tag}_$i; rm -rf $out
   ( cd $GRAFT_REPO_ROOT && timeout 600 rocprofv3 --pmc $set -d $out -o pmc -- python /tmp/ab.py ) > gpurun_out/${tag}_log$i.txt 2>&1
   db=$(find $out -name "*.db" | head -1)
-  [ -n "$db" ] && python tools/pmc_summary.py "$db" attn_fwd >> gpurun_out/${tag}.txt 2>&1 || tail -5 gpurun_out/${tag}_log$i.txt
+  [ -n "$db" ] && python tools/pmc_summary.py "$db" attn_ >> gpurun_out/${tag}.txt 2>&1 || tail -5 gpurun_out/${tag}_log$i.txt
 done
 cat gpurun_out/${tag}.txt
