@@ -450,6 +450,37 @@ __global__ __launch_bounds__(256) void pool_fwd_tcf_kernel(const T* __restrict__
     DT<T>::st(out + i, sp[oh * (C + 1) + c]);
   }
 }
+// The same with 16-byte accesses on both sides (C and H2 multiples of the chunk): a thread pools EPC channels of one window row
+// from four 16-byte loads, and writes EPC consecutive features c*H2 + oh .. oh + EPC - 1 (gathered from LDS) as one 16-byte store.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_tcf_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float sp[];     // [H2][C+1]
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
+  const int ow = blockIdx.x % W2, b = blockIdx.x / W2;
+  for (int i = threadIdx.x; i < H2 * groups; i += 256) {
+    const int cg = i % groups, oh = i / groups;
+    const T* base = x + ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+    Chunk<T> a, bb, c, d;
+    a.v = *reinterpret_cast<const uint4*>(base);
+    bb.v = *reinterpret_cast<const uint4*>(base + C);
+    c.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C);
+    d.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C + C);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j)
+      sp[oh * (C + 1) + cg * EPC + j] = fmaxf(fmaxf(DT<T>::from(a.e[j]), DT<T>::from(bb.e[j])), fmaxf(DT<T>::from(c.e[j]), DT<T>::from(d.e[j])));
+  }
+  __syncthreads();
+  T* out = y + ((int64_t)b * W2 + ow) * (int64_t)C * H2;
+  const int hg = H2 / EPC;
+  for (int i = threadIdx.x; i < C * hg; i += 256) {
+    const int c = i / hg, oh0 = (i % hg) * EPC;
+    Chunk<T> o;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) o.e[j] = DT<T>::to(sp[(oh0 + j) * (C + 1) + c]);
+    *reinterpret_cast<uint4*>(out + c * H2 + oh0) = o.v;
+  }
+}
 // dx for one 2x2 window: gradient goes to the FIRST maximum in scan order (PyTorch max_pool2d), times ReLU'(x)
 template <typename T>
 __device__ __forceinline__ void pool_bwd_window(const T* __restrict__ x, T* __restrict__ dx, int64_t base, int C, int W, float gy) {
@@ -519,6 +550,53 @@ __global__ __launch_bounds__(256) void pool_bwd_tcf_kernel(const T* __restrict__
   for (int i = threadIdx.x; i < H2 * C; i += 256) {
     const int c = i % C, oh = i / C;
     pool_bwd_window<T>(x, dx, ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + c, C, W, sp[oh * (C + 1) + c]);
+  }
+}
+// The same with 16-byte accesses: dy (C, H2) comes in as chunks of EPC consecutive oh of one channel, the 2x2 windows go out as in
+// pool_bwd_nhwc_kernel (EPC channels per thread: four 16-byte loads, four 16-byte stores).
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_tcf_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx,
+                                                               int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float sp[];     // [H2][C+1]
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC, hg = H2 / EPC;
+  const int ow = blockIdx.x % W2, b = blockIdx.x / W2;
+  const T* in = dy + ((int64_t)b * W2 + ow) * (int64_t)C * H2;
+  for (int i = threadIdx.x; i < C * hg; i += 256) {
+    const int c = i / hg, oh0 = (i % hg) * EPC;
+    Chunk<T> g;
+    g.v = *reinterpret_cast<const uint4*>(in + c * H2 + oh0);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) sp[(oh0 + j) * (C + 1) + c] = DT<T>::from(g.e[j]);
+  }
+  __syncthreads();
+  const int64_t rowp = (int64_t)W * C;
+  for (int i = threadIdx.x; i < H2 * groups; i += 256) {
+    const int cg = i % groups, oh = i / groups;
+    const int64_t base = ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+    Chunk<T> v0, v1, v2, v3, o0, o1, o2, o3;
+    v0.v = *reinterpret_cast<const uint4*>(x + base);
+    v1.v = *reinterpret_cast<const uint4*>(x + base + C);
+    v2.v = *reinterpret_cast<const uint4*>(x + base + rowp);
+    v3.v = *reinterpret_cast<const uint4*>(x + base + rowp + C);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const float a0 = DT<T>::from(v0.e[j]), a1 = DT<T>::from(v1.e[j]), a2 = DT<T>::from(v2.e[j]), a3 = DT<T>::from(v3.e[j]);
+      int arg = 0; float m = a0;                      // the FIRST maximum in scan order takes the gradient (PyTorch max_pool2d)
+      if (a1 > m) { m = a1; arg = 1; }
+      if (a2 > m) { m = a2; arg = 2; }
+      if (a3 > m) { m = a3; arg = 3; }
+      const T gr = DT<T>::to(m > 0.f ? sp[oh * (C + 1) + cg * EPC + j] : 0.f);       // times ReLU'(x)
+      const T zero = DT<T>::to(0.f);
+      o0.e[j] = arg == 0 ? gr : zero;
+      o1.e[j] = arg == 1 ? gr : zero;
+      o2.e[j] = arg == 2 ? gr : zero;
+      o3.e[j] = arg == 3 ? gr : zero;
+    }
+    *reinterpret_cast<uint4*>(dx + base) = o0.v;
+    *reinterpret_cast<uint4*>(dx + base + C) = o1.v;
+    *reinterpret_cast<uint4*>(dx + base + rowp) = o2.v;
+    *reinterpret_cast<uint4*>(dx + base + rowp + C) = o3.v;
   }
 }
 // rows/cols that floor-mode pooling drops (odd H or W) get zero gradient: touch only those pixels
@@ -893,6 +971,10 @@ extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int 
   if (out_tcf) {
     const size_t lds = (size_t)H2 * (C + 1) * sizeof(float);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    if (C % epc == 0 && H2 % epc == 0 && aligned16(x) && aligned16(y)) {
+      if (dtype == ASR_F32) { allow_big_lds(pool_fwd_tcf_vec_kernel<float>, lds); hipLaunchKernelGGL((pool_fwd_tcf_vec_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (float*)y, B, H, W, C); }
+      else { allow_big_lds(pool_fwd_tcf_vec_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_fwd_tcf_vec_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C); }
+    } else
     if (dtype == ASR_F32) { allow_big_lds(pool_fwd_tcf_kernel<float>, lds); hipLaunchKernelGGL((pool_fwd_tcf_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (float*)y, B, H, W, C); }
     else { allow_big_lds(pool_fwd_tcf_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_fwd_tcf_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C); }
   } else {
@@ -922,6 +1004,11 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
   if (in_tcf) {
     const size_t lds = (size_t)H2 * (C + 1) * sizeof(float);
     if (lds > 150 * 1024) return ASR_EUNSUPPORTED;
+    const int epc = dtype == ASR_F32 ? 4 : 8;
+    if (C % epc == 0 && H2 % epc == 0 && aligned16(x) && aligned16(dy) && aligned16(dx)) {
+      if (dtype == ASR_F32) { allow_big_lds(pool_bwd_tcf_vec_kernel<float>, lds); hipLaunchKernelGGL((pool_bwd_tcf_vec_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C); }
+      else { allow_big_lds(pool_bwd_tcf_vec_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_bwd_tcf_vec_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C); }
+    } else
     if (dtype == ASR_F32) { allow_big_lds(pool_bwd_tcf_kernel<float>, lds); hipLaunchKernelGGL((pool_bwd_tcf_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C); }
     else { allow_big_lds(pool_bwd_tcf_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_bwd_tcf_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C); }
   } else {

@@ -665,7 +665,7 @@ def test_conv3x3_c64_persistent(ops, tw, cfg, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 21, 38, 64), (1, 161, 16, 64), (2, 40, 16, 128)])
+@pytest.mark.parametrize("shape", [(2, 21, 38, 64), (1, 161, 16, 64), (2, 40, 16, 128), (2, 80, 12, 128)])
 def test_maxpool_fwd_bwd_both_layouts(ops, dtype, shape):
     B, H, W, C = shape
     g = torch.Generator().manual_seed(H + W)
