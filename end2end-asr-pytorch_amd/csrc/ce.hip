@@ -29,7 +29,8 @@ __global__ __launch_bounds__(64 * CE_ROWS) void ce_fwd_kernel(const float* __res
     const int V4 = vec ? (V & ~3) : 0;
     MaxIdx mi{-INFINITY, 0x7fffffff};
     float sum = 0.f;
-    for (int v = lane * 4; v < V4; v += 256) {
+#pragma unroll 4
+    for (int v = lane * 4; v < V4; v += 256) {         // four 16-byte loads in flight per lane: the row is one memory round trip deep, not 17
       const float4 x = *reinterpret_cast<const float4*>(l + v);
       sum += (x.x + x.y) + (x.z + x.w);
       if (x.x > mi.v) { mi.v = x.x; mi.i = v; }
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(64 * CE_ROWS) void ce_fwd_kernel(const float* __res
     }
     sum = wave_sum(sum);
     float e = 0.f;
+#pragma unroll 4
     for (int v = lane * 4; v < V4; v += 256) {
       const float4 x = *reinterpret_cast<const float4*>(l + v);
       e += (expf(x.x - mi.v) + expf(x.y - mi.v)) + (expf(x.z - mi.v) + expf(x.w - mi.v));
@@ -91,7 +93,16 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* l = logits + (int64_t)row * ld;
   MaxIdx mi{-INFINITY, 0x7fffffff};
-  for (int v = tid; v < V; v += 256) {
+  const int V4 = ((((uintptr_t)l) & 15) == 0) ? (V & ~3) : 0;
+#pragma unroll 4
+  for (int v = tid * 4; v < V4; v += 1024) {           // 16-byte loads, four in flight (strictly-greater keeps the lowest index per lane)
+    const float4 x = *reinterpret_cast<const float4*>(l + v);
+    if (x.x > mi.v) { mi.v = x.x; mi.i = v; }
+    if (x.y > mi.v) { mi.v = x.y; mi.i = v + 1; }
+    if (x.z > mi.v) { mi.v = x.z; mi.i = v + 2; }
+    if (x.w > mi.v) { mi.v = x.w; mi.i = v + 3; }
+  }
+  for (int v = V4 + tid; v < V; v += 256) {
     const float x = l[v];
     if (x > mi.v) { mi.v = x; mi.i = v; }
   }
