@@ -682,6 +682,7 @@ class CEFn(Function):
 
     @staticmethod
     def forward(ctx, pred, gold, smoothing, pad_id, global_count):
+        ctx.set_materialize_grads(False)       # no zero-filled gradients for the two statistics outputs (one fill launch each per step)
         V = pred.shape[-1]
         logits = pred.reshape(-1, V)
         if logits.dtype != torch.float32:
