@@ -52,7 +52,37 @@ __device__ __forceinline__ void conv1_window(const float* __restrict__ x, int64_
   }
 }
 
-template <typename T>
+// The two halves of conv1_window: the clamped loads alone (issued early), and the zeroing of out-of-image taps (applied when the
+// values are consumed) -- a select right behind the load would make the compiler wait for the load where it is issued.
+__device__ __forceinline__ void conv1_window_load(const float* __restrict__ x, int64_t b, int yh, int x0, int H, int W,
+                                                  float (*raw)[C1_PW + 2]) {
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = yh + ky - 1;
+    const float* xr = x + (b * H + ((yy >= 0 && yy < H) ? yy : yh)) * (int64_t)W;
+#pragma unroll
+    for (int k = 0; k < C1_PW + 2; ++k) {
+      const int xx = x0 + k - 1;
+      raw[ky][k] = xr[xx < 0 ? 0 : (xx < W ? xx : W - 1)];
+    }
+  }
+}
+__device__ __forceinline__ void conv1_window_mask(int yh, int x0, int H, int W, const float (*raw)[C1_PW + 2], float (*in)[C1_PW + 2]) {
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = yh + ky - 1;
+    const bool rowok = yy >= 0 && yy < H;
+#pragma unroll
+    for (int k = 0; k < C1_PW + 2; ++k) {
+      const int xx = x0 + k - 1;
+      in[ky][k] = (rowok && xx >= 0 && xx < W) ? raw[ky][k] : 0.f;
+    }
+  }
+}
+
+// FULL: W is a multiple of the quad width, every quad stores exactly C1_PW chunks -- the compiler then KNOWS how many stores follow
+// the prefetch loads and can wait for the loads alone (s_waitcnt vmcnt(C1_PW)); behind a conditional store it has to assume none.
+template <typename T, bool FULL>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, T* __restrict__ y, int B, int H,
                                                         int W, int C0) {
@@ -70,16 +100,31 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
   // int64 div/mod costs more instructions than the 288 FMAs of a quad)
   const int wq = (W + C1_PW - 1) / C1_PW;
   const int qpb = 256 / groups;
+  // the weights have landed before the loops start: left pending, their first use INSIDE the quad loop carries an
+  // s_waitcnt vmcnt(<prefetch loads>) that every iteration then pays by waiting for the previous iteration's stores
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {             // (an empty asm that "reads" every weight register: the waits happen here)
+    asm volatile("" ::"v"(br[j][0]), "v"(br[j][1]));
+#pragma unroll
+    for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(wr[j][t][0]), "v"(wr[j][t][1]));
+  }
   for (int row = blockIdx.x; row < B * H; row += gridDim.x) {
    const int yh = row % H;
    const int64_t b = row / H;
-   for (int qx = threadIdx.x / groups; qx < wq; qx += qpb) {
+   // The NEXT quad's window is loaded before this quad's stores are issued: loads and stores retire through one in-order counter
+   // (vmcnt), so a window loaded AFTER the stores could only be waited for together with them -- every iteration then exposed a
+   // full store round trip to HBM and the 60 us of arithmetic never overlapped the 114 us of stores.
+   float in[3][C1_PW + 2], nxt[3][C1_PW + 2];
+   int qx = threadIdx.x / groups;
+   if (qx < wq) conv1_window(x, b, yh, qx * C1_PW, H, W, in);
+   for (; qx < wq; qx += qpb) {
     const int x0 = qx * C1_PW;
-    float in[3][C1_PW + 2];
-    conv1_window(x, b, yh, x0, H, W, in);
+    const int qn = min(qx + qpb, wq - 1);            // always issued (clamped): no branch between the prefetch and the stores
+    conv1_window_load(x, b, yh, qn * C1_PW, H, W, nxt);
+    __builtin_amdgcn_sched_barrier(0);               // (the scheduler otherwise sinks the loads below the first stores)
 #pragma unroll
     for (int px = 0; px < C1_PW; ++px) {
-      if (x0 + px >= W) break;
+      if (!FULL && x0 + px >= W) break;
       Chunk<T> o;
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
@@ -96,6 +141,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
       }
       *reinterpret_cast<uint4*>(y + (((b * H + yh) * (int64_t)W) + x0 + px) * C0 + cg * EPC) = o.v;
     }
+    __builtin_amdgcn_sched_barrier(0);               // consume the prefetch only here: C1_PW stores are younger, s_waitcnt vmcnt(C1_PW) suffices
+    conv1_window_mask(yh, qn * C1_PW, H, W, nxt, in);
    }
   }
 }
@@ -879,8 +926,12 @@ extern "C" int asr_conv1_fwd(const float* x, const float* w, const float* bias, 
   ASR_CHECK_ARG(rows < ((int64_t)1 << 31));
   unsigned grid1 = (unsigned)(rows < 8192 ? rows : 8192);
   AsrProfScope prof(ASR_OP_CONV1, s);
-  if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float>), dim3(grid1), dim3(256), 0, s, x, w, bias, (float*)y, B, H, W, C0);
-  else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t>), dim3(grid1), dim3(256), 0, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
+  if (W % C1_PW == 0) {
+    if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float, true>), dim3(grid1), dim3(256), 0, s, x, w, bias, (float*)y, B, H, W, C0);
+    else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t, true>), dim3(grid1), dim3(256), 0, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
+  } else
+  if (dtype == ASR_F32) hipLaunchKernelGGL((conv1_fwd_kernel<float, false>), dim3(grid1), dim3(256), 0, s, x, w, bias, (float*)y, B, H, W, C0);
+  else hipLaunchKernelGGL((conv1_fwd_kernel<bf16_t, false>), dim3(grid1), dim3(256), 0, s, x, w, bias, (bf16_t*)y, B, H, W, C0);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
