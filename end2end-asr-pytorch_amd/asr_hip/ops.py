@@ -317,7 +317,7 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     d_y = torch.empty_like(z) if p > 0 else d_res
     n_ws = L.load().asr_add_ln_bwd_workspace(M, D)
     ws = torch.empty(n_ws, device=z.device, dtype=torch.float32)       # caching allocator: no cost after the first step
-    if _ln_multi and torch.cuda.is_current_stream_capturing():
+    if _ln_multi and D % 2 == 0 and torch.cuda.is_current_stream_capturing():
         # graph capture: the dgamma / dbeta sums of all layers in one launch at the end of backward (flush_ln_reduces)
         L.call("asr_add_ln_bwd_partials", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
                L.ptr(d_res), L.ptr(d_y), L.ptr(ws), n_ws, M, D, float(p), int(seed), _seed_dev(z), L.dt(z), L.stream())

@@ -235,17 +235,36 @@ struct LnMultiArgs {
   const float* ws[LN_MULTI]; float* dgamma[LN_MULTI]; float* dbeta[LN_MULTI]; int nblk[LN_MULTI];
   int D2;
 };
-__global__ __launch_bounds__(256) void ln_partial_reduce_multi_kernel(LnMultiArgs a) {
-  const int L = blockIdx.z, c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= a.D2) return;
+// No atomics (64 slices x 1024 columns x 20 layers of same-address fp32 atomics were most of this launch) and a fixed summation
+// order: a 1024-thread workgroup owns 256 columns of one layer, its 16 waves each add a sixteenth of the partial rows with 16-byte
+// loads, the sixteen meet in LDS and wave 0 does the plain += .
+__global__ __launch_bounds__(1024) void ln_partial_reduce_multi_kernel(LnMultiArgs a) {
+  __shared__ float4 red[16][64];
+  const int L = blockIdx.y, cg = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + cg) * 4;                   // 4 consecutive columns of [dgamma | dbeta]
   const int nblk = a.nblk[L];
-  const int per = (nblk + gridDim.y - 1) / gridDim.y;
-  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
-  const float* partial = a.ws[L];
-  float acc = 0.f;
-  for (int b = b0; b < b1; ++b) acc += partial[(int64_t)b * a.D2 + c];
+  const int per = (nblk + 15) / 16;
+  const int b0 = sl * per, b1 = min(nblk, b0 + per);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < a.D2) {
+    const float* partial = a.ws[L] + c;
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b) {
+      const float4 v = *reinterpret_cast<const float4*>(partial + (int64_t)b * a.D2);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[sl][cg] = acc;
+  __syncthreads();
+  if (sl != 0 || c >= a.D2) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const float4 v = red[k][cg];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
   const int D = a.D2 / 2;
-  if (b0 < b1) atomicAdd(c < D ? a.dgamma[L] + c : a.dbeta[L] + (c - D), acc);
+  float* dst = c < D ? a.dgamma[L] + c : a.dbeta[L] + (c - D);
+  dst[0] += acc.x; dst[1] += acc.y; dst[2] += acc.z; dst[3] += acc.w;
 }
 
 }  // namespace
@@ -355,20 +374,17 @@ extern "C" int asr_add_ln_bwd_partials(const void* dout, const void* z, const fl
 
 extern "C" int asr_ln_reduce_multi(const float* const* workspaces, const int* rows, float* const* dgamma, float* const* dbeta, int n,
                                    int D, hipStream_t s) {
-  ASR_CHECK_ARG(n >= 0 && D > 0 && (n == 0 || (workspaces && rows && dgamma && dbeta)));
+  ASR_CHECK_ARG(n >= 0 && D > 0 && D % 2 == 0 && (n == 0 || (workspaces && rows && dgamma && dbeta)));     // (16-byte partial rows)
   for (int i0 = 0; i0 < n; i0 += LN_MULTI) {
     LnMultiArgs a{};
     const int cnt = n - i0 < LN_MULTI ? n - i0 : LN_MULTI;
-    int max_blk = 0;
     for (int i = 0; i < cnt; ++i) {
       ASR_CHECK_ARG(workspaces[i0 + i] && dgamma[i0 + i] && dbeta[i0 + i] && rows[i0 + i] >= 0);
       a.ws[i] = workspaces[i0 + i]; a.dgamma[i] = dgamma[i0 + i]; a.dbeta[i] = dbeta[i0 + i];
       a.nblk[i] = (rows[i0 + i] + 7) / 8;                   // the first stage's 8 rows per block
-      if (a.nblk[i] > max_blk) max_blk = a.nblk[i];
     }
     a.D2 = 2 * D;
-    const int slices = max_blk >= 512 ? 64 : (max_blk >= 64 ? 16 : 1);
-    hipLaunchKernelGGL(ln_partial_reduce_multi_kernel, dim3((2 * D + 255) / 256, slices, cnt), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ln_partial_reduce_multi_kernel, dim3((2 * D + 255) / 256, cnt), dim3(1024), 0, s, a);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
