@@ -27,6 +27,11 @@ def test_library_loads_and_exports_header_symbols():
     assert h.asr_conv3x3_wgrad_workspace(32, 161, 800, 64, 64) == 510 * 9 * 64 * 64      # 33600 patches, 66 per workgroup
     assert h.asr_gemm_tn_workspace(6400, 2048, 512, 0, 1) == 8 * 64 * 16384      # pipelined 128 x 128 blocks: 64 blocks x 8 m-slices
     assert h.asr_gemm_tn_workspace(6400, 512, 512, 0, 1) == 8 * 64 * 4096         # 64 x 64 tiles: 64 tiles x 8 m-slices
+    # one-launch linear backward: m-slices of 16 stages of 64 rows, no empty slice, one 64 x 64 fp32 tile per (slice, tile)
+    assert h.asr_gemm_nn_tn_splits(6400, 0) == 7 and h.asr_gemm_nn_tn_splits(3200, 0) == 4 and h.asr_gemm_nn_tn_splits(37, 0) == 1
+    assert h.asr_gemm_nn_tn_splits(6400, 100) == 100 and h.asr_gemm_nn_tn_splits(100, 100) == 2
+    assert h.asr_gemm_nn_tn_workspace(6400, 512, 2048, 0) == 7 * 8 * 32 * 4096
+    assert h.asr_gemm_nn_tn_workspace(3200, 4364, 512, 0) == 4 * 69 * 8 * 4096
 
 
 def test_product_path_has_no_cpu_fallback():
