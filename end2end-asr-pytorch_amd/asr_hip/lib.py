@@ -7,7 +7,13 @@ import ctypes
 import os
 import re
 
-import torch
+# Kernel arguments of every launch (and of every node of a replayed hipGraph) in DEVICE memory: the runtime's default on this
+# stack, pinned here because the step is ~216 dependent launches -- with host-resident arguments every launch starts with a
+# PCIe read (measured with HIP_FORCE_DEV_KERNARG=0: 7.17 instead of 6.83 ms/step, profiles/r02_ab_kernarg.txt).  Read by the
+# HIP runtime when it initialises, i.e. at the first device call, which comes after this import.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+import torch  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libasr_hip.so")
