@@ -14,6 +14,10 @@ OBJ = os.path.join(HERE, "_obj")
 # softmax / epilogue code pays a v_accvgpr_read/write pair for every accumulator element it touches.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result",
          "-mllvm", "-amdgpu-mfma-vgpr-form=1"] + os.environ.get("ASR_HIPCC_EXTRA", "").split()    # e.g. -DASR_TUNE_ABLATE (tuning builds)
+# Per-file additions.  attention_pp.hip: with NaNs honoured every fmaxf() on an MFMA result is preceded by a canonicalising
+# v_max_f32 v, x, x (the row maximum of a score tile cost 55 vector instructions instead of 16 v_max3_f32); the kernel never
+# produces or consumes a NaN by construction (masked scores are -inf, the reference starts finite).
+PER_FILE_FLAGS = {"attention_pp.hip": ["-fno-honor-nans"]}
 
 
 def _hipcc():
@@ -31,6 +35,7 @@ def _digest():
                 h.update(f.encode())
                 h.update(open(os.path.join(root, f), "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(PER_FILE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -45,7 +50,7 @@ def build(force=False, verbose=False):
 
     def one(f):
         o = os.path.join(OBJ, f[:-4] + ".o")
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, f), "-o", o]
+        cmd = [hipcc] + FLAGS + PER_FILE_FLAGS.get(f, []) + ["-c", os.path.join(CSRC, f), "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s" % (f, r.stderr[-4000:]))

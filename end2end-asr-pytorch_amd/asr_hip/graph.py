@@ -86,7 +86,7 @@ class GraphedTrainStep:
         pred, gold, self.hyp_seq, self.gold_seq = self.model(self.src, self.src_len, self.tgt)
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
         loss.backward()
-        self._body_c()
+        self._body_c(guard=sums)                 # sums[0] = the loss sum: non-finite -> the update is skipped on the device
         return loss.detach(), sums
 
     # ------------------------------------------------------------------------------------------------ data parallel
@@ -121,11 +121,16 @@ class GraphedTrainStep:
             feats.backward(dfeats)
         ops.join_deferred()
 
-    def _body_c(self):
+    def _body_c(self, guard=None):
+        """(clip) + Noam/Adam.  `guard`: device scalar whose non-finiteness cancels the update (the reference trainer's
+        `if loss == inf: continue`, trainer/asr/trainer.py:102-104, for a step that cannot branch on the host); data parallel:
+        the all-reduced loss sum in the gradient buffer's stats slot, so every rank takes the same decision."""
         adam = self.opt.optimizer
         if self.clip is not None:
             adam.clip_grad_norm_(self.clip)
-        adam.step_device(self.factor_ms, float(self.opt.warmup), float(self.opt.min_lr), self.lr_dev)
+        if guard is None and self.red is not None:
+            guard = adam.flat.stats
+        adam.step_device(self.factor_ms, float(self.opt.warmup), float(self.opt.min_lr), self.lr_dev, guard=guard)
 
     def _exchange_a(self):
         return self.red.all_reduce_range(0, self._split)

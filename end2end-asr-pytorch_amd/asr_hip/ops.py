@@ -705,11 +705,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=None):
            float(eps), float(bc1), float(bc2), L.ptr(grad_scale), L.stream())
 
 
-def adam_noam_step(p, g, m, v, beta1, beta2, eps, factor_ms, warmup, min_lr, grad_scale=None, lr_out=None):
-    """Adam update whose step count / Noam lr / bias corrections come from step_state()[1] on the device."""
+def adam_noam_step(p, g, m, v, beta1, beta2, eps, factor_ms, warmup, min_lr, grad_scale=None, lr_out=None, guard=None):
+    """Adam update whose step count / Noam lr / bias corrections come from step_state()[1] on the device.  `guard`: optional
+    device scalar (the step's loss sum); a non-finite guard or gradient scale leaves parameters and moments untouched."""
     L.call("asr_adam_noam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(step_state(p.device)),
            float(beta1), float(beta2), float(eps), float(factor_ms), float(warmup), float(min_lr), L.ptr(grad_scale),
-           L.ptr(lr_out), L.stream())
+           L.ptr(lr_out), L.ptr(guard), L.stream())
 
 
 def sumsq_acc(g, acc):

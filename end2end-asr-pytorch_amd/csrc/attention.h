@@ -68,5 +68,7 @@ __device__ __forceinline__ int key_end(const AttnArgs& p, int b) {
 // fast path entry points (attention_fast.hip); return ASR_EUNSUPPORTED when the shape / layout is not theirs
 int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s);
 int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s);
+// long-sequence forward (attention_pp.hip): bf16, d = 64, no causal mask; the caller has checked fast_ok()
+int attn_pp_fwd(const AttnArgs& p, hipStream_t s);
 
 }  // namespace asr_attn

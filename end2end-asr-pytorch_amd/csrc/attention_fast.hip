@@ -857,6 +857,7 @@ bool fast_ok(const AttnArgs& p, int d, int dtype) {
 
 int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   if (!fast_ok(p, d, dtype) || (((uintptr_t)p.Out) & 7) != 0 || p.o_st % 4 != 0 || p.o_sb % 4 != 0) return ASR_EUNSUPPORTED;
+  if (!p.causal && p.Tk >= asr_tuning("ATTN_PP_MIN", 384) && asr_tuning("ATTN_PP", 1) != 0 && attn_pp_fwd(p, s) == ASR_OK) return ASR_OK;
   if (p.Tq <= asr_tuning("ATTN_SHORT", 256)) {
     const dim3 grid((unsigned)(((p.Tq + 63) / 64) * p.B * p.H));
     if (p.thr) attn_fwd_bf16_d64_kernel<1, true><<<grid, dim3(256), 0, s>>>(p);

@@ -177,7 +177,11 @@ __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, c
                                                         float* __restrict__ v, int64_t n4, int64_t n,
                                                         const uint64_t* __restrict__ state, float b1, float b2, float eps,
                                                         float factor_ms, float warmup, float min_lr,
-                                                        const float* __restrict__ gscale, float* __restrict__ lr_out) {
+                                                        const float* __restrict__ gscale, float* __restrict__ lr_out,
+                                                        const float* __restrict__ guard) {
+  const float gs = gscale ? *gscale : 1.f;
+  // a non-finite loss (or clipping coefficient) skips the whole update: the reference's `if loss == inf: continue`
+  if (!isfinite(gs) || (guard && !isfinite(*guard))) return;
   const double t = (double)state[1];
   const double w15 = pow((double)warmup, -1.5);
   const double sched = fmin(pow(t, -0.5), t * w15);
@@ -185,7 +189,6 @@ __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, c
   const float bc1 = (float)(1.0 - pow((double)b1, t));
   const float bc2_sqrt = sqrtf((float)(1.0 - pow((double)b2, t)));
   if (lr_out && blockIdx.x == 0 && threadIdx.x == 0) *lr_out = lr;
-  const float gs = gscale ? *gscale : 1.f;
   const float step = lr / bc1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -436,7 +439,7 @@ extern "C" int asr_step_advance(uint64_t* state, hipStream_t s) {
 
 extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
                                   float beta2, float eps, float factor_ms, float warmup, float min_lr, const float* gscale,
-                                  float* lr_out, hipStream_t s) {
+                                  float* lr_out, const float* guard, hipStream_t s) {
   ASR_CHECK_ARG(p && g && m && v && state && n >= 0 && warmup > 0.f);
   if (n == 0) return ASR_OK;
   ASR_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v));
@@ -445,7 +448,7 @@ extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, 
   if (blocks > 4096) blocks = 4096;
   AsrProfScope prof(ASR_OP_ADAM, s);
   hipLaunchKernelGGL(adam_noam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, n, state, beta1, beta2, eps,
-                     factor_ms, warmup, min_lr, gscale, lr_out);
+                     factor_ms, warmup, min_lr, gscale, lr_out, guard);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -224,6 +224,12 @@ class Decoder(nn.Module):
             x, _, _ = layer(x, encoder_padded_outputs, causal_only=True)
         return F_.LinearFn.apply(x, self.output_linear.weight, None, True, False)
 
+    def _kv_cache_supported(self):
+        """The incremental decoders (asr_hip/decode.py) read the full-rank projection weights of every layer; the Low-Rank
+        Transformer (--rank > 0: LowRankLinear holds .u / .v, no .weight) decodes by re-running the layer modules over the
+        prefix instead, like the reference's own loop."""
+        return all(isinstance(l.self_attn, MultiHeadAttention) and isinstance(l.encoder_attn, MultiHeadAttention) for l in self.layers)
+
     @torch.no_grad()
     def greedy_search(self, encoder_padded_outputs, beam_width=2, lm_rescoring=False, lm=None, lm_weight=0.1, c_weight=1,
                       use_cache=True):
@@ -235,6 +241,7 @@ class Decoder(nn.Module):
         step the same within the bf16 tolerance (tests/test_gpu_decode_fused.py)."""
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
+        use_cache = use_cache and self._kv_cache_supported()
         if use_cache == "eager":                      # cached, launches issued from Python per token
             from asr_hip.decode import greedy_search as cached_greedy
             toks = cached_greedy(self, encoder_padded_outputs, steps=300).cpu().tolist()
@@ -272,6 +279,7 @@ class Decoder(nn.Module):
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
         from asr_hip.decode import DecoderKVCache
+        use_cache = use_cache and self._kv_cache_supported()
         ids_out, strs_out = [], []
         max_len = encoder_padded_outputs.size(1)
         dev = encoder_padded_outputs.device

@@ -65,7 +65,10 @@ class _Pending:
         self.event.synchronize()
         loss_value = float(self.loss[0])
         if loss_value != loss_value or loss_value in (float("inf"), float("-inf")):
-            logging.info("non-finite loss: the step has already been applied")
+            # reference trainer.py:102-104 skips such a batch; a replayed step cannot branch on the host, so the device-side optimiser
+            # step cancelled itself (asr_adam_noam_step guard) and the batch is left out of the running loss here
+            logging.info("Found infinity loss, masking (the replayed step left weights and moments untouched)")
+            return None
         return (loss_value,) + Trainer._text_metrics(self.ids.tolist(), self.id2label)
 
 
@@ -191,6 +194,8 @@ class Trainer():
             pbar = tqdm(iter(feed), leave=True, total=len(train_loader), disable=not rank0)
             def account(r, i):
                 nonlocal total_loss, total_cer, total_wer, total_char, total_word, n_batches
+                if r is None:                    # a masked (non-finite) batch
+                    return
                 loss, cer, wer, chars, words = r
                 total_loss += loss; total_cer += cer; total_wer += wer; total_char += chars; total_word += words
                 n_batches += 1

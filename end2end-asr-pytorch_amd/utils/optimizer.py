@@ -159,7 +159,7 @@ class FusedAdam(torch.optim.Adam):
         P.bump_generation()          # masters were rewritten through the C ABI: weight shadows are stale
 
     @torch.no_grad()
-    def step_device(self, factor_ms, warmup, min_lr, lr_out=None):
+    def step_device(self, factor_ms, warmup, min_lr, lr_out=None, guard=None):
         """Graph-replayable step: step count, Noam lr and bias corrections are computed ON THE DEVICE from
         ops.step_state()[1] (advanced by ops.step_advance() at the top of the step).  Needs flat storage."""
         self._ensure_flat()
@@ -168,7 +168,7 @@ class FusedAdam(torch.optim.Adam):
         self._pre_step()
         b1, b2 = self.param_groups[0]['betas']
         ops.adam_noam_step(self.flat.data, self.flat.grad, self._m, self._v, b1, b2, self.param_groups[0]['eps'], factor_ms,
-                           warmup, min_lr, self.grad_scale, lr_out)
+                           warmup, min_lr, self.grad_scale, lr_out, guard)
         self.grad_scale = None
 
     def after_replay(self, n=1):

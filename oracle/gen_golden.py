@@ -236,6 +236,13 @@ BIG = {
                            "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "100",
                            "--src-max-len", "800", "--label-smoothing", "0.1", "--dropout", "0.0"],
                     V=4364, B=2, T=800, src_len=[800, 170], tgt_len=[99, 31], smoothing=0.1),
+    # configs[1] AS BENCHED: batch 32 (the kernel variants chosen only at this size -- 1700-tile data-gradient path,
+    # tn128p weight gradients, 128-row one-launch tiles -- meet the executed reference here, not only in op tests).  Ragged lengths.
+    "cfg1_b32": dict(flags=["--num-layers", "4", "--num-heads", "8", "--dim-model", "512", "--dim-key", "64", "--dim-value", "64",
+                            "--dim-inner", "2048", "--dim-emb", "512", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "100",
+                            "--src-max-len", "800", "--label-smoothing", "0.1", "--dropout", "0.0"],
+                     V=4364, B=32, T=800, src_len=[800 - 37 * (i % 9) if i else 800 for i in range(32)],
+                     tgt_len=[99 if i == 0 else 20 + (7 * i) % 79 for i in range(32)], smoothing=0.1),
     # configs[3]-shaped: emb_cnn, T=1600 -> T'=795, d512 h8 dk64, V=32, 2 encoder / 1 decoder layers (constructors: the CLI has
     # one --num-layers for both, reference utils/functions.py:148-151)
     "cfg3_shape": dict(flags=["--num-layers", "2", "--num-heads", "8", "--dim-model", "512", "--dim-key", "64", "--dim-value", "64",

@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import torch
 
-BIG_CASES = ["cfg0", "cfg1_b2", "cfg3_shape"]
+BIG_CASES = ["cfg0", "cfg1_b2", "cfg3_shape", "cfg1_b32"]
 
 
 def load(golden_dir, name):

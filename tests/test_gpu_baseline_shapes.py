@@ -7,6 +7,8 @@
   cfg0        BASELINE configs[0] exactly: 2-layer d256 h4 dk=64 vgg_cnn, B=4, T=800 -> T'=200, Td=100, V=4364
   cfg1_b2     configs[1] (the benched 4-layer d512 h8 dk=64 model) at B=2
   cfg3_shape  configs[3]-shaped: emb_cnn, T=1600 -> T'=795 (ragged), d512 h8 dk=64, V=32, 2 encoder / 1 decoder layers
+  cfg1_b32    configs[1] AS BENCHED: batch 32, ragged lengths (round 3: the kernel variants that are chosen only at this size -- the
+              1700-tile data-gradient path, tn128p weight gradients, 128-row one-launch tiles -- against the oracle, not only in op tests)
 
 dk=64 + bf16 runs attention_fast.hip, the 128x64 / tn128 GEMM tiles and the V=4364 -> 4416 padded vocabulary GEMM
 that the tiny goldens never reach.  Ragged lengths: source rows below T' and targets from 5 to 99 tokens.
@@ -28,9 +30,12 @@ multiples of those floors:
              DESIGN.md section 2).  That the imposed selections are legitimate is checked by the oracle's FORWARD under them:
              its logits must equal the free-running fp64 logits to 1e-6.  The error against the free-running fp64 gradient
              is reported next to it (parity json: grad_rel_l2_free).
-  bf16 mode: logits atol 4e-2*max|logit|; loss 2e-2; per-tensor gradient relative L2 error <= max(REL_BF16, 2*ebf);
-             arg-max equal wherever the reference's top-2 margin exceeds 8e-2*max|logit|.
-Measured values (every tensor) are written to gpurun_out/parity_r02.json and quoted in DESIGN.md section 2.
+             Also asserted: the error against the FREE-RUNNING fp64 gradient (the oracle's own selections) <= 5e-3 per tensor.
+  bf16 mode: logits atol 4e-2*max|logit|; loss 2e-2; per-tensor gradient relative L2 error <= max(REL_BF16, 1.5*ebf);
+             arg-max: checked on EVERY row -- a row may differ from the oracle's arg-max only if the oracle's top-2 margin on that
+             row is <= 2 x the measured max logit error of this run (north_star: "token-index argmax bit-exact"; a tie within the
+             arithmetic's own error is the only admissible difference); the number of such rows is reported.
+Measured values (every tensor) are written to gpurun_out/parity_r03.json and quoted in DESIGN.md section 2.
 """
 import json
 import os
@@ -43,7 +48,7 @@ import big_cases as BC
 
 pytestmark = pytest.mark.gpu
 
-REL_BF16 = 5e-2        # floor of the per-tensor bound ||g - g_64|| / ||g_64|| in bf16 mode (the bound is max(this, 2 * ebf[name]))
+REL_BF16 = 5e-2        # floor of the per-tensor bound ||g - g_64|| / ||g_64|| in bf16 mode (the bound is max(this, 1.5 * ebf[name]))
 _oracle_cache = {}
 _report = {}
 
@@ -98,7 +103,7 @@ def _oracle_under_selections(z, model, taps, src, src_len, tgt, ref):
 def _dump():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_r02.json"), "w") as f:
+    with open(os.path.join(out, "parity_r03.json"), "w") as f:
         json.dump(_report, f, indent=1, sort_keys=True)
 
 
@@ -143,7 +148,7 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
         truth, sel_logit_dev = _oracle_under_selections(z, model, taps, src, src_len, tgt, ref)
     rel = {k: BC.rel_l2(grads[k].numpy(), truth[k].numpy()) for k in grads if not BC.noise_driven(k, emb)}
     floor = {k: float(z[("e32/" if precision == "fp32" else "ebf/") + k]) for k in rel}
-    bound = {k: max(2e-4, 4 * floor[k]) if precision == "fp32" else max(REL_BF16, 2 * floor[k]) for k in rel}
+    bound = {k: max(2e-4, 4 * floor[k]) if precision == "fp32" else max(REL_BF16, 1.5 * floor[k]) for k in rel}
     worst = max(rel, key=lambda k: rel[k] / bound[k])
     perr64 = float((p.double() - ref["pred64"]).abs().max())
     summ = BC.summary_errors(z, pred, loss.item(), grads)
@@ -152,6 +157,10 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
     rm = ref["pred"].topk(2, dim=2).values
     sure = (rm[..., 0] - rm[..., 1]) > margin
     miss_o = int((hyp.cpu()[sure] != ref["hyp"][sure]).sum())
+    # every row: a difference from the oracle's arg-max is admissible only inside the run's own logit error
+    diff_rows = hyp.cpu() != ref["hyp"]
+    n_diff = int(diff_rows.sum())
+    worst_diff_margin = float((rm[..., 0] - rm[..., 1])[diff_rows].max()) if n_diff else 0.0
     opt.step()
     _, _, _, loss2, _ = step()
     l2err = abs(loss2.item() - ref_loss2)
@@ -167,6 +176,7 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
         "grad_rel_l2_free": {k: rel_free[k] for k in sorted(rel_free, key=lambda k: -rel_free[k])[:12]},
         "oracle_logit_shift_under_product_selections": sel_logit_dev,
         "argmax_rows_checked": nsure, "argmax_mismatch_vs_reference": miss, "argmax_mismatch_vs_oracle": miss_o,
+        "argmax_rows_total": int(diff_rows.numel()), "argmax_rows_differing": n_diff, "argmax_worst_margin_of_a_differing_row": worst_diff_margin,
         "ref_summary_pred_sub": summ["pred_sub"], "ref_summary_gs_worst": max(v for k, v in summ["gs"].items() if not BC.noise_driven(k, emb)),
         "num_correct": int(ncorrect), "lr1": opt._rate}
     _dump()
@@ -177,12 +187,14 @@ def test_product_matches_oracle_and_reference_at_baseline_shape(golden_dir, name
         assert perr <= 5e-5 * max(1.0, amax), perr
         assert lerr < 2e-5 and l2err < 1e-4, (lerr, l2err)
         assert rel[worst] <= bound[worst], (worst, rel[worst], bound[worst])
+        assert max(rel_free.values()) <= 5e-3, max(rel_free.items(), key=lambda kv: kv[1])
         assert summ["pred_sub"] <= 1e-4 and abs(loss2.item() - float(z["loss2"])) < 1e-4
     else:
         assert perr <= 4e-2 * amax, (perr, amax)
         assert lerr < 2e-2 and l2err < 3e-2, (lerr, l2err)
         assert rel[worst] <= bound[worst], (worst, rel[worst], bound[worst])
     assert miss == 0 and miss_o == 0 and nsure > (20 if precision == "fp32" else 5), (miss, miss_o, nsure)
+    assert worst_diff_margin <= 2 * perr + 1e-12, (n_diff, worst_diff_margin, perr)
 
 
 def test_graph_replay_equals_eager_at_dk64_bf16(golden_dir):

@@ -66,6 +66,32 @@ def test_graph_replay_changes_dropout_masks(golden_dir):
         assert torch.equal(v, w[k]), k            # lr = 0: nothing moves
 
 
+def test_graph_replay_skips_a_batch_with_non_finite_loss(golden_dir):
+    """one overflowing batch must not poison weights or Adam moments under --graph-buckets.  A replay on a batch holding
+    an inf leaves every parameter and both moments bit-identical (the reference skips such a batch, trainer.py:102-104); the next
+    finite batch trains normally."""
+    from asr_hip.graph import GraphedTrainStep
+    z, args, m, o = build(golden_dir, "vgg_tiny", "fp32")
+    src, src_len, tgt = _batch(z)
+    gs = GraphedTrainStep(m, o, float(z["smoothing"]), src, src_len, tgt, warmup_steps=1)
+    adam = o.optimizer
+    core = m.module if hasattr(m, "module") else m
+    wout = core.decoder.output_linear.weight
+    keep = float(wout.data[5, 7])
+    wout.data[5, 7] = float("inf")               # an overflowed logit column: the loss of this step cannot be finite
+    w = adam.flat.data.clone(); m1 = adam._m.clone(); v1 = adam._v.clone()
+    loss, _ = gs(src, src_len, tgt)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(loss).all()
+    assert torch.equal(adam.flat.data, w) and torch.equal(adam._m, m1) and torch.equal(adam._v, v1)
+    wout.data[5, 7] = keep
+    w = adam.flat.data.clone()
+    loss, _ = gs(src, src_len, tgt)
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss).all() and not torch.equal(adam.flat.data, w)
+    assert torch.isfinite(adam.flat.data).all() and torch.isfinite(adam._m).all()
+
+
 @pytest.mark.parametrize("case", ["vgg_tiny", "emb_tiny"])
 def test_graph_replay_with_dropout_equals_eager_at_the_same_seed_counter(golden_dir, case):
     """The benched path -- dropout > 0 under hipGraph replay -- against the eager launch sequence: the dropout masks are a pure

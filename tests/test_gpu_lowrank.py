@@ -151,3 +151,28 @@ def test_lowrank_fp8_forward_close_to_bf16():
           % (d, amax, outs["fp8"][1], outs["bf16"][1], outs["fp8"][2], outs["bf16"][2]))
     assert d > 0 and d <= 0.15 * amax and abs(outs["fp8"][1] - outs["bf16"][1]) < 5e-2
     assert np.isfinite(outs["fp8"][2]) and abs(outs["fp8"][2] - outs["bf16"][2]) < 0.3 * outs["bf16"][2]
+
+
+def test_lowrank_model_decodes(monkeypatch):
+    """a --rank > 0 checkpoint must go through Transformer.evaluate (greedy and beam) -- the KV-cached decoders read
+    full-rank .weight tensors that LowRankLinear does not have, so the low-rank model decodes by re-running the layer modules over
+    the prefix (Decoder._kv_cache_supported).  Same strings whether the caller asks for the cache or not."""
+    from utils import constant
+    from utils.functions import init_transformer_model
+    flags = [f if f != "24" else "301" for f in FLAGS]
+    args = constant.parse(flags + ["--precision", "fp32", "--cuda"])
+    V = 40
+    chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(V - 3)]
+    l2i = {c: i for i, c in enumerate(chars)}
+    torch.manual_seed(7)
+    model = init_transformer_model(args, l2i, {i: c for c, i in l2i.items()}).cuda().eval()
+    assert not model.decoder._kv_cache_supported()
+    src, src_len, tgt = _batch(V)
+    _, hyp_greedy, gold = model.evaluate(src.cuda(), src_len, tgt.cuda())
+    assert len(hyp_greedy) == 3 and len(gold) == 3
+    feats = model._features(src.cuda())
+    enc_out, _ = model.encoder(feats, src_len)
+    assert model.decoder.greedy_search(enc_out, use_cache=False) == hyp_greedy
+    assert model.decoder.greedy_search(enc_out, use_cache="graph") == hyp_greedy
+    _, hyp_beam, _ = model.evaluate(src.cuda(), src_len, tgt.cuda(), beam_search=True, beam_width=2, beam_nbest=1)
+    assert len(hyp_beam) == 3

@@ -510,6 +510,27 @@ def test_adam_matches_oracle(ops):
     assert abs(acc.sqrt().item() - nrm) < 1e-3 * nrm and abs(coef.item() - min(1.0, 0.5 / (nrm + 1e-6))) < 1e-6
 
 
+def test_device_side_step_is_cancelled_by_a_non_finite_guard(ops):
+    """asr_adam_noam_step(guard_dev): a non-finite loss sum (or gradient scale) leaves parameters and both moments untouched --
+    the reference trainer's `if loss == inf: continue` (trainer/asr/trainer.py:102-104) for a step replayed from a hipGraph."""
+    from asr_hip import ops as O
+    D = dev()
+    n = 1001
+    g = torch.Generator().manual_seed(5)
+    p = torch.randn(n, generator=g).to(D); grad = torch.randn(n, generator=g).to(D)
+    m = torch.rand(n, generator=g).to(D); v = torch.rand(n, generator=g).to(D)
+    O.step_state(D)[1] = 3
+    for bad in (float("inf"), float("nan"), float("-inf")):
+        p0, m0, v0 = p.clone(), m.clone(), v.clone()
+        O.adam_noam_step(p, grad, m, v, 0.9, 0.98, 1e-9, 0.01, 4000.0, 1e-5, guard=torch.tensor([bad, 1.0], device=D))
+        assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0), bad
+        O.adam_noam_step(p, grad, m, v, 0.9, 0.98, 1e-9, 0.01, 4000.0, 1e-5, grad_scale=torch.tensor([bad], device=D))
+        assert torch.equal(p, p0) and torch.equal(m, m0) and torch.equal(v, v0), bad
+    p0 = p.clone()
+    O.adam_noam_step(p, grad, m, v, 0.9, 0.98, 1e-9, 0.01, 4000.0, 1e-5, guard=torch.tensor([2.5, 1.0], device=D))
+    assert not torch.equal(p, p0)
+
+
 # ------------------------------------------------------------------------------------------------ conv front end
 def nhwc(x):       # (B,C,H,W) -> (B,H,W,C)
     return x.permute(0, 2, 3, 1).contiguous()
@@ -723,6 +744,36 @@ def test_gpu_spectrogram_matches_host_convention(ops):
     raw, _ = ops.log_spectrogram(torch.from_numpy(wav[:2]).to(D), torch.tensor(lens[:2], dtype=torch.int32, device=D), normalize=False)
     ref = log_spectrogram(wav[1, :lens[1]], normalize=False)
     np.testing.assert_allclose(raw[1, 0, :, :ref.shape[1]].cpu().numpy(), ref, rtol=0, atol=1e-4)
+
+
+def test_gpu_spectrogram_matches_scipy_restatement_and_known_answer(ops):
+    """The GPU front end against the two independent pins of the convention (tests/test_host.py): the scipy.signal.stft restatement of
+    SpectrogramParser.parse_audio (reference utils/data_loader.py:72-89) on ragged noise, and the hand-computed impulse spectrogram
+    (symmetric Hamming w[k] = 0.54 - 0.46 cos(2 pi k / 319), reflect centring, hop 160, log1p) -- no FFT library on that side."""
+    import test_host as TH
+    rng = np.random.RandomState(11)
+    lens = [4807, 16000, 321]
+    wav = np.zeros((4, max(lens)), dtype=np.float32)
+    for i, n in enumerate(lens):
+        wav[i, :n] = (0.1 * rng.randn(n)).astype(np.float32)
+    y, exp = TH.spectrogram_known_answer()
+    wav[3, :y.size] = y
+    lens.append(int(y.size))
+    D = dev()
+    for norm in (False, True):
+        sp, nfr = ops.log_spectrogram(torch.from_numpy(wav).to(D), torch.tensor(lens, dtype=torch.int32, device=D), normalize=norm)
+        sp = sp.cpu().numpy()
+        for i, n in enumerate(lens[:3]):
+            ref = TH._scipy_spectrogram(wav[i, :n], norm)
+            assert int(nfr[i]) == ref.shape[1] == 1 + n // 160
+            np.testing.assert_allclose(sp[i, 0, :, :ref.shape[1]], ref, rtol=0, atol=2e-4 * max(1.0, np.abs(ref).max()), err_msg="%d %s" % (n, norm))
+        assert int(nfr[3]) == 3
+        if not norm:
+            np.testing.assert_allclose(sp[3, 0, :, :3], exp, rtol=0, atol=2e-5)
+        else:
+            mean = exp.sum() / exp.size
+            std = np.sqrt(((exp - mean) ** 2).sum() / (exp.size - 1))
+            np.testing.assert_allclose(sp[3, 0, :, :3], (exp - mean) / std, rtol=0, atol=2e-4)
 
 
 def test_device_prefetcher_delivers_device_batches():
