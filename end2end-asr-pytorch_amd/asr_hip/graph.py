@@ -189,6 +189,12 @@ class GraphedTrainStep:
             sl = torch.as_tensor(src_len)
             if not (sl.is_cuda and sl.data_ptr() == self.src_len.data_ptr()):
                 self.src_len.copy_(sl.to(torch.int32), non_blocking=True)
+        flat = self.opt.optimizer.flat
+        if getattr(self.opt.optimizer, "_shadow_by_step", False) and flat.shadow_is_stale(torch.bfloat16):
+            # a master was rewritten through torch between replays (checkpoint load, a test's poke): the captured forward reads the
+            # bf16 shadow the previous step's optimiser launch wrote, so refresh it here, outside the graph
+            ops.cast_flat(flat.data, flat.shadow_for_step(torch.bfloat16))
+            flat.mark_shadow_fresh(torch.bfloat16)
         self._replay()
         self._host_after()
         return self.loss, self.sums

@@ -80,7 +80,7 @@ _SIGS = {
     "asr_ce_bwd": (_I, [_P, _L, _P, _P, _I, _I, _F, _I, _P, _P, _P, _L, _I, _P]),
     "asr_adam_step": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _F, _P, _P]),
     "asr_step_advance": (_I, [_P, _P]),
-    "asr_adam_noam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "asr_adam_noam_step": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P]),
     "asr_sumsq_acc": (_I, [_P, _L, _P, _P]),
     "asr_clip_coef": (_I, [_P, _F, _P, _P]),
     "asr_grad_coef": (_I, [_P, _F, _P, _P, _P]),
@@ -139,7 +139,7 @@ def load():
 TUNING_NAMES = ("ATTN_GENERIC", "IGEMM_TH", "IGEMM_TPS", "IGEMM_WBUF", "CONV1_WGRAD_MFMA", "IGEMM_ABLATE", "C64", "CONV_POOL",
                 "WGRAD_ABLATE", "WGRAD_DMA", "CONV1_WGRAD_WGS", "C64_PER_CU", "C64_ABLATE", "C64_SHAPE", "GEMM_NS", "GEMM_TILE",
                 "GEMM_GENERIC", "TN_WGS", "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG", "TN_PIPE", "TN_PIPE_MIN", "GEMM_ABLATE", "ATTN_SHORT", "ATTN_SHORT_BWD", "ATTN_BOTH", "NNTN_STAGES", "ATTN_PIPE",
-                "ATTN_PP", "ATTN_PP_MIN", "ATTN_PP_TAIL", "ATTN_PP_PRIO")
+                "ATTN_PP", "ATTN_PP_MIN", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_WAVES")
 
 
 def _forward_env_tuning(lib):

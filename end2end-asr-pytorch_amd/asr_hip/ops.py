@@ -705,12 +705,14 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=None):
            float(eps), float(bc1), float(bc2), L.ptr(grad_scale), L.stream())
 
 
-def adam_noam_step(p, g, m, v, beta1, beta2, eps, factor_ms, warmup, min_lr, grad_scale=None, lr_out=None, guard=None):
+def adam_noam_step(p, g, m, v, beta1, beta2, eps, factor_ms, warmup, min_lr, grad_scale=None, lr_out=None, guard=None, shadow=None):
     """Adam update whose step count / Noam lr / bias corrections come from step_state()[1] on the device.  `guard`: optional
-    device scalar (the step's loss sum); a non-finite guard or gradient scale leaves parameters and moments untouched."""
+    device scalar (the step's loss sum); a non-finite guard or gradient scale leaves parameters and moments untouched.  `shadow`:
+    optional bf16 tensor of p's size that receives the rounded new parameters (the flat compute-dtype shadow)."""
+    assert shadow is None or (shadow.dtype == torch.bfloat16 and shadow.numel() == p.numel())
     L.call("asr_adam_noam_step", L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(step_state(p.device)),
            float(beta1), float(beta2), float(eps), float(factor_ms), float(warmup), float(min_lr), L.ptr(grad_scale),
-           L.ptr(lr_out), L.ptr(guard), L.stream())
+           L.ptr(lr_out), L.ptr(guard), L.ptr(shadow), L.stream())
 
 
 def sumsq_acc(g, acc):

@@ -196,5 +196,25 @@ class FlatParams:
             ent[2] = {id(q): q._version for q in self.params}
         return ent[0][off:off + p.numel()]
 
+    def shadow_for_step(self, dtype):
+        """The flat compute-dtype shadow as a destination for the optimiser kernel (asr_adam_noam_step writes the rounded new
+        parameters into it); mark_shadow_fresh() afterwards."""
+        ent = self._shadow.get(dtype)
+        if ent is None:
+            ent = [torch.empty(self.total, device=self.data.device, dtype=dtype), -1, {}]
+            self._shadow[dtype] = ent
+        return ent[0]
+
+    def mark_shadow_fresh(self, dtype):
+        ent = self._shadow.get(dtype)
+        if ent is not None:
+            ent[1] = _state["generation"]
+            ent[2] = {id(q): q._version for q in self.params}
+
+    def shadow_is_stale(self, dtype):
+        """True when a master was modified through torch since the shadow was written (a replayed graph cannot notice)."""
+        ent = self._shadow.get(dtype)
+        return ent is not None and any(ent[2].get(id(q)) != q._version for q in self.params)
+
     def zero_grad(self):
         self.grad_all.zero_()

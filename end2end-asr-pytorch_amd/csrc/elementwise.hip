@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, c
                                                         const uint64_t* __restrict__ state, float b1, float b2, float eps,
                                                         float factor_ms, float warmup, float min_lr,
                                                         const float* __restrict__ gscale, float* __restrict__ lr_out,
-                                                        const float* __restrict__ guard) {
+                                                        const float* __restrict__ guard, bf16_t* __restrict__ shadow) {
   const float gs = gscale ? *gscale : 1.f;
   // a non-finite loss (or clipping coefficient) skips the whole update: the reference's `if loss == inf: continue`
   if (!isfinite(gs) || (guard && !isfinite(*guard))) return;
@@ -205,6 +205,9 @@ __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, c
     reinterpret_cast<float4*>(p)[i] = pp;
     reinterpret_cast<float4*>(m)[i] = mm;
     reinterpret_cast<float4*>(v)[i] = vv;
+    // the bf16 shadow every GEMM of the next step reads, written here instead of by a cast pass over the masters
+    if (shadow) reinterpret_cast<uint2*>(shadow)[i] = make_uint2((uint32_t)f32_to_bf16(pp.x) | ((uint32_t)f32_to_bf16(pp.y) << 16),
+                                                                 (uint32_t)f32_to_bf16(pp.z) | ((uint32_t)f32_to_bf16(pp.w) << 16));
   }
   const int64_t tail = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tail < n) {
@@ -212,7 +215,9 @@ __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, c
     const float mo = b1 * m[tail] + (1.f - b1) * gj;
     const float vo = b2 * v[tail] + (1.f - b2) * gj * gj;
     m[tail] = mo; v[tail] = vo;
-    p[tail] -= step * (mo / (sqrtf(vo) / bc2_sqrt + eps));
+    const float pn = p[tail] - step * (mo / (sqrtf(vo) / bc2_sqrt + eps));
+    p[tail] = pn;
+    if (shadow) shadow[tail] = f32_to_bf16(pn);
   }
 }
 template <typename T>
@@ -439,16 +444,16 @@ extern "C" int asr_step_advance(uint64_t* state, hipStream_t s) {
 
 extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
                                   float beta2, float eps, float factor_ms, float warmup, float min_lr, const float* gscale,
-                                  float* lr_out, const float* guard, hipStream_t s) {
+                                  float* lr_out, const float* guard, void* shadow_bf16, hipStream_t s) {
   ASR_CHECK_ARG(p && g && m && v && state && n >= 0 && warmup > 0.f);
   if (n == 0) return ASR_OK;
-  ASR_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v));
+  ASR_CHECK_ARG(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow_bf16 || (((uintptr_t)shadow_bf16) & 7) == 0));
   const int64_t n4 = n / 4;
   int64_t blocks = ceil_div64(n4 > 0 ? n4 : 1, 256);
   if (blocks > 4096) blocks = 4096;
   AsrProfScope prof(ASR_OP_ADAM, s);
   hipLaunchKernelGGL(adam_noam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n4, n, state, beta1, beta2, eps,
-                     factor_ms, warmup, min_lr, gscale, lr_out, guard);
+                     factor_ms, warmup, min_lr, gscale, lr_out, guard, static_cast<bf16_t*>(shadow_bf16));
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

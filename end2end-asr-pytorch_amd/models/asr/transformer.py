@@ -241,7 +241,8 @@ class Decoder(nn.Module):
         step the same within the bf16 tolerance (tests/test_gpu_decode_fused.py)."""
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
-        use_cache = use_cache and self._kv_cache_supported()
+        if not self._kv_cache_supported():
+            use_cache = False
         if use_cache == "eager":                      # cached, launches issued from Python per token
             from asr_hip.decode import greedy_search as cached_greedy
             toks = cached_greedy(self, encoder_padded_outputs, steps=300).cpu().tolist()
@@ -279,7 +280,8 @@ class Decoder(nn.Module):
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
         from asr_hip.decode import DecoderKVCache
-        use_cache = use_cache and self._kv_cache_supported()
+        if not self._kv_cache_supported():
+            use_cache = False
         ids_out, strs_out = [], []
         max_len = encoder_padded_outputs.size(1)
         dev = encoder_padded_outputs.device

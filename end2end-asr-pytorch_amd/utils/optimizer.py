@@ -167,8 +167,11 @@ class FusedAdam(torch.optim.Adam):
             raise RuntimeError("step_device needs the parameters on a GPU")
         self._pre_step()
         b1, b2 = self.param_groups[0]['betas']
+        # bf16 compute: the step itself writes the flat bf16 shadow the next step's GEMMs read (no cast pass over the masters)
+        shadow = self.flat.shadow_for_step(torch.bfloat16) if ops.compute_dtype() == torch.bfloat16 else None
         ops.adam_noam_step(self.flat.data, self.flat.grad, self._m, self._v, b1, b2, self.param_groups[0]['eps'], factor_ms,
-                           warmup, min_lr, self.grad_scale, lr_out, guard)
+                           warmup, min_lr, self.grad_scale, lr_out, guard, shadow)
+        self._shadow_by_step = shadow is not None
         self.grad_scale = None
 
     def after_replay(self, n=1):
@@ -177,6 +180,8 @@ class FusedAdam(torch.optim.Adam):
         for p in self.flat.params:
             self.state[p]['step'] += n
         P.bump_generation()
+        if getattr(self, "_shadow_by_step", False):
+            self.flat.mark_shadow_fresh(torch.bfloat16)       # written by the step that this call accounts for
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

@@ -282,11 +282,13 @@ int asr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * through its `seed_dev` argument (NULL = host seed only).  guard_dev (optional device scalar, e.g. the step's loss sum): when it
  * or the gradient scale is not finite the launch changes NOTHING -- parameters and both moments keep their values -- which is
  * the reference trainer's `if loss == inf: continue` (trainer/asr/trainer.py:102-104) for a step that is replayed from a graph
- * and cannot branch on the host.                                                                                     */
+ * and cannot branch on the host.  shadow_bf16 (optional, n elements): receives the updated parameters rounded to bf16 -- the
+ * compute-dtype copy the next step's GEMMs read -- so that no separate cast pass over the masters is needed.            */
 int asr_step_advance(uint64_t* state, asr_stream_t stream);
 int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
                        float beta2, float eps, float factor_ms, float warmup, float min_lr,
-                       const float* grad_scale_dev, float* lr_out, const float* guard_dev, asr_stream_t stream);
+                       const float* grad_scale_dev, float* lr_out, const float* guard_dev, void* shadow_bf16,
+                       asr_stream_t stream);
 /* row_keep[b*T + t] = t < lengths[b]: the encoder's non_pad_mask (common_layers.py:33-38 via transformer.py:168)     */
 int asr_length_mask(const int32_t* lengths, int B, int T, uint8_t* row_keep, asr_stream_t stream);
 /* out[0] = num[0] / den[0]: the mean over non-PAD tokens (utils/metrics.py:127-130) from asr_ce_fwd's sums            */
