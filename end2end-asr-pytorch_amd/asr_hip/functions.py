@@ -76,11 +76,20 @@ def _dgrad(dy2d, wparam, dx_out=None, accumulate=False, relu_mask=None):
 
 def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_dx=True, relu_mask=None):
     """dy2d (M,N[p]) and x2d (M,K) in the compute dtype.  Accumulates dW / db, returns dx = dy W (M,K) or None."""
+    N, K = wparam.shape[0], wparam.numel() // wparam.shape[0]
+    defer = ops.defer_wgrad_now(dy2d.dtype) and ops.gemm_tn_supported(dy2d, x2d) and x2d.dtype == dy2d.dtype
     if not need_dx:
-        _wgrad_bias(dy2d, x2d, wparam, bparam)
+        if defer:
+            ops.queue_wgrad(dy2d, x2d, P.grad_of(wparam).view(N, K), P.grad_of(bparam) if bparam is not None else None, N, K)
+        else:
+            _wgrad_bias(dy2d, x2d, wparam, bparam)
         return None
     W = P.linear_weight(wparam)
-    N, K = wparam.shape[0], wparam.numel() // wparam.shape[0]
+    if defer and W.shape[1] == K and ops.gemm_nn_supported(dy2d, W):
+        # data gradient now (it is what the rest of backward waits for), weight gradient with the other layers' at the end
+        dx = ops.gemm_nn(dy2d, W, out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
+        ops.queue_wgrad(dy2d, x2d, P.grad_of(wparam).view(N, K), P.grad_of(bparam) if bparam is not None else None, N, K)
+        return dx
     if W.shape[1] == K and ops.gemm_nn_tn_supported(dy2d, W, x2d):      # graph capture, bf16: dX and dW workgroups in ONE launch
         return ops.gemm_nn_tn(dy2d, W, x2d, P.grad_of(wparam).view(N, K), P.grad_of(bparam) if bparam is not None else None,
                               out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
@@ -124,6 +133,11 @@ class _Fused:
 
     def bwd(self, dy2d, x2d, dx_out=None, accumulate=False, need_dx=True):
         g = self.w_grad.view(self.N, self.K)
+        if (ops.defer_wgrad_now(dy2d.dtype) and ops.gemm_tn_supported(dy2d, x2d) and x2d.dtype == dy2d.dtype and
+                (not need_dx or ops.gemm_nn_supported(dy2d, self.W))):
+            dx = ops.gemm_nn(dy2d, self.W, out=dx_out, accumulate=accumulate) if need_dx else None
+            ops.queue_wgrad(dy2d, x2d, g, self.b_grad, self.N, self.K)
+            return dx
         if need_dx and ops.gemm_nn_tn_supported(dy2d, self.W, x2d):
             return ops.gemm_nn_tn(dy2d, self.W, x2d, g, self.b_grad, out=dx_out, accumulate=accumulate)
         ops.join_if_pending_reads(dx_out)
@@ -370,6 +384,7 @@ class EncInFn(Function):
         dout2 = dout.reshape(B * T, -1).contiguous()
         dz, _ = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, None, P.grad_of(gamma), P.grad_of(beta))
         dx = _linear_bwd(dz, x2, Win, bin_, need_dx=ctx.need_dx)
+        ops.flush_wgrads()                      # the transformer's backward ends here: every queued weight gradient in grouped launches
         P.grad_ready(*ctx.params)
         if dx is not None:
             dx = dx.view(B, T, Din).to(ctx.in_dtype)

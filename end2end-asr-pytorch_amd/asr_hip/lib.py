@@ -40,6 +40,7 @@ _SIGS = {
     "asr_gemm_nt": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _I, _I, _I, _F, _I, _I, _I, _I, _P]),
     "asr_gemm_tn_workspace": (_L, [_I, _I, _I, _I, _I]),
     "asr_gemm_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
+    "asr_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "asr_gemm_nn": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _I, _I, _I, _P]),
     "asr_gemm_nn_tn_splits": (_I, [_I, _I]),
     "asr_gemm_nn_tn_workspace": (_L, [_I, _I, _I, _I]),
@@ -139,7 +140,7 @@ def load():
 TUNING_NAMES = ("ATTN_GENERIC", "IGEMM_TH", "IGEMM_TPS", "IGEMM_WBUF", "CONV1_WGRAD_MFMA", "IGEMM_ABLATE", "C64", "CONV_POOL",
                 "WGRAD_ABLATE", "WGRAD_DMA", "CONV1_WGRAD_WGS", "C64_PER_CU", "C64_ABLATE", "C64_SHAPE", "GEMM_NS", "GEMM_TILE",
                 "GEMM_GENERIC", "TN_WGS", "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG", "TN_PIPE", "TN_PIPE_MIN", "GEMM_ABLATE", "ATTN_SHORT", "ATTN_SHORT_BWD", "ATTN_BOTH", "NNTN_STAGES", "ATTN_PIPE",
-                "ATTN_PP", "ATTN_PP_MIN", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_WAVES")
+                "ATTN_PP", "ATTN_PP_MIN", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "TN_GROUP_STAGES")
 
 
 def _forward_env_tuning(lib):

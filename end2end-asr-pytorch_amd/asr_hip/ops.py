@@ -113,9 +113,55 @@ def join_if_pending_reads(t):
                 return
 
 
+# ---- deferred, grouped weight gradients.  Only a linear layer's DATA gradient feeds the rest of backward; its weight gradient is a
+# latency-bound chain of 16 - 64 blocks when launched alone.  While a hipGraph is being captured (bf16, no data-parallel reducer
+# waiting for per-layer gradients) the layers' (dy, x) pairs are queued and contracted by ONE launch per 16 layers at the end of the
+# transformer's backward (asr_gemm_tn_grouped).  ASR_DEFER_WGRAD=0 restores the per-layer launches.
+_defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
+_wgrad_q = []
+WGRAD_GROUP = 16
+
+
+def defer_wgrad_now(dtype=None):
+    if not _defer_wgrad or not torch.cuda.is_current_stream_capturing() or (dtype or compute_dtype()) != torch.bfloat16:
+        return False
+    from . import params as P_
+    r = P_._state["reducer"]
+    return r is None or not getattr(r, "active", False)
+
+
+def queue_wgrad(dy, x, dw, db, N, K):
+    """dw (N,K) fp32 += dy[:, :N]^T x[:, :K] and db (N) += column sums of dy, later (flush_wgrads).  dy and x stay referenced by the
+    queue: the caller must not write to them afterwards."""
+    assert gemm_tn_supported(dy, x) and dw.dtype == torch.float32 and dw.stride(1) == 1
+    _wgrad_q.append((dy, x, dw, db, int(N), int(K)))
+    if len(_wgrad_q) >= WGRAD_GROUP:
+        flush_wgrads()
+
+
+def flush_wgrads():
+    import ctypes
+    while _wgrad_q:
+        grp = _wgrad_q[:WGRAD_GROUP]
+        del _wgrad_q[:WGRAD_GROUP]
+        n = len(grp)
+        P_, L_, I_ = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+        rc = L.load().asr_gemm_tn_grouped(
+            n, P_(*[e[0].data_ptr() for e in grp]), L_(*[e[0].stride(0) for e in grp]), P_(*[e[1].data_ptr() for e in grp]),
+            L_(*[e[1].stride(0) for e in grp]), P_(*[e[2].data_ptr() for e in grp]), L_(*[e[2].stride(0) for e in grp]),
+            P_(*[(e[3].data_ptr() if e[3] is not None else None) for e in grp]), I_(*[e[0].shape[0] for e in grp]),
+            I_(*[e[4] for e in grp]), I_(*[e[5] for e in grp]), L.dt(grp[0][0]), L.stream())
+        if rc == L.EUNSUPPORTED:
+            for dy, x, dw, db, N, K in grp:
+                gemm_tn(dy, x, dw, colsum_acc=db, N=N, K=K)
+        else:
+            L.check(rc, "asr_gemm_tn_grouped")
+
+
 def join_deferred():
     """Main stream waits for everything deferred on the second stream (called before anything reads the weight gradients
     and at the end of every captured graph body)."""
+    flush_wgrads()
     if _side["pending"] and _side["stream"] is not None:
         torch.cuda.current_stream().wait_stream(_side["stream"])
     _side["pending"] = []
@@ -310,11 +356,12 @@ def add_ln_fwd(y, residual, gamma, beta, post_add=None, row_keep=None, eps=1e-5,
 
 
 def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=0):
-    """Returns (d_res, d_y); d_y is d_res itself when p == 0."""
+    """Returns (d_res, d_y); d_y is d_res itself when p == 0 (unless weight gradients are being deferred)."""
     M, D = z.shape
     assert dout.is_contiguous() and z.is_contiguous()
     d_res = torch.empty_like(z)
-    d_y = torch.empty_like(z) if p > 0 else d_res
+    # (deferred weight gradients keep d_y until the end of backward while d_res goes on accumulating: never the same buffer then)
+    d_y = torch.empty_like(z) if (p > 0 or defer_wgrad_now(z.dtype)) else d_res
     n_ws = L.load().asr_add_ln_bwd_workspace(M, D)
     ws = torch.empty(n_ws, device=z.device, dtype=torch.float32)       # caching allocator: no cost after the first step
     if _ln_multi and D % 2 == 0 and torch.cuda.is_current_stream_capturing():

@@ -7,7 +7,8 @@
 //     a 64-key tile sit in its own registers -> row maximum and row sum are lane-local (one v_permlane32_swap per tile for the
 //     maximum, none for the sum until the epilogue), and the register -> key map of an S^T block IS the k order of the second
 //     contraction, so P goes from the softmax straight into the MFMA operand (no LDS, no lane permutes);
-//   * Q is pre-scaled by scale * log2(e) once per wave, probabilities are exp2(s - m): sub + exp per score, nothing else;
+//   * the S^T accumulators start at -reference instead of 0, so a probability is exp2(c2 * s): half a packed multiply and one
+//     v_exp_f32 per score, no subtraction;
 //   * the running maximum is only moved when a tile's maximum exceeds it by more than 2^THR (wave-uniform branch): the O(d) rescale
 //     of the accumulators leaves the tile loop; everything still at the old maximum (O and l) is rescaled at that one point, before
 //     the tile's probabilities are formed, and the previous tile's P V is complete by then;
@@ -31,7 +32,6 @@ constexpr int KT = 64;                     // keys per tile
 constexpr int TILE = KT * ROWB;            // 8 KB
 constexpr int NS = 3;                      // ring depth
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
 constexpr float THR = 8.f;                 // deferred maximum: P <= 2^THR
 constexpr float M_INIT = -1e30f;
 
@@ -171,9 +171,13 @@ __device__ __forceinline__ void read_v(uint4 (&vf)[2][2][2], unsigned stage, con
 __device__ __forceinline__ int key_of(int kb, int r, int half) { return kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // Per-lane softmax state of one query.  Scores leave the first contraction already RELATIVE to the reference `ref` (the accumulators
-// of S^T start at nref = -ref in every register instead of 0), so a probability is one v_exp_f32.  `ref` follows the running
-// maximum lazily: it moves when a tile's maximum exceeds it by more than 2^THR, or at the first tile that has a live key
-// (`gate` = -FLT_MAX until then, THR afterwards: one compare covers both).  nref is 0 until then, never -(-inf).
+// of S^T start at nref = -ref in every register instead of 0): a probability is exp2(c2 * s), one packed multiply per two scores and
+// one v_exp_f32 per score.  `ref` (raw score units) follows the running maximum lazily: it moves when a tile's maximum exceeds it by
+// more than THR / c2, or at the first tile that has a live key (`gate` = -FLT_MAX until then, THR / c2 afterwards: one compare
+// covers both).  nref is 0 until then, never -(-inf).
+// (Round 3 first folded c2 = scale * log2(e) into a bf16 re-rounding of Q: one instruction per score less, but the second rounding
+//  of Q costs 0.25 % of a score -- 0.1 in the exponent at |score| = 40, measured by tools/ab/ab_attn_pp.py "spiked keys" -- where
+//  the first-generation kernel and the reference are exact in fp32.  Not kept.)
 struct Soft {
   float ref, gate;
   f32x2_t la, lb;     // four partial row sums (two independent packed chains)
@@ -194,7 +198,7 @@ __device__ __forceinline__ void mask_tile(f32x16_t (&s)[2], int k0, int half, in
 // P V is complete by then (it was issued before this tile's S in program order).
 template <bool DROP>
 __device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_t (&o)[2], uint4 (&pk)[2][2], uint32_t rkey, int k0,
-                                             int half, uint32_t thr) {
+                                             int half, uint32_t thr, float c2) {
   const uint32_t thrm1 = (thr - 1u) * 0x10001u;        // (thr - 1) in both halves (DROP: thr >= 1)
   float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
@@ -204,9 +208,9 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_
   if (__builtin_amdgcn_ballot_w64(move) != 0ull) {
     // lanes that do not move: delta = 0, alpha = 1.  A first move (gate = -FLT_MAX) has O = l = 0: alpha is kept finite.
     const float delta = (move && mx > -INFINITY) ? mx : 0.f;
-    const float alpha = __builtin_amdgcn_exp2f(fminf(-delta, 100.f));
+    const float alpha = __builtin_amdgcn_exp2f(fminf(-delta * c2, 100.f));
     st.ref += delta;
-    st.gate = (move && mx > -INFINITY) ? THR : st.gate;
+    st.gate = (move && mx > -INFINITY) ? THR / c2 : st.gate;
     st.la *= alpha;
     st.lb *= alpha;
     o[0] *= alpha;
@@ -215,6 +219,8 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_
     s[1] -= delta;
     st.nref -= delta;
   }
+  s[0] *= c2;                                          // v_pk_mul_f32: log2 units
+  s[1] *= c2;
 #pragma unroll
   for (int r = 0; r < 16; r += 2) {
     const float a0 = __builtin_amdgcn_exp2f(s[0][r]), a1 = __builtin_amdgcn_exp2f(s[0][r + 1]);
@@ -275,6 +281,7 @@ struct Ctx {             // loop-invariant per-lane / per-wave values
   unsigned lds0;
   int half, kend, ntile, prio;
   uint32_t rkey;
+  float c2;            // scale * log2(e)
 };
 
 // one iteration of the chunk loop on ring stage STG (compile time: every LDS offset of the iteration is an instruction immediate)
@@ -287,7 +294,7 @@ __device__ __forceinline__ void chunk_iter(const AttnArgs& p, const Ctx& c, cons
   __builtin_amdgcn_sched_barrier(0);
   const int k0 = t * KT;
   if (k0 + KT > c.kend) mask_tile(s, k0, c.half, c.kend);
-  softmax_tile<DROP>(s, st, o, pk, c.rkey, k0, c.half, p.thr);
+  softmax_tile<DROP>(s, st, o, pk, c.rkey, k0, c.half, p.thr, c.c2);
   __builtin_amdgcn_sched_barrier(0);
   if (c.prio == 1) __builtin_amdgcn_s_setprio(1);
   // K(t+1) fragments are read behind the first half of P V (the registers of V's first key block are free by then) and land under
@@ -316,7 +323,7 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   c.rkey = 0u;
   if (DROP) c.rkey = drop_row_key(asr_mix_seed(p.seed, p.seed_dev), drop_row(p, b, h, q));
   c.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  c.half = half; c.prio = prio;
+  c.half = half; c.prio = prio; c.c2 = p.scale * LOG2E;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) c.koff[ks] = c.lds0 + (unsigned)(n * ROWB + (((2 * ks + half) ^ swz_k(n)) << 4));
 #pragma unroll
@@ -328,20 +335,12 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   Stager<4> sg;
   sg.init(p, Kb, Vb, tid, wave);
 
-  // Q^T fragments (B operand), pre-scaled by scale * log2(e)
+  // Q^T fragments (B operand)
   uint4 qf[4];
   {
-    const float c2 = p.scale * LOG2E;
     const int qr = q < p.Tq ? q : p.Tq - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      Chunk<bf16_t> ch;
-      ch.v = *reinterpret_cast<const uint4*>(Qb + (int64_t)qr * p.q_st + ks * 16 + half * 8);
-      uint32_t w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = pack_bf16(bf16_to_f32(ch.e[2 * e]) * c2, bf16_to_f32(ch.e[2 * e + 1]) * c2);
-      qf[ks] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(Qb + (int64_t)qr * p.q_st + ks * 16 + half * 8);
   }
   const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   f32x16_t o[2] = {zero16, zero16}, s[2] = {zero16, zero16};
@@ -381,7 +380,7 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
         qk_phase(s, f, qf, st.nref);
         const int k0 = t * KT;
         if (k0 + KT > c.kend) mask_tile(s, k0, half, c.kend);
-        softmax_tile<DROP>(s, st, o, pk, c.rkey, k0, half, p.thr);
+        softmax_tile<DROP>(s, st, o, pk, c.rkey, k0, half, p.thr, c.c2);
         pv_phase<0>(o, f, pk);
         pv_phase<1>(o, f, pk);
       }
@@ -398,7 +397,7 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
     red[(wave * 34 + 0) * 64 + lane] = ref;
     __syncthreads();
     const float mg = fmaxf(fmaxf(red[(0 * 34) * 64 + lane], red[(1 * 34) * 64 + lane]), fmaxf(red[(2 * 34) * 64 + lane], red[(3 * 34) * 64 + lane]));
-    const float a = __builtin_amdgcn_exp2f(ref - mg);        // all at M_INIT (no key seen by anyone): exp2(0) = 1 on zeros
+    const float a = __builtin_amdgcn_exp2f((ref - mg) * c.c2);        // all at M_INIT (no key seen by anyone): exp2(0) = 1 on zeros
     red[(wave * 34 + 1) * 64 + lane] = l * a;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -420,7 +419,7 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   // ---- epilogue: O = O^T / l, stored as 16-byte row pieces (half 0 and half 1 of a query exchange 8-byte pieces)
   if (q0 >= p.Tq) return;
   const float inv_l = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
-  if (half == 0 && q < p.Tq) p.lse[((int64_t)b * p.H + h) * p.Tq + q] = l_tot > 0.f ? ref * LN2 + __logf(l_tot) : INFINITY;
+  if (half == 0 && q < p.Tq) p.lse[((int64_t)b * p.H + h) * p.Tq + q] = l_tot > 0.f ? ref * p.scale + __logf(l_tot) : INFINITY;
   const int64_t orow = (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD;
   bf16_t* Ob = static_cast<bf16_t*>(p.Out) + orow;
 #pragma unroll
@@ -461,214 +460,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pp_bf16_d64_kernel(AttnArgs p
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------- 8-wave ping-pong
-// The same wave program in a 512-thread workgroup (256 queries, two waves per SIMD: wave w and w + 4 share one), the two halves of the
-// workgroup half a tile apart (MI355X_MICROARCH.md "Two waves per SIMD"): in every barrier interval one wave of a SIMD is in its
-// matrix phase (16 MFMAs on registers + the K fragment reads) while its partner is in its softmax phase (V fragment reads + vector
-// work), then they swap -- the SIMD's matrix pipe and vector pipe are fed by different waves BY CONSTRUCTION instead of by the drift of
-// two independent workgroups.  Two barriers per tile; a K / V tile is staged once for eight waves (2 LDS-DMA pieces per wave and tile
-// instead of 4: the wave-blocking issue of a piece costs 60 - 180 cycles, MI355X_MICROARCH.md "Per-instruction cycle constants").
-//
-//   half-step      group 0 (waves 0-3)                       group 1 (waves 4-7)
-//   2t             softmax of S(t)  [V(t) frags]             O += P(t-1) V(t-1); S(t) = K(t) Q^T  [K(t) frags]
-//   2t + 1         O += P(t) V(t); S(t+1)  [K(t+1) frags]    softmax of S(t)  [V(t) frags]
-//
-// Tile t is read in half-steps 2t-1 .. 2t+1, so its stage is refilled (with tile t + 3) at the start of half-step 2t + 2; every wave
-// waits for its own DMA pieces one full tile after issuing them, in front of the barrier that ends the odd half-step.
-// pairwise merge of two partial softmax states of the same queries (different key ranges): this wave's (ref, l, o) absorbs the
-// one stored in `red` by wave `src`
-__device__ __forceinline__ void merge_state(const float* red, int src, int lane, float& ref, float& l, f32x16_t (&o)[2]) {
-  const float r2 = red[(src * 34 + 0) * 64 + lane], l2 = red[(src * 34 + 1) * 64 + lane];
-  const float m = fmaxf(ref, r2);
-  const float a1 = __builtin_amdgcn_exp2f(ref - m), a2 = __builtin_amdgcn_exp2f(r2 - m);     // both at M_INIT: 1 and 1 on zeros
-  ref = m;
-  l = l * a1 + l2 * a2;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    o[0][r] = o[0][r] * a1 + red[(src * 34 + 2 + r) * 64 + lane] * a2;
-    o[1][r] = o[1][r] * a1 + red[(src * 34 + 18 + r) * 64 + lane] * a2;
-  }
-}
-__device__ __forceinline__ void store_state(float* red, int slot, int lane, float ref, float l, const f32x16_t (&o)[2]) {
-  red[(slot * 34 + 0) * 64 + lane] = ref;
-  red[(slot * 34 + 1) * 64 + lane] = l;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    red[(slot * 34 + 2 + r) * 64 + lane] = o[0][r];
-    red[(slot * 34 + 18 + r) * 64 + lane] = o[1][r];
-  }
-}
-
-// epilogue shared by the 8-wave bodies: O = O^T / l as 16-byte row pieces, lse
-__device__ __forceinline__ void store_out(const AttnArgs& p, int b, int h, int q, int half, float ref, float l, f32x16_t (&o)[2]) {
-  const float l_tot = sum_halves(l);
-  const float inv_l = l_tot > 0.f ? p.inv_keep / l_tot : 0.f;
-  if (half == 0 && q < p.Tq) p.lse[((int64_t)b * p.H + h) * p.Tq + q] = l_tot > 0.f ? ref * LN2 + __logf(l_tot) : INFINITY;
-  const int64_t orow = (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD;
-  bf16_t* Ob = static_cast<bf16_t*>(p.Out) + orow;
-#pragma unroll
-  for (int db = 0; db < 2; ++db) {
-    const f32x16_t v = o[db] * inv_l;
-    if (p.Out32 && q < p.Tq) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg)
-        *reinterpret_cast<f32x4_t*>(p.Out32 + orow + db * 32 + rg * 8 + half * 4) = f32x4_t{v[4 * rg], v[4 * rg + 1], v[4 * rg + 2], v[4 * rg + 3]};
-    }
-#pragma unroll
-    for (int pg = 0; pg < 2; ++pg) {
-      uint2 a = make_uint2(pack_bf16(v[8 * pg + 0], v[8 * pg + 1]), pack_bf16(v[8 * pg + 2], v[8 * pg + 3]));
-      uint2 cc = make_uint2(pack_bf16(v[8 * pg + 4], v[8 * pg + 5]), pack_bf16(v[8 * pg + 6], v[8 * pg + 7]));
-      auto r0 = __builtin_amdgcn_permlane32_swap(a.x, cc.x, false, false);
-      auto r1 = __builtin_amdgcn_permlane32_swap(a.y, cc.y, false, false);
-      if (q < p.Tq) *reinterpret_cast<uint4*>(Ob + db * 32 + (2 * pg + half) * 8) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-    }
-  }
-}
-
-// grid: n_full * B * H chunk workgroups of 256 queries, then n_tail * B * H tail workgroups of up to 64 queries (two 32-query blocks x
-// four key ranges: wave w -> block w >> 2, tiles (w & 3), (w & 3) + 4, ...; pairwise combine through LDS)
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void attn_fwd_pp8_bf16_d64_kernel(AttnArgs p, int n_full, int n_tail, int prio) {
-  __shared__ __attribute__((aligned(256))) unsigned char smem[NS * 2 * TILE];
-  const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5, l16 = lane & 15, dh = (lane >> 4) & 1;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int BH = p.B * p.H;
-  const int n_main = n_full * BH;
-  const int bid = (int)blockIdx.x;
-  const bool tail = bid >= n_main;
-  int bh, q0;
-  if (!tail) {
-    const int vid = xcd_linear(bid, n_main);
-    bh = vid / n_full;
-    q0 = (vid - bh * n_full) * 256 + wave * 32;
-  } else {
-    const int vid = xcd_linear(bid - n_main, n_tail * BH);
-    bh = vid / n_tail;
-    q0 = n_full * 256 + (vid - bh * n_tail) * 64 + (wave >> 2) * 32;
-  }
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int q = q0 + n;
-  const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
-  const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
-  const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
-  Ctx c;
-  c.rkey = 0u;
-  if (DROP) c.rkey = drop_row_key(asr_mix_seed(p.seed, p.seed_dev), drop_row(p, b, h, q));
-  c.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  c.half = half; c.prio = prio;
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) c.koff[ks] = c.lds0 + (unsigned)(n * ROWB + (((2 * ks + half) ^ swz_k(n)) << 4));
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-    c.voff[db] = c.lds0 + (unsigned)((4 * half + (l16 >> 2)) * ROWB + (((4 * (db ^ ((l16 >> 3) & 1)) + 2 * dh + ((l16 & 3) >> 1))) << 4) + (l16 & 1) * 8);
-  c.kend = key_end(p, b);
-  c.ntile = (c.kend + KT - 1) / KT;
-  const int ntile = c.ntile;
-  Stager<8> sg;
-  sg.init(p, Kb, Vb, tid, wave);
-  uint4 qf[4];
-  {
-    const float c2 = p.scale * LOG2E;
-    const int qr = q < p.Tq ? q : p.Tq - 1;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      Chunk<bf16_t> ch;
-      ch.v = *reinterpret_cast<const uint4*>(Qb + (int64_t)qr * p.q_st + ks * 16 + half * 8);
-      uint32_t w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = pack_bf16(bf16_to_f32(ch.e[2 * e]) * c2, bf16_to_f32(ch.e[2 * e + 1]) * c2);
-      qf[ks] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-  }
-  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  f32x16_t o[2] = {zero16, zero16}, s[2] = {zero16, zero16};
-  Soft st;
-  st.ref = 0.f; st.la = f32x2_t{0.f, 0.f}; st.lb = st.la; st.gate = -3.0e38f; st.nref = zero16;
-  Frags f;
-  uint4 pk[2][2];
-  if (ntile > 0) sg.issue(c.lds0, 0);
-  if (ntile > 1) sg.issue(c.lds0 + 2 * TILE, KT);
-  if (ntile > 2) sg.issue(c.lds0 + 2 * 2 * TILE, 2 * KT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  if (!tail) {
-    if (prio == 2 && wave >= 4) __builtin_amdgcn_s_setprio(1);     // static priority for the later-dispatched half
-    const int grp = wave >> 2;
-    // ONE program for both halves, half a tile apart: half-step h is a softmax phase for group 0 when h is even and for group 1 when
-    // h is odd, a matrix phase otherwise (wave-uniform branch; the ring stage of a tile is a scalar added to the lane offsets).
-    // The K fragments live inside one branch only (read and consumed there): no loop-carried copy of them.
-    if (ntile > 0) {                                               // S(0) for both halves (group 1 then idles through half-step 0)
-      read_k(f.kf, 0u, c.koff);
-      qk_phase(s, f, qf, st.nref);
-    }
-    for (int h = 0; h <= 2 * ntile; ++h) {
-      // refill the stage of tile h/2 - 1 (read for the last time in half-step h - 1) with tile h/2 + 2
-      if (!(h & 1) && h >= 2 && (h >> 1) + 2 < ntile) sg.issue(c.lds0 + (unsigned)((((h >> 1) + 2) % NS) * 2 * TILE), ((h >> 1) + 2) * KT);
-      const int hh = h - grp;
-      const int t = hh >> 1;
-      if (hh >= 0 && t < ntile) {
-        if (!(hh & 1)) {                                           // softmax phase of tile t
-          const unsigned stg = (unsigned)((t % NS) * 2 * TILE);
-          read_v(f.vf, stg + TILE, c.voff);
-          __builtin_amdgcn_sched_barrier(0);
-          const int k0 = t * KT;
-          if (k0 + KT > c.kend) mask_tile(s, k0, half, c.kend);
-          softmax_tile<DROP>(s, st, o, pk, c.rkey, k0, half, p.thr);
-        } else if (t + 1 < ntile) {                                // matrix phase behind tile t: O += P(t) V(t); S(t+1) = K(t+1) Q^T
-          pv_phase<0>(o, f, pk);
-          __builtin_amdgcn_sched_barrier(0);
-          read_k(f.kf, (unsigned)(((t + 1) % NS) * 2 * TILE), c.koff);
-          pv_phase<1>(o, f, pk);
-          qk_phase(s, f, qf, st.nref);
-        } else {                                                   // ... behind the last tile
-          pv_phase<0>(o, f, pk);
-          pv_phase<1>(o, f, pk);
-        }
-      }
-      if (h & 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    if (q0 >= p.Tq) return;
-    float l = (st.la[0] + st.la[1]) + (st.lb[0] + st.lb[1]);
-    store_out(p, b, h, q, half, st.gate > 0.f ? st.ref : M_INIT, l, o);
-    return;
-  }
-  // ---- tail workgroups
-  const int ks = wave & 3;
-  for (int t = 0; t < ntile; ++t) {
-    if ((t & 3) == ks) {
-      const unsigned stg_t = (unsigned)((t % NS) * 2 * TILE);
-      read_k(f.kf, stg_t, c.koff);
-      read_v(f.vf, stg_t + TILE, c.voff);
-      qk_phase(s, f, qf, st.nref);
-      const int k0 = t * KT;
-      if (k0 + KT > c.kend) mask_tile(s, k0, half, c.kend);
-      softmax_tile<DROP>(s, st, o, pk, c.rkey, k0, half, p.thr);
-      pv_phase<0>(o, f, pk);
-      pv_phase<1>(o, f, pk);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 3 < ntile) sg.issue(c.lds0 + (unsigned)((t % NS) * 2 * TILE), (t + 3) * KT);
-  }
-  float l = (st.la[0] + st.la[1]) + (st.lb[0] + st.lb[1]);
-  float ref = st.gate > 0.f ? st.ref : M_INIT;
-  float* red = reinterpret_cast<float*>(smem);       // 4 slots x [34][64] floats = 34 KB (the ring is idle: the loop's last barrier retired it)
-  const int blk = wave >> 2;
-  // round 1: key ranges 2, 3 -> 0, 1; round 2: 1 -> 0
-  if (ks >= 2) store_state(red, blk * 2 + (ks - 2), lane, ref, l, o);
-  __syncthreads();
-  if (ks < 2) merge_state(red, blk * 2 + ks, lane, ref, l, o);
-  __syncthreads();
-  if (ks == 1) store_state(red, blk, lane, ref, l, o);
-  __syncthreads();
-  if (ks != 0) return;
-  merge_state(red, blk, lane, ref, l, o);
-  if (q0 >= p.Tq) return;
-  store_out(p, b, h, q, half, ref, l, o);
-}
-
 }  // namespace
 
 // Entry: ASR_EUNSUPPORTED unless the long-sequence kernel applies (bf16, d = 64, no causal mask, no padding bytes -- key lengths only --, 16-byte aligned rows -- checked by
@@ -678,20 +469,6 @@ int attn_pp_fwd(const AttnArgs& p, hipStream_t s) {
   if ((((uintptr_t)p.Out) & 15) != 0 || p.o_st % 8 != 0 || p.o_sb % 8 != 0) return ASR_EUNSUPPORTED;
   if (p.Out32 && (((uintptr_t)p.Out32) & 15) != 0) return ASR_EUNSUPPORTED;
   const int BH = p.B * p.H;
-  const int prio8 = (int)asr_tuning("ATTN_PP_PRIO", 0);
-  // 8-wave ping-pong workgroups (256 queries) from 256 queries on; 4-wave workgroups (128 queries) below or on request
-  const int64_t nw = asr_tuning("ATTN_PP_WAVES", 0);
-  if (nw == 8 || (nw == 0 && p.Tq >= 256)) {
-    int nf8 = p.Tq / 256;
-    const int rest8 = p.Tq - nf8 * 256;
-    int nt8 = (rest8 + 63) / 64;
-    if (asr_tuning("ATTN_PP_TAIL", 1) == 0 && rest8 > 0) { nf8 += 1; nt8 = 0; }
-    const dim3 grid8((unsigned)((nf8 + nt8) * BH));
-    if (p.thr) attn_fwd_pp8_bf16_d64_kernel<true><<<grid8, dim3(512), 0, s>>>(p, nf8, nt8, prio8);
-    else attn_fwd_pp8_bf16_d64_kernel<false><<<grid8, dim3(512), 0, s>>>(p, nf8, nt8, prio8);
-    ASR_LAUNCH_CHECK();
-    return ASR_OK;
-  }
   const int n_full = p.Tq / 128;
   const int rest = p.Tq - n_full * 128;
   int n_tail = (rest + 31) / 32;

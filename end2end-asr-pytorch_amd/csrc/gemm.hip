@@ -868,14 +868,11 @@ __device__ __forceinline__ uint4 tn32_pack(const unsigned char* tile, int lr, in
 }
 
 template <int NST>
-__global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
+__device__ __forceinline__ void tn128p_body(const Tn128Args& p, unsigned char* smem, int wid, bool single) {
   constexpr int RM = 32, ROWB = 256, TILEB = RM * ROWB, STAGEB = 2 * TILEB;       // 8 KB per operand, 16 KB per stage
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
-  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
-  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
   const int split = wid / p.ntiles, tile = wid % p.ntiles;
   const int n0 = (tile / p.tiles_k) * 128, k0 = (tile % p.tiles_k) * 128;
   const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
@@ -963,7 +960,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
   }
 
   // ---- the wave's 64 x 64 quadrant: lane (lr, g) holds rows 4g..4g+3 of column lr of every fragment
-  const bool single = gridDim.x == (unsigned)p.ntiles;
   float* part = p.ws ? p.ws + ((int64_t)split * p.ntiles + tile) * 16384 : nullptr;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -991,6 +987,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
       if (g == 0 && gn < p.N) atomicAdd(p.colsum + gn, v);
     }
   }
+}
+
+template <int NST>
+__global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  tn128p_body<NST>(p, smem, wid, gridDim.x == (unsigned)p.ntiles);
+}
+
+// ---- grouped form: the weight gradients of up to TN_GROUP_MAX linear layers in ONE launch.  A weight gradient is off the
+// critical path of backward (only the data gradient feeds the next layer), and alone it is latency bound: 16 - 64 blocks of dW, each
+// a serial chain over all M rows.  Queued and launched together at the end of backward, the layers' blocks fill the chip
+// (~1900 blocks of 128 x 128 for the 4-layer model), every block contracts ALL rows of its layer (no m-split: no partial-sum
+// workspace, no fold pass, plain += into the fp32 gradient), longest layers first.
+constexpr int TN_GROUP_MAX = 16;
+struct TnGroupArgs {
+  Tn128Args p[TN_GROUP_MAX];
+  int first[TN_GROUP_MAX + 1];       // first[i] = number of blocks of the problems before i
+  int n;
+};
+template <int NST>
+__global__ __launch_bounds__(256, 2) void gemm_tn128g_kernel(TnGroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  int i = 0;
+  while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
+  tn128p_body<NST>(ga.p[i], smem, wid - ga.first[i], true);
 }
 
 __global__ __launch_bounds__(256) void tn128_reduce_kernel(const float* __restrict__ ws, float* C, int64_t ldc, int N, int K,
@@ -1623,6 +1648,54 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
                        splits);
     ASR_LAUNCH_CHECK();
   }
+  return ASR_OK;
+}
+
+extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
+                                   float* const* dw, const int64_t* ld_dw, float* const* db, const int* M, const int* N, const int* K,
+                                   int dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(n >= 0 && n <= TN_GROUP_MAX && dtype == ASR_BF16);
+  if (n == 0) return ASR_OK;
+  ASR_CHECK_ARG(dy && ld_dy && x && ld_x && dw && ld_dw && db && M && N && K);
+  int order[TN_GROUP_MAX];
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    ASR_CHECK_ARG(dy[i] && x[i] && dw[i] && M[i] >= 0 && N[i] >= 0 && K[i] >= 0);
+    if (M[i] == 0 || N[i] == 0 || K[i] == 0) continue;
+    if (ld_dy[i] % 8 != 0 || ld_x[i] % 8 != 0 || !aligned16(dy[i]) || !aligned16(x[i]) || ld_dy[i] < N[i] ||
+        ld_dy[i] >= ((int64_t)1 << 22) || ld_x[i] >= ((int64_t)1 << 22))
+      return ASR_EUNSUPPORTED;
+    order[cnt++] = i;
+  }
+  if (cnt == 0) return ASR_OK;
+  // longest row count first: a block's run time is proportional to M, and the late blocks decide when the launch ends
+  for (int a = 1; a < cnt; ++a)
+    for (int b = a; b > 0 && M[order[b]] > M[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  TnGroupArgs ga{};
+  int total = 0;
+  for (int j = 0; j < cnt; ++j) {
+    const int i = order[j];
+    Tn128Args& q = ga.p[j];
+    q.A = dy[i]; q.B = x[i]; q.C = dw[i]; q.colsum = db[i]; q.ws = nullptr;
+    q.lda = ld_dy[i]; q.ldb = ld_x[i]; q.ldc = ld_dw[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
+    q.tiles_k = (K[i] + 127) / 128;
+    q.ntiles = ((N[i] + 127) / 128) * q.tiles_k;
+    q.m_per_split = (M[i] + 31) / 32 * 32;
+    ga.first[j] = total;
+    total += q.ntiles;
+  }
+  ga.first[cnt] = total;
+  ga.n = cnt;
+  static bool granted = false;
+  if (!granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384);
+    granted = true;
+  }
+  AsrProfScope prof(ASR_OP_GEMM, stream);
+  if (asr_tuning("TN_GROUP_STAGES", 3) == 4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);
+  else hipLaunchKernelGGL(gemm_tn128g_kernel<3>, dim3((unsigned)total), dim3(256), 3 * 16384, stream, ga);
+  ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
 

@@ -70,11 +70,10 @@ def diag_case(name, B, H, Tq, Tk, key_len=None):
         print("   first bad rows (b,q): O", (eo.amax(dim=2) > 2e-2).nonzero()[:6].tolist(), " lse", (el.amax(dim=1) > 2e-2).nonzero()[:6].tolist())
 
 
-def diag(waves=4):
-    print("== diagnostics, ATTN_PP = 1, ATTN_PP_MIN = 1 (every shape goes through attention_pp.hip), ATTN_PP_WAVES = %d" % waves)
+def diag():
+    print("== diagnostics, ATTN_PP = 1, ATTN_PP_MIN = 1 (every shape goes through attention_pp.hip)")
     L.set_tuning("ATTN_PP", 1)
     L.set_tuning("ATTN_PP_MIN", 1)
-    L.set_tuning("ATTN_PP_WAVES", waves)
     diag_case("tail  Tq=32  Tk=64  (1 tile)", 1, 1, 32, 64)
     diag_case("tail  Tq=32  Tk=256 (4 tiles)", 1, 2, 32, 256)
     diag_case("tail  Tq=32  Tk=832 (13 tiles)", 2, 2, 32, 832)
@@ -114,7 +113,6 @@ def diag(waves=4):
     print("%-34s |O32(pp) - O32(v1)| %.3e   lse diff %.3e   (same dropout mask <=> small)" %
           ("dropout p=0.25 vs first generation", (o32a - o32b).abs().max().item(), (lse1 - lse0).abs().max().item()))
     L.set_tuning("ATTN_PP_MIN", None)
-    L.set_tuning("ATTN_PP_WAVES", None)
 
 
 def timeit(fn, n=30):
@@ -138,9 +136,8 @@ def time_all():
     shapes = [(32, 8, 800, 800, 0.0), (32, 8, 800, 800, 0.1), (16, 8, 795, 795, 0.0), (16, 8, 795, 795, 0.1), (16, 8, 100, 795, 0.1),
               (32, 8, 200, 200, 0.0), (32, 8, 200, 200, 0.1), (32, 8, 100, 200, 0.1), (32, 8, 512, 512, 0.0), (32, 8, 1024, 1024, 0.0),
               (8, 8, 2048, 2048, 0.0)]
-    variants = [("v1", dict(ATTN_PP=0)), ("pp4", dict(ATTN_PP=1, ATTN_PP_WAVES=4)), ("pp4 no tails", dict(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_TAIL=0)),
-                ("pp4 prio1", dict(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_PRIO=1)), ("pp8", dict(ATTN_PP=1, ATTN_PP_WAVES=8)),
-                ("pp8 no tails", dict(ATTN_PP=1, ATTN_PP_WAVES=8, ATTN_PP_TAIL=0)), ("pp8 prio2", dict(ATTN_PP=1, ATTN_PP_WAVES=8, ATTN_PP_PRIO=2))]
+    variants = [("v1", dict(ATTN_PP=0)), ("pp", dict(ATTN_PP=1)), ("pp no tails", dict(ATTN_PP=1, ATTN_PP_TAIL=0)),
+                ("pp prio1", dict(ATTN_PP=1, ATTN_PP_PRIO=1))]
     for B, H, Tq, Tk, p in shapes:
         q = torch.randn(B, Tq, H * 64, device=D).bfloat16()
         k = torch.randn(B, Tk, H * 64, device=D).bfloat16()
@@ -149,20 +146,19 @@ def time_all():
         fl = 4.0 * B * H * Tq * Tk * 64
         row = []
         for name, tv in variants:
-            for kk in ("ATTN_PP", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_WAVES"):
+            for kk in ("ATTN_PP", "ATTN_PP_TAIL", "ATTN_PP_PRIO"):
                 L.set_tuning(kk, tv.get(kk))
             L.set_tuning("ATTN_PP_MIN", 1)
             us = timeit(lambda: ops.attn_fwd(q, k, v, H, 64, key_len=kl, scale=0.125, p=p, seed=5))
             row.append("%s %6.1f us %4.1f%%" % (name, us, fl / us / 25e6))
         print("  (%d,%d,%d,%d) p=%.1f : %s" % (B, H, Tq, Tk, p, " | ".join(row)))
-    for kk in ("ATTN_PP", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_WAVES", "ATTN_PP_MIN"):
+    for kk in ("ATTN_PP", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_MIN"):
         L.set_tuning(kk, None)
 
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("diag", "all"):
-        diag(4)
-        diag(8)
+        diag()
     if which in ("time", "all"):
         time_all()
