@@ -38,6 +38,8 @@ LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
 TRAFFIC_FILE = os.path.join("profiles", "r02_roofline_traffic.json")
+# per-family kernel time of the REPLAYED step (tools/prof_families.py over a committed rocprofv3 trace of this command)
+REPLAYED_FAMILIES_FILE = os.path.join("profiles", "r03_replayed_families.json")
 
 
 # ------------------------------------------------------------------------------------------------ algorithmic work
@@ -61,6 +63,32 @@ def family_flops(B, L=4, D=512, H=8, dk=64, Dff=2048, vocab=V, t_src=T_SRC, t_tg
             "attention bwd": (2.5 * att, None)}
 
 
+def gemm_family_flops(workload, B):
+    """Algorithmic FLOPs per training step of everything that runs on the asr_gemm_* kernels (every linear layer: forward + data
+    gradient + weight gradient) for the non-headline workloads.
+    librispeech (configs[3]): 12 encoder / 6 decoder layers, D_in = 32*21, T' = 795, Td = 100, V = 32, plus the two emb_cnn
+      convolutions, which are GEMMs here (im2col windows): conv.0 1->32 k(41,11) s(2,2) forward + weight gradient, conv.3 32->32
+      k(21,11) s(2,1) forward + data + weight gradient.
+    lowrank (configs[4]): 12/12 layers, vgg_cnn, every attention / feed-forward projection (in -> out) as (in -> 64 -> out)."""
+    D, HD, Dff = 512, 512, 2048
+    if workload == "librispeech":
+        Te, Td, Le, Ld, vocab, Din = 795, LIBRI["T_TGT"], LIBRI["enc_layers"], LIBRI["dec_layers"], LIBRI["V"], 32 * 21
+        Me, Md = B * Te, B * Td
+        lin = Me * D * Din + Le * (Me * 3 * HD * D + Me * D * HD + 2 * Me * Dff * D)
+        lin += Ld * (Md * 3 * HD * D + Md * D * HD + Md * HD * D + Me * 2 * HD * D + Md * D * HD + 2 * Md * Dff * D) + Md * vocab * D
+        conv0 = 32 * 41 * 11 * 61 * 805 * B
+        conv3 = 32 * 32 * 21 * 11 * 21 * 795 * B
+        return 3 * 2 * lin + 2 * 2 * conv0 + 3 * 2 * conv3
+    r, L = 64, 12
+    Te, Td = T_SRC // 4, T_TGT
+    Me, Md = B * Te, B * Td
+    pr = lambda M, i, o: M * r * (i + o)
+    lin = Me * D * 5120 + L * (3 * pr(Me, D, HD) + pr(Me, HD, D) + pr(Me, D, Dff) + pr(Me, Dff, D))
+    lin += L * (3 * pr(Md, D, HD) + pr(Md, HD, D) + pr(Md, D, HD) + 2 * pr(Me, D, HD) + pr(Md, HD, D) + pr(Md, D, Dff) + pr(Md, Dff, D))
+    lin += Md * V * D
+    return 3 * 2 * lin
+
+
 def measured_traffic(a):
     """HBM bytes per launch of the conv igemm family from the committed rocprofv3 PMC passes (separate FETCH_SIZE /
     WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
@@ -73,6 +101,28 @@ def measured_traffic(a):
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+def replayed_families(a, peak):
+    """Per-family time of the graph-replayed step from the committed rocprofv3 trace (NOT measured by this run: events cannot be
+    recorded inside a graph replay), with the family's algorithmic FLOPs over it where the family is an MFMA family."""
+    if a.batch != 32 or a.precision != "bf16" or a.workload != "headline":
+        return None
+    try:
+        with open(os.path.join(ROOT, REPLAYED_FAMILIES_FILE)) as fh:
+            d = json.load(fh)
+    except (OSError, ValueError):
+        return None
+    fl = family_flops(a.batch)
+    out = {}
+    for k, v in d["families"].items():
+        e = dict(v)
+        if k in fl and v["ms_per_step"] > 0:
+            e["achieved"] = fl[k][0] / (v["ms_per_step"] * 1e-3) / 1e12
+            e["frac"] = e["achieved"] / peak
+        out[k] = e
+    return {"families": out, "wall_ms_per_step": d.get("wall_ms_per_step"), "launches_per_step": d.get("launches_per_step"),
+            "source": "%s (%s; committed, NOT measured by this run)" % (REPLAYED_FAMILIES_FILE, d.get("source"))}
 
 
 def labels(vocab=V):
@@ -122,6 +172,7 @@ def cpu_baseline(state_dict, flags, batch, seconds_budget=150.0):
     import torch
     common = {"unit": "frames/s", "cores": torch.get_num_threads(), "nproc": os.cpu_count(), "cpu_model": cpu_model_name(),
               "dtype": "f32", "batch": batch}
+    # (the GPU step runs the model's dropout; the two baseline kinds differ: see "dropout" in the returned object)
     ref_dir = os.environ.get("ASR_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref_dir, "models")):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "time_reference.py"), "--batch", str(batch),
@@ -130,7 +181,7 @@ def cpu_baseline(state_dict, flags, batch, seconds_budget=150.0):
             t = json.loads(r.stdout.strip().splitlines()[-1])
             times = t["times"]
             return dict(common, value=batch * T_SRC / min(times), median=batch * T_SRC / statistics.median(times), kind="reference",
-                        cores=t["threads"], step_s_best=min(times), step_s_median=statistics.median(times),
+                        cores=t["threads"], step_s_best=min(times), step_s_median=statistics.median(times), dropout=0.1,
                         sample="the unmodified reference train step (models/asr/transformer.py:59-85, utils/metrics.py:78-130, "
                                "utils/optimizer.py:15-22) imported from /root/reference, fp32, dropout 0.1, 4-layer d512 vgg_cnn, "
                                "batch %d x T_src 800, 1 warm-up + %d timed steps (best / median); data loading and CER "
@@ -154,7 +205,7 @@ def cpu_baseline(state_dict, flags, batch, seconds_budget=150.0):
         if time.time() - t_start > seconds_budget:
             break
     return dict(common, value=batch * T_SRC / min(times), median=batch * T_SRC / statistics.median(times), kind="port",
-                step_s_best=min(times), step_s_median=statistics.median(times),
+                step_s_best=min(times), step_s_median=statistics.median(times), dropout=0.0,
                 sample="oracle/asr_oracle.py train_step (restatement of the reference step pinned to it by tests/: forward + "
                        "label-smoothed CE + backward + Noam/Adam, fp32, dropout off), same 4-layer d512 vgg_cnn model, same "
                        "synthetic tensors, batch %d x T_src 800, 1 warm-up + %d timed steps (best / median); data loading and CER "
@@ -314,7 +365,9 @@ def main():
     prof = None
     fam_ops = {"conv3x3_igemm (3 fwd + 3 dgrad)": L.OP_CONV_IGEMM, "conv3x3_wgrad": L.OP_CONV_WGRAD,
                "linear GEMMs (fwd + dgrad + wgrad)": L.OP_GEMM, "attention fwd": L.OP_ATTN_FWD, "attention bwd": L.OP_ATTN_BWD}
-    if not a.no_roofline and not libri and not lowrank:
+    if not a.no_roofline and (libri or lowrank):
+        fam_ops = {"GEMM family (asr_gemm_*)": L.OP_GEMM}
+    if not a.no_roofline:
         prof_steps = min(a.steps, 3)
         for op in fam_ops.values():
             ops.prof_enable(op, True)
@@ -363,7 +416,19 @@ def main():
             out["config"]["gradient_allreduce"] = dict(exposure, bytes=4 * red.flat.total_all,
                                                        note="147 MB fp32 gradients + stats slot; the encoder/decoder slice is in "
                                                             "flight during the conv backward graph")
-        if prof is not None:
+        if prof is not None and (libri or lowrank):
+            tot_ms, n = prof["GEMM family (asr_gemm_*)"]
+            if n > 0 and tot_ms > 0:
+                fl_g = gemm_family_flops(a.workload, a.batch)
+                ach = fl_g * prof_steps / (tot_ms * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": "asr_gemm_* (every linear layer's forward, data and weight gradient%s): the family "
+                                   "that owns this workload's step" % ("; the emb_cnn convolutions as window GEMMs" if libri else ", rank-64 factors"),
+                                   "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                   "timing": "HIP events around every launch on its own stream during %d EAGER steps right after the timed "
+                                             "(graph-replayed) region" % prof_steps,
+                                   "launches": n, "avg_launch_ms": tot_ms / n, "ms_per_step": tot_ms / prof_steps,
+                                   "algorithmic_gflop_per_step": fl_g / 1e9}
+        elif prof is not None:
             fl = family_flops(a.batch)
             fams = {}
             for k, (tot_ms, n) in prof.items():
@@ -386,8 +451,16 @@ def main():
                                              "timed (graph-replayed) region" % prof_steps,
                                    "launches": n_launch, "avg_launch_ms": prof[key][0] / n_launch,
                                    "algorithmic_flop_per_launch_avg": fl[key][0] / fl[key][1],
-                                   "families": fams,
-                                   "largest_family_by_time": max(fams, key=lambda k: fams[k]["ms_per_step"])}
+                                   "families_eager": fams,
+                                   "families_eager_note": "MFMA families during the EAGER steps of the roofline pass: a linear layer's backward is "
+                                                          "two launches there, not the one-launch / grouped forms of the replayed step",
+                                   "largest_family_by_time_eager": max(fams, key=lambda k: fams[k]["ms_per_step"])}
+                rep = replayed_families(a, peak)
+                if rep is not None:
+                    out["roofline"]["families_replayed"] = rep
+                    mf = {k: v for k, v in rep["families"].items() if "frac" in v}
+                    if mf:
+                        out["roofline"]["largest_family_by_time_replayed"] = max(mf, key=lambda k: mf[k]["ms_per_step"])
         if sd_cpu is not None:
             try:
                 out["cpu_baseline"] = cpu_baseline(sd_cpu, " ".join(MODEL_FLAGS), a.batch)

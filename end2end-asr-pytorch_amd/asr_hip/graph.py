@@ -111,6 +111,8 @@ class GraphedTrainStep:
         leaf = feats.detach().requires_grad_(feats.requires_grad)
         enc_out, _ = core.encoder(leaf, self.src_len)
         pred, gold, *_ = core.decoder(self.tgt, enc_out, self.src_len)
+        self.hyp_seq = ops.argmax_rows(pred.detach().reshape(-1, pred.shape[-1])).view(pred.shape[0], pred.shape[1])
+        self.gold_seq = gold
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
         loss.backward()
         ops.join_deferred()                     # every forked stream must have re-joined before this graph ends

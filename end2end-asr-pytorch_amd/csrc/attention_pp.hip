@@ -285,8 +285,8 @@ struct Ctx {             // loop-invariant per-lane / per-wave values
 };
 
 // one iteration of the chunk loop on ring stage STG (compile time: every LDS offset of the iteration is an instruction immediate)
-template <bool DROP, int STG>
-__device__ __forceinline__ void chunk_iter(const AttnArgs& p, const Ctx& c, const Stager<4>& sg, unsigned char* smem, int t, f32x16_t (&s)[2],
+template <bool DROP, int STG, int NW>
+__device__ __forceinline__ void chunk_iter(const AttnArgs& p, const Ctx& c, const Stager<NW>& sg, unsigned char* smem, int t, f32x16_t (&s)[2],
                                            f32x16_t (&o)[2], Soft& st, Frags& f, const uint4 (&qf)[4], uint4 (&pk)[2][2]) {
   constexpr unsigned stg_t = STG * 2 * TILE, stg_n = ((STG + 1) % NS) * 2 * TILE;
   const bool more = t + 1 < c.ntile;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void chunk_iter(const AttnArgs& p, const Ctx& c, cons
   if (t + 3 < c.ntile) sg.issue(c.lds0 + (unsigned)(STG * 2 * TILE), (t + 3) * KT);
 }
 
-template <bool DROP, bool TAIL>
+template <bool DROP, bool TAIL, int NW>
 __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned char* smem, int bh, int q0, int prio) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5, l16 = lane & 15, dh = (lane >> 4) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -332,7 +332,7 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   c.kend = key_end(p, b);
   c.ntile = (c.kend + KT - 1) / KT;
   const int ntile = c.ntile;
-  Stager<4> sg;
+  Stager<NW> sg;
   sg.init(p, Kb, Vb, tid, wave);
 
   // Q^T fragments (B operand)
@@ -364,14 +364,15 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
       qk_phase(s, f, qf, st.nref);
     }
     for (int t = 0; t < ntile; t += 3) {
-      chunk_iter<DROP, 0>(p, c, sg, smem, t, s, o, st, f, qf, pk);
+      chunk_iter<DROP, 0, NW>(p, c, sg, smem, t, s, o, st, f, qf, pk);
       if (t + 1 >= ntile) break;
-      chunk_iter<DROP, 1>(p, c, sg, smem, t + 1, s, o, st, f, qf, pk);
+      chunk_iter<DROP, 1, NW>(p, c, sg, smem, t + 1, s, o, st, f, qf, pk);
       if (t + 2 >= ntile) break;
-      chunk_iter<DROP, 2>(p, c, sg, smem, t + 2, s, o, st, f, qf, pk);
+      chunk_iter<DROP, 2, NW>(p, c, sg, smem, t + 2, s, o, st, f, qf, pk);
     }
   } else {
-    // wave w computes tiles w, w + 4, ...; the workgroup still stages EVERY tile in order (the ring and the barriers are common)
+    // wave w < 4 computes tiles w, w + 4, ...; the workgroup still stages EVERY tile in order (the ring and the barriers are common;
+    // the waves 4 .. 7 of an 8-wave workgroup only stage)
     for (int t = 0; t < ntile; ++t) {
       if ((t & 3) == wave) {
         const unsigned stg_t = (unsigned)((t % NS) * 2 * TILE);
@@ -394,15 +395,17 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   if (TAIL) {
     // combine the four key ranges of the block (wave 0 collects); the loop's last barrier has retired every ring access
     float* red = reinterpret_cast<float*>(smem);       // [wave][34][64]: ref, l, o[0][16], o[1][16] per lane
-    red[(wave * 34 + 0) * 64 + lane] = ref;
+    if (wave < 4) red[(wave * 34 + 0) * 64 + lane] = ref;
     __syncthreads();
     const float mg = fmaxf(fmaxf(red[(0 * 34) * 64 + lane], red[(1 * 34) * 64 + lane]), fmaxf(red[(2 * 34) * 64 + lane], red[(3 * 34) * 64 + lane]));
     const float a = __builtin_amdgcn_exp2f((ref - mg) * c.c2);        // all at M_INIT (no key seen by anyone): exp2(0) = 1 on zeros
-    red[(wave * 34 + 1) * 64 + lane] = l * a;
+    if (wave < 4) {
+      red[(wave * 34 + 1) * 64 + lane] = l * a;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      red[(wave * 34 + 2 + r) * 64 + lane] = o[0][r] * a;
-      red[(wave * 34 + 18 + r) * 64 + lane] = o[1][r] * a;
+      for (int r = 0; r < 16; ++r) {
+        red[(wave * 34 + 2 + r) * 64 + lane] = o[0][r] * a;
+        red[(wave * 34 + 18 + r) * 64 + lane] = o[1][r] * a;
+      }
     }
     __syncthreads();
     if (wave != 0) return;
@@ -442,8 +445,8 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_fwd_pp_bf16_d64_kernel(AttnArgs p, int n_full, int n_tail, int prio) {
+template <bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pp_bf16_d64_kernel(AttnArgs p, int n_full, int n_tail, int prio) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[NS * 2 * TILE];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int BH = p.B * p.H;
@@ -452,11 +455,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_pp_bf16_d64_kernel(AttnArgs p
   if (bid < n_main) {
     const int vid = xcd_linear(bid, n_main);
     const int bh = vid / n_full;
-    attn_fwd_pp_body<DROP, false>(p, smem, bh, (vid - bh * n_full) * 128 + wave * 32, prio);
+    attn_fwd_pp_body<DROP, false, NW>(p, smem, bh, (vid - bh * n_full) * (32 * NW) + wave * 32, prio);
   } else {
     const int vid = xcd_linear(bid - n_main, n_tail * BH);
     const int bh = vid / n_tail;
-    attn_fwd_pp_body<DROP, true>(p, smem, bh, n_full * 128 + (vid - bh * n_tail) * 32, prio);
+    attn_fwd_pp_body<DROP, true, NW>(p, smem, bh, n_full * (32 * NW) + (vid - bh * n_tail) * 32, prio);
   }
 }
 
@@ -469,15 +472,24 @@ int attn_pp_fwd(const AttnArgs& p, hipStream_t s) {
   if ((((uintptr_t)p.Out) & 15) != 0 || p.o_st % 8 != 0 || p.o_sb % 8 != 0) return ASR_EUNSUPPORTED;
   if (p.Out32 && (((uintptr_t)p.Out32) & 15) != 0) return ASR_EUNSUPPORTED;
   const int BH = p.B * p.H;
-  const int n_full = p.Tq / 128;
-  const int rest = p.Tq - n_full * 128;
+  // workgroups of 8 waves (256 queries: a K / V tile is staged once for eight waves -- 2 LDS-DMA pieces per wave and tile instead
+  // of 4) when the sequence has at least one such chunk, else 4 waves (128 queries); ATTN_PP_WAVES forces either
+  const int64_t nwt = asr_tuning("ATTN_PP_WAVES", 0);
+  const int nw = nwt == 4 || nwt == 8 ? (int)nwt : (p.Tq >= 256 ? 8 : 4);
+  const int n_full = p.Tq / (32 * nw);
+  const int rest = p.Tq - n_full * 32 * nw;
   int n_tail = (rest + 31) / 32;
   int nf = n_full;
   if (asr_tuning("ATTN_PP_TAIL", 1) == 0 && rest > 0) { nf = n_full + 1; n_tail = 0; }      // A/B: leftover queries as one more (partly idle) chunk
   const dim3 grid((unsigned)((nf + n_tail) * BH));
   const int prio = (int)asr_tuning("ATTN_PP_PRIO", 0);
-  if (p.thr) attn_fwd_pp_bf16_d64_kernel<true><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
-  else attn_fwd_pp_bf16_d64_kernel<false><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
+  if (nw == 8) {
+    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 8><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
+    else attn_fwd_pp_bf16_d64_kernel<false, 8><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
+  } else {
+    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 4><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
+    else attn_fwd_pp_bf16_d64_kernel<false, 4><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
+  }
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

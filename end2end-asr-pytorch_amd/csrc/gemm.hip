@@ -416,12 +416,16 @@ int launch_fast_ns(const GemmArgs& a, int splits, hipStream_t s) {
   p.ntiles = tiles_m * p.tiles_n;
   dim3 grid((unsigned)(p.ntiles * splits), 1, 1);
   size_t lds = (size_t)NS * (BM + BN) * 128;
-  const size_t cl = (size_t)BM * (BN * 4 + 16);
+  // epilogue staging: the tile in the OUTPUT dtype when the 16-byte-chunk epilogue applies (same test as in the kernel), else fp32.
+  // (Sizing it as fp32 always cost the 128 x 128 tile two of its four workgroups per CU.)
+  constexpr int EPCO = 16 / (int)sizeof(TO);
+  const bool chunked = sizeof(TO) == sizeof(T) && p.vecC && !p.atomic && !p.accumulate && p.N % EPCO == 0 && p.ldc % EPCO == 0;
+  const size_t cl = chunked ? (size_t)BM * (BN * sizeof(TO) + 16) : (size_t)BM * (BN * 4 + 16);
   if (cl > lds) lds = cl;
-  static bool granted = false;
-  if (lds > 48 * 1024 && !granted) {
+  static size_t granted = 0;
+  if (lds > 48 * 1024 && lds > granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<T, TO, BM, BN, NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    granted = true;
+    granted = lds;
   }
   hipLaunchKernelGGL((gemm_glds_kernel<T, TO, BM, BN, NS>), grid, dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();

@@ -82,12 +82,13 @@ class Trainer():
         columns (Decoder.preprocess strips PAD, so the targets are unchanged; the extra zero frames are seen by the model exactly
         like the collate function's own padding of shorter utterances) -- and the graph is replayed.  The first batch of a new
         shape runs eagerly (that IS its training step) and captures.  Returns (loss value, gold_seq, hyp_seq) or None when the
-        shapes do not fit (falls back to eager launches)."""
+        shapes do not fit (falls back to eager launches).  Under --parallel (an active gradient reducer) the step is the three-graph
+        form of asr_hip/graph.py with the RCCL all-reduces between the graphs: every rank pads to the same bucket (the sampler
+        hands every rank the same bin, so the padded shape is a function of the bin), so all ranks replay the same sequence."""
         from asr_hip.graph import GraphedTrainStep
         a = constant.args
-        red = getattr(opt.optimizer, "reducer", None)
         L = int(a.tgt_max_len) - 1
-        if (red is not None and red.active) or tgt.shape[1] > L or src.dim() != 4:
+        if tgt.shape[1] > L or src.dim() != 4:
             return None
         N = int(a.graph_buckets)
         B, C, F, T = src.shape
@@ -104,7 +105,8 @@ class Trainer():
             gs = graphs[key] = GraphedTrainStep(model, opt, smoothing, src_b, lens, tgt_b,
                                                 clip_max_norm=a.max_norm if a.clip else None, warmup_steps=1,
                                                 replay_after_capture=False)
-            return gs.warm                              # the eager step the constructor ran IS this batch's training step
+            loss, gold_seq, hyp_seq = gs.warm           # the eager step the constructor ran IS this batch's training step
+            return self._global_loss(opt, loss), gold_seq, hyp_seq
         else:
             gs.src[..., :T].copy_(src, non_blocking=True)
             if Tb > T:
@@ -113,7 +115,31 @@ class Trainer():
             gs.tgt[:, :tgt.shape[1]].copy_(tgt, non_blocking=True)
             gs.sync_step_counter()
             gs(src_len=lens)
-        return gs.loss, gs.gold_seq, gs.hyp_seq
+        return self._global_loss(opt, gs.loss), gs.gold_seq, gs.hyp_seq
+
+    @staticmethod
+    def publish_mean_loss(opt, loss):
+        """Data-parallel normalisation for a loss that is a MEAN over the local batch (CTC, reference utils/metrics.py:133-154 with
+        reduction 'mean'): every rank back-propagates its local mean; the stats slot of the gradient buffer gets [local mean, 1], so
+        the one gradient all-reduce also produces [sum of the local means, number of ranks] and the optimiser divides the summed
+        gradients by the rank count -- the mean over the gathered batch (the sampler gives every rank the same number of
+        utterances), which is what the reference's nn.DataParallel computes.  Call between the loss and backward()."""
+        red = getattr(opt.optimizer, "reducer", None)
+        if red is None or not red.active:
+            return
+        st = opt.optimizer.flat.stats
+        st[0:1].copy_(loss.detach().reshape(1).float())
+        st[1:2].fill_(1.0)
+
+    @staticmethod
+    def _global_loss(opt, local_loss):
+        """Data parallel: the reference's number is the mean over the gathered batch = all-reduced loss sum / all-reduced token
+        count, both in the gradient buffer's stats slot once the step has run (device tensors: no host synchronisation)."""
+        red = getattr(opt.optimizer, "reducer", None)
+        if red is None or not red.active:
+            return local_loss
+        st = opt.optimizer.flat.stats
+        return st[0] / st[1].clamp_min(1.0)
 
     def _run_batch(self, model, data, smoothing, loss_type, id2label, opt=None):
         src, tgt, src_percentages, src_lengths, tgt_lengths = data
@@ -131,13 +157,11 @@ class Trainer():
             opt.zero_grad()
         pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)
         if loss_type == "ctc":
-            red = getattr(getattr(opt, "optimizer", None), "reducer", None) if opt is not None else None
-            if red is not None and red.active:
-                raise RuntimeError("--loss ctc is single-GPU here: the data-parallel loss normalisation (global token count in "
-                                   "the gradient buffer's stats slot) is implemented for the cross-entropy path only")
             # reference trainer.py:81-85: input lengths = source percentages x decoder positions, targets' true lengths
             sizes = (src_percentages.float() * int(pred.size(1))).int()
             loss, sums = calculate_metrics(pred, gold, input_lengths=sizes, target_lengths=tgt_lengths, loss_type="ctc")
+            if opt is not None:
+                self.publish_mean_loss(opt, loss)
         else:
             loss, sums = calculate_metrics(pred, gold, smoothing=smoothing, loss_type=loss_type, sync=False)
         finite = torch.isfinite(loss.detach()).float()
