@@ -319,7 +319,7 @@ def main():
         return loss
 
     # The step is replayed from captured hipGraphs (same kernels, no per-launch host cost): one graph on one GPU; under data
-    # parallelism three graphs with the RCCL all-reduces between them (asr_hip/graph.py).
+    # parallelism four graphs with the RCCL all-reduces between them (asr_hip/graph.py).
     gs = None
     if not a.eager:
         from asr_hip.graph import GraphedTrainStep
@@ -390,7 +390,7 @@ def main():
         value = frames / dt
         peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         mode = "eager" if a.eager else ("hipGraph replay" if red is None or not red.active else
-                                        "3 hipGraphs per step, RCCL all-reduces between them")
+                                        "4 hipGraphs per step, RCCL all-reduces between them")
         out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic", "launch_mode": mode,
@@ -414,8 +414,8 @@ def main():
                           "final_loss": final_loss}}
         if exposure is not None:
             out["config"]["gradient_allreduce"] = dict(exposure, bytes=4 * red.flat.total_all,
-                                                       note="147 MB fp32 gradients + stats slot; the encoder/decoder slice is in "
-                                                            "flight during the conv backward graph")
+                                                       note="147 MB fp32 gradients + stats slot; the decoder slice is in flight during the encoder's "
+                                                            "backward graph, the encoder slice during the conv backward graph")
         if prof is not None and (libri or lowrank):
             tot_ms, n = prof["GEMM family (asr_gemm_*)"]
             if n > 0 and tot_ms > 0:

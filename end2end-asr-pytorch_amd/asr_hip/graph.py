@@ -6,17 +6,22 @@ step (ops.step_state()).
 
 Single GPU: ONE graph.
 
-Data parallel (a GradReducer is attached to the optimiser): THREE graphs with the RCCL collectives BETWEEN them -- a
+Data parallel (a GradReducer is attached to the optimiser): FOUR graphs with the RCCL collectives BETWEEN them -- a
 collective inside a capture ties the graph to the communicator's internal streams and could not be validated on a
-one-GPU box, while graph -> all-reduce -> graph is ordinary stream ordering:
+one-GPU box, while graph -> all-reduce -> graph is ordinary stream ordering.  The flat gradient buffer is laid out
+[encoder | decoder | conv front end | stats] (registration order of models/asr/transformer.py), and backward produces the
+slices right to left except for the conv slice, which comes last:
 
-    graph A   step_advance, zero_grad, conv front end forward, encoder, decoder, CE, backward down to the conv output
-      -> all-reduce (async, RCCL's stream) of the encoder + decoder slice of the flat gradient buffer (99 % of the bytes)
-    graph B   conv front end backward                      (runs WHILE the all-reduce above is in flight)
-      -> all-reduce of the conv slice + the stats slot [loss sum, token count, num_correct]; wait for both
+    graph A1  step_advance, zero_grad, conv front end forward, encoder, decoder, CE, backward through the DECODER
+      -> all-reduce (async, RCCL's stream) of the decoder slice (57 % of the bytes)
+    graph A2  backward through the ENCODER          (the latency-bound part of backward: the decoder slice flies under it)
+      -> all-reduce of the encoder slice (42 %)
+    graph B   conv front end backward                      (the encoder slice flies under it)
+      -> all-reduce of the conv slice (1.5 MB) + the stats slot [loss sum, token count, num_correct]; wait for all three
     graph C   (clip) + Noam/Adam with 1 / global token count folded into the gradient scale
 
-The three graphs share one memory pool (activations saved by A are read by B) and are always replayed in this order.
+(Round 2 had one cut: the whole 145 MB transformer slice under the conv backward alone -- the densest MFMA + HBM part of the step.)
+The graphs share one memory pool (activations saved by A1 are read by A2 and B) and are always replayed in this order.
 Shapes are static per instance: one GraphedTrainStep per (B, T_src, L_tgt) bucket.
 """
 import torch
@@ -47,6 +52,7 @@ class GraphedTrainStep:
         self.factor_ms = float(opt.factor) * float(opt.model_size) ** -0.5
         if self.red is not None:
             self._split = self._conv_split(adam.flat)
+            self._split_dec = self._decoder_split(adam.flat, self.core, self._split)
             self.red.hold = True                      # the collectives are issued here, between the graphs
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -65,16 +71,18 @@ class GraphedTrainStep:
                 self.loss, self.sums = self._body_single()
             self.graphs = [self.graph]
         else:
-            self.graph_a, self.graph_b, self.graph_c = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            self.graph_a, self.graph_a2, self.graph_b, self.graph_c = (torch.cuda.CUDAGraph() for _ in range(4))
             with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
-                self.loss, self.sums, feats, dfeats = self._body_a()
+                self.loss, self.sums, st = self._body_a()
             pool = self.graph_a.pool()
+            with torch.cuda.graph(self.graph_a2, pool=pool, capture_error_mode="thread_local"):
+                self._body_a2(st)
             with torch.cuda.graph(self.graph_b, pool=pool, capture_error_mode="thread_local"):
-                self._body_b(feats, dfeats)
+                self._body_b(st)
             with torch.cuda.graph(self.graph_c, pool=pool, capture_error_mode="thread_local"):
                 self._body_c()
-            del feats, dfeats
-            self.graphs = [self.graph_a, self.graph_b, self.graph_c]
+            del st
+            self.graphs = [self.graph_a, self.graph_a2, self.graph_b, self.graph_c]
         if replay_after_capture:
             self._host_after()                           # capture does not execute; replay below does
             self._replay()
@@ -103,6 +111,21 @@ class GraphedTrainStep:
             raise RuntimeError("the conv parameters are expected at the end of the flat parameter buffer")
         return flat.offsets[first]
 
+    @staticmethod
+    def _decoder_split(flat, core, conv_split):
+        """Offset where the decoder's parameters begin ([encoder | decoder | conv]); conv_split when the model has no such layout
+        (then the whole transformer slice is exchanged in one piece)."""
+        dec = {id(p) for p in core.decoder.parameters()}
+        idx = [i for i, p in enumerate(flat.params) if id(p) in dec]
+        if not idx:
+            return conv_split
+        first, last = min(idx), max(idx)
+        contiguous = all(id(p) in dec for p in flat.params[first:last + 1])
+        enc_before = all(flat.offsets[i] >= conv_split or id(flat.params[i]) not in dec for i in range(first))
+        if not contiguous or not enc_before or flat.offsets[last] >= conv_split:
+            return conv_split
+        return flat.offsets[first]
+
     def _body_a(self):
         ops.step_advance()
         self.opt.zero_grad()
@@ -110,17 +133,22 @@ class GraphedTrainStep:
         feats = core._features(self.src)
         leaf = feats.detach().requires_grad_(feats.requires_grad)
         enc_out, _ = core.encoder(leaf, self.src_len)
-        pred, gold, *_ = core.decoder(self.tgt, enc_out, self.src_len)
+        enc_leaf = enc_out.detach().requires_grad_(True)          # second cut: the decoder's backward ends here
+        pred, gold, *_ = core.decoder(self.tgt, enc_leaf, self.src_len)
         self.hyp_seq = ops.argmax_rows(pred.detach().reshape(-1, pred.shape[-1])).view(pred.shape[0], pred.shape[1])
         self.gold_seq = gold
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
         loss.backward()
         ops.join_deferred()                     # every forked stream must have re-joined before this graph ends
-        return loss.detach(), sums, feats, leaf.grad
+        return loss.detach(), sums, {"feats": feats, "leaf": leaf, "enc_out": enc_out, "d_enc": enc_leaf.grad}
 
-    def _body_b(self, feats, dfeats):
-        if feats.requires_grad:
-            feats.backward(dfeats)
+    def _body_a2(self, st):
+        st["enc_out"].backward(st["d_enc"])
+        ops.join_deferred()
+
+    def _body_b(self, st):
+        if st["feats"].requires_grad:
+            st["feats"].backward(st["leaf"].grad)
         ops.join_deferred()
 
     def _body_c(self, guard=None):
@@ -135,21 +163,26 @@ class GraphedTrainStep:
         adam.step_device(self.factor_ms, float(self.opt.warmup), float(self.opt.min_lr), self.lr_dev, guard=guard)
 
     def _exchange_a(self):
-        return self.red.all_reduce_range(0, self._split)
+        return self.red.all_reduce_range(self._split_dec, self._split)           # decoder slice
 
-    def _exchange_b(self, wa):
-        wb = self.red.all_reduce_range(self._split, self.red.flat.total_all)
-        for w in (wa, wb):
+    def _exchange_a2(self):
+        return self.red.all_reduce_range(0, self._split_dec)                     # encoder slice
+
+    def _exchange_b(self, works):
+        wb = self.red.all_reduce_range(self._split, self.red.flat.total_all)     # conv slice + stats slot
+        for w in list(works) + [wb]:
             if w is not None:
                 w.wait()
 
     def _eager_step(self):
         if self.red is None:
             return self._body_single()
-        loss, sums, feats, dfeats = self._body_a()
+        loss, sums, st = self._body_a()
         wa = self._exchange_a()
-        self._body_b(feats, dfeats)
-        self._exchange_b(wa)
+        self._body_a2(st)
+        wa2 = self._exchange_a2()
+        self._body_b(st)
+        self._exchange_b((wa, wa2))
         self._body_c()
         return loss, sums
 
@@ -159,8 +192,10 @@ class GraphedTrainStep:
             return
         self.graph_a.replay()
         wa = self._exchange_a()
+        self.graph_a2.replay()
+        wa2 = self._exchange_a2()
         self.graph_b.replay()
-        self._exchange_b(wa)
+        self._exchange_b((wa, wa2))
         self.graph_c.replay()
 
     def _host_after(self):

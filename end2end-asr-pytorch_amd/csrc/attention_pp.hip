@@ -196,10 +196,8 @@ __device__ __forceinline__ void mask_tile(f32x16_t (&s)[2], int k0, int half, in
 // softmax phase: relative scores (log2 units) -> P as the packed B operand pk[key block][k step].  Everything still at the old
 // reference (O, l, and this tile's scores) is moved at ONE point, before the tile's probabilities are formed; the previous tile's
 // P V is complete by then (it was issued before this tile's S in program order).
-template <bool DROP>
-__device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_t (&o)[2], uint4 (&pk)[2][2], uint32_t rkey, int k0,
-                                             int half, uint32_t thr, float c2) {
-  const uint32_t thrm1 = (thr - 1u) * 0x10001u;        // (thr - 1) in both halves (DROP: thr >= 1)
+// part 1: tile maximum, and (rare, wave-uniform) the move of the reference with everything that still sits at the old one
+__device__ __forceinline__ void softmax_decide(f32x16_t (&s)[2], Soft& st, f32x16_t (&o)[2], float c2) {
   float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
   for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
@@ -219,6 +217,12 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_
     s[1] -= delta;
     st.nref -= delta;
   }
+}
+// part 2: probabilities, row sums, dropout, packed B operand
+template <bool DROP>
+__device__ __forceinline__ void softmax_form(f32x16_t (&s)[2], Soft& st, uint4 (&pk)[2][2], uint32_t rkey, int k0, int half, uint32_t thr,
+                                             float c2) {
+  const uint32_t thrm1 = (thr - 1u) * 0x10001u;        // (thr - 1) in both halves (DROP: thr >= 1)
   s[0] *= c2;                                          // v_pk_mul_f32: log2 units
   s[1] *= c2;
 #pragma unroll
@@ -251,6 +255,13 @@ __device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_
       }
       pk[kb][j] = make_uint4(w[0], w[1], w[2], w[3]);
     }
+}
+
+template <bool DROP>
+__device__ __forceinline__ void softmax_tile(f32x16_t (&s)[2], Soft& st, f32x16_t (&o)[2], uint4 (&pk)[2][2], uint32_t rkey, int k0,
+                                             int half, uint32_t thr, float c2) {
+  softmax_decide(s, st, o, c2);
+  softmax_form<DROP>(s, st, pk, rkey, k0, half, thr, c2);
 }
 
 // matrix work: O^T += V(t)^T P(t)^T (two accumulator chains) and S^T(t+1) = K(t+1) Q^T - ref (two chains)
@@ -310,7 +321,41 @@ __device__ __forceinline__ void chunk_iter(const AttnArgs& p, const Ctx& c, cons
   if (t + 3 < c.ntile) sg.issue(c.lds0 + (unsigned)(STG * 2 * TILE), (t + 3) * KT);
 }
 
-template <bool DROP, bool TAIL, int NW>
+// Software-pipelined iteration (ATTN_PP_PIPE=1): the first contraction of tile t + 1 is issued inside the exp / sum / pack stream
+// of tile t -- one MFMA, then a dozen vector instructions (sched_group_barrier) -- so that the matrix pipe runs under the wave's
+// OWN softmax instead of waiting for the other workgroup's wave to be in the complementary phase.  Costs the registers of a second
+// score tile (sa / sb alternate roles: two iterations per loop trip, no copies).
+template <bool DROP, int NW>
+__device__ __forceinline__ void pipe_iter(const AttnArgs& p, const Ctx& c, const Stager<NW>& sg, int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2],
+                                          f32x16_t (&o)[2], Soft& st, Frags& f, const uint4 (&qf)[4], uint4 (&pk)[2][2]) {
+  const unsigned stg_t = (unsigned)((t % NS) * 2 * TILE), stg_n = (unsigned)(((t + 1) % NS) * 2 * TILE);
+  const bool more = t + 1 < c.ntile;
+  if (more) read_k(f.kf, stg_n, c.koff);
+  const int k0 = t * KT;
+  if (k0 + KT > c.kend) mask_tile(cur, k0, c.half, c.kend);
+  softmax_decide(cur, st, o, c.c2);
+  __builtin_amdgcn_sched_barrier(0);
+  if (more) {
+    qk_phase(nxt, f, qf, st.nref);
+    softmax_form<DROP>(cur, st, pk, c.rkey, k0, c.half, p.thr, c.c2);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, DROP ? 24 : 12, 0);      // vector instructions of the softmax stream
+    }
+  } else {
+    softmax_form<DROP>(cur, st, pk, c.rkey, k0, c.half, p.thr, c.c2);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  read_v(f.vf, stg_t + TILE, c.voff);              // (read here, not at the top: two score tiles + both operand sets do not fit 256 registers)
+  pv_phase<0>(o, f, pk);
+  pv_phase<1>(o, f, pk);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (t + 3 < c.ntile) sg.issue(c.lds0 + stg_t, (t + 3) * KT);
+}
+
+template <bool DROP, bool TAIL, int NW, bool PIPE>
 __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned char* smem, int bh, int q0, int prio) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5, l16 = lane & 15, dh = (lane >> 4) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -363,6 +408,14 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
       read_k(f.kf, 0u, c.koff);
       qk_phase(s, f, qf, st.nref);
     }
+    if constexpr (PIPE) {
+      f32x16_t s2[2] = {zero16, zero16};
+      for (int t = 0; t < ntile; t += 2) {
+        pipe_iter<DROP, NW>(p, c, sg, t, s, s2, o, st, f, qf, pk);
+        if (t + 1 >= ntile) break;
+        pipe_iter<DROP, NW>(p, c, sg, t + 1, s2, s, o, st, f, qf, pk);
+      }
+    } else
     for (int t = 0; t < ntile; t += 3) {
       chunk_iter<DROP, 0, NW>(p, c, sg, smem, t, s, o, st, f, qf, pk);
       if (t + 1 >= ntile) break;
@@ -445,21 +498,31 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   }
 }
 
-template <bool DROP, int NW>
+template <bool DROP, int NW, bool PIPE>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pp_bf16_d64_kernel(AttnArgs p, int n_full, int n_tail, int prio) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[NS * 2 * TILE];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int BH = p.B * p.H;
   const int n_main = n_full * BH;
   const int bid = (int)blockIdx.x;
+  // Stagger (prio bits 8..): the two workgroups that share a CU start together and run phases of equal length, i.e. in lockstep --
+  // both in their softmax phase, then both in their matrix phase -- which is the one arrangement in which the SIMD's vector and
+  // matrix pipes never overlap.  Every other workgroup (by the dispatch order's CU round: bit 8 of the block id, or bit 3) starts
+  // `stagger` x 64 cycles late; equal run times keep the offset for the rest of the launch.
+  {
+    const int stagger = (prio >> 8) & 0xff, sel = (prio >> 16) & 1;
+    if (stagger && ((bid >> (sel ? 3 : 8)) & 1))
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+    prio &= 0xff;
+  }
   if (bid < n_main) {
     const int vid = xcd_linear(bid, n_main);
     const int bh = vid / n_full;
-    attn_fwd_pp_body<DROP, false, NW>(p, smem, bh, (vid - bh * n_full) * (32 * NW) + wave * 32, prio);
+    attn_fwd_pp_body<DROP, false, NW, PIPE>(p, smem, bh, (vid - bh * n_full) * (32 * NW) + wave * 32, prio);
   } else {
     const int vid = xcd_linear(bid - n_main, n_tail * BH);
     const int bh = vid / n_tail;
-    attn_fwd_pp_body<DROP, true, NW>(p, smem, bh, n_full * (32 * NW) + (vid - bh * n_tail) * 32, prio);
+    attn_fwd_pp_body<DROP, true, NW, false>(p, smem, bh, n_full * (32 * NW) + (vid - bh * n_tail) * 32, prio);
   }
 }
 
@@ -482,13 +545,18 @@ int attn_pp_fwd(const AttnArgs& p, hipStream_t s) {
   int nf = n_full;
   if (asr_tuning("ATTN_PP_TAIL", 1) == 0 && rest > 0) { nf = n_full + 1; n_tail = 0; }      // A/B: leftover queries as one more (partly idle) chunk
   const dim3 grid((unsigned)((nf + n_tail) * BH));
-  const int prio = (int)asr_tuning("ATTN_PP_PRIO", 0);
+  const int prio = (int)asr_tuning("ATTN_PP_PRIO", 0) | ((int)asr_tuning("ATTN_PP_STAGGER", 0) << 8) |
+                   ((int)asr_tuning("ATTN_PP_STAGGER_SEL", 0) << 16);
+  const bool pipe = asr_tuning("ATTN_PP_PIPE", 0) != 0;
   if (nw == 8) {
-    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 8><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
-    else attn_fwd_pp_bf16_d64_kernel<false, 8><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
+    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 8, false><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
+    else attn_fwd_pp_bf16_d64_kernel<false, 8, false><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
+  } else if (pipe) {
+    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 4, true><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
+    else attn_fwd_pp_bf16_d64_kernel<false, 4, true><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
   } else {
-    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 4><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
-    else attn_fwd_pp_bf16_d64_kernel<false, 4><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
+    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 4, false><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
+    else attn_fwd_pp_bf16_d64_kernel<false, 4, false><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;

@@ -82,7 +82,7 @@ class Trainer():
         columns (Decoder.preprocess strips PAD, so the targets are unchanged; the extra zero frames are seen by the model exactly
         like the collate function's own padding of shorter utterances) -- and the graph is replayed.  The first batch of a new
         shape runs eagerly (that IS its training step) and captures.  Returns (loss value, gold_seq, hyp_seq) or None when the
-        shapes do not fit (falls back to eager launches).  Under --parallel (an active gradient reducer) the step is the three-graph
+        shapes do not fit (falls back to eager launches).  Under --parallel (an active gradient reducer) the step is the four-graph
         form of asr_hip/graph.py with the RCCL all-reduces between the graphs: every rank pads to the same bucket (the sampler
         hands every rank the same bin, so the padded shape is a function of the bin), so all ranks replay the same sequence."""
         from asr_hip.graph import GraphedTrainStep

@@ -1,7 +1,7 @@
 """Data-parallel equivalence on the GPU: TWO ranks, each with its share of a
 golden batch, must reproduce the reference's SINGLE-process numbers -- loss over the gathered batch, every gradient,
 the weights after two Noam/Adam steps -- both with the eager bucketed reducer (trainer path) and with the
-three-graphs-per-step replay (bench path).  The ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+four-graphs-per-step replay (bench path).  The ranks share cuda:0 and talk over gloo (RCCL refuses two ranks on one
 device); the product code path is the same, only the backend string differs.  Also: clip_grad_norm_() followed by
 step() reduces the gradients once."""
 import os
@@ -115,7 +115,7 @@ if mode == "eager":
 else:
     from asr_hip.graph import GraphedTrainStep
     gs = GraphedTrainStep(model, opt, sm, src, src_len, tgt, clip_max_norm=1e9, warmup_steps=1)   # 1 eager + 1 replayed step
-    assert len(gs.graphs) == 3 and opt._step == 2
+    assert len(gs.graphs) == 4 and opt._step == 2
     assert abs(gs.global_loss() - float(z["loss2"])) < 5e-5, gs.global_loss()
     assert abs(gs.lr_dev.item() - float(z["lr2"])) < 1e-11
 lr_sum = float(z["lr1"]) + float(z["lr2"])
