@@ -140,22 +140,28 @@ def queue_wgrad(dy, x, dw, db, N, K):
 
 
 def flush_wgrads():
-    import ctypes
     while _wgrad_q:
         grp = _wgrad_q[:WGRAD_GROUP]
         del _wgrad_q[:WGRAD_GROUP]
-        n = len(grp)
-        P_, L_, I_ = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
-        rc = L.load().asr_gemm_tn_grouped(
-            n, P_(*[e[0].data_ptr() for e in grp]), L_(*[e[0].stride(0) for e in grp]), P_(*[e[1].data_ptr() for e in grp]),
-            L_(*[e[1].stride(0) for e in grp]), P_(*[e[2].data_ptr() for e in grp]), L_(*[e[2].stride(0) for e in grp]),
-            P_(*[(e[3].data_ptr() if e[3] is not None else None) for e in grp]), I_(*[e[0].shape[0] for e in grp]),
-            I_(*[e[4] for e in grp]), I_(*[e[5] for e in grp]), L.dt(grp[0][0]), L.stream())
-        if rc == L.EUNSUPPORTED:
-            for dy, x, dw, db, N, K in grp:
-                gemm_tn(dy, x, dw, colsum_acc=db, N=N, K=K)
-        else:
-            L.check(rc, "asr_gemm_tn_grouped")
+        gemm_tn_grouped(grp)
+
+
+def gemm_tn_grouped(grp):
+    """grp: up to 16 tuples (dy (M,>=N) bf16, x (M,>=K) bf16, dw (N,K) fp32, db (N) fp32 or None, N, K): dw += dy[:, :N]^T x[:, :K] and
+    db += column sums of dy for all of them in one launch (asr_gemm_tn_grouped); per-layer launches when a layout does not fit."""
+    import ctypes
+    n = len(grp)
+    P_, L_, I_ = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    rc = L.load().asr_gemm_tn_grouped(
+        n, P_(*[e[0].data_ptr() for e in grp]), L_(*[e[0].stride(0) for e in grp]), P_(*[e[1].data_ptr() for e in grp]),
+        L_(*[e[1].stride(0) for e in grp]), P_(*[e[2].data_ptr() for e in grp]), L_(*[e[2].stride(0) for e in grp]),
+        P_(*[(e[3].data_ptr() if e[3] is not None else None) for e in grp]), I_(*[e[0].shape[0] for e in grp]),
+        I_(*[e[4] for e in grp]), I_(*[e[5] for e in grp]), L.dt(grp[0][0]), L.stream())
+    if rc == L.EUNSUPPORTED:
+        for dy, x, dw, db, N, K in grp:
+            gemm_tn(dy, x, dw, colsum_acc=db, N=N, K=K)
+    else:
+        L.check(rc, "asr_gemm_tn_grouped")
 
 
 def join_deferred():

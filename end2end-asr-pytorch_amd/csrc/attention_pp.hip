@@ -321,41 +321,7 @@ __device__ __forceinline__ void chunk_iter(const AttnArgs& p, const Ctx& c, cons
   if (t + 3 < c.ntile) sg.issue(c.lds0 + (unsigned)(STG * 2 * TILE), (t + 3) * KT);
 }
 
-// Software-pipelined iteration (ATTN_PP_PIPE=1): the first contraction of tile t + 1 is issued inside the exp / sum / pack stream
-// of tile t -- one MFMA, then a dozen vector instructions (sched_group_barrier) -- so that the matrix pipe runs under the wave's
-// OWN softmax instead of waiting for the other workgroup's wave to be in the complementary phase.  Costs the registers of a second
-// score tile (sa / sb alternate roles: two iterations per loop trip, no copies).
-template <bool DROP, int NW>
-__device__ __forceinline__ void pipe_iter(const AttnArgs& p, const Ctx& c, const Stager<NW>& sg, int t, f32x16_t (&cur)[2], f32x16_t (&nxt)[2],
-                                          f32x16_t (&o)[2], Soft& st, Frags& f, const uint4 (&qf)[4], uint4 (&pk)[2][2]) {
-  const unsigned stg_t = (unsigned)((t % NS) * 2 * TILE), stg_n = (unsigned)(((t + 1) % NS) * 2 * TILE);
-  const bool more = t + 1 < c.ntile;
-  if (more) read_k(f.kf, stg_n, c.koff);
-  const int k0 = t * KT;
-  if (k0 + KT > c.kend) mask_tile(cur, k0, c.half, c.kend);
-  softmax_decide(cur, st, o, c.c2);
-  __builtin_amdgcn_sched_barrier(0);
-  if (more) {
-    qk_phase(nxt, f, qf, st.nref);
-    softmax_form<DROP>(cur, st, pk, c.rkey, k0, c.half, p.thr, c.c2);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, DROP ? 24 : 12, 0);      // vector instructions of the softmax stream
-    }
-  } else {
-    softmax_form<DROP>(cur, st, pk, c.rkey, k0, c.half, p.thr, c.c2);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  read_v(f.vf, stg_t + TILE, c.voff);              // (read here, not at the top: two score tiles + both operand sets do not fit 256 registers)
-  pv_phase<0>(o, f, pk);
-  pv_phase<1>(o, f, pk);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (t + 3 < c.ntile) sg.issue(c.lds0 + stg_t, (t + 3) * KT);
-}
-
-template <bool DROP, bool TAIL, int NW, bool PIPE>
+template <bool DROP, bool TAIL, int NW>
 __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned char* smem, int bh, int q0, int prio) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, half = lane >> 5, l16 = lane & 15, dh = (lane >> 4) & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -408,14 +374,6 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
       read_k(f.kf, 0u, c.koff);
       qk_phase(s, f, qf, st.nref);
     }
-    if constexpr (PIPE) {
-      f32x16_t s2[2] = {zero16, zero16};
-      for (int t = 0; t < ntile; t += 2) {
-        pipe_iter<DROP, NW>(p, c, sg, t, s, s2, o, st, f, qf, pk);
-        if (t + 1 >= ntile) break;
-        pipe_iter<DROP, NW>(p, c, sg, t + 1, s2, s, o, st, f, qf, pk);
-      }
-    } else
     for (int t = 0; t < ntile; t += 3) {
       chunk_iter<DROP, 0, NW>(p, c, sg, smem, t, s, o, st, f, qf, pk);
       if (t + 1 >= ntile) break;
@@ -498,7 +456,7 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   }
 }
 
-template <bool DROP, int NW, bool PIPE>
+template <bool DROP, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pp_bf16_d64_kernel(AttnArgs p, int n_full, int n_tail, int prio) {
   __shared__ __attribute__((aligned(256))) unsigned char smem[NS * 2 * TILE];
   const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -518,11 +476,11 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd_pp_bf16_d64_kernel(AttnAr
   if (bid < n_main) {
     const int vid = xcd_linear(bid, n_main);
     const int bh = vid / n_full;
-    attn_fwd_pp_body<DROP, false, NW, PIPE>(p, smem, bh, (vid - bh * n_full) * (32 * NW) + wave * 32, prio);
+    attn_fwd_pp_body<DROP, false, NW>(p, smem, bh, (vid - bh * n_full) * (32 * NW) + wave * 32, prio);
   } else {
     const int vid = xcd_linear(bid - n_main, n_tail * BH);
     const int bh = vid / n_tail;
-    attn_fwd_pp_body<DROP, true, NW, false>(p, smem, bh, n_full * (32 * NW) + (vid - bh * n_tail) * 32, prio);
+    attn_fwd_pp_body<DROP, true, NW>(p, smem, bh, n_full * (32 * NW) + (vid - bh * n_tail) * 32, prio);
   }
 }
 
@@ -535,29 +493,19 @@ int attn_pp_fwd(const AttnArgs& p, hipStream_t s) {
   if ((((uintptr_t)p.Out) & 15) != 0 || p.o_st % 8 != 0 || p.o_sb % 8 != 0) return ASR_EUNSUPPORTED;
   if (p.Out32 && (((uintptr_t)p.Out32) & 15) != 0) return ASR_EUNSUPPORTED;
   const int BH = p.B * p.H;
-  // workgroups of 8 waves (256 queries: a K / V tile is staged once for eight waves -- 2 LDS-DMA pieces per wave and tile instead
-  // of 4) when the sequence has at least one such chunk, else 4 waves (128 queries); ATTN_PP_WAVES forces either
-  const int64_t nwt = asr_tuning("ATTN_PP_WAVES", 0);
-  const int nw = nwt == 4 || nwt == 8 ? (int)nwt : (p.Tq >= 256 ? 8 : 4);
+  constexpr int nw = 4;
   const int n_full = p.Tq / (32 * nw);
   const int rest = p.Tq - n_full * 32 * nw;
   int n_tail = (rest + 31) / 32;
   int nf = n_full;
   if (asr_tuning("ATTN_PP_TAIL", 1) == 0 && rest > 0) { nf = n_full + 1; n_tail = 0; }      // A/B: leftover queries as one more (partly idle) chunk
   const dim3 grid((unsigned)((nf + n_tail) * BH));
-  const int prio = (int)asr_tuning("ATTN_PP_PRIO", 0) | ((int)asr_tuning("ATTN_PP_STAGGER", 0) << 8) |
-                   ((int)asr_tuning("ATTN_PP_STAGGER_SEL", 0) << 16);
-  const bool pipe = asr_tuning("ATTN_PP_PIPE", 0) != 0;
-  if (nw == 8) {
-    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 8, false><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
-    else attn_fwd_pp_bf16_d64_kernel<false, 8, false><<<grid, dim3(512), 0, s>>>(p, nf, n_tail, prio);
-  } else if (pipe) {
-    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 4, true><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
-    else attn_fwd_pp_bf16_d64_kernel<false, 4, true><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
-  } else {
-    if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, 4, false><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
-    else attn_fwd_pp_bf16_d64_kernel<false, 4, false><<<grid, dim3(256), 0, s>>>(p, nf, n_tail, prio);
-  }
+  // measured (profiles/r03_attention_pp_stagger_pipe_ab.txt): any delay of 4 .. 12 x 64 cycles on block-id bit 3 takes the north-star
+  // shape from 71.8 to 65.8 us at p = 0 and changes nothing elsewhere
+  const int prio = (int)asr_tuning("ATTN_PP_PRIO", 0) | ((int)asr_tuning("ATTN_PP_STAGGER", 8) << 8) |
+                   ((int)asr_tuning("ATTN_PP_STAGGER_SEL", 1) << 16);
+  if (p.thr) attn_fwd_pp_bf16_d64_kernel<true, nw><<<grid, dim3(64 * nw), 0, s>>>(p, nf, n_tail, prio);
+  else attn_fwd_pp_bf16_d64_kernel<false, nw><<<grid, dim3(64 * nw), 0, s>>>(p, nf, n_tail, prio);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -1001,6 +1001,142 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
   tn128p_body<NST>(p, smem, wid, gridDim.x == (unsigned)p.ntiles);
 }
 
+// ---- 256 x 256 blocks of dW, eight waves (4 x 2 grid of 64 x 128 quadrants), 32 rows of m per stage in an NST-deep ring.
+// Twice the flop per staged byte of the 128 x 128 block (128 instead of 64): the grouped launch below has ~500 of them in flight
+// with a contraction 1600 - 6400 rows long, so the block lives in its steady state, and what bounds the 128 x 128 form there is the
+// operand traffic per MFMA (4 LDS-DMA pieces and 16 transposing reads per 16 MFMAs; here 4 pieces and 24 reads per 32).
+// LDS image of an operand tile: [32 rows][32 chunks of 16 B]; chunk c of row r sits in slot c ^ key(r), key(r) = ((r & 3) | ((r >> 3)
+// & 1) << 2) << 1: the 8 rows one transposing read touches (r0 .. r0+3 and r0+8 .. r0+11, 32 bytes each) land on 8 different
+// 32-byte bank groups.
+__device__ __forceinline__ int tn256_key(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
+__device__ __forceinline__ uint4 tn256_pack(const unsigned char* tile, int lr, int g, int c0) {
+  const int row = 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);
+  const int chunk = col >> 3, half = (col >> 2) & 1;
+  const uint2 lo = asr_lds_read_tr16(tile + row * 512 + ((chunk ^ tn256_key(row)) << 4) + half * 8);
+  const uint2 hi = asr_lds_read_tr16(tile + (row + 4) * 512 + ((chunk ^ tn256_key(row + 4)) << 4) + half * 8);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+
+template <int NST>
+__device__ __forceinline__ void tn256_body(const Tn128Args& p, unsigned char* smem, int wid) {
+  constexpr int RM = 32, TILEB = RM * 512, STAGEB = 2 * TILEB;       // 16 KB per operand, 32 KB per stage
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  const int split = wid / p.ntiles, tile = wid % p.ntiles;
+  const int n0 = (tile / p.tiles_k) * 256, k0 = (tile % p.tiles_k) * 256;
+  const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
+  const int nstage = (m_end - m_beg + RM - 1) / RM;
+  const bool single = p.m_per_split >= p.M;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * 2 / 16);
+
+  // per-thread DMA pieces: 1024 chunks per operand tile = 2 per thread; chunk c = (row, slot), source chunk slot ^ key(row)
+  int64_t offA[2], offB[2];
+  int rowi[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid, row = c >> 5, slot = (c & 31) ^ tn256_key(row);
+    int ca = n0 * 2 / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;       // columns past N / K are never stored
+    int cb = k0 * 2 / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+    offA[i] = (int64_t)row * p.lda * 2 + (int64_t)ca * 16;
+    offB[i] = (int64_t)row * p.ldb * 2 + (int64_t)cb * 16;
+    rowi[i] = row;
+  }
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(&tn_zero_page);
+  auto stage = [&](int st) __attribute__((always_inline)) {
+    const unsigned sl = wave_lds + (unsigned)((st % NST) * STAGEB);
+    const int64_t mrow = m_beg + (int64_t)st * RM;
+    const unsigned char* ba = A + mrow * p.lda * 2;
+    const unsigned char* bb = B + mrow * p.ldb * 2;
+    const int valid = m_end - (int)mrow;                  // rows of this stage that exist (uniform)
+    if (valid >= RM) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        tn_dma(sl + i * 8192, ba + offA[i]);
+        tn_dma(sl + TILEB + i * 8192, bb + offB[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool in = rowi[i] < valid;
+        tn_dma(sl + i * 8192, in ? ba + offA[i] : zero);
+        tn_dma(sl + TILEB + i * 8192, in ? bb + offB[i] : zero);
+      }
+    }
+  };
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = p.colsum != nullptr && k0 == 0 && wk == 0;
+
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st)
+    if (st < nstage) stage(st);
+  for (int st = 0; st < nstage; ++st) {
+    // stage st has landed once at most the DMA pieces of the later stages are outstanding (4 pieces per stage and thread, in order)
+    const int ahead = min(NST - 2, nstage - 1 - st);
+    if (ahead >= 2) wait_vmcnt<8>();
+    else if (ahead == 1) wait_vmcnt<4>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();              // stage st visible to every wave; every wave is done reading stage st - 1
+    asm volatile("" ::: "memory");
+    if (st + NST - 1 < nstage) stage(st + NST - 1);
+    const unsigned char* sA = smem + (st % NST) * STAGEB;
+    const unsigned char* sB = sA + TILEB;
+    uint4 a[4], b[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = tn256_pack(sA, lr, g, wn * 64 + i * 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = tn256_pack(sB, lr, g, wk * 128 + j * 16);
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        Chunk<bf16_t> c; c.v = a[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mma16<bf16_t>(acc[i][j], a[i], b[j]);
+  }
+
+  // ---- the wave's 64 x 128 quadrant: lane (lr, g) holds rows 4g..4g+3 of column lr of every fragment
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int gn = n0 + wn * 64 + i * 16 + g * 4 + r;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int gk = k0 + wk * 128 + j * 16 + lr;
+        if (gn < p.N && gk < p.K) {
+          float* dst = p.C + (int64_t)gn * p.ldc + gk;
+          if (single) *dst += acc[i][j][r]; else atomicAdd(dst, acc[i][j][r]);
+        }
+      }
+    }
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int gn = n0 + wn * 64 + i * 16 + lr;
+      if (g == 0 && gn < p.N) atomicAdd(p.colsum + gn, v);
+    }
+  }
+}
+
 // ---- grouped form: the weight gradients of up to TN_GROUP_MAX linear layers in ONE launch.  A weight gradient is off the
 // critical path of backward (only the data gradient feeds the next layer), and alone it is latency bound: 16 - 64 blocks of dW, each
 // a serial chain over all M rows.  Queued and launched together at the end of backward, the layers' blocks fill the chip
@@ -1012,6 +1148,15 @@ struct TnGroupArgs {
   int first[TN_GROUP_MAX + 1];       // first[i] = number of blocks of the problems before i
   int n;
 };
+template <int NST>
+__global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  int i = 0;
+  while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
+  tn256_body<NST>(ga.p[i], smem, wid - ga.first[i]);
+}
 template <int NST>
 __global__ __launch_bounds__(256, 2) void gemm_tn128g_kernel(TnGroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1677,16 +1822,26 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     for (int b = a; b > 0 && M[order[b]] > M[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   TnGroupArgs ga{};
   int total = 0;
+  // 256 x 256 blocks (eight waves) with the rows of m cut into slices of <= TN_GROUP_MROWS so that the ~500 blocks of a step balance
+  // over the 256 CUs (fp32 atomics where a block of dW has more than one slice: 2 - 4 adds per element); TN_GROUP_TILE=128 keeps the
+  // 128 x 128 / four-wave form with one block per whole contraction
+  const bool big = asr_tuning("TN_GROUP_TILE", 256) == 256;
+  const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 1600);
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];
     Tn128Args& q = ga.p[j];
     q.A = dy[i]; q.B = x[i]; q.C = dw[i]; q.colsum = db[i]; q.ws = nullptr;
     q.lda = ld_dy[i]; q.ldb = ld_x[i]; q.ldc = ld_dw[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
-    q.tiles_k = (K[i] + 127) / 128;
-    q.ntiles = ((N[i] + 127) / 128) * q.tiles_k;
-    q.m_per_split = (M[i] + 31) / 32 * 32;
+    const int T = big ? 256 : 128;
+    q.tiles_k = (K[i] + T - 1) / T;
+    q.ntiles = ((N[i] + T - 1) / T) * q.tiles_k;
+    int splits = 1;
+    if (big && mrows > 0) splits = (M[i] + mrows - 1) / mrows;
+    if (splits < 1) splits = 1;
+    q.m_per_split = ((M[i] + splits - 1) / splits + 31) / 32 * 32;
+    splits = (M[i] + q.m_per_split - 1) / q.m_per_split;
     ga.first[j] = total;
-    total += q.ntiles;
+    total += q.ntiles * splits;
   }
   ga.first[cnt] = total;
   ga.n = cnt;
@@ -1694,10 +1849,16 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
   if (!granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     granted = true;
   }
   AsrProfScope prof(ASR_OP_GEMM, stream);
-  if (asr_tuning("TN_GROUP_STAGES", 3) == 4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);
+  const bool nst4 = asr_tuning("TN_GROUP_STAGES", 3) == 4;
+  if (big) {
+    if (nst4) hipLaunchKernelGGL(gemm_tn256g_kernel<4>, dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
+    else hipLaunchKernelGGL(gemm_tn256g_kernel<3>, dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
+  } else if (nst4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);
   else hipLaunchKernelGGL(gemm_tn128g_kernel<3>, dim3((unsigned)total), dim3(256), 3 * 16384, stream, ga);
   ASR_LAUNCH_CHECK();
   return ASR_OK;

@@ -286,6 +286,43 @@ def test_add_ln_dropout_consistency(ops, dtype):
     assert not torch.equal(yz2, yz)
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+def test_grouped_weight_gradients(ops, tile):
+    """asr_gemm_tn_grouped: the weight and bias gradients of several linear layers in ONE launch (every linear layer's dW in the
+    graph-replayed step, reference models/common_layers.py:136-142,181-187 via autograd) against fp32 torch.  Shapes: the model's
+    (512 x 512 / 1536 x 512 / 2048 x 512 / 512 x 2048 over 400 .. 1700 rows), a vocabulary-like N = 300 with a padded leading dimension,
+    K not a multiple of the block, M not a multiple of the 32-row stage, a problem without bias, an empty problem; both block
+    sizes (TN_GROUP_TILE = 128: one block per contraction; 256: eight waves, rows cut in slices that meet in fp32 atomics)."""
+    from asr_hip import lib as L
+    g = torch.Generator().manual_seed(17)
+    D = dev()
+    probs = []     # (M, N, K, ld_dy, ld_x, bias)
+    for M, N, K, ldy, ldx, hb in [(1700, 512, 512, 512, 512, True), (933, 1536, 512, 1536, 512, True), (400, 2048, 512, 2048, 512, True),
+                                 (1601, 512, 2048, 512, 2048, True), (640, 300, 512, 320, 512, True), (777, 512, 264, 512, 264, False),
+                                 (0, 64, 64, 64, 64, True), (3300, 256, 256, 256, 256, True)]:
+        dy = torch.zeros(max(M, 1), ldy)
+        dy[:, :N] = torch.randn(max(M, 1), N, generator=g)
+        x = torch.randn(max(M, 1), ldx, generator=g)
+        dyd, xd = dy[:M].to(D).bfloat16(), x[:M].to(D).bfloat16()
+        dw0 = torch.randn(N, K, generator=g)
+        db0 = torch.randn(N, generator=g) if hb else None
+        probs.append((dyd, xd, dw0.to(D), db0.to(D) if hb else None, N, K, dw0, db0))
+    L.set_tuning("TN_GROUP_TILE", tile)
+    try:
+        ops.gemm_tn_grouped([pr[:6] for pr in probs])
+        torch.cuda.synchronize()
+    finally:
+        L.set_tuning("TN_GROUP_TILE", None)
+    for dyd, xd, dw, db, N, K, dw0, db0 in probs:
+        dyf, xf = dyd.float().cpu(), xd.float().cpu()
+        ref = dw0 + dyf[:, :N].t() @ xf[:, :K]
+        tol = 2e-3 * max(1.0, float(ref.abs().max()))
+        assert (dw.cpu() - ref).abs().max().item() < tol, (dyd.shape, N, K, (dw.cpu() - ref).abs().max().item())
+        if db is not None:
+            refb = db0 + dyf[:, :N].sum(0)
+            assert (db.cpu() - refb).abs().max().item() < 2e-3 * max(1.0, float(refb.abs().max())), (N, K)
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def attn_ref(qx, kx, vx, H, d, key_len, key_pad, causal, scale):
     B, Tq, _ = qx.shape

@@ -1,6 +1,8 @@
 """A/B of the long-sequence attention forward's launch-structure switches: ATTN_PP_STAGGER (x 64 cycles start delay for every other
-workgroup of a CU), ATTN_PP_STAGGER_SEL (which block-id bit picks them), ATTN_PP_PIPE (S(t+1) issued inside the softmax stream of
-tile t), ATTN_PP_PRIO.  usage: python tools/ab/ab_attn_stagger.py"""
+workgroup of a CU), ATTN_PP_STAGGER_SEL (which block-id bit picks them), ATTN_PP_PRIO.  (Round 3 also measured, through switches that
+have since been removed: S(t+1) issued inside the softmax stream of tile t -- 71.0 vs 71.8 us, worse with dropout -- and 8-wave
+workgroups, plain 79.4 us and as a two-barrier ping-pong 101 us against 72.5: profiles/r03_attention_pp_*.txt.)
+usage: python tools/ab/ab_attn_stagger.py"""
 import os
 import sys
 
@@ -14,7 +16,7 @@ from asr_hip import ops  # noqa: E402
 import ab_attn_pp as AB  # noqa: E402
 
 D = torch.device("cuda")
-KEYS = ("ATTN_PP", "ATTN_PP_WAVES", "ATTN_PP_STAGGER", "ATTN_PP_STAGGER_SEL", "ATTN_PP_PIPE", "ATTN_PP_PRIO")
+KEYS = ("ATTN_PP", "ATTN_PP_STAGGER", "ATTN_PP_STAGGER_SEL", "ATTN_PP_PRIO")
 
 
 def setk(**kw):
@@ -23,22 +25,12 @@ def setk(**kw):
 
 
 def main():
-    # correctness of the pipelined variant first
-    setk(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_PIPE=1)
-    L.set_tuning("ATTN_PP_MIN", 1)
-    print("== ATTN_PP_PIPE=1 diagnostics")
-    for name, a in (("chunk Tq=128 Tk=64", (1, 1, 128, 64)), ("chunk Tq=128 Tk=192", (1, 2, 128, 192)), ("chunk Tq=128 Tk=448", (1, 2, 128, 448)),
-                    ("mixed Tq=800 Tk=800", (2, 8, 800, 800)), ("mixed Tq=795 Tk=795", (2, 8, 795, 795))):
-        AB.diag_case(name, *a, key_len=[a[3], max(1, a[3] * 3 // 4)][:a[0]] if a[0] == 2 else None)
-    L.set_tuning("ATTN_PP_MIN", None)
     variants = [("v1", dict(ATTN_PP=0))]
-    variants += [("pp4", dict(ATTN_PP=1, ATTN_PP_WAVES=4))]
+    variants += [("pp stag0", dict(ATTN_PP=1, ATTN_PP_STAGGER=0))]
     for sel in (0, 1):
         for st in (4, 8, 12, 16, 24):
-            variants.append(("stag%d/b%d" % (st, 3 if sel else 8), dict(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_STAGGER=st, ATTN_PP_STAGGER_SEL=sel)))
-    variants += [("pipe", dict(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_PIPE=1)),
-                 ("pipe+stag12/b8", dict(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_PIPE=1, ATTN_PP_STAGGER=12)),
-                 ("pipe+prio1", dict(ATTN_PP=1, ATTN_PP_WAVES=4, ATTN_PP_PIPE=1, ATTN_PP_PRIO=1))]
+            variants.append(("stag%d/b%d" % (st, 3 if sel else 8), dict(ATTN_PP=1, ATTN_PP_STAGGER=st, ATTN_PP_STAGGER_SEL=sel)))
+    variants += [("default", dict(ATTN_PP=1)), ("default prio1", dict(ATTN_PP=1, ATTN_PP_PRIO=1))]
     print("== forward time (us) and % of the 2.5 PF dense bf16 peak")
     for B, H, Tq, Tk, p in [(32, 8, 800, 800, 0.0), (32, 8, 800, 800, 0.1), (16, 8, 795, 795, 0.1), (8, 8, 2048, 2048, 0.0)]:
         q = torch.randn(B, Tq, H * 64, device=D).bfloat16()
