@@ -229,8 +229,8 @@ def respawn(a):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 16 for --workload librispeech)")
     ap.add_argument("--workload", default="headline", choices=["headline", "librispeech", "lowrank"],
                     help="headline = BASELINE configs[1] (the judged metric); librispeech = configs[3] (12/6 layers, emb_cnn); "

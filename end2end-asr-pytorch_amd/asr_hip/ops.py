@@ -119,7 +119,8 @@ def join_if_pending_reads(t):
 # transformer's backward (asr_gemm_tn_grouped).  ASR_DEFER_WGRAD=0 restores the per-layer launches.
 _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
-WGRAD_GROUP = 16
+WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "16"))
+_wgrad_side = os.environ.get("ASR_WGRAD_SIDE", "0") == "1"
 
 
 def defer_wgrad_now(dtype=None):
@@ -140,10 +141,19 @@ def queue_wgrad(dy, x, dw, db, N, K):
 
 
 def flush_wgrads():
+    """Contract everything queued.  ASR_WGRAD_SIDE=1: on the second stream (a branch of the captured graph), so that the grouped
+    launch shares the chip with the data-gradient chain that follows it on the main stream -- the decoder's kernels there are
+    12 - 200 blocks each; the operands stay referenced until join_deferred()."""
     while _wgrad_q:
         grp = _wgrad_q[:WGRAD_GROUP]
         del _wgrad_q[:WGRAD_GROUP]
-        gemm_tn_grouped(grp)
+        if _wgrad_side and torch.cuda.is_current_stream_capturing():
+            f = fork()
+            with f:
+                gemm_tn_grouped(grp)
+            f.defer(*[t for e in grp for t in e[:2]])
+        else:
+            gemm_tn_grouped(grp)
 
 
 def gemm_tn_grouped(grp):

@@ -1809,8 +1809,9 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
   int order[TN_GROUP_MAX];
   int cnt = 0;
   for (int i = 0; i < n; ++i) {
-    ASR_CHECK_ARG(dy[i] && x[i] && dw[i] && M[i] >= 0 && N[i] >= 0 && K[i] >= 0);
-    if (M[i] == 0 || N[i] == 0 || K[i] == 0) continue;
+    ASR_CHECK_ARG(M[i] >= 0 && N[i] >= 0 && K[i] >= 0);
+    if (M[i] == 0 || N[i] == 0 || K[i] == 0) continue;   // an empty problem adds nothing (its pointers may be null)
+    ASR_CHECK_ARG(dy[i] && x[i] && dw[i]);
     if (ld_dy[i] % 8 != 0 || ld_x[i] % 8 != 0 || !aligned16(dy[i]) || !aligned16(x[i]) || ld_dy[i] < N[i] ||
         ld_dy[i] >= ((int64_t)1 << 22) || ld_x[i] >= ((int64_t)1 << 22))
       return ASR_EUNSUPPORTED;
@@ -1822,11 +1823,11 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     for (int b = a; b > 0 && M[order[b]] > M[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   TnGroupArgs ga{};
   int total = 0;
-  // 256 x 256 blocks (eight waves) with the rows of m cut into slices of <= TN_GROUP_MROWS so that the ~500 blocks of a step balance
+  // 256 x 256 blocks (eight waves) with the rows of m cut into slices of <= TN_GROUP_MROWS (3200: A/B in profiles/r03_grouped_wgrad_ab.txt) so that the ~500 blocks of a step balance
   // over the 256 CUs (fp32 atomics where a block of dW has more than one slice: 2 - 4 adds per element); TN_GROUP_TILE=128 keeps the
   // 128 x 128 / four-wave form with one block per whole contraction
   const bool big = asr_tuning("TN_GROUP_TILE", 256) == 256;
-  const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 1600);
+  const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 3200);
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];
     Tn128Args& q = ga.p[j];

@@ -368,12 +368,22 @@ def reference_eval_cer(constant, strs_hyps, strs_gold):
     return total_cer, total_char, total_wer, total_word
 
 
+# The same at a shape the SHIPPED bf16 decode path accepts (asr_hip/decode.py:fused_decode_supported: dk = dv = 64, d_model and the
+# inner dimension multiples of 64): dec_tiny's dk = 16 only ever reaches the kernel-per-op step.  d_model 128 keeps the fixture
+# (all reference-trained weights) at a few MB; the kernels are the ones a d512 model runs.  Also stored: the reference's logits at
+# every greedy step, so that a test can tell a genuine near-tie from an error.
+DEC64 = dict(flags=["--num-layers", "2", "--num-heads", "2", "--dim-model", "128", "--dim-key", "64", "--dim-value", "64",
+                    "--dim-inner", "256", "--dim-emb", "128", "--feat_extractor", "vgg_cnn", "--tgt-max-len", "301",
+                    "--src-max-len", "64", "--label-smoothing", "0.1", "--dropout", "0.0", "--warmup", "40", "--k-lr", "3"],
+             B=4, T=64, src_len=[64, 52, 40, 33], tgt_len=[14, 10, 7, 3], smoothing=0.1, train_steps=120, beam_width=4)
+
+
 def run_dec(name="dec_tiny"):
     """Train the tiny vgg model for a few Noam/Adam steps on one batch WITH THE REFERENCE (so that it emits EOS and the
     strings mean something), then run the reference's own Transformer.evaluate(): greedy and beam search."""
     import json
     import numpy as np
-    cfg = DEC
+    cfg = DEC if name == "dec_tiny" else DEC64
     constant = _boot(cfg["flags"])
     import torch
     import models.asr.transformer as T
@@ -415,7 +425,18 @@ def run_dec(name="dec_tiny"):
     for k, v in model.state_dict().items():
         out["w/" + k] = v.detach().numpy().copy()
     with torch.no_grad():
+        rec = []
+        hook = model.decoder.output_linear.register_forward_hook(lambda m, i, o: rec.append(o.detach()))
         _, g_hyps, g_gold = model.evaluate(src, src_len, tgt, beam_search=False)
+        hook.remove()
+        if name != "dec_tiny":
+            # the last call of the greedy loop saw the whole 300-token prefix; the decoder is causal, so row t of it IS step t's logits
+            logits = rec[-1]
+            assert logits.shape[1] == 300
+            out["greedy_logits"] = logits.numpy().astype(np.float32)
+            out["greedy_ids"] = logits.argmax(2).numpy().astype(np.int16)
+            top2 = logits.topk(2, dim=2).values
+            out["greedy_margin"] = (top2[..., 0] - top2[..., 1]).numpy().astype(np.float32)
         _, b_hyps, b_gold = model.evaluate(src, src_len, tgt, beam_search=True, beam_width=cfg["beam_width"], beam_nbest=1,
                                            c_weight=constant.args.c_weight)
         # per-step margins of the greedy path (teacher-forced on the greedy output): how decisive each argmax was
@@ -506,8 +527,8 @@ if __name__ == "__main__":
                                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     elif which in BIG:
         run_big(which)
-    elif which == "dec_tiny":
-        run_dec()
+    elif which in ("dec_tiny", "dec_d128"):
+        run_dec(which)
     elif which in ("ref_ckpt_plain", "ref_ckpt_parallel"):
         run_ckpt(which.endswith("parallel"))
     else:
