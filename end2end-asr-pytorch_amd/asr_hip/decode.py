@@ -238,8 +238,10 @@ def _dec_pack(decoder):
 
 
 def fused_decode_supported(decoder, encoder_padded_outputs, max_len):
-    """The 34-launch step (csrc/decode.hip): bf16, <= 32 sequences, d_model <= 512 and a multiple of 64, dk = dv = 64,
-    inner dimension a multiple of 64, at most 512 cached positions / encoder frames, plain (full-rank) projections."""
+    """The 34-launch step (csrc/decode.hip): bf16, d_model <= 512 and a multiple of 64, dk = dv = 64, inner dimension a multiple
+    of 64, plain (full-rank) projections.  Any number of sequences (greedy_search_graphed decodes them 32 at a time: the step's GEMMs
+    are one 32-row MFMA tile) and of encoder frames / positions (asr_dec_attn walks the keys in passes of 512; the one-launch
+    projection + attention form, asr_dec_attn_fused, is used up to 512 keys)."""
     if ops.compute_dtype() != torch.bfloat16 or not hasattr(decoder.layers[0].self_attn, "query_linear"):
         return False
     sa = decoder.layers[0].self_attn
@@ -249,8 +251,8 @@ def fused_decode_supported(decoder, encoder_padded_outputs, max_len):
     B, Te, _ = encoder_padded_outputs.shape
     ff = decoder.layers[0].pos_ffn
     w1 = ff.conv_1 if hasattr(ff, "conv_1") else ff.linear_1
-    return (B <= 32 and D % 64 == 0 and D <= 512 and decoder.dim_key == 64 and getattr(decoder, "dim_value", 64) == 64 and
-            w1.weight.shape[0] % 64 == 0 and max_len <= 512 and Te <= 512 and (decoder.num_heads * decoder.dim_key) % 64 == 0)
+    return (B >= 1 and D % 64 == 0 and D <= 512 and decoder.dim_key == 64 and getattr(decoder, "dim_value", 64) == 64 and
+            w1.weight.shape[0] % 64 == 0 and (decoder.num_heads * decoder.dim_key) % 64 == 0)
 
 
 class FusedGreedyDecoder:
@@ -278,6 +280,11 @@ class FusedGreedyDecoder:
         bf = torch.bfloat16
         self.B, self.max_len = c.B, max_len
         B, D, HD = c.B, decoder.dim_model, c.H * c.dk
+        if B > 32:
+            raise ValueError("the fused step holds at most 32 sequences (greedy_search_graphed splits larger batches)")
+        # the one-launch projection + attention kernels keep every key of a (sequence, head) in registers: up to 512 of them
+        self.fuse_cross = self.FUSE_CROSS and encoder_padded_outputs.shape[1] <= 512
+        self.fuse_self = self.FUSE_SELF and max_len <= 512
         self.pack = _dec_pack(decoder)
         self.state = torch.zeros(2, dtype=torch.int64, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -307,7 +314,7 @@ class FusedGreedyDecoder:
             return ops.dec_gemm(w[0], bias, out, w_frag=w[1], **kw)
 
         for i, Lw in enumerate(P_["layers"]):
-            if self.FUSE_SELF:
+            if self.fuse_self:
                 src = dict(embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale)) if prev is None else dict(ln=prev)
                 ops.dec_attn_fused(Lw["wqkv_rm"], Lw["bqkv"], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale, x_out=x0,
                                    state=self.state, self_attention=True, out_frag=True, **src)
@@ -319,7 +326,7 @@ class FusedGreedyDecoder:
                 ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
                              k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state, out_frag=True)
             gemm(Lw["wo_s"], Lw["bo_s"], self.y, x=self.o, x_frag=True)
-            if self.FUSE_CROSS:
+            if self.fuse_cross:
                 ops.dec_attn_fused(Lw["wq_c_rm"], Lw["bq_c"], c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale,
                                    ln=(self.y, x0) + Lw["ln_s"], x_out=x1, out_frag=True)
             else:
@@ -399,6 +406,10 @@ def greedy_search_graphed(decoder, encoder_padded_outputs, steps=300, fused=None
         fused = fused_decode_supported(decoder, encoder_padded_outputs, steps)
     if fused:
         B, Te, _ = encoder_padded_outputs.shape
+        if B > 32:                                            # 32 sequences per pass of the fused step; rows are independent
+            parts = [greedy_search_graphed(decoder, encoder_padded_outputs[i:i + 32], steps=steps, fused=True) for i in range(0, B, 32)]
+            n = max(t.shape[1] for t in parts)
+            return torch.cat([torch.nn.functional.pad(t, (0, n - t.shape[1]), value=constant.EOS_TOKEN) for t in parts], dim=0)
         slot = (B, Te, steps, str(encoder_padded_outputs.device))
         held = getattr(decoder, "_asr_fused_decoders", None)
         if held is None:
@@ -407,7 +418,8 @@ def greedy_search_graphed(decoder, encoder_padded_outputs, steps=300, fused=None
         if obj is not None and obj.key == _weights_key(decoder):
             obj.reset(encoder_padded_outputs)
         else:
-            held.clear()                                      # one shape at a time: the buffers of a 32 x 300 decode are ~80 MB
+            if len(held) >= 2:                                # a full 32-row shape and a remainder shape: the buffers of a 32 x 300 decode are ~80 MB
+                held.clear()
             obj = held[slot] = FusedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps)
         return obj.run(steps)
     return GraphedGreedyDecoder(decoder, encoder_padded_outputs, max_len=steps).run(steps)

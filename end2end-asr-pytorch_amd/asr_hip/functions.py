@@ -262,8 +262,8 @@ def cross_kv_fused(layers):
     ws, bs = [], []
     for layer in layers:
         att = getattr(layer, "encoder_attn", None)
-        if att is None or not hasattr(att, "key_linear") or not hasattr(att, "value_linear"):
-            return None
+        if att is None or not all(isinstance(getattr(getattr(att, n, None), "weight", None), torch.Tensor) for n in ("key_linear", "value_linear")):
+            return None                                   # (the Low-Rank Transformer's projections hold .u / .v, no .weight)
         ws += [att.key_linear.weight, att.value_linear.weight]
         bs += [att.key_linear.bias, att.value_linear.bias]
     if any(b is None for b in bs):

@@ -221,15 +221,17 @@ struct DecAttnArgs {
   const int64_t* state;                                  // self attention: state[0] = position t (keys 0..t); null: all `rows` keys
 };
 
-constexpr int DEC_MAX_KEYS = 512;
+constexpr int DEC_MAX_KEYS = 512;                        // keys per pass of dec_attn_kernel; the fused kernel's limit
 
 // One workgroup per (sequence, head).  thread = (16-byte channel chunk c = tid % 8, key group jg = tid / 8): keys jg, jg + 32, ...
 // -- the 8 lanes of a key read its 128-byte row as ONE contiguous access, for the scores (partial dot products over 8 channels,
 // three xor shuffles) and for P V alike; all <= 16 + 16 loads of a thread are issued before the first use (the values do not
-// depend on the softmax), the softmax statistics go through LDS.
+// depend on the softmax), the softmax statistics go through LDS.  More than 512 keys (encoder outputs of 795 frames at the
+// Librispeech shape): passes of 512 keys with a running maximum -- sum and accumulators are rescaled when it moves.
 __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs p) {
   constexpr int NI = DEC_MAX_KEYS / 32;
-  __shared__ float wred[2][4];
+  __shared__ float wmax[2][4];
+  __shared__ float wsum[4];
   __shared__ float ored[4][8][8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
@@ -249,55 +251,68 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs p) {
     *reinterpret_cast<uint4*>((tid < 8 ? p.kc : p.vc) + b * p.cbs + (int64_t)t * p.cld + h * 64 + c) = v;
   }
   const int c = (tid & 7) * 8, jg = tid >> 3;
-  Chunk<bf16_t> kq, kk[NI], vv[NI];
+  Chunk<bf16_t> kq;
   kq.v = *reinterpret_cast<const uint4*>(p.q + (int64_t)b * p.ldq + h * 64 + c);
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-    if (i * 32 < L) {                                    // uniform
-      const int j = jg + 32 * i, jj = j < L ? j : L - 1;
-      kk[i].v = *reinterpret_cast<const uint4*>((jj == tsel ? kn : kc + (int64_t)jj * p.cld) + c);
-    }
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-    if (i * 32 < L) {
-      const int j = jg + 32 * i, jj = j < L ? j : L - 1;
-      vv[i].v = *reinterpret_cast<const uint4*>((jj == tsel ? vn : vc + (int64_t)jj * p.cld) + c);
-    }
-  // ---- scores
   float qf[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) qf[e] = bf16_to_f32(kq.e[e]);
-  float sc[NI];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    sc[i] = -INFINITY;
-    if (i * 32 < L) {
-      float d = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) d += qf[e] * bf16_to_f32(kk[i].e[e]);
-      d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
-      if (jg + 32 * i < L) sc[i] = d * p.scale;
-      mx = fmaxf(mx, sc[i]);
-    }
-  }
-  mx = wave_max(mx);
-  if (lane == 0) wred[0][wave] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(wred[0][0], wred[0][1]), fmaxf(wred[0][2], wred[0][3]));
-  // ---- probabilities (every lane of a key group holds the same value) and P V
-  float l = 0.f, acc[8];
+  float run = -INFINITY, l = 0.f, acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  int par = 0;
+#pragma unroll 1
+  for (int j0 = 0; j0 < L; j0 += DEC_MAX_KEYS, par ^= 1) {
+    const int n = L - j0;                                // keys of this pass (uniform), >= 1
+    Chunk<bf16_t> kk[NI], vv[NI];
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
-    if (i * 32 < L) {
-      const float pr = sc[i] == -INFINITY ? 0.f : __expf(sc[i] - mx);
-      l += pr;
-      const float pj = bf16_to_f32(f32_to_bf16(pr));     // the probabilities enter P V in the storage type
+    for (int i = 0; i < NI; ++i)
+      if (i * 32 < n) {                                  // uniform
+        const int j = j0 + jg + 32 * i, jj = j < L ? j : L - 1;
+        kk[i].v = *reinterpret_cast<const uint4*>((jj == tsel ? kn : kc + (int64_t)jj * p.cld) + c);
+      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += pj * bf16_to_f32(vv[i].e[e]);
+    for (int i = 0; i < NI; ++i)
+      if (i * 32 < n) {
+        const int j = j0 + jg + 32 * i, jj = j < L ? j : L - 1;
+        vv[i].v = *reinterpret_cast<const uint4*>((jj == tsel ? vn : vc + (int64_t)jj * p.cld) + c);
+      }
+    // ---- scores
+    float sc[NI];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      sc[i] = -INFINITY;
+      if (i * 32 < n) {
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qf[e] * bf16_to_f32(kk[i].e[e]);
+        d += __shfl_xor(d, 1, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 4, 64);
+        if (j0 + jg + 32 * i < L) sc[i] = d * p.scale;
+        mx = fmaxf(mx, sc[i]);
+      }
     }
+    mx = wave_max(mx);
+    if (lane == 0) wmax[par][wave] = mx;
+    __syncthreads();                                     // (the other parity is written next pass: no second barrier needed)
+    mx = fmaxf(fmaxf(fmaxf(wmax[par][0], wmax[par][1]), fmaxf(wmax[par][2], wmax[par][3])), run);
+    if (run != -INFINITY && mx != run) {                 // uniform: the running maximum moved
+      const float corr = __expf(run - mx);
+      l *= corr;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= corr;
+    }
+    run = mx;
+    // ---- probabilities (every lane of a key group holds the same value) and P V
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      if (i * 32 < n) {
+        const float pr = sc[i] == -INFINITY ? 0.f : __expf(sc[i] - mx);
+        l += pr;
+        const float pj = bf16_to_f32(f32_to_bf16(pr));   // the probabilities enter P V in the storage type
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += pj * bf16_to_f32(vv[i].e[e]);
+      }
+  }
   // sums over the 8 key groups of a wave (lane bits 3..5), then over the 4 waves through LDS; l is replicated 8 x per key
   l += __shfl_xor(l, 8, 64); l += __shfl_xor(l, 16, 64); l += __shfl_xor(l, 32, 64);
 #pragma unroll
@@ -307,11 +322,11 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(DecAttnArgs p) {
   if (lane < 8) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) ored[wave][lane][e] = acc[e];
-    if (lane == 0) wred[1][wave] = l;
+    if (lane == 0) wsum[wave] = l;
   }
   __syncthreads();
   if (tid < 8) {
-    const float lt = wred[1][0] + wred[1][1] + wred[1][2] + wred[1][3];
+    const float lt = wsum[0] + wsum[1] + wsum[2] + wsum[3];
     const float inv = lt > 0.f ? 1.f / lt : 0.f;
     Chunk<bf16_t> o;
 #pragma unroll
@@ -651,7 +666,7 @@ extern "C" int asr_dec_attn(const void* q, int64_t ldq, const void* k_new, const
   ASR_CHECK_ARG(q && k_cache && v_cache && out && B >= 0 && H > 0 && rows > 0);
   ASR_CHECK_ARG((k_new == nullptr) == (v_new == nullptr));
   ASR_CHECK_ARG(!k_new || state);                        // an appended row needs its position
-  if (dk != 64 || rows > DEC_MAX_KEYS) return ASR_EUNSUPPORTED;
+  if (dk != 64) return ASR_EUNSUPPORTED;
   if (ldq % 8 != 0 || ldo % 8 != 0 || cache_row_stride % 8 != 0 || cache_batch_stride % 8 != 0 || (k_new && ld_new % 8 != 0) ||
       !aligned16(q) || !aligned16(out) || !aligned16(k_cache) || !aligned16(v_cache) || (k_new && (!aligned16(k_new) || !aligned16(v_new))))
     return ASR_EUNSUPPORTED;

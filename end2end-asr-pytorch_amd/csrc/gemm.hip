@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_big.h"
 
 namespace {
 
@@ -1018,16 +1019,13 @@ __device__ __forceinline__ uint4 tn256_pack(const unsigned char* tile, int lr, i
 }
 
 template <int NST>
-__device__ __forceinline__ void tn256_body(const Tn128Args& p, unsigned char* smem, int wid) {
+__device__ __forceinline__ void tn256_body(const Tn128Args& p, unsigned char* smem, int tile, int m_beg, int m_end, bool single) {
   constexpr int RM = 32, TILEB = RM * 512, STAGEB = 2 * TILEB;       // 16 KB per operand, 32 KB per stage
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 1, wk = wave & 1;
-  const int split = wid / p.ntiles, tile = wid % p.ntiles;
   const int n0 = (tile / p.tiles_k) * 256, k0 = (tile % p.tiles_k) * 256;
-  const int m_beg = split * p.m_per_split, m_end = min(p.M, m_beg + p.m_per_split);
   const int nstage = (m_end - m_beg + RM - 1) / RM;
-  const bool single = p.m_per_split >= p.M;
   const unsigned char* A = static_cast<const unsigned char*>(p.A);
   const unsigned char* B = static_cast<const unsigned char*>(p.B);
   const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * 2 / 16);
@@ -1155,7 +1153,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
   const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
   int i = 0;
   while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
-  tn256_body<NST>(ga.p[i], smem, wid - ga.first[i]);
+  const Tn128Args& p = ga.p[i];
+  const int w = wid - ga.first[i], split = w / p.ntiles, m_beg = split * p.m_per_split;
+  tn256_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
+}
+
+// ---- the same blocks, scheduled by the host: the launch is ONE workgroup per CU and every workgroup gets the same number of 32-row
+// stages.  All (problem, block of dW, stage) triples of the launch form one line -- problems in launch order, blocks within a
+// problem, stages within a block -- which is cut into gridDim.x equal pieces; a workgroup walks its piece: the tail of one block's
+// rows, whole blocks, the head of the next (a block of dW whose rows are shared between workgroups is summed with fp32 atomics).
+// Measured before (profiles/r03_bench_timeline.txt, launch-by-launch listing): 184 / 300 / 304 equal-length blocks on 256 CUs
+// took 185 / 340 / 266 us -- the second round of 44 blocks costs as much as the first of 256.
+// first[] holds the prefix sums of STAGES per problem here; m_per_split the stages of one block of that problem.
+template <int NST>
+__global__ __launch_bounds__(512, 2) void gemm_tn256s_kernel(TnGroupArgs ga, int per_wg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  const int total = ga.first[ga.n];
+  int x = wid * per_wg;
+  const int x1 = min(total, x + per_wg);
+  int i = 0;
+  bool again = false;
+  while (x < x1) {
+    while (i + 1 < ga.n && x >= ga.first[i + 1]) ++i;
+    const Tn128Args& p = ga.p[i];
+    const int spb = p.m_per_split;                         // stages of one block of this problem
+    const int w = x - ga.first[i], tile = w / spb, st0 = w % spb;
+    const int st1 = min(spb, st0 + (x1 - x));
+    if (again) __syncthreads();                            // every wave is done reading the previous piece's last stages
+    tn256_body<NST>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
+    x += st1 - st0;
+    again = true;
+  }
 }
 template <int NST>
 __global__ __launch_bounds__(256, 2) void gemm_tn128g_kernel(TnGroupArgs ga) {
@@ -1634,6 +1664,14 @@ extern "C" int asr_gemm_nt(const void* A, int64_t lda, const void* B, int64_t ld
 #ifdef ASR_TUNE_ABLATE
   p.ablate = (int)asr_tuning("GEMM_ABLATE", 0);
 #endif
+  // eight-wave 256 x 256 / 128 x 128 blocks (csrc/gemm_big.hip) for the bf16 linear layers whose shape fills the chip with them
+  if (in_dtype == ASR_BF16 && splits == 1 && !relu_mask) {
+    BigGemmArgs q{};
+    q.A = A; q.B = B; q.C = C; q.bias = bias; q.mask = nullptr;
+    q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.M = M; q.N = N; q.K = K; q.alpha = alpha;
+    q.relu = p.relu; q.accumulate = p.accumulate; q.out_f32 = out_dtype == ASR_F32;
+    if (asr_gemm_big_nt(q, stream)) return ASR_OK;
+  }
   // fast path: LDS-DMA staging needs whole 16-B chunks everywhere and whole 128-byte K steps
   const bool fast = p.vecA && p.vecB && K > 0 && (K % bk == 0) && (kps % bk == 0) &&
                     asr_tuning("GEMM_GENERIC", 0) == 0;
@@ -1823,10 +1861,12 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     for (int b = a; b > 0 && M[order[b]] > M[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   TnGroupArgs ga{};
   int total = 0;
-  // 256 x 256 blocks (eight waves) with the rows of m cut into slices of <= TN_GROUP_MROWS (3200: A/B in profiles/r03_grouped_wgrad_ab.txt) so that the ~500 blocks of a step balance
-  // over the 256 CUs (fp32 atomics where a block of dW has more than one slice: 2 - 4 adds per element); TN_GROUP_TILE=128 keeps the
-  // 128 x 128 / four-wave form with one block per whole contraction
-  const bool big = asr_tuning("TN_GROUP_TILE", 256) == 256;
+  // TN_GROUP_TILE 0 (default): 256 x 256 blocks (eight waves), one workgroup per CU, the launch's stages dealt out in equal pieces
+  // (gemm_tn256s_kernel); 256: one workgroup per (block of dW, slice of <= TN_GROUP_MROWS rows), fp32 atomics where a block has more
+  // than one slice (A/B of the slice length: profiles/r03_grouped_wgrad_ab.txt); 128: the 128 x 128 / four-wave form, one workgroup
+  // per whole contraction
+  const int tmode = (int)asr_tuning("TN_GROUP_TILE", 0);     // 0: host-scheduled 256 x 256 blocks; 256: one block per (block of dW, row slice); 128
+  const bool big = tmode != 128, sched = tmode == 0;
   const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 3200);
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];
@@ -1836,12 +1876,17 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     const int T = big ? 256 : 128;
     q.tiles_k = (K[i] + T - 1) / T;
     q.ntiles = ((N[i] + T - 1) / T) * q.tiles_k;
+    ga.first[j] = total;
+    if (sched) {
+      q.m_per_split = (M[i] + 31) / 32;                      // stages per block
+      total += q.ntiles * q.m_per_split;
+      continue;
+    }
     int splits = 1;
     if (big && mrows > 0) splits = (M[i] + mrows - 1) / mrows;
     if (splits < 1) splits = 1;
     q.m_per_split = ((M[i] + splits - 1) / splits + 31) / 32 * 32;
     splits = (M[i] + q.m_per_split - 1) / q.m_per_split;
-    ga.first[j] = total;
     total += q.ntiles * splits;
   }
   ga.first[cnt] = total;
@@ -1852,11 +1897,22 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     granted = true;
   }
   AsrProfScope prof(ASR_OP_GEMM, stream);
   const bool nst4 = asr_tuning("TN_GROUP_STAGES", 3) == 4;
-  if (big) {
+  if (sched) {
+    // one workgroup per CU (TN_GROUP_WGS), at least 16 stages each; pieces of equal length
+    int nwg = (int)asr_tuning("TN_GROUP_WGS", 256);
+    if (nwg > total / 16) nwg = total / 16;
+    if (nwg < 1) nwg = 1;
+    const int per_wg = (total + nwg - 1) / nwg;
+    nwg = (total + per_wg - 1) / per_wg;
+    if (nst4) hipLaunchKernelGGL(gemm_tn256s_kernel<4>, dim3((unsigned)nwg), dim3(512), 4 * 32768, stream, ga, per_wg);
+    else hipLaunchKernelGGL(gemm_tn256s_kernel<3>, dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
+  } else if (big) {
     if (nst4) hipLaunchKernelGGL(gemm_tn256g_kernel<4>, dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
     else hipLaunchKernelGGL(gemm_tn256g_kernel<3>, dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
   } else if (nst4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);

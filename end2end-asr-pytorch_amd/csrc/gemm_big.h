@@ -1,0 +1,18 @@
+// Eight-wave linear-layer GEMMs (csrc/gemm_big.hip): one workgroup of 512 threads per 256 x 256 or 128 x 128 output block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct BigGemmArgs {
+  const void* A; const void* B; void* C;        // A (M, K) bf16 row-major; B: NT (N, K) bf16 row-major, NN (K, N) bf16 row-major
+  const float* bias;                            // (N) fp32 or null
+  const void* mask;                             // NN only: (M, N) bf16 laid out like C; C = 0 where mask <= 0 (ReLU backward)
+  int64_t lda, ldb, ldc;                        // elements
+  int M, N, K;
+  float alpha;
+  int relu, accumulate, out_f32;
+};
+
+// -> true when the shape / layout is taken (launched on `stream`), false when the caller should use the four-wave kernels.
+bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream);
+bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream);

@@ -1,0 +1,224 @@
+// Eight-wave GEMMs for the linear layers of the Transformer (reference: models/common_layers.py:136-142,181-198 nn.Linear /
+// Conv1d(k=1) through autograd): C = act(alpha A B^T + bias) ("NT", forward) and C (+)= (A B) [masked] ("NN", data gradient).
+//
+// Why a second family next to csrc/gemm.hip's four-wave kernels.  The model's contractions are SHORT (K = 512: 8 steps of 64) over
+// 3200 - 6400 rows: a 64 x 64 or 128 x 64 block issues 64 - 128 MFMAs per wave in its whole life, so every launch is mostly
+// fill / drain (measured in the replayed step: 6400 x 2048 x 512 in 25 us = 530 TF/s, 3200 x 512 x 2048 in 31 us = 216 TF/s).
+// Here one 512-thread workgroup owns a 256 x 256 (or 128 x 128) block of C:
+//   * 8 waves as 2 (m) x 4 (n): a wave's quadrant is 128 x 64 (64 x 32), i.e. 64 (16) MFMAs per 64-deep step against 24 (12)
+//     16-byte operand reads -- two waves per SIMD, one reading while the other multiplies;
+//   * both operands come in by LDS-DMA (global_load_lds_dwordx4, hand-issued: csrc/gemm.hip tn_dma) in 128-byte rows, the
+//     16-byte slot XOR-ed with (row & 7) on the SOURCE side and again on the fragment read -- conflict-free ds_read_b128;
+//     NS stages in a ring with counted vmcnt, ONE s_barrier per step (the barrier that publishes step t also frees the
+//     buffer step t + NS - 1 is loaded into);
+//   * the epilogue stages the block in the OUTPUT type through the same LDS and stores 16-byte row pieces.
+// The NN form reads its B operand (the weight, (K, N) row-major = contraction index along rows) with ds_read_b64_tr_b16.
+#include "common.h"
+#include "gemm_big.h"
+
+namespace {
+
+__device__ __forceinline__ void big_dma(unsigned lds_wave_base, const unsigned char* src) {
+  unsigned keep;      // M0 saved and restored: neutral for whatever the compiler keeps there
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
+}
+template <int N> __device__ __forceinline__ void big_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// One operand tile of R rows x 128 bytes: piece i of a thread = chunk c = i * 512 + tid -> (row c >> 3, slot c & 7); the source is
+// chunk slot ^ (row & 7) of global row (row0 + row), clamped to the last valid row (rows past the edge are never stored).
+template <int R>
+__device__ __forceinline__ void big_src(const unsigned char* base, int64_t ld_bytes, int row0, int row_limit, int tid,
+                                        const unsigned char* (&src)[R / 64]) {
+#pragma unroll
+  for (int i = 0; i < R / 64; ++i) {
+    const int c = i * 512 + tid, row = c >> 3, slot = (c & 7) ^ (row & 7);
+    int gr = row0 + row;
+    gr = gr < row_limit ? gr : row_limit - 1;
+    src[i] = base + (int64_t)gr * ld_bytes + slot * 16;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ NT
+// TO: bf16_t or float.  Requirements (checked by the launcher): K % 64 == 0, 16-byte aligned A / B rows, C rows in whole 16-byte pieces.
+template <int BM, int BN, int NS, typename TO>
+__global__ __launch_bounds__(512, 2) void gemm_big_nt_kernel(BigGemmArgs p, int tiles_n, int ntiles) {
+  constexpr int WM = BM / 2, WN = BN / 4, FM = WM / 16, FN = WN / 16;
+  constexpr int TA = BM * 128, TB = BN * 128, STAGE = TA + TB;
+  constexpr int LA = BM / 64, LB = BN / 64, LPS = LA + LB;          // LDS-DMA pieces per thread and stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // XCD-aware order: blocks b, b + 8, ... share an XCD (private L2) -> consecutive tiles (n fastest: they share their A rows)
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  if (tile >= ntiles) return;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = p.K / 64;
+
+  const unsigned char* srcA[LA];
+  const unsigned char* srcB[LB];
+  big_src<BM>(static_cast<const unsigned char*>(p.A), p.lda * 2, m0, p.M, tid, srcA);
+  big_src<BN>(static_cast<const unsigned char*>(p.B), p.ldb * 2, n0, p.N, tid, srcB);
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    const unsigned sl = wave_lds + (unsigned)((kt % NS) * STAGE);
+    const int64_t kb = (int64_t)kt * 128;
+#pragma unroll
+    for (int i = 0; i < LA; ++i) big_dma(sl + i * 8192, srcA[i] + kb);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) big_dma(sl + TA + i * 8192, srcB[i] + kb);
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  // fragment read offsets: row (w * W + f * 16 + lr), 16-byte slot (ms * 4 + g) ^ (lr & 7): two per lane, the rest immediates
+  const int offA = (wm * WM + lr) * 128, offB = TA + (wn * WN + lr) * 128;
+  const int sw0 = ((g) ^ (lr & 7)) << 4, sw1 = ((4 + g) ^ (lr & 7)) << 4;
+
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nk) stage(st);
+  for (int kt = 0; kt < nk; ++kt) {
+    // step kt has landed once at most the pieces of the later steps are outstanding (LPS per step and thread, retired in order)
+    const int ahead = min(NS - 2, nk - 1 - kt);
+    if (NS >= 4 && ahead >= 2) big_wait_vmcnt<2 * LPS>();
+    else if (NS >= 3 && ahead >= 1) big_wait_vmcnt<LPS>();
+    else big_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();              // step kt visible to every wave; every wave is done reading step kt - 1
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) stage(kt + NS - 1);   // into the buffer step kt - 1 used
+    const unsigned char* s = smem + (kt % NS) * STAGE;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int sw = ms ? sw1 : sw0;
+      uint4 a[FM], b[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const uint4*>(s + offB + j * 2048 + sw);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const uint4*>(s + offA + i * 2048 + sw);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mma16<bf16_t>(acc[i][j], b[j], a[i]);     // operands swapped: the fragment is C^T, see the epilogue
+    }
+  }
+  __syncthreads();                               // every wave is done with the operand stages: the epilogue reuses them
+
+  // ---- epilogue: alpha / bias / ReLU on the accumulators, the block staged in the output type, 16-byte row pieces out.
+  // fp32 output of a 256-row block: two passes of 128 rows (the block does not fit the LDS in fp32).
+  constexpr int OESZ = (int)sizeof(TO), EPC = 16 / OESZ;
+  constexpr int OP = BN * OESZ + 16;             // row pitch: + 16 bytes keeps 16-byte alignment and staggers the banks
+  constexpr int PASSES = (BM * OP > 140 * 1024) ? 2 : 1;
+  constexpr int PR = BM / PASSES;                // rows per pass
+  // The MFMAs ran with the operands swapped (first = B rows, second = A rows), so lane (lr, g) holds C[m = lr][n = 4 g + r]: four
+  // CONSECUTIVE columns of one row -- one 8-byte (bf16) or 16-byte (fp32) LDS write per fragment instead of four 2-byte ones.
+  TO* C = static_cast<TO*>(p.C);
+  float bv[FN][4];
+#pragma unroll
+  for (int j = 0; j < FN; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int col = n0 + wn * WN + j * 16 + g * 4 + r;
+      bv[j][r] = (p.bias != nullptr && col < p.N) ? p.bias[col] : 0.f;
+    }
+#pragma unroll
+  for (int pass = 0; pass < PASSES; ++pass) {
+    if (PASSES == 1 || wm == pass) {
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[i][j][r] * p.alpha + bv[j][r];
+            if (p.relu) v[r] = fmaxf(v[r], 0.f);
+          }
+          const int row = (PASSES == 1 ? wm * WM : 0) + i * 16 + lr;
+          unsigned char* dst = smem + row * OP + (wn * WN + j * 16 + g * 4) * OESZ;
+          if constexpr (OESZ == 2) {
+            uint2 w;
+            w.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            w.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(dst) = w;
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / EPC;                // 16-byte pieces per row
+    for (int c = tid; c < PR * CPR; c += 512) {
+      const int row = c / CPR, pc = c % CPR;
+      const int grow = m0 + pass * PR + row, gcol = n0 + pc * EPC;
+      if (grow < p.M && gcol < p.N) {            // N is a whole number of pieces (launcher)
+        uint4 v = *reinterpret_cast<const uint4*>(smem + row * OP + pc * 16);
+        TO* dst = C + (int64_t)grow * p.ldc + gcol;
+        if (p.accumulate) {
+          Chunk<TO> o, n;
+          o.v = *reinterpret_cast<const uint4*>(dst);
+          n.v = v;
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) n.e[e] = DT<TO>::to(DT<TO>::from(o.e[e]) + DT<TO>::from(n.e[e]));
+          v = n.v;
+        }
+        *reinterpret_cast<uint4*>(dst) = v;
+      }
+    }
+    if (PASSES > 1) __syncthreads();
+  }
+}
+
+template <int BM, int BN, int NS, typename TO>
+void launch_nt(const BigGemmArgs& p, hipStream_t s) {
+  constexpr int OP = BN * (int)sizeof(TO) + 16;
+  constexpr int PASSES = (BM * OP > 140 * 1024) ? 2 : 1;
+  constexpr size_t lds_stage = (size_t)NS * (BM + BN) * 128, lds_out = (size_t)(BM / PASSES) * OP;
+  constexpr size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
+  static bool granted = false;
+  if (!granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_nt_kernel<BM, BN, NS, TO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = true;
+  }
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm_big_nt_kernel<BM, BN, NS, TO>), dim3((unsigned)ntiles), dim3(512), lds, s, p, tiles_n, ntiles);
+}
+
+}  // namespace
+
+bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
+  const int mode = (int)asr_tuning("GEMM_BIG", 1);            // 0: off; 1: automatic; 256 / 128: force the block size
+  if (mode == 0 || p.mask != nullptr || (p.accumulate && !p.out_f32)) return false;   // (+= in bf16 keeps the four-wave kernel's single rounding)
+  const int oesz = p.out_f32 ? 4 : 2, epc = 16 / oesz;
+  if (p.K <= 0 || p.K % 64 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || !aligned16(p.A) || !aligned16(p.B) || !aligned16(p.C) ||
+      p.ldc % epc != 0 || p.N % epc != 0 || p.lda < p.K || p.ldb < p.K)
+    return false;
+  // block size (profiles/r03_gemm_big_ab.txt): the 128 x 128 form wins wherever the four-wave kernels were latency-bound -- long
+  // contractions (K >= 2048: 4 stages) and tall operands; 256 x 256 pays for fp32 output (the vocabulary projection) only
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  int tile = mode == 256 || mode == 128 ? mode : (p.out_f32 && p.N >= 2048 ? 256 : 128);
+  if (tile == 128 && mode == 1 && t128 < (p.K >= 2048 ? 150 : 48)) return false;      // too few blocks: 64 x 64 four-wave blocks fill the chip better
+  if (tile == 256) {
+    if (p.out_f32) launch_nt<256, 256, 2, float>(p, stream); else launch_nt<256, 256, 2, bf16_t>(p, stream);
+  } else {
+    // stages of the 128 x 128 form: 2 (64 KB: two workgroups per CU), 3 (default) or 4 (one workgroup per CU, deeper prefetch)
+    // two stages = 64 KB = two workgroups per CU: best whenever there are more blocks than CUs; else deeper prefetch for long K
+    const int ns = (int)asr_tuning("GEMM_BIG_NS", (t128 > 256 || p.K < 2048) ? 2 : 4);
+    if (p.out_f32) launch_nt<128, 128, 3, float>(p, stream);
+    else if (ns == 2) launch_nt<128, 128, 2, bf16_t>(p, stream);
+    else if (ns == 4) launch_nt<128, 128, 4, bf16_t>(p, stream);
+    else launch_nt<128, 128, 3, bf16_t>(p, stream);
+  }
+  return hipGetLastError() == hipSuccess;
+}
+
+bool asr_gemm_big_nn(const BigGemmArgs&, hipStream_t) { return false; }

@@ -152,7 +152,7 @@ class Decoder(nn.Module):
     """Decoder(id2label, num_src_vocab, num_trg_vocab, num_layers, num_heads, dim_emb, dim_model, dim_inner, dim_key,
     dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False)   (reference: transformer.py:206-305)"""
 
-    group_cross_kv = os.environ.get("ASR_GROUP_CROSS_KV", "1") != "0"       # A/B switch: 0 = one K|V projection launch per layer
+    group_cross_kv = os.environ.get("ASR_GROUP_CROSS_KV", "0") == "1"       # off by default: measured 6.52 / 6.56 ms per step grouped, 6.50 / 6.51 per layer (profiles/r03_step_ab_scheduled_dw_big_nt.txt)
 
     def __init__(self, id2label, num_src_vocab, num_trg_vocab, num_layers, num_heads, dim_emb, dim_model, dim_inner, dim_key,
                  dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False, rank=0):

@@ -114,11 +114,12 @@ def _attn_ref(q, K, V, H, scale):
     return (p @ Vh).reshape(B, HD)
 
 
-@pytest.mark.parametrize("t", [0, 17, 63, 64, 299])
+@pytest.mark.parametrize("t", [0, 17, 63, 64, 299, 511, 512, 700, 1100])
 def test_dec_attn_self_appends_and_attends(t):
+    """positions >= 512: the kernel walks the cache in passes of 512 keys with a running maximum"""
     from asr_hip import ops
     g = torch.Generator().manual_seed(t)
-    B, H, d, max_len = 5, 8, 64, 300
+    B, H, d, max_len = 5, 8, 64, (300 if t < 300 else 1200)
     HD = H * d
     kc = torch.randn(B, max_len, HD, generator=g).to(bf).cuda()
     vc = torch.randn(B, max_len, HD, generator=g).to(bf).cuda()
@@ -135,7 +136,7 @@ def test_dec_attn_self_appends_and_attends(t):
     assert (out.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("rows,shared", [(200, False), (37, True), (512, False)])
+@pytest.mark.parametrize("rows,shared", [(200, False), (37, True), (512, False), (513, False), (795, False), (1300, True)])
 def test_dec_attn_cross(rows, shared):
     from asr_hip import ops
     g = torch.Generator().manual_seed(rows)
@@ -313,3 +314,33 @@ def test_fused_greedy_graph_replay_equals_eager_and_follows_the_per_op_argmax():
     assert torch.equal(a2, fresh.out.t()[:, :a2.shape[1]]) and not torch.equal(a2[:, :8], a1[:, :8])
     strs = dec.greedy_search(enc[:2], use_cache=True)
     assert len(strs) == 2
+
+
+def test_greedy_beyond_32_sequences_and_512_encoder_frames():
+    """configs[3]'s decode shape class (795 encoder frames) and more than 32 utterances stay on the fused step: the batch is decoded
+    32 sequences at a time, cross attention walks the 600 keys in two passes.  Rows are independent, so every row equals the row of
+    a decode of its own 32-chunk, and follows the per-op step's arg max within the bf16 tolerance."""
+    from asr_hip.decode import DecoderKVCache, FusedGreedyDecoder, fused_decode_supported, greedy_search_graphed
+    model = _model(layers=2, inner=256, V=60)
+    dec = model.decoder
+    g = torch.Generator().manual_seed(9)
+    B, Te, steps = 40, 600, 24
+    enc = torch.randn(B, Te, 512, generator=g).cuda()
+    assert fused_decode_supported(dec, enc, steps)
+    toks = greedy_search_graphed(dec, enc, steps=steps)
+    assert toks.shape[0] == B
+    for lo in (0, 32):
+        part = FusedGreedyDecoder(dec, enc[lo:lo + 32], max_len=steps)
+        assert not part.fuse_cross                                   # more than 512 keys: query GEMM + multi-pass attention
+        for _ in range(steps):
+            part._step()
+        want = part.out.t()
+        n = min(toks.shape[1], steps)
+        assert torch.equal(toks[lo:lo + 32, :n], want[:, :n])
+    slow = DecoderKVCache(dec, enc, max_len=steps)
+    prev = torch.full((B,), 1, dtype=torch.int64, device="cuda")
+    for t in range(min(toks.shape[1], steps)):
+        lg = slow.step(prev).float()
+        got = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        assert ((lg.max(1).values - got) <= 3e-2 * lg.abs().max()).all(), t
+        prev = toks[:, t].contiguous()

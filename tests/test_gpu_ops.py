@@ -72,6 +72,53 @@ def test_gemm_nt_bias_relu(ops, dtype, shape):
     close("gemm+relu fp32 out", out, ref.relu(), torch.float32 if dtype == torch.float32 else dtype, scale=0.1 if dtype != torch.float32 else 1)
 
 
+@pytest.mark.parametrize("block,ns", [(256, 2), (128, 2), (128, 3), (128, 4)])
+def test_gemm_nt_eight_wave_blocks(ops, block, ns):
+    """csrc/gemm_big.hip (512-thread workgroups, 256 x 256 / 128 x 128 blocks, LDS-DMA ring) forced on shapes that exercise every
+    edge: rows not a multiple of the block (3200 = 12.5 x 256, 777), N not a multiple of it (300 -> one partial block column, 4364),
+    K = 64 (one step) .. 2048, a row stride larger than K, bias / ReLU / alpha, fp32 output, accumulate.  Reference: fp32 torch on
+    the same bf16 operands; tolerance 2 bf16 ulp of the result (fp32 accumulation, another summation order)."""
+    from asr_hip import lib as L
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(block + ns)
+    L.set_tuning("GEMM_BIG", block)
+    L.set_tuning("GEMM_BIG_NS", ns)
+    try:
+        for M, N, K, ldk, kind in [(3200, 512, 512, 512, "bias_relu"), (777, 304, 64, 64, "bias"), (1000, 1536, 2048, 2048, "plain"),
+                                   (513, 4364, 512, 576, "f32"), (640, 512, 192, 192, "alpha_acc"), (256, 256, 128, 128, "f32acc")]:
+            A = torch.randn(M, ldk, generator=g).to(dev()).to(bf)[:, :K]
+            B = (torch.randn(N, ldk, generator=g) * K ** -0.5).to(dev()).to(bf)[:, :K]
+            ref = A.float() @ B.float().t()
+            if kind == "bias_relu":
+                bias = torch.randn(N, generator=g).to(dev())
+                out = ops.gemm_nt(A, B, bias=bias, relu=True)
+                ref = (ref + bias).relu()
+            elif kind == "bias":
+                bias = torch.randn(N, generator=g).to(dev())
+                out = ops.gemm_nt(A, B, bias=bias)
+                ref = ref + bias
+            elif kind == "plain":
+                out = ops.gemm_nt(A, B)
+            elif kind == "f32":
+                out = ops.gemm_nt(A, B, out_dtype=torch.float32)
+            elif kind == "alpha_acc":
+                c0 = torch.randn(M, N, generator=g).to(dev()).to(bf)
+                out = c0.clone()
+                ops.gemm_nt(A, B, out=out, accumulate=True, alpha=0.5)
+                ref = c0.float() + 0.5 * ref
+            else:
+                c0 = torch.randn(M, N, generator=g).to(dev())
+                out = c0.clone()
+                ops.gemm_nt(A, B, out=out, accumulate=True)
+                ref = c0 + ref
+            tol = (2.0 ** -7 if out.dtype == bf else 2e-5) * ref.abs().clamp_min(0.05 if out.dtype == bf else 1.0)
+            bad = (out.float() - ref).abs() > tol
+            assert not bad.any(), (M, N, K, kind, (out.float() - ref).abs().max().item(), int(bad.sum()))
+    finally:
+        L.set_tuning("GEMM_BIG", None)
+        L.set_tuning("GEMM_BIG_NS", None)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_splitk_accumulate_and_mask(ops, dtype):
     g = torch.Generator().manual_seed(7)
@@ -286,13 +333,14 @@ def test_add_ln_dropout_consistency(ops, dtype):
     assert not torch.equal(yz2, yz)
 
 
-@pytest.mark.parametrize("tile", [128, 256])
+@pytest.mark.parametrize("tile", [0, 128, 256])
 def test_grouped_weight_gradients(ops, tile):
     """asr_gemm_tn_grouped: the weight and bias gradients of several linear layers in ONE launch (every linear layer's dW in the
     graph-replayed step, reference models/common_layers.py:136-142,181-187 via autograd) against fp32 torch.  Shapes: the model's
     (512 x 512 / 1536 x 512 / 2048 x 512 / 512 x 2048 over 400 .. 1700 rows), a vocabulary-like N = 300 with a padded leading dimension,
     K not a multiple of the block, M not a multiple of the 32-row stage, a problem without bias, an empty problem; both block
-    sizes (TN_GROUP_TILE = 128: one block per contraction; 256: eight waves, rows cut in slices that meet in fp32 atomics)."""
+    sizes (TN_GROUP_TILE = 128: one block per contraction; 256: eight waves, rows cut in slices that meet in fp32 atomics; 0, the
+    default: the same blocks dealt out to one workgroup per CU in equal pieces of 32-row stages)."""
     from asr_hip import lib as L
     g = torch.Generator().manual_seed(17)
     D = dev()
