@@ -119,6 +119,7 @@ def join_if_pending_reads(t):
 # transformer's backward (asr_gemm_tn_grouped).  ASR_DEFER_WGRAD=0 restores the per-layer launches.
 _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
+_debug_group = os.environ.get("ASR_DEBUG_GROUP") == "1"
 WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "16"))
 _wgrad_side = os.environ.get("ASR_WGRAD_SIDE", "0") == "1"
 
@@ -156,10 +157,31 @@ def flush_wgrads():
             gemm_tn_grouped(grp)
 
 
+def _tn_group_ok(e):
+    """The layout test of asr_gemm_tn_grouped (csrc/gemm.hip) for one problem."""
+    dy, x, dw, db, N, K = e
+    if dy.shape[0] == 0 or N == 0 or K == 0:
+        return True
+    return (dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and
+            dy.stride(0) >= N and dy.stride(0) < (1 << 22) and x.stride(0) < (1 << 22))
+
+
 def gemm_tn_grouped(grp):
     """grp: up to 16 tuples (dy (M,>=N) bf16, x (M,>=K) bf16, dw (N,K) fp32, db (N) fp32 or None, N, K): dw += dy[:, :N]^T x[:, :K] and
-    db += column sums of dy for all of them in one launch (asr_gemm_tn_grouped); per-layer launches when a layout does not fit."""
+    db += column sums of dy for all of them in one launch (asr_gemm_tn_grouped); problems whose layout the grouped kernel does not
+    take (a row stride that is not a whole number of 16-byte chunks) go through the per-layer kernel, the others stay grouped."""
     import ctypes
+    odd = [e for e in grp if not _tn_group_ok(e)]
+    if odd:
+        if _debug_group:
+            for dy, x, dw, db, N, K in odd:
+                print("gemm_tn_grouped: per-layer launch for dy %s stride %s, x %s stride %s, N %d K %d" %
+                      (tuple(dy.shape), dy.stride(), tuple(x.shape), x.stride(), N, K), flush=True)
+        for dy, x, dw, db, N, K in odd:
+            gemm_tn(dy, x, dw, colsum_acc=db, N=N, K=K)
+        grp = [e for e in grp if _tn_group_ok(e)]
+        if not grp:
+            return
     n = len(grp)
     P_, L_, I_ = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
     rc = L.load().asr_gemm_tn_grouped(
@@ -218,6 +240,11 @@ def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0, use_ws=True):
     N = dy.shape[1] if N is None else N
     K = x.shape[1] if K is None else K
     assert dw.dtype == torch.float32 and dw.stride(1) == 1 and dy.dtype == x.dtype
+    if _debug_group and torch.cuda.is_current_stream_capturing():
+        import traceback
+        print("gemm_tn inside a capture: dy %s stride %s x %s stride %s N %s K %s  <- %s" %
+              (tuple(dy.shape), dy.stride(), tuple(x.shape), x.stride(), N, K,
+               " < ".join("%s:%d" % (f.name, f.lineno) for f in traceback.extract_stack()[-5:-1])), flush=True)
     n_ws = L.load().asr_gemm_tn_workspace(M, N, K, int(splits), L.dt(dy)) if use_ws else 0
     ws = torch.empty(n_ws, device=dy.device, dtype=torch.float32) if n_ws else None
     L.call("asr_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(dw), dw.stride(0), L.ptr(colsum_acc), L.ptr(ws),

@@ -1937,6 +1937,13 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   p.accumulate = (flags & ASR_GEMM_ACCUMULATE) != 0;
   p.vecC = ((((uintptr_t)C) & 15) == 0) && (ldc % 4 == 0);
   AsrProfScope prof(ASR_OP_GEMM, stream);
+  if (in_dtype == ASR_BF16 && out_dtype == ASR_BF16) {    // eight-wave 128 x 128 blocks (csrc/gemm_big.hip) where the shape fills the chip with them
+    BigGemmArgs q{};
+    q.A = A; q.B = B; q.C = C; q.bias = nullptr; q.mask = relu_mask;
+    q.lda = lda; q.ldb = ldb; q.ldc = ldc; q.M = M; q.N = N; q.K = K; q.alpha = alpha;
+    q.relu = 0; q.accumulate = p.accumulate; q.out_f32 = 0;
+    if (asr_gemm_big_nn(q, stream)) return ASR_OK;
+  }
   const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
   const int64_t nn_big = asr_tuning("NN_BIG", 1700);      // 128x64 tiles from this many 64x64 tiles on
   const bool big = t64 >= nn_big && M > 64;

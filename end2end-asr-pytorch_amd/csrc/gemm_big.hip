@@ -193,6 +193,150 @@ void launch_nt(const BigGemmArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_big_nt_kernel<BM, BN, NS, TO>), dim3((unsigned)ntiles), dim3(512), lds, s, p, tiles_n, ntiles);
 }
 
+// ------------------------------------------------------------------------------------------------ NN
+// C (M, N) bf16 (+)= A (M, K) . B (K, N), optionally zeroed where mask (laid out like C) <= 0: a linear layer's data gradient
+// dX = dY . W with W in its natural (out_features, in_features) layout (reference: nn.Linear backward through autograd).
+// 128 x 128 blocks.  The A side is the NT kernel's; the B tile is 64 contraction rows x 128 columns (256-byte rows, 16-byte slot
+// XOR (row & 7)), read with ds_read_b64_tr_b16 so that a lane gets 8 consecutive contraction indices of ONE column -- the same
+// (column, k-chunk) operand layout the NT kernel reads with plain 16-byte loads.  The block is staged in fp32 for the epilogue, so
+// that `+=` into a bf16 destination and the ReLU mask act on unrounded sums (one rounding, like the four-wave kernel).
+template <int NS>
+__global__ __launch_bounds__(512, 2) void gemm_big_nn_kernel(BigGemmArgs p, int tiles_n, int ntiles) {
+  constexpr int BM = 128, BN = 128;
+  constexpr int WM = BM / 2, WN = BN / 4, FM = WM / 16, FN = WN / 16;
+  constexpr int TA = BM * 128, TB = 64 * BN * 2, STAGE = TA + TB;
+  constexpr int LA = BM / 64, LB = TB / 8192, LPS = LA + LB;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
+  const int tile = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  if (tile >= ntiles) return;
+  const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+  const int nk = p.K / 64;
+
+  const unsigned char* srcA[LA];
+  const unsigned char* srcB[LB];
+  big_src<BM>(static_cast<const unsigned char*>(p.A), p.lda * 2, m0, p.M, tid, srcA);
+  const int nchunks = p.N / 8;                     // N is a whole number of 16-byte chunks (launcher)
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int c = i * 512 + tid, row = c >> 4, slot = (c & 15) ^ (row & 7);
+    int gc = n0 / 8 + slot;
+    gc = gc < nchunks ? gc : nchunks - 1;          // columns past N are never stored
+    srcB[i] = static_cast<const unsigned char*>(p.B) + (int64_t)row * p.ldb * 2 + (int64_t)gc * 16;
+  }
+  const int64_t stepB = (int64_t)64 * p.ldb * 2;
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
+  auto stage = [&](int kt) __attribute__((always_inline)) {
+    const unsigned sl = wave_lds + (unsigned)((kt % NS) * STAGE);
+#pragma unroll
+    for (int i = 0; i < LA; ++i) big_dma(sl + i * 8192, srcA[i] + (int64_t)kt * 128);
+#pragma unroll
+    for (int i = 0; i < LB; ++i) big_dma(sl + TA + i * 8192, srcB[i] + kt * stepB);
+  };
+
+  f32x4_t acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int offA = (wm * WM + lr) * 128;
+  const int sw0 = ((g) ^ (lr & 7)) << 4, sw1 = ((4 + g) ^ (lr & 7)) << 4;
+  // B fragment j, macro step ms: rows 32 ms + 8 g + (lr >> 2) and + 4, columns wn * WN + 16 j + 4 (lr & 3) ..
+  const int brow = 8 * g + (lr >> 2), bcol = wn * WN + 4 * (lr & 3);
+  const int bhalf = ((bcol >> 2) & 1) * 8;
+
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st)
+    if (st < nk) stage(st);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int ahead = min(NS - 2, nk - 1 - kt);
+    if (NS >= 4 && ahead >= 2) big_wait_vmcnt<2 * LPS>();
+    else if (NS >= 3 && ahead >= 1) big_wait_vmcnt<LPS>();
+    else big_wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (kt + NS - 1 < nk) stage(kt + NS - 1);
+    const unsigned char* s = smem + (kt % NS) * STAGE;
+    const unsigned char* sB = s + TA;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      const int sw = ms ? sw1 : sw0;
+      uint4 a[FM], b[FN];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int r0 = 32 * ms + brow, chunk = (bcol + j * 16) >> 3;
+        const uint2 lo = asr_lds_read_tr16(sB + r0 * 256 + ((chunk ^ (r0 & 7)) << 4) + bhalf);
+        const uint2 hi = asr_lds_read_tr16(sB + (r0 + 4) * 256 + ((chunk ^ ((r0 + 4) & 7)) << 4) + bhalf);
+        b[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const uint4*>(s + offA + i * 2048 + sw);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) mma16<bf16_t>(acc[i][j], b[j], a[i]);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: the block in fp32 through LDS, then 16-byte pieces of 8 bf16: mask, optional +=, one rounding
+  constexpr int OP = BN * 4 + 16;
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int row = wm * WM + i * 16 + lr;
+      *reinterpret_cast<float4*>(smem + row * OP + (wn * WN + j * 16 + g * 4) * 4) =
+          make_float4(acc[i][j][0] * p.alpha, acc[i][j][1] * p.alpha, acc[i][j][2] * p.alpha, acc[i][j][3] * p.alpha);
+    }
+  __syncthreads();
+  bf16_t* C = static_cast<bf16_t*>(p.C);
+  const bf16_t* Msk = static_cast<const bf16_t*>(p.mask);
+  constexpr int CPR = BN / 8;
+  for (int c = tid; c < BM * CPR; c += 512) {
+    const int row = c / CPR, pc = c % CPR;
+    const int grow = m0 + row, gcol = n0 + pc * 8;
+    if (grow < p.M && gcol < p.N) {
+      const float4 v0 = *reinterpret_cast<const float4*>(smem + row * OP + pc * 32);
+      const float4 v1 = *reinterpret_cast<const float4*>(smem + row * OP + pc * 32 + 16);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      const int64_t off = (int64_t)grow * p.ldc + gcol;
+      if (Msk) {
+        Chunk<bf16_t> m;
+        m.v = *reinterpret_cast<const uint4*>(Msk + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = bf16_to_f32(m.e[e]) > 0.f ? v[e] : 0.f;
+      }
+      Chunk<bf16_t> o;
+      if (p.accumulate) {
+        o.v = *reinterpret_cast<const uint4*>(C + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf16_to_f32(o.e[e]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = f32_to_bf16(v[e]);
+      *reinterpret_cast<uint4*>(C + off) = o.v;
+    }
+  }
+}
+
+template <int NS>
+void launch_nn(const BigGemmArgs& p, hipStream_t s) {
+  constexpr size_t lds_stage = (size_t)NS * (128 * 128 + 64 * 128 * 2), lds_out = (size_t)128 * (128 * 4 + 16);
+  constexpr size_t lds = lds_stage > lds_out ? lds_stage : lds_out;
+  static bool granted = false;
+  if (!granted) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_nn_kernel<NS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    granted = true;
+  }
+  const int tiles_m = (p.M + 127) / 128, tiles_n = (p.N + 127) / 128, ntiles = tiles_m * tiles_n;
+  hipLaunchKernelGGL((gemm_big_nn_kernel<NS>), dim3((unsigned)ntiles), dim3(512), lds, s, p, tiles_n, ntiles);
+}
+
 }  // namespace
 
 bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
@@ -221,4 +365,15 @@ bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess;
 }
 
-bool asr_gemm_big_nn(const BigGemmArgs&, hipStream_t) { return false; }
+bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream) {
+  const int mode = (int)asr_tuning("GEMM_BIG_NN", 1);         // 0: off; 1: automatic; 2: always (tests)
+  if (mode == 0 || p.out_f32 || p.bias != nullptr || p.relu) return false;
+  if (p.K <= 0 || p.K % 64 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0 || p.N % 8 != 0 || !aligned16(p.A) || !aligned16(p.B) ||
+      !aligned16(p.C) || (p.mask && !aligned16(p.mask)) || p.lda < p.K || p.ldb < p.N)
+    return false;
+  const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+  if (mode == 1 && t128 < (p.K >= 2048 ? 150 : 48)) return false;
+  const int ns = (int)asr_tuning("GEMM_BIG_NS", (t128 > 256 || p.K < 2048) ? 2 : 4);
+  if (ns == 2) launch_nn<2>(p, stream); else if (ns == 4) launch_nn<4>(p, stream); else launch_nn<3>(p, stream);
+  return hipGetLastError() == hipSuccess;
+}

@@ -184,11 +184,53 @@ def test_gemm_nn_data_gradient(ops, dtype, shape):
     close("nn relu mask", out, (dy @ w) * (mask > 0), dtype)
 
 
+@pytest.fixture
+def four_wave_nn():
+    """asr_gemm_nn on the four-wave kernel only (GEMM_BIG_NN = 0) for the duration of a test."""
+    from asr_hip import lib as L
+    L.set_tuning("GEMM_BIG_NN", 0)
+    yield
+    L.set_tuning("GEMM_BIG_NN", None)
+
+
+@pytest.mark.parametrize("ns", [2, 3, 4])
+def test_gemm_nn_eight_wave_blocks(ops, ns):
+    """csrc/gemm_big.hip gemm_big_nn_kernel (128 x 128 blocks, the weight read with transposing LDS reads) forced on shapes with
+    ragged rows (777), an output width that is not a multiple of the block (200: partial block column; 264), contractions of 64 ..
+    2048 and a weight row stride larger than its width; plain, `+=` into bf16 (one rounding) and ReLU-mask epilogues, alpha.
+    Reference: fp32 torch on the same bf16 operands, 2 bf16 ulp."""
+    from asr_hip import lib as L
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(ns)
+    D = dev()
+    L.set_tuning("GEMM_BIG_NN", 2)
+    L.set_tuning("GEMM_BIG_NS", ns)
+    try:
+        for M, N, K, ldw in [(6400, 512, 512, 512), (777, 200, 64, 200), (1000, 2048, 512, 2048), (3200, 512, 2048, 512), (130, 264, 192, 320)]:
+            # out (M, N) = dy (M, K) @ w (K, N): K is the contracted width here (ops.gemm_nn names it N)
+            dy = torch.randn(M, K, generator=g).to(D).to(bf)
+            w = (torch.randn(K, ldw, generator=g) * K ** -0.5).to(D).to(bf)[:, :N]
+            ref = dy.float() @ w.float()
+            out = ops.gemm_nn(dy, w)
+            base = torch.randn(M, N, generator=g).to(D).to(bf)
+            acc = base.clone()
+            ops.gemm_nn(dy, w, out=acc, accumulate=True, alpha=0.5)
+            mask = torch.randn(M, N, generator=g).to(D).to(bf)
+            msk = ops.gemm_nn(dy, w, relu_mask=mask)
+            for name, got, want in (("plain", out, ref), ("accumulate", acc, base.float() + 0.5 * ref), ("mask", msk, ref * (mask.float() > 0))):
+                tol = 2.0 ** -7 * want.abs().clamp_min(0.05)
+                bad = (got.float() - want).abs() > tol
+                assert not bad.any(), (M, N, K, name, (got.float() - want).abs().max().item(), int(bad.sum()))
+    finally:
+        L.set_tuning("GEMM_BIG_NN", None)
+        L.set_tuning("GEMM_BIG_NS", None)
+
+
 @pytest.mark.parametrize("shape", [(6400, 512, 512), (3200, 512, 2048), (3200, 2048, 512), (200, 64, 64), (130, 192, 72),
                                    (37, 64, 200), (1000, 1536, 512)])
-def test_gemm_nn_tn_one_launch(ops, shape):
+def test_gemm_nn_tn_one_launch(ops, shape, four_wave_nn):
     """A linear layer's dX and dW from ONE launch (asr_gemm_nn_tn) + the multi-layer fold (asr_tn_reduce_multi): dX bit-identical
-    to asr_gemm_nn (the same workgroup code), dW / db against fp32 torch and against asr_gemm_tn."""
+    to the four-wave asr_gemm_nn (the same workgroup code), dW / db against fp32 torch and against asr_gemm_tn."""
     M, N, K = shape
     dtype = torch.bfloat16
     g = torch.Generator().manual_seed(M + N + K)
