@@ -490,6 +490,7 @@ class EmbedFn(Function):
 
 # ================================================================================================ vgg front end
 _conv_overlap = os.environ.get("ASR_CONV_OVERLAP", "0") == "1"
+_pool_codes = os.environ.get("ASR_POOL_CODES", "1") != "0"         # A/B switch: 0 = the pooling backward finds the arg max again from the activations
 # fold of the conv weight-gradient partial blocks on the second stream, under the next data-gradient convolution: measured SLOWER
 # (7.44 -> 7.50 / 7.59 ms per step: the data-gradient convolutions are as much HBM- as MFMA-bound), default off
 _conv_reduce_side = os.environ.get("ASR_CONV_REDUCE_SIDE", "0") == "1"      # A/B switch, default OFF: conv weight gradients on the second stream next to the
@@ -503,21 +504,35 @@ class VGGFn(Function):
         src = src.contiguous().float()
         y1 = ops.conv1_fwd(src, w0.data, b0.data, cd)
         wk2, _ = P.conv_shadow(w2)
-        y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])      # conv.2 + ReLU + MaxPool2d in one epilogue
+        # conv.2 + ReLU + MaxPool2d in one epilogue.  With selection codes (one byte per pooled element) the backward never reads the
+        # un-pooled activations again, so y2 (527 MB at the benchmark shape) is not even stored -- unless the parity tests' tap
+        # (capture_selections) or a no-code fallback needs it.
+        tap = capture_selections is not None
+        fused = ops.conv3x3_relu_pool_code(y1, wk2, b2.data, w2.shape[0], keep_y=tap) if _pool_codes else None
+        if fused is not None:
+            y2, p1, c1 = fused
+        else:
+            y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])
+            c1 = None
         wk5, _ = P.conv_shadow(w5)
         y3 = ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True)
         wk7, _ = P.conv_shadow(w7)
         y4 = ops.conv3x3(y3, wk7, b7.data, w7.shape[0], relu=True)
-        out = ops.maxpool_fwd(y4, tcf=True)
-        if capture_selections is not None:
+        pooled = ops.maxpool_fwd_code(y4, tcf=True) if _pool_codes else None
+        if pooled is not None:
+            out, c4 = pooled
+        else:
+            out, c4 = ops.maxpool_fwd(y4, tcf=True), None
+        if tap:
             capture_selections.append(("vgg", (y1, y2, y3, y4)))
-        ctx.t = (src, y1, y2, p1, y3, y4)
+        # what backward reads: the conv inputs (y1, p1, y3), the ReLU masks (y1, y3) and either the codes or the pre-pool activations
+        ctx.t = (src, y1, None if c1 is not None else y2, p1, y3, None if c4 is not None else y4, c1, c4, tuple(y4.shape))
         ctx.params = (w0, b0, w2, b2, w5, b5, w7, b7)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        src, y1, y2, p1, y3, y4 = ctx.t
+        src, y1, y2, p1, y3, y4, c1, c4, y4_shape = ctx.t
         w0, b0, w2, b2, w5, b5, w7, b7 = ctx.params
 
         forks = []
@@ -543,7 +558,7 @@ class VGGFn(Function):
             else:
                 ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
 
-        dy4 = ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
+        dy4 = ops.maxpool_bwd_code(c4, dout.contiguous(), y4_shape, tcf=True) if c4 is not None else ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
         wgrad(y3, dy4, w7, b7, "c7")
         P.grad_ready(w7, b7)
         _, wd7 = P.conv_shadow(w7)
@@ -552,7 +567,7 @@ class VGGFn(Function):
         P.grad_ready(w5, b5)
         _, wd5 = P.conv_shadow(w5)
         dp1 = ops.conv3x3(dy3, wd5, None, w5.shape[1], relu=False)
-        dy2 = ops.maxpool_bwd(y2, dp1)
+        dy2 = ops.maxpool_bwd_code(c1, dp1, tuple(y1.shape), tcf=False) if c1 is not None else ops.maxpool_bwd(y2, dp1)
         wgrad(y1, dy2, w2, b2, "c2")
         P.grad_ready(w2, b2)
         _, wd2 = P.conv_shadow(w2)

@@ -890,6 +890,45 @@ def conv3x3_relu_pool(x, wk, bias, Cout):
     return y, pool
 
 
+def conv3x3_relu_pool_code(x, wk, bias, Cout, keep_y=False):
+    """(y or None, pool, code): pool = 2x2/2 max-pool of ReLU(conv3x3(x) + bias), code = one selection byte per pooled element
+    (maxpool_bwd_code routes the gradient with it); the un-pooled y is stored only on request.  None when the library has no fused
+    form for this shape (callers use conv3x3_relu_pool)."""
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, H, W, Cout), device=x.device, dtype=x.dtype) if keep_y else None
+    pool = torch.empty((B, H // 2, W // 2, Cout), device=x.device, dtype=x.dtype)
+    code = torch.empty((B, H // 2, W // 2, Cout), device=x.device, dtype=torch.uint8)
+    rc = L.load().asr_conv3x3_relu_pool_code(L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(y), L.ptr(pool), L.ptr(code), B, H, W, Cin, Cout,
+                                             L.dt(x), L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_conv3x3_relu_pool_code")
+    return y, pool, code
+
+
+def maxpool_fwd_code(x, tcf=False):
+    """(y, code) or None when the layout has no 16-byte form."""
+    B, H, W, C = x.shape
+    shape = (B, W // 2, C * (H // 2)) if tcf else (B, H // 2, W // 2, C)
+    y = torch.empty(shape, device=x.device, dtype=x.dtype)
+    code = torch.empty(shape, device=x.device, dtype=torch.uint8)
+    rc = L.load().asr_maxpool_fwd_code(L.ptr(x), L.ptr(y), L.ptr(code), B, H, W, C, int(tcf), L.dt(x), L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_maxpool_fwd_code")
+    return y, code
+
+
+def maxpool_bwd_code(code, dy, x_shape, tcf=False):
+    """dx (x_shape = (B, H, W, C)) from the pooled gradient and the forward's selection codes."""
+    B, H, W, C = x_shape
+    assert dy.is_contiguous() and code.is_contiguous() and code.dtype == torch.uint8
+    dx = torch.empty(x_shape, device=dy.device, dtype=dy.dtype)
+    L.call("asr_maxpool_bwd_code", L.ptr(code), L.ptr(dy), L.ptr(dx), B, H, W, C, int(tcf), L.dt(dy), L.stream())
+    return dx
+
+
 def maxpool_fwd(x, tcf=False):
     B, H, W, C = x.shape
     if tcf:

@@ -646,6 +646,165 @@ __global__ __launch_bounds__(256) void pool_bwd_tcf_vec_kernel(const T* __restri
     *reinterpret_cast<uint4*>(dx + base + rowp + C) = o3.v;
   }
 }
+// ---- pooling with a selection code.  The backward kernels above find the arg max again from the pre-pool activations: for the
+// first pool of the VGG front end that is 527 MB read back per step (and the only reason conv.2's full-resolution output is
+// stored at all).  The *_code forms write one byte per POOLED element next to it -- 0: the maximum is <= 0 (ReLU'(x) = 0, no
+// gradient), 1 + k: gradient to window position k in scan order (the FIRST maximum, PyTorch max_pool2d) -- and the backward reads
+// dy and the codes only.  Code layout = layout of the pooled tensor.
+__device__ __forceinline__ uint32_t pool_code(float a0, float a1, float a2, float a3, float* mx) {
+  int arg = 0; float m = a0;
+  if (a1 > m) { m = a1; arg = 1; }
+  if (a2 > m) { m = a2; arg = 2; }
+  if (a3 > m) { m = a3; arg = 3; }
+  *mx = m;
+  return m > 0.f ? (uint32_t)(1 + arg) : 0u;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_tcf_code_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ code,
+                                                                int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float sp[];     // [H2][C+1] maxima, then [H2][C+4] code bytes
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
+  uint8_t* sc = reinterpret_cast<uint8_t*>(sp + H2 * (C + 1));
+  const int ow = blockIdx.x % W2, b = blockIdx.x / W2;
+  for (int i = threadIdx.x; i < H2 * groups; i += 256) {
+    const int cg = i % groups, oh = i / groups;
+    const T* base = x + ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+    Chunk<T> a, bb, c, d;
+    a.v = *reinterpret_cast<const uint4*>(base);
+    bb.v = *reinterpret_cast<const uint4*>(base + C);
+    c.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C);
+    d.v = *reinterpret_cast<const uint4*>(base + (int64_t)W * C + C);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      float m;
+      const uint32_t k = pool_code(DT<T>::from(a.e[j]), DT<T>::from(bb.e[j]), DT<T>::from(c.e[j]), DT<T>::from(d.e[j]), &m);
+      sp[oh * (C + 1) + cg * EPC + j] = m;
+      sc[oh * (C + 4) + cg * EPC + j] = (uint8_t)k;
+    }
+  }
+  __syncthreads();
+  const int64_t o0 = ((int64_t)b * W2 + ow) * (int64_t)C * H2;
+  const int hg = H2 / EPC;
+  for (int i = threadIdx.x; i < C * hg; i += 256) {
+    const int c = i / hg, oh0 = (i % hg) * EPC;
+    Chunk<T> o;
+    union { uint8_t b[EPC]; uint32_t w[EPC / 4]; } k;
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      o.e[j] = DT<T>::to(sp[(oh0 + j) * (C + 1) + c]);
+      k.b[j] = sc[(oh0 + j) * (C + 4) + c];
+    }
+    *reinterpret_cast<uint4*>(y + o0 + c * H2 + oh0) = o.v;
+#pragma unroll
+    for (int w = 0; w < EPC / 4; ++w) *reinterpret_cast<uint32_t*>(code + o0 + c * H2 + oh0 + 4 * w) = k.w[w];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_tcf_code_kernel(const uint8_t* __restrict__ code, const T* __restrict__ dy, T* __restrict__ dx,
+                                                                int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  extern __shared__ float sp[];     // [H2][C+1] gradients, then [H2][C+4] code bytes
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC, hg = H2 / EPC;
+  uint8_t* sc = reinterpret_cast<uint8_t*>(sp + H2 * (C + 1));
+  const int ow = blockIdx.x % W2, b = blockIdx.x / W2;
+  const int64_t o0 = ((int64_t)b * W2 + ow) * (int64_t)C * H2;
+  for (int i = threadIdx.x; i < C * hg; i += 256) {
+    const int c = i / hg, oh0 = (i % hg) * EPC;
+    Chunk<T> g;
+    g.v = *reinterpret_cast<const uint4*>(dy + o0 + c * H2 + oh0);
+    union { uint8_t b[EPC]; uint32_t w[EPC / 4]; } k;
+#pragma unroll
+    for (int w = 0; w < EPC / 4; ++w) k.w[w] = *reinterpret_cast<const uint32_t*>(code + o0 + c * H2 + oh0 + 4 * w);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      sp[(oh0 + j) * (C + 1) + c] = DT<T>::from(g.e[j]);
+      sc[(oh0 + j) * (C + 4) + c] = k.b[j];
+    }
+  }
+  __syncthreads();
+  const int64_t rowp = (int64_t)W * C;
+  for (int i = threadIdx.x; i < H2 * groups; i += 256) {
+    const int cg = i % groups, oh = i / groups;
+    const int64_t base = ((((int64_t)b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+    Chunk<T> o0v, o1v, o2v, o3v;
+    const T zero = DT<T>::to(0.f);
+#pragma unroll
+    for (int j = 0; j < EPC; ++j) {
+      const T gr = DT<T>::to(sp[oh * (C + 1) + cg * EPC + j]);
+      const uint32_t k = sc[oh * (C + 4) + cg * EPC + j];
+      o0v.e[j] = k == 1u ? gr : zero;
+      o1v.e[j] = k == 2u ? gr : zero;
+      o2v.e[j] = k == 3u ? gr : zero;
+      o3v.e[j] = k == 4u ? gr : zero;
+    }
+    *reinterpret_cast<uint4*>(dx + base) = o0v.v;
+    *reinterpret_cast<uint4*>(dx + base + C) = o1v.v;
+    *reinterpret_cast<uint4*>(dx + base + rowp) = o2v.v;
+    *reinterpret_cast<uint4*>(dx + base + rowp + C) = o3v.v;
+  }
+}
+// NHWC forward with codes (models without the fused conv epilogue) and backward from codes: one thread = EPC channels of a window
+template <typename T>
+__global__ __launch_bounds__(256) void pool_fwd_nhwc_code_kernel(const T* __restrict__ x, T* __restrict__ y, uint8_t* __restrict__ code,
+                                                                 int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W2 * groups) return;
+  const int cg = t % groups, ow = t / groups;
+  const int oh = blockIdx.y % H2;
+  const int64_t b = blockIdx.y / H2;
+  const int64_t rowp = (int64_t)W * C;
+  const int64_t base = (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+  Chunk<T> v0, v1, v2, v3, o;
+  v0.v = *reinterpret_cast<const uint4*>(x + base);
+  v1.v = *reinterpret_cast<const uint4*>(x + base + C);
+  v2.v = *reinterpret_cast<const uint4*>(x + base + rowp);
+  v3.v = *reinterpret_cast<const uint4*>(x + base + rowp + C);
+  union { uint8_t b[EPC]; uint32_t w[EPC / 4]; } k;
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    float m;
+    k.b[j] = (uint8_t)pool_code(DT<T>::from(v0.e[j]), DT<T>::from(v1.e[j]), DT<T>::from(v2.e[j]), DT<T>::from(v3.e[j]), &m);
+    o.e[j] = DT<T>::to(m);
+  }
+  const int64_t po = (((b * H2 + oh) * (int64_t)W2 + ow) * C) + cg * EPC;
+  *reinterpret_cast<uint4*>(y + po) = o.v;
+#pragma unroll
+  for (int w = 0; w < EPC / 4; ++w) *reinterpret_cast<uint32_t*>(code + po + 4 * w) = k.w[w];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bwd_nhwc_code_kernel(const uint8_t* __restrict__ code, const T* __restrict__ dy, T* __restrict__ dx,
+                                                                 int B, int H, int W, int C) {
+  constexpr int EPC = DT<T>::EPC;
+  const int H2 = H / 2, W2 = W / 2, groups = C / EPC;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= W2 * groups) return;
+  const int cg = t % groups, ow = t / groups;
+  const int oh = blockIdx.y % H2;
+  const int64_t b = blockIdx.y / H2;
+  const int64_t rowp = (int64_t)W * C;
+  const int64_t base = (((b * H + 2 * oh) * W + 2 * ow) * (int64_t)C) + cg * EPC;
+  const int64_t po = (((b * H2 + oh) * (int64_t)W2 + ow) * C) + cg * EPC;
+  Chunk<T> g, o0, o1, o2, o3;
+  g.v = *reinterpret_cast<const uint4*>(dy + po);
+  union { uint8_t b[EPC]; uint32_t w[EPC / 4]; } k;
+#pragma unroll
+  for (int w = 0; w < EPC / 4; ++w) k.w[w] = *reinterpret_cast<const uint32_t*>(code + po + 4 * w);
+  const T zero = DT<T>::to(0.f);
+#pragma unroll
+  for (int j = 0; j < EPC; ++j) {
+    o0.e[j] = k.b[j] == 1 ? g.e[j] : zero;
+    o1.e[j] = k.b[j] == 2 ? g.e[j] : zero;
+    o2.e[j] = k.b[j] == 3 ? g.e[j] : zero;
+    o3.e[j] = k.b[j] == 4 ? g.e[j] : zero;
+  }
+  *reinterpret_cast<uint4*>(dx + base) = o0.v;
+  *reinterpret_cast<uint4*>(dx + base + C) = o1.v;
+  *reinterpret_cast<uint4*>(dx + base + rowp) = o2.v;
+  *reinterpret_cast<uint4*>(dx + base + rowp + C) = o3.v;
+}
 // rows/cols that floor-mode pooling drops (odd H or W) get zero gradient: touch only those pixels
 template <typename T>
 __global__ __launch_bounds__(256) void pool_bwd_edges_kernel(T* __restrict__ dx, int B, int H, int W, int C) {
@@ -1012,6 +1171,25 @@ extern "C" int asr_conv3x3_relu_pool(const void* x, const void* wk, const float*
   return asr_conv3x3_c64_launch(a, s);
 }
 
+/* The same without the full-resolution output: pool (B, H/2, W/2, Cout) and one selection byte per pooled element (`code`, layout of
+ * pool; asr_maxpool_bwd_code consumes it) -- what the training step needs of conv.2: its un-pooled output is only ever read to find
+ * the arg max again.  y_or_null != null additionally stores y. */
+extern "C" int asr_conv3x3_relu_pool_code(const void* x, const void* wk, const float* bias, void* y_or_null, void* pool, uint8_t* code,
+                                          int B, int H, int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && wk && pool && code && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (dtype != ASR_BF16 || Cin != 64 || Cout != 64 || !aligned16(x) || !aligned16(wk) || (y_or_null && !aligned16(y_or_null)) || !aligned16(pool) ||
+      (((uintptr_t)code) & 7) != 0 || (int64_t)B * H * W * 128 >= ((int64_t)1 << 32) || asr_tuning("CONV_POOL", 1) == 0)
+    return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  C64Args a{};
+  a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
+  a.y = static_cast<bf16_t*>(y_or_null); a.pool = static_cast<bf16_t*>(pool); a.code = code;
+  a.B = B; a.H = H; a.W = W; a.relu = 1;
+  return asr_conv3x3_c64_launch(a, s);
+}
+
 extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && y && B >= 0 && H >= 2 && W >= 2 && C > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
@@ -1069,6 +1247,61 @@ extern "C" int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, i
     const dim3 grid((unsigned)ceil_div64((int64_t)W2 * (C / epc), 256), (unsigned)(B * H2));
     if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_nhwc_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (const float*)dy, (float*)dx, B, H, W, C);
     else hipLaunchKernelGGL((pool_bwd_nhwc_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+// ---- pooling with selection codes (see pool_fwd_tcf_code_kernel): 16-byte layouts only, ASR_EUNSUPPORTED otherwise (callers then
+// use asr_maxpool_fwd / asr_maxpool_bwd, which need the pre-pool activations)
+extern "C" int asr_maxpool_fwd_code(const void* x, void* y, uint8_t* code, int B, int H, int W, int C, int out_tcf, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && y && code && B >= 0 && H >= 2 && W >= 2 && C > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  const int H2 = H / 2, W2 = W / 2;
+  if (C % epc != 0 || !aligned16(x) || !aligned16(y) || (((uintptr_t)code) & 3) != 0) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_POOL, s);
+  if (out_tcf) {
+    const size_t lds = (size_t)H2 * (C + 1) * sizeof(float) + (size_t)H2 * (C + 4);
+    if (lds > 150 * 1024 || H2 % epc != 0) return ASR_EUNSUPPORTED;
+    if (dtype == ASR_F32) { allow_big_lds(pool_fwd_tcf_code_kernel<float>, lds); hipLaunchKernelGGL((pool_fwd_tcf_code_kernel<float>), dim3(B * W2), dim3(256), lds, s, (const float*)x, (float*)y, code, B, H, W, C); }
+    else { allow_big_lds(pool_fwd_tcf_code_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_fwd_tcf_code_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, (const bf16_t*)x, (bf16_t*)y, code, B, H, W, C); }
+  } else {
+    if ((int64_t)B * H2 > 65535) return ASR_EUNSUPPORTED;
+    const dim3 grid((unsigned)ceil_div64((int64_t)W2 * (C / epc), 256), (unsigned)(B * H2));
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_fwd_nhwc_code_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (float*)y, code, B, H, W, C);
+    else hipLaunchKernelGGL((pool_fwd_nhwc_code_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, code, B, H, W, C);
+  }
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_maxpool_bwd_code(const uint8_t* code, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
+                                    hipStream_t s) {
+  ASR_CHECK_ARG(code && dy && dx && B >= 0 && H >= 2 && W >= 2 && C > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  const int H2 = H / 2, W2 = W / 2;
+  if (C % epc != 0 || !aligned16(dy) || !aligned16(dx) || (((uintptr_t)code) & 3) != 0) return ASR_EUNSUPPORTED;
+  if (in_tcf && (H2 % epc != 0 || (size_t)H2 * (C + 1) * sizeof(float) + (size_t)H2 * (C + 4) > 150 * 1024)) return ASR_EUNSUPPORTED;
+  if (!in_tcf && (int64_t)B * H2 > 65535) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_POOL, s);
+  if ((H & 1) || (W & 1)) {
+    const int64_t total = (int64_t)B * ((int64_t)(H & 1) * W + (int64_t)(W & 1) * (H - (H & 1))) * C;
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_edges_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, (float*)dx, B, H, W, C);
+    else hipLaunchKernelGGL((pool_bwd_edges_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, (bf16_t*)dx, B, H, W, C);
+    ASR_LAUNCH_CHECK();
+  }
+  if (in_tcf) {
+    const size_t lds = (size_t)H2 * (C + 1) * sizeof(float) + (size_t)H2 * (C + 4);
+    if (dtype == ASR_F32) { allow_big_lds(pool_bwd_tcf_code_kernel<float>, lds); hipLaunchKernelGGL((pool_bwd_tcf_code_kernel<float>), dim3(B * W2), dim3(256), lds, s, code, (const float*)dy, (float*)dx, B, H, W, C); }
+    else { allow_big_lds(pool_bwd_tcf_code_kernel<bf16_t>, lds); hipLaunchKernelGGL((pool_bwd_tcf_code_kernel<bf16_t>), dim3(B * W2), dim3(256), lds, s, code, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C); }
+  } else {
+    const dim3 grid((unsigned)ceil_div64((int64_t)W2 * (C / epc), 256), (unsigned)(B * H2));
+    if (dtype == ASR_F32) hipLaunchKernelGGL((pool_bwd_nhwc_code_kernel<float>), grid, dim3(256), 0, s, code, (const float*)dy, (float*)dx, B, H, W, C);
+    else hipLaunchKernelGGL((pool_bwd_nhwc_code_kernel<bf16_t>), grid, dim3(256), 0, s, code, (const bf16_t*)dy, (bf16_t*)dx, B, H, W, C);
   }
   ASR_LAUNCH_CHECK();
   return ASR_OK;

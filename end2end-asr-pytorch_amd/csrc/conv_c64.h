@@ -9,6 +9,7 @@ struct C64Args {
   const bf16_t* mask;   // (B, H, W, 64) or null: output zeroed where mask <= 0 (ReLU mask of the consumer's input, dgrad)
   bf16_t* y;            // (B, H, W, 64)
   bf16_t* pool;         // optional (forward, ReLU, no mask): (B, H/2, W/2, 64) = 2x2/2 floor max-pool of y, written by the same epilogue
+  uint8_t* code;        // optional, with pool: one selection byte per pooled element (csrc/conv.hip pool_code); y may then be null (not stored)
   int B, H, W, relu;
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
   long long* dbg;                 // tuning only (-DC64_TIMING builds): per-section cycle totals of workgroup 0

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
       }
       const int f = (tl >> 7) * 4 + i;
       const bool ok = (f / CB < rows_ok) & ((f % CB) * 16 < cols_ok) & !C64_ABL(p, 4);
-      if (ok) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
+      if (ok && (!POOL || p.y != nullptr)) *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo[i])) = o;
     }
     if (POOL) {
       // 2x2 / stride 2 max-pool of the tile (8 x 16 -> 4 x 8 pixels) from the packed halves: the values are ReLU outputs (>= 0), so
@@ -350,8 +350,49 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
           lo[d] = sw[0]; hi[d] = sw[1];
         }
         const int prow = (h0 >> 1) + (tl >> 7) * 2 + pr, pcol = (w0 >> 1) + ((tl & 15) >> 1);
+        const int64_t pidx = (((int64_t)b * H2 + prow) * W2 + pcol) * 64 + co0;
         if (!(tl & 1) && prow < H2 && pcol < W2)
-          *reinterpret_cast<uint4*>(p.pool + ((((int64_t)b * H2 + prow) * W2 + pcol) * 64 + co0)) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+          *reinterpret_cast<uint4*>(p.pool + pidx) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+        if (p.code != nullptr) {
+          // selection byte per pooled element: 0 where the maximum is 0 (a ReLU output: no gradient), else 1 + position of the FIRST
+          // maximum in scan order (row 0: this lane pair's even / odd lane, row 1 the same).  Packed 16-bit arithmetic on the bf16 bit
+          // patterns (non-negative values: equal numbers <=> equal bits): ne_k = min(v_k xor m, 1) per half,
+          // code = (1 + ne0 + ne0 ne1 + ne0 ne1 ne2) * min(m, 1).  Every lane computes its pair's code; the even lane stores.
+          uint32_t clo[2], chi[2];
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            uint32_t cw[2];
+#pragma unroll
+            for (int cf = 0; cf < 2; ++cf) {
+              const uint32_t mine0 = keep[2 * pr][cf][d], mine1 = keep[2 * pr + 1][cf][d];
+              const uint32_t oth0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine0, 0xB1, 0xf, 0xf, true);      // lane ^ 1
+              const uint32_t oth1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine1, 0xB1, 0xf, 0xf, true);
+              const bool odd = (tl & 1) != 0;
+              const uint32_t v0 = odd ? oth0 : mine0, v1 = odd ? mine0 : oth0, v2 = odd ? oth1 : mine1, v3 = odd ? mine1 : oth1;
+              uint32_t m = v0;
+              asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v1));
+              asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v2));
+              asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v3));
+              const uint32_t one = 0x00010001u;
+              uint32_t n0 = v0 ^ m, n1 = v1 ^ m, n2 = v2 ^ m, nz = m;
+              asm("v_pk_min_u16 %0, %0, %1" : "+v"(n0) : "v"(one));
+              asm("v_pk_min_u16 %0, %0, %1" : "+v"(n1) : "v"(one));
+              asm("v_pk_min_u16 %0, %0, %1" : "+v"(n2) : "v"(one));
+              asm("v_pk_min_u16 %0, %0, %1" : "+v"(nz) : "v"(one));
+              const uint32_t n01 = n0 & n1, n012 = n01 & n2;
+              uint32_t c = one + n0 + n01 + n012;            // halves stay <= 4: no carry between them
+              asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(c) : "v"(nz));
+              cw[cf] = c;
+            }
+            auto sw = __builtin_amdgcn_permlane16_swap(cw[0], cw[1], false, false);    // the same lane-group exchange as the values
+            clo[d] = sw[0]; chi[d] = sw[1];
+          }
+          if (!(tl & 1) && prow < H2 && pcol < W2) {
+            // 8 codes in channel order as 16-bit halves of (clo[0], clo[1], chi[0], chi[1]) -> 8 bytes
+            const uint32_t b0 = __builtin_amdgcn_perm(clo[1], clo[0], 0x06040200u), b1 = __builtin_amdgcn_perm(chi[1], chi[0], 0x06040200u);
+            *reinterpret_cast<uint2*>(p.code + pidx) = make_uint2(b0, b1);
+          }
+        }
       }
     }
     C64_STAMP(4)

@@ -337,6 +337,17 @@ int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_
 /* dx = scatter of dy to the first maximum of each window, times (x > 0); dy layout per in_tcf                   */
 int asr_maxpool_bwd(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
                     asr_stream_t stream);
+/* The same pooling (nn.MaxPool2d(2, stride=2) after a ReLU, transformer.py:46,52) with a SELECTION CODE instead of the pre-pool
+ * activations in backward: the forward writes one byte per pooled element, in the pooled tensor's layout -- 0: maximum <= 0 (no
+ * gradient: ReLU'), 1 + k: the first maximum is window position k in scan order -- and the backward reads dy and the codes only
+ * (first pool of the VGG front end: 0.72 GB moved instead of 1.19 GB, and the 527 MB un-pooled activation need not be kept).
+ * ASR_EUNSUPPORTED for layouts without whole 16-byte chunks (callers use the pair above).                          */
+int asr_maxpool_fwd_code(const void* x, void* y, uint8_t* code, int B, int H, int W, int C, int out_tcf, int dtype, asr_stream_t stream);
+int asr_maxpool_bwd_code(const uint8_t* code, const void* dy, void* dx, int B, int H, int W, int C, int in_tcf, int dtype,
+                         asr_stream_t stream);
+/* asr_conv3x3_relu_pool that writes the pooled output and its selection codes; y_or_null = NULL: the un-pooled output is not stored */
+int asr_conv3x3_relu_pool_code(const void* x, const void* wk, const float* bias, void* y_or_null, void* pool, uint8_t* code, int B,
+                               int H, int W, int Cin, int Cout, int dtype, asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
  * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip; bf16 with a workspace: the LDS-DMA
  * pipelined kernel of conv_wgrad_dma.hip).                                                                      */

@@ -765,6 +765,15 @@ def test_conv3x3_relu_pool_fused(ops, shape):
     y, pool = ops.conv3x3_relu_pool(xd, wk, b.to(D), 64)
     assert torch.equal(y, y_ref)
     assert pool.shape == p_ref.shape and torch.equal(pool, p_ref)
+    # the same epilogue with selection codes, with and without the un-pooled output: same pool; the codes route a gradient exactly
+    # like the pooling backward that re-reads y (first maximum in scan order, nothing where the maximum is 0)
+    dy = q(torch.randn(B, H // 2, W // 2, 64, generator=g), dtype).to(D, dtype)
+    dx_ref = ops.maxpool_bwd(y_ref, dy)
+    for keep_y in (True, False):
+        y2, pool2, code = ops.conv3x3_relu_pool_code(xd, wk, b.to(D), 64, keep_y=keep_y)
+        assert torch.equal(pool2, p_ref) and (y2 is None) == (not keep_y) and (y2 is None or torch.equal(y2, y_ref))
+        assert code.dtype == torch.uint8 and int(code.max()) <= 4 and torch.equal(code == 0, p_ref == 0)
+        assert torch.equal(ops.maxpool_bwd_code(code, dy, tuple(y_ref.shape)), dx_ref)
 
 
 @pytest.mark.parametrize("cfg", [(3, 97, 130, 64, 128), (2, 50, 200, 128, 64)])
@@ -836,6 +845,16 @@ def test_maxpool_fwd_bwd_both_layouts(ops, dtype, shape):
     dy_tcf = dy.reshape(B, C * H2, W2).transpose(1, 2).contiguous()
     dx2 = ops.maxpool_bwd(xd, dy_tcf.to(D, dtype), tcf=True)
     assert torch.equal(dx2.float().cpu(), want)
+    # selection codes instead of the activations in backward (asr_maxpool_fwd_code / asr_maxpool_bwd_code), both layouts
+    for tcf, gy in ((False, nhwc(dy)), (True, dy_tcf)):
+        res = ops.maxpool_fwd_code(xd, tcf=tcf)
+        if res is None:                     # no 16-byte form for this shape: the library said so, callers keep the pair above
+            assert C % (4 if dtype == torch.float32 else 8) != 0 or (tcf and H2 % (4 if dtype == torch.float32 else 8) != 0)
+            continue
+        yc, code = res
+        assert torch.equal(yc, ytcf if tcf else y)
+        dxc = ops.maxpool_bwd_code(code, gy.to(D, dtype), tuple(xd.shape), tcf=tcf)
+        assert torch.equal(dxc.float().cpu(), want)
 
 
 def test_ops_refuse_host_tensors(ops):
