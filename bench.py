@@ -37,7 +37,7 @@ MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm
 LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0, "enc_layers": 12, "dec_layers": 6}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FILE = os.path.join("profiles", "r02_roofline_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_roofline_traffic.json")
 # per-family kernel time of the REPLAYED step (tools/prof_families.py over a committed rocprofv3 trace of this command)
 REPLAYED_FAMILIES_FILE = os.path.join("profiles", "r03_replayed_families.json")
 
@@ -94,7 +94,7 @@ def measured_traffic(a):
     WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
     if a.batch != 32 or a.precision != "bf16":
         return None
-    for f in (TRAFFIC_FILE, os.path.join("profiles", "r01_roofline_traffic.json")):
+    for f in (TRAFFIC_FILE, os.path.join("profiles", "r02_roofline_traffic.json"), os.path.join("profiles", "r01_roofline_traffic.json")):
         try:
             with open(os.path.join(ROOT, f)) as fh:
                 return json.load(fh)["traffic_bytes_per_launch_avg"], f
