@@ -9,6 +9,7 @@ choice are identical on every rank and to a single-GPU run; the decision to skip
 collectively so that ranks never diverge.
 """
 import logging
+import os
 import sys
 import time
 
@@ -73,6 +74,8 @@ class _Pending:
 
 
 class Trainer():
+    GRAPH_CACHE = int(os.environ.get("ASR_GRAPH_CACHE", "12"))     # captured step shapes kept by --graph-buckets
+
     def __init__(self):
         logging.info("Trainer is initialized")
 
@@ -80,7 +83,10 @@ class Trainer():
         """--graph-buckets N: the training step as a captured hipGraph per (batch, padded frames) shape.  The batch is copied
         into the graph's static buffers -- time axis zero-padded to a multiple of N frames, targets PAD-padded to --tgt-max-len - 1
         columns (Decoder.preprocess strips PAD, so the targets are unchanged; the extra zero frames are seen by the model exactly
-        like the collate function's own padding of shorter utterances) -- and the graph is replayed.  The first batch of a new
+        like the collate function's own padding of shorter utterances -- for vgg_cnn.  With --feat_extractor emb_cnn the BatchNorm
+        batch statistics are taken over padded positions as well (as they are over the collate padding in the reference), so bucket
+        padding changes them: results are NOT identical to --graph-buckets 0 there) -- and the graph is replayed.  At most
+        GRAPH_CACHE shapes stay captured (least recently used first out: a captured step owns its activations' memory pool).  The first batch of a new
         shape runs eagerly (that IS its training step) and captures.  Returns (loss value, gold_seq, hyp_seq) or None when the
         shapes do not fit (falls back to eager launches).  Under --parallel (an active gradient reducer) the step is the four-graph
         form of asr_hip/graph.py with the RCCL all-reduces between the graphs: every rank pads to the same bucket (the sampler
@@ -95,7 +101,13 @@ class Trainer():
         Tb = (T + N - 1) // N * N
         key = (B, C, F, Tb, L, src.dtype)
         graphs = self.__dict__.setdefault("_graphs", {})
-        gs = graphs.get(key)
+        gs = graphs.pop(key, None)
+        if gs is not None:
+            graphs[key] = gs                      # most recently used last
+        while gs is None and len(graphs) >= self.GRAPH_CACHE:
+            old = next(iter(graphs))
+            del graphs[old]                       # frees that shape's graph, static buffers and memory pool
+            logging.info("graph cache: dropped the captured step of shape %s", (old,))
         lens = torch.as_tensor(src_lengths).to(torch.int32)
         if gs is None:
             src_b = torch.zeros((B, C, F, Tb), device=src.device, dtype=src.dtype)

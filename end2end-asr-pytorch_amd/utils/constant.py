@@ -82,10 +82,20 @@ if torch.cuda.is_available():
     torch.cuda.manual_seed_all(123456)
 
 
+def _given(argv):
+    """Destinations of the options that appear on this command line (as opposed to argparse defaults)."""
+    out = set()
+    for act in parser._actions:
+        if any(tok == o or tok.startswith(o + "=") for o in act.option_strings for tok in argv):
+            out.add(act.dest)
+    return out
+
+
 def parse(argv):
     """Parse an explicit argv (list of strings) into the process-global Namespace."""
-    global args, USE_CUDA
+    global args, USE_CUDA, explicit
     args = parser.parse_args(argv)
+    explicit = _given(list(argv))
     USE_CUDA = args.cuda
     return args
 
@@ -99,6 +109,7 @@ def set_args(ns):
 
 _entry = os.path.basename(sys.argv[0]) if sys.argv and sys.argv[0] else ""
 args = parser.parse_args(sys.argv[1:] if _entry in ("train.py", "test.py") else [])
+explicit = _given(sys.argv[1:] if _entry in ("train.py", "test.py") else [])      # options the user actually typed (load_model)
 USE_CUDA = args.cuda
 
 PAD_TOKEN, SOS_TOKEN, EOS_TOKEN = 0, 1, 2

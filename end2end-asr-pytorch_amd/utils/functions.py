@@ -5,6 +5,8 @@ here every rank of a torch.distributed job owns one GPU and gradients are all-re
 import math
 import os
 
+import logging
+
 import torch
 import torch.distributed as dist
 
@@ -49,8 +51,16 @@ def load_model(load_path):
         # laid out over GPUs (the reference re-wraps according to the current --parallel, train.py:92-99; a checkpoint saved
         # without it must not silently train un-synchronised replicas), where it runs, and the MI355X-path switches a
         # reference-written checkpoint does not carry at all.
-        for k in ("parallel", "device_ids", "precision", "dist_backend", "bucket_mb", "gpu_frontend"):
+        for k in ("parallel", "device_ids", "dist_backend", "bucket_mb"):
             if hasattr(cur, k):
+                setattr(args, k, getattr(cur, k))
+        # numerics switches: what the checkpoint was trained with stays, unless the user typed the option on THIS command line or
+        # the (reference-written) checkpoint does not carry it -- an fp32-trained model must not silently resume in bf16
+        for k in ("precision", "gpu_frontend"):
+            if hasattr(cur, k) and (k in getattr(constant, "explicit", ()) or not hasattr(args, k)):
+                if hasattr(args, k) and getattr(args, k) != getattr(cur, k):
+                    logging.info("load_model: --%s %s from the command line overrides the checkpoint's %s", k.replace("_", "-"),
+                                 getattr(cur, k), getattr(args, k))
                 setattr(args, k, getattr(cur, k))
         args.cuda = bool(getattr(args, "cuda", False) or getattr(cur, "cuda", False))
     label2id, id2label = ckpt['label2id'], ckpt['id2label']

@@ -344,3 +344,18 @@ def test_native_edit_distance_matches_python_and_oracle():
     words = [(a.split(), b.split()) for a, b in pairs]
     assert edit_distance_batch(words) == [edit_distance_py(a, b) for a, b in words]
     assert edit_distance("flaw", "lawn") == 2 and edit_distance_batch([]) == []
+
+
+def test_command_line_records_which_options_were_typed():
+    """load_model keeps a checkpoint's --precision unless the user typed the option (utils/functions.py): constant.explicit holds the
+    destinations of the options present on the command line, not the argparse defaults."""
+    from utils import constant
+    old_args, old_explicit = constant.args, constant.explicit
+    try:
+        a = constant.parse(["--num-layers", "2", "--precision=fp32"])
+        assert a.precision == "fp32" and {"num_layers", "precision"} <= constant.explicit and "gpu_frontend" not in constant.explicit
+        constant.parse(["--num-layers", "2"])
+        assert "precision" not in constant.explicit
+    finally:
+        constant.set_args(old_args)
+        constant.explicit = old_explicit
