@@ -120,7 +120,7 @@ def join_if_pending_reads(t):
 _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
 _debug_group = os.environ.get("ASR_DEBUG_GROUP") == "1"
-WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "16"))
+WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "32"))      # layers per grouped launch (<= 32: asr_gemm_tn_grouped); 16 / 24 / 32 measured: profiles/r03_grouped_wgrad_group_size_ab.txt
 _wgrad_side = os.environ.get("ASR_WGRAD_SIDE", "0") == "1"
 
 
@@ -167,7 +167,7 @@ def _tn_group_ok(e):
 
 
 def gemm_tn_grouped(grp):
-    """grp: up to 16 tuples (dy (M,>=N) bf16, x (M,>=K) bf16, dw (N,K) fp32, db (N) fp32 or None, N, K): dw += dy[:, :N]^T x[:, :K] and
+    """grp: up to 32 tuples (dy (M,>=N) bf16, x (M,>=K) bf16, dw (N,K) fp32, db (N) fp32 or None, N, K): dw += dy[:, :N]^T x[:, :K] and
     db += column sums of dy for all of them in one launch (asr_gemm_tn_grouped); problems whose layout the grouped kernel does not
     take (a row stride that is not a whole number of 16-byte chunks) go through the per-layer kernel, the others stay grouped."""
     import ctypes

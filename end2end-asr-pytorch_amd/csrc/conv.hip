@@ -1058,7 +1058,15 @@ int launch_igemm(const ConvArgs& a, hipStream_t s) {
   const int th = (int)asr_tuning("IGEMM_TH", 16);
   const int tps = (int)asr_tuning("IGEMM_TPS", 1);
   const int wbuf = (int)asr_tuning("IGEMM_WBUF", 1);
-  if (sizeof(T) == 2 && th == 16) return launch_igemm_t<T, NCO, 16, 1, 1>(a, s);
+  if constexpr (sizeof(T) == 2) {
+    if (th == 16) {
+      // (A/B, round 3: profiles/r03_igemm_variants_ab.txt) at the 16-row tile two weight buffers or two taps per step still leave two
+      // workgroups per CU (74 KB each) -- and change nothing: 307 - 313 us on the 128 -> 128 layer whichever way
+      if (wbuf == 2 && tps == 1) return launch_igemm_t<T, NCO, 16, 1, 2>(a, s);
+      if (tps == 2) return launch_igemm_t<T, NCO, 16, 2, 1>(a, s);
+      return launch_igemm_t<T, NCO, 16, 1, 1>(a, s);
+    }
+  }
   if (sizeof(T) == 2 && NCO == 64 && tps == 2) return launch_igemm_t<T, NCO, 8, 2, 2>(a, s);
   if (wbuf == 1) return launch_igemm_t<T, NCO, 8, 1, 1>(a, s);
   return launch_igemm_t<T, NCO, 8, 1, 2>(a, s);

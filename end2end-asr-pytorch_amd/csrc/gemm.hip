@@ -1140,7 +1140,7 @@ __device__ __forceinline__ void tn256_body(const Tn128Args& p, unsigned char* sm
 // a serial chain over all M rows.  Queued and launched together at the end of backward, the layers' blocks fill the chip
 // (~1900 blocks of 128 x 128 for the 4-layer model), every block contracts ALL rows of its layer (no m-split: no partial-sum
 // workspace, no fold pass, plain += into the fp32 gradient), longest layers first.
-constexpr int TN_GROUP_MAX = 16;
+constexpr int TN_GROUP_MAX = 32;
 struct TnGroupArgs {
   Tn128Args p[TN_GROUP_MAX];
   int first[TN_GROUP_MAX + 1];       // first[i] = number of blocks of the problems before i
