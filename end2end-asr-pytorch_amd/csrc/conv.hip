@@ -1156,6 +1156,21 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
     a.B = B; a.H = H; a.W = W; a.relu = relu;
     return asr_conv3x3_c64_launch(a, s);
   }
+  // 64 -> 128 channels without a mask (conv.5 forward): the same kernel once per half of the output channels -- each half's 72 KB of
+  // weights sits in registers, the 64-channel input is read twice (the second time from L2 / MALL); 0 = the generic implicit GEMM
+  if (c64 && dtype == ASR_BF16 && Cin == 64 && Cout == 128 && !mask_src && (int64_t)B * H * W * 256 < ((int64_t)1 << 32) && !p.ablate &&
+      asr_tuning("C64_SPLIT", 1) != 0) {
+    for (int half = 0; half < 2; ++half) {
+      C64Args a{};
+      a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk) + (size_t)half * 64 * 9 * 64;
+      a.bias = bias ? bias + half * 64 : nullptr;
+      a.y = static_cast<bf16_t*>(y) + half * 64; a.ypix = 256;
+      a.B = B; a.H = H; a.W = W; a.relu = relu;
+      const int rc = asr_conv3x3_c64_launch(a, s);
+      if (rc != ASR_OK) return rc;
+    }
+    return ASR_OK;
+  }
   if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
   return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);
 }

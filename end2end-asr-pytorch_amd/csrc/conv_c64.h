@@ -11,6 +11,7 @@ struct C64Args {
   bf16_t* pool;         // optional (forward, ReLU, no mask): (B, H/2, W/2, 64) = 2x2/2 floor max-pool of y, written by the same epilogue
   uint8_t* code;        // optional, with pool: one selection byte per pooled element (csrc/conv.hip pool_code); y may then be null (not stored)
   int B, H, W, relu;
+  int ypix;             // bytes per pixel of y (0 = 128: 64 channels); 256 = y is a 128-channel tensor and this launch fills 64 of them (no mask then)
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
   long long* dbg;                 // tuning only (-DC64_TIMING builds): per-section cycle totals of workgroup 0
   int ablate;                     // tuning only (ASR_C64_ABLATE in -DASR_TUNE_ABLATE builds)

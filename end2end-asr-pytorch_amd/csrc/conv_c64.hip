@@ -174,7 +174,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int f = wm * 4 + i;
-    relo[i] = ((f / CB) * p.W + (f % CB) * 16 + lr) * 128 + co0 * 2;
+    relo[i] = ((f / CB) * p.W + (f % CB) * 16 + lr) * (MASK ? 128 : p.ypix) + co0 * 2;
   }
   // halo patch of tile n -> buffer n % NBUF.  Tiles whose halo lies inside the image: one add per chunk.  Border tiles: per-chunk
   // bounds test, outside pixels come from the zero page (`t_` = the thread index, laundered per tile by the caller so that this
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
     int tl = tid;
     asm volatile("" : "+v"(tl));
     const int b = org[0].b, h0 = org[0].h0, w0 = org[0].w0;
-    const unsigned obase = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * 128u;
+    const unsigned obase = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * (MASK ? 128u : (unsigned)p.ypix);
     const bool whole = h0 + TH <= p.H && w0 + TW <= p.W;          // every output pixel of the tile is inside the image
     if (MASK) {                        // this tile's mask chunks -> the lane's private stash (pixels outside the image: clamped)
       const unsigned char* Mk = reinterpret_cast<const unsigned char*>(p.mask);
@@ -461,6 +461,8 @@ int launch_t(C64Args p, hipStream_t s) {
 
 int asr_conv3x3_c64_launch(const C64Args& a_, hipStream_t s) {
   C64Args a = a_;
+  if (a.ypix == 0) a.ypix = 128;
+  if (a.ypix != 128 && (a.mask || a.pool)) return ASR_EUNSUPPORTED;
   a.ablate = (int)asr_tuning("C64_ABLATE", 0);
   // shape (ASR_C64_SHAPE, tuning): 0 = two 4-wave workgroups per CU on 8 x 16 pixel tiles (default: the two workgroups are not in
   // phase, so one's address / epilogue VALU work overlaps the other's MFMAs); 1 / 2 = one 8-wave workgroup on 16 x 16 / 8 x 32 tiles
