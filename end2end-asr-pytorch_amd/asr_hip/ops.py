@@ -116,7 +116,8 @@ def join_if_pending_reads(t):
 # ---- deferred, grouped weight gradients.  Only a linear layer's DATA gradient feeds the rest of backward; its weight gradient is a
 # latency-bound chain of 16 - 64 blocks when launched alone.  While a hipGraph is being captured (bf16, no data-parallel reducer
 # waiting for per-layer gradients) the layers' (dy, x) pairs are queued and contracted by ONE launch per 16 layers at the end of the
-# transformer's backward (asr_gemm_tn_grouped).  ASR_DEFER_WGRAD=0 restores the per-layer launches.
+# transformer's backward (asr_gemm_tn_grouped).  ASR_DEFER_WGRAD=0 restores the per-layer launches.  (Round 3: also under the multi-graph
+# data-parallel step, whose reducer only exchanges between graphs.)
 _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
 _debug_group = os.environ.get("ASR_DEBUG_GROUP") == "1"
@@ -129,7 +130,10 @@ def defer_wgrad_now(dtype=None):
         return False
     from . import params as P_
     r = P_._state["reducer"]
-    return r is None or not getattr(r, "active", False)
+    # data parallel: an eager reducer wants every layer's gradient the moment its backward ran (bucket by bucket); in graph-replay
+    # mode the collectives are issued BETWEEN the graphs (hold), every graph body ends with join_deferred() -> flush_wgrads(), so the
+    # gradients of a graph's layers are complete before its slice is exchanged
+    return r is None or not getattr(r, "active", False) or getattr(r, "hold", False)
 
 
 def queue_wgrad(dy, x, dw, db, N, K):
