@@ -167,6 +167,10 @@ class _Fused:
 
 
 # ================================================================================================ plain linear
+_logit_handover = [None]              # (data_ptr of the latest fp32 logits, box of the LinearFn that produced them)
+_logit_handover_on = os.environ.get("ASR_LOGIT_HANDOVER", "1") != "0"
+
+
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, out_fp32, mark_ready):
@@ -179,12 +183,21 @@ class LinearFn(Function):
         ctx.weight, ctx.bias, ctx.mark_ready = weight, bias, mark_ready
         ctx.in_shape = x.shape
         ctx.need_dx = x.requires_grad
+        ctx.box = None
+        if out_fp32 and cd == torch.bfloat16 and _logit_handover_on:
+            # fp32 logits of a bf16 model (the vocabulary projection): the loss's backward may leave the gradient in the compute dtype,
+            # zero padded to the data-gradient kernel's stage, in this box instead of an fp32 tensor that would be cast and padded
+            # here (CEFn.backward; one slot: the latest logits)
+            ctx.box = {}
+            _logit_handover[0] = (y.data_ptr(), ctx.box, tuple(y.shape))
         return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, dy):
         N = ctx.weight.shape[0]
-        dy_c = _as_compute(dy.reshape(-1, N))
+        dy_c = ctx.box.pop("dy", None) if ctx.box is not None else None
+        if dy_c is None:
+            dy_c = _as_compute(dy.reshape(-1, N))
         dx = _linear_bwd(dy_c, ctx.x2, ctx.weight, ctx.bias, need_dx=ctx.need_dx)
         if ctx.mark_ready:
             P.grad_ready(*[p for p in (ctx.weight, ctx.bias) if p is not None])
@@ -818,7 +831,16 @@ class CEFn(Function):
         logits, g, lse, count = ctx.t
         if count is None:
             count = ops.ones_scalar(logits.device)
-        dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, dloss.reshape(1).float().contiguous(), count)
+        go = dloss.reshape(1).float().contiguous()
+        slot = _logit_handover[0]
+        if slot is not None and slot[0] == logits.data_ptr() and slot[2] == tuple(logits.shape):
+            # the logits come straight from a LinearFn of a bf16 model: hand it the gradient in bf16, padded to 64 columns (what its
+            # data-gradient GEMM reads), and return a stride-0 zero as the formal fp32 gradient -- saves the 56 MB fp32 tensor, its
+            # cast / pad launch and half of this kernel's stores (reference: loss.backward() through utils/metrics.py:118-130)
+            _logit_handover[0] = None
+            slot[1]["dy"] = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count, out_dtype=torch.bfloat16, pad=64)
+            return torch.zeros((), device=logits.device, dtype=torch.float32).expand(ctx.shape), None, None, None, None
+        dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count)
         return dl.view(ctx.shape), None, None, None, None
 
 

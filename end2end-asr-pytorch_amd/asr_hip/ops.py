@@ -781,14 +781,15 @@ def logsoftmax_topk(logits, k):
     return vals, idx
 
 
-def ce_bwd(logits, gold, lse, smoothing, pad_id, grad_out, count):
-    """Returns fp32 dlogits as an (M,V) view of an (M, pad8(V)) buffer whose pad columns are zero."""
+def ce_bwd(logits, gold, lse, smoothing, pad_id, grad_out, count, out_dtype=torch.float32, pad=8):
+    """Returns dlogits as an (M,V) view of an (M, V rounded up to `pad`) buffer whose pad columns are zero; with a 64-column pad
+    the WHOLE padded buffer is returned (the data-gradient GEMM contracts the padded width)."""
     M, V = logits.shape
-    ld = _pad8(V)
-    dl = torch.empty((M, ld), device=logits.device, dtype=torch.float32)
+    ld = (V + pad - 1) // pad * pad
+    dl = torch.empty((M, ld), device=logits.device, dtype=out_dtype)
     L.call("asr_ce_bwd", L.ptr(logits), logits.stride(0), L.ptr(gold), L.ptr(lse), M, V, float(smoothing), int(pad_id),
-           L.ptr(grad_out), L.ptr(count), L.ptr(dl), ld, L.F32, L.stream())
-    return dl[:, :V]
+           L.ptr(grad_out), L.ptr(count), L.ptr(dl), ld, L.dt(dl), L.stream())
+    return dl if pad == 64 else dl[:, :V]
 
 
 # ------------------------------------------------------------------------------------------------ optimiser
