@@ -503,6 +503,7 @@ class EmbedFn(Function):
 
 # ================================================================================================ vgg front end
 _conv_overlap = os.environ.get("ASR_CONV_OVERLAP", "0") == "1"
+_conv7_pool = os.environ.get("ASR_CONV7_POOL", "1") != "0"       # A/B switch: 0 = conv.7 stores its output, the pooling kernel reads it back
 _pool_codes = os.environ.get("ASR_POOL_CODES", "1") != "0"         # A/B switch: 0 = the pooling backward finds the arg max again from the activations
 # fold of the conv weight-gradient partial blocks on the second stream, under the next data-gradient convolution: measured SLOWER
 # (7.44 -> 7.50 / 7.59 ms per step: the data-gradient convolutions are as much HBM- as MFMA-bound), default off
@@ -530,16 +531,23 @@ class VGGFn(Function):
         wk5, _ = P.conv_shadow(w5)
         y3 = ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True)
         wk7, _ = P.conv_shadow(w7)
-        y4 = ops.conv3x3(y3, wk7, b7.data, w7.shape[0], relu=True)
-        pooled = ops.maxpool_fwd_code(y4, tcf=True) if _pool_codes else None
-        if pooled is not None:
-            out, c4 = pooled
+        y4_shape = tuple(y3.shape[:3]) + (w7.shape[0],)
+        # conv.7 + ReLU + MaxPool2d + the (B, T', C F') transpose from the convolution's epilogue: y4 is never stored (not for the tap)
+        fused7 = ops.conv3x3_relu_pool_tcf_code(y3, wk7, b7.data, w7.shape[0]) if (_pool_codes and _conv7_pool and not tap) else None
+        if fused7 is not None:
+            y4 = None
+            out, c4 = fused7
         else:
-            out, c4 = ops.maxpool_fwd(y4, tcf=True), None
+            y4 = ops.conv3x3(y3, wk7, b7.data, w7.shape[0], relu=True)
+            pooled = ops.maxpool_fwd_code(y4, tcf=True) if _pool_codes else None
+            if pooled is not None:
+                out, c4 = pooled
+            else:
+                out, c4 = ops.maxpool_fwd(y4, tcf=True), None
         if tap:
             capture_selections.append(("vgg", (y1, y2, y3, y4)))
         # what backward reads: the conv inputs (y1, p1, y3), the ReLU masks (y1, y3) and either the codes or the pre-pool activations
-        ctx.t = (src, y1, None if c1 is not None else y2, p1, y3, None if c4 is not None else y4, c1, c4, tuple(y4.shape))
+        ctx.t = (src, y1, None if c1 is not None else y2, p1, y3, None if c4 is not None else y4, c1, c4, y4_shape)
         ctx.params = (w0, b0, w2, b2, w5, b5, w7, b7)
         return out
 

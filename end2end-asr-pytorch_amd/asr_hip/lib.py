@@ -97,6 +97,7 @@ _SIGS = {
     "asr_maxpool_fwd_code": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_maxpool_bwd_code": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_relu_pool_code": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "asr_conv3x3_relu_pool_tcf_code": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_wgrad_workspace": (_L, [_I, _I, _I, _I, _I]),
     "asr_conv3x3_wgrad_nhwc": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_wgrad_partials": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P]),

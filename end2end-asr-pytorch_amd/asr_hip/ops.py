@@ -912,6 +912,21 @@ def conv3x3_relu_pool_code(x, wk, bias, Cout, keep_y=False):
     return y, pool, code
 
 
+def conv3x3_relu_pool_tcf_code(x, wk, bias, Cout):
+    """(pool (B, W/2, Cout * H/2), code): the encoder-layout max-pool of ReLU(conv3x3(x) + bias) and its selection bytes from the
+    convolution's own epilogue (the un-pooled output is never stored); None when the library has no fused form for this shape."""
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    pool = torch.empty((B, W // 2, Cout * (H // 2)), device=x.device, dtype=x.dtype)
+    code = torch.empty((B, W // 2, Cout * (H // 2)), device=x.device, dtype=torch.uint8)
+    rc = L.load().asr_conv3x3_relu_pool_tcf_code(L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(pool), L.ptr(code), B, H, W, Cin, Cout,
+                                                 L.dt(x), L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_conv3x3_relu_pool_tcf_code")
+    return pool, code
+
+
 def maxpool_fwd_code(x, tcf=False):
     """(y, code) or None when the layout has no 16-byte form."""
     B, H, W, C = x.shape

@@ -232,6 +232,7 @@ __device__ const uint4 conv_zero_page = {0u, 0u, 0u, 0u};      // source of halo
 
 struct ConvArgs {
   const void* x; const void* wk; const float* bias; const void* mask_src; void* y;
+  void* pool; uint8_t* code;    // PT kernels: (B, W/2, Cout, H/2) pooled output + its selection bytes instead of y
   int B, H, W, Cin, Cout, relu, tiles_h, tiles_w;
   int ablate;   // tuning only (ASR_IGEMM_ABLATE in -DASR_TUNE_ABLATE builds): 1 = no patch loads, 2 = no weight loads, 4 = no stores, 8 = no MFMAs
 };
@@ -242,7 +243,7 @@ struct ConvArgs {
 // fragments.  TH = 16 gives 4 x 4 (NCO 64) / 4 x 8 (NCO 128) fragments per wave: 2 / 2.7 MFMAs per LDS operand read
 // instead of 1.3 / 2 with TH = 8.  What bounds the loop is instruction issue around the MFMAs (an MFMA leaves room for about two
 // other vector instructions, tools/probes/mfma_valu_probe.hip; this loop carries 1.8 - 3.4) and the two barriers per tap.
-template <typename T, int NCO, int TH, int TPS, int WBUF>
+template <typename T, int NCO, int TH, int TPS, int WBUF, bool PT = false>
 __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
   constexpr int EPC = DT<T>::EPC, ESZ = (int)sizeof(T);
   constexpr int CPP = 64 / EPC;            // 16-B chunks per 64-channel pixel slice
@@ -385,6 +386,68 @@ __global__ __launch_bounds__(256) void conv3x3_igemm_kernel(ConvArgs p) {
 #undef ASR_WWRITE
 #undef ASR_SLOT
 
+  if constexpr (PT) {
+    // ---- pooled epilogue (conv.7 + ReLU + MaxPool2d + the view / transpose of transformer.py:50-52,74-76): bias + ReLU on the
+    // accumulators, 2 x 2 maximum over the wave's row pairs (registers) and the lane pairs (lr, lr ^ 1: DPP), one selection byte per
+    // pooled element (packed 16-bit arithmetic on the bf16 bit patterns, as in conv_c64.hip), the 8 x 8 x 128 pooled tile and its
+    // bytes staged in LDS as [pooled column][channel][pooled row] so that the (B, W/2, C, H/2) output gets 16-byte runs along H/2.
+    // The un-pooled output is never stored.  Launcher: bf16, 128 outputs, H and W multiples of 16.
+    static_assert(!PT || (sizeof(T) == 2 && NCO == 128 && TH == 16 && WM == 4), "pooled epilogue: bf16, 128 channels, 16-row tile");
+    __syncthreads();                       // every wave is done with the operand tiles
+    bf16_t* sPool = reinterpret_cast<bf16_t*>(smem);
+    uint8_t* sCode = smem + 8 * 128 * 8 * 2;
+    const bool odd = (lr & 1) != 0;
+    const uint32_t one = 0x00010001u;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const f32x4_t bvj = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + j * 16 + 4 * g) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+        uint32_t mx[2], cd[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+          const f32x4_t x0 = acc[2 * pr][j] + bvj, x1 = acc[2 * pr + 1][j] + bvj;
+          const uint32_t mine0 = (uint32_t)f32_to_bf16(fmaxf(x0[2 * d], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(x0[2 * d + 1], 0.f)) << 16);
+          const uint32_t mine1 = (uint32_t)f32_to_bf16(fmaxf(x1[2 * d], 0.f)) | ((uint32_t)f32_to_bf16(fmaxf(x1[2 * d + 1], 0.f)) << 16);
+          const uint32_t oth0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine0, 0xB1, 0xf, 0xf, true);      // lane ^ 1
+          const uint32_t oth1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine1, 0xB1, 0xf, 0xf, true);
+          const uint32_t v0 = odd ? oth0 : mine0, v1 = odd ? mine0 : oth0, v2 = odd ? oth1 : mine1, v3 = odd ? mine1 : oth1;
+          uint32_t m = v0;
+          asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v1));
+          asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v2));
+          asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v3));
+          uint32_t n0 = v0 ^ m, n1 = v1 ^ m, n2 = v2 ^ m, nz = m;
+          asm("v_pk_min_u16 %0, %0, %1" : "+v"(n0) : "v"(one));
+          asm("v_pk_min_u16 %0, %0, %1" : "+v"(n1) : "v"(one));
+          asm("v_pk_min_u16 %0, %0, %1" : "+v"(n2) : "v"(one));
+          asm("v_pk_min_u16 %0, %0, %1" : "+v"(nz) : "v"(one));
+          const uint32_t n01 = n0 & n1, n012 = n01 & n2;
+          uint32_t c = one + n0 + n01 + n012;
+          asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(c) : "v"(nz));
+          mx[d] = m; cd[d] = c;
+        }
+        if (!odd) {
+          const int base = (((lr >> 1) * 128 + j * 16 + 4 * g) * 8) + wave * 2 + pr;       // [pooled column][channel][pooled row]
+#pragma unroll
+          for (int d = 0; d < 2; ++d) {
+            sPool[base + (2 * d) * 8] = (bf16_t)(mx[d] & 0xffffu);
+            sPool[base + (2 * d + 1) * 8] = (bf16_t)(mx[d] >> 16);
+            sCode[base + (2 * d) * 8] = (uint8_t)(cd[d] & 0xffu);
+            sCode[base + (2 * d + 1) * 8] = (uint8_t)((cd[d] >> 16) & 0xffu);
+          }
+        }
+      }
+    __syncthreads();
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+    bf16_t* out = static_cast<bf16_t*>(p.pool);
+    for (int c = tid; c < 8 * 128; c += 256) {
+      const int owl = c >> 7, ch = c & 127;
+      const int64_t gi = (((int64_t)b * W2 + (w0 >> 1) + owl) * 128 + ch) * H2 + (h0 >> 1);
+      *reinterpret_cast<uint4*>(out + gi) = *reinterpret_cast<const uint4*>(sPool + c * 8);
+      *reinterpret_cast<uint2*>(p.code + gi) = *reinterpret_cast<const uint2*>(sCode + c * 8);
+    }
+    return;
+  }
   // ---- epilogue straight from the accumulators (operands were swapped: a fragment is (16 co rows) x (16 pixel columns), so a
   // lane holds 4 consecutive output channels of ONE pixel).  bias / ReLU in fp32, then the storage dtype; bf16 lanes exchange
   // halves with the neighbouring lane group (v_permlane16_swap) so that every lane owns one aligned 16-byte chunk of a pixel's
@@ -1035,14 +1098,14 @@ template <typename K> void allow_big_lds(K kernel, size_t lds) {
   }
 }
 
-template <typename T, int NCO, int TH, int TPS, int WBUF>
+template <typename T, int NCO, int TH, int TPS, int WBUF, bool PT = false>
 int launch_igemm_t(const ConvArgs& a, hipStream_t s) {
   ConvArgs p = a;
   p.tiles_h = (p.H + TH - 1) / TH;
   p.tiles_w = (p.W + 15) / 16;
-  size_t lds = (size_t)((TH + 2) * 18 + WBUF * TPS * NCO) * (64 * sizeof(T));
-  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>, lds);
-  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
+  size_t lds = (size_t)((TH + 2) * 18 + WBUF * TPS * NCO) * (64 * sizeof(T));      // (>= the 24 KB the pooled epilogue stages)
+  allow_big_lds(conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF, PT>, lds);
+  hipLaunchKernelGGL((conv3x3_igemm_kernel<T, NCO, TH, TPS, WBUF, PT>), dim3((unsigned)(p.B * p.tiles_h * p.tiles_w)), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -1211,6 +1274,25 @@ extern "C" int asr_conv3x3_relu_pool_code(const void* x, const void* wk, const f
   a.y = static_cast<bf16_t*>(y_or_null); a.pool = static_cast<bf16_t*>(pool); a.code = code;
   a.B = B; a.H = H; a.W = W; a.relu = 1;
   return asr_conv3x3_c64_launch(a, s);
+}
+
+/* y never stored: pool (B, W/2, Cout, H/2) = the encoder layout (B, T', C F') of the 2x2/2 max-pool of ReLU(conv3x3_pad1(x; wk) + bias), and
+ * one selection byte per pooled element in the same layout (conv.7 + ReLU + MaxPool2d + view / transpose, transformer.py:50-52,74-76).
+ * ASR_EUNSUPPORTED unless bf16, Cout = 128, Cin a multiple of 64, H and W multiples of 16 (callers use asr_conv3x3_igemm +
+ * asr_maxpool_fwd_code). */
+extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H,
+                                              int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && wk && pool && code && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
+  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 16 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
+      (((uintptr_t)code) & 7) != 0 || asr_tuning("CONV_POOL", 1) == 0 || asr_tuning("IGEMM_TH", 16) != 16)
+    return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  ConvArgs p{};
+  p.x = x; p.wk = wk; p.bias = bias; p.pool = pool; p.code = code;
+  p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  return launch_igemm_t<bf16_t, 128, 16, 1, 1, true>(p, s);
 }
 
 extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, hipStream_t s) {

@@ -348,6 +348,10 @@ int asr_maxpool_bwd_code(const uint8_t* code, const void* dy, void* dx, int B, i
 /* asr_conv3x3_relu_pool that writes the pooled output and its selection codes; y_or_null = NULL: the un-pooled output is not stored */
 int asr_conv3x3_relu_pool_code(const void* x, const void* wk, const float* bias, void* y_or_null, void* pool, uint8_t* code, int B,
                                int H, int W, int Cin, int Cout, int dtype, asr_stream_t stream);
+/* conv.7 + ReLU + MaxPool2d + the (B, T', C F') view / transpose of transformer.py:50-52,74-76 from one epilogue: pool (B, W/2, Cout, H/2)
+ * and its selection bytes (same layout); the un-pooled output is never stored.  bf16, Cout = 128, H and W multiples of 16.     */
+int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H, int W,
+                                   int Cin, int Cout, int dtype, asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
  * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip; bf16 with a workspace: the LDS-DMA
  * pipelined kernel of conv_wgrad_dma.hip).                                                                      */

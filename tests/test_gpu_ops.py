@@ -776,6 +776,28 @@ def test_conv3x3_relu_pool_fused(ops, shape):
         assert torch.equal(ops.maxpool_bwd_code(code, dy, tuple(y_ref.shape)), dx_ref)
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 48, 128), (1, 16, 16, 64), (3, 80, 64, 128)])
+def test_conv3x3_relu_pool_tcf_fused(ops, cfg):
+    """conv.7 + ReLU + MaxPool2d + the (B, T', C F') transpose from the convolution's epilogue (asr_conv3x3_relu_pool_tcf_code) ==
+    the convolution followed by asr_maxpool_fwd_code in the encoder layout, bit for bit: pooled values AND selection bytes."""
+    B, H, W, Cin = cfg
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(H * 3 + W + Cin)
+    x = q(torch.randn(B, H, W, Cin, generator=g).relu(), dtype)
+    w = torch.randn(128, Cin, 3, 3, generator=g) / (3 * math.sqrt(Cin))
+    b = torch.randn(128, generator=g) / 3
+    D = dev()
+    wk = torch.empty(128, 9, Cin, device=D, dtype=dtype); wd = torch.empty(Cin, 9, 128, device=D, dtype=dtype)
+    ops.conv_pack_weight(w.to(D), wk, wd)
+    xd = x.to(D, dtype)
+    y_ref = ops.conv3x3(xd, wk, b.to(D), 128, relu=True)
+    p_ref, c_ref = ops.maxpool_fwd_code(y_ref, tcf=True)
+    pool, code = ops.conv3x3_relu_pool_tcf_code(xd, wk, b.to(D), 128)
+    assert pool.shape == p_ref.shape and torch.equal(pool, p_ref)
+    assert torch.equal(code, c_ref)
+    assert ops.conv3x3_relu_pool_tcf_code(xd[:, :H - 1].contiguous(), wk, b.to(D), 128) is None      # H not a multiple of 16: not taken
+
+
 @pytest.mark.parametrize("cfg", [(3, 97, 130, 64, 128), (2, 50, 200, 128, 64)])
 def test_conv3x3_wgrad_dma_pipeline(ops, cfg):
     """bf16 weight gradient on the LDS-DMA pipelined kernel (conv_wgrad_dma.hip) at sizes with interior AND border patches, several
