@@ -475,7 +475,7 @@ class EncInFn(Function):
         dout2 = dout.reshape(B * T, -1).contiguous()
         dz, _ = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, None, P.grad_of(gamma), P.grad_of(beta))
         dx = _linear_bwd(dz, x2, Win, bin_, need_dx=ctx.need_dx)
-        ops.flush_wgrads()                      # the transformer's backward ends here: every queued weight gradient in grouped launches
+        ops.flush_wgrads(final=True)                      # the transformer's backward ends here: every queued weight gradient in grouped launches
         P.grad_ready(*ctx.params)
         if dx is not None:
             dx = dx.view(B, T, Din).to(ctx.in_dtype)

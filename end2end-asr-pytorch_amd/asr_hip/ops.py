@@ -122,7 +122,7 @@ _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
 _debug_group = os.environ.get("ASR_DEBUG_GROUP") == "1"
 WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "32"))      # layers per grouped launch (<= 32: asr_gemm_tn_grouped); 16 / 24 / 32 measured: profiles/r03_grouped_wgrad_group_size_ab.txt
-_wgrad_side = os.environ.get("ASR_WGRAD_SIDE", "0") == "1"
+_wgrad_side = int(os.environ.get("ASR_WGRAD_SIDE", "0"))
 
 
 def defer_wgrad_now(dtype=None):
@@ -145,14 +145,15 @@ def queue_wgrad(dy, x, dw, db, N, K):
         flush_wgrads()
 
 
-def flush_wgrads():
+def flush_wgrads(final=False):
     """Contract everything queued.  ASR_WGRAD_SIDE=1: on the second stream (a branch of the captured graph), so that the grouped
     launch shares the chip with the data-gradient chain that follows it on the main stream -- the decoder's kernels there are
-    12 - 200 blocks each; the operands stay referenced until join_deferred()."""
+    12 - 200 blocks each; the operands stay referenced until join_deferred().  ASR_WGRAD_SIDE=2: only the flush at the end of the
+    transformer's backward (final: what follows on the main stream is the conv front end's backward).  Both measured slower."""
     while _wgrad_q:
         grp = _wgrad_q[:WGRAD_GROUP]
         del _wgrad_q[:WGRAD_GROUP]
-        if _wgrad_side and torch.cuda.is_current_stream_capturing():
+        if (_wgrad_side == 1 or (_wgrad_side == 2 and final)) and torch.cuda.is_current_stream_capturing():
             f = fork()
             with f:
                 gemm_tn_grouped(grp)
