@@ -324,8 +324,14 @@ class MHAFn(Function):
         O, lse, attn = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
                                     causal=cfg.get("causal", False), scale=scale, p=p_att, seed=seed_a,
                                     want_attn=cfg.get("want_attn", False), o32=O32)
-        Y = _linear_fwd(O.view(B * Tq, HD), Wo, bo)
-        out, mean, rstd = ops.add_ln_fwd(Y, q2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
+        # output projection + dropout + residual + LayerNorm (+ row mask) as ONE launch where the library has it (bf16, d_model 512)
+        fused_ln = ops.gemm_nt_add_ln(O.view(B * Tq, HD), P.linear_weight(Wo), bo.data if bo is not None else None, q2, gamma.data,
+                                      beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
+        if fused_ln is not None:
+            out, Y, mean, rstd = fused_ln
+        else:
+            Y = _linear_fwd(O.view(B * Tq, HD), Wo, bo)
+            out, mean, rstd = ops.add_ln_fwd(Y, q2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
         ctx.cfg, ctx.self_attn, ctx.fused, ctx.projected = cfg, self_attn, fused, projected
         ctx.seeds = (seed_a, seed_o)
         ctx.scale = scale
