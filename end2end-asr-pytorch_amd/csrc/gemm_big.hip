@@ -284,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void gemm_big_nt_ln512_kernel(BigLnArgs p) 
     for (int j = 0; j < FN; ++j)
       rr[i][j] = R ? *reinterpret_cast<const uint2*>(R + (int64_t)rc * N + wave * 64 + j * 16 + g * 4) : make_uint2(0u, 0u);
   }
-  float zs[FM][FN][4], rs_sum[FM];
+  float zs[FM][FN][4];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int row = m0 + i * 16 + lr;
@@ -309,7 +309,6 @@ __global__ __launch_bounds__(512, 2) void gemm_big_nt_ln512_kernel(BigLnArgs p) 
     }
     s += __shfl_xor(s, 16, 64);
     s += __shfl_xor(s, 32, 64);
-    rs_sum[i] = s;
     if (g == 0) s_part[wave * 64 + i * 16 + lr] = s;
   }
   __syncthreads();
