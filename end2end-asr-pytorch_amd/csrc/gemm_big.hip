@@ -555,7 +555,9 @@ bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream) {
       !aligned16(p.C) || (p.mask && !aligned16(p.mask)) || p.lda < p.K || p.ldb < p.N)
     return false;
   const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
-  if (mode == 1 && t128 < (p.K >= 2048 ? 150 : 48)) return false;
+  // (profiles/r03_gemm_big_nn_shapes.txt: below ~150 blocks the four-wave 64 x 64 kernel fills the chip better -- 3200 x 512 over K = 1536:
+  // 13.8 vs 19.0 us)
+  if (mode == 1 && t128 < 150) return false;
   const int ns = (int)asr_tuning("GEMM_BIG_NS", (t128 > 256 || p.K < 2048) ? 2 : 4);
   if (ns == 2) launch_nn<2>(p, stream); else if (ns == 4) launch_nn<4>(p, stream); else launch_nn<3>(p, stream);
   return hipGetLastError() == hipSuccess;
