@@ -323,165 +323,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------- forward, software pipelined
-// The same work split, but the wave's phases overlap: S(t+1) = K(t+1) Q^T is ISSUED before the softmax of S(t), and the two are
-// interleaved instruction by instruction (sched_group_barrier: one MFMA, then a few vector instructions) -- the matrix pipe runs
-// under the softmax's vector work of the SAME wave instead of waiting for another wave to have MFMAs ready.  Costs the registers of
-// a second score tile.  K tiles are prefetched two iterations ahead (K(t+2) overwrites K(t), consumed one iteration ago), V one.
-template <int NQ, bool DROP>
-__global__ __launch_bounds__(256) void attn_fwd_pipe_bf16_d64_kernel(AttnArgs p) {
-  constexpr int FQW = 64 * NQ;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];      // [K0 | K1 | V0 | V1]
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nqb = (p.Tq + FQW - 1) / FQW;
-  const int vid = xcd_linear_id();
-  const int bh = vid / nqb, qb = vid - bh * nqb;
-  const int b = bh / p.H, h = bh - b * p.H;
-  const int qw = qb * FQW + wave * 16 * NQ;
-  const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
-  const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
-  const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
-  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
-  const float c2 = p.scale * LOG2E;
-
-  uint4 qf[NQ][2];
-  uint32_t rkey[NQ];
-#pragma unroll
-  for (int qi = 0; qi < NQ; ++qi) {
-#pragma unroll
-    for (int ds = 0; ds < 2; ++ds) qf[qi][ds] = load_row16(Qb, p.q_st, qw + qi * 16 + lr, p.Tq, ds * 32 + g * 8);
-    rkey[qi] = drop_row_key(seed, drop_row(p, b, h, qw + qi * 16 + lr));
-  }
-  f32x4_t o[NQ][4];
-  float m[NQ], l[NQ];
-#pragma unroll
-  for (int qi = 0; qi < NQ; ++qi) {
-    m[qi] = -INFINITY;
-    l[qi] = 0.f;
-#pragma unroll
-    for (int df = 0; df < 4; ++df) o[qi][df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  const int kend = key_end(p, b);
-  int kstop = kend;
-  if (p.causal) kstop = min(kend, qb * FQW + FQW);
-  const int ntile = (kstop + 63) >> 6;
-  unsigned char* const sKb = smem;
-  unsigned char* const sVb = smem + 2 * TILE;
-
-  const unsigned voK[2] = {tile_voff(p.k_st, tid, 0), tile_voff(p.k_st, tid, 1)};
-  const unsigned voV[2] = {tile_voff(p.v_st, tid, 0), tile_voff(p.v_st, tid, 1)};
-  if (ntile > 0) {
-    stage_tile_h(sKb, Kb, p.k_st, 0, p.Tk, voK, tid, wave);
-    stage_tile_h(sVb, Vb, p.v_st, 0, p.Tk, voV, tid, wave);
-    if (ntile > 1) stage_tile_h(sKb + TILE, Kb, p.k_st, 64, p.Tk, voK, tid, wave);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  auto qk = [&](f32x4_t (*s)[4], const unsigned char* sK) __attribute__((always_inline)) {
-#pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-#pragma unroll
-      for (int qi = 0; qi < NQ; ++qi) s[qi][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ds = 0; ds < 2; ++ds) {
-        const uint4 a = frag_rows(sK, kf * 16 + lr, ds, g);
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) mma(s[qi][kf], a, qf[qi][ds]);
-      }
-    }
-  };
-  f32x4_t s[NQ][4], sn[NQ][4];
-  if (ntile > 0) qk(s, sKb);
-  for (int t = 0; t < ntile; ++t) {
-    const int k0 = t << 6;
-    const unsigned char* sV = sVb + (t & 1) * TILE;
-    const bool need_mask = (k0 + 64 > kend) || p.key_pad != nullptr || (p.causal && k0 + 63 > qw);
-    if (need_mask) mask_scores<4, NQ>(p, s, b, k0, g, qw + lr, kend);
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 2 < ntile) stage_tile_h(sKb + (t & 1) * TILE, Kb, p.k_st, k0 + 128, p.Tk, voK, tid, wave);
-    if (t + 1 < ntile) stage_tile_h(sVb + ((t + 1) & 1) * TILE, Vb, p.v_st, k0 + 64, p.Tk, voV, tid, wave);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S(t+1) (matrix pipe; for the last tile the operands are stale and the result is dropped) under the softmax of S(t)
-    qk(sn, sKb + ((t + 1) & 1) * TILE);
-    uint4 pb[NQ][2];
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi) {
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qi][kf][r]);
-      mx = group_max4(mx);
-      const float m_new = fmaxf(m[qi], mx);
-      const float m_safe = m_new == -INFINITY ? 0.f : m_new;
-      const float alpha = __builtin_amdgcn_exp2f((m[qi] - m_safe) * c2);
-      const float mc = m_safe * c2;
-      float psum = 0.f;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = __builtin_amdgcn_exp2f(s[qi][kf][r] * c2 - mc);
-          psum += pv;
-          s[qi][kf][r] = pv;
-        }
-      if (DROP) {
-#pragma unroll
-        for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-          for (int pr = 0; pr < 2; ++pr) {
-            const uint32_t y = drop_pair_bits(rkey[qi], (uint32_t)(k0 + kf * 16 + g * 4 + pr * 2) >> 1);
-            if ((y & 0xffffu) < p.thr) s[qi][kf][2 * pr] = 0.f;
-            if ((y >> 16) < p.thr) s[qi][kf][2 * pr + 1] = 0.f;
-          }
-      }
-      psum = group_sum4(psum);
-      l[qi] = l[qi] * alpha + psum;
-      m[qi] = m_new;
-#pragma unroll
-      for (int df = 0; df < 4; ++df) o[qi][df] *= alpha;
-      pb[qi][0] = pack_p(s[qi], 0);
-      pb[qi][1] = pack_p(s[qi], 1);
-    }
-    // one MFMA of S(t+1), then a share of the softmax's vector instructions, 8 NQ times
-#pragma unroll
-    for (int i = 0; i < 8 * NQ; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, DROP ? 16 : 10, 0);
-    }
-    // ---- O^T[d][q] += V^T . P^T
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms)
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        const uint4 vt = frag_cols(sV, df * 16, ms, lr, g);
-#pragma unroll
-        for (int qi = 0; qi < NQ; ++qi) mma(o[qi][df], vt, pb[qi][ms]);
-      }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#pragma unroll
-    for (int qi = 0; qi < NQ; ++qi)
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf) s[qi][kf] = sn[qi][kf];
-  }
-
-#pragma unroll
-  for (int qi = 0; qi < NQ; ++qi) {
-    const int q = qw + qi * 16 + lr;
-    if (q >= p.Tq) continue;
-    const float inv_l = l[qi] > 0.f ? p.inv_keep / l[qi] : 0.f;
-    if (g == 0) p.lse[((int64_t)b * p.H + h) * p.Tq + q] = l[qi] > 0.f ? m[qi] * p.scale + logf(l[qi]) : INFINITY;
-    bf16_t* Ob = static_cast<bf16_t*>(p.Out) + (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD;
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      const f32x4_t v = o[qi][df] * inv_l;
-      *reinterpret_cast<uint2*>(Ob + df * 16 + g * 4) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
-      if (p.Out32) *reinterpret_cast<f32x4_t*>(p.Out32 + (int64_t)b * p.o_sb + (int64_t)q * p.o_st + (int64_t)h * HD + df * 16 + g * 4) = v;
-    }
-  }
-}
+// (A software-pipelined form of the forward -- S(t+1) issued before the softmax of S(t), interleaved instruction by instruction -- was
+// measured slower at every shape in round 2, profiles/r02_ab_attn_pipe.txt, and removed in round 3.)
 
 // ================================================================================================ backward: dQ
 // Same work split as the forward (wave = 32 queries, 64-key K / V tiles double buffered in LDS):
@@ -863,19 +706,7 @@ int attn_fast_fwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
     if (p.thr) attn_fwd_bf16_d64_kernel<1, true><<<grid, dim3(256), 0, s>>>(p);
     else attn_fwd_bf16_d64_kernel<1, false><<<grid, dim3(256), 0, s>>>(p);
   } else {
-    const int pipe = (int)asr_tuning("ATTN_PIPE", 0);
-    if (pipe == 1) {
-      const dim3 grid1((unsigned)(((p.Tq + 63) / 64) * p.B * p.H));
-      if (p.thr) attn_fwd_pipe_bf16_d64_kernel<1, true><<<grid1, dim3(256), 0, s>>>(p);
-      else attn_fwd_pipe_bf16_d64_kernel<1, false><<<grid1, dim3(256), 0, s>>>(p);
-      ASR_LAUNCH_CHECK();
-      return ASR_OK;
-    }
     const dim3 grid((unsigned)(((p.Tq + FQ - 1) / FQ) * p.B * p.H));
-    if (pipe == 2) {
-      if (p.thr) attn_fwd_pipe_bf16_d64_kernel<2, true><<<grid, dim3(256), 0, s>>>(p);
-      else attn_fwd_pipe_bf16_d64_kernel<2, false><<<grid, dim3(256), 0, s>>>(p);
-    } else
     if (p.thr) attn_fwd_bf16_d64_kernel<2, true><<<grid, dim3(256), 0, s>>>(p);
     else attn_fwd_bf16_d64_kernel<2, false><<<grid, dim3(256), 0, s>>>(p);
   }

@@ -118,14 +118,15 @@ def test_fp8_gemm_is_exact_on_its_quantised_operands(shape):
     full = A.double() @ B.double().t() + bias.double()
     rel = float((out.double().cpu() - full).norm() / full.norm())
     print("fp8 gemm %s: rel L2 vs the unquantised product %.3e" % (shape, rel))
-    assert rel <= 4e-2, rel
+    assert rel <= 3.2e-2, rel            # measured 2.5e-2 .. 2.7e-2 on the five shapes (e4m3: 3 mantissa bits on both operands)
     relu = ops.gemm_nt_fp8(qa, sa, qb, sb, bias=bias.cuda(), relu=True, out_dtype=torch.bfloat16, K=qa.shape[1])
     assert (relu.float().cpu() - exact.clamp_min(0).float()).abs().max().item() <= 1.6e-2 * exact.abs().max().item()
 
 
 def test_lowrank_fp8_forward_close_to_bf16():
     """--precision fp8: the r-rank projections' forward GEMMs on the fp8 MFMA.  Stated tolerance against the bf16 run of the
-    same model: logits within 0.15 * max|logit| and loss within 5e-2 (e4m3 has 3 mantissa bits; ~20 chained projections); the
+    same model: logits within 0.10 * max|logit| and loss within 3e-2 (measured 0.075 and 1.5e-2; e4m3 has 3 mantissa bits, ~20
+    chained projections; the parity of this model family is unpinned -- there is no reference code for it); the
     backward pass is the bf16 straight-through one and must stay finite."""
     from utils import constant
     from utils.functions import init_optimizer
@@ -149,7 +150,7 @@ def test_lowrank_fp8_forward_close_to_bf16():
     d = (outs["fp8"][0] - outs["bf16"][0]).abs().max().item()
     print("fp8 vs bf16 low-rank model: max |dlogit| %.3e (max |logit| %.2f), loss %.4f vs %.4f, |grad| %.3e vs %.3e"
           % (d, amax, outs["fp8"][1], outs["bf16"][1], outs["fp8"][2], outs["bf16"][2]))
-    assert d > 0 and d <= 0.15 * amax and abs(outs["fp8"][1] - outs["bf16"][1]) < 5e-2
+    assert d > 0 and d <= 0.10 * amax and abs(outs["fp8"][1] - outs["bf16"][1]) < 3e-2
     assert np.isfinite(outs["fp8"][2]) and abs(outs["fp8"][2] - outs["bf16"][2]) < 0.3 * outs["bf16"][2]
 
 
