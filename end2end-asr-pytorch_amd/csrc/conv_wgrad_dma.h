@@ -8,6 +8,7 @@ struct WgdArgs {
   float* db;            // (Cout) accumulated with atomics, or null
   float* ws;            // per-workgroup partial dW blocks [blocks_y][wgx][9][64 co][64 ci]
   int B, H, W, Cin, Cout, tiles_h, tiles_w, npatch, patches_per_wg, nci;
+  int wgx, blocks_y, xcd_order;   // filled by the launcher: the grid is ONE dimension of wgx * blocks_y workgroups
 };
 
 int asr_conv3x3_wgrad_dma_launch(const WgdArgs& p, unsigned wgx, unsigned blocks_y, hipStream_t s);

@@ -55,10 +55,21 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
   constexpr int RX = (NXC + 255) / 256, RD = NDC / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
-  const int co0 = (blockIdx.y / p.nci) * 64, ci0 = (blockIdx.y % p.nci) * 64;
+  // The (co block, ci block) workgroups of one patch range read the same X patches / dY tiles: they are made NEIGHBOURS in an id that
+  // is dealt so that consecutive ids run on one XCD (blockIdx round-robins over the 8 XCDs, each with its own L2) -- the shared slice
+  // comes from HBM once per XCD instead of once per sibling (a 2-D grid put the siblings wgx ids apart: on whatever XCDs).
+  int vid = (int)blockIdx.x;
+  if (p.xcd_order) {
+    const int nwg = (int)gridDim.x, xcd = vid & 7, qn = nwg >> 3, rn = nwg & 7;
+    vid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (vid >> 3);
+  }
+  // (wave-uniform by construction; readfirstlane tells the compiler so: the DMA below takes its base pointers in scalar registers)
+  const int by = __builtin_amdgcn_readfirstlane(p.xcd_order ? vid % p.blocks_y : vid / p.wgx);
+  const int bx = __builtin_amdgcn_readfirstlane(p.xcd_order ? vid / p.blocks_y : vid % p.wgx);
+  const int co0 = (by / p.nci) * 64, ci0 = (by % p.nci) * 64;
   const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x) + ci0 * 2;
   const unsigned char* DY = reinterpret_cast<const unsigned char*>(p.dy) + co0 * 2;
-  const int p_beg = blockIdx.x * p.patches_per_wg, p_end = min(p.npatch, p_beg + p.patches_per_wg);
+  const int p_beg = bx * p.patches_per_wg, p_end = min(p.npatch, p_beg + p.patches_per_wg);
   const int xrow = p.Cin * 2, drow = p.Cout * 2;       // bytes per pixel
 
   // ---- per-thread DMA source offsets relative to the patch's first pixel
@@ -181,8 +192,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
     }
   }
 
-  // ---- partial dW block -> workspace [blockIdx.y][blockIdx.x][tap][co][ci]
-  float* part = p.ws + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (9 * 64 * 64);
+  // ---- partial dW block -> workspace [block of dW][patch range][tap][co][ci]
+  float* part = p.ws + ((int64_t)by * p.wgx + bx) * (9 * 64 * 64);
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -211,7 +222,9 @@ int asr_conv3x3_wgrad_dma_launch(const WgdArgs& p, unsigned wgx, unsigned blocks
       return ASR_ELAUNCH;
     granted = true;
   }
-  hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(wgx, blocks_y), dim3(256), lds, s, p);
+  WgdArgs q = p;
+  q.wgx = (int)wgx; q.blocks_y = (int)blocks_y; q.xcd_order = asr_tuning("WGRAD_XCD", 1) != 0;
+  hipLaunchKernelGGL(conv3x3_wgrad_dma_kernel, dim3(wgx * blocks_y), dim3(256), lds, s, q);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
