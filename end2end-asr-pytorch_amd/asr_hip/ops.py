@@ -123,6 +123,11 @@ _wgrad_q = []
 _debug_group = os.environ.get("ASR_DEBUG_GROUP") == "1"
 WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "32"))      # layers per grouped launch (<= 32: asr_gemm_tn_grouped); 16 / 24 / 32 measured: profiles/r03_grouped_wgrad_group_size_ab.txt
 _wgrad_side = int(os.environ.get("ASR_WGRAD_SIDE", "0"))
+# a group is also closed once it holds this many 64-row stages of 256 x 256 blocks (about 150 per workgroup of the scheduled kernel):
+# with 12 720 rows per layer (configs[3]) groups of 16 layers measure 0.3 - 0.5 ms per step faster than groups of 32, with 6 400 rows
+# groups of 32 are the faster ones -- both are ~38 000 stages.  profiles/r03_grouped_wgrad_group_size_ab.txt
+WGRAD_STAGES = int(os.environ.get("ASR_WGRAD_STAGES", "38000"))
+_wgrad_stages = [0]
 
 
 def defer_wgrad_now(dtype=None):
@@ -141,7 +146,8 @@ def queue_wgrad(dy, x, dw, db, N, K):
     queue: the caller must not write to them afterwards."""
     assert gemm_tn_supported(dy, x) and dw.dtype == torch.float32 and dw.stride(1) == 1
     _wgrad_q.append((dy, x, dw, db, int(N), int(K)))
-    if len(_wgrad_q) >= WGRAD_GROUP:
+    _wgrad_stages[0] += -(-int(N) // 256) * -(-int(K) // 256) * -(-dy.shape[0] // 64)
+    if len(_wgrad_q) >= WGRAD_GROUP or (WGRAD_STAGES and _wgrad_stages[0] >= WGRAD_STAGES):
         flush_wgrads()
 
 
@@ -150,6 +156,7 @@ def flush_wgrads(final=False):
     launch shares the chip with the data-gradient chain that follows it on the main stream -- the decoder's kernels there are
     12 - 200 blocks each; the operands stay referenced until join_deferred().  ASR_WGRAD_SIDE=2: only the flush at the end of the
     transformer's backward (final: what follows on the main stream is the conv front end's backward).  Both measured slower."""
+    _wgrad_stages[0] = 0
     while _wgrad_q:
         grp = _wgrad_q[:WGRAD_GROUP]
         del _wgrad_q[:WGRAD_GROUP]
