@@ -624,6 +624,7 @@ def _conv_gemm_fwd(x_nhwc, g, w, b, tag):
 
 
 _emb_window = os.environ.get("ASR_EMB_WINDOW", "1") != "0"
+_emb_shift_wgrad = os.environ.get("ASR_EMB_SHIFT_WGRAD", "1") != "0"
 
 
 def _window_ok(g):
@@ -691,15 +692,27 @@ def _conv_window_bwd(dy, A, w, b_grad, g, tag, need_dx):
     D = ops.workspace(tag + "_d", (lead + R + tail, Cout), cd, dev)
     D[lead:lead + R].view(B * OH, Wg, Cout)[:, :OW].copy_(dy[:M].view(B * OH, OW, dy.shape[1])[:, :, :Cout])
     K = KW * blk
-    dw = torch.zeros((Cout, K), device=dev, dtype=torch.float32)
-    ops.gemm_tn(D[lead:lead + R], A, dw, colsum_acc=b_grad, N=Cout, K=K)
-    dw = dw.view(Cout, KW, blk)[:, :, :KH * C].reshape(Cout, KW, KH, C).permute(0, 3, 2, 1)      # (co, kx, ky, ci) -> (co, ci, ky, kx)
+    Ad = torch.as_strided(D, (R, Kdp), (Cout, 1))
+    if _emb_shift_wgrad and SW == 1 and PW == 0 and blk >= 256:
+        # unit time stride: X2 row r' meets dy row r' - kx under tap kx, i.e. G[(ky, c), (j, co)] = sum_r' X2[r', (ky, c)] * Ad[r', (j, co)]
+        # with j = KW - 1 - kx -- the SAME shifted view of dy the data gradient contracts.  One contraction over the rows with a
+        # (blk x KW*Cout) result (672 x 352: six 256 x 256 blocks on the equal-piece kernel) instead of a 32-column one against the
+        # KW-fold window view: X2 is read once, not KW times.  (Rows r' >= R of X2 only meet the zero rows behind the last group.)
+        X2 = torch.as_strided(A, (R, blk), (blk, 1))
+        G = torch.zeros((blk, Kd), device=dev, dtype=torch.float32)
+        ops.gemm_tn_grouped([(X2, Ad, G, None, blk, Kd)])
+        if b_grad is not None:
+            ops.colsum_acc(D[lead:lead + R], b_grad)
+        dw = G[:KH * C].view(KH, C, KW, Cout).flip(2).permute(3, 1, 0, 2)                        # [(ky, ci), (j, co)] -> (co, ci, ky, kx)
+    else:
+        dw = torch.zeros((Cout, K), device=dev, dtype=torch.float32)
+        ops.gemm_tn(D[lead:lead + R], A, dw, colsum_acc=b_grad, N=Cout, K=K)
+        dw = dw.view(Cout, KW, blk)[:, :, :KH * C].reshape(Cout, KW, KH, C).permute(0, 3, 2, 1)  # (co, kx, ky, ci) -> (co, ci, ky, kx)
     if not need_dx:
         return dw, None
     assert SW == 1 and PW == 0
     Wd = ops.workspace(tag + "_wd", ((blk + 63) // 64 * 64, Kdp), cd, dev)
     Wd[:KH * C, :Kd].copy_(w.data.flip(3).permute(2, 1, 3, 0).reshape(KH * C, Kd))     # [(ky, ci), (j = KW-1-kx, co)]
-    Ad = torch.as_strided(D, (R, Kdp), (Cout, 1))
     dX2 = ops.gemm_nt(Ad, Wd[:blk], out=ops.workspace(tag + "_dx2", (R, blk), cd, dev))
     return dw, ops.col2im(dX2, g1)
 
