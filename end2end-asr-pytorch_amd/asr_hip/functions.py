@@ -625,6 +625,7 @@ def _conv_gemm_fwd(x_nhwc, g, w, b, tag):
 
 _emb_window = os.environ.get("ASR_EMB_WINDOW", "1") != "0"
 _emb_shift_wgrad = os.environ.get("ASR_EMB_SHIFT_WGRAD", "1") != "0"
+_emb_shift_fwd = os.environ.get("ASR_EMB_SHIFT_FWD", "1") != "0"
 
 
 def _window_ok(g):
@@ -640,7 +641,9 @@ def _window_geom(g):
     Wg: GEMM rows per (b, oh) group, R: GEMM rows)"""
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
     g1 = ops.conv_geom(B, H, W, C, KH, 1, SH, 1, 0, PW)              # OH x (W + 2 PW) positions, one (padded) time step per row
-    blk = (KH * C + 7) // 8 * 8
+    # a wide block (32 channels x 21 rows = 672) is padded to whole 64-element steps (704): X2 is then the A operand of the eight-wave
+    # GEMM of the unit-stride form below; the one-channel block of the first convolution (41 -> 48) stays as tight as 16 bytes allow
+    blk = (KH * C + 63) // 64 * 64 if KH * C >= 256 else (KH * C + 7) // 8 * 8
     Wg = g1[11] // SW
     return g1, blk, Wg, B * OH * Wg
 
@@ -662,13 +665,23 @@ def _conv_window_fwd(x_nhwc, g, w, b, tag):
     slack = (Kp + blk - 1) // blk + SW                               # rows the last window reads past the last group
     X2 = ops.im2col(x_nhwc, g1, ops.workspace(tag + "_x2", (rows1 + slack, blk), cd, dev))
     A = torch.as_strided(X2, (R, Kp), (SW * blk, 1))
-    Ws = ops.workspace(tag + "_w", (64, Kp), cd, dev)                # rows >= Cout, columns >= K and the ky padding stay zero
-    Ws[:Cout, :K].view(Cout, KW, blk)[:, :, :KH * C].copy_(w.data.permute(0, 3, 2, 1).reshape(Cout, KW, KH * C))   # (co, kx, ky, ci)
     bias = ops.workspace(tag + "_b", (64,), torch.float32, dev)
     bias[:Cout].copy_(b.data)
     Mp = (M + 127) // 128 * 128
-    yf = ops.gemm_nt(A, Ws, bias=bias, out=ops.workspace(tag + "_yf", (R, 64), torch.float32, dev))
     y = ops.workspace(tag + "_y", (Mp, 64), torch.float32, dev)
+    if _emb_shift_fwd and SW == 1 and PW == 0 and blk % 64 == 0 and Cout % 4 == 0:
+        # unit time stride: ONE dense product over the single-step patches, Z[r', (kx, co)] = X2[r'] . W[co, kx] (N = KW * Cout = 352
+        # useful columns instead of 32 padded to 64, X2 read once instead of through the KW-fold window view), then the taps are
+        # folded along time into the compact rows of y (asr_window_sum: every element of Z read once, bias added there)
+        Nz = ops._pad8(KW * Cout)
+        Wz = ops.workspace(tag + "_wz", ((Nz + 127) // 128 * 128, blk), cd, dev)          # rows >= KW * Cout and the ky padding stay zero
+        Wz[:KW * Cout, :KH * C].copy_(w.data.permute(3, 0, 2, 1).reshape(KW * Cout, KH * C))       # [(kx, co), (ky, ci)]
+        Z = ops.gemm_nt(X2[:R + KW - 1], Wz[:Nz], out=ops.workspace(tag + "_z", (R + KW - 1, Nz), torch.float32, dev))
+        ops.window_sum(Z, y, bias, B * OH, Wg, OW, KW, Cout)
+        return X2, A, y, M
+    Ws = ops.workspace(tag + "_w", (64, Kp), cd, dev)                # rows >= Cout, columns >= K and the ky padding stay zero
+    Ws[:Cout, :K].view(Cout, KW, blk)[:, :, :KH * C].copy_(w.data.permute(0, 3, 2, 1).reshape(Cout, KW, KH * C))   # (co, kx, ky, ci)
+    yf = ops.gemm_nt(A, Ws, bias=bias, out=ops.workspace(tag + "_yf", (R, 64), torch.float32, dev))
     y[:M].view(B * OH, OW, 64).copy_(yf.view(B * OH, Wg, 64)[:, :OW])
     return X2, A, y, M
 

@@ -107,6 +107,7 @@ _SIGS = {
     "asr_spect_finish": (_I, [_P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_im2col": (_I, [_P, _P] + [_I] * 12 + [_L, _L, _I, _I, _P]),
     "asr_col2im": (_I, [_P, _P] + [_I] * 12 + [_L, _I, _P]),
+    "asr_window_sum": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "asr_bn_stats": (_I, [_P, _L, _L, _I, _P, _P, _P]),
     "asr_bn_stats_blocks": (_L, [_L]),
     "asr_bn_stats_partial": (_I, [_P, _L, _L, _I, _P, _P, _P, _P]),

@@ -1070,6 +1070,16 @@ def col2im(dcol, g, dtype=None):
     return dx
 
 
+def window_sum(Z, y, bias, groups, Wg, OW, KW, Cout):
+    """y[g*OW + j, co] = bias[co] + sum_kx Z[g*Wg + j + kx, kx*Cout + co] for j < OW (asr_window_sum): the per-tap partial products
+    of the unit-stride window convolution folded along time; columns >= Cout of y are zeroed."""
+    assert Z.dtype == torch.float32 and y.dtype == torch.float32 and Z.stride(1) == 1 and y.stride(1) == 1
+    assert Z.shape[0] >= groups * Wg + KW - 1 - (Wg - OW) and y.shape[0] >= groups * OW
+    L.call("asr_window_sum", L.ptr(Z), Z.stride(0), L.ptr(y), y.stride(0), L.ptr(bias) if bias is not None else None, groups, Wg, OW,
+           KW, Cout, L.stream())
+    return y
+
+
 def bn_batch_stats(y, M, C):
     """Training-mode BatchNorm statistics of the fp32 conv output y (rows, ld) over its first M rows / C columns:
     (mean, biased var), two passes (mean, then centred second moment)."""

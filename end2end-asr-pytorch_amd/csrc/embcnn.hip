@@ -327,6 +327,45 @@ extern "C" int asr_col2im(const void* dcol, void* dx, int B, int H, int W, int C
   return ASR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- window sum
+// The unit-time-stride convolution as ONE dense GEMM over the KW = 1 patches: Z[r', (kx, co)] = X2[r', :] . W[co, kx, :] for every
+// (padded) time step r' and tap kx, then y[(g, j), co] = bias[co] + sum_kx Z[g Wg + j + kx, kx Cout + co] for the OW valid steps of
+// each (b, oh) group g.  Every element of Z is read exactly once.  One thread = 4 columns of one output row; columns >= Cout of y
+// (the row pitch of the BatchNorm kernels) are written as 0.
+__global__ void __launch_bounds__(256) window_sum_kernel(const float* __restrict__ Z, int64_t ldz, float* __restrict__ y, int64_t ldy,
+                                                         const float* __restrict__ bias, int64_t M, int Wg, int OW, int KW, int Cout) {
+  const int cq = (int)(ldy / 4);
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= M * cq) return;
+  const int64_t m = gid / cq;
+  const int c0 = (int)(gid - m * cq) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c0 < Cout) {
+    const int64_t g = m / OW;
+    const int j = (int)(m - g * OW);
+    const float* z = Z + (g * Wg + j) * ldz + c0;
+    if (bias) acc = *reinterpret_cast<const float4*>(bias + c0);
+    for (int kx = 0; kx < KW; ++kx) {
+      const float4 v = *reinterpret_cast<const float4*>(z + (int64_t)kx * (ldz + Cout));
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  *reinterpret_cast<float4*>(y + m * ldy + c0) = acc;
+}
+
+extern "C" int asr_window_sum(const float* Z, int64_t ldz, float* y, int64_t ldy, const float* bias, int64_t groups, int Wg, int OW,
+                              int KW, int Cout, hipStream_t stream) {
+  ASR_CHECK_ARG(Z && y && groups >= 0 && Wg > 0 && OW > 0 && KW > 0 && Cout > 0 && OW + KW - 1 <= Wg + KW - 1);
+  ASR_CHECK_ARG(Cout % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && ldy >= Cout && ldz >= (int64_t)KW * Cout && aligned16(Z) && aligned16(y) &&
+                (!bias || aligned16(bias)));
+  if (groups == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_LAYOUT, stream);
+  const int64_t n = groups * OW * (ldy / 4);
+  window_sum_kernel<<<(unsigned)ceil_div64(n, 256), 256, 0, stream>>>(Z, ldz, y, ldy, bias, groups * OW, Wg, OW, KW, Cout);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 extern "C" int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, hipStream_t stream) {
   ASR_CHECK_ARG(y && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C);
   BnArgs a{};

@@ -386,6 +386,11 @@ int asr_im2col(const void* x, void* col, int B, int H, int W, int C, int KH, int
 /* dx (B,H,W,C) <- sum of the dcol entries that cover each input pixel (the conv data gradient; gather, no atomics)  */
 int asr_col2im(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int SH, int SW, int PH, int PW,
                int OH, int OW, int64_t ld_col, int dtype, asr_stream_t stream);
+/* The unit-time-stride big-window convolution (transformer.py:37, Conv2d(32,32,(21,11),(2,1))) after ONE dense product over the
+ * single-time-step patches, Z (groups*Wg + KW - 1, ldz >= KW*Cout) fp32 with Z[r, kx*Cout + co] = patch(r) . W[co, kx]:
+ * y[g*OW + j, co] = bias[co] + sum_kx Z[g*Wg + j + kx, kx*Cout + co], j < OW; columns Cout .. ldy-1 of y are written as 0.  */
+int asr_window_sum(const float* Z, int64_t ldz, float* y, int64_t ldy, const float* bias, int64_t groups, int Wg, int OW,
+                   int KW, int Cout, asr_stream_t stream);
 /* nn.BatchNorm2d statistics over the rows of the fp32 conv output y (M, ldy), channel = column:
  * sums[0:C] += sum(y - center), sums[C:2C] += sum((y - center)^2); center may be NULL (two-pass mean / variance).     */
 int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, asr_stream_t stream);

@@ -914,6 +914,68 @@ def test_maxpool_fwd_bwd_both_layouts(ops, dtype, shape):
         assert torch.equal(dxc.float().cpu(), want)
 
 
+def test_window_sum_folds_the_taps_along_time(ops):
+    """asr_window_sum: y[g*OW + j, co] = bias[co] + sum_kx Z[g*Wg + j + kx, kx*Cout + co]; the pad columns of y are zeroed."""
+    G, Wg, KW, Cout, ldz, ldy = 5, 23, 11, 32, 352, 64
+    OW = Wg - KW + 1
+    g = torch.Generator().manual_seed(3)
+    Z = torch.randn(G * Wg + KW - 1, ldz, generator=g)
+    bias = torch.randn(Cout, generator=g)
+    want = torch.zeros(G * OW, ldy)
+    for gi in range(G):
+        for j in range(OW):
+            acc = bias.clone()
+            for kx in range(KW):
+                acc = acc + Z[gi * Wg + j + kx, kx * Cout:(kx + 1) * Cout]
+            want[gi * OW + j, :Cout] = acc
+    D = dev()
+    y = torch.full((G * OW + 3, ldy), 7.0, device=D)
+    ops.window_sum(Z.to(D), y, bias.to(D), G, Wg, OW, KW, Cout)
+    assert torch.equal(y[:G * OW].cpu(), want)
+    assert bool((y[G * OW:] == 7.0).all())
+
+
+@pytest.mark.parametrize("shift", ["1", "0"])
+def test_unit_stride_window_convolution_against_conv2d(ops, shift, monkeypatch):
+    """The 32 -> 32, 21 x 11, stride (2, 1) convolution of emb_cnn (reference transformer.py:37) in its bf16 forms -- the dense product
+    over single-step patches + window sum / the (672 x 352) weight-gradient contraction (shift = 1), and the window-view GEMMs
+    (shift = 0) -- against F.conv2d in fp32 on the same bf16-rounded operands: output, weight, bias and data gradient."""
+    from asr_hip import functions as Fn
+    monkeypatch.setattr(Fn, "_emb_shift_fwd", shift == "1")
+    monkeypatch.setattr(Fn, "_emb_shift_wgrad", shift == "1")
+    B, H, W, C, Cout, KH, KW = 2, 61, 37, 32, 32, 21, 11
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, C, KH, KW, generator=g) * (C * KH * KW) ** -0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride=(2, 1))
+    OH, OW = ref.shape[2], ref.shape[3]
+    dy = torch.randn(B, Cout, OH, OW, generator=g).bfloat16().float()
+    ref.backward(dy)
+    D = dev()
+    prev = ops.compute_dtype()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        geo = ops.conv_geom(B, H, W, C, KH, KW, 2, 1, 0, 0)
+        assert Fn._window_ok(geo)
+        wd, bd = torch.nn.Parameter(w.to(D)), torch.nn.Parameter(b.to(D))
+        X2, A, y, M = Fn._conv_window_fwd(nhwc(x).to(D, torch.bfloat16).contiguous(), geo, wd, bd, "t_win")
+        got = y[:M, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
+        assert (got - ref.detach()).abs().max().item() < 2e-3 * max(1.0, ref.detach().abs().max().item())
+        assert bool((y[:M, Cout:] == 0).all())
+        dyd = torch.zeros((y.shape[0], 64), device=D, dtype=torch.bfloat16)
+        dyd[:M, :Cout] = nhwc(dy).reshape(M, Cout).to(D, torch.bfloat16)
+        bg = torch.zeros(Cout, device=D)
+        dw, dx = Fn._conv_window_bwd(dyd, A, wd, bg, geo, "t_win", True)
+        assert (dw.cpu() - wr.grad).abs().max().item() < 3e-3 * wr.grad.abs().max().item()
+        assert (bg.cpu() - br.grad).abs().max().item() < 1e-3 * br.grad.abs().max().item()
+        dxr = nhwc(xr.grad)
+        assert (dx.float().cpu() - dxr).abs().max().item() < 1.2e-2 * dxr.abs().max().item()     # dx is stored in bf16
+    finally:
+        ops.set_compute_dtype(prev)
+
+
 def test_ops_refuse_host_tensors(ops):
     from asr_hip.lib import AsrHipError
     with pytest.raises(AsrHipError):
