@@ -706,17 +706,22 @@ def _conv_window_bwd(dy, A, w, b_grad, g, tag, need_dx):
     D[lead:lead + R].view(B * OH, Wg, Cout)[:, :OW].copy_(dy[:M].view(B * OH, OW, dy.shape[1])[:, :, :Cout])
     K = KW * blk
     Ad = torch.as_strided(D, (R, Kdp), (Cout, 1))
-    if _emb_shift_wgrad and SW == 1 and PW == 0 and blk >= 256:
-        # unit time stride: X2 row r' meets dy row r' - kx under tap kx, i.e. G[(ky, c), (j, co)] = sum_r' X2[r', (ky, c)] * Ad[r', (j, co)]
-        # with j = KW - 1 - kx -- the SAME shifted view of dy the data gradient contracts.  One contraction over the rows with a
-        # (blk x KW*Cout) result (672 x 352: six 256 x 256 blocks on the equal-piece kernel) instead of a 32-column one against the
-        # KW-fold window view: X2 is read once, not KW times.  (Rows r' >= R of X2 only meet the zero rows behind the last group.)
-        X2 = torch.as_strided(A, (R, blk), (blk, 1))
-        G = torch.zeros((blk, Kd), device=dev, dtype=torch.float32)
-        ops.gemm_tn_grouped([(X2, Ad, G, None, blk, Kd)])
+    Q = (KW + SW - 1) // SW
+    if _emb_shift_wgrad and Wg - OW >= Q - 1 and lead >= Q - 1:
+        # Tap kx = SW q + p of output step r reads X2 row SW r + kx = row p of the SW-row packet r + q, i.e. packet r'' meets dy row
+        # r'' - q under (q, p):   G[(p, ky, c), (j, co)] = sum_r'' Xp[r'', (p, ky, c)] * dy[r'' - (Q - 1) + j, co],   j = Q - 1 - q,
+        # with Xp = X2 seen as packets of SW rows and the second operand the SAME kind of shifted view of D the data gradient
+        # contracts (the zero rows behind each group and in front of the first absorb the shifts).  One contraction over the rows with
+        # an (SW blk) x (Q Cout) result -- 704 x 352 for the 32 -> 32 convolution, 96 x 192 for the 1 -> 32 one -- on the equal-piece
+        # 256 x 256 kernel, X2 read once; the 32-column contraction against the KW-fold window view it replaces ran at 30 - 100 TF/s.
+        Xp = torch.as_strided(A, (R, SW * blk), (SW * blk, 1))
+        AdQ = torch.as_strided(D, (R, Q * Cout), (Cout, 1), (lead - (Q - 1)) * Cout)
+        G = torch.zeros((SW * blk, Q * Cout), device=dev, dtype=torch.float32)
+        ops.gemm_tn_grouped([(Xp, AdQ, G, None, SW * blk, Q * Cout)])
         if b_grad is not None:
             ops.colsum_acc(D[lead:lead + R], b_grad)
-        dw = G[:KH * C].view(KH, C, KW, Cout).flip(2).permute(3, 1, 0, 2)                        # [(ky, ci), (j, co)] -> (co, ci, ky, kx)
+        T = G.view(SW, blk, Q, Cout)[:, :KH * C].flip(2).reshape(SW, KH, C, Q, Cout)             # (p, ky, ci, q, co)
+        dw = T.permute(4, 2, 1, 3, 0).reshape(Cout, C, KH, Q * SW)[..., :KW]                     # (co, ci, ky, kx = SW q + p)
     else:
         dw = torch.zeros((Cout, K), device=dev, dtype=torch.float32)
         ops.gemm_tn(D[lead:lead + R], A, dw, colsum_acc=b_grad, N=Cout, K=K)

@@ -936,20 +936,23 @@ def test_window_sum_folds_the_taps_along_time(ops):
 
 
 @pytest.mark.parametrize("shift", ["1", "0"])
-def test_unit_stride_window_convolution_against_conv2d(ops, shift, monkeypatch):
-    """The 32 -> 32, 21 x 11, stride (2, 1) convolution of emb_cnn (reference transformer.py:37) in its bf16 forms -- the dense product
-    over single-step patches + window sum / the (672 x 352) weight-gradient contraction (shift = 1), and the window-view GEMMs
-    (shift = 0) -- against F.conv2d in fp32 on the same bf16-rounded operands: output, weight, bias and data gradient."""
+@pytest.mark.parametrize("cfg", [(2, 61, 37, 32, 21, 11, 2, 1, 0), (2, 161, 50, 1, 41, 11, 2, 2, 10)])
+def test_window_convolutions_against_conv2d(ops, shift, cfg, monkeypatch):
+    """The two convolutions of emb_cnn (reference transformer.py:33-40: 1 -> 32, 41 x 11, stride (2,2), time padding 10, and 32 -> 32,
+    21 x 11, stride (2,1)) in their bf16 forms -- shift = 1: dense product over single-step patches + window sum (unit stride) and the
+    packet-of-rows weight-gradient contraction; shift = 0: the window-view GEMMs -- against F.conv2d in fp32 on the same bf16-rounded
+    operands: output, weight and bias gradient, and (unit stride) the data gradient."""
     from asr_hip import functions as Fn
     monkeypatch.setattr(Fn, "_emb_shift_fwd", shift == "1")
     monkeypatch.setattr(Fn, "_emb_shift_wgrad", shift == "1")
-    B, H, W, C, Cout, KH, KW = 2, 61, 37, 32, 32, 21, 11
+    B, H, W, C, KH, KW, SH, SW, PW = cfg
+    Cout = 32
     g = torch.Generator().manual_seed(11)
     x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
     w = (torch.randn(Cout, C, KH, KW, generator=g) * (C * KH * KW) ** -0.5).bfloat16().float()
     b = torch.randn(Cout, generator=g)
     xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
-    ref = F.conv2d(xr, wr, br, stride=(2, 1))
+    ref = F.conv2d(xr, wr, br, stride=(SH, SW), padding=(0, PW))
     OH, OW = ref.shape[2], ref.shape[3]
     dy = torch.randn(B, Cout, OH, OW, generator=g).bfloat16().float()
     ref.backward(dy)
@@ -957,21 +960,25 @@ def test_unit_stride_window_convolution_against_conv2d(ops, shift, monkeypatch):
     prev = ops.compute_dtype()
     ops.set_compute_dtype(torch.bfloat16)
     try:
-        geo = ops.conv_geom(B, H, W, C, KH, KW, 2, 1, 0, 0)
+        geo = ops.conv_geom(B, H, W, C, KH, KW, SH, SW, 0, PW)
         assert Fn._window_ok(geo)
+        tag = "t_win%d" % SW
         wd, bd = torch.nn.Parameter(w.to(D)), torch.nn.Parameter(b.to(D))
-        X2, A, y, M = Fn._conv_window_fwd(nhwc(x).to(D, torch.bfloat16).contiguous(), geo, wd, bd, "t_win")
+        xin = nhwc(x).to(D, torch.bfloat16 if C > 1 else torch.float32).contiguous()
+        X2, A, y, M = Fn._conv_window_fwd(xin, geo, wd, bd, tag)
         got = y[:M, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
         assert (got - ref.detach()).abs().max().item() < 2e-3 * max(1.0, ref.detach().abs().max().item())
         assert bool((y[:M, Cout:] == 0).all())
         dyd = torch.zeros((y.shape[0], 64), device=D, dtype=torch.bfloat16)
         dyd[:M, :Cout] = nhwc(dy).reshape(M, Cout).to(D, torch.bfloat16)
         bg = torch.zeros(Cout, device=D)
-        dw, dx = Fn._conv_window_bwd(dyd, A, wd, bg, geo, "t_win", True)
+        dw, dx = Fn._conv_window_bwd(dyd, A, wd, bg, geo, tag, SW == 1)
+        assert tuple(dw.shape) == tuple(w.shape)
         assert (dw.cpu() - wr.grad).abs().max().item() < 3e-3 * wr.grad.abs().max().item()
         assert (bg.cpu() - br.grad).abs().max().item() < 1e-3 * br.grad.abs().max().item()
-        dxr = nhwc(xr.grad)
-        assert (dx.float().cpu() - dxr).abs().max().item() < 1.2e-2 * dxr.abs().max().item()     # dx is stored in bf16
+        if SW == 1:
+            dxr = nhwc(xr.grad)
+            assert (dx.float().cpu() - dxr).abs().max().item() < 1.2e-2 * dxr.abs().max().item()     # dx is stored in bf16
     finally:
         ops.set_compute_dtype(prev)
 
