@@ -1220,7 +1220,11 @@ __global__ __launch_bounds__(256) void tn128_reduce_kernel(const float* __restri
 // C[M,N] (op)= alpha * sum_k A[m,k] * B[k,n]  with B = W (K_red, N_out) in its NATURAL master layout: dX = dY . W needs the
 // contraction index as W's slow axis, so the B operand is built with the transposing LDS read (bf16) / 4-byte reads (fp32)
 // exactly like gemm_tn -- no transposed weight shadows.  A staging, pipeline and epilogue are those of gemm_glds (BN = 64).
-template <typename T, typename TO, int BM>
+// NST = 1: one LDS stage, "load, wait, compute" -- the form for launches of several workgroups per CU, which hide each other's load
+// latency.  NST = 3 (bf16): a private ring of hand-issued LDS-DMA stages with counted waits and ONE barrier per K step, for launches
+// that leave a CU with a single workgroup (the decoder's data gradients: 1600 rows x 512 columns = 200 blocks over K = 1536 - 4416):
+// there nothing else covers the ~0.9 us a K step spends waiting for its operands.
+template <typename T, typename TO, int BM, int NST = 1>
 __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, const int nwg, unsigned char* smem) {
   using P = TnPack<T>;
   constexpr int ESZ = (int)sizeof(T);
@@ -1261,13 +1265,7 @@ __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, c
     }
   };
 
-  // one LDS stage: load, wait, compute (see gemm_glds_kernel: workgroups per CU beat a private prefetch queue here)
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt > 0) __syncthreads();                 // everybody is done reading step kt-1
-    stage(kt, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const unsigned char* sA = smem;
+  auto compute = [&](const unsigned char* sA) __attribute__((always_inline)) {
     const unsigned char* sB = sA + BM * BKB;
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -1283,6 +1281,53 @@ __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, c
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) mma16<T>(acc[i][j], a[i], b[j]);
+    }
+  };
+  if constexpr (NST == 1) {
+    // one LDS stage: load, wait, compute (see gemm_glds_kernel: workgroups per CU beat a private prefetch queue here)
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt > 0) __syncthreads();                 // everybody is done reading step kt-1
+      stage(kt, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      compute(smem);
+    }
+  } else {
+    static_assert(ESZ == 2, "the ring form is bf16 only");
+    constexpr int PA = BM * 8 / 256, PB = BKR * P::CPR / 256;      // DMA pieces per thread and stage: A rows, B rows
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
+    // the DMA is hand issued (the compiler does not count it): its waits are the counted ones below, and the operand reads of
+    // compute() carry no s_waitcnt vmcnt(0) of the compiler's own
+    auto stage_ring = [&](int kt) __attribute__((always_inline)) {
+      const unsigned sl = wave_lds + (unsigned)((kt % NST) * STAGE);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int c = i * 256 + tid, row = c >> 3, slot = (c & 7) ^ (row & 7);
+        int gr = m0 + row;
+        gr = gr < p.M ? gr : p.M - 1;
+        tn_dma(sl + (unsigned)(i * 4096), A + (int64_t)gr * p.lda * ESZ + (int64_t)kt * BKB + slot * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int c = i * 256 + tid, row = c / P::CPR, slot = (c % P::CPR) ^ (row & 7);
+        int cb = n0 * ESZ / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+        const int br = min(kt * BKR + row, p.K - 1);
+        tn_dma(sl + (unsigned)(BM * BKB + i * 4096), B + (int64_t)br * p.ldb * ESZ + (int64_t)cb * 16);
+      }
+    };
+#pragma unroll
+    for (int kt = 0; kt < NST - 1; ++kt)
+      if (kt < nk) stage_ring(kt);
+    for (int kt = 0; kt < nk; ++kt) {
+      // step kt has landed once at most the pieces of the later steps are outstanding (PA + PB per step and thread, retired in order)
+      const int ahead = min(NST - 2, nk - 1 - kt);
+      if (ahead >= 1) wait_vmcnt<PA + PB>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();                // step kt visible to every wave; every wave is done reading step kt - 1
+      asm volatile("" ::: "memory");
+      if (kt + NST - 1 < nk) stage_ring(kt + NST - 1);
+      compute(smem + (kt % NST) * STAGE);
     }
   }
   __syncthreads();                               // operand stage free for the epilogue
@@ -1397,10 +1442,10 @@ __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, c
   }
 }
 
-template <typename T, typename TO, int BM>
+template <typename T, typename TO, int BM, int NST = 1>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  gemm_nn_body<T, TO, BM>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+  gemm_nn_body<T, TO, BM, NST>(p, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------------ TN on quadrant waves (bf16)
@@ -1576,22 +1621,22 @@ __global__ __launch_bounds__(256) void tn_reduce_multi_kernel(TnMultiArgs q) {
   tn_fold_block(q.ws[l], q.C[l], q.ldc[l], q.N[l], q.K[l], q.splits[l], (int)blockIdx.x);
 }
 
-template <typename T, typename TO, int BM>
+template <typename T, typename TO, int BM, int NST = 1>
 int launch_nn(const GemmArgs& a, hipStream_t s) {
   GemmArgs p = a;
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + 63) / 64;
   p.ntiles = tiles_m * p.tiles_n;
   const int esz = (int)sizeof(T);
-  size_t lds = (size_t)(BM * 128 + (128 / esz) * (64 * esz));      // one operand stage
+  size_t lds = (size_t)NST * (size_t)(BM * 128 + (128 / esz) * (64 * esz));      // NST operand stages
   const size_t cl = (size_t)BM * (64 * 4 + 16);
   if (cl > lds) lds = cl;
   static bool granted = false;
   if (lds > 48 * 1024 && !granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nn_kernel<T, TO, BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nn_kernel<T, TO, BM, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     granted = true;
   }
-  hipLaunchKernelGGL((gemm_nn_kernel<T, TO, BM>), dim3((unsigned)p.ntiles), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((gemm_nn_kernel<T, TO, BM, NST>), dim3((unsigned)p.ntiles), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -1948,6 +1993,10 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
   const int64_t nn_big = asr_tuning("NN_BIG", 1700);      // 128x64 tiles from this many 64x64 tiles on
   const bool big = t64 >= nn_big && M > 64;
   if (in_dtype == ASR_F32) return big ? launch_nn<float, float, 128>(p, stream) : launch_nn<float, float, 64>(p, stream);
+  // a launch that leaves a CU with one workgroup or two and walks at least four K steps: the private three-stage ring (NN_RING: the
+  // largest number of 64 x 64 blocks that takes it; 0 = never).  profiles/r03_gemm_nn_ring_ab.txt
+  if (out_dtype == ASR_BF16 && !big && t64 <= asr_tuning("NN_RING", 512) && K >= 256)
+    return launch_nn<bf16_t, bf16_t, 64, 3>(p, stream);
   if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);
   return big ? launch_nn<bf16_t, float, 128>(p, stream) : launch_nn<bf16_t, float, 64>(p, stream);
 }

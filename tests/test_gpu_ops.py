@@ -261,6 +261,43 @@ def test_gemm_nn_eight_wave_blocks(ops, ns):
         L.set_tuning("GEMM_BIG_NS", None)
 
 
+def test_gemm_nn_private_ring_equals_single_stage(ops, four_wave_nn):
+    """The four-wave data-gradient kernel in its three-stage LDS-DMA ring form (launches of at most NN_RING blocks: the decoder's
+    1600-row gradients) against its single-stage form (NN_RING = 0): the same MFMA sequence, so bit-identical -- plain, `+=` and
+    ReLU-mask epilogues, ragged rows, a partial block column, a partial last K stage (4364 -> zero columns up to 4416) -- and
+    against fp32 torch on the same operands."""
+    from asr_hip import lib as L
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    D = dev()
+    for M, N, K, ldw in [(1600, 512, 2048, 512), (1600, 512, 1536, 512), (1601, 512, 512, 512), (777, 200, 256, 200), (1600, 512, 4364, 512),
+                         (130, 264, 320, 320), (64, 64, 4096, 64)]:
+        Kp = (K + 63) // 64 * 64
+        dy = torch.zeros(M, Kp)
+        dy[:, :K] = torch.randn(M, K, generator=g)
+        dy = dy.to(D).to(bf)
+        w = (torch.randn(K, ldw, generator=g) * K ** -0.5).to(D).to(bf)[:, :N]
+        base = torch.randn(M, N, generator=g).to(D).to(bf)
+        mask = torch.randn(M, N, generator=g).to(D).to(bf)
+        ref = dy[:, :K].float() @ w.float()
+        got = {}
+        for ring in (0, None):
+            L.set_tuning("NN_RING", ring)
+            try:
+                acc = base.clone()
+                ops.gemm_nn(dy, w, out=acc, accumulate=True, alpha=0.5)      # (the contracted width is w's row count: dy may be wider)
+                got[ring] = (ops.gemm_nn(dy, w), acc, ops.gemm_nn(dy, w, relu_mask=mask))
+            finally:
+                L.set_tuning("NN_RING", None)
+        for a, b in zip(got[0], got[None]):
+            assert torch.equal(a, b), (M, N, K)
+        for name, out, want in (("plain", got[None][0], ref), ("accumulate", got[None][1], base.float() + 0.5 * ref),
+                                ("mask", got[None][2], ref * (mask.float() > 0))):
+            tol = 2.0 ** -7 * want.abs().clamp_min(0.05)
+            bad = (out.float() - want).abs() > tol
+            assert not bad.any(), (M, N, K, name, (out.float() - want).abs().max().item(), int(bad.sum()))
+
+
 @pytest.mark.parametrize("shape", [(6400, 512, 512), (3200, 512, 2048), (3200, 2048, 512), (200, 64, 64), (130, 192, 72),
                                    (37, 64, 200), (1000, 1536, 512)])
 def test_gemm_nn_tn_one_launch(ops, shape, four_wave_nn):
