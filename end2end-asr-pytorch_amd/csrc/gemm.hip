@@ -434,7 +434,12 @@ int launch_fast_ns(const GemmArgs& a, int splits, hipStream_t s) {
 }
 template <typename T, typename TO, int BM, int BN>
 int launch_fast(const GemmArgs& a, int splits, hipStream_t s) {
-  const int ns = (int)asr_tuning("GEMM_NS", 1);      // LDS stages (tuning hook)
+  // LDS stages: ONE wherever several workgroups share a CU (they cover each other's load latency: the measurement in front of
+  // gemm_glds_kernel); a launch of at most NT_RING 64 x 64 blocks leaves a CU with one workgroup or two, and there the private
+  // three-stage ring wins (the decoder's 3200 x 512 projections over K = 2048: 32 -> ~14 us; profiles/r03_gemm_nn_ring_ab.txt)
+  const int64_t blocks = ceil_div64(a.M, BM) * ceil_div64(a.N, BN) * splits;
+  const bool ring = BM == 64 && BN == 64 && sizeof(T) == 2 && a.K >= 256 && blocks <= asr_tuning("NT_RING", 512);
+  const int ns = (int)asr_tuning("GEMM_NS", ring ? 3 : 1);
   if (ns == 2) return launch_fast_ns<T, TO, BM, BN, 2>(a, splits, s);
   if (ns == 3) return launch_fast_ns<T, TO, BM, BN, 3>(a, splits, s);
   if (ns == 4) return launch_fast_ns<T, TO, BM, BN, 4>(a, splits, s);

@@ -261,6 +261,45 @@ def test_gemm_nn_eight_wave_blocks(ops, ns):
         L.set_tuning("GEMM_BIG_NS", None)
 
 
+def test_gemm_nt_private_ring_equals_single_stage(ops):
+    """The four-wave forward GEMM (gemm_glds_kernel, 64 x 64 blocks) in its three-stage ring form -- taken by launches of at most NT_RING
+    blocks, e.g. the decoder's 3200 x 512 projection over K = 2048 -- against the single-stage form (NT_RING = 0): the same MFMA sequence,
+    bit-identical; bias + ReLU, fp32 output, `+=` into fp32, ReLU-mask epilogues, ragged rows and a partial block column; and against
+    fp32 torch.  GEMM_BIG = 0 keeps the eight-wave blocks out of the way."""
+    from asr_hip import lib as L
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    D = dev()
+    L.set_tuning("GEMM_BIG", 0)
+    try:
+        for M, N, K in [(3200, 512, 2048), (1600, 64, 512), (777, 200, 256), (130, 264, 320), (64, 64, 4096), (3200, 512, 192)]:
+            A = torch.randn(M, K, generator=g).to(D).to(bf)
+            W = (torch.randn(N, K, generator=g) * K ** -0.5).to(D).to(bf)
+            bias = torch.randn(N, generator=g).to(D)
+            base = torch.randn(M, N, generator=g).to(D)
+            mask = torch.randn(M, N, generator=g).to(D).to(bf)
+            ref = A.float() @ W.float().t()
+            got = {}
+            for ring in (0, None):
+                L.set_tuning("NT_RING", ring)
+                try:
+                    acc = base.clone()
+                    ops.gemm_nt(A, W, out=acc, accumulate=True, alpha=0.5)
+                    got[ring] = (ops.gemm_nt(A, W, bias=bias, relu=True), ops.gemm_nt(A, W, out_dtype=torch.float32), acc,
+                                 ops.gemm_nt(A, W, relu_mask=mask))
+                finally:
+                    L.set_tuning("NT_RING", None)
+            for a, b in zip(got[0], got[None]):
+                assert torch.equal(a, b), (M, N, K)
+            for name, out, want in (("bias+relu", got[None][0], (ref + bias).relu()), ("fp32", got[None][1], ref),
+                                    ("accumulate", got[None][2], base + 0.5 * ref), ("mask", got[None][3], ref * (mask.float() > 0))):
+                tol = 2.0 ** -7 * want.abs().clamp_min(0.05)
+                bad = (out.float() - want).abs() > tol
+                assert not bad.any(), (M, N, K, name, (out.float() - want).abs().max().item(), int(bad.sum()))
+    finally:
+        L.set_tuning("GEMM_BIG", None)
+
+
 def test_gemm_nn_private_ring_equals_single_stage(ops, four_wave_nn):
     """The four-wave data-gradient kernel in its three-stage LDS-DMA ring form (launches of at most NN_RING blocks: the decoder's
     1600-row gradients) against its single-stage form (NN_RING = 0): the same MFMA sequence, so bit-identical -- plain, `+=` and
