@@ -507,7 +507,7 @@ bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
   // contractions (K >= 2048: 4 stages) and tall operands; 256 x 256 pays for fp32 output (the vocabulary projection) only
   const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
   int tile = mode == 256 || mode == 128 ? mode : (p.out_f32 && p.N >= 2048 ? 256 : 128);
-  if (tile == 128 && mode == 1 && t128 < (p.K >= 2048 ? 150 : 48)) return false;      // too few blocks: 64 x 64 four-wave blocks fill the chip better
+  if (tile == 128 && mode == 1 && t128 < (p.K >= 2048 ? 150 : asr_tuning("GEMM_BIG_MIN", 128))) return false;      // too few blocks: 64 x 64 four-wave blocks (with their ring, gemm.hip launch_fast) fill the chip better -- 48 -> 128: headline 6.02 -> 5.98 ms
   if (tile == 256) {
     if (p.out_f32) launch_nt<256, 256, 2, float>(p, stream); else launch_nt<256, 256, 2, bf16_t>(p, stream);
   } else {
