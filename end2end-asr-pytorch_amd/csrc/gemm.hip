@@ -1911,13 +1911,18 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     for (int b = a; b > 0 && M[order[b]] > M[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   TnGroupArgs ga{};
   int total = 0;
-  // TN_GROUP_TILE 0 (default): 256 x 256 blocks (eight waves), one workgroup per CU, the launch's stages dealt out in equal pieces
-  // (gemm_tn256s_kernel); 256: one workgroup per (block of dW, slice of <= TN_GROUP_MROWS rows), fp32 atomics where a block has more
-  // than one slice (A/B of the slice length: profiles/r03_grouped_wgrad_ab.txt); 128: the 128 x 128 / four-wave form, one workgroup
-  // per whole contraction
-  const int tmode = (int)asr_tuning("TN_GROUP_TILE", 0);     // 0: host-scheduled 256 x 256 blocks; 256: one block per (block of dW, row slice); 128
-  const bool big = tmode != 128, sched = tmode == 0;
+  // Forms: 256 x 256 blocks (eight waves), one workgroup per CU, the launch's stages dealt out in equal pieces (gemm_tn256s_kernel);
+  // one workgroup per (block of dW, slice of <= TN_GROUP_MROWS rows), fp32 atomics where a block has more than one slice (A/B of the
+  // slice length: profiles/r03_grouped_wgrad_ab.txt); the 128 x 128 / four-wave form, one workgroup per whole contraction.  TN_GROUP_TILE:
+  // 0 (default): by the longest contraction of the group -- equal pieces up to TN_GROUP_SLICE_MIN rows, per-slice blocks from there on: with
+  // >= 3 slices per block of dW the launch is several rounds of workgroups whatever the form, and the slices of one block run side by
+  // side on one L2 (47 % hits against 7 %, profiles/r03_tn_group_l2.txt): configs[3] (12 720 rows) 13.16 -> 12.92 ms/step, while the
+  // headline's 6 400 rows (2 slices: 1.2 rounds) keep the equal pieces.  1: equal pieces always; 256: per-slice always; 128.
+  const int tmode = (int)asr_tuning("TN_GROUP_TILE", 0);
   const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 3200);
+  int max_m = 0;
+  for (int j = 0; j < cnt; ++j) max_m = M[order[j]] > max_m ? M[order[j]] : max_m;
+  const bool big = tmode != 128, sched = tmode == 1 || (tmode == 0 && max_m < asr_tuning("TN_GROUP_SLICE_MIN", 9600));
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];
     Tn128Args& q = ga.p[j];

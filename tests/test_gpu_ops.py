@@ -486,14 +486,15 @@ def test_add_ln_dropout_consistency(ops, dtype):
     assert not torch.equal(yz2, yz)
 
 
-@pytest.mark.parametrize("tile", [0, 128, 256])
+@pytest.mark.parametrize("tile", [0, 1, 128, 256])
 def test_grouped_weight_gradients(ops, tile):
     """asr_gemm_tn_grouped: the weight and bias gradients of several linear layers in ONE launch (every linear layer's dW in the
     graph-replayed step, reference models/common_layers.py:136-142,181-187 via autograd) against fp32 torch.  Shapes: the model's
     (512 x 512 / 1536 x 512 / 2048 x 512 / 512 x 2048 over 400 .. 1700 rows), a vocabulary-like N = 300 with a padded leading dimension,
     K not a multiple of the block, M not a multiple of the 32-row stage, a problem without bias, an empty problem; both block
-    sizes (TN_GROUP_TILE = 128: one block per contraction; 256: eight waves, rows cut in slices that meet in fp32 atomics; 0, the
-    default: the same blocks dealt out to one workgroup per CU in equal pieces of 32-row stages)."""
+    sizes (TN_GROUP_TILE = 128: one block per contraction; 256: eight waves, rows cut in slices that meet in fp32 atomics; 1: the same
+    blocks dealt out to one workgroup per CU in equal pieces of 32-row stages; 0, the default: equal pieces below 9 600 rows, slices
+    from there on)."""
     from asr_hip import lib as L
     g = torch.Generator().manual_seed(17)
     D = dev()
