@@ -485,6 +485,7 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   const float c2 = p.scale * LOG2E;
   const int kend = key_end(p, b);
   const int64_t stat0 = ((int64_t)b * p.H + h) * p.Tq;
+  const uint32_t field_sh = (uint32_t)(lr & 1) << 4;        // this lane's keys are kw + 16 ki + lr with kw a multiple of 16: key & 1 = lr & 1
 
   uint4 kfr[NK][2], vfr[NK][2];
 #pragma unroll
@@ -593,19 +594,29 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
             }
         }
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2)
+        for (int q2 = 0; q2 < 2; ++q2) {
+          // Dropout mask of this lane's 4 consecutive query rows at ONE key.  The hash word of (row, key pair) holds the fields of keys
+          // 2j and 2j + 1, i.e. of this lane and of lane ^ 1: the even lane of a pair hashes rows 0 and 1, the odd lane rows 2 and 3,
+          // and both read all four words through quad permutes -- two hashes and four v_mov_dpp per lane instead of four hashes
+          // (the row key is linear in the row: + 0x9E3779B1 per row, attention.h).
+          uint32_t yw[4] = {0u, 0u, 0u, 0u};
+          if (p.thr) {
+            const uint32_t rk0 = drop_row_key(seed, drop_row(p, b, h, q0 + (2 * ms + q2) * 16 + g * 4 + 2 * (lr & 1)));
+            const uint32_t ya = drop_pair_bits(rk0, (uint32_t)key >> 1), yb = drop_pair_bits(rk0 + 0x9E3779B1u, (uint32_t)key >> 1);
+            yw[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)ya, 0xA0, 0xf, 0xf, true);        // quad_perm [0,0,2,2]: the pair's even lane
+            yw[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xA0, 0xf, 0xf, true);
+            yw[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)ya, 0xF5, 0xf, 0xf, true);        // quad_perm [1,1,3,3]: the pair's odd lane
+            yw[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xF5, 0xf, 0xf, true);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pv = __builtin_amdgcn_exp2f(s[ki][q2][r] * c2 - lse2[q2][r]);
             float keepf = 1.f;
-            if (p.thr) {
-              const uint32_t rk = drop_row_key(seed, drop_row(p, b, h, q0 + (2 * ms + q2) * 16 + g * 4 + r));
-              const uint32_t y = drop_pair_bits(rk, (uint32_t)key >> 1);
-              keepf = ((key & 1) ? (y >> 16) : (y & 0xffffu)) < p.thr ? 0.f : p.inv_keep;
-            }
+            if (p.thr) keepf = ((yw[r] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep;      // field of key & 1 (v_bfe_u32)
             s[ki][q2][r] = pv * keepf;                                   // dropped / rescaled probabilities (for dV)
             dp[ki][q2][r] = pv * (dp[ki][q2][r] * keepf - dlt[q2][r]);   // dS (for dK)
           }
+        }
         pa[ki] = pack_p(s[ki], 0);
         pd[ki] = pack_p(dp[ki], 0);
       }
