@@ -676,7 +676,7 @@ def _conv_window_fwd(x_nhwc, g, w, b, tag):
         Nz = ops._pad8(KW * Cout)
         Wz = ops.workspace(tag + "_wz", ((Nz + 127) // 128 * 128, blk), cd, dev)          # rows >= KW * Cout and the ky padding stay zero
         Wz[:KW * Cout, :KH * C].copy_(w.data.permute(3, 0, 2, 1).reshape(KW * Cout, KH * C))       # [(kx, co), (ky, ci)]
-        Z = ops.gemm_nt(X2[:R + KW - 1], Wz[:Nz], out=ops.workspace(tag + "_z", (R + KW - 1, Nz), torch.float32, dev))
+        Z = ops.gemm_nt(X2[:R + KW - 1], Wz[:Nz], out=ops.workspace(tag + "_z", (R + KW - 1, Nz), torch.float32, dev, zero=False))   # written whole by the product
         ops.window_sum(Z, y, bias, B * OH, Wg, OW, KW, Cout)
         return X2, A, y, M
     Ws = ops.workspace(tag + "_w", (64, Kp), cd, dev)                # rows >= Cout, columns >= K and the ky padding stay zero
