@@ -28,12 +28,27 @@ __device__ __forceinline__ uint32_t drop_row_key(uint64_t seed, uint32_t row) {
   // linear in the row (one multiply-add per row even where rows change per element); drop_pair_bits does the mixing
   return (uint32_t)seed + (uint32_t)(seed >> 32) * 0x85EBCA6Bu + row * 0x9E3779B1u;
 }
-__device__ __forceinline__ uint32_t drop_pair_bits(uint32_t row_key, uint32_t key_pair) {
-  uint32_t y = (row_key + key_pair) * 0xC2B2AE35u;
+constexpr uint32_t DROP_C1 = 0xC2B2AE35u;
+// second half of drop_pair_bits, for callers that keep y0 = (row_key + key_pair) * DROP_C1 as a running sum (the product is linear
+// modulo 2^32: one add per key pair instead of an add and a multiply)
+__device__ __forceinline__ uint32_t drop_pair_mix(uint32_t y) {
   y ^= y >> 15;
   y *= 0x27D4EB2Fu;
   y ^= y >> 13;
   return y;
+}
+__device__ __forceinline__ uint32_t drop_pair_bits(uint32_t row_key, uint32_t key_pair) {
+  return drop_pair_mix((row_key + key_pair) * DROP_C1);
+}
+// The keep mask applied to a packed bf16 pair w whose two uniform fields are y: field >= thr  <=>  saturating (field - (thr - 1)) != 0;
+// min(., 1) is then 0 / 1 per half and multiplies the bit pattern.  Three packed 16-bit instructions, written out because the compiler
+// turns the equivalent builtins into two compares, two selects and a byte permute.  thrm1x2 = (thr - 1) in both halves (thr >= 1).
+__device__ __forceinline__ uint32_t drop_apply_pk(uint32_t w, uint32_t y, uint32_t thrm1x2, uint32_t ones) {
+  uint32_t t, m, r;
+  asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(t) : "v"(y), "v"(thrm1x2));
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(t), "v"(ones));
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(m));
+  return r;
 }
 __device__ __forceinline__ bool drop_keep(uint32_t row_key, int k, uint32_t thr16) {
   const uint32_t y = drop_pair_bits(row_key, (uint32_t)k >> 1);

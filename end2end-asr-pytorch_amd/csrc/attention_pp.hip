@@ -223,6 +223,9 @@ template <bool DROP>
 __device__ __forceinline__ void softmax_form(f32x16_t (&s)[2], Soft& st, uint4 (&pk)[2][2], uint32_t rkey, int k0, int half, uint32_t thr,
                                              float c2) {
   const uint32_t thrm1 = (thr - 1u) * 0x10001u;        // (thr - 1) in both halves (DROP: thr >= 1)
+  // rkey is the lane's hash base ALREADY multiplied out: (row key + 2 half) * DROP_C1 (attn_fwd_pp_body); the pair index of register r
+  // of key block kb is k0 / 2 + 2 half + kb 16 + (r & 3) / 2 + 4 (r >> 2), so a pair's first-stage value is tile base + a literal
+  const uint32_t ytile = rkey + (uint32_t)(k0 >> 1) * DROP_C1;
   s[0] *= c2;                                          // v_pk_mul_f32: log2 units
   s[1] *= c2;
 #pragma unroll
@@ -244,13 +247,9 @@ __device__ __forceinline__ void softmax_form(f32x16_t (&s)[2], Soft& st, uint4 (
         const int r = 8 * j + 2 * e;
         w[e] = pack_bf16(s[kb][r], s[kb][r + 1]);
         if (DROP) {
-          // the pair's two 16-bit uniform fields against the threshold, both at once on the packed-16 ALU: keep <=> field >= thr
-          // <=> saturating (field - (thr - 1)) != 0; min(., 1) negated is the 16-bit keep mask of the packed bf16 pair
-          const uint32_t y = drop_pair_bits(rkey, (uint32_t)(k0 + key_of(kb, r, half)) >> 1);
-          const u16x2_t t = __builtin_elementwise_sub_sat(__builtin_bit_cast(u16x2_t, y), __builtin_bit_cast(u16x2_t, thrm1));
-          const u16x2_t one = {1, 1}, zero = {0, 0};
-          const u16x2_t keep = zero - __builtin_elementwise_min(t, one);
-          w[e] &= __builtin_bit_cast(uint32_t, keep);
+          // the pair's two 16-bit uniform fields against the threshold, both at once on the packed-16 ALU (drop_apply_pk, attention.h)
+          const uint32_t y = drop_pair_mix(ytile + (uint32_t)(key_of(kb, r, 0) >> 1) * DROP_C1);
+          w[e] = drop_apply_pk(w[e], y, thrm1, 0x10001u);
         }
       }
       pk[kb][j] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -332,7 +331,8 @@ __device__ __forceinline__ void attn_fwd_pp_body(const AttnArgs& p, unsigned cha
   const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
   Ctx c;
   c.rkey = 0u;
-  if (DROP) c.rkey = drop_row_key(asr_mix_seed(p.seed, p.seed_dev), drop_row(p, b, h, q));
+  // (multiplied out, with the lane half's two key pairs folded in: softmax_form adds the tile's and the register's part)
+  if (DROP) c.rkey = (drop_row_key(asr_mix_seed(p.seed, p.seed_dev), drop_row(p, b, h, q)) + 2u * (uint32_t)half) * DROP_C1;
   c.lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   c.half = half; c.prio = prio; c.c2 = p.scale * LOG2E;
 #pragma unroll
