@@ -359,3 +359,130 @@ def test_command_line_records_which_options_were_typed():
     finally:
         constant.set_args(old_args)
         constant.explicit = old_explicit
+
+
+def test_deferred_weight_gradients_close_their_groups_by_work(monkeypatch):
+    """Host logic of asr_hip/ops.py queue_wgrad / flush_wgrads (no kernel runs: the grouped launch is replaced by a recorder): a group
+    is closed at 32 layers or ~38 000 block-stages of 256 x 256 x 64 rows, whichever comes first -- 32 layers at the 6 400 rows of
+    configs[1], 16 at the 12 720 rows of configs[3] -- and a flush empties the queue in order."""
+    from asr_hip import ops
+    seen = []
+    monkeypatch.setattr(ops, "gemm_tn_grouped", lambda grp: seen.append([(e[0].shape[0], e[4], e[5]) for e in grp]))
+    monkeypatch.setattr(ops, "_wgrad_q", [])
+    monkeypatch.setattr(ops, "_wgrad_stages", [0])
+
+    def layer(M):
+        for N, K in ((1536, 512), (512, 512), (2048, 512), (512, 2048)):
+            ops.queue_wgrad(torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, K, dtype=torch.bfloat16),
+                            torch.zeros(N, K), torch.zeros(N), N, K)
+
+    for _ in range(10):
+        layer(6400)
+    assert [len(g) for g in seen] == [32]
+    ops.flush_wgrads()
+    assert [len(g) for g in seen] == [32, 8] and not ops._wgrad_q
+    del seen[:]
+    for _ in range(10):
+        layer(12720)
+    ops.flush_wgrads()
+    assert [len(g) for g in seen] == [16, 16, 8]
+    assert [e[0] for g in seen for e in g] == [12720] * 40
+    del seen[:]
+    for _ in range(12):                                   # decoder-sized problems: the count cap decides
+        layer(1600)
+    ops.flush_wgrads()
+    assert [len(g) for g in seen] == [32, 16]
+
+
+@pytest.mark.parametrize("cfg", [(2, 61, 23, 32, 21, 11, 2, 1, 0), (2, 61, 30, 1, 41, 11, 2, 2, 10)])
+@pytest.mark.parametrize("shift", [True, False])
+def test_window_convolution_algebra_on_cpu_stand_ins(monkeypatch, cfg, shift):
+    """The index algebra of asr_hip/functions.py _conv_window_fwd / _conv_window_bwd -- single-time-step patches X2, the overlapping-rows
+    window view, the dense per-tap product + window sum, the packet-of-rows weight-gradient contraction against the shifted dy view, the
+    data gradient through col2im -- with every kernel replaced by a few lines of torch on the CPU (fp32 arithmetic on bf16-typed
+    buffers' values): equal to F.conv2d and its autograd.  Both emb_cnn layers (reference transformer.py:33-40), both forms."""
+    import torch.nn.functional as F
+    from asr_hip import functions as Fn
+    from asr_hip import ops
+    B, H, W, C, KH, KW, SH, SW, PW = cfg
+    Cout = 32
+
+    def im2col(x, g, col):
+        Bq, Hq, Wq, Cq, kh, kw, sh, sw, ph, pw, oh, ow = g
+        xp = F.pad(x.float(), (0, 0, pw, pw, ph, ph))
+        rows = torch.zeros(Bq, oh, ow, kh, kw, Cq)
+        for ky in range(kh):
+            for kx in range(kw):
+                rows[:, :, :, ky, kx] = xp[:, ky:ky + sh * (oh - 1) + 1:sh, kx:kx + sw * (ow - 1) + 1:sw]
+        col.zero_()
+        col[:Bq * oh * ow, :kh * kw * Cq] = rows.reshape(Bq * oh * ow, -1).to(col.dtype)
+        return col
+
+    def col2im(dcol, g):
+        Bq, Hq, Wq, Cq, kh, kw, sh, sw, ph, pw, oh, ow = g
+        dx = torch.zeros(Bq, Hq + 2 * ph, Wq + 2 * pw, Cq)
+        d = dcol[:Bq * oh * ow, :kh * kw * Cq].float().reshape(Bq, oh, ow, kh, kw, Cq)
+        for ky in range(kh):
+            for kx in range(kw):
+                dx[:, ky:ky + sh * (oh - 1) + 1:sh, kx:kx + sw * (ow - 1) + 1:sw] += d[:, :, :, ky, kx]
+        return dx[:, ph:ph + Hq, pw:pw + Wq].to(dcol.dtype)
+
+    def gemm_nt(A, Bm, out=None, bias=None, **kw):
+        r = A.float() @ Bm.float().t()
+        if bias is not None:
+            r = r + bias[:r.shape[1]]
+        out.copy_(r.to(out.dtype))
+        return out
+
+    def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, **kw):
+        dw += dy[:, :N].float().t() @ x[:, :K].float()
+        if colsum_acc is not None:
+            colsum_acc += dy[:, :N].float().sum(0)
+
+    def gemm_tn_grouped(grp):
+        for dy, x, dw, db, N, K in grp:
+            gemm_tn(dy, x, dw, colsum_acc=db, N=N, K=K)
+
+    def window_sum(Z, y, bias, groups, Wg, OW, KW_, Co):
+        y.zero_()
+        for kx in range(KW_):
+            y[:groups * OW, :Co] += Z[kx:kx + groups * Wg].view(groups, Wg, -1)[:, :OW, kx * Co:(kx + 1) * Co].reshape(groups * OW, Co)
+        y[:groups * OW, :Co] += bias[:Co]
+        return y
+
+    def colsum_acc(x, out):
+        out += x.float().sum(0)
+
+    for name, fn in (("im2col", im2col), ("col2im", col2im), ("gemm_nt", gemm_nt), ("gemm_tn", gemm_tn), ("gemm_tn_grouped", gemm_tn_grouped),
+                     ("window_sum", window_sum), ("colsum_acc", colsum_acc)):
+        monkeypatch.setattr(ops, name, fn)
+    monkeypatch.setattr(ops, "_ws", {})
+    monkeypatch.setattr(ops, "compute_dtype", lambda: torch.bfloat16)
+    monkeypatch.setattr(Fn, "_emb_shift_fwd", shift)
+    monkeypatch.setattr(Fn, "_emb_shift_wgrad", shift)
+
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    w = (torch.randn(Cout, C, KH, KW, generator=g) * (C * KH * KW) ** -0.5).bfloat16().float()
+    b = torch.randn(Cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = F.conv2d(xr, wr, br, stride=(SH, SW), padding=(0, PW))
+    OH, OW = ref.shape[2], ref.shape[3]
+    dy = torch.randn(B, Cout, OH, OW, generator=g).bfloat16().float()
+    ref.backward(dy)
+    geo = ops.conv_geom(B, H, W, C, KH, KW, SH, SW, 0, PW)
+    assert Fn._window_ok(geo)
+    wd, bd = torch.nn.Parameter(w.clone()), torch.nn.Parameter(b.clone())
+    X2, A, y, M = Fn._conv_window_fwd(x.permute(0, 2, 3, 1).contiguous().bfloat16(), geo, wd, bd, "cpu_win")
+    got = y[:M, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    assert (got - ref.detach()).abs().max().item() < 1e-4 * max(1.0, ref.detach().abs().max().item())
+    dyd = torch.zeros((y.shape[0], 64), dtype=torch.bfloat16)
+    dyd[:M, :Cout] = dy.permute(0, 2, 3, 1).reshape(M, Cout).bfloat16()
+    bg = torch.zeros(Cout)
+    dw, dx = Fn._conv_window_bwd(dyd, A, wd, bg, geo, "cpu_win", SW == 1)
+    assert tuple(dw.shape) == tuple(w.shape)
+    assert (dw - wr.grad).abs().max().item() < 1e-4 * wr.grad.abs().max().item()
+    assert (bg - br.grad).abs().max().item() < 1e-4 * br.grad.abs().max().item()
+    if SW == 1:
+        dxr = xr.grad.permute(0, 2, 3, 1)
+        assert (dx.float() - dxr).abs().max().item() < 1.5e-2 * dxr.abs().max().item()       # dX2 and dx are stored in bf16
