@@ -1,0 +1,94 @@
+"""Static checks on the gfx950 code the compiler emits for three software-pipelined kernels (no GPU: hipcc cross-compiles to assembly
+with the flags of asr_hip/build.py).  They guard properties the measurements of DESIGN.md section 4 depend on and that a compiler
+upgrade or an innocent edit can silently undo:
+  * the private three-stage rings of the four-wave GEMM kernels keep their COUNTED waits -- a compiler that sees the LDS-DMA in flight
+    drains it (s_waitcnt vmcnt(0)) before every LDS read and the ring degenerates to "load, wait, compute";
+  * the long-sequence attention forward applies its dropout mask with three packed 16-bit instructions per key pair and one 32-bit
+    multiply (the builtin form was compiled to two compares, two selects and a byte permute: 13 instead of 9 instructions per pair)."""
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "end2end-asr-pytorch_amd"))
+
+
+def _asm(tmp, name):
+    from asr_hip import build
+    hipcc = build._hipcc()
+    if os.path.isabs(hipcc) and not os.path.exists(hipcc) or not os.path.isabs(hipcc) and shutil.which(hipcc) is None:
+        pytest.skip("hipcc not available")
+    out = os.path.join(tmp, name + ".s")
+    flags = [f for f in build.FLAGS if f != "-fPIC"] + build.PER_FILE_FLAGS.get(name, [])
+    r = subprocess.run([hipcc] + flags + ["--cuda-device-only", "-S", os.path.join(build.CSRC, name), "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return open(out).read().split("\n")
+
+
+def _kernel(lines, pattern):
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z\w+:", l)]
+    mine = [i for i in starts if re.search(pattern, lines[i])]
+    assert mine, pattern
+    a = mine[0]
+    return lines[a:min([i for i in starts if i > a] + [len(lines)])]
+
+
+def _ops(seg):
+    out = []
+    for l in seg:
+        t = l.strip().split()
+        if t and not t[0].startswith((".", ";")) and not t[0].endswith(":"):
+            out.append((t[0], l.strip()))
+    return out
+
+
+@pytest.fixture(scope="module")
+def gemm_asm(tmp_path_factory):
+    return _asm(str(tmp_path_factory.mktemp("isa")), "gemm.hip")
+
+
+@pytest.mark.parametrize("kernel,pieces", [(r"gemm_nn_kernelIttLi64ELi3E", 4), (r"gemm_glds_kernelIttLi64ELi64ELi3E", 4)])
+def test_ring_kernels_keep_their_counted_waits(gemm_asm, kernel, pieces):
+    ops = _ops(_kernel(gemm_asm, kernel))
+    mf = [i for i, (o, _) in enumerate(ops) if o.startswith("v_mfma")]
+    assert len(mf) == 8                                         # one 64-deep K step of a 32 x 32 quadrant: the loop is not unrolled
+    # the main loop = everything up to the barrier that follows the last MFMA (the epilogue starts there)
+    end = next(i for i in range(mf[-1], len(ops)) if ops[i][0] == "s_barrier")
+    waits = [t for o, t in ops[:end] if o == "s_waitcnt" and "vmcnt" in t]
+    counted = [t for t in waits if "vmcnt(%d)" % pieces in t]
+    drained = [t for t in waits if "vmcnt(0)" in t]
+    # exactly the kernel's own two waits: `pieces` DMA instructions of the next step may stay in flight; the last step drains
+    assert len(counted) == 1 and len(drained) == 1 and len(waits) == 2, waits
+    assert sum(1 for o, _ in ops[:end] if o == "global_load_lds_dwordx4") >= 2 * pieces        # prologue stage(s) + the refill inside the loop
+
+
+def test_attention_dropout_mask_is_packed_sixteen_bit_arithmetic(tmp_path):
+    lines = _asm(str(tmp_path), "attention_pp.hip")
+    seg = _kernel(lines, r"attn_fwd_pp_bf16_d64_kernelILb1ELi4E")
+    ops = _ops(seg)
+    bars = [i for i, (o, _) in enumerate(ops) if o == "s_barrier"]
+    tiles = []
+    for a, b in zip(bars, bars[1:]):
+        names = [o for o, _ in ops[a:b]]
+        if sum(n.startswith("v_mfma") for n in names) == 16:      # one 64-key tile: 8 MFMAs of P V + 8 of the next K Q^T
+            tiles.append(names)
+    assert len(tiles) >= 2
+    for names in tiles[-2:]:                                       # the steady-state iterations of the three-stage loop
+        for op in ("v_pk_sub_u16", "v_pk_min_u16", "v_pk_mul_lo_u16"):
+            assert names.count(op) == 16, (op, names.count(op))    # 16 key pairs per lane and tile
+        assert names.count("v_mul_lo_u32") <= 17                   # one multiply per pair (+ the tile's base)
+        assert names.count("v_perm_b32") == 0
+        valu = sum(n.startswith("v_") and not n.startswith("v_mfma") for n in names)
+        assert valu <= 430, valu                                   # 415 measured (482 before); includes the wave-uniform rare branches
+    # and without dropout the tile stays where profiles/r03_attention_d64_pmc.txt measured it
+    ops0 = _ops(_kernel(lines, r"attn_fwd_pp_bf16_d64_kernelILb0ELi4E"))
+    bars0 = [i for i, (o, _) in enumerate(ops0) if o == "s_barrier"]
+    steady = [[o for o, _ in ops0[a:b]] for a, b in zip(bars0, bars0[1:])]
+    steady = [n for n in steady if sum(x.startswith("v_mfma") for x in n) == 16][-2:]
+    for names in steady:
+        assert sum(n.startswith("v_") and not n.startswith("v_mfma") for n in names) <= 285
+        assert not any(n.startswith("v_pk_sub_u16") for n in names)
