@@ -412,6 +412,12 @@ def main():
                           "step_tflops_whole_model": (value * mflop_per_frame * 1e6 / 1e12) if mflop_per_frame else None,
                           "frac_of_mfma_peak_whole_step": (value * mflop_per_frame * 1e6 / 1e12 / (peak * world)) if mflop_per_frame else None,
                           "final_loss": final_loss}}
+        if lowrank:
+            # BASELINE configs[4] has no code in the reference tree (README.md:9 cites arXiv:1910.13923 only): the oracle for it is this
+            # repository's own restatement, checked by nothing the reference executed
+            out["parity"] = "unpinned"
+            out["config"]["parity_note"] = ("parity unpinned: the Low-Rank Transformer is not in the reference tree; tests compare with "
+                                            "oracle/asr_oracle.py's restatement of arXiv:1910.13923 only")
         if exposure is not None:
             out["config"]["gradient_allreduce"] = dict(exposure, bytes=4 * red.flat.total_all,
                                                        note="147 MB fp32 gradients + stats slot; the decoder slice is in flight during the encoder's "

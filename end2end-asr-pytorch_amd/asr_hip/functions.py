@@ -13,6 +13,7 @@ Sub-layer -> reference code
   CEFn       utils/metrics.py:102-132
 """
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -167,8 +168,18 @@ class _Fused:
 
 
 # ================================================================================================ plain linear
-_logit_handover = [None]              # (data_ptr of the latest fp32 logits, box of the LinearFn that produced them)
+_logit_handover = [None]              # (weakref to the latest fp32 logits, their data_ptr, numel, the producing LinearFn's box)
 _logit_handover_on = os.environ.get("ASR_LOGIT_HANDOVER", "1") != "0"
+
+
+def _claim_logit_handover(logits):
+    """CEFn.forward: the box of the LinearFn that produced `logits` (a view of them), or None.  The claim is made at FORWARD time and
+    empties the slot: the association is by a live weak reference to the producer's output tensor (while it is alive its memory
+    cannot have been recycled) plus address and size, never by an address alone, and it cannot outlive the forward that made it."""
+    slot, _logit_handover[0] = _logit_handover[0], None
+    if slot is None or slot[0]() is None:
+        return None
+    return slot[3] if (slot[1] == logits.data_ptr() and slot[2] == logits.numel()) else None
 
 
 class LinearFn(Function):
@@ -184,13 +195,15 @@ class LinearFn(Function):
         ctx.in_shape = x.shape
         ctx.need_dx = x.requires_grad
         ctx.box = None
-        if out_fp32 and cd == torch.bfloat16 and _logit_handover_on:
-            # fp32 logits of a bf16 model (the vocabulary projection): the loss's backward may leave the gradient in the compute dtype,
-            # zero padded to the data-gradient kernel's stage, in this box instead of an fp32 tensor that would be cast and padded
-            # here (CEFn.backward; one slot: the latest logits)
+        out = y.view(*x.shape[:-1], weight.shape[0])
+        _logit_handover[0] = None              # one slot, and only for the forward that has just run (never across a no_grad forward)
+        if out_fp32 and cd == torch.bfloat16 and _logit_handover_on and any(ctx.needs_input_grad):
+            # fp32 logits of a bf16 model (the vocabulary projection): the loss's backward may leave ITS part of the gradient in the
+            # compute dtype, zero padded to the data-gradient kernel's stage, in this box instead of an fp32 tensor that would be cast
+            # and padded here (CEFn claims the box in its forward)
             ctx.box = {}
-            _logit_handover[0] = (y.data_ptr(), ctx.box, tuple(y.shape))
-        return y.view(*x.shape[:-1], weight.shape[0])
+            _logit_handover[0] = (weakref.ref(out), y.data_ptr(), y.numel(), ctx.box)
+        return out
 
     @staticmethod
     def backward(ctx, dy):
@@ -198,6 +211,10 @@ class LinearFn(Function):
         dy_c = ctx.box.pop("dy", None) if ctx.box is not None else None
         if dy_c is None:
             dy_c = _as_compute(dy.reshape(-1, N))
+        elif dy is not None and any(st != 0 for st in dy.stride()):
+            # the logits had a second differentiable consumer (an auxiliary loss, a regulariser): autograd has summed its gradient with
+            # the loss's stride-0 zero placeholder into a dense tensor -- add it to the handed-over part instead of dropping it
+            dy_c = dy_c + _as_compute(dy.reshape(-1, N))
         dx = _linear_bwd(dy_c, ctx.x2, ctx.weight, ctx.bias, need_dx=ctx.need_dx)
         if ctx.mark_ready:
             P.grad_ready(*[p for p in (ctx.weight, ctx.bias) if p is not None])
@@ -594,7 +611,7 @@ class VGGFn(Function):
         P.grad_ready(w5, b5)
         _, wd5 = P.conv_shadow(w5)
         dp1 = ops.conv3x3(dy3, wd5, None, w5.shape[1], relu=False)
-        dy2 = ops.maxpool_bwd_code(c1, dp1, tuple(y1.shape), tcf=False) if c1 is not None else ops.maxpool_bwd(y2, dp1)
+        dy2 = ops.maxpool_bwd_code(c1, dp1, tuple(y1.shape[:3]) + (w2.shape[0],), tcf=False) if c1 is not None else ops.maxpool_bwd(y2, dp1)
         wgrad(y1, dy2, w2, b2, "c2")
         P.grad_ready(w2, b2)
         _, wd2 = P.conv_shadow(w2)
@@ -867,6 +884,7 @@ class CEFn(Function):
             count = global_count if global_count is not None else sums[1:2]
         ctx.t = (logits, g, lse, count)
         ctx.smoothing, ctx.pad_id, ctx.shape = smoothing, pad_id, pred.shape
+        ctx.handover = _claim_logit_handover(logits) if ctx.needs_input_grad[0] else None
         loss = ops.ratio(sums[0:1], global_count if global_count is not None else sums[1:2]).reshape(())
         ctx.mark_non_differentiable(sums, am)
         return loss, sums, am
@@ -877,13 +895,11 @@ class CEFn(Function):
         if count is None:
             count = ops.ones_scalar(logits.device)
         go = dloss.reshape(1).float().contiguous()
-        slot = _logit_handover[0]
-        if slot is not None and slot[0] == logits.data_ptr() and slot[2] == tuple(logits.shape):
+        if ctx.handover is not None:
             # the logits come straight from a LinearFn of a bf16 model: hand it the gradient in bf16, padded to 64 columns (what its
             # data-gradient GEMM reads), and return a stride-0 zero as the formal fp32 gradient -- saves the 56 MB fp32 tensor, its
             # cast / pad launch and half of this kernel's stores (reference: loss.backward() through utils/metrics.py:118-130)
-            _logit_handover[0] = None
-            slot[1]["dy"] = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count, out_dtype=torch.bfloat16, pad=64)
+            ctx.handover["dy"] = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count, out_dtype=torch.bfloat16, pad=64)
             return torch.zeros((), device=logits.device, dtype=torch.float32).expand(ctx.shape), None, None, None, None
         dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count)
         return dl.view(ctx.shape), None, None, None, None

@@ -202,6 +202,7 @@ class GraphedTrainStep:
         self.opt._step += 1
         self.opt._rate = self.opt.rate()
         self.opt.optimizer.after_replay(1)
+        self.opt._dev_step = self.opt._step      # host mirror and device counter moved together (see step_skipped)
 
     def global_loss(self):
         """Data parallel: loss over the gathered batch (host float; one D2H copy).  Single GPU: the step's loss."""
@@ -211,8 +212,26 @@ class GraphedTrainStep:
 
     def sync_step_counter(self):
         """Several graphs (one per shape bucket) and eager steps may alternate on one optimiser: the device-side step counter
-        every replay reads is set from the optimiser's host-side count first."""
-        ops.step_state(self.src.device)[1] = int(self.opt._step)
+        every replay reads is set from the optimiser's host-side count first -- only when the host count moved WITHOUT the device
+        (an eager NoamOpt.step()): a replayed step advances both, and a step the device cancelled (non-finite loss) is un-counted on
+        the device by the next asr_step_advance and on the host by step_skipped(), whenever the host learns of it."""
+        if getattr(self.opt, "_dev_step", None) != self.opt._step:
+            st = ops.step_state(self.src.device)
+            st[1] = int(self.opt._step)
+            st[2] = 0
+            self.opt._dev_step = self.opt._step
+
+    @staticmethod
+    def step_skipped(opt):
+        """Host-side accounting for ONE replayed step whose loss turned out non-finite: the device left weights and moments untouched
+        and will reuse the step number (asr_adam_noam_step / asr_step_advance); the host mirror follows -- Noam step, rate, Adam's
+        per-parameter 'step' fields -- so schedule and bias correction do not advance for a batch that was not applied (reference
+        trainer/asr/trainer.py:102-104: `continue` in front of opt.step())."""
+        opt._step -= 1
+        opt._rate = opt.rate() if opt._step > 0 else 0
+        if getattr(opt, "_dev_step", None) is not None:
+            opt._dev_step -= 1
+        opt.optimizer.after_replay(-1)
 
     def __call__(self, src=None, src_len=None, tgt=None):
         """Copy the batch into the static buffers (skip arguments that are already there) and replay.

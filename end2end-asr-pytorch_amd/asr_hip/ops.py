@@ -14,11 +14,11 @@ _cfg = {"dtype": torch.bfloat16, "state": None}
 
 
 def step_state(device=None):
-    """Device uint64[2] {dropout seed counter, optimiser step}: mixed into every dropout seed and read by the
-    graph-replayable optimiser kernel; advanced once per training step by step_advance()."""
+    """Device uint64[4] {dropout seed counter, optimiser step, "the last optimiser launch skipped its update", unused}: mixed into
+    every dropout seed and read by the graph-replayable optimiser kernel; advanced once per training step by step_advance()."""
     st = _cfg["state"]
     if st is None or (device is not None and st.device != torch.device(device)):
-        st = torch.zeros(2, dtype=torch.int64, device=device or "cuda")
+        st = torch.zeros(4, dtype=torch.int64, device=device or "cuda")
         _cfg["state"] = st
     return st
 

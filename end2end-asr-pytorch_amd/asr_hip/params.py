@@ -212,9 +212,10 @@ class FlatParams:
             ent[2] = {id(q): q._version for q in self.params}
 
     def shadow_is_stale(self, dtype):
-        """True when a master was modified through torch since the shadow was written (a replayed graph cannot notice)."""
+        """True when a master was modified since the shadow was written -- through torch (version counters) or through the C ABI
+        (an eager FusedAdam.step() between two replays: generation counter) -- which a replayed graph cannot notice."""
         ent = self._shadow.get(dtype)
-        return ent is not None and any(ent[2].get(id(q)) != q._version for q in self.params)
+        return ent is not None and (ent[1] != _state["generation"] or any(ent[2].get(id(q)) != q._version for q in self.params))
 
     def zero_grad(self):
         self.grad_all.zero_()

@@ -175,20 +175,26 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // memory, so that a captured hipGraph replays a correct optimiser step (reference: utils/optimizer.py:15-32).
 __global__ __launch_bounds__(256) void adam_noam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, int64_t n4, int64_t n,
-                                                        const uint64_t* __restrict__ state, float b1, float b2, float eps,
+                                                        uint64_t* __restrict__ state, float b1, float b2, float eps,
                                                         float factor_ms, float warmup, float min_lr,
                                                         const float* __restrict__ gscale, float* __restrict__ lr_out,
                                                         const float* __restrict__ guard, bf16_t* __restrict__ shadow) {
   const float gs = gscale ? *gscale : 1.f;
-  // a non-finite loss (or clipping coefficient) skips the whole update: the reference's `if loss == inf: continue`
-  if (!isfinite(gs) || (guard && !isfinite(*guard))) return;
   const double t = (double)state[1];
   const double w15 = pow((double)warmup, -1.5);
   const double sched = fmin(pow(t, -0.5), t * w15);
   const float lr = fmaxf(min_lr, (float)((double)factor_ms * sched));
+  // a non-finite loss (or clipping coefficient) skips the whole update: the reference's `if loss == inf: continue`
+  // (trainer/asr/trainer.py:102-104 -- the batch is dropped BEFORE opt.step(), so neither the weights nor the step count move).
+  // state[2] tells the next asr_step_advance that this step number was not consumed; the rate is reported either way.
+  const bool skip = !isfinite(gs) || (guard && !isfinite(*guard));
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (lr_out) *lr_out = lr;
+    state[2] = skip ? 1u : 0u;
+  }
+  if (skip) return;
   const float bc1 = (float)(1.0 - pow((double)b1, t));
   const float bc2_sqrt = sqrtf((float)(1.0 - pow((double)b2, t)));
-  if (lr_out && blockIdx.x == 0 && threadIdx.x == 0) *lr_out = lr;
   const float step = lr / bc1;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -232,7 +238,8 @@ __global__ __launch_bounds__(256) void cast_flat_kernel(const float* __restrict_
     }
   }
 }
-__global__ void step_advance_kernel(uint64_t* state) { state[0] += 1; state[1] += 1; }
+// state = {dropout seed counter, optimiser step, 1 when the previous optimiser launch skipped its update, unused}
+__global__ void step_advance_kernel(uint64_t* state) { state[0] += 1; state[1] += 1 - (state[2] ? 1 : 0); state[2] = 0; }
 
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* acc) {
   __shared__ float red[4];
@@ -442,7 +449,7 @@ extern "C" int asr_step_advance(uint64_t* state, hipStream_t s) {
   return ASR_OK;
 }
 
-extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
+extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, uint64_t* state, float beta1,
                                   float beta2, float eps, float factor_ms, float warmup, float min_lr, const float* gscale,
                                   float* lr_out, const float* guard, void* shadow_bf16, hipStream_t s) {
   ASR_CHECK_ARG(p && g && m && v && state && n >= 0 && warmup > 0.f);

@@ -47,7 +47,8 @@ class _Pending:
     enqueued the next step, so the strings / CER / WER of step i are computed while the GPU runs step i + 1."""
     _pool = {}
 
-    def __init__(self, gold_seq, hyp_seq, loss, id2label):
+    def __init__(self, gold_seq, hyp_seq, loss, id2label, graph_opt=None):
+        self.graph_opt = graph_opt             # the optimiser when the step was a REPLAYED one (its skip is accounted on the host here)
         turn = _Pending._pool["turn"] = (_Pending._pool.get("turn", 0) + 1) & 1        # two buffers per shape: one pending, one filling
         key = (tuple(gold_seq.shape), turn)
         buf = _Pending._pool.get(key)
@@ -69,12 +70,15 @@ class _Pending:
             # reference trainer.py:102-104 skips such a batch; a replayed step cannot branch on the host, so the device-side optimiser
             # step cancelled itself (asr_adam_noam_step guard) and the batch is left out of the running loss here
             logging.info("Found infinity loss, masking (the replayed step left weights and moments untouched)")
+            if self.graph_opt is not None:
+                from asr_hip.graph import GraphedTrainStep
+                GraphedTrainStep.step_skipped(self.graph_opt)
             return None
         return (loss_value,) + Trainer._text_metrics(self.ids.tolist(), self.id2label)
 
 
 class Trainer():
-    GRAPH_CACHE = int(os.environ.get("ASR_GRAPH_CACHE", "12"))     # captured step shapes kept by --graph-buckets
+    GRAPH_CACHE = max(1, int(os.environ.get("ASR_GRAPH_CACHE", "12")))     # captured step shapes kept by --graph-buckets (at least one)
 
     def __init__(self):
         logging.info("Trainer is initialized")
@@ -97,6 +101,10 @@ class Trainer():
         if tgt.shape[1] > L or src.dim() != 4:
             return None
         N = int(a.graph_buckets)
+        if getattr(a, "feat_extractor", "") == "emb_cnn" and not self.__dict__.get("_warned_bn_buckets"):
+            self._warned_bn_buckets = True
+            logging.warning("--graph-buckets with --feat_extractor emb_cnn: BatchNorm batch statistics include the bucket padding "
+                            "(as they include the collate padding in the reference); results differ from --graph-buckets 0")
         B, C, F, T = src.shape
         Tb = (T + N - 1) // N * N
         key = (B, C, F, Tb, L, src.dtype)
@@ -164,7 +172,7 @@ class Trainer():
             r = self._graph_step(model, opt, src, src_lengths, tgt, smoothing)
             if r is not None:
                 loss, gold_seq, hyp_seq = r
-                return _Pending(gold_seq, hyp_seq, loss, id2label)         # asynchronous D2H; no sync in this step
+                return _Pending(gold_seq, hyp_seq, loss, id2label, graph_opt=opt)         # asynchronous D2H; no sync in this step
         if opt is not None:
             opt.zero_grad()
         pred, gold, hyp_seq, gold_seq = model(src, src_lengths, tgt, verbose=False)

@@ -293,17 +293,19 @@ int asr_ce_bwd(const float* logits, int64_t ld, const int64_t* gold, const float
  * grad_scale_dev: optional device scalar multiplied into g (gradient clipping coefficient), may be NULL.        */
 int asr_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float bias_corr1, float bias_corr2, const float* grad_scale_dev, asr_stream_t stream);
-/* Graph-replayable variant: state = device uint64[2] {dropout seed counter, optimiser step t}; asr_step_advance()
- * increments both (one launch at the top of every step, captured or not).  asr_adam_noam_step reads t from state[1] and
+/* Graph-replayable variant: state = device uint64[4] {dropout seed counter, optimiser step t, skipped flag, unused}; asr_step_advance()
+ * increments the first two (one launch at the top of every step, captured or not) -- except that t stays when the previous
+ * asr_adam_noam_step cancelled its update (state[2], cleared here): a skipped batch does not consume a step number, like the
+ * reference's `continue` in front of opt.step().  asr_adam_noam_step reads t from state[1] and
  * computes lr = max(min_lr, factor_ms * min(t^-0.5, t * warmup^-1.5)) (factor_ms = k_lr * model_size^-0.5) and Adam's
  * bias corrections on the device; *lr_out (optional) receives lr.  Every dropout kernel mixes state[0] into its seed
  * through its `seed_dev` argument (NULL = host seed only).  guard_dev (optional device scalar, e.g. the step's loss sum): when it
- * or the gradient scale is not finite the launch changes NOTHING -- parameters and both moments keep their values -- which is
+ * or the gradient scale is not finite the launch changes NOTHING -- parameters and both moments keep their values; state[2] is set; *lr_out is still written -- which is
  * the reference trainer's `if loss == inf: continue` (trainer/asr/trainer.py:102-104) for a step that is replayed from a graph
  * and cannot branch on the host.  shadow_bf16 (optional, n elements): receives the updated parameters rounded to bf16 -- the
  * compute-dtype copy the next step's GEMMs read -- so that no separate cast pass over the masters is needed.            */
 int asr_step_advance(uint64_t* state, asr_stream_t stream);
-int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, const uint64_t* state, float beta1,
+int asr_adam_noam_step(float* p, const float* g, float* m, float* v, int64_t n, uint64_t* state, float beta1,
                        float beta2, float eps, float factor_ms, float warmup, float min_lr,
                        const float* grad_scale_dev, float* lr_out, const float* guard_dev, void* shadow_bf16,
                        asr_stream_t stream);

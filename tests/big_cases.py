@@ -1,4 +1,4 @@
-"""Shared helpers for the BASELINE-shape parity cases (tests/golden/{cfg0,cfg1_b2,cfg3_shape}.npz).
+"""Shared helpers for the BASELINE-shape parity cases (tests/golden/{cfg0,cfg1_b2,cfg3_shape,cfg1_b32,cfg3_b16}.npz).
 
 The fixtures were produced by EXECUTING the reference (oracle/gen_golden.py, BIG cases) and hold summaries only; the
 weights are rebuilt here from the reference's seed: the product's constructors consume torch's CPU RNG exactly like
@@ -12,7 +12,7 @@ import zlib
 import numpy as np
 import torch
 
-BIG_CASES = ["cfg0", "cfg1_b2", "cfg3_shape", "cfg1_b32"]
+BIG_CASES = ["cfg0", "cfg1_b2", "cfg3_shape", "cfg1_b32", "cfg3_b16"]
 
 
 def load(golden_dir, name):

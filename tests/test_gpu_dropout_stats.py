@@ -1,0 +1,170 @@
+"""Dropout ON at the shapes the benchmark runs (Weak #1 (ii)): every oracle comparison runs dropout 0, the benched
+step runs 0.1.  These are statistics of the SHIPPED kernels over 64 seeds, at the benched shapes, bf16:
+
+  * keep rate within 4 sigma of 1 - p_q (p_q = p quantised to 1/65536, the kernels' own resolution);
+  * unbiasedness: E_seed[out] against the p = 0 output.  With the mean over S seeds m and the p = 0 output o0, the regression
+    coefficient c = <m - o0, o0> / <o0, o0> is 0 for an unbiased mask with the exact 1 / (1 - p) rescale (a missing rescale gives
+    c = -p, a keep rate off by 1 % gives c = -/+ 0.01); |c| <= 2e-3 is asserted, and the residual's size is compared with the
+    analytic dropout noise sqrt(p / (1 - p) / S) * sqrt(sum_k P_k^2 v_k^2): its rms z-score must be 1 +- 0.15 -- a mask that is
+    correlated across keys, or reused across seeds, shows up there;
+  * one seed per shape: O equals (dumped dropped probabilities) @ V, which ties the fast kernels' mask to the dump kernel's.
+
+Reference semantics: models/common_layers.py:221-222 (nn.Dropout on the attention matrix), :140-141 / :197 (dropout before the
+residual add), models/asr/transformer.py:293 (embedding dropout).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SEEDS = 64
+P = 0.1
+PQ = round(P * 65536) / 65536.0
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from asr_hip import ops as o
+    o.set_compute_dtype(torch.bfloat16)
+    return o
+
+
+def _softmax_ref(q, k, H, d, key_len, causal, key_pad, scale):
+    B, Tq, _ = q.shape
+    Tk = k.shape[1]
+    qh = q.float().view(B, Tq, H, d).permute(0, 2, 1, 3)
+    kh = k.float().view(B, Tk, H, d).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) * scale
+    mask = torch.zeros(B, 1, Tq, Tk, dtype=torch.bool, device=q.device)
+    if key_len is not None:
+        mask |= (torch.arange(Tk, device=q.device)[None, :] >= key_len[:, None].long())[:, None, None, :]
+    if key_pad is not None:
+        mask |= key_pad.bool()[:, None, None, :]
+    if causal:
+        mask |= torch.triu(torch.ones(Tq, Tk, dtype=torch.bool, device=q.device), diagonal=1)[None, None]
+    return torch.softmax(s.masked_fill(mask, float("-inf")), dim=-1)          # (B,H,Tq,Tk) fp32, on the device
+
+
+ATT = [
+    # (tag, B, H, Tq, Tk, causal, ragged)                     configs[1] per GPU: B = 32, H = 8, d = 64
+    ("cfg1 encoder self-attention", 32, 8, 200, 200, False, True),
+    ("cfg1 decoder cross-attention", 32, 8, 100, 200, False, True),
+    ("cfg1 decoder self-attention", 32, 8, 100, 100, True, True),
+    ("north-star / configs[3] long-sequence kernel", 2, 8, 800, 800, False, True),
+]
+
+
+@pytest.mark.parametrize("case", ATT, ids=[c[0] for c in ATT])
+def test_attention_dropout_statistics_at_benched_shapes(ops, case):
+    tag, B, H, Tq, Tk, causal, ragged = case
+    d, dev = 64, "cuda"
+    g = torch.Generator().manual_seed(Tq * 3 + Tk)
+    q = (torch.randn(B, Tq, H * d, generator=g)).to(dev, torch.bfloat16)
+    k = (torch.randn(B, Tk, H * d, generator=g)).to(dev, torch.bfloat16)
+    v = (torch.randn(B, Tk, H * d, generator=g) + 1.0).to(dev, torch.bfloat16)      # a common component: |O| ~ 1, a scale error is visible
+    scale = 1.0 / math.sqrt(d)
+    key_len = key_pad = None
+    if causal:
+        key_pad = torch.zeros(B, Tk, dtype=torch.uint8)
+        for b in range(B):
+            key_pad[b, Tk - (b % 7) * 5:] = 1 if b % 7 else 0
+        key_pad = key_pad.to(dev)
+    elif ragged:
+        key_len = torch.tensor([Tk - (37 * b) % (Tk // 2) for b in range(B)], dtype=torch.int32, device=dev)
+    o0f = torch.empty(B, Tq, H * d, device=dev, dtype=torch.float32)      # the kernels' un-rounded fp32 copy of O (what training keeps for delta)
+    ops.attn_fwd(q, k, v, H, d, key_len=key_len, key_pad=key_pad, causal=causal, scale=scale, o32=o0f)
+    o32 = torch.empty_like(o0f)
+    P0 = _softmax_ref(q, k, H, d, key_len, causal, key_pad, scale)
+    acc = torch.zeros(B, Tq, H * d, device=dev, dtype=torch.float32)
+    kept = tot = 0
+    live = P0 > 1e-7                                                       # entries whose keep / drop is observable in the dump
+    for s in range(SEEDS):
+        want = s < 4                                                       # the dump is 4 x (B H Tq Tk) fp32: a few seeds are enough
+        o, _, attn = ops.attn_fwd(q, k, v, H, d, key_len=key_len, key_pad=key_pad, causal=causal, scale=scale, p=P, seed=1000 + 17 * s,
+                                  want_attn=want, o32=o32)
+        acc += o32
+        if want:
+            a = attn.view(H, B, Tq, Tk).permute(1, 0, 2, 3)
+            kept += int(((a != 0) & live).sum())
+            tot += int(live.sum())
+            if s == 0:                                                     # the fast kernel's mask == the dump's mask
+                vh = v.float().view(B, Tk, H, d).permute(0, 2, 1, 3)
+                o_dump = (a @ vh).permute(0, 2, 1, 3).reshape(B, Tq, H * d)
+                err = float((o.float() - o_dump).abs().max())
+                assert err <= 2.5e-2 * float(o_dump.abs().max()), (tag, err)
+            del a, attn
+    rate = kept / tot
+    sigma = math.sqrt(PQ * (1 - PQ) / tot)
+    assert abs(rate - (1 - PQ)) <= 4 * sigma + 1e-6, (tag, rate, 1 - PQ, sigma)
+    m = acc / SEEDS
+    c = float((m - o0f).flatten().double() @ o0f.flatten().double() / (o0f.flatten().double() @ o0f.flatten().double()))
+    assert abs(c) <= 2e-3, (tag, c)
+    vh2 = (v.float() ** 2).view(B, Tk, H, d).permute(0, 2, 1, 3)
+    noise = torch.sqrt(((P0 ** 2) @ vh2).permute(0, 2, 1, 3).reshape(B, Tq, H * d) * (PQ / (1 - PQ) / SEEDS))
+    rowsok = noise > 1e-6                                                  # rows with a single live key have no dropout noise to compare with
+    z = ((m - o0f) / noise.clamp_min(1e-6))[rowsok]
+    rms = float(z.double().pow(2).mean().sqrt())
+    print("%s: keep rate %.6f (expected %.6f, sigma %.1e), bias coefficient %.2e, residual rms z %.3f" % (tag, rate, 1 - PQ, sigma, c, rms))
+    assert 0.85 <= rms <= 1.15, (tag, rms)
+
+
+@pytest.mark.parametrize("M", [6400, 3200])
+def test_add_ln_dropout_statistics_at_benched_shapes(ops, M):
+    """asr_add_ln_fwd at the encoder's (6400 x 512) and the decoder's (3200 x 512) sub-layer outputs: z = dropout(y) + residual is
+    left in y's buffer -- keep rate, exact 1 / (1 - p_q) rescale of the kept elements and E_seed[z] = y + residual."""
+    D, dev = 512, "cuda"
+    g = torch.Generator().manual_seed(M)
+    y0 = torch.randn(M, D, generator=g)
+    y = (torch.sign(y0) * (0.5 + y0.abs())).to(dev, torch.bfloat16)          # bounded away from 0: "z == residual" <=> dropped
+    res = torch.randn(M, D, generator=g).to(dev, torch.bfloat16)
+    gamma, beta = torch.ones(D, device=dev), torch.zeros(D, device=dev)
+    acc = torch.zeros(M, D, device=dev, dtype=torch.float32)
+    kept = 0
+    yf, rf = y.float(), res.float()
+    for s in range(SEEDS):
+        z = y.clone()
+        ops.add_ln_fwd(z, res, gamma, beta, p=P, seed=5000 + 31 * s)
+        zf = z.float()
+        dropped = zf == rf
+        kept += int((~dropped).sum())
+        acc += zf
+        if s == 0:
+            ref = rf + yf / (1 - PQ)
+            keptm = ~dropped
+            assert float((zf - ref)[keptm].abs().max()) <= 2.0 ** -7 * float(ref.abs().max())      # one bf16 rounding of the sum
+    tot = SEEDS * M * D
+    rate = kept / tot
+    sigma = math.sqrt(PQ * (1 - PQ) / tot)
+    assert abs(rate - (1 - PQ)) <= 4 * sigma + 2e-6, (rate, 1 - PQ, sigma)
+    m = acc / SEEDS - rf                                                     # estimates y
+    c = float((m - yf).flatten().double() @ yf.flatten().double() / (yf.flatten().double() @ yf.flatten().double()))
+    assert abs(c) <= 2e-3, c
+    z = (m - yf) / (yf.abs() * math.sqrt(PQ / (1 - PQ) / SEEDS)).clamp_min(1e-6)
+    rms = float(z.double().pow(2).mean().sqrt())
+    print("add_ln M=%d: keep rate %.6f (expected %.6f, sigma %.1e), bias coefficient %.2e, residual rms z %.3f" % (M, rate, 1 - PQ, sigma, c, rms))
+    assert 0.85 <= rms <= 1.15, rms
+
+
+def test_embedding_dropout_statistics_at_benched_shape(ops):
+    """asr_embed_fwd at (32, 100) tokens x 512: dropout(emb * scale + pe)."""
+    B, T, D, V, dev = 32, 100, 512, 4364, "cuda"
+    g = torch.Generator().manual_seed(3)
+    tok = torch.randint(3, V, (B, T), generator=g).to(dev)
+    table = (torch.randn(V, D, generator=g) + 1.5).to(dev)
+    pe = torch.randn(T, D, generator=g).to(dev) * 0.1
+    o0 = ops.embed_fwd(tok, table, pe, 1.0, 0.0, 0, torch.bfloat16).float()
+    acc = torch.zeros_like(o0)
+    kept = 0
+    for s in range(SEEDS):
+        o = ops.embed_fwd(tok, table, pe, 1.0, P, 9000 + 13 * s, torch.bfloat16).float()
+        kept += int((o != 0).sum())
+        acc += o
+    tot = SEEDS * o0.numel()
+    rate = kept / tot
+    sigma = math.sqrt(PQ * (1 - PQ) / tot)
+    assert abs(rate - (1 - PQ)) <= 4 * sigma + 2e-6, (rate, sigma)
+    m = acc / SEEDS
+    c = float((m - o0).flatten().double() @ o0.flatten().double() / (o0.flatten().double() @ o0.flatten().double()))
+    assert abs(c) <= 2e-3, c

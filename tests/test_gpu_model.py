@@ -234,3 +234,53 @@ def test_grouped_cross_attention_projections_equal_per_layer_ones(golden_dir, pr
             continue
         scale = gb[k].abs().max().item()
         assert (ga[k] - gb[k]).abs().max().item() <= tol * scale + 1e-7, k
+
+
+def test_logit_handover_keeps_a_second_consumers_gradient(golden_dir):
+    """the loss hands its logit gradient to the vocabulary projection in bf16 through a box claimed at forward
+    time.  (1) the stock path really takes the hand-over; (2) with a SECOND differentiable consumer of the logits (an auxiliary
+    term) the projection's weight gradient equals the one computed with the hand-over switched off -- the auxiliary gradient
+    is added, not dropped; (3) a no_grad forward leaves nothing behind for a later loss to claim."""
+    from asr_hip import functions as F_
+    from utils.metrics import calculate_loss
+    z, args, model, opt = build(golden_dir, "vgg_tiny", "bf16")
+    src = torch.from_numpy(z["src"]).cuda()
+    tgt = torch.from_numpy(z["tgt"]).cuda()
+    src_len = torch.from_numpy(z["src_len"])
+
+    def grads(handover, aux):
+        F_._logit_handover_on = handover
+        try:
+            opt.zero_grad()
+            pred, gold, _, _ = model(src, src_len, tgt)
+            claimed_before = F_._logit_handover[0] is not None
+            loss = calculate_loss(pred, gold, smoothing=0.1)
+            claimed = claimed_before and F_._logit_handover[0] is None
+            if aux:
+                loss = loss + 0.5 * pred.float().square().mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            return claimed, {k: q.grad.detach().float().clone() for k, q in model.named_parameters()}
+        finally:
+            F_._logit_handover_on = True
+
+    model.eval()                       # dropout off: the two runs must be the same function
+    for p_ in model.parameters():
+        p_.requires_grad_(True)
+    claimed, g_on = grads(True, False)
+    assert claimed, "the stock bf16 path did not take the logit hand-over"
+    _, g_off = grads(False, False)
+    claimed2, a_on = grads(True, True)
+    _, a_off = grads(False, True)
+    assert claimed2
+    k = "decoder.output_linear.weight"
+    # same function with and without the hand-over (bf16 rounding of the handed gradient is the only difference)
+    for (gon, goff) in ((g_on, g_off), (a_on, a_off)):
+        for name in (k, "encoder.input_linear.weight"):
+            rel = float((gon[name] - goff[name]).norm() / (goff[name].norm() + 1e-30))
+            assert rel < 2e-2, (name, rel)
+    # and the auxiliary term is really in there: its contribution is far above that tolerance
+    assert float((a_on[k] - g_on[k]).norm() / (g_on[k].norm() + 1e-30)) > 0.1
+    with torch.no_grad():
+        model(src, src_len, tgt)
+    assert F_._logit_handover[0] is None

@@ -33,7 +33,11 @@ def test_oracle_matches_reference_at_baseline_shape(golden_dir, name):
     for k in r["grads"]:
         if BC.noise_driven(k, emb):
             continue
-        assert e["gn"][k] < 2e-4 and e["gp"][k] < 1e-3 and e["gs"][k] < 5e-4, (k, e["gn"][k], e["gp"][k], e["gs"][k])
+        # two fp32 evaluations (the oracle's and the reference's) of a gradient whose fp32 floor against fp64 is e32 (stored by the
+        # generator): they may differ by a few floors -- matters only for the near-zero cross-attention query / key gradients of the
+        # 12 / 6-layer case (e32 up to 3.5e-4)
+        f = 4 * float(z["e32/" + k])
+        assert e["gn"][k] < max(2e-4, f) and e["gp"][k] < max(1e-3, f) and e["gs"][k] < max(5e-4, f), (k, e["gn"][k], e["gp"][k], e["gs"][k], f)
 
 
 def _dec(golden_dir):
