@@ -182,6 +182,18 @@ def _claim_logit_handover(logits):
     return slot[3] if (slot[1] == logits.data_ptr() and slot[2] == logits.numel()) else None
 
 
+_grad_mode = [False]      # torch.is_grad_enabled() at the call site of the running LinearFn (inside Function.forward it always reads False)
+
+
+def linear(x, weight, bias, out_fp32=False, mark_ready=True):
+    """LinearFn.apply with the caller's grad mode recorded: under torch.no_grad() no hand-over slot is left behind."""
+    _grad_mode[0] = torch.is_grad_enabled()
+    try:
+        return LinearFn.apply(x, weight, bias, out_fp32, mark_ready)
+    finally:
+        _grad_mode[0] = False
+
+
 class LinearFn(Function):
     @staticmethod
     def forward(ctx, x, weight, bias, out_fp32, mark_ready):
@@ -197,7 +209,7 @@ class LinearFn(Function):
         ctx.box = None
         out = y.view(*x.shape[:-1], weight.shape[0])
         _logit_handover[0] = None              # one slot, and only for the forward that has just run (never across a no_grad forward)
-        if out_fp32 and cd == torch.bfloat16 and _logit_handover_on and any(ctx.needs_input_grad):
+        if out_fp32 and cd == torch.bfloat16 and _logit_handover_on and _grad_mode[0] and any(ctx.needs_input_grad):
             # fp32 logits of a bf16 model (the vocabulary projection): the loss's backward may leave ITS part of the gradient in the
             # compute dtype, zero padded to the data-gradient kernel's stage, in this box instead of an fp32 tensor that would be cast
             # and padded here (CEFn claims the box in its forward)

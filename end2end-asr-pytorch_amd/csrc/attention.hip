@@ -223,6 +223,75 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnArgs p, int HD) {
   if (idx < total && sub == 0) p.delta[idx] = s;
 }
 
+// ================================================================================================ delta, consistent form (fp32 parity mode)
+// delta[q] = sum_k P'[q,k] dA'[q,k] / sum_k P'[q,k]   (P' = exp(S - lse) as the two backward kernels recompute it, dA' = dropout-scaled
+// dO . V_k from the same MFMA contractions; both sums in fp64).  Mathematically this is rowsum(dO * O) (the kernel above).  Numerically
+// it makes sum_k dS[q,k] = sum_k P'(dA' - delta) vanish EXACTLY whatever common factor the recomputed P' carries (lse is rounded:
+// sum P' = 1 + 2e-7), and every remaining rounding error enters multiplied by the small difference (dA' - delta).  With rowsum(dO * O)
+// the forward's rounding of O leaves a rank-one residual (delta_true - delta) * P[q,k], which the query / key projections' gradients
+// see multiplied by the MEAN key: when attention is nearly uniform over ~800 similar rows (the cross-attention of configs[3] at random
+// init: the true gradient is a difference 1e-3 of its terms) that residual dominated -- measured at cfg3_b16: 1.1e-3 - 2.4e-3 relative
+// against the fp64 oracle where the reference's own fp32 floor is 0.9e-4 - 2.4e-4; the un-normalised sum is WORSE (6.7e-3: the 2e-7 of
+// lse times delta).  Reference: torch's softmax backward, grad * P - P * sum(grad * P) (models/common_layers.py:211-225).
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_delta_consistent_kernel(AttnArgs p) {
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
+  using A = AT<T, HD>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sK = smem;
+  unsigned char* sV = smem + 64 * A::PN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, g = lane >> 4;
+  const int b = blockIdx.y / p.H, h = blockIdx.y % p.H;
+  const int q = blockIdx.x * 64 + wave * 16 + lr;
+  const T* Qb = static_cast<const T*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
+  const T* Kb = static_cast<const T*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
+  const T* Vb = static_cast<const T*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
+  const T* dOb = static_cast<const T*>(p.dO) + (int64_t)b * p.o_sb + (int64_t)h * HD;
+  uint4 qf[A::NDS], dof[A::NDS];
+#pragma unroll
+  for (int ds = 0; ds < A::NDS; ++ds) {
+    const int col0 = ds * A::KS + g * A::EPC;
+    qf[ds] = gload16<T>(Qb + (int64_t)q * p.q_st + col0, q < p.Tq && col0 < HD, p.vec);
+    dof[ds] = gload16<T>(dOb + (int64_t)q * p.o_st + col0, q < p.Tq && col0 < HD, p.vec);
+  }
+  const int64_t sidx = ((int64_t)b * p.H + h) * p.Tq + q;
+  const float lse = q < p.Tq ? p.lse[sidx] : INFINITY;
+  const int kend = key_end(p, b);
+  int kstop = kend;
+  if (p.causal) kstop = min(kend, (int)blockIdx.x * 64 + 64);
+  double acc = 0.0, accp = 0.0;
+  for (int k0 = 0; k0 < kstop; k0 += 64) {
+    __syncthreads();
+    stage_natural<T, HD>(sK, Kb, p.k_st, k0, p.Tk, p.vec);
+    stage_natural<T, HD>(sV, Vb, p.v_st, k0, p.Tk, p.vec);
+    __syncthreads();
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < A::NDS; ++ds) {
+        mma16<T>(s, frag_nat<T, HD>(sK, kf * 16 + lr, ds, g), qf[ds]);
+        mma16<T>(dp, frag_nat<T, HD>(sV, kf * 16 + lr, ds, g), dof[ds]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kg = k0 + kf * 16 + g * 4 + r;
+        float pv = 0.f;
+        if (!key_masked(p, b, kg, q, kend)) pv = expf(s[r] * p.scale - lse);
+        float da = dp[r];
+        if (p.thr) da = drop_keep(drop_row_key(seed, drop_row(p, b, h, q)), kg, p.thr) ? da * p.inv_keep : 0.f;
+        acc += (double)pv * (double)da;
+        accp += (double)pv;
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  accp += __shfl_xor(accp, 16, 64);
+  accp += __shfl_xor(accp, 32, 64);
+  if (q < p.Tq && g == 0) p.delta[sidx] = accp > 0.0 ? (float)(acc / accp) : 0.f;
+}
+
 // ================================================================================================ dQ
 template <typename T, int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -447,11 +516,14 @@ int run_fwd(const AttnArgs& p, hipStream_t s) {
 template <typename T, int HD>
 int run_bwd(const AttnArgs& p, hipStream_t s) {
   const int64_t rows = (int64_t)p.B * p.H * p.Tq;
+  const size_t l1 = lds_dq<T, HD>(), l2 = lds_dkv<T, HD>();
   if (p.parts & ASR_ATTN_DELTA) {
-    hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, p, HD);
+    if constexpr (sizeof(T) == 4)      // fp32 parity mode: the consistent form (one more pass over the keys; see the kernel's note)
+      hipLaunchKernelGGL((attn_delta_consistent_kernel<T, HD>), dim3((p.Tq + 63) / 64, p.B * p.H), dim3(256), l1, s, p);
+    else
+      hipLaunchKernelGGL((attn_delta_kernel<T>), dim3((unsigned)ceil_div64(rows, 16)), dim3(256), 0, s, p, HD);
     ASR_LAUNCH_CHECK();
   }
-  const size_t l1 = lds_dq<T, HD>(), l2 = lds_dkv<T, HD>();
   static bool granted = false;
   if (l2 > 48 * 1024 && !granted) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel<T, HD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);

@@ -218,7 +218,7 @@ class Decoder(nn.Module):
             self_attns.append(sa)
             enc_attns.append(ea)
         # with --emb_trg_sharing the embedding backward (which runs last) reports the shared weight as ready
-        pred = F_.LinearFn.apply(x, self.output_linear.weight, None, True, not tied)
+        pred = F_.linear(x, self.output_linear.weight, None, True, not tied)
         return pred, seq_out, self_attns, enc_attns
 
     def post_process_hyp(self, hyp):
@@ -233,7 +233,7 @@ class Decoder(nn.Module):
                              constant.PAD_TOKEN, True)
         for layer in self.layers:
             x, _, _ = layer(x, encoder_padded_outputs, causal_only=True)
-        return F_.LinearFn.apply(x, self.output_linear.weight, None, True, False)
+        return F_.linear(x, self.output_linear.weight, None, True, False)
 
     def _kv_cache_supported(self):
         """The incremental decoders (asr_hip/decode.py) read the full-rank projection weights of every layer; the Low-Rank

@@ -21,6 +21,11 @@ pytestmark = pytest.mark.gpu
 
 SEEDS = 64
 P = 0.1
+# 64-bit seeds spread like the product's own (asr_hip/params.py:next_seed multiplies a counter by an odd 64-bit constant).  The mask
+# functions are LINEAR in the seed's low word before mixing (csrc/attention.h:drop_row_key: seed + row * C0 + key pair), so seeds that
+# differ by a small integer d reuse the same random bits d key pairs further on -- consecutive small seeds are NOT independent draws
+# (measured: seeds 1000 + 17 s gave a residual rms z of 1.34); the training path never produces such seeds.
+SEED_LIST = [((0x1234567 + s) * 0x9E3779B97F4A7C15) & 0x7FFFFFFFFFFFFFFF for s in range(SEEDS)]
 PQ = round(P * 65536) / 65536.0
 
 
@@ -82,7 +87,7 @@ def test_attention_dropout_statistics_at_benched_shapes(ops, case):
     live = P0 > 1e-7                                                       # entries whose keep / drop is observable in the dump
     for s in range(SEEDS):
         want = s < 4                                                       # the dump is 4 x (B H Tq Tk) fp32: a few seeds are enough
-        o, _, attn = ops.attn_fwd(q, k, v, H, d, key_len=key_len, key_pad=key_pad, causal=causal, scale=scale, p=P, seed=1000 + 17 * s,
+        o, _, attn = ops.attn_fwd(q, k, v, H, d, key_len=key_len, key_pad=key_pad, causal=causal, scale=scale, p=P, seed=SEED_LIST[s],
                                   want_attn=want, o32=o32)
         acc += o32
         if want:
@@ -125,7 +130,7 @@ def test_add_ln_dropout_statistics_at_benched_shapes(ops, M):
     yf, rf = y.float(), res.float()
     for s in range(SEEDS):
         z = y.clone()
-        ops.add_ln_fwd(z, res, gamma, beta, p=P, seed=5000 + 31 * s)
+        ops.add_ln_fwd(z, res, gamma, beta, p=P, seed=SEED_LIST[s] ^ 0x5555)
         zf = z.float()
         dropped = zf == rf
         kept += int((~dropped).sum())
@@ -158,7 +163,7 @@ def test_embedding_dropout_statistics_at_benched_shape(ops):
     acc = torch.zeros_like(o0)
     kept = 0
     for s in range(SEEDS):
-        o = ops.embed_fwd(tok, table, pe, 1.0, P, 9000 + 13 * s, torch.bfloat16).float()
+        o = ops.embed_fwd(tok, table, pe, 1.0, P, SEED_LIST[s] ^ 0x3333, torch.bfloat16).float()
         kept += int((o != 0).sum())
         acc += o
     tot = SEEDS * o0.numel()
