@@ -546,23 +546,37 @@ _conv_reduce_side = os.environ.get("ASR_CONV_REDUCE_SIDE", "0") == "1"      # A/
 # following data gradient measured 7.82-7.94 vs 7.70 ms/step (both kernels are MFMA bound: sharing the CUs only slows both)
 
 
+# The full-resolution level (conv.0, conv.2, first pool) as three launches that never store a 64-channel full-resolution tensor
+# (csrc/conv_level0.hip): forward, weight side and data side of the backward.  A/B switch: 0 = the launch chain on stored activations.
+_level0 = os.environ.get("ASR_LEVEL0", "1") != "0"
+
+
 class VGGFn(Function):
     @staticmethod
     def forward(ctx, src, w0, b0, w2, b2, w5, b5, w7, b7):
         cd = ops.compute_dtype()
         src = src.contiguous().float()
-        y1 = ops.conv1_fwd(src, w0.data, b0.data, cd)
         wk2, _ = P.conv_shadow(w2)
-        # conv.2 + ReLU + MaxPool2d in one epilogue.  With selection codes (one byte per pooled element) the backward never reads the
-        # un-pooled activations again, so y2 (527 MB at the benchmark shape) is not even stored -- unless the parity tests' tap
-        # (capture_selections) or a no-code fallback needs it.
         tap = capture_selections is not None
-        fused = ops.conv3x3_relu_pool_code(y1, wk2, b2.data, w2.shape[0], keep_y=tap) if _pool_codes else None
-        if fused is not None:
-            y2, p1, c1 = fused
+        # conv.0 + ReLU recomputed inside conv.2's loader, conv.2 + ReLU + MaxPool2d + selection codes from its epilogue: the log-mel
+        # frames in, the pooled tensor out (bf16 compute; the parity tests' tap needs the stored activations)
+        lvl0 = None
+        if _level0 and _pool_codes and cd == torch.bfloat16 and not tap and w0.shape[0] == 64 and tuple(w2.shape[:2]) == (64, 64):
+            lvl0 = ops.vgg_level0_fwd(src, w0.data, b0.data, wk2, b2.data)
+        if lvl0 is not None:
+            y1 = y2 = None
+            p1, c1 = lvl0
         else:
-            y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])
-            c1 = None
+            y1 = ops.conv1_fwd(src, w0.data, b0.data, cd)
+            # conv.2 + ReLU + MaxPool2d in one epilogue.  With selection codes (one byte per pooled element) the backward never reads the
+            # un-pooled activations again, so y2 (527 MB at the benchmark shape) is not even stored -- unless the parity tests' tap
+            # (capture_selections) or a no-code fallback needs it.
+            fused = ops.conv3x3_relu_pool_code(y1, wk2, b2.data, w2.shape[0], keep_y=tap) if _pool_codes else None
+            if fused is not None:
+                y2, p1, c1 = fused
+            else:
+                y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])
+                c1 = None
         wk5, _ = P.conv_shadow(w5)
         y3 = ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True)
         wk7, _ = P.conv_shadow(w7)
@@ -623,6 +637,16 @@ class VGGFn(Function):
         P.grad_ready(w5, b5)
         _, wd5 = P.conv_shadow(w5)
         dp1 = ops.conv3x3(dy3, wd5, None, w5.shape[1], relu=False)
+        if y1 is None:
+            # full-resolution level from the frames, the pooled gradient and the selection codes (forward ran asr_vgg_level0_fwd)
+            ops.vgg_level0_wgrad(src, w0.data, b0.data, dp1, c1, P.grad_of(w2), P.grad_of(b2))
+            P.grad_ready(w2, b2)
+            _, wd2 = P.conv_shadow(w2)
+            ops.vgg_level0_dgrad(dp1, c1, src, w0.data, b0.data, wd2, P.grad_of(w0), P.grad_of(b0))
+            P.grad_ready(w0, b0)
+            for f in forks:
+                f.join()
+            return (None,) * 9
         dy2 = ops.maxpool_bwd_code(c1, dp1, tuple(y1.shape[:3]) + (w2.shape[0],), tcf=False) if c1 is not None else ops.maxpool_bwd(y2, dp1)
         wgrad(y1, dy2, w2, b2, "c2")
         P.grad_ready(w2, b2)

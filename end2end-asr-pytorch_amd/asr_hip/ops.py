@@ -946,6 +946,48 @@ def conv3x3_relu_pool_code(x, wk, bias, Cout, keep_y=False):
     return y, pool, code
 
 
+def vgg_level0_fwd(src, w0, b0, wk2, b2):
+    """(pool (B, H/2, W/2, 64) bf16, code uint8) = MaxPool(ReLU(conv.2(ReLU(conv.0(src))))) from ONE launch that never stores a
+    full-resolution 64-channel tensor (csrc/conv_level0.hip); src (B, 1, H, W) or (B, H, W) fp32.  None when the library does not
+    take the shape."""
+    src3 = src.reshape(src.shape[0], src.shape[-2], src.shape[-1])
+    assert src3.is_contiguous() and src3.dtype == torch.float32 and w0.shape[0] == 64
+    B, H, W = src3.shape
+    pool = torch.empty((B, H // 2, W // 2, 64), device=src.device, dtype=torch.bfloat16)
+    code = torch.empty((B, H // 2, W // 2, 64), device=src.device, dtype=torch.uint8)
+    rc = L.load().asr_vgg_level0_fwd(L.ptr(src3), L.ptr(w0), L.ptr(b0), L.ptr(wk2), L.ptr(b2), L.ptr(pool), L.ptr(code), B, H, W, L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_vgg_level0_fwd")
+    return pool, code
+
+
+def _level0_ws(B, H, W, device):
+    n = L.load().asr_vgg_level0_bwd_workspace(B, H, W)
+    return workspace("wgrad_ws", (max(int(n), 1),), torch.float32, device, zero=False), int(n)      # the conv weight gradients' shared scratch
+
+
+def vgg_level0_dgrad(dpool, code, src, w0, b0, wd2, dw0, db0):
+    """dw0 += , db0 += : conv.2's data gradient of the pooled gradient (expanded through the codes in the kernel), conv.0's ReLU mask
+    recomputed, contracted against the frames -- no full-resolution gradient tensor exists."""
+    src3 = src.reshape(src.shape[0], src.shape[-2], src.shape[-1])
+    B, H, W = src3.shape
+    assert dpool.is_contiguous() and code.is_contiguous() and tuple(dpool.shape) == (B, H // 2, W // 2, 64)
+    ws, n = _level0_ws(B, H, W, src.device)
+    L.call("asr_vgg_level0_dgrad", L.ptr(dpool), L.ptr(code), L.ptr(src3), L.ptr(w0), L.ptr(b0), L.ptr(wd2), L.ptr(dw0), L.ptr(db0),
+           L.ptr(ws), n, B, H, W, L.stream())
+
+
+def vgg_level0_wgrad(src, w0, b0, dpool, code, dw2, db2):
+    """dw2 += , db2 += for conv.2 from ReLU(conv.0(src)) recomputed on halo patches and the expanded pooled gradient."""
+    src3 = src.reshape(src.shape[0], src.shape[-2], src.shape[-1])
+    B, H, W = src3.shape
+    assert dpool.is_contiguous() and code.is_contiguous()
+    ws, n = _level0_ws(B, H, W, src.device)
+    L.call("asr_vgg_level0_wgrad", L.ptr(src3), L.ptr(w0), L.ptr(b0), L.ptr(dpool), L.ptr(code), L.ptr(dw2), L.ptr(db2), L.ptr(ws), n,
+           B, H, W, L.stream())
+
+
 def conv3x3_relu_pool_tcf_code(x, wk, bias, Cout):
     """(pool (B, W/2, Cout * H/2), code): the encoder-layout max-pool of ReLU(conv3x3(x) + bias) and its selection bytes from the
     convolution's own epilogue (the un-pooled output is never stored); None when the library has no fused form for this shape."""

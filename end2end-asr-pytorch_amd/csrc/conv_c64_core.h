@@ -1,0 +1,76 @@
+// Shared pieces of the persistent 64 -> 64 channel kernels (conv_c64.hip: conv.2 forward / data gradient on stored activations;
+// conv_level0.hip: the same contractions with the halo patch PRODUCED in LDS -- conv.0 recomputed from the log-mel frames, or the
+// pooled gradient expanded through its selection codes).  See conv_c64.hip for the design notes.
+#pragma once
+#include "common.h"
+
+#include <utility>
+
+namespace {
+
+__device__ const uint4 c64_zero_page = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((ext_vector_type(2))) float c64_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 c64_bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b) {      // one v_cvt_pk_bf16_f32
+  const c64_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, c64_bf16x2_t));
+}
+
+__device__ __forceinline__ void lds_read16(u32x4_t& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+}
+
+// k step S = (tap, 32-channel half): the 4 pixel-fragment operands of the step.  Address = the lane's register for this
+// (dx, half) -- buffer base + wave / lane part + swizzled chunk -- plus a compile-time (fragment, tap) offset (instruction immediate).
+template <int S, int PW, int CB>
+__device__ __forceinline__ void c64_issue(u32x4_t (&dst)[4], const unsigned (&pbd)[3][2]) {
+  constexpr int tap = S >> 1, ms = S & 1, dy = tap / 3, dx = tap % 3;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    asm volatile("ds_read_b128 %0, %1 offset:%2"
+                 : "=v"(dst[i])
+                 : "v"(pbd[dx][ms]), "n"((((i / CB) + dy) * PW + (i % CB) * 16 + dx) * 128));
+}
+
+// FLIP = false: A = weights (rows = output channels), B = pixels: a lane owns 4 channels of ONE pixel (the NHWC store epilogue).
+// FLIP = true : A = pixels, B = weights: a lane owns 4 consecutive PIXELS of one channel -- the accumulator fragment is then itself the
+// B operand (k = pixel) of a 16x16x16 contraction over the pixels (conv_level0.hip: the first layer's weight gradient from the tile).
+template <int S, int PW, int CB, bool FLIP = false>
+__device__ __forceinline__ void c64_step(f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4], const u32x4_t (&wB)[9][2][2],
+                                         const unsigned (&pbd)[3][2], u32x4_t (&bq)[2]) {
+  u32x4_t(&cur)[4] = a[S & 1];
+  if constexpr (S == 0) {
+    c64_issue<S + 1, PW, CB>(a[(S + 1) & 1], pbd);
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(bq[0]), "+v"(bq[1]));
+  } else if constexpr (S + 1 < 18) {
+    c64_issue<S + 1, PW, CB>(a[(S + 1) & 1], pbd);           // next step's operands in flight under this step's MFMAs
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+  }
+  constexpr int tap = S >> 1, ms = S & 1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)      // the first step starts every accumulator from the bias of its 4 output channels
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, FLIP ? cur[i] : wB[tap][ms][j]),
+                                                          __builtin_bit_cast(bf16x8_t, FLIP ? wB[tap][ms][j] : cur[i]),
+                                                          S == 0 ? __builtin_bit_cast(f32x4_t, bq[j]) : acc[i][j], 0, 0, 0);
+}
+
+template <int PW, int CB, bool FLIP = false, int... S>
+__device__ __forceinline__ void c64_steps(std::integer_sequence<int, S...>, f32x4_t (&acc)[4][2], u32x4_t (&a)[2][4],
+                                          const u32x4_t (&wB)[9][2][2], const unsigned (&pbd)[3][2], u32x4_t (&bq)[2]) {
+  (c64_step<S, PW, CB, FLIP>(acc, a, wB, pbd, bq), ...);
+}
+
+// 2 bf16 of `o` zeroed where the mask element is not > 0 (packed 16-bit integer ops: a bf16 is > 0 iff its bits are > 0 as int16;
+// op_sel_hi:[0,1]: the high lane takes the shift count from the LOW half of the inline constant too)
+__device__ __forceinline__ uint32_t c64_mask2(uint32_t o, uint32_t m) {
+  uint32_t t;
+  asm("v_pk_max_i16 %0, %1, 0\n\tv_pk_sub_i16 %0, 0, %0\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(t) : "v"(m));
+  return o & t;
+}
+
+}  // namespace

@@ -1,0 +1,961 @@
+// The full-resolution level of vgg_cnn without its full-resolution activations (reference: models/asr/transformer.py:42-47 --
+// conv.0 (1 -> 64) + ReLU, conv.2 (64 -> 64) + ReLU, MaxPool2d(2, 2) -- and their autograd).
+//
+// At the benchmark shape (B = 32, 161 x 800) every 64-channel full-resolution tensor is 528 MB in bf16, and the level used to move
+// 5.3 GB per step through HBM: conv.0 wrote y1, conv.2 read it, the pooling backward expanded the 131 MB pooled gradient into 528 MB,
+// conv.2's weight gradient read that and y1, its data gradient read it again plus y1 as the ReLU mask and wrote dy1, and conv.0's
+// weight gradient read dy1 (the data gradient alone: 1.73 GB in 307 us = 5.6 TB/s, HBM-bound at 39 % of the MFMA peak).  None of those
+// tensors carries information that is not in the 16.5 MB of log-mel frames, the 131 MB pooled tensor and its selection codes:
+//
+//   forward  (vgg_level0_fwd_kernel)    src -> [conv.0 + ReLU as a K = 32 MFMA per 16 pixels, straight into the LDS halo patch]
+//                                           -> conv.2 (register-resident weights, conv_c64_core.h) -> ReLU -> pool + selection codes
+//   dgrad    (vgg_level0_dgrad_kernel)  pooled gradient + codes -> [expanded into the LDS halo patch] -> conv.2 data gradient
+//                                           -> ReLU mask of conv.0 RECOMPUTED for the tile -> dW0 / db0 contracted from the tile in
+//                                           registers (16x16x16 MFMAs over the pixels); dy1 is never stored
+//   wgrad    (vgg_level0_wgrad_kernel)  src -> [conv.0 + ReLU into the LDS patch], pooled gradient + codes -> [expanded dY tile]
+//                                           -> the 64 x 64 x 9 weight-gradient block of conv_wgrad_dma.hip
+//
+// conv.0 as an MFMA: per output pixel the contraction index is (tap row ky = lane group, slot): slots {hi(x[ky][0..2]), 0, lo(x[ky][0..2]), 0}
+// of the fp32 frame value split x = hi + lo into two bf16 (hi = truncation, lo = round(x - hi): 16 mantissa bits), against the weight
+// rounded to bf16 twice (w = whi + wlo: the second MFMA adds hi(x) * wlo), bias as the accumulator's initial value: products exact
+// to 2^-16, fp32 accumulation -- the fp32 vector-ALU kernel it replaces (conv1_fwd) agrees to rounding of the bf16 result.
+// The frame patch (12 x 20 values per 8 x 16 tile) arrives by 4-byte LDS-DMA and is split in place by the thread that fetched it.
+#include "common.h"
+#include "conv_c64_core.h"
+#include "conv_level0.h"
+
+#include <utility>
+
+extern "C" int asr_conv3x3_wgrad_reduce(const float* workspace, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t s);
+
+namespace {
+
+constexpr int L0_PB = 180 * 128;        // halo patch of 64 bf16 channels: 10 x 18 pixels, 16-B chunk c of the pixel in patch column x in slot c ^ (x & 7)
+constexpr int L0_SS = 1536;             // frame patch buffer: 12 x 20 packed (hi << 16 | lo) dwords (960 B, padded to 1024), 256 B of (1.0 | 0), 256 B of zeros
+constexpr int L0_WM = 8192;             // conv.0 weights as MFMA operands: [channel fragment 4][whi, wlo][64 lanes][16 B]
+
+typedef __attribute__((ext_vector_type(4))) short l0_s16x4_t;
+
+#define L0_FENCE() asm volatile("" ::: "memory")
+
+// LDS-DMA issued by hand (M0 saved / restored; the compiler neither counts these loads nor drains them before its own LDS reads)
+__device__ __forceinline__ void l0_dma4(unsigned lds_wave_base, const void* src) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_wave_base), "v"(src) : "memory");
+}
+__device__ __forceinline__ void l0_dma16(unsigned lds_wave_base, const void* src) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_wave_base), "v"(src) : "memory");
+}
+
+// fp32 frame value -> (hi << 16) | lo, hi = the top 16 bits (a bf16, exact), lo = bf16(x - hi)
+__device__ __forceinline__ uint32_t l0_split(float x) {
+  const uint32_t xb = __float_as_uint(x), hb = xb & 0xffff0000u;
+  return hb | (uint32_t)f32_to_bf16(x - __uint_as_float(hb));
+}
+
+// One conv.0 operand of a pixel: the lane's tap row (3 packed frame values at p, p + 4, p + 8) -> slots {hi0, hi1, hi2, 0, lo0, lo1, lo2, 0}
+__device__ __forceinline__ u32x4_t l0_frame_operand(const unsigned char* p) {
+  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(p), d1 = *reinterpret_cast<const uint32_t*>(p + 4),
+                 d2 = *reinterpret_cast<const uint32_t*>(p + 8);
+  u32x4_t r;
+  r[0] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+  r[1] = __builtin_amdgcn_perm(0u, d2, 0x0C0C0302u);
+  r[2] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
+  r[3] = __builtin_amdgcn_perm(0u, d2, 0x0C0C0100u);
+  return r;
+}
+
+// conv.0 weights of output channel `co`, tap row g (0..2; lane group 3 contributes nothing) as the matching operand pair
+__device__ __forceinline__ void l0_weight_operands(const float* w0, int co, int g, u32x4_t& hi, u32x4_t& lo) {
+  hi = u32x4_t{0u, 0u, 0u, 0u};
+  lo = hi;
+  if (g < 3) {
+    uint32_t h[3], l[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float w = w0[co * 9 + g * 3 + j];
+      h[j] = f32_to_bf16(w);
+      l[j] = f32_to_bf16(w - bf16_to_f32((bf16_t)h[j]));
+    }
+    hi[0] = h[0] | (h[1] << 16); hi[1] = h[2]; hi[2] = hi[0]; hi[3] = hi[1];
+    lo[0] = l[0] | (l[1] << 16); lo[1] = l[2];
+  }
+}
+
+// tile walk of the persistent kernels: origins advance by a fixed (images, tile rows, tile columns) step with carries (conv_c64.hip)
+struct L0Org { int b, h0, w0; };
+struct L0Walk {
+  int dtw, dth, db, wlim, hlim;
+  __device__ __forceinline__ void init(int nwg, int tiles_w, int tiles_h) {
+    dtw = (nwg % tiles_w) * 16;
+    const int q1 = nwg / tiles_w;
+    dth = (q1 % tiles_h) * 8;
+    db = q1 / tiles_h;
+    wlim = tiles_w * 16; hlim = tiles_h * 8;
+  }
+  __device__ __forceinline__ void advance(L0Org& o) const {
+    o.w0 += dtw;
+    const bool c1 = o.w0 >= wlim;
+    o.w0 -= c1 ? wlim : 0;
+    o.h0 += dth + (c1 ? 8 : 0);
+    const bool c2 = o.h0 >= hlim;
+    o.h0 -= c2 ? hlim : 0;
+    o.b += db + (c2 ? 1 : 0);
+  }
+  __device__ __forceinline__ void first(L0Org& o, int t, int tiles_w, int tiles_h) const {
+    o.w0 = (t % tiles_w) * 16; t /= tiles_w;
+    o.h0 = (t % tiles_h) * 8; o.b = t / tiles_h;
+  }
+};
+
+// the frame patch of a tile (rows h0 - 2 .. h0 + 9, columns w0 - 2 .. w0 + 17; zeros outside the image): one 4-byte DMA per thread
+__device__ __forceinline__ void l0_stage_frames(const L0Args& p, const L0Org& o, unsigned sbuf_lds, int tid, int wave_u) {
+  if (tid < 240) {
+    const int sr = tid / 20, sc = tid - sr * 20;
+    const int gy = o.h0 + sr - 2, gx = o.w0 + sc - 2;
+    const bool in = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const float* s = in ? p.src + ((int64_t)o.b * p.H + gy) * p.W + gx : reinterpret_cast<const float*>(&c64_zero_page);
+    l0_dma4(sbuf_lds + (unsigned)wave_u * 256u, s);
+  }
+}
+__device__ __forceinline__ void l0_split_frames(unsigned char* sbuf, int tid) {      // after the thread's own DMA has landed
+  if (tid < 240) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(sbuf) + tid;
+    *q = l0_split(__uint_as_float(*q));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- conv.0 + ReLU into a halo patch
+// 180 halo pixels = 12 fragments of 16 (the last one 4 pixels); fragment f, lane lr <-> halo pixel hp = 16 f + lr = patch (hp / 18, hp % 18).
+// Swapped operands (A = weights): a lane gets 4 consecutive channels of ONE pixel = 8 bytes of the pixel's 128-byte patch row.
+struct L0GenLane {          // per (lane, fragment) addressing, recomputed per tile (a dozen vector instructions; 36 registers if kept)
+  int gaddr;                // frame-patch byte offset of the lane's tap row for this pixel
+  int waddr;                // patch byte offset of the lane's 8 output bytes for channel fragment 0 (other fragments: ^ (cf << 5))
+  int prc;                  // patch row | patch column << 8 | (hp < 180) << 16
+  __device__ __forceinline__ void init(int f, int lr, int g) {
+    const int hp = f * 16 + lr, hpc = hp < 180 ? hp : 179;
+    const int pr = (hpc * 3641) >> 16, pc = hpc - pr * 18;          // hpc / 18 for hpc < 192
+    gaddr = (hpc + 2 * pr + 20 * (g < 3 ? g : 2)) * 4;              // ((pr + tap row) * 20 + pc) * 4
+    waddr = hpc * 128 + ((((g >> 1) ^ (pc & 7))) << 4) + (g & 1) * 8;
+    prc = pr | (pc << 8) | ((hp < 180 ? 1 : 0) << 16);
+  }
+};
+
+// One unit = (16 halo pixels) x (16 channels), in two stages so that a caller can run the MFMAs of several units back to back and
+// convert / store behind them (a unit alone is a chain MFMA -> MFMA -> convert -> ReLU -> store of ~190 cycles; twelve of them in
+// sequence cost as much as the tile's 144 main MFMAs -- in-kernel section timing, profiles/r04_level0_structure_ab.txt).
+template <bool WSPLIT>
+__device__ __forceinline__ f32x4_t l0_gen_mfma(const u32x4_t& bop, const u32x4_t& whi, const u32x4_t& wlo, const f32x4_t& bias) {
+  f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, whi), __builtin_bit_cast(bf16x8_t, bop), bias, 0, 0, 0);
+  if (WSPLIT) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wlo), __builtin_bit_cast(bf16x8_t, bop), a, 0, 0, 0);
+  return a;
+}
+// `wa`: the lane's output offset for channel fragment 0 -- L0GenLane::waddr, or the offset of a 128-byte dump area for the lanes of the
+// last fragment that lie past the patch (an address select instead of a branch keeps the units in ONE basic block)
+__device__ __forceinline__ void l0_gen_store(unsigned char* ypatch, int wa, const f32x4_t& a, int cf, uint32_t vmask) {
+  // halo pixels outside the image are conv.2's zero padding (vmask), not conv.0 of padded frames
+  uint32_t pa = pack_bf16(a[0], a[1]), pb = pack_bf16(a[2], a[3]);
+  asm("v_pk_max_i16 %0, %0, 0" : "+v"(pa));          // ReLU on the bf16 bit patterns (conv_c64.hip); plain asm: free to be scheduled
+  asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb));
+  *reinterpret_cast<uint2*>(ypatch + (wa ^ (cf << 5))) = make_uint2(pa & vmask, pb & vmask);
+}
+__device__ __forceinline__ uint32_t l0_halo_valid(const L0Args& p, const L0Org& o, int prc) {
+  const int gy = o.h0 + (prc & 0xff) - 1, gx = o.w0 + ((prc >> 8) & 0xff) - 1;
+  return ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
+}
+
+// pooled 2 x 2 max + selection codes from the accumulators of an 8 x 16 tile (the POOL epilogue of conv3x3_c64_kernel, y never stored)
+__device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)[4][2], int tl, int b, int h0, int w0, int co0) {
+  uint32_t keep[4][2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      uint32_t pa = pack_bf16(acc[i][0][2 * d], acc[i][0][2 * d + 1]);
+      uint32_t pb2 = pack_bf16(acc[i][1][2 * d], acc[i][1][2 * d + 1]);
+      asm("v_pk_max_i16 %0, %0, 0" : "+v"(pa));
+      asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb2));
+      keep[i][0][d] = pa; keep[i][1][d] = pb2;
+    }
+  const int H2 = p.H >> 1, W2 = p.W >> 1;
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    uint32_t lo[2], hi[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      uint32_t va = keep[2 * pr][0][d], vb = keep[2 * pr][1][d];
+      asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(keep[2 * pr + 1][0][d]));
+      asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(keep[2 * pr + 1][1][d]));
+      const uint32_t na = (uint32_t)__builtin_amdgcn_mov_dpp((int)va, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: lane ^ 1
+      const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)vb, 0xB1, 0xf, 0xf, true);
+      asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(na));
+      asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(nb));
+      auto sw = __builtin_amdgcn_permlane16_swap(va, vb, false, false);
+      lo[d] = sw[0]; hi[d] = sw[1];
+    }
+    const int prow = (h0 >> 1) + (tl >> 7) * 2 + pr, pcol = (w0 >> 1) + ((tl & 15) >> 1);
+    const int64_t pidx = (((int64_t)b * H2 + prow) * W2 + pcol) * 64 + co0;
+    const bool st = !(tl & 1) && prow < H2 && pcol < W2;
+    if (st) *reinterpret_cast<uint4*>(p.pool + pidx) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
+    uint32_t clo[2], chi[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      uint32_t cw[2];
+#pragma unroll
+      for (int cf = 0; cf < 2; ++cf) {
+        const uint32_t mine0 = keep[2 * pr][cf][d], mine1 = keep[2 * pr + 1][cf][d];
+        const uint32_t oth0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine0, 0xB1, 0xf, 0xf, true);
+        const uint32_t oth1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine1, 0xB1, 0xf, 0xf, true);
+        const bool odd = (tl & 1) != 0;
+        const uint32_t v0 = odd ? oth0 : mine0, v1 = odd ? mine0 : oth0, v2 = odd ? oth1 : mine1, v3 = odd ? mine1 : oth1;
+        uint32_t m = v0;
+        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v1));
+        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v2));
+        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v3));
+        const uint32_t one = 0x00010001u;
+        uint32_t n0 = v0 ^ m, n1 = v1 ^ m, n2 = v2 ^ m, nz = m;
+        asm("v_pk_min_u16 %0, %0, %1" : "+v"(n0) : "v"(one));
+        asm("v_pk_min_u16 %0, %0, %1" : "+v"(n1) : "v"(one));
+        asm("v_pk_min_u16 %0, %0, %1" : "+v"(n2) : "v"(one));
+        asm("v_pk_min_u16 %0, %0, %1" : "+v"(nz) : "v"(one));
+        const uint32_t n01 = n0 & n1, n012 = n01 & n2;
+        uint32_t c = one + n0 + n01 + n012;
+        asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(c) : "v"(nz));
+        cw[cf] = c;
+      }
+      auto sw = __builtin_amdgcn_permlane16_swap(cw[0], cw[1], false, false);
+      clo[d] = sw[0]; chi[d] = sw[1];
+    }
+    if (st) {
+      const uint32_t b0 = __builtin_amdgcn_perm(clo[1], clo[0], 0x06040200u), b1 = __builtin_amdgcn_perm(chi[1], chi[0], 0x06040200u);
+      *reinterpret_cast<uint2*>(p.code + pidx) = make_uint2(b0, b1);
+    }
+  }
+}
+
+// ================================================================================================ forward
+template <bool WSPLIT>
+__global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
+  constexpr int PW = 18, CB = 1;
+  constexpr int S_OFF = 2 * L0_PB, WM_OFF = S_OFF + 2 * L0_SS, B0_OFF = WM_OFF + L0_WM, B2_OFF = B0_OFF + 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nwg = gridDim.x;
+  const int vid = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int cnt = vid < p.ntiles ? (p.ntiles - vid + nwg - 1) / nwg : 0;
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // conv.2 weights: A operand of every main MFMA, resident in registers
+  u32x4_t wB[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wB[tap][ms][j] = *reinterpret_cast<const u32x4_t*>(p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * 64 + ms * 32 + g * 8);
+  {   // conv.0 operands (wave = channel fragment) and both biases into LDS
+    u32x4_t hi, lo;
+    l0_weight_operands(p.w0, wave * 16 + lr, g, hi, lo);
+    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 0) * 64 + lane) * 16) = hi;
+    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 1) * 64 + lane) * 16) = lo;
+    if (tid < 64) {
+      reinterpret_cast<float*>(smem + B0_OFF)[tid] = p.b0 ? p.b0[tid] : 0.f;
+      reinterpret_cast<float*>(smem + B2_OFF)[tid] = p.b2 ? p.b2[tid] : 0.f;
+    }
+  }
+  L0Walk walk;
+  walk.init(nwg, p.tiles_w, p.tiles_h);
+  L0Org org[3];
+  walk.first(org[0], vid, p.tiles_w, p.tiles_h);
+  org[1] = org[0]; walk.advance(org[1]);
+  org[2] = org[1]; walk.advance(org[2]);
+
+  const int co0 = wn * 32 + (g & 1) * 16 + (g & 2) * 4;
+
+  auto generate = [&](int yb, int sb, const L0Org& o) __attribute__((always_inline)) {
+    unsigned char* yp = smem + yb * L0_PB;
+    const unsigned char* sp = smem + S_OFF + sb * L0_SS;
+    const bool inside = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 9 <= p.H && o.w0 + 17 <= p.W;
+    int lrl = lr;
+    asm volatile("" : "+v"(lrl));       // (recomputed per tile on purpose: see L0GenLane)
+    u32x4_t bop[3];
+    uint32_t vm[3];
+    int wa[3];
+#pragma unroll
+    for (int fi = 0; fi < 3; ++fi) {
+      L0GenLane gl;
+      gl.init(wave * 3 + fi, lrl, g);
+      bop[fi] = l0_frame_operand(sp + gl.gaddr);
+      vm[fi] = inside ? 0xffffffffu : l0_halo_valid(p, o, gl.prc);
+      wa[fi] = (gl.prc & 0x10000) ? gl.waddr : (S_OFF + 1024 - yb * L0_PB);      // dump area: the unused tail of frame buffer 0
+    }
+    // two halves of two channel fragments: every LDS read of a half first, then its 6 + 6 MFMAs back to back (six independent
+    // accumulator chains: the second MFMA of a chain issues 96 cycles after the first), then the six convert / store tails
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      u32x4_t wh[2], wl[2];
+      f32x4_t acc6[2][3];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int cf = 2 * h + c;
+        wh[c] = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + ((cf * 2 + 0) * 64 + lane) * 16);
+        wl[c] = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + ((cf * 2 + 1) * 64 + lane) * 16);
+        acc6[c][0] = acc6[c][1] = acc6[c][2] = *reinterpret_cast<const f32x4_t*>(smem + B0_OFF + (cf * 16 + 4 * g) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi)
+          acc6[c][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wh[c]), __builtin_bit_cast(bf16x8_t, bop[fi]), acc6[c][fi], 0, 0, 0);
+      if (WSPLIT) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int fi = 0; fi < 3; ++fi)
+            acc6[c][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[c]), __builtin_bit_cast(bf16x8_t, bop[fi]), acc6[c][fi], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int fi = 0; fi < 3; ++fi) l0_gen_store(yp, wa[fi], acc6[c][fi], 2 * h + c, vm[fi]);
+    }
+  };
+
+  if (cnt > 0) l0_stage_frames(p, org[0], smem_base + S_OFF, tid, wave_u);
+  if (cnt > 1) l0_stage_frames(p, org[1], smem_base + S_OFF + L0_SS, tid, wave_u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  l0_split_frames(smem + S_OFF, tid);
+  l0_split_frames(smem + S_OFF + L0_SS, tid);
+  __syncthreads();
+  if (cnt > 0) generate(0, 0, org[0]);
+
+  unsigned pbd[3][2];           // operand addresses of the CURRENT tile's patch buffer (toggled per tile, not re-derived from a second copy)
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+      pbd[dx][ms] = smem_base + (unsigned)((((wm * 4) / CB) * PW + ((wm * 4) % CB) * 16 + lr) * 128) +
+                    (unsigned)(((ms * 4 + g) ^ ((lr + dx) & 7)) << 4);
+
+  for (int n = 0; n < cnt; ++n) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's patch / frame-split writes are in LDS
+    __builtin_amdgcn_s_barrier();       // patch n complete, frame patch n + 1 split; everybody is done with tile n - 1
+    L0_FENCE();
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (n + 2 < cnt) l0_stage_frames(p, org[2], smem_base + S_OFF + (unsigned)((n & 1) * L0_SS), tl, wave_u);
+    if (n + 1 < cnt) generate((n + 1) & 1, (n + 1) & 1, org[1]);
+    L0_FENCE();
+
+    u32x4_t bq[2];
+    const unsigned bias_addr = smem_base + (unsigned)(B2_OFF + (((tl >> 6) & 1) * 32 + 4 * ((tl >> 4) & 3)) * 4);
+    lds_read16(bq[0], bias_addr);
+    lds_read16(bq[1], bias_addr + 64);
+    f32x4_t acc[4][2];
+    u32x4_t a[2][4];
+    c64_issue<0, PW, CB>(a[0], pbd);
+    c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);
+
+    L0_FENCE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // frame patch n + 2 (issued a whole tile ago) -- and last tile's stores
+    if (n + 2 < cnt) l0_split_frames(smem + S_OFF + (n & 1) * L0_SS, tl);
+    l0_pool_epilogue(p, acc, tl, org[0].b, org[0].h0, org[0].w0, ((tl >> 6) & 1) * 32 + ((tl >> 4) & 1) * 16 + ((tl >> 4) & 2) * 4);
+    org[0] = org[1]; org[1] = org[2];
+    walk.advance(org[2]);
+    const unsigned flip = (n & 1) ? (unsigned)(-L0_PB) : (unsigned)L0_PB;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] += flip;
+  }
+}
+
+// ================================================================================================ data gradient + dW0 / db0
+// Pooled gradient patch of an 8 x 16 tile's halo: pooled rows h0/2 - 1 .. h0/2 + 4, columns w0/2 - 1 .. w0/2 + 8 (60 pooled pixels):
+// values 60 x 128 B and selection codes 60 x 64 B by 16-byte DMA, then every (pooled pixel, 8-channel chunk) item is expanded into
+// its four window positions of the halo patch: out[k] = value where code == 1 + k.
+constexpr int L0_PV = 60 * 128, L0_PST = 60 * 192;      // staged bytes: values, values + codes
+
+__device__ __forceinline__ void l0_stage_pooled(const L0Args& p, const L0Org& o, unsigned pst_lds, int t, int wave_u) {
+  const int H2 = p.H >> 1, W2 = p.W >> 1;
+  const int ph0 = (o.h0 >> 1) - 1, pw0 = (o.w0 >> 1) - 1;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(&c64_zero_page);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int ci = t + it * 256;
+    if (ci < 480) {
+      const int q = ci >> 3, c = ci & 7, qr = q / 10, qc = q - qr * 10;
+      const int ph = ph0 + qr, pw = pw0 + qc;
+      const bool in = (unsigned)ph < (unsigned)H2 && (unsigned)pw < (unsigned)W2;
+      const unsigned char* s = in ? reinterpret_cast<const unsigned char*>(p.dpool) + ((((int64_t)o.b * H2 + ph) * W2 + pw) * 64 + c * 8) * 2 : zero;
+      l0_dma16(pst_lds + (unsigned)(it * 4096) + (unsigned)wave_u * 1024u, s);
+    }
+  }
+  if (t < 240) {
+    const int q = t >> 2, qr = q / 10, qc = q - qr * 10;
+    const int ph = ph0 + qr, pw = pw0 + qc;
+    const bool in = (unsigned)ph < (unsigned)H2 && (unsigned)pw < (unsigned)W2;
+    const unsigned char* s = in ? p.code + (((int64_t)o.b * H2 + ph) * W2 + pw) * 64 + (t & 3) * 16 : zero;
+    l0_dma16(pst_lds + (unsigned)L0_PV + (unsigned)wave_u * 1024u, s);
+  }
+}
+
+// selection codes of 8 channels (8 bytes) -> for window position k the 16-bit keep masks of the 8 channels (4 dwords)
+struct L0CodeMasks {
+  uint32_t oh[4];           // per 16-bit half: 1 << code
+  __device__ __forceinline__ void init(uint2 k) {
+    uint32_t c16[4];
+    c16[0] = __builtin_amdgcn_perm(0u, k.x, 0x0C010C00u);
+    c16[1] = __builtin_amdgcn_perm(0u, k.x, 0x0C030C02u);
+    c16[2] = __builtin_amdgcn_perm(0u, k.y, 0x0C010C00u);
+    c16[3] = __builtin_amdgcn_perm(0u, k.y, 0x0C030C02u);
+    const uint32_t one = 0x00010001u;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(oh[d]) : "v"(c16[d]), "v"(one));
+  }
+  template <int K>          // K = 1 + window position: bit K of the one-hot word, spread over the half
+  __device__ __forceinline__ uint32_t mask(int d) const {
+    uint32_t m;
+    asm("v_pk_lshlrev_b16 %0, %2, %1 op_sel_hi:[0,1]\n\tv_pk_ashrrev_i16 %0, 15, %0 op_sel_hi:[0,1]" : "=&v"(m) : "v"(oh[d]), "n"(15 - K));
+    return m;
+  }
+};
+
+template <bool WSPLIT>
+__global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
+  constexpr int PW = 18, CB = 1;
+  constexpr int PST_OFF = 2 * L0_PB, S_OFF = PST_OFF + 2 * L0_PST, WM_OFF = S_OFF + 2 * L0_SS, B0_OFF = WM_OFF + L0_WM, DUMP_OFF = B0_OFF + 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int nwg = gridDim.x;
+  const int vid = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int cnt = vid < p.ntiles ? (p.ntiles - vid + nwg - 1) / nwg : 0;
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  // tap-flipped conv.2 weights (ci, flipped tap, co): here the B operand (columns = input channels of conv.2 = this kernel's outputs)
+  u32x4_t wB[9][2][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wB[tap][ms][j] = *reinterpret_cast<const u32x4_t*>(p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * 64 + ms * 32 + g * 8);
+  {
+    u32x4_t hi, lo;
+    l0_weight_operands(p.w0, wave * 16 + lr, g, hi, lo);
+    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 0) * 64 + lane) * 16) = hi;
+    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 1) * 64 + lane) * 16) = lo;
+    if (tid < 64) {
+      reinterpret_cast<float*>(smem + B0_OFF)[tid] = p.b0 ? p.b0[tid] : 0.f;
+#pragma unroll
+      for (int sb = 0; sb < 2; ++sb) {
+        reinterpret_cast<uint32_t*>(smem + S_OFF + sb * L0_SS + 1024)[tid] = 0x3F800000u;      // (hi, lo) = (1.0, 0): the bias-gradient row
+        reinterpret_cast<uint32_t*>(smem + S_OFF + sb * L0_SS + 1280)[tid] = 0u;
+        if (tid < 16) reinterpret_cast<uint32_t*>(smem + S_OFF + sb * L0_SS + 960)[tid] = 0u;
+      }
+    }
+  }
+  L0Walk walk;
+  walk.init(nwg, p.tiles_w, p.tiles_h);
+  L0Org org[3];
+  walk.first(org[0], vid, p.tiles_w, p.tiles_h);
+  org[1] = org[0]; walk.advance(org[1]);
+  org[2] = org[1]; walk.advance(org[2]);
+
+  // expansion items of this thread: (pooled pixel q, chunk c) = tid and tid + 256 (< 480).  xa[it][dx]: patch byte offset of window
+  // column dx in window row 0 (row 1: + 18 * 128); flags: bit 0/1 = window row 0/1 inside the patch, bit 2/3 = column 0/1
+  // xa[it][dx] (multiples of 16) carry the validity flags in their low bits: xa[it][0] bit 0/1 = window row 0/1 inside the patch,
+  // bit 2 = window column 0 inside; xa[it][1] bit 0 = window column 1 inside, bit 1 = the item exists
+  int xa[2][2];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int item = tid + it * 256, q = item >> 3, c = item & 7, qr = q / 10, qc = q - qr * 10;
+    const int rowbase = (2 * qr - 1) * (18 * 128);
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int x = 2 * qc + dx - 1;
+      xa[it][dx] = rowbase + x * 128 + ((c ^ (x & 7)) << 4);
+    }
+    const int ok = item < 480 ? 1 : 0;
+    xa[it][0] |= ok * ((qr > 0 ? 1 : 0) | (qr < 5 ? 2 : 0) | (qc > 0 ? 4 : 0));
+    xa[it][1] |= ok * ((qc < 9 ? 1 : 0) | 2);
+  }
+  // (window positions that fall outside the patch -- and the second item of the threads that have none -- go to a 16-byte dump slot by
+  // an address select: no branches, the 8 stores of a thread issue back to back)
+  auto expand = [&](int yb, int ps) __attribute__((always_inline)) {
+    unsigned char* yp = smem + yb * L0_PB;
+    const unsigned char* pp = smem + PST_OFF + ps * L0_PST;
+    const int dump = DUMP_OFF - yb * L0_PB;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int item = it == 0 ? tid : (tid < 224 ? tid + 256 : tid);
+      const u32x4_t v = *reinterpret_cast<const u32x4_t*>(pp + item * 16);
+      const uint2 k = *reinterpret_cast<const uint2*>(pp + L0_PV + item * 8);
+      L0CodeMasks cm;
+      cm.init(k);
+      u32x4_t o1, o2, o3, o4;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        o1[d] = v[d] & cm.mask<1>(d); o2[d] = v[d] & cm.mask<2>(d);
+        o3[d] = v[d] & cm.mask<3>(d); o4[d] = v[d] & cm.mask<4>(d);
+      }
+      const int f0 = xa[it][0] & 15, f1 = xa[it][1] & 15, a0 = xa[it][0] & ~15, a1 = xa[it][1] & ~15;
+      const bool c0 = (f0 & 4) != 0, c1 = (f1 & 3) == 3;
+      *reinterpret_cast<u32x4_t*>(yp + (((f0 & 1) && c0) ? a0 : dump)) = o1;
+      *reinterpret_cast<u32x4_t*>(yp + (((f0 & 1) && c1) ? a1 : dump)) = o2;
+      *reinterpret_cast<u32x4_t*>(yp + (((f0 & 2) && c0) ? a0 + 18 * 128 : dump)) = o3;
+      *reinterpret_cast<u32x4_t*>(yp + (((f0 & 2) && c1) ? a1 + 18 * 128 : dump)) = o4;
+    }
+  };
+
+  // ---- prologue: pooled patches 0 (expanded now) and 1, frame patch 0
+  if (cnt > 0) {
+    l0_stage_pooled(p, org[0], smem_base + PST_OFF, tid, wave_u);
+    l0_stage_frames(p, org[0], smem_base + S_OFF, tid, wave_u);
+  }
+  if (cnt > 1) l0_stage_pooled(p, org[1], smem_base + PST_OFF + L0_PST, tid, wave_u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  l0_split_frames(smem + S_OFF, tid);
+  __syncthreads();
+  if (cnt > 0) expand(0, 0);
+
+  unsigned offk[3][2];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+      offk[dx][ms] = smem_base + (unsigned)((((wm * 4) / CB) * PW + ((wm * 4) % CB) * 16 + lr) * 128) +
+                     (unsigned)(((ms * 4 + g) ^ ((lr + dx) & 7)) << 4);
+  // epilogue addressing (frame patch, packed dwords): conv.0 recomputed for the tile pixels of this wave (pixel column lr, tap row g),
+  // and the frame values under every tap for 4 consecutive pixels 4 g .. 4 g + 3 (tap = lr; 9 = the row of ones, above = zeros)
+  const int mbase = ((wm * 4 + 1 + (g < 3 ? g : 2)) * 20 + lr + 1) * 4;
+  const int tbase = lr < 9 ? ((wm * 4 + 1 + lr / 3) * 20 + 4 * g + 1 + lr % 3) * 4 : (lr == 9 ? 1024 : 1280);
+  f32x4_t dw0[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};      // [tap rows 4 g + r][channel lr of fragment j]
+
+  for (int n = 0; n < cnt; ++n) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();       // patch n expanded, pooled patch n + 1 landed, frame patch n split
+    L0_FENCE();
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (n + 2 < cnt) l0_stage_pooled(p, org[2], smem_base + PST_OFF + (unsigned)((n & 1) * L0_PST), tl, wave_u);
+    if (n + 1 < cnt) {
+      l0_stage_frames(p, org[1], smem_base + S_OFF + (unsigned)(((n + 1) & 1) * L0_SS), tl, wave_u);
+      expand((n + 1) & 1, (n + 1) & 1);
+    }
+    L0_FENCE();
+
+    u32x4_t bq[2] = {u32x4_t{0u, 0u, 0u, 0u}, u32x4_t{0u, 0u, 0u, 0u}};
+    f32x4_t acc[4][2];
+    unsigned pbd[3][2];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n & 1) * L0_PB);
+    u32x4_t a[2][4];
+    c64_issue<0, PW, CB>(a[0], pbd);
+    c64_steps<PW, CB, true>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);   // acc[i][j]: rows = pixels 4 g + r of tile row 4 wm + i, column = channel
+
+    L0_FENCE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pooled patch n + 2 and frame patch n + 1
+    if (n + 1 < cnt) l0_split_frames(smem + S_OFF + ((n + 1) & 1) * L0_SS, tl);
+
+    // ---- epilogue: ReLU mask of conv.0 recomputed, then dW0 / db0 += frames^T . dy1 over the tile's pixels
+    const unsigned char* sp = smem + S_OFF + (n & 1) * L0_SS;
+    const int h0 = org[0].h0, w0 = org[0].w0;
+    const bool whole = h0 + 8 <= p.H && w0 + 16 <= p.W;
+    float bj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bj[j] = *reinterpret_cast<const float*>(smem + B0_OFF + (wn * 32 + j * 16 + lr) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const u32x4_t am = l0_frame_operand(sp + mbase + i * 80);
+      const uint32_t d0 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80), d1 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 4),
+                     d2 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 8), d3 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 12);
+      const uint2 fhi = make_uint2(__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u));
+      const uint2 flo = make_uint2(__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u));
+      const bool rowok = whole || (wm * 4 + i < p.H - h0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // (the conv.0 operands are re-read per use: 16 registers held across the epilogue would not fit beside the 144 of the weights)
+        const u32x4_t wh = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + (((wn * 2 + j) * 2 + 0) * 64 + lane) * 16);
+        f32x4_t y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, am), __builtin_bit_cast(bf16x8_t, wh),
+                                                           f32x4_t{bj[j], bj[j], bj[j], bj[j]}, 0, 0, 0);
+        if (WSPLIT) {
+          const u32x4_t wl = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + (((wn * 2 + j) * 2 + 1) * 64 + lane) * 16);
+          y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, am), __builtin_bit_cast(bf16x8_t, wl), y, 0, 0, 0);
+        }
+        float dy[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = y[r] > 0.f && rowok && (whole || 4 * g + r < p.W - w0);
+          dy[r] = ok ? acc[i][j][r] : 0.f;
+        }
+        const uint2 bd = make_uint2(pack_bf16(dy[0], dy[1]), pack_bf16(dy[2], dy[3]));
+        dw0[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(l0_s16x4_t, fhi), __builtin_bit_cast(l0_s16x4_t, bd), dw0[j], 0, 0, 0);
+        dw0[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(l0_s16x4_t, flo), __builtin_bit_cast(l0_s16x4_t, bd), dw0[j], 0, 0, 0);
+      }
+    }
+    org[0] = org[1]; org[1] = org[2];
+    walk.advance(org[2]);
+  }
+  // partial sums of the workgroup: the two waves that own a channel (tile rows 0 - 3 / 4 - 7) meet in LDS -> ws[workgroup][tap row 0 .. 9][64]
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4_t*>(red + (wave * 2 + j) * 256 + lane * 4) = dw0[j];
+  __syncthreads();
+  for (int o = tid; o < 640; o += 256) {
+    const int tap = o >> 6, co = o & 63;
+    const int wn2 = co >> 5, j = (co >> 4) & 1, ln = (tap >> 2) * 16 + (co & 15), r = tap & 3;
+    p.ws[(int64_t)blockIdx.x * 640 + o] = red[((0 * 2 + wn2) * 2 + j) * 256 + ln * 4 + r] + red[((1 * 2 + wn2) * 2 + j) * 256 + ln * 4 + r];
+  }
+}
+
+// dW0[co][tap] += / db0[co] += the workgroups' partial sums, fixed order (block = tap row 0 .. 9, thread = (channel, quarter of the workgroups))
+__global__ __launch_bounds__(1024) void vgg_level0_dw0_reduce_kernel(const float* __restrict__ ws, int nwg, float* dw0, float* db0) {
+  __shared__ float red[16][64];
+  const int tap = blockIdx.x, co = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float s = 0.f;
+  for (int w = part; w < nwg; w += 128) {          // 8 loads in flight per thread
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (w + u * 16 < nwg) ? ws[(int64_t)(w + u * 16) * 640 + tap * 64 + co] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  red[part][co] = s;
+  __syncthreads();
+  if (part != 0) return;
+#pragma unroll
+  for (int k = 1; k < 16; ++k) s += red[k][co];
+  if (tap < 9) dw0[co * 9 + tap] += s;
+  else db0[co] += s;
+}
+
+// ================================================================================================ weight gradient of conv.2
+// The block walk, operand reads and partial-block layout of conv3x3_wgrad_dma_kernel (conv_wgrad_dma.hip) with both stage halves
+// produced in LDS: X = ReLU(conv.0(frames)) on the 10 x 18 halo patch (wave = channel fragment, all 12 pixel fragments), dY = the
+// pooled gradient of the tile's 4 x 8 pooled pixels expanded through the selection codes (one (pixel, chunk) item per thread, its
+// 16 + 8 bytes fetched into registers one patch ahead).
+constexpr int L0_XB = 180 * 128, L0_DB = 128 * 128, L0_STAGE = L0_XB + L0_DB;
+
+__device__ __forceinline__ bf16x8_t l0_read_tr(const unsigned char* lo, const unsigned char* hi) {
+  const uint2 a = asr_lds_read_tr16(lo), b = asr_lds_read_tr16(hi);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
+}
+
+template <bool WSPLIT>
+__global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
+  constexpr int S_OFF = 2 * L0_STAGE, B0_OFF = S_OFF + 2 * 1024, DUMP_OFF = B0_OFF + 256;      // 128-byte dump area behind the bias
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  int vid = (int)blockIdx.x;
+  {
+    const int nwg = (int)gridDim.x, xcd = vid & 7, qn = nwg >> 3, rn = nwg & 7;
+    vid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (vid >> 3);
+  }
+  const int npatch = p.ntiles;
+  const int p_beg = vid * p.patches_per_wg, p_end = min(npatch, p_beg + p.patches_per_wg);
+  const int np = p_end - p_beg;
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const int H2 = p.H >> 1, W2 = p.W >> 1;
+
+  // conv.0 operands of this wave's channel fragment (registers) and its bias
+  u32x4_t whi, wlo;
+  l0_weight_operands(p.w0, wave * 16 + lr, g, whi, wlo);
+  if (tid < 64) reinterpret_cast<float*>(smem + B0_OFF)[tid] = p.b0 ? p.b0[tid] : 0.f;
+  __syncthreads();
+  const f32x4_t bias0 = *reinterpret_cast<const f32x4_t*>(smem + B0_OFF + (wave * 16 + 4 * g) * 4);
+
+  // patch origins (this kernel walks CONSECUTIVE patches: plain carries)
+  L0Org org[3];
+  {
+    int t = p_beg;
+    org[0].w0 = (t % p.tiles_w) * 16; t /= p.tiles_w;
+    org[0].h0 = (t % p.tiles_h) * 8; org[0].b = t / p.tiles_h;
+  }
+  auto next = [&](L0Org o) __attribute__((always_inline)) {
+    o.w0 += 16;
+    if (o.w0 >= p.tiles_w * 16) { o.w0 = 0; o.h0 += 8; if (o.h0 >= p.tiles_h * 8) { o.h0 = 0; ++o.b; } }
+    return o;
+  };
+  org[1] = next(org[0]);
+  org[2] = next(org[1]);
+
+  // the thread's expansion item: pooled pixel (qr, qc) of the tile's 4 x 8, chunk c
+  const int iq = tid >> 3, ic = tid & 7, iqr = iq >> 3, iqc = iq & 7;
+  const int da0 = L0_XB + ((2 * iqr) * 16 + 2 * iqc) * 128 + ((ic ^ ((2 * iqc) & 7)) << 4);        // window (0, 0); (0, 1) = (da0 + 128) ^ 16; row 1: + 16 * 128
+  u32x4_t pv = u32x4_t{0u, 0u, 0u, 0u};
+  uint2 pk = make_uint2(0u, 0u);
+  auto load_pooled = [&](const L0Org& o) __attribute__((always_inline)) {
+    const int ph = (o.h0 >> 1) + iqr, pw = (o.w0 >> 1) + iqc;
+    pv = u32x4_t{0u, 0u, 0u, 0u};
+    pk = make_uint2(0u, 0u);
+    if (ph < H2 && pw < W2) {
+      const int64_t e = (((int64_t)o.b * H2 + ph) * W2 + pw) * 64 + ic * 8;
+      pv = *reinterpret_cast<const u32x4_t*>(p.dpool + e);
+      pk = *reinterpret_cast<const uint2*>(p.code + e);
+    }
+  };
+  auto expand = [&](int st) __attribute__((always_inline)) {
+    unsigned char* dp = smem + st * L0_STAGE;
+    L0CodeMasks cm;
+    cm.init(pk);
+    u32x4_t o1, o2, o3, o4;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      o1[d] = pv[d] & cm.mask<1>(d); o2[d] = pv[d] & cm.mask<2>(d);
+      o3[d] = pv[d] & cm.mask<3>(d); o4[d] = pv[d] & cm.mask<4>(d);
+    }
+    const int a0 = da0, a1 = (da0 + 128) ^ 16;
+    *reinterpret_cast<u32x4_t*>(dp + a0) = o1;
+    *reinterpret_cast<u32x4_t*>(dp + a1) = o2;
+    *reinterpret_cast<u32x4_t*>(dp + a0 + 16 * 128) = o3;
+    *reinterpret_cast<u32x4_t*>(dp + a1 + 16 * 128) = o4;
+  };
+  auto generate = [&](int st, int sb, const L0Org& o) __attribute__((always_inline)) {
+    unsigned char* xp = smem + st * L0_STAGE;
+    const unsigned char* sp = smem + S_OFF + sb * 1024;
+    const bool inside = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 9 <= p.H && o.w0 + 17 <= p.W;
+    int lrl = lr;
+    asm volatile("" : "+v"(lrl));
+    // software pipeline over groups of 3 pixel fragments: the 6 MFMAs of group k issued, then group k - 1 converted / stored (its
+    // addressing recomputed there: a dozen vector instructions against 6 registers held across the MFMAs)
+    f32x4_t acc3[2][3];
+    auto finish = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        const int f = k * 3 + u;
+        L0GenLane gl;
+        gl.init(f, lrl, g);
+        const uint32_t vm = inside ? 0xffffffffu : l0_halo_valid(p, o, gl.prc);
+        const int wa = (f < 11 || (gl.prc & 0x10000)) ? gl.waddr : (DUMP_OFF - st * L0_STAGE);
+        l0_gen_store(xp, wa, acc3[k & 1][u], wave, vm);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        L0GenLane gl;
+        gl.init(k * 3 + u, lrl, g);
+        acc3[k & 1][u] = l0_gen_mfma<WSPLIT>(l0_frame_operand(sp + gl.gaddr), whi, wlo, bias0);
+      }
+      if (k > 0) finish(k - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    finish(3);
+  };
+
+  // ---- per-lane operand offsets inside a stage (conv_wgrad_dma.hip)
+  const int colb = 8 * (g & 1) + (lr >> 2), rowb = g >> 1, sub = 8 * (lr & 1), cpair = (lr & 3) >> 1;
+  int xlo[3], xhi[3], dlo[4], dhi[4];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int c = colb + dx, ch = wave * 2 + cpair;
+    xlo[dx] = (rowb * 18 + c) * 128 + ((ch ^ (c & 7)) << 4) + sub;
+    xhi[dx] = (rowb * 18 + c + 4) * 128 + ((ch ^ ((c + 4) & 7)) << 4) + sub;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ch = 2 * i + cpair;
+    dlo[i] = L0_XB + (rowb * 16 + colb) * 128 + ((ch ^ (colb & 7)) << 4) + sub;
+    dhi[i] = L0_XB + (rowb * 16 + colb + 4) * 128 + ((ch ^ ((colb + 4) & 7)) << 4) + sub;
+  }
+  f32x4_t acc[9][4];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_bias = p.db != nullptr && wave == 0;
+
+  // ---- prologue: frame patches 0 and 1, stage 0 complete
+  if (np > 0) { l0_stage_frames(p, org[0], smem_base + S_OFF, tid, wave_u); load_pooled(org[0]); }
+  if (np > 1) l0_stage_frames(p, org[1], smem_base + S_OFF + 1024, tid, wave_u);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  l0_split_frames(smem + S_OFF, tid);
+  l0_split_frames(smem + S_OFF + 1024, tid);
+  __syncthreads();
+  if (np > 0) { generate(0, 0, org[0]); expand(0); }
+
+  for (int j = 0; j < np; ++j) {
+    const int buf = j & 1;
+    __syncthreads();          // stage `buf` complete for every wave; everybody is done with the other stage; frame patch j + 1 split
+    int tl = tid;
+    asm volatile("" : "+v"(tl));
+    if (j + 2 < np) l0_stage_frames(p, org[2], smem_base + S_OFF + (unsigned)(buf * 1024), tl, wave_u);
+    if (j + 1 < np) {
+      load_pooled(org[1]);
+      generate(buf ^ 1, buf ^ 1, org[1]);
+    }
+    const unsigned char* sb = smem + buf * L0_STAGE;
+#pragma unroll
+    for (int ms = 0; ms < 4; ++ms) {
+      bf16x8_t a[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = l0_read_tr(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
+      if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const u32x4_t u = __builtin_bit_cast(u32x4_t, a[i]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int off = ((2 * ms + t / 3) * 18) * 128;
+        const bf16x8_t bb = l0_read_tr(sb + xlo[t % 3] + off, sb + xhi[t % 3] + off);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb, acc[t][i], 0, 0, 0);
+        if (t % 3 == 2) L0_FENCE();
+      }
+    }
+    if (j + 1 < np) expand(buf ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (j + 2 < np) l0_split_frames(smem + S_OFF + buf * 1024, tl);
+    org[0] = org[1]; org[1] = org[2]; org[2] = next(org[2]);
+  }
+
+  float* part = p.ws + (int64_t)vid * (9 * 64 * 64);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[(t * 64 + i * 16 + g * 4 + r) * 64 + wave * 16 + lr] = acc[t][i][r];
+  if (do_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (g == 0) atomicAdd(p.db + i * 16 + lr, v);
+    }
+  }
+}
+
+int l0_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cus = n;
+  }
+  return cus;
+}
+template <typename K> int l0_grant(K kernel, size_t lds) {
+  static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
+  if (!granted) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASR_ELAUNCH;
+    granted = true;
+  }
+  return ASR_OK;
+}
+bool l0_shape_ok(int B, int H, int W) {
+  return B >= 0 && H >= 2 && W >= 2 && (int64_t)B * H * W * 128 < ((int64_t)1 << 32);
+}
+void l0_wgrad_grid(int B, int H, int W, int* wgx, int* ppw) {      // = wgrad_grid of conv.hip for one 64 x 64 block
+  const int npatch = B * ((H + 7) / 8) * ((W + 15) / 16);
+  int pp = (npatch + 511) / 512;
+  if (pp < 4) pp = 4;
+  *ppw = pp;
+  *wgx = (npatch + pp - 1) / pp;
+}
+
+}  // namespace
+
+extern "C" int asr_vgg_level0_fwd(const float* src, const float* w0, const float* b0, const void* wk2, const float* b2, void* pool,
+                                  uint8_t* code, int B, int H, int W, hipStream_t s) {
+  ASR_CHECK_ARG(src && w0 && b0 && wk2 && b2 && pool && code);
+  if (!l0_shape_ok(B, H, W) || !aligned16(wk2) || !aligned16(pool) || (((uintptr_t)code) & 7) != 0) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  L0Args a{};
+  a.src = src; a.w0 = w0; a.b0 = b0; a.wk = static_cast<const bf16_t*>(wk2); a.b2 = b2;
+  a.pool = static_cast<bf16_t*>(pool); a.code = code; a.B = B; a.H = H; a.W = W;
+  a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
+  const size_t lds = 2 * L0_PB + 2 * L0_SS + L0_WM + 512;
+  const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
+  const int rc = split ? l0_grant(vgg_level0_fwd_kernel<true>, lds) : l0_grant(vgg_level0_fwd_kernel<false>, lds);
+  if (rc != ASR_OK) return rc;
+  const int64_t slots = (int64_t)l0_cus() * 2;
+  const unsigned grid = (unsigned)(a.ntiles < slots ? a.ntiles : slots);
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  if (split) hipLaunchKernelGGL(vgg_level0_fwd_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(vgg_level0_fwd_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int64_t asr_vgg_level0_bwd_workspace(int B, int H, int W) {
+  if (!l0_shape_ok(B, H, W)) return 0;
+  int wgx, ppw;
+  l0_wgrad_grid(B, H, W, &wgx, &ppw);
+  const int64_t a = (int64_t)wgx * 9 * 64 * 64, b = (int64_t)l0_cus() * 2 * 640;
+  return a > b ? a : b;
+}
+
+extern "C" int asr_vgg_level0_dgrad(const void* dpool, const uint8_t* code, const float* src, const float* w0, const float* b0,
+                                    const void* wd2, float* dw0, float* db0, float* workspace, int64_t workspace_floats, int B, int H,
+                                    int W, hipStream_t s) {
+  ASR_CHECK_ARG(dpool && code && src && w0 && b0 && wd2 && dw0 && db0 && workspace);
+  if (!l0_shape_ok(B, H, W) || !aligned16(wd2) || !aligned16(dpool) || !aligned16(code) || !aligned16(workspace)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  L0Args a{};
+  a.src = src; a.w0 = w0; a.b0 = b0; a.wk = static_cast<const bf16_t*>(wd2);
+  a.dpool = static_cast<const bf16_t*>(dpool); a.code = const_cast<uint8_t*>(code); a.ws = workspace; a.B = B; a.H = H; a.W = W;
+  a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
+  const size_t lds = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16;
+  const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
+  const int rc = split ? l0_grant(vgg_level0_dgrad_kernel<true>, lds) : l0_grant(vgg_level0_dgrad_kernel<false>, lds);
+  if (rc != ASR_OK) return rc;
+  const int64_t slots = (int64_t)l0_cus() * 2;
+  const unsigned grid = (unsigned)(a.ntiles < slots ? a.ntiles : slots);
+  if (workspace_floats < (int64_t)grid * 640) return ASR_EINVAL;
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  if (split) hipLaunchKernelGGL(vgg_level0_dgrad_kernel<true>, dim3(grid), dim3(256), lds, s, a);
+  else hipLaunchKernelGGL(vgg_level0_dgrad_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+  ASR_LAUNCH_CHECK();
+  hipLaunchKernelGGL(vgg_level0_dw0_reduce_kernel, dim3(10), dim3(1024), 0, s, workspace, (int)grid, dw0, db0);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_vgg_level0_wgrad(const float* src, const float* w0, const float* b0, const void* dpool, const uint8_t* code, float* dw2,
+                                    float* db2, float* workspace, int64_t workspace_floats, int B, int H, int W, hipStream_t s) {
+  ASR_CHECK_ARG(src && w0 && b0 && dpool && code && dw2 && workspace);
+  if (!l0_shape_ok(B, H, W) || !aligned16(dpool) || (((uintptr_t)code) & 7) != 0 || !aligned16(workspace)) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  L0Args a{};
+  a.src = src; a.w0 = w0; a.b0 = b0; a.dpool = static_cast<const bf16_t*>(dpool); a.code = const_cast<uint8_t*>(code);
+  a.ws = workspace; a.db = db2; a.B = B; a.H = H; a.W = W;
+  a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
+  int wgx;
+  l0_wgrad_grid(B, H, W, &wgx, &a.patches_per_wg);
+  if (workspace_floats < (int64_t)wgx * 9 * 64 * 64) return ASR_EINVAL;
+  const size_t lds = 2 * L0_STAGE + 2 * 1024 + 256 + 128;
+  const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
+  const int rc = split ? l0_grant(vgg_level0_wgrad_kernel<true>, lds) : l0_grant(vgg_level0_wgrad_kernel<false>, lds);
+  if (rc != ASR_OK) return rc;
+  {
+    AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
+    if (split) hipLaunchKernelGGL(vgg_level0_wgrad_kernel<true>, dim3((unsigned)wgx), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(vgg_level0_wgrad_kernel<false>, dim3((unsigned)wgx), dim3(256), lds, s, a);
+    ASR_LAUNCH_CHECK();
+  }
+  return asr_conv3x3_wgrad_reduce(workspace, dw2, B, H, W, 64, 64, s);
+}

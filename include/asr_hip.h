@@ -360,6 +360,26 @@ int asr_maxpool_bwd_code(const uint8_t* code, const void* dy, void* dx, int B, i
 /* asr_conv3x3_relu_pool that writes the pooled output and its selection codes; y_or_null = NULL: the un-pooled output is not stored */
 int asr_conv3x3_relu_pool_code(const void* x, const void* wk, const float* bias, void* y_or_null, void* pool, uint8_t* code, int B,
                                int H, int W, int Cin, int Cout, int dtype, asr_stream_t stream);
+/* ---- the full-resolution level of vgg_cnn without its full-resolution activations (reference: models/asr/transformer.py:42-47 and
+ * its autograd; csrc/conv_level0.hip).  bf16 activations, 64 channels.  src (B, H, W) fp32 = the front end's single input channel.
+ * forward: pool (B, H/2, W/2, 64) = MaxPool2d(2,2)(ReLU(conv.2(ReLU(conv.0(src))))) and one selection byte per pooled element
+ * (layout of pool: 0 = the maximum is 0, 1 + k = first maximum at window position k); conv.0's 64-channel output exists only as
+ * halo patches in LDS.  w0 (64,1,3,3) / b0 fp32 masters, wk2 = conv.2's packed forward weights (asr_conv_pack_weight), b2 fp32.
+ * Replaces asr_conv1_fwd + asr_conv3x3_relu_pool_code. */
+int asr_vgg_level0_fwd(const float* src, const float* w0, const float* b0, const void* wk2, const float* b2, void* pool,
+                       uint8_t* code, int B, int H, int W, asr_stream_t stream);
+/* floats of workspace the two backward entry points need (the larger of the two) */
+int64_t asr_vgg_level0_bwd_workspace(int B, int H, int W);
+/* backward, data side: dpool (gradient of pool) is expanded through `code` inside the kernel, contracted with conv.2's tap-flipped
+ * weights wd2 (asr_conv_pack_weight), masked with conv.0's ReLU mask RECOMPUTED from src, and reduced against the frames:
+ * dw0 (64,1,3,3) += , db0 (64) += .  The gradient of conv.0's output is never stored (the input frames need none).
+ * Replaces asr_maxpool_bwd_code + asr_conv3x3_igemm(mask) + asr_conv1_wgrad. */
+int asr_vgg_level0_dgrad(const void* dpool, const uint8_t* code, const float* src, const float* w0, const float* b0, const void* wd2,
+                         float* dw0, float* db0, float* workspace, int64_t workspace_floats, int B, int H, int W, asr_stream_t stream);
+/* backward, weight side of conv.2: dw2 (64,64,3,3) += , db2 (64) += from ReLU(conv.0(src)) recomputed on halo patches and the
+ * expanded dpool.  Replaces asr_maxpool_bwd_code + asr_conv3x3_wgrad_nhwc for this layer. */
+int asr_vgg_level0_wgrad(const float* src, const float* w0, const float* b0, const void* dpool, const uint8_t* code, float* dw2,
+                         float* db2, float* workspace, int64_t workspace_floats, int B, int H, int W, asr_stream_t stream);
 /* conv.7 + ReLU + MaxPool2d + the (B, T', C F') view / transpose of transformer.py:50-52,74-76 from one epilogue: pool (B, W/2, Cout, H/2)
  * and its selection bytes (same layout); the un-pooled output is never stored.  bf16, Cout = 128, H and W multiples of 16.     */
 int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H, int W,
