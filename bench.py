@@ -37,19 +37,21 @@ MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm
 LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0, "enc_layers": 12, "dec_layers": 6}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FILE = os.path.join("profiles", "r03_roofline_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_roofline_traffic.json")
 # per-family kernel time of the REPLAYED step (tools/prof_families.py over a committed rocprofv3 trace of this command)
-REPLAYED_FAMILIES_FILE = os.path.join("profiles", "r03_replayed_families.json")
+REPLAYED_FAMILIES_FILE = os.path.join("profiles", "r04_replayed_families.json")
 
 
 # ------------------------------------------------------------------------------------------------ algorithmic work
 def family_flops(B, L=4, D=512, H=8, dk=64, Dff=2048, vocab=V, t_src=T_SRC, t_tgt=T_TGT):
     """Algorithmic FLOPs (2*MAC) of ONE training step of configs[1], by kernel family -> {family: (flop, launches)}.
-    conv: 3 forward + 3 data-gradient implicit GEMMs (2*9*Cin*Cout per pixel); conv weight gradients the same flop once more;
+    conv: 3 forward + 3 data-gradient implicit GEMMs (2*9*Cin*Cout per pixel) -- since round 4 conv.2's two launches also carry conv.0's
+    forward and weight gradient (2*9*64 per pixel each: csrc/conv_level0.hip); conv weight gradients the same flop once more;
     linear: every nn.Linear / Conv1d(k=1): forward + data gradient + weight gradient = 3 * 2*M*N*K;
     attention: forward 4*B*H*Tq*Tk*d, backward 2.5 x forward."""
     px1, px2 = B * 161 * t_src, B * 80 * (t_src // 2)
     conv_fwd = 2 * 9 * (64 * 64 * px1 + 64 * 128 * px2 + 128 * 128 * px2)
+    conv0 = 2 * 9 * 64 * px1
     Te, Td = t_src // 4, t_tgt
     Me, Md = B * Te, B * Td
     HD = H * dk
@@ -58,7 +60,7 @@ def family_flops(B, L=4, D=512, H=8, dk=64, Dff=2048, vocab=V, t_src=T_SRC, t_tg
     lin += L * (Md * 3 * HD * D + Md * D * HD + Md * HD * D + Me * 2 * HD * D + Md * D * HD + 2 * Md * Dff * D)
     lin += Md * vocab * D
     att = L * 4 * B * H * dk * (Te * Te + Td * Td + Td * Te)
-    return {"conv3x3_igemm (3 fwd + 3 dgrad)": (2 * conv_fwd, 6), "conv3x3_wgrad": (conv_fwd, 3),
+    return {"conv3x3_igemm (3 fwd + 3 dgrad)": (2 * conv_fwd + 2 * conv0, 6), "conv3x3_wgrad": (conv_fwd, 3),
             "linear GEMMs (fwd + dgrad + wgrad)": (3 * 2 * lin, None), "attention fwd": (att, 3 * L),
             "attention bwd": (2.5 * att, None)}
 
@@ -94,10 +96,11 @@ def measured_traffic(a):
     WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
     if a.batch != 32 or a.precision != "bf16":
         return None
-    for f in (TRAFFIC_FILE, os.path.join("profiles", "r02_roofline_traffic.json"), os.path.join("profiles", "r01_roofline_traffic.json")):
+    for f in (TRAFFIC_FILE, os.path.join("profiles", "r03_roofline_traffic.json")):
         try:
             with open(os.path.join(ROOT, f)) as fh:
-                return json.load(fh)["traffic_bytes_per_launch_avg"], f
+                d = json.load(fh)
+            return d["traffic_bytes_per_launch_avg"], f, d.get("per_kernel")
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -447,14 +450,19 @@ def main():
                 f = fams[key]
                 tr = measured_traffic(a)
                 n_launch = prof[key][1]
-                out["roofline"] = {"bound": "mfma", "kernel": "asr_conv3x3_igemm: conv3x3_c64_kernel / conv3x3_igemm_kernel, 3 forward "
-                                   "+ 3 data-gradient launches per step (45 % of the step's algorithmic FLOPs)",
+                out["roofline"] = {"bound": "mfma", "kernel": "the front end's 3 forward + 3 data-gradient convolutions: vgg_level0_fwd / "
+                                   "vgg_level0_dgrad (conv.2 with conv.0, the first pool and dW0 inside), conv3x3_c64_kernel (conv.5, two passes), "
+                                   "conv3x3_igemm_kernel (conv.7 and the two 128-channel data gradients): 45 % of the step's algorithmic FLOPs",
                                    "achieved": f["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": f["frac"],
                                    "traffic": tr[0] if tr else None,
                                    "traffic_source": ("constant read from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                                       "command, committed; NOT measured by this run)" % tr[1]) if tr else None,
                                    "timing": "HIP events around every launch on its own stream during %d EAGER steps right after the "
                                              "timed (graph-replayed) region" % prof_steps,
+                                   "bound_per_launch": ({k: {"bound": v.get("bound"), "hbm_MB": round(v["hbm_bytes_per_launch"] / 1e6, 1),
+                                                             "algorithmic_gflop": v.get("algorithmic_gflop_per_launch"),
+                                                             "t_hbm_us_at_6.29TBs": v.get("t_hbm_us_at_6.29TBs"), "t_mfma_us_at_2.5PF": v.get("t_mfma_us_at_2.5PF")}
+                                                         for k, v in tr[2].items()} if tr and tr[2] else None),
                                    "launches": n_launch, "avg_launch_ms": prof[key][0] / n_launch,
                                    "algorithmic_flop_per_launch_avg": fl[key][0] / fl[key][1],
                                    "families_eager": fams,

@@ -12,7 +12,7 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   ( cd $root && timeout 600 rocprofv3 --pmc $ctr -d $out -o pmc -- $cmd ) > $root/gpurun_out/${tag}_pmc_${ctr}.log 2>&1
   db=$(find $out -name "*.db" | head -1)
   echo "# rocprofv3 --pmc $ctr -- $cmd" >> $root/gpurun_out/${tag}_traffic_pmc.txt
-  if [ -n "$db" ]; then python $root/tools/pmc_summary.py "$db" conv3x3 >> $root/gpurun_out/${tag}_traffic_pmc.txt 2>&1; else echo "no database" >> $root/gpurun_out/${tag}_traffic_pmc.txt; fi
+  if [ -n "$db" ]; then python $root/tools/pmc_summary.py "$db" "conv3x3|vgg_level0" >> $root/gpurun_out/${tag}_traffic_pmc.txt 2>&1; else echo "no database" >> $root/gpurun_out/${tag}_traffic_pmc.txt; fi
 done
 python $root/tools/make_traffic_json.py $root/gpurun_out/${tag}_traffic_pmc.txt > $root/gpurun_out/${tag}_roofline_traffic.json
 cat $root/gpurun_out/${tag}_roofline_traffic.json | tail -5

@@ -15,7 +15,7 @@ ix = {n: i for i, n in enumerate(cols)}
 acc = defaultdict(lambda: defaultdict(list))
 for r in rows:
     kn = re.sub(r'\(anonymous namespace\)::', '', str(r[ix.get('kernel_name', ix.get('name', 0))]))
-    if flt and flt not in kn:
+    if flt and not re.search(flt, kn):
         continue
     acc[kn[:90]][r[ix['counter_name']]].append(float(r[ix['value']]))
 for kn, d in acc.items():

@@ -11,9 +11,9 @@ import sys
 from collections import defaultdict
 
 FAMILIES = [
-    ("conv3x3_igemm (3 fwd + 3 dgrad)", r"conv3x3_igemm_kernel|conv3x3_c64_kernel"),
-    ("conv3x3_wgrad", r"conv3x3_wgrad|wgrad_reduce_kernel"),
-    ("conv1 + pooling (HBM-bound)", r"conv1_|pool_"),
+    ("conv3x3_igemm (3 fwd + 3 dgrad)", r"conv3x3_igemm_kernel|conv3x3_c64_kernel|vgg_level0_fwd_kernel|vgg_level0_dgrad_kernel"),
+    ("conv3x3_wgrad", r"conv3x3_wgrad|wgrad_reduce_kernel|vgg_level0_wgrad_kernel"),
+    ("conv1 + pooling (HBM-bound)", r"conv1_|pool_|vgg_level0_dw0_reduce"),
     ("linear GEMMs (fwd + dgrad + wgrad)", r"gemm_|tn_reduce|tn128_reduce"),
     ("attention fwd", r"attn_fwd"),
     ("attention bwd", r"attn_bwd|attn_delta"),
@@ -33,7 +33,12 @@ def main():
     seg = rows[marks[-4]:marks[-1]]
     nsteps = 3
     fam = defaultdict(lambda: [0.0, 0])
+    perk = defaultdict(lambda: [0.0, 0])
     for name, s, e in seg:
+        if re.search(r"conv|vgg_level0|pool_", name):
+            k = re.sub(r"\(anonymous namespace\)::", "", name)[:90]
+            perk[k][0] += (e - s) / 1e3
+            perk[k][1] += 1
         for label, pat in FAMILIES:
             if re.search(pat, name):
                 break
@@ -44,7 +49,8 @@ def main():
     wall = (max(r[2] for r in seg) - seg[0][1]) / 1e6 / nsteps
     res = {"source": "rocprofv3 --kernel-trace of: " + cmd, "steps_summed": nsteps, "wall_ms_per_step": wall,
            "kernel_time_ms_per_step": sum(v[0] for v in fam.values()), "launches_per_step": len(seg) // nsteps,
-           "families": {k: {"ms_per_step": v[0], "launches_per_step": v[1] / nsteps} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}}
+           "families": {k: {"ms_per_step": v[0], "launches_per_step": v[1] / nsteps} for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])},
+           "conv_front_end_kernels_us": {k: {"avg_us": v[0] / v[1], "launches_per_step": v[1] / nsteps} for k, v in sorted(perk.items(), key=lambda kv: -kv[1][0])}}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     print(json.dumps(res, indent=1))
