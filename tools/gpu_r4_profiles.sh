@@ -9,7 +9,7 @@ db=$(find $out -name "*.db" | head -1)
 python tools/prof_summary.py "$db" 11 "rocprofv3 --kernel-trace --stats -- $cmd (11 steps in the trace: eager warm-up + capture + replays)" > gpurun_out/r04_bench_kernel_stats.txt 2>&1
 python tools/prof_timeline.py "$db" "timeline of the last 3 replayed steps: rocprofv3 --kernel-trace -- $cmd" > gpurun_out/r04_bench_timeline.txt 2>&1
 python tools/prof_families.py "$db" gpurun_out/r04_replayed_families.json "$cmd" > /dev/null 2>&1
-python tools/prof_sequence.py "$db" > gpurun_out/r04_step_sequence.txt 2>&1
+python tools/prof_sequence.py "$db" gpurun_out/r04_step_sequence.txt > /dev/null 2>&1
 bash tools/gpu_pmc_traffic.sh r04 > /dev/null 2>&1
 bash tools/gpu_pmc_mfma.sh r04_step > /dev/null 2>&1
 head -30 gpurun_out/r04_bench_kernel_stats.txt; tail -12 gpurun_out/r04_step_mfma_pmc.txt; python -c "
