@@ -244,6 +244,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-exposure", action="store_true", help="N > 1: skip the extra no-collective steps that measure how much "
                     "of the gradient all-reduce is exposed")
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype in which the gradient slices are "
+                    "all-reduced (bf16 = half the bytes per xGMI link, summed in bf16 by the collective; asr_hip/ddp.py)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     a = ap.parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -288,7 +290,7 @@ def main():
     if lowrank:                              # argparse: the later --num-layers wins
         flags += ["--num-layers", "12", "--rank", "64"]
     if world > 1 or force_ddp:
-        flags.append("--parallel")
+        flags += ["--parallel", "--grad-wire", a.grad_wire]
     args = constant.parse(flags)
     l2i, i2l = labels(vocab)
     torch.manual_seed(123456)
@@ -411,6 +413,9 @@ def main():
                           "per_gpu_frames_per_s": value / world,
                           "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                           "collective_ranks": (dist.get_world_size() if dist.is_initialized() else 1),
+                          "collective_library": (("RCCL %s" % ".".join(str(x) for x in torch.cuda.nccl.version()))
+                                                 if dist.is_initialized() and dist.get_backend() == "nccl" else None),
+                          "grad_wire": (a.grad_wire if (world > 1 or force_ddp) else None),
                           "rank0_ms_per_step": dt_local / a.steps * 1e3,
                           "step_tflops_whole_model": (value * mflop_per_frame * 1e6 / 1e12) if mflop_per_frame else None,
                           "frac_of_mfma_peak_whole_step": (value * mflop_per_frame * 1e6 / 1e12 / (peak * world)) if mflop_per_frame else None,
@@ -422,9 +427,11 @@ def main():
             out["config"]["parity_note"] = ("parity unpinned: the Low-Rank Transformer is not in the reference tree; tests compare with "
                                             "oracle/asr_oracle.py's restatement of arXiv:1910.13923 only")
         if exposure is not None:
-            out["config"]["gradient_allreduce"] = dict(exposure, bytes=4 * red.flat.total_all,
-                                                       note="147 MB fp32 gradients + stats slot; the decoder slice is in flight during the encoder's "
-                                                            "backward graph, the encoder slice during the conv backward graph")
+            wire16 = getattr(red, "wire", "fp32") == "bf16"
+            out["config"]["gradient_allreduce"] = dict(exposure, bytes=(2 if wire16 else 4) * red.flat.total + 4 * (red.flat.total_all - red.flat.total),
+                                                       wire=getattr(red, "wire", "fp32"),
+                                                       note="flat gradient buffer (%s on the wire) + fp32 stats slot; the decoder slice is in flight during the "
+                                                            "encoder's backward graph, the encoder slice during the conv backward graph" % ("bf16" if wire16 else "fp32"))
         if prof is not None and (libri or lowrank):
             tot_ms, n = prof["GEMM family (asr_gemm_*)"]
             if n > 0 and tot_ms > 0:

@@ -48,6 +48,7 @@ _SIGS = {
     "asr_gemm_nn_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P]),
     "asr_tn_reduce_multi": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "asr_cast_flat": (_I, [_P, _P, _L, _I, _P]),
+    "asr_widen_flat": (_I, [_P, _P, _L, _P]),
     "asr_transpose": (_I, [_P, _L, _P, _L, _I, _I, _P, _I, _P]),
     "asr_cast_weight": (_I, [_P, _L, _P, _L, _P, _L, _I, _I, _I, _P]),
     "asr_colsum_acc": (_I, [_P, _L, _I, _I, _P, _I, _P]),

@@ -351,6 +351,12 @@ def cast_flat(src, dst):
     L.call("asr_cast_flat", L.ptr(src), L.ptr(dst), src.numel(), L.dt(dst), L.stream())
 
 
+def widen_flat(src_bf16, dst):
+    """dst (fp32) = src (bf16), elementwise: the way back from the bf16 gradient wire format (asr_hip/ddp.py)."""
+    assert src_bf16.dtype == torch.bfloat16 and dst.dtype == torch.float32 and src_bf16.numel() == dst.numel()
+    L.call("asr_widen_flat", L.ptr(src_bf16), L.ptr(dst), dst.numel(), L.stream())
+
+
 def transpose_padded(x, colsum_acc=None):
     """(rows, cols) -> (cols, pad8(rows)) with zero pad columns (so a contraction may run over the padded axis).
     colsum_acc (fp32, cols): optionally accumulate the column sums of x (bias gradient) in the same pass."""

@@ -465,6 +465,35 @@ extern "C" int asr_adam_noam_step(float* p, const float* g, float* m, float* v, 
   return ASR_OK;
 }
 
+// dst[i] = (float) src[i] for a bf16 buffer: the way back from the bf16 wire format of the data-parallel gradient exchange
+__global__ __launch_bounds__(256) void widen_flat_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i * 8 < n; i += stride) {
+    if (i * 8 + 8 <= n) {
+      const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+      float4 lo, hi;
+      lo.x = __uint_as_float(v.x << 16); lo.y = __uint_as_float(v.x & 0xffff0000u);
+      lo.z = __uint_as_float(v.y << 16); lo.w = __uint_as_float(v.y & 0xffff0000u);
+      hi.x = __uint_as_float(v.z << 16); hi.y = __uint_as_float(v.z & 0xffff0000u);
+      hi.z = __uint_as_float(v.w << 16); hi.w = __uint_as_float(v.w & 0xffff0000u);
+      reinterpret_cast<float4*>(dst)[2 * i] = lo;
+      reinterpret_cast<float4*>(dst)[2 * i + 1] = hi;
+    } else {
+      for (int64_t e = i * 8; e < n; ++e) dst[e] = bf16_to_f32(src[e]);
+    }
+  }
+}
+extern "C" int asr_widen_flat(const void* src_bf16, float* dst, int64_t n, hipStream_t s) {
+  ASR_CHECK_ARG(src_bf16 && dst && n >= 0 && aligned16(src_bf16) && aligned16(dst));
+  if (n == 0) return ASR_OK;
+  int64_t blocks = ceil_div64(n, 2048 * 2);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(widen_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<const bf16_t*>(src_bf16), dst, n);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 extern "C" int asr_cast_flat(const float* src, void* dst, int64_t n, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(src && dst && n >= 0 && aligned16(src));
   if (n == 0) return ASR_OK;

@@ -8,7 +8,7 @@ Differences that do not change old command lines:
     script, which makes its modules unusable from tests); otherwise `args` holds the defaults and can be replaced with
     `set_args(ns)` / `parse(argv)`;
   * `--precision {bf16,fp32}` selects the kernels' storage type (bf16 = perf mode, fp32 = parity mode);
-  * `--dist-backend` / `--bucket-mb` tune the RCCL data-parallel path that replaces nn.DataParallel under --parallel;
+  * `--dist-backend` / `--bucket-mb` / `--grad-wire` tune the RCCL data-parallel path that replaces nn.DataParallel under --parallel;
   * `--gpu-frontend`: the loader ships padded waveforms and the log-spectrogram is computed on the GPU (asr_stft_frames +
     fp32 MFMA DFT + asr_spect_finish) instead of on the host in the DataLoader workers.
 """
@@ -63,6 +63,7 @@ _FLAGS = [
     # MI355X path (additions)
     (("--precision",), dict(default="bf16", choices=["bf16", "fp32", "fp8"])),     # fp8: bf16 storage, fp8 MFMA for the --rank projections
     (("--dist-backend",), dict(default="nccl")), (("--bucket-mb",), dict(default=32.0, type=_F)),
+    (("--grad-wire",), dict(default="fp32", choices=["fp32", "bf16"])),
     (("--gpu-frontend",), dict(action="store_true")),
     # 0: eager launches on the batch exactly as collated.  N > 0: training batches are zero-padded along time to a multiple of N
     # frames (the way the collate function pads shorter utterances) and to --tgt-max-len - 1 target columns, and the step is a

@@ -51,7 +51,7 @@ def load_model(load_path):
         # laid out over GPUs (the reference re-wraps according to the current --parallel, train.py:92-99; a checkpoint saved
         # without it must not silently train un-synchronised replicas), where it runs, and the MI355X-path switches a
         # reference-written checkpoint does not carry at all.
-        for k in ("parallel", "device_ids", "dist_backend", "bucket_mb"):
+        for k in ("parallel", "device_ids", "dist_backend", "bucket_mb", "grad_wire"):
             if hasattr(cur, k):
                 setattr(args, k, getattr(cur, k))
         # numerics switches: what the checkpoint was trained with stays, unless the user typed the option on THIS command line or
@@ -93,7 +93,8 @@ def init_optimizer(args, model, opt_type="noam"):
     if opt_type == "noam":
         core = _unwrap(model)
         bucket = int(getattr(args, "bucket_mb", 32.0) * (1 << 20)) if getattr(args, "parallel", False) else None
-        adam = FusedAdam(list(core.parameters()), betas=(0.9, 0.98), eps=1e-9, ddp_bucket_bytes=bucket)
+        adam = FusedAdam(list(core.parameters()), betas=(0.9, 0.98), eps=1e-9, ddp_bucket_bytes=bucket,
+                         ddp_wire=getattr(args, "grad_wire", "fp32"))
         return NoamOpt(args.dim_input, args.k_lr, args.warmup, adam, min_lr=args.min_lr)
     if opt_type == "sgd":
         return AnnealingOpt(args.lr, args.lr_anneal, torch.optim.SGD(model.parameters(), lr=args.lr, momentum=args.momentum,

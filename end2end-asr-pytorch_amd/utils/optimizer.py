@@ -12,11 +12,12 @@ from asr_hip import params as P
 
 
 class FusedAdam(torch.optim.Adam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, ddp_bucket_bytes=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, ddp_bucket_bytes=None, ddp_wire="fp32"):
         super().__init__(params, lr=lr, betas=betas, eps=eps)
         self.flat = None            # asr_hip.params.FlatParams, created once the parameters live on a GPU
         self.reducer = None         # asr_hip.ddp.GradReducer (only under --parallel with world_size > 1)
         self.ddp_bucket_bytes = ddp_bucket_bytes
+        self.ddp_wire = ddp_wire
         self.grad_scale = None      # device scalar set by clip_grad_norm_()
         self._t = 0
         self._ensure_flat()
@@ -45,7 +46,7 @@ class FusedAdam(torch.optim.Adam):
             import os
             if dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("ASR_FORCE_DDP") == "1"):
                 from asr_hip.ddp import GradReducer
-                self.reducer = GradReducer(self.flat, bucket_bytes=self.ddp_bucket_bytes)
+                self.reducer = GradReducer(self.flat, bucket_bytes=self.ddp_bucket_bytes, wire=self.ddp_wire)
                 self.reducer.broadcast_parameters(0)
         P.set_reducer(self.reducer)
 

@@ -121,6 +121,9 @@ int asr_tn_reduce_multi(const float* const* workspaces, float* const* dw, const 
                         const int* splits, int count, asr_stream_t stream);
 /* dst[i] = (dtype) src[i] : the one-launch refresh of the flat compute-dtype weight shadow after an optimiser step  */
 int asr_cast_flat(const float* src, void* dst, int64_t n, int dtype, asr_stream_t stream);
+/* dst[i] = (float) src_bf16[i]: the way back from the bf16 wire format of the data-parallel gradient exchange (--grad-wire bf16:
+ * asr_cast_flat into a staging buffer, all-reduce of the staging buffer, this).  Both pointers 16-byte aligned.                  */
+int asr_widen_flat(const void* src_bf16, float* dst, int64_t n, asr_stream_t stream);
 
 /* out[c*ld_out + r] = in[r*ld_in + c]   (operand preparation for dgrad / wgrad).  If colsum_acc != NULL also
  * colsum_acc[c] += sum_r in[r,c]  (the bias gradient, from the tile that is in LDS anyway).                    */

@@ -32,7 +32,11 @@ if "--feat_extractor" in flags and (flags.index("--feat_extractor") + 1 >= len(f
     flags.insert(flags.index("--feat_extractor") + 1, "")
 T_src = int(z["src"].shape[-1])
 args = constant.parse(flags + ["--precision", "fp32", "--cuda", "--parallel", "--bucket-mb", "0.05"] +
-                      (["--graph-buckets", str(T_src // 2)] if mode == "trainer" else []))
+                      (["--graph-buckets", str(T_src // 2)] if mode == "trainer" else []) +
+                      (["--grad-wire", "bf16"] if mode == "wire" else []))
+if mode == "wire":                              # tiny model: let its 12 K-element buckets take the bf16 wire too
+    from asr_hip.ddp import GradReducer
+    GradReducer.WIRE_MIN = 64
 V = int(z["V"])
 chars = [constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR] + [chr(0x4E00 + i) for i in range(V - 3)]
 l2i = {c: i for i, c in enumerate(chars)}; i2l = {i: c for c, i in l2i.items()}
@@ -55,11 +59,12 @@ sm = float(z["smoothing"])
 core = model.module
 noise = lambda k: k.endswith("key_linear.bias")
 
+WIRE = mode == "wire"      # gradients summed in bf16 by the collective: 2^-8 per value, the stats slot (loss, counts) stays exact
 def check_grads():
     cnt = float(adam.flat.stats[1])
     for k, p in core.named_parameters():
         ref = z["g0/" + k]
-        tol = 1e-6 + 2e-4 * np.abs(ref).max()
+        tol = 1e-6 + (1e-2 if WIRE else 2e-4) * np.abs(ref).max()
         np.testing.assert_allclose(p.grad.cpu().numpy() / cnt, ref, rtol=0, atol=tol, err_msg=k)
 
 if mode == "ctc":
@@ -98,7 +103,9 @@ if mode == "ctc":
             continue
         np.testing.assert_allclose(a.cpu().numpy(), b2.cpu().numpy(), rtol=0, atol=2.1 * float(z["lr1"]) if noise(k) else 2e-5, err_msg=k)
     dist.barrier(); dist.destroy_process_group(); print("ok", rank); sys.exit(0)
-if mode == "eager":
+if mode in ("eager", "wire"):
+    if WIRE:
+        assert red.wire == "bf16"
     for it in range(2):
         opt.zero_grad()
         pred, gold, hyp, _ = model(src, src_len, tgt)
@@ -111,7 +118,9 @@ if mode == "eager":
         opt.step()
         assert torch.equal(g_before, adam.flat.grad), "step() reduced the gradients a second time"
         gl = adam.global_loss()
-        assert abs(gl - float(z["loss" if it == 0 else "loss2"])) < 5e-5, (it, gl)
+        assert abs(gl - float(z["loss" if it == 0 else "loss2"])) < (2e-3 if WIRE and it else 5e-5), (it, gl)
+        if WIRE:
+            assert red._staging is not None and red._staging.dtype == torch.bfloat16
         assert int(adam.flat.stats[2]) == (int(z["num_correct"]) if it == 0 else int(adam.flat.stats[2]))
     assert abs(opt._rate - float(z["lr2"])) < 1e-12
 elif mode == "trainer":
@@ -138,7 +147,7 @@ lr_sum = float(z["lr1"]) + float(z["lr2"])
 for k, v in core.state_dict().items():
     if k.endswith(".pe") or k.endswith("num_batches_tracked"):
         continue
-    np.testing.assert_allclose(v.cpu().numpy(), z["w2/" + k], rtol=0, atol=2.1 * lr_sum if noise(k) else 2e-5, err_msg=k)
+    np.testing.assert_allclose(v.cpu().numpy(), z["w2/" + k], rtol=0, atol=2.1 * lr_sum if noise(k) else (2e-5 + 0.05 * lr_sum if WIRE else 2e-5), err_msg=k)
 if mode in ("graph", "trainer"):                 # a third step from the graphs keeps the ranks identical
     if mode == "trainer":
         tr._graph_step(model, opt, src, src_len, tgt, sm)
@@ -156,7 +165,7 @@ print("ok", rank)
 '''
 
 
-@pytest.mark.parametrize("mode", ["eager", "graph", "trainer"])
+@pytest.mark.parametrize("mode", ["eager", "graph", "trainer", "wire"])
 @pytest.mark.parametrize("name", ["raw_tiny", "vgg_tiny"])
 def test_two_ranks_equal_the_single_process_reference(tmp_path, name, mode):
     script = tmp_path / "w.py"
