@@ -257,63 +257,6 @@ class FanOutFn(Function):
         return g, None, None
 
 
-class CrossKVFn(Function):
-    """The cross-attention key / value projections of EVERY decoder layer as one GEMM: they all read the encoder output
-    (reference: transformer.py:296-299 calls each layer's encoder_attn, common_layers.py:181-187 projects key and value inside it), so
-    with the layers' key / value weights adjacent in the flat parameter buffer (utils/optimizer.py:_slot_order) the L x 2 projections are
-    one (B*Te, D) x (D, L*2*H*dk) contraction right after the encoder instead of L launches of a quarter of the size, and in backward
-    ONE data-gradient GEMM over K = L*2*H*dk instead of L accumulating ones.  The layers write their dK | dV into slices of
-    box['dkv'] (MHAFn.backward, kv_projected) and return no gradient for their view; this node contracts the whole buffer."""
-
-    @staticmethod
-    def forward(ctx, enc, box, *wb):
-        fused = box["fused"]
-        B, Te, D = enc.shape
-        x2 = enc.reshape(B * Te, D).contiguous()
-        kv = fused.fwd(x2).view(B, Te, fused.N)
-        ctx.fused, ctx.x2, ctx.box, ctx.params, ctx.shape = fused, x2, box, wb, (B, Te, D)
-        ctx.set_materialize_grads(False)
-        n = len(wb) // 4
-        w = fused.N // n
-        return tuple(kv[:, :, i * w:(i + 1) * w] for i in range(n))
-
-    @staticmethod
-    def backward(ctx, *grads):
-        B, Te, D = ctx.shape
-        fused = ctx.fused
-        dkv = ctx.box.pop("dkv", None)
-        w = fused.N // len(grads)
-        if any(g is not None for g in grads):                 # a consumer that went through plain autograd
-            if dkv is None:
-                dkv = torch.zeros((B, Te, fused.N), device=ctx.x2.device, dtype=ctx.x2.dtype)
-            for i, g in enumerate(grads):
-                if g is not None:
-                    dkv[:, :, i * w:(i + 1) * w] += g
-        d_enc = None
-        if dkv is not None:
-            d_enc = fused.bwd(dkv.view(B * Te, fused.N), ctx.x2, need_dx=ctx.needs_input_grad[0])
-            if d_enc is not None:
-                d_enc = d_enc.view(B, Te, D)
-        P.grad_ready(*ctx.params)
-        return (d_enc, None) + (None,) * len(ctx.params)
-
-
-def cross_kv_fused(layers):
-    """-> (_Fused over [Wk_0, Wv_0, Wk_1, ...], weights, biases) when every layer's cross attention has plain projections whose
-    parameters are adjacent in the flat buffers, else None."""
-    ws, bs = [], []
-    for layer in layers:
-        att = getattr(layer, "encoder_attn", None)
-        if att is None or not all(isinstance(getattr(getattr(att, n, None), "weight", None), torch.Tensor) for n in ("key_linear", "value_linear")):
-            return None                                   # (the Low-Rank Transformer's projections hold .u / .v, no .weight)
-        ws += [att.key_linear.weight, att.value_linear.weight]
-        bs += [att.key_linear.bias, att.value_linear.bias]
-    if any(b is None for b in bs):
-        return None
-    f = _Fused(ws, bs)
-    return (f, ws, bs) if f.ok else None
-
-
 # ================================================================================================ attention sub-layer
 class MHAFn(Function):
     @staticmethod
@@ -322,17 +265,13 @@ class MHAFn(Function):
         HD = H * dk
         B, Tq, D = q_in.shape
         self_attn = kv_in is None
-        projected = (not self_attn) and cfg.get("kv_projected", False)     # kv_in IS K|V (CrossKVFn)
         kv = q_in if self_attn else kv_in
         Tk = kv.shape[1]
         q2 = q_in.reshape(B * Tq, D).contiguous()
-        kv2 = None if projected else kv.reshape(B * Tk, D).contiguous()
+        kv2 = kv.reshape(B * Tk, D).contiguous()
         # one GEMM for Q|K|V (self attention) or K|V (cross attention) when the flat layout allows it
-        fused = None if projected else (_Fused([Wq, Wk, Wv], [bq, bk, bv]) if self_attn else _Fused([Wk, Wv], [bk, bv]))
-        if projected:
-            Q = _linear_fwd(q2, Wq, bq).view(B, Tq, HD)
-            K, V = kv_in[:, :, :HD], kv_in[:, :, HD:]
-        elif fused.ok and self_attn:
+        fused = _Fused([Wq, Wk, Wv], [bq, bk, bv]) if self_attn else _Fused([Wk, Wv], [bk, bv])
+        if fused.ok and self_attn:
             qkv = fused.fwd(q2).view(B, Tq, 3 * HD)
             Q, K, V = qkv[:, :, :HD], qkv[:, :, HD:2 * HD], qkv[:, :, 2 * HD:]
         elif fused.ok:
@@ -353,15 +292,11 @@ class MHAFn(Function):
         O, lse, attn = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
                                     causal=cfg.get("causal", False), scale=scale, p=p_att, seed=seed_a,
                                     want_attn=cfg.get("want_attn", False), o32=O32)
-        # output projection + dropout + residual + LayerNorm (+ row mask) as ONE launch where the library has it (bf16, d_model 512)
-        fused_ln = ops.gemm_nt_add_ln(O.view(B * Tq, HD), P.linear_weight(Wo), bo.data if bo is not None else None, q2, gamma.data,
-                                      beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
-        if fused_ln is not None:
-            out, Y, mean, rstd = fused_ln
-        else:
-            Y = _linear_fwd(O.view(B * Tq, HD), Wo, bo)
-            out, mean, rstd = ops.add_ln_fwd(Y, q2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
-        ctx.cfg, ctx.self_attn, ctx.fused, ctx.projected = cfg, self_attn, fused, projected
+        # (output projection, then dropout + residual + LayerNorm + row mask: the one-launch form lost -- 50 - 100 workgroups of whole rows on
+        # 256 CUs, profiles/r03_gemm_ln_ab.txt -- and was removed in round 4)
+        Y = _linear_fwd(O.view(B * Tq, HD), Wo, bo)
+        out, mean, rstd = ops.add_ln_fwd(Y, q2, gamma.data, beta.data, row_keep=cfg.get("row_keep"), p=p_att, seed=seed_o)
+        ctx.cfg, ctx.self_attn, ctx.fused = cfg, self_attn, fused
         ctx.seeds = (seed_a, seed_o)
         ctx.scale = scale
         ctx.t = (q2, kv2, Q, K, V, O, lse, Y, mean, rstd, O32)      # Y now holds z
@@ -388,19 +323,7 @@ class MHAFn(Function):
                                     P.grad_of(beta), p=cfg["p"], seed=seed_o)
         dO = _linear_bwd(d_y, O.view(B * Tq, HD), Wo, bo)
         # gradient buffers mirror the forward layout so that the fused projections see one contiguous (M, 2|3*HD) operand
-        if ctx.projected:
-            dQ = torch.empty((B, Tq, HD), device=dout.device, dtype=Q.dtype)
-            box = cfg.get("kv_grad_box") if ctx.need_dkv else None
-            slot, nslots = cfg["kv_slot"]
-            if box is not None:
-                if box.get("dkv") is None:                      # the first layer to run backward allocates; every layer fills its slice
-                    box["dkv"] = torch.empty((B, Tk, nslots * 2 * HD), device=dout.device, dtype=Q.dtype)
-                dkv = box["dkv"][:, :, slot * 2 * HD:(slot + 1) * 2 * HD]
-                dK, dV = dkv[:, :, :HD], dkv[:, :, HD:]
-            else:
-                dK = torch.empty_strided(K.shape, K.stride(), device=dout.device, dtype=Q.dtype)
-                dV = torch.empty_strided(V.shape, V.stride(), device=dout.device, dtype=Q.dtype)
-        elif fused.ok and ctx.self_attn:
+        if fused.ok and ctx.self_attn:
             dqkv = torch.empty((B, Tq, 3 * HD), device=dout.device, dtype=Q.dtype)
             dQ, dK, dV = dqkv[:, :, :HD], dqkv[:, :, HD:2 * HD], dqkv[:, :, 2 * HD:]
         elif fused.ok:
@@ -413,10 +336,6 @@ class MHAFn(Function):
                      causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV), o32=O32)
         d_kv = None
         # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulated straight into d_res
-        if ctx.projected:
-            _linear_bwd(dQ.view(B * Tq, HD), q2, Wq, bq, dx_out=d_res, accumulate=True)
-            P.grad_ready(Wq, bq, Wo, bo, gamma, beta)
-            return (d_res.view(B, Tq, D), None) + (None,) * 11
         if fused.ok and ctx.self_attn:
             fused.bwd(dqkv.view(B * Tq, 3 * HD), q2, dx_out=d_res, accumulate=True)
         elif fused.ok:

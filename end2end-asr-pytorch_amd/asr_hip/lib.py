@@ -41,7 +41,6 @@ _SIGS = {
     "asr_gemm_tn_workspace": (_L, [_I, _I, _I, _I, _I]),
     "asr_gemm_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _I, _I, _P]),
     "asr_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
-    "asr_gemm_nt_add_ln": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _U64, _P, _I, _P]),
     "asr_gemm_nn": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _I, _I, _I, _P]),
     "asr_gemm_nn_tn_splits": (_I, [_I, _I]),
     "asr_gemm_nn_tn_workspace": (_L, [_I, _I, _I, _I]),

@@ -416,32 +416,6 @@ def add_ln_fwd(y, residual, gamma, beta, post_add=None, row_keep=None, eps=1e-5,
     return out, mean, rstd
 
 
-# OFF by default: measured 6.43 / 6.50 ms per step against 6.31 for the two launches (profiles/r03_gemm_ln_ab.txt) -- 50 - 100 workgroups
-# of 64 rows, each streaming the whole 512 x K weight, lose more than the LayerNorm launch they save
-_gemm_ln = os.environ.get("ASR_GEMM_LN", "0") == "1"
-
-
-def gemm_nt_add_ln(x, W, bias, residual, gamma, beta, row_keep=None, eps=1e-5, p=0.0, seed=0, force=False):
-    """(out, z, mean, rstd) = LayerNorm(dropout(x W^T + bias) + residual) * row_keep from ONE launch (asr_gemm_nt_add_ln: bf16, 512
-    output features), or None when the shape is not taken -- callers then use gemm_nt + add_ln_fwd."""
-    M, K = x.shape
-    N = W.shape[0]
-    if ((not _gemm_ln and not force) or x.dtype != torch.bfloat16 or N != 512 or K % 64 != 0 or x.stride(1) != 1 or W.stride(1) != 1 or
-            W.dtype != x.dtype or (residual is not None and (not residual.is_contiguous() or residual.shape != (M, N)))):
-        return None
-    z = torch.empty((M, N), device=x.device, dtype=x.dtype)
-    out = torch.empty((M, N), device=x.device, dtype=x.dtype)
-    mean = torch.empty(M, device=x.device, dtype=torch.float32)
-    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
-    rc = L.load().asr_gemm_nt_add_ln(L.ptr(x), x.stride(0), L.ptr(W), W.stride(0), L.ptr(bias), L.ptr(residual), L.ptr(gamma), L.ptr(beta),
-                                     L.ptr(row_keep), L.ptr(z), L.ptr(out), L.ptr(mean), L.ptr(rstd), M, N, K, float(eps), float(p),
-                                     int(seed), _seed_dev(x), L.dt(x), L.stream())
-    if rc == L.EUNSUPPORTED:
-        return None
-    L.check(rc, "asr_gemm_nt_add_ln")
-    return out, z, mean, rstd
-
-
 def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=0):
     """Returns (d_res, d_y); d_y is d_res itself when p == 0 (unless weight gradients are being deferred)."""
     M, D = z.shape

@@ -193,163 +193,6 @@ void launch_nt(const BigGemmArgs& p, hipStream_t s) {
   hipLaunchKernelGGL((gemm_big_nt_kernel<BM, BN, NS, TO>), dim3((unsigned)ntiles), dim3(512), lds, s, p, tiles_n, ntiles);
 }
 
-// ------------------------------------------------------------------------------------------------ NT + dropout + residual + LayerNorm
-// out = LayerNorm(dropout(A W^T + bias) + residual) * row_keep for a projection whose WHOLE output row (N = 512) belongs to one
-// workgroup (reference: models/common_layers.py:197-198 `output = self.layer_norm(self.dropout(output) + residual)` after the
-// attention output projection, and the `*= non_pad_mask` of transformer.py:536-543) -- the epilogue does what asr_add_ln_fwd
-// does as a second launch, with the same rounding points (the projection and z = dropout(.) + residual are rounded to bf16 before they
-// are used further, z is what backward reads), the same dropout function of (seed, row * 512 + column) and the same two-pass
-// statistics.  Block = 64 rows x 512 columns, eight waves of 64 x 64; K steps of 64 through a two-stage LDS-DMA ring (8 KB of A,
-// 64 KB of W per stage); row sums meet through LDS.
-struct BigLnArgs {
-  const void* A; const void* W; const float* bias; const void* res; const float* gamma; const float* beta; const uint8_t* keep;
-  void* z; void* out; float* mean; float* rstd;
-  int64_t lda, ldw;
-  int M, K;
-  float eps, inv_keep; uint32_t thr; uint64_t seed; const uint64_t* seed_dev;
-};
-
-__global__ __launch_bounds__(512, 2) void gemm_big_nt_ln512_kernel(BigLnArgs p) {
-  constexpr int N = 512, BM = 64, FM = 4, FN = 4;
-  constexpr int TA = BM * 128, TB = N * 128, STAGE = TA + TB, NS = 2, LPS = 1 + 8;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* s_part = reinterpret_cast<float*>(smem + NS * STAGE);       // [2][8 waves][64 rows]
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * BM;
-  const int nk = p.K / 64;
-  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
-
-  const unsigned char* srcA[1];
-  const unsigned char* srcB[8];
-  big_src<BM>(static_cast<const unsigned char*>(p.A), p.lda * 2, m0, p.M, tid, srcA);
-  big_src<N>(static_cast<const unsigned char*>(p.W), p.ldw * 2, 0, N, tid, srcB);
-  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
-  auto stage = [&](int kt) __attribute__((always_inline)) {
-    const unsigned sl = wave_lds + (unsigned)((kt % NS) * STAGE);
-    const int64_t kb = (int64_t)kt * 128;
-    big_dma(sl, srcA[0] + kb);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) big_dma(sl + TA + i * 8192, srcB[i] + kb);
-  };
-  f32x4_t acc[FM][FN];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  const int offA = lr * 128, offB = TA + (wave * 64 + lr) * 128;
-  const int sw0 = ((g) ^ (lr & 7)) << 4, sw1 = ((4 + g) ^ (lr & 7)) << 4;
-  stage(0);
-  for (int kt = 0; kt < nk; ++kt) {
-    big_wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (kt + 1 < nk) stage(kt + 1);
-    const unsigned char* s = smem + (kt % NS) * STAGE;
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-      const int sw = ms ? sw1 : sw0;
-      uint4 a[FM], b[FN];
-#pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = *reinterpret_cast<const uint4*>(s + offB + j * 2048 + sw);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = *reinterpret_cast<const uint4*>(s + offA + i * 2048 + sw);
-#pragma unroll
-      for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) mma16<bf16_t>(acc[i][j], b[j], a[i]);     // lane (lr, g): C[row 16 i + lr][col 64 w + 16 j + 4 g + r]
-    }
-  }
-
-  // ---- epilogue.  Every global operand of the lane first (one memory round trip), then the arithmetic.
-  const bf16_t* R = static_cast<const bf16_t*>(p.res);
-  bf16_t* Z = static_cast<bf16_t*>(p.z);
-  bf16_t* O = static_cast<bf16_t*>(p.out);
-  f32x4_t gm[FN], bt[FN], bs[FN];
-#pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int col = wave * 64 + j * 16 + g * 4;
-    gm[j] = *reinterpret_cast<const f32x4_t*>(p.gamma + col);
-    bt[j] = *reinterpret_cast<const f32x4_t*>(p.beta + col);
-    bs[j] = p.bias ? *reinterpret_cast<const f32x4_t*>(p.bias + col) : f32x4_t{0.f, 0.f, 0.f, 0.f};
-  }
-  uint2 rr[FM][FN];
-  float kp[FM];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = m0 + i * 16 + lr, rc = row < p.M ? row : p.M - 1;
-    kp[i] = p.keep ? (p.keep[rc] ? 1.f : 0.f) : 1.f;
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-      rr[i][j] = R ? *reinterpret_cast<const uint2*>(R + (int64_t)rc * N + wave * 64 + j * 16 + g * 4) : make_uint2(0u, 0u);
-  }
-  float zs[FM][FN][4];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = m0 + i * 16 + lr;
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int col = wave * 64 + j * 16 + g * 4;
-      const float r4[4] = {bf16_to_f32((bf16_t)(rr[i][j].x & 0xffffu)), bf16_to_f32((bf16_t)(rr[i][j].x >> 16)),
-                           bf16_to_f32((bf16_t)(rr[i][j].y & 0xffffu)), bf16_to_f32((bf16_t)(rr[i][j].y >> 16))};
-      bf16_t zb[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float v = bf16_to_f32(f32_to_bf16(acc[i][j][r] + bs[j][r]));            // the projection, rounded as its own launch stores it
-        if (p.thr) v = asr_keep(seed, (uint64_t)row * N + col + r, p.thr) ? v * p.inv_keep : 0.f;
-        v += r4[r];
-        zb[r] = f32_to_bf16(v);                                                  // z is what backward reads: rounded before it is used
-        zs[i][j][r] = bf16_to_f32(zb[r]);
-        s += zs[i][j][r];
-      }
-      if (row < p.M)
-        *reinterpret_cast<uint2*>(Z + (int64_t)row * N + col) = make_uint2((uint32_t)zb[0] | ((uint32_t)zb[1] << 16), (uint32_t)zb[2] | ((uint32_t)zb[3] << 16));
-    }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    if (g == 0) s_part[wave * 64 + i * 16 + lr] = s;
-  }
-  __syncthreads();
-  float mu[FM];
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_part[w * 64 + i * 16 + lr];
-    mu[i] = t * (1.f / (float)N);
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < FN; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { const float d = zs[i][j][r] - mu[i]; q += d * d; }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    if (g == 0) s_part[512 + wave * 64 + i * 16 + lr] = q;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < FM; ++i) {
-    const int row = m0 + i * 16 + lr;
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) t += s_part[512 + w * 64 + i * 16 + lr];
-    const float rs = rsqrtf(t * (1.f / (float)N) + p.eps);
-    if (row < p.M) {
-      if (wave == 0 && g == 0) { p.mean[row] = mu[i]; p.rstd[row] = rs; }
-#pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        bf16_t ob[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ob[r] = f32_to_bf16(((zs[i][j][r] - mu[i]) * rs * gm[j][r] + bt[j][r]) * kp[i]);
-        *reinterpret_cast<uint2*>(O + (int64_t)row * N + wave * 64 + j * 16 + g * 4) =
-            make_uint2((uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16));
-      }
-    }
-  }
-}
-
 // ------------------------------------------------------------------------------------------------ NN
 // C (M, N) bf16 (+)= A (M, K) . B (K, N), optionally zeroed where mask (laid out like C) <= 0: a linear layer's data gradient
 // dX = dY . W with W in its natural (out_features, in_features) layout (reference: nn.Linear backward through autograd).
@@ -520,32 +363,6 @@ bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
     else launch_nt<128, 128, 3, bf16_t>(p, stream);
   }
   return hipGetLastError() == hipSuccess;
-}
-
-extern "C" int asr_gemm_nt_add_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
-                                  const float* gamma, const float* beta, const uint8_t* row_keep, void* z, void* out, float* mean,
-                                  float* rstd, int M, int N, int K, float eps, float p, uint64_t seed, const uint64_t* seed_dev,
-                                  int dtype, hipStream_t stream) {
-  ASR_CHECK_ARG(A && W && gamma && beta && z && out && mean && rstd && M >= 0 && N > 0 && K > 0 && p >= 0.f && p < 1.f);
-  if (dtype != ASR_BF16 || N != 512 || K % 64 != 0 || lda % 8 != 0 || ldw % 8 != 0 || lda < K || ldw < K || !aligned16(A) || !aligned16(W) ||
-      !aligned16(z) || !aligned16(out) || (residual && !aligned16(residual)) || !aligned16(gamma) || !aligned16(beta) ||
-      (bias && !aligned16(bias)))
-    return ASR_EUNSUPPORTED;
-  if (M == 0) return ASR_OK;
-  BigLnArgs q{};
-  q.A = A; q.W = W; q.bias = bias; q.res = residual; q.gamma = gamma; q.beta = beta; q.keep = row_keep; q.z = z; q.out = out;
-  q.mean = mean; q.rstd = rstd; q.lda = lda; q.ldw = ldw; q.M = M; q.K = K; q.eps = eps;
-  q.thr = asr_drop_threshold(p); q.inv_keep = 1.f / (1.f - p); q.seed = seed; q.seed_dev = seed_dev;
-  constexpr size_t lds = (size_t)2 * (64 * 128 + 512 * 128) + 2 * 512 * sizeof(float);
-  static bool granted = false;
-  if (!granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_nt_ln512_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    granted = true;
-  }
-  AsrProfScope prof(ASR_OP_GEMM, stream);
-  hipLaunchKernelGGL(gemm_big_nt_ln512_kernel, dim3((unsigned)((M + 63) / 64)), dim3(512), lds, stream, q);
-  ASR_LAUNCH_CHECK();
-  return ASR_OK;
 }
 
 bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream) {

@@ -6,7 +6,6 @@ compared against the POST-CNN time axis; every parameter with dim > 1 is re-init
 decoder rows whose input token is EOS are zeroed; targets are always padded to --tgt-max-len; the encoder owns a Dropout
 it never applies.
 """
-import os
 
 import numpy as np
 import torch
@@ -15,7 +14,7 @@ import torch.nn as nn
 from asr_hip import functions as F_
 from asr_hip import ops
 from models.common_layers import (LowRankMultiHeadAttention, LowRankPositionwiseFeedForward, MultiHeadAttention,
-                                  PositionalEncoding, PositionwiseFeedForwardWithConv, _to_compute)
+                                  PositionalEncoding, PositionwiseFeedForwardWithConv)
 from utils import constant
 
 
@@ -152,8 +151,6 @@ class Decoder(nn.Module):
     """Decoder(id2label, num_src_vocab, num_trg_vocab, num_layers, num_heads, dim_emb, dim_model, dim_inner, dim_key,
     dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False)   (reference: transformer.py:206-305)"""
 
-    group_cross_kv = os.environ.get("ASR_GROUP_CROSS_KV", "0") == "1"       # off by default: measured 6.52 / 6.56 ms per step grouped, 6.50 / 6.51 per layer (profiles/r03_step_ab_scheduled_dw_big_nt.txt)
-
     def __init__(self, id2label, num_src_vocab, num_trg_vocab, num_layers, num_heads, dim_emb, dim_model, dim_inner, dim_key,
                  dim_value, dropout=0.1, trg_max_length=1000, emb_trg_sharing=False, rank=0):
         super().__init__()
@@ -202,19 +199,12 @@ class Decoder(nn.Module):
         # one gradient buffer for the encoder output: the layers' cross-attention backward GEMMs accumulate into it
         box = None
         enc_views = [encoder_padded_outputs] * len(self.layers)
-        kv_pre = None
-        grouped = F_.cross_kv_fused(self.layers) if len(self.layers) > 1 and self.group_cross_kv else None
-        if grouped is not None:
-            # every layer's cross-attention K | V projection of the encoder output in ONE GEMM (and one data-gradient GEMM back)
-            box = {"fused": grouped[0]}
-            kv_pre = F_.CrossKVFn.apply(_to_compute(encoder_padded_outputs), box, *grouped[1], *grouped[2])
-        elif torch.is_grad_enabled() and encoder_padded_outputs.requires_grad and len(self.layers) > 1:
+        if torch.is_grad_enabled() and encoder_padded_outputs.requires_grad and len(self.layers) > 1:
             box = {}
             enc_views = F_.FanOutFn.apply(encoder_padded_outputs, len(self.layers), box)
         for li, layer in enumerate(self.layers):
             x, sa, ea = layer(x, enc_views[li], row_keep=row_keep, self_key_pad=key_pad, enc_key_len=enc_len,
-                              need_attn=need_attn, kv_grad_box=box,
-                              kv_projected=None if kv_pre is None else (kv_pre[li], (li, len(self.layers))))
+                              need_attn=need_attn, kv_grad_box=box)
             self_attns.append(sa)
             enc_attns.append(ea)
         # with --emb_trg_sharing the embedding backward (which runs last) reports the shared weight as ready
@@ -357,13 +347,10 @@ class DecoderLayer(nn.Module):
             return
         self.self_attn = MultiHeadAttention(num_heads, dim_model, dim_key, dim_value, dropout=dropout)
         self.encoder_attn = MultiHeadAttention(num_heads, dim_model, dim_key, dim_value, dropout=dropout)
-        # hint for the flat-parameter layout: the key / value weights of ALL layers' cross attention adjacent (one grouped GEMM)
-        self.encoder_attn.key_linear.weight._asr_cross_kv = True
         self.pos_ffn = PositionwiseFeedForwardWithConv(dim_model, dim_inner, dropout=dropout)
 
     def forward(self, decoder_input, encoder_output, non_pad_mask=None, self_attn_mask=None, dec_enc_attn_mask=None,
-                row_keep=None, self_key_pad=None, enc_key_len=None, causal_only=False, need_attn=False, kv_grad_box=None,
-                kv_projected=None):
+                row_keep=None, self_key_pad=None, enc_key_len=None, causal_only=False, need_attn=False, kv_grad_box=None):
         if causal_only:
             x, sa = self.self_attn(decoder_input, decoder_input, decoder_input, causal=True, need_attn=need_attn)
             x, ea = self.encoder_attn(x, encoder_output, encoder_output, need_attn=need_attn)
@@ -374,6 +361,6 @@ class DecoderLayer(nn.Module):
         x, sa = self.self_attn(decoder_input, decoder_input, decoder_input, mask=self_attn_mask if generic else None,
                                key_pad=self_key_pad, causal=not generic, row_keep=row_keep, need_attn=need_attn)
         x, ea = self.encoder_attn(x, encoder_output, encoder_output, mask=dec_enc_attn_mask, key_len=enc_key_len,
-                                  row_keep=row_keep, need_attn=need_attn, kv_grad_box=kv_grad_box, kv_projected=kv_projected)
+                                  row_keep=row_keep, need_attn=need_attn, kv_grad_box=kv_grad_box)
         x = self.pos_ffn(x, row_keep=row_keep)
         return x, sa, ea

@@ -107,9 +107,7 @@ class MultiHeadAttention(nn.Module):
         self.query_linear.weight._asr_qkv = True      # hint for the flat-parameter layout: q/k/v weights adjacent
 
     def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
-                need_attn=True, kv_grad_box=None, kv_projected=None):
-        """kv_projected = (K|V view (B,Tk,2*H*dk), (slot, slots)): the key / value projections were already applied by the
-        decoder's one grouped GEMM (asr_hip/functions.py:CrossKVFn); key / value are then only used for their length."""
+                need_attn=True, kv_grad_box=None):
         if key is not value:
             raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
         cfg = dict(H=self.num_heads, dk=self.dim_key, p=self.dropout.p if self.training else 0.0, key_len=key_len,
@@ -117,9 +115,6 @@ class MultiHeadAttention(nn.Module):
                    want_attn=need_attn, kv_grad_box=kv_grad_box)
         q = _to_compute(query)
         kv = None if key is query else _to_compute(key)
-        if kv_projected is not None:
-            kv, cfg["kv_slot"] = kv_projected
-            cfg["kv_projected"] = True
         res = F_.MHAFn.apply(q, kv, self.query_linear.weight, self.query_linear.bias, self.key_linear.weight,
                              self.key_linear.bias, self.value_linear.weight, self.value_linear.bias,
                              self.output_linear.weight, self.output_linear.bias, self.layer_norm.weight,
@@ -214,7 +209,7 @@ class LowRankMultiHeadAttention(nn.Module):
         self.dropout = nn.Dropout(dropout)
 
     def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
-                need_attn=False, kv_grad_box=None, kv_projected=None):
+                need_attn=False, kv_grad_box=None):
         if key is not value:
             raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
         p = self.dropout.p if self.training else 0.0

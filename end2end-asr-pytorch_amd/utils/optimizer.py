@@ -54,33 +54,18 @@ class FusedAdam(torch.optim.Adam):
     def _slot_order(plist):
         """Registration order, except that inside every attention block the three projection weights (and then their
         three biases) are made adjacent, so Q/K/V (or K/V) run as ONE GEMM over a contiguous slice of the flat buffers.
-        nn.Module registration order inside MultiHeadAttention is q.w q.b k.w k.b v.w v.b ... (models/common_layers.py).
-        The decoder's cross-attention blocks (key weight flagged _asr_cross_kv) give their key / value parameters to one
-        run placed after the last of them: k.w_0 v.w_0 k.w_1 v.w_1 ... then k.b_0 v.b_0 ...: every layer's pair is still
-        adjacent (one K|V GEMM per layer) and all of them together are ONE GEMM over the encoder output
-        (asr_hip/functions.py:CrossKVFn)."""
+        nn.Module registration order inside MultiHeadAttention is q.w q.b k.w k.b v.w v.b ... (models/common_layers.py)."""
         out, i = [], 0
-        cross_w, cross_b = [], []
-        n_cross = sum(1 for p in plist if getattr(p, "_asr_cross_kv", False))
         while i < len(plist):
             grp = plist[i:i + 6]
             if (len(grp) == 6 and all(g.dim() == 2 for g in grp[0::2]) and all(g.dim() == 1 for g in grp[1::2]) and
                     grp[0].shape == grp[2].shape == grp[4].shape and grp[1].shape == grp[3].shape == grp[5].shape and
                     grp[0].shape[0] == grp[1].shape[0] and getattr(grp[0], "_asr_qkv", False)):
-                if getattr(grp[2], "_asr_cross_kv", False) and n_cross > 1:
-                    out += [grp[0], grp[1]]
-                    cross_w += [grp[2], grp[4]]
-                    cross_b += [grp[3], grp[5]]
-                    if len(cross_w) == 2 * n_cross:
-                        out += cross_w + cross_b
-                else:
-                    out += [grp[0], grp[2], grp[4], grp[1], grp[3], grp[5]]
+                out += [grp[0], grp[2], grp[4], grp[1], grp[3], grp[5]]
                 i += 6
             else:
                 out.append(plist[i])
                 i += 1
-        if len(cross_w) != 2 * n_cross and cross_w:      # a flagged weight outside a recognised block: keep everything, ungrouped
-            out += cross_w + cross_b
         return out
 
     def _bind_state(self):

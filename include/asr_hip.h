@@ -76,16 +76,6 @@ int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C
                 float* workspace, int64_t workspace_floats, int M, int N, int K, int splits, int dtype,
                 asr_stream_t stream);
 
-/* out = LayerNorm(dropout(A W^T + bias) + residual) * row_keep in ONE launch, for a projection whose whole output row belongs to a
- * workgroup (N = 512): the attention output projection followed by `self.layer_norm(self.dropout(output) + residual)` and the
- * `*= non_pad_mask` (models/common_layers.py:197-198, models/asr/transformer.py:536-543).  z (M, N) receives dropout(.) + residual
- * (what asr_add_ln_bwd reads), mean / rstd the row statistics.  Same rounding points, dropout function and statistics as asr_gemm_nt
- * followed by asr_add_ln_fwd.  bf16, N = 512, K a multiple of 64; ASR_EUNSUPPORTED otherwise (callers use the pair).            */
-int asr_gemm_nt_add_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const void* residual,
-                       const float* gamma, const float* beta, const uint8_t* row_keep, void* z, void* out, float* mean, float* rstd,
-                       int M, int N, int K, float eps, float p, uint64_t seed, const uint64_t* seed_dev, int dtype,
-                       asr_stream_t stream);
-
 /* The weight (and bias) gradients of up to 32 linear layers in ONE launch: dw[i] (N[i],K[i]) fp32 += dy[i][:, :N]^T x[i][:, :K],
  * db[i] (N[i]) += column sums of dy[i] (db[i] may be NULL), each over M[i] rows; bf16 operands with 16-byte aligned rows.  A weight
  * gradient is off the critical path of backward (models/common_layers.py:136-142,181-187 leave it to autograd's order): queued and
