@@ -51,7 +51,7 @@ extern "C" const char* asr_strerror(int code) {
     default: return "unknown error";
   }
 }
-extern "C" int asr_abi_version(void) { return 3; }
+extern "C" int asr_abi_version(void) { return 4; }
 
 extern "C" int asr_prof_enable(int op, int enable) {
   if (op < 0 || op >= ASR_OP_COUNT) return ASR_EINVAL;

@@ -40,7 +40,7 @@ enum {
 };
 
 const char* asr_strerror(int code);
-int asr_abi_version(void);
+int asr_abi_version(void);   /* 4 since round 4: asr_gemm_nt_add_ln removed; the state block of asr_adam_noam_step is {seed counter, step, skipped flag, unused} */
 
 /* ---- tuning / A-B switches.  The library reads no environment variables and has no other mutable global state than
  * this table and the profiling slots below: a switch (names: the ASR_* list of DESIGN.md section 4 without the prefix,

@@ -20,7 +20,7 @@ def test_library_loads_and_exports_header_symbols():
     for s in syms:
         assert hasattr(h, s), s
     assert set(syms) == set(lib._SIGS), set(syms) ^ set(lib._SIGS)
-    assert h.asr_abi_version() == 3
+    assert h.asr_abi_version() == 4
     assert h.asr_strerror(-3).decode().startswith("unsupported")
     # pure host helpers of the ABI (no device needed): workspace sizes
     assert h.asr_add_ln_bwd_workspace(6400, 512) == 800 * 1024
