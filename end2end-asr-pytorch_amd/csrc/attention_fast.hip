@@ -66,6 +66,14 @@ __device__ __forceinline__ void lds_dma16(unsigned lds_wave_base, const void* sr
                : "s"(lds_wave_base), "v"(src)
                : "memory");
 }
+// 4 bytes per lane (a row of 64 floats per wave)
+__device__ __forceinline__ void lds_dma4(unsigned lds_wave_base, const void* src) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds_wave_base), "v"(src)
+               : "memory");
+}
 // The same with a wave-uniform base address (SGPR pair) + a per-thread 32-bit byte offset that does not change from tile to tile:
 // the loops of the forward kernel hoist the offsets (tile_voff) and pay no vector instruction per prefetch (the per-tile 64-bit
 // row * stride arithmetic was 24 of the 245 vector instructions of a forward tile).
@@ -118,6 +126,32 @@ __device__ __forceinline__ uint4 frag_cols(const unsigned char* tile, int c0, in
   // the builtin (not inline asm) so that the compiler tracks lgkmcnt for the result registers itself
   const uint2 lo = asr_lds_read_tr16(tile + row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
   const uint2 hi = asr_lds_read_tr16(tile + (row + 16) * ROWB + ((chunk ^ ((row + 16) & 7)) << 4) + half * 8);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+// The same two reads with the LANE part of the address (row within its 16-row fragment, swizzled chunk) computed once per kernel:
+// the row of a fragment read is 16 X + lr (rows) or 32 ms + 4 g + (lr >> 2) (+ 16) (columns), so row & 7 -- the swizzle -- does not
+// depend on X / ms, and what is left per read is tile base + lane offset + a compile-time constant that fits the DS offset field.
+// (Computed per read, the address arithmetic was ~20 of the ~100 vector instructions of a backward half tile.)
+struct FragOff {
+  unsigned rows[2];          // [ds]
+  unsigned cols[4];          // [df]
+  __device__ __forceinline__ void init(int lr, int g) {
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) rows[ds] = (unsigned)(lr * ROWB + (((ds * 4 + g) ^ (lr & 7)) << 4));
+    const int row = 4 * g + (lr >> 2);
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      const int chunk = 2 * df + ((lr & 3) >> 1), half = lr & 1;       // column 16 df + 4 (lr & 3): 16-byte chunk, 8-byte half
+      cols[df] = (unsigned)(row * ROWB + ((chunk ^ (row & 7)) << 4) + half * 8);
+    }
+  }
+};
+__device__ __forceinline__ uint4 frag_rows_at(const unsigned char* tile, unsigned off, int X) {
+  return *reinterpret_cast<const uint4*>(tile + off + X * 16 * ROWB);
+}
+__device__ __forceinline__ uint4 frag_cols_at(const unsigned char* tile, unsigned off, int ms) {
+  const uint2 lo = asr_lds_read_tr16(tile + off + 32 * ms * ROWB);
+  const uint2 hi = asr_lds_read_tr16(tile + off + (32 * ms + 16) * ROWB);
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 // B-operand pack from C fragments v[f][r] = X[16 f + 4 g + r][col]: k = 32 ms + 4 g + r (f = 2 ms), 32 ms + 16 + 4 g + r (f = 2 ms + 1)
@@ -192,6 +226,8 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
   const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
   const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   const float c2 = p.scale * LOG2E;
+  FragOff fo;
+  fo.init(lr, g);
 
   uint4 qf[NQ][2];
   uint32_t rkey[NQ];
@@ -235,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
       for (int qi = 0; qi < NQ; ++qi) s[qi][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) {
-        const uint4 a = frag_rows(sK, kf * 16 + lr, ds, g);
+        const uint4 a = frag_rows_at(sK, fo.rows[ds], kf);
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) mma(s[qi][kf], a, qf[qi][ds]);
       }
@@ -299,7 +335,7 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_d64_kernel(AttnArgs p) {
     for (int ms = 0; ms < 2; ++ms)
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const uint4 vt = frag_cols(sV, df * 16, ms, lr, g);
+        const uint4 vt = frag_cols_at(sV, fo.cols[df], ms);
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) mma(o[qi][df], vt, pb[qi][ms]);
       }
@@ -348,6 +384,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
   const bf16_t* dOb = static_cast<const bf16_t*>(p.dO) + (int64_t)b * p.o_sb + (int64_t)h * HD;
   const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
   const float c2 = p.scale * LOG2E;
+  const float keep_prob = p.thr ? 1.f / p.inv_keep : 1.f, out_scale = p.thr ? p.scale * p.inv_keep : p.scale;
+  const uint32_t thr_hi = p.thr << 16;            // field >= thr  <=>  (field << 16) >= thr_hi (thr <= 0xffff)
+  const unsigned voK[2] = {tile_voff(p.k_st, tid, 0), tile_voff(p.k_st, tid, 1)};
+  const unsigned voV[2] = {tile_voff(p.v_st, tid, 0), tile_voff(p.v_st, tid, 1)};
+  FragOff fo;
+  fo.init(lr, g);
 
   uint4 qf[NQ][2], dof[NQ][2];
   uint32_t rkey[NQ];
@@ -360,10 +402,14 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
       qf[qi][ds] = load_row16(Qb, p.q_st, q, p.Tq, ds * 32 + g * 8);
       dof[qi][ds] = load_row16(dOb, p.o_st, q, p.Tq, ds * 32 + g * 8);
     }
-    rkey[qi] = drop_row_key(seed, drop_row(p, b, h, q));
+    // first hash stage of the dropout mask as a running sum: (row key + key pair) * DROP_C1 is linear modulo 2^32, the lane part
+    // (row, 2 g) is multiplied once here, a tile adds 32 * DROP_C1, the (half, fragment, pair) part is a literal
+    rkey[qi] = (drop_row_key(seed, drop_row(p, b, h, q)) + 2u * (uint32_t)g) * DROP_C1;
     const int64_t si = ((int64_t)b * p.H + h) * p.Tq + (q < p.Tq ? q : p.Tq - 1);
     lse2[qi] = p.lse[si] * LOG2E;                 // +inf for fully masked rows: exp2(-inf) = 0
-    dlt[qi] = p.delta[si];
+    // dS = P (keep / (1 - p) dP - delta) = 1 / (1 - p) * P (keep dP - (1 - p) delta): the rescale leaves the loop (it joins p.scale
+    // in the epilogue), the mask becomes a plain select of dP
+    dlt[qi] = p.delta[si] * keep_prob;
   }
   f32x4_t dq[NQ][4];
 #pragma unroll
@@ -376,8 +422,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
   const int ntile = (kstop + 63) >> 6;
 
   if (ntile > 0) {
-    stage_tile(smem, Kb, p.k_st, 0, p.Tk, tid, wave);
-    stage_tile(smem + TILE, Vb, p.v_st, 0, p.Tk, tid, wave);
+    stage_tile_h(smem, Kb, p.k_st, 0, p.Tk, voK, tid, wave);
+    stage_tile_h(smem + TILE, Vb, p.v_st, 0, p.Tk, voV, tid, wave);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -399,8 +445,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
         }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
-          const uint4 ak = frag_rows(sK, (2 * ms + k2) * 16 + lr, ds, g);
-          const uint4 av = frag_rows(sV, (2 * ms + k2) * 16 + lr, ds, g);
+          const uint4 ak = frag_rows_at(sK, fo.rows[ds], 2 * ms + k2);
+          const uint4 av = frag_rows_at(sV, fo.rows[ds], 2 * ms + k2);
 #pragma unroll
           for (int qi = 0; qi < NQ; ++qi) {
             mma(s[qi][k2], ak, qf[qi][ds]);
@@ -413,8 +459,8 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntile) {
           unsigned char* nb = smem + ((t + 1) & 1) * 2 * TILE;
-          stage_tile(nb, Kb, p.k_st, k0 + 64, p.Tk, tid, wave);
-          stage_tile(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, tid, wave);
+          stage_tile_h(nb, Kb, p.k_st, k0 + 64, p.Tk, voK, tid, wave);
+          stage_tile_h(nb + TILE, Vb, p.v_st, k0 + 64, p.Tk, voV, tid, wave);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -426,9 +472,9 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
           for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
-              const uint32_t y = drop_pair_bits(rkey[qi], (uint32_t)(k0 + (2 * ms + k2) * 16 + g * 4 + pr * 2) >> 1);
-              dp[qi][k2][2 * pr] = (y & 0xffffu) < p.thr ? 0.f : dp[qi][k2][2 * pr] * p.inv_keep;
-              dp[qi][k2][2 * pr + 1] = (y >> 16) < p.thr ? 0.f : dp[qi][k2][2 * pr + 1] * p.inv_keep;
+              const uint32_t y = drop_pair_mix(rkey[qi] + (uint32_t)((2 * ms + k2) * 8 + pr) * DROP_C1);
+              dp[qi][k2][2 * pr] = (y << 16) < thr_hi ? 0.f : dp[qi][k2][2 * pr];
+              dp[qi][k2][2 * pr + 1] = y < thr_hi ? 0.f : dp[qi][k2][2 * pr + 1];
             }
         }
 #pragma unroll
@@ -442,11 +488,13 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
       }
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const uint4 kt = frag_cols(sK, df * 16, ms, lr, g);
+        const uint4 kt = frag_cols_at(sK, fo.cols[df], ms);
 #pragma unroll
         for (int qi = 0; qi < NQ; ++qi) mma(dq[qi][df], kt, pb[qi]);
       }
     }
+#pragma unroll
+    for (int qi = 0; qi < NQ; ++qi) rkey[qi] += 32u * DROP_C1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -457,7 +505,7 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
     bf16_t* o = static_cast<bf16_t*>(p.dQ) + (int64_t)b * p.q_sb + (int64_t)q * p.q_st + (int64_t)h * HD;
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
-      const f32x4_t v = dq[qi][df] * p.scale;
+      const f32x4_t v = dq[qi][df] * out_scale;
       *reinterpret_cast<uint2*>(o + df * 16 + g * 4) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
     }
   }
@@ -486,6 +534,10 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   const int kend = key_end(p, b);
   const int64_t stat0 = ((int64_t)b * p.H + h) * p.Tq;
   const uint32_t field_sh = (uint32_t)(lr & 1) << 4;        // this lane's keys are kw + 16 ki + lr with kw a multiple of 16: key & 1 = lr & 1
+  const unsigned voQ[2] = {tile_voff(p.q_st, tid, 0), tile_voff(p.q_st, tid, 1)};
+  const unsigned voO[2] = {tile_voff(p.o_st, tid, 0), tile_voff(p.o_st, tid, 1)};
+  FragOff fo;
+  fo.init(lr, g);
 
   uint4 kfr[NK][2], vfr[NK][2];
 #pragma unroll
@@ -503,14 +555,30 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   // causal: query tiles that end before the first key of this workgroup never see it
   const int t0 = p.causal ? (kb * FKW) >> 6 : 0;
   const int ntile = (p.Tq + 63) >> 6;
+  // first hash stage of the dropout mask, (row key + key pair) * DROP_C1, as a running sum (linear modulo 2^32; the row key is linear
+  // in the row, + DROP_ROW_C per row): the lane part (row 4 g + 2 (lr & 1) of tile t0, this lane's key pair) is multiplied once, a
+  // tile adds 64 rows, the (half, fragment) part and the second row of the lane are literals
+  constexpr uint32_t DROP_ROW_C = 0x9E3779B1u;
+  uint32_t ybase[NK];
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki)
+    ybase[ki] = (drop_row_key(seed, drop_row(p, b, h, (t0 << 6) + g * 4 + 2 * (lr & 1))) + ((uint32_t)(kw + ki * 16 + lr) >> 1)) * DROP_C1;
 
-  // lse (x log2 e) / delta of query tile t for threads 0..63 / 64..127.  An ordinary load: it must have been CONSUMED before the
-  // hand-issued DMA of that tile goes out (vmcnt retires in order: waiting for it later would wait for the DMA as well), so the
-  // loop loads it at the top of tile t - 1 and stores it to LDS right before the prefetch.
+  // lse / delta of query tile t (64 floats each).  Full tiles: part of the tile's DMA request (wave 0 fetches the lse row, wave 1
+  // the delta row, 4 bytes per lane) -- as ordinary loads stored to LDS by the threads, every tile exposed a global-memory round
+  // trip: the value has to be CONSUMED before the hand-issued DMA of that tile goes out (vmcnt retires in order: waiting for it
+  // later would wait for the DMA as well), i.e. half a tile after it was requested.  The ragged last tile (rows past Tq must read
+  // lse = +inf: P = exp2(-inf) = 0) and the first tile keep the load / store path.
   auto load_stat = [&](int t) __attribute__((always_inline)) -> float {
     const int ql = tid & 63, qq = (t << 6) + ql;
-    if (tid < 64) return qq < p.Tq ? p.lse[stat0 + qq] * LOG2E : INFINITY;        // rows past Tq: P = exp2(-inf) = 0
+    if (tid < 64) return qq < p.Tq ? p.lse[stat0 + qq] : INFINITY;
     return (tid < 128 && qq < p.Tq) ? p.delta[stat0 + qq] : 0.f;
+  };
+  auto dma_stats = [&](int t, int buf) __attribute__((always_inline)) {
+    if (wave < 2) {
+      const float* src = (wave == 0 ? p.lse : p.delta) + stat0 + (t << 6) + lane;
+      lds_dma4((unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)&s_stat[buf][wave][0], src);
+    }
   };
   auto stage_stats = [&](int t, int buf) __attribute__((always_inline)) {
     const float v = load_stat(t);
@@ -518,8 +586,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   };
   if (t0 < ntile) {
     stage_stats(t0, t0 & 1);
-    stage_tile(smem, Qb, p.q_st, t0 << 6, p.Tq, tid, wave);
-    stage_tile(smem + TILE, dOb, p.o_st, t0 << 6, p.Tq, tid, wave);
+    stage_tile_h(smem, Qb, p.q_st, t0 << 6, p.Tq, voQ, tid, wave);
+    stage_tile_h(smem + TILE, dOb, p.o_st, t0 << 6, p.Tq, voO, tid, wave);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -530,7 +598,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
     const float* st_lse = s_stat[t & 1][0];
     const float* st_dlt = s_stat[t & 1][1];
     const bool need_mask = p.key_pad != nullptr || (p.causal && kw + 16 * NK - 1 > q0) || (kw + 16 * NK > kend);
-    const float next_stat = t + 1 < ntile ? load_stat(t + 1) : 0.f;
+    const bool next_ragged = q0 + 128 > p.Tq;
+    const float next_stat = (t + 1 < ntile && next_ragged) ? load_stat(t + 1) : 0.f;
     // the query tile is consumed in two halves of 32 queries (one macro step of the dV / dK contractions each)
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -544,8 +613,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
         }
 #pragma unroll
         for (int ds = 0; ds < 2; ++ds) {
-          const uint4 aq = frag_rows(sQ, (2 * ms + q2) * 16 + lr, ds, g);
-          const uint4 ao = frag_rows(sdO, (2 * ms + q2) * 16 + lr, ds, g);
+          const uint4 aq = frag_rows_at(sQ, fo.rows[ds], 2 * ms + q2);
+          const uint4 ao = frag_rows_at(sdO, fo.rows[ds], 2 * ms + q2);
 #pragma unroll
           for (int ki = 0; ki < NK; ++ki) {
             mma(s[ki][q2], aq, kfr[ki][ds]);
@@ -557,16 +626,17 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
       f32x4_t lse2[2], dlt[2];
 #pragma unroll
       for (int q2 = 0; q2 < 2; ++q2) {
-        lse2[q2] = *reinterpret_cast<const f32x4_t*>(st_lse + (2 * ms + q2) * 16 + g * 4);
+        lse2[q2] = *reinterpret_cast<const f32x4_t*>(st_lse + (2 * ms + q2) * 16 + g * 4) * LOG2E;
         dlt[q2] = *reinterpret_cast<const f32x4_t*>(st_dlt + (2 * ms + q2) * 16 + g * 4);
       }
       if (ms == 0) {
         __builtin_amdgcn_sched_barrier(0);
         if (t + 1 < ntile) {
           unsigned char* nb = smem + ((t + 1 - t0) & 1) * 2 * TILE;
-          if (tid < 128) s_stat[(t + 1) & 1][tid >> 6][tid & 63] = next_stat;
-          stage_tile(nb, Qb, p.q_st, q0 + 64, p.Tq, tid, wave);
-          stage_tile(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, tid, wave);
+          if (!next_ragged) dma_stats(t + 1, (t + 1) & 1);
+          else if (tid < 128) s_stat[(t + 1) & 1][tid >> 6][tid & 63] = next_stat;
+          stage_tile_h(nb, Qb, p.q_st, q0 + 64, p.Tq, voQ, tid, wave);
+          stage_tile_h(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, voO, tid, wave);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -601,8 +671,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
           // (the row key is linear in the row: + 0x9E3779B1 per row, attention.h).
           uint32_t yw[4] = {0u, 0u, 0u, 0u};
           if (p.thr) {
-            const uint32_t rk0 = drop_row_key(seed, drop_row(p, b, h, q0 + (2 * ms + q2) * 16 + g * 4 + 2 * (lr & 1)));
-            const uint32_t ya = drop_pair_bits(rk0, (uint32_t)key >> 1), yb = drop_pair_bits(rk0 + 0x9E3779B1u, (uint32_t)key >> 1);
+            const uint32_t ya = drop_pair_mix(ybase[ki] + (uint32_t)((2 * ms + q2) * 16) * DROP_ROW_C * DROP_C1);
+            const uint32_t yb = drop_pair_mix(ybase[ki] + (uint32_t)((2 * ms + q2) * 16 + 1) * DROP_ROW_C * DROP_C1);
             yw[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)ya, 0xA0, 0xf, 0xf, true);        // quad_perm [0,0,2,2]: the pair's even lane
             yw[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xA0, 0xf, 0xf, true);
             yw[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)ya, 0xF5, 0xf, 0xf, true);        // quad_perm [1,1,3,3]: the pair's odd lane
@@ -611,8 +681,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pv = __builtin_amdgcn_exp2f(s[ki][q2][r] * c2 - lse2[q2][r]);
-            float keepf = 1.f;
-            if (p.thr) keepf = ((yw[r] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep;      // field of key & 1 (v_bfe_u32)
+            // field of key & 1 (v_bfe_u32).  No test of p.thr here: with dropout off thr = 0 never exceeds a field and inv_keep = 1
+            const float keepf = ((yw[r] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep;
             s[ki][q2][r] = pv * keepf;                                   // dropped / rescaled probabilities (for dV)
             dp[ki][q2][r] = pv * (dp[ki][q2][r] * keepf - dlt[q2][r]);   // dS (for dK)
           }
@@ -622,8 +692,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
       }
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const uint4 aot = frag_cols(sdO, df * 16, ms, lr, g);
-        const uint4 aqt = frag_cols(sQ, df * 16, ms, lr, g);
+        const uint4 aot = frag_cols_at(sdO, fo.cols[df], ms);
+        const uint4 aqt = frag_cols_at(sQ, fo.cols[df], ms);
 #pragma unroll
         for (int ki = 0; ki < NK; ++ki) {
           mma(dv[ki][df], aot, pa[ki]);
@@ -631,6 +701,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
         }
       }
     }
+#pragma unroll
+    for (int ki = 0; ki < NK; ++ki) ybase[ki] += 64u * DROP_ROW_C * DROP_C1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
