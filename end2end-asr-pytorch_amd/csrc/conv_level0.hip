@@ -183,7 +183,7 @@ __device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)
   const int H2 = p.H >> 1, W2 = p.W >> 1;
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr) {
-    uint32_t lo[2], hi[2];
+    uint32_t lo[2], hi[2], pmax[2][2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
       uint32_t va = keep[2 * pr][0][d], vb = keep[2 * pr][1][d];
@@ -193,6 +193,7 @@ __device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)
       const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)vb, 0xB1, 0xf, 0xf, true);
       asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(na));
       asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(nb));
+      pmax[0][d] = va; pmax[1][d] = vb;
       auto sw = __builtin_amdgcn_permlane16_swap(va, vb, false, false);
       lo[d] = sw[0]; hi[d] = sw[1];
     }
@@ -206,15 +207,12 @@ __device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)
       uint32_t cw[2];
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf) {
-        const uint32_t mine0 = keep[2 * pr][cf][d], mine1 = keep[2 * pr + 1][cf][d];
-        const uint32_t oth0 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine0, 0xB1, 0xf, 0xf, true);
-        const uint32_t oth1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine1, 0xB1, 0xf, 0xf, true);
-        const bool odd = (tl & 1) != 0;
-        const uint32_t v0 = odd ? oth0 : mine0, v1 = odd ? mine0 : oth0, v2 = odd ? oth1 : mine1, v3 = odd ? mine1 : oth1;
-        uint32_t m = v0;
-        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v1));
-        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v2));
-        asm("v_pk_max_u16 %0, %0, %1" : "+v"(m) : "v"(v3));
+        // Only the EVEN lane of a pixel pair stores (st): the window order (this lane's pixel, its neighbour's) is the even lane's, the
+        // odd lane computes a word nobody reads.  The window maximum is the pooled value of above (non-negative bf16: signed = unsigned order).
+        const uint32_t v0 = keep[2 * pr][cf][d], v2 = keep[2 * pr + 1][cf][d];
+        const uint32_t v1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v0, 0xB1, 0xf, 0xf, true);
+        const uint32_t v3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v2, 0xB1, 0xf, 0xf, true);
+        const uint32_t m = pmax[cf][d];
         const uint32_t one = 0x00010001u;
         uint32_t n0 = v0 ^ m, n1 = v1 ^ m, n2 = v2 ^ m, nz = m;
         asm("v_pk_min_u16 %0, %0, %1" : "+v"(n0) : "v"(one));

@@ -21,6 +21,5 @@ def t(fn, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 fns = {"fwd": lambda: ops.vgg_level0_fwd(src, w0, b0, wk, b2), "wgrad": lambda: ops.vgg_level0_wgrad(src, w0, b0, dp, code, dw2, db2),
        "dgrad": lambda: ops.vgg_level0_dgrad(dp, code, src, w0, b0, wd, dw0, db0)}
-for spec in (sys.argv[1] if len(sys.argv) > 1 else "1").split(","):
-    L.set_tuning("L0_PP", int(spec))
-    print("ping-pong %d: " % int(spec) + "  ".join("%s %.1f us" % (k, t(f)) for k, f in fns.items()), flush=True)
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
+    print("level 0: " + "  ".join("%s %.1f us" % (k, t(f)) for k, f in fns.items()), flush=True)
