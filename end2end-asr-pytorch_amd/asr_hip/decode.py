@@ -48,8 +48,10 @@ class DecoderKVCache:
             self.self_v.append(torch.empty((self.B, max_len, HD), device=dev, dtype=cd))
 
     # ------------------------------------------------------------------------------------------------ hypotheses
-    def select(self, rows):
-        """Keep / duplicate / reorder decoder rows (beam search: row i of the new state continues old row rows[i])."""
+    def select(self, rows, cross=True):
+        """Keep / duplicate / reorder decoder rows (beam search: row i of the new state continues old row rows[i]).
+        cross=False: the cross-attention keys / values stay where they are (the caller guarantees that rows[i] and i belong to
+        the same utterance, and len(rows) is the current batch)."""
         idx = torch.as_tensor(rows, device=self.self_k[0].device, dtype=torch.int64)
         t = self.t
         for i in range(len(self.self_k)):
@@ -58,6 +60,9 @@ class DecoderKVCache:
             nk[:, :t] = self.self_k[i][:, :t].index_select(0, idx)
             nv[:, :t] = self.self_v[i][:, :t].index_select(0, idx)
             self.self_k[i], self.self_v[i] = nk, nv
+            if not cross:
+                assert len(rows) == self.B
+                continue
             k, v = self.cross[i]
             if k.stride(0) == 0:
                 self.cross[i] = (k[:1].expand(len(rows), -1, -1), v[:1].expand(len(rows), -1, -1))

@@ -276,13 +276,16 @@ class Decoder(nn.Module):
                     c_weight=1, prob_weight=1.0, use_cache=True):
         """Per-utterance beam search with the reference's scoring (transformer.py:396-517, LM branch excluded).  With
         use_cache the live hypotheses of an utterance are one batch of the KV-cached decoder (one step = one token per
-        hypothesis); the candidate bookkeeping on the host is the reference's, including its in-loop re-sort (:460)."""
-        import math
+        hypothesis); the candidate bookkeeping on the host is the reference's, including its in-loop re-sort (:460).
+        With more than one utterance the cached search runs for all of them at once (_beam_search_batched);
+        use_cache="per_utterance" keeps the utterance loop."""
         if lm_rescoring:
             raise NotImplementedError("LM rescoring is outside the accelerated path (SURVEY.md section 2, row 12)")
         from asr_hip.decode import DecoderKVCache
         if not self._kv_cache_supported():
             use_cache = False
+        if use_cache and use_cache != "per_utterance" and encoder_padded_outputs.size(0) > 1:
+            return self._beam_search_batched(encoder_padded_outputs, beam_width, nbest, c_weight)
         ids_out, strs_out = [], []
         max_len = encoder_padded_outputs.size(1)
         dev = encoder_padded_outputs.device
@@ -316,12 +319,7 @@ class Decoder(nn.Module):
                 alive = []
                 for hyp in hyps:
                     if hyp['yseq'][-1] == constant.EOS_TOKEN:
-                        s = "".join(self.id2label[t] for t in hyp['yseq'])
-                        for ch in (constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR):
-                            s = s.replace(ch, "")
-                        s = s.replace("  ", " ")
-                        hyp['final_score'] = hyp['score'] + math.sqrt(len(s.split())) * c_weight
-                        ended.append(hyp)
+                        ended.append(self._finish_hyp(hyp, c_weight))
                     else:
                         alive.append(hyp)
                 hyps = alive
@@ -330,6 +328,72 @@ class Decoder(nn.Module):
                 if use_cache:
                     cache.select([h['parent'] for h in hyps])
             for hyp in sorted(ended, key=lambda h: h['final_score'], reverse=True)[:min(len(ended), nbest)]:
+                ids_out.append(hyp['yseq'])
+                strs_out.append(self.post_process_hyp(hyp))
+        return ids_out, strs_out
+
+
+    def _finish_hyp(self, hyp, c_weight):
+        import math
+        s = "".join(self.id2label[t] for t in hyp['yseq'])
+        for ch in (constant.PAD_CHAR, constant.SOS_CHAR, constant.EOS_CHAR):
+            s = s.replace(ch, "")
+        s = s.replace("  ", " ")
+        hyp['final_score'] = hyp['score'] + math.sqrt(len(s.split())) * c_weight
+        return hyp
+
+    def _beam_search_batched(self, encoder_padded_outputs, beam_width, nbest, c_weight):
+        """The same search for ALL utterances of the batch at once: utterance b owns decoder rows b * W .. b * W + W - 1 of ONE
+        KV-cached decoder batch (its live hypotheses in the first rows, the others idle), so a step is one decoder step, one
+        log-softmax / top-W launch and one device -> host copy for the whole batch instead of one of each per utterance.  The
+        candidate bookkeeping per utterance is the reference's (transformer.py:437-497: the in-loop re-sort, forced EOS at the
+        last encoder frame, sqrt(words) * c_weight on finished hypotheses), so the strings are those of the per-utterance loop."""
+        from asr_hip.decode import DecoderKVCache
+        W = beam_width
+        B, max_len = encoder_padded_outputs.size(0), encoder_padded_outputs.size(1)
+        dev = encoder_padded_outputs.device
+        cache = DecoderKVCache(self, encoder_padded_outputs.repeat_interleave(W, dim=0), max_len=300)
+        hyps = [[{'score': 0.0, 'yseq': [constant.SOS_TOKEN]}] for _ in range(B)]
+        ended = [[] for _ in range(B)]
+        for i in range(300):
+            last = [constant.SOS_TOKEN] * (B * W)
+            for b in range(B):
+                for hi, h in enumerate(hyps[b]):
+                    last[b * W + hi] = h['yseq'][-1]
+            logits = cache.step(torch.tensor(last, dtype=torch.int64, device=dev))
+            best_all, idx_all = ops.logsoftmax_topk(logits.float().contiguous(), W)
+            best_all, idx_all = best_all.tolist(), idx_all.tolist()
+            rows = list(range(B * W))
+            moved = False
+            for b in range(B):
+                if not hyps[b]:
+                    continue
+                cand = []
+                for hi, hyp in enumerate(hyps[b]):
+                    best, idx = best_all[b * W + hi], idx_all[b * W + hi]
+                    for j in range(W):
+                        cand.append({'score': hyp['score'] + best[j], 'yseq': hyp['yseq'] + [idx[j]], 'parent': hi})
+                    cand = sorted(cand, key=lambda h: h['score'], reverse=True)[:W]      # the reference's in-loop re-sort (:460)
+                if i == max_len - 1:
+                    for hyp in cand:
+                        hyp['yseq'] = hyp['yseq'] + [constant.EOS_TOKEN]
+                alive = []
+                for hyp in cand:
+                    if hyp['yseq'][-1] == constant.EOS_TOKEN:
+                        ended[b].append(self._finish_hyp(hyp, c_weight))
+                    else:
+                        alive.append(hyp)
+                hyps[b] = alive
+                for j, hyp in enumerate(alive):
+                    moved |= hyp['parent'] != j
+                    rows[b * W + j] = b * W + hyp['parent']
+            if not any(hyps):
+                break
+            if moved:
+                cache.select(rows, cross=False)           # parents stay inside their utterance: the cross keys / values do not move
+        ids_out, strs_out = [], []
+        for b in range(B):
+            for hyp in sorted(ended[b], key=lambda h: h['final_score'], reverse=True)[:min(len(ended[b]), nbest)]:
                 ids_out.append(hyp['yseq'])
                 strs_out.append(self.post_process_hyp(hyp))
         return ids_out, strs_out

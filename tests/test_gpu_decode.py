@@ -57,9 +57,24 @@ def test_greedy_and_beam_cached_match_uncached(precision):
     b = dec.greedy_search(enc, use_cache=False)
     c = dec.greedy_search(enc, use_cache="eager")
     assert a == b == c and len(a) == 2
-    ia, sa = dec.beam_search(enc, beam_width=3, nbest=2, use_cache=True)
+    ia, sa = dec.beam_search(enc, beam_width=3, nbest=2, use_cache=True)             # all utterances in one decoder batch
     ib, sb = dec.beam_search(enc, beam_width=3, nbest=2, use_cache=False)
-    assert sa == sb and ia == ib
+    ic, sc = dec.beam_search(enc, beam_width=3, nbest=2, use_cache="per_utterance")
+    assert sa == sb == sc and ia == ib == ic
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_batched_beam_search_equals_the_utterance_loop(precision):
+    """Beam search over a batch of utterances as ONE KV-cached decoder batch (utterance b owns rows b * W ..) against the loop over
+    utterances: the same token ids and strings, with utterances that finish at different steps and more utterances than beams."""
+    model = _model(precision, layers=2)
+    dec = model.decoder
+    g = torch.Generator().manual_seed(11)
+    enc = torch.randn(5, 9, 512, generator=g).cuda()
+    for W, nbest in ((4, 3), (2, 1)):
+        ia, sa = dec.beam_search(enc, beam_width=W, nbest=nbest, c_weight=0.1, use_cache=True)
+        ib, sb = dec.beam_search(enc, beam_width=W, nbest=nbest, c_weight=0.1, use_cache="per_utterance")
+        assert ia == ib and sa == sb and len(sa) >= 5
 
 
 # ------------------------------------------------------------------------------------------------ vs the reference

@@ -10,6 +10,11 @@ python tools/prof_summary.py "$db" 11 "rocprofv3 --kernel-trace --stats -- $cmd 
 python tools/prof_timeline.py "$db" "timeline of the last 3 replayed steps: rocprofv3 --kernel-trace -- $cmd" > gpurun_out/r04_bench_timeline.txt 2>&1
 python tools/prof_families.py "$db" gpurun_out/r04_replayed_families.json "$cmd" > /dev/null 2>&1
 python tools/prof_sequence.py "$db" gpurun_out/r04_step_sequence.txt > /dev/null 2>&1
+cmd2="python bench.py --workload librispeech --steps 5 --warmup 3 --no-cpu-baseline --no-roofline"
+out2=/tmp/prof_r04_ls; rm -rf $out2
+( cd $root && timeout 900 rocprofv3 --kernel-trace -d $out2 -o trace -- $cmd2 ) > gpurun_out/r04_prof_ls.log 2>&1
+db2=$(find $out2 -name "*.db" | head -1)
+python tools/prof_timeline.py "$db2" "timeline of the last 3 replayed steps: rocprofv3 --kernel-trace -- $cmd2" > gpurun_out/r04_librispeech_timeline.txt 2>&1
 bash tools/gpu_pmc_traffic.sh r04 > /dev/null 2>&1
 bash tools/gpu_pmc_mfma.sh r04_step > /dev/null 2>&1
 head -30 gpurun_out/r04_bench_kernel_stats.txt; tail -12 gpurun_out/r04_step_mfma_pmc.txt; python -c "

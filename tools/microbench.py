@@ -190,6 +190,15 @@ def decode():
             torch.cuda.synchronize()
         print("  %-36s %8.1f ms" % ({True: "KV cache + hipGraph, 30-launch step", "graph": "KV cache + hipGraph, op per launch", "eager": "KV cache, eager launches", False: "full re-run (reference)"}[mode],
                                       (time.time() - t0) * 1e3))
+    if os.environ.get("MICRO_DECODE_BEAM", "1") == "1":
+        print("== beam search (width 4), the same 32 utterances (random weights: every hypothesis runs to the 200-frame limit)")
+        for mode, label in ((True, "all utterances in one decoder batch"), ("per_utterance", "loop over utterances")):
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                t0 = time.time()
+                model.decoder.beam_search(enc, beam_width=4, nbest=1, c_weight=0.1, use_cache=mode)
+                torch.cuda.synchronize()
+            print("  %-36s %8.1f ms" % (label, (time.time() - t0) * 1e3))
 
 
 
