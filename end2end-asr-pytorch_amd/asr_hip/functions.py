@@ -624,8 +624,9 @@ def _conv_window_fwd(x_nhwc, g, w, b, tag):
     """The same convolution WITHOUT the kx axis in im2col: X2[(b, oh, t), (ky, c)] = x[b, SH*oh + ky, t - PW, c] for every
     (padded) input time step t (about KW / SW times fewer bytes than the full im2col), and the GEMM's A operand is the
     overlapping-rows view A[(b, oh, j)] = X2 flat[row * SW * blk : ... + KW * blk] -- KW consecutive X2 rows ARE the patch of
-    output step j, in column order (kx, ky, c).  Rows j >= OW of a (b, oh) group run into the next group and are dropped when y
-    is compacted.  Returns (X2, A view, y fp32 (Mp, 64) compact, M)."""
+    output step j, in column order (kx, ky, c).  Rows j >= OW of a (b, oh) group run into the next group; the BatchNorm kernels
+    that read y skip them through the row grid (Wg, OW) returned here ((0, 0): y is compact -- the unit-stride form below writes
+    it that way).  Returns (X2, A view, y fp32, M, ygrid)."""
     cd = ops.compute_dtype()
     dev = x_nhwc.device
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
@@ -639,33 +640,42 @@ def _conv_window_fwd(x_nhwc, g, w, b, tag):
     A = torch.as_strided(X2, (R, Kp), (SW * blk, 1))
     bias = ops.workspace(tag + "_b", (64,), torch.float32, dev)
     bias[:Cout].copy_(b.data)
-    Mp = (M + 127) // 128 * 128
-    y = ops.workspace(tag + "_y", (Mp, 64), torch.float32, dev)
     if _emb_shift_fwd and SW == 1 and PW == 0 and blk % 64 == 0 and Cout % 4 == 0:
         # unit time stride: ONE dense product over the single-step patches, Z[r', (kx, co)] = X2[r'] . W[co, kx] (N = KW * Cout = 352
         # useful columns instead of 32 padded to 64, X2 read once instead of through the KW-fold window view), then the taps are
         # folded along time into the compact rows of y (asr_window_sum: every element of Z read once, bias added there)
         Nz = ops._pad8(KW * Cout)
+        y = ops.workspace(tag + "_y", ((M + 127) // 128 * 128, 64), torch.float32, dev)
         Wz = ops.workspace(tag + "_wz", ((Nz + 127) // 128 * 128, blk), cd, dev)          # rows >= KW * Cout and the ky padding stay zero
         Wz[:KW * Cout, :KH * C].copy_(w.data.permute(3, 0, 2, 1).reshape(KW * Cout, KH * C))       # [(kx, co), (ky, ci)]
         Z = ops.gemm_nt(X2[:R + KW - 1], Wz[:Nz], out=ops.workspace(tag + "_z", (R + KW - 1, Nz), torch.float32, dev, zero=False))   # written whole by the product
         ops.window_sum(Z, y, bias, B * OH, Wg, OW, KW, Cout)
-        return X2, A, y, M
+        return X2, A, y, M, (0, 0)
     Ws = ops.workspace(tag + "_w", (64, Kp), cd, dev)                # rows >= Cout, columns >= K and the ky padding stay zero
     Ws[:Cout, :K].view(Cout, KW, blk)[:, :, :KH * C].copy_(w.data.permute(0, 3, 2, 1).reshape(Cout, KW, KH * C))   # (co, kx, ky, ci)
     yf = ops.gemm_nt(A, Ws, bias=bias, out=ops.workspace(tag + "_yf", (R, 64), torch.float32, dev))
-    y[:M].view(B * OH, OW, 64).copy_(yf.view(B * OH, Wg, 64)[:, :OW])
-    return X2, A, y, M
+    return X2, A, yf, M, (Wg, OW)
 
 
-def _conv_window_bwd(dy, A, w, b_grad, g, tag, need_dx):
-    """dy (Mp, 64) compact rows -> weight gradient (Cout, Cin, KH, KW) fp32 (returned), bias gradient (accumulated) and, for a
-    unit time stride, the data gradient dx (B, H, W, C).  D holds dy's Cout columns densely on the GEMM's row grid (rows j >= OW
-    of a group zero) with KW - 1 zero rows in front, so that D flat[r * Cout : r * Cout + KW * Cout] = dy rows r - (KW - 1) .. r:
-    the data gradient of X2 is ONE GEMM against the weights in (kx reversed, co) order, and the weight gradient one TN GEMM
-    against the window view A (asr_gemm_tn with ldb < K)."""
+def _window_dy(g, Cout, tag, dev):
+    """The dense dy operand D of the window gradients: dy's Cout columns on the GEMM's row grid (rows j >= OW of a group stay zero)
+    with KW - 1 zero rows in front, so that D flat[r * Cout : r * Cout + KW * Cout] = dy rows r - (KW - 1) .. r.  The BatchNorm
+    backward writes its output straight into it (asr_bn_act_bwd's dy grid).  -> (D, the (R, Cout) view the rows go to, (Wg, OW))"""
+    B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
+    g1, blk, Wg, R = _window_geom(g)
+    Kdp = ops._pad8(KW * Cout)
+    lead = KW - 1
+    tail = (Kdp + Cout - 1) // Cout + 1
+    D = ops.workspace(tag + "_d", (lead + R + tail, Cout), ops.compute_dtype(), dev)       # zero at creation; only output rows are ever written
+    return D, D[lead:lead + R], (Wg, OW)
+
+
+def _conv_window_bwd(D, A, w, b_grad, g, tag, need_dx):
+    """D = _window_dy(...) filled with dy -> weight gradient (Cout, Cin, KH, KW) fp32 (returned), bias gradient (accumulated) and,
+    for a unit time stride, the data gradient dx (B, H, W, C): the data gradient of X2 is ONE GEMM against the weights in
+    (kx reversed, co) order, and the weight gradient one TN GEMM against the window view A (asr_gemm_tn with ldb < K)."""
     cd = ops.compute_dtype()
-    dev = dy.device
+    dev = D.device
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
     Cout = w.shape[0]
     g1, blk, Wg, R = _window_geom(g)
@@ -673,9 +683,6 @@ def _conv_window_bwd(dy, A, w, b_grad, g, tag, need_dx):
     Kd = KW * Cout
     Kdp = ops._pad8(Kd)
     lead = KW - 1
-    tail = (Kdp + Cout - 1) // Cout + 1
-    D = ops.workspace(tag + "_d", (lead + R + tail, Cout), cd, dev)
-    D[lead:lead + R].view(B * OH, Wg, Cout)[:, :OW].copy_(dy[:M].view(B * OH, OW, dy.shape[1])[:, :, :Cout])
     K = KW * blk
     Ad = torch.as_strided(D, (R, Kdp), (Cout, 1))
     Q = (KW + SW - 1) // SW
@@ -707,10 +714,10 @@ def _conv_window_bwd(dy, A, w, b_grad, g, tag, need_dx):
     return dw, ops.col2im(dX2, g1)
 
 
-def _bn_stats(bn, y, M, C, training):
+def _bn_stats(bn, y, M, C, training, ygrid=(0, 0)):
     """nn.BatchNorm2d statistics (eps / momentum of the module; unbiased running variance) -> (mean, rstd)."""
     if training:
-        mean, var = ops.bn_batch_stats(y, M, C)
+        mean, var = ops.bn_batch_stats(y, M, C, ygrid)
         if bn.track_running_stats:
             mom = 0.1 if bn.momentum is None else bn.momentum
             bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
@@ -737,28 +744,31 @@ class EmbCNNFn(Function):
         gA = ops.conv_geom(B, Fq, T, 1, w0.shape[2], w0.shape[3], 2, 2, 0, 10)
         winA = _window_ok(gA)
         if winA:
-            colA, WsA, yA, MA = _conv_window_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embV")      # colA = X2, WsA = the window view
+            colA, WsA, yA, MA, ygA = _conv_window_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embV")      # colA = X2, WsA = the window view
             KA = gA[3] * gA[4] * gA[5]
         else:
             colA, WsA, yA, MA, KA = _conv_gemm_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embA")
-        meanA, rstdA = _bn_stats(bn1, yA, MA, C1, training)
+            ygA = (0, 0)
+        meanA, rstdA = _bn_stats(bn1, yA, MA, C1, training, ygA)
         a1 = torch.empty((B, gA[10], gA[11], C1), device=src.device, dtype=cd)
-        ops.bn_act_fwd(yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, a1.view(MA, C1))
+        ops.bn_act_fwd(yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, a1.view(MA, C1), ygrid=ygA)
         gB = ops.conv_geom(B, gA[10], gA[11], C1, w3.shape[2], w3.shape[3], 2, 1, 0, 0)
         win = _window_ok(gB)
         if win:
-            colB, WsB, yB, MB = _conv_window_fwd(a1, gB, w3, b3, "embW")       # colB = X2, WsB = the window view
+            colB, WsB, yB, MB, ygB = _conv_window_fwd(a1, gB, w3, b3, "embW")       # colB = X2, WsB = the window view
             KB = gB[3] * gB[4] * gB[5]
         else:
             colB, WsB, yB, MB, KB = _conv_gemm_fwd(a1, gB, w3, b3, "embB")
-        meanB, rstdB = _bn_stats(bn4, yB, MB, C2, training)
+            ygB = (0, 0)
+        meanB, rstdB = _bn_stats(bn4, yB, MB, C2, training, ygB)
         out = torch.empty((B, gB[11], C2 * gB[10]), device=src.device, dtype=cd)
-        ops.bn_act_fwd(yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, out, tH=gB[10], tW=gB[11])
+        ops.bn_act_fwd(yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, out, tH=gB[10], tW=gB[11], ygrid=ygB)
         ctx.t = (colA, WsA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB)
         # colA / yA / colB / yB are SHARED grow-only workspaces (ops.workspace): a later forward overwrites them
         _emb_generation[0] += 1
         ctx.generation = _emb_generation[0]
         ctx.geo = (gA, gB, MA, KA, MB, KB)
+        ctx.ygrid = (ygA, ygB)
         ctx.win, ctx.winA = win, winA
         ctx.params = (w0, b0, g1, be1, w3, b3, g4, be4)
         return out
@@ -778,12 +788,16 @@ class EmbCNNFn(Function):
         if dout.dtype != cd:
             dout = dout.to(cd)
         # ---- second conv block
-        dyB = ops.workspace("embB_dy", (yB.shape[0], 64), cd, dev)
-        sB = ops.bn_act_bwd(dout, yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, dyB, tH=gB[10], tW=gB[11])
+        ygA, ygB = ctx.ygrid
+        if ctx.win:
+            DB, dyB, dgB = _window_dy(gB, C2, "embW", dev)
+        else:
+            dyB, dgB = ops.workspace("embB_dy", (yB.shape[0], 64), cd, dev), (0, 0)
+        sB = ops.bn_act_bwd(dout, yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, dyB, tH=gB[10], tW=gB[11], ygrid=ygB, dygrid=dgB)
         P.grad_of(be4).add_(sB[:C2])
         P.grad_of(g4).add_(sB[C2:])
         if ctx.win:
-            dwB, da1 = _conv_window_bwd(dyB, WsB, w3, P.grad_of(b3), gB, "embW", True)
+            dwB, da1 = _conv_window_bwd(DB, WsB, w3, P.grad_of(b3), gB, "embW", True)
             P.grad_of(w3).add_(dwB)
             P.grad_ready(w3, b3, g4, be4)
         else:
@@ -794,12 +808,15 @@ class EmbCNNFn(Function):
             dcolB = ops.gemm_nn(dyB, WsB, out=colB)          # colB is dead after the weight gradient: reuse its storage
             da1 = ops.col2im(dcolB, gB)
         # ---- first conv block (no data gradient: the input is the spectrogram)
-        dyA = ops.workspace("embA_dy", (yA.shape[0], 64), cd, dev)
-        sA = ops.bn_act_bwd(da1.view(MA, C1), yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, dyA)
+        if ctx.winA:
+            DA, dyA, dgA = _window_dy(gA, C1, "embV", dev)
+        else:
+            dyA, dgA = ops.workspace("embA_dy", (yA.shape[0], 64), cd, dev), (0, 0)
+        sA = ops.bn_act_bwd(da1.view(MA, C1), yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, dyA, ygrid=ygA, dygrid=dgA)
         P.grad_of(be1).add_(sA[:C1])
         P.grad_of(g1).add_(sA[C1:])
         if ctx.winA:
-            dwA, _ = _conv_window_bwd(dyA, WsA, w0, P.grad_of(b0), gA, "embV", False)
+            dwA, _ = _conv_window_bwd(DA, WsA, w0, P.grad_of(b0), gA, "embV", False)
             P.grad_of(w0).add_(dwA)
         else:
             ops.gemm_tn(dyA, colA, P.grad_of(w0).view(C1, KA), colsum_acc=P.grad_of(b0), N=C1, K=KA)

@@ -1102,35 +1102,38 @@ def window_sum(Z, y, bias, groups, Wg, OW, KW, Cout):
     return y
 
 
-def bn_batch_stats(y, M, C):
+def bn_batch_stats(y, M, C, ygrid=(0, 0)):
     """Training-mode BatchNorm statistics of the fp32 conv output y (rows, ld) over its first M rows / C columns:
-    (mean, biased var), two passes (mean, then centred second moment)."""
+    (mean, biased var), two passes (mean, then centred second moment).  ygrid = (Wg, OW): y is the un-compacted output of a
+    window GEMM (groups of Wg rows, the first OW of each are the convolution's rows; include/asr_hip.h)."""
     nb = L.load().asr_bn_stats_blocks(M)
     part = torch.empty((nb, 2 * C), device=y.device, dtype=torch.float32)       # per-workgroup sums, added in a fixed order:
     s1 = torch.empty(2 * C, device=y.device, dtype=torch.float32)               # reproducible statistics (no atomics)
-    L.call("asr_bn_stats_partial", L.ptr(y), y.stride(0), M, C, None, L.ptr(part), L.ptr(s1), L.stream())
+    L.call("asr_bn_stats_partial", L.ptr(y), y.stride(0), M, C, None, L.ptr(part), L.ptr(s1), ygrid[0], ygrid[1], L.stream())
     mean = s1[:C] / M
     s2 = torch.empty(2 * C, device=y.device, dtype=torch.float32)
-    L.call("asr_bn_stats_partial", L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(part), L.ptr(s2), L.stream())
+    L.call("asr_bn_stats_partial", L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(part), L.ptr(s2), ygrid[0], ygrid[1], L.stream())
     return mean, s2[C:] / M
 
 
-def bn_act_fwd(y, M, C, mean, rstd, gamma, beta, lo, hi, out, tH=0, tW=0):
+def bn_act_fwd(y, M, C, mean, rstd, gamma, beta, lo, hi, out, tH=0, tW=0, ygrid=(0, 0)):
     ldo = 0 if tH else out.stride(0)
     L.call("asr_bn_act_fwd", L.ptr(y), y.stride(0), L.ptr(out), ldo, M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta),
-           float(lo), float(hi), tH, tW, L.dt(out), L.stream())
+           float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], L.dt(out), L.stream())
     return out
 
 
-def bn_act_bwd(dout, y, M, C, mean, rstd, gamma, beta, lo, hi, dy, tH=0, tW=0):
-    """-> sums (2C): [dbeta, dgamma]; writes dy[:M, :C] (the gradient w.r.t. the conv output) in dy's dtype."""
+def bn_act_bwd(dout, y, M, C, mean, rstd, gamma, beta, lo, hi, dy, tH=0, tW=0, ygrid=(0, 0), dygrid=(0, 0)):
+    """-> sums (2C): [dbeta, dgamma]; writes dy[:M, :C] (the gradient w.r.t. the conv output) in dy's dtype.  dygrid = (Wg, OW): row m
+    goes to dy row (m // OW) * Wg + m % OW (dy is the dense operand of the window gradients; the rows in between are left alone)."""
     assert dout.dtype == dy.dtype and dout.is_contiguous()
     ldo = 0 if tH else dout.stride(0)
     sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
     L.call("asr_bn_act_bwd_reduce", L.ptr(dout), ldo, L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
-           L.ptr(beta), float(lo), float(hi), tH, tW, L.ptr(sums), L.dt(dout), L.stream())
+           L.ptr(beta), float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], L.ptr(sums), L.dt(dout), L.stream())
     L.call("asr_bn_act_bwd", L.ptr(dout), ldo, L.ptr(y), y.stride(0), L.ptr(dy), dy.stride(0), M, C, L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(beta), float(lo), float(hi), tH, tW, L.ptr(sums), L.dt(dout), L.stream())
+           L.ptr(gamma), L.ptr(beta), float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], dygrid[0], dygrid[1], L.ptr(sums),
+           L.dt(dout), L.stream())
     return sums
 
 

@@ -127,7 +127,16 @@ struct BnArgs {
   float lo, hi;
   int tH, tW;          // > 0: rows are (b, h, w) over (B, tH, tW) and the activation side uses (B, tW, C*tH), feature c*tH + h
   int64_t ldo;
-};
+  int yW, yOW;         // yOW > 0: y lives on the row grid of a window GEMM -- groups of yW rows of which the first yOW are outputs
+};                     // (row m of the convolution = y row (m / yOW) * yW + m % yOW); 0: y is compact
+
+// row m of the convolution output -> row of a buffer laid out in groups of gw rows with gow outputs each (gow == 0: identity)
+__device__ __forceinline__ int64_t grid_row(int64_t m, int gw, int gow) {
+  if (gow <= 0) return m;
+  const unsigned q = (unsigned)m / (unsigned)gow;          // bn_args_ok: M < 2^31
+  return (int64_t)q * gw + ((unsigned)m - q * (unsigned)gow);
+}
+__device__ __forceinline__ float bn_y(const BnArgs& a, int64_t m, int c) { return a.y[grid_row(m, a.yW, a.yOW) * a.ldy + c]; }
 
 __device__ __forceinline__ int64_t act_index(const BnArgs& a, int64_t m, int c) {
   if (a.tH > 0) {
@@ -156,13 +165,13 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __
   float s = 0.f, q = 0.f;
   int64_t r = r0 + rl;
   for (; r + 3 * nrl < r1; r += 4 * nrl) {
-    const float v0 = a.y[r * a.ldy + c] - ctr, v1 = a.y[(r + nrl) * a.ldy + c] - ctr;
-    const float v2 = a.y[(r + 2 * nrl) * a.ldy + c] - ctr, v3 = a.y[(r + 3 * nrl) * a.ldy + c] - ctr;
+    const float v0 = bn_y(a, r, c) - ctr, v1 = bn_y(a, r + nrl, c) - ctr;
+    const float v2 = bn_y(a, r + 2 * nrl, c) - ctr, v3 = bn_y(a, r + 3 * nrl, c) - ctr;
     s += (v0 + v1) + (v2 + v3);
     q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
   }
   for (; r < r1; r += nrl) {
-    const float v = a.y[r * a.ldy + c] - ctr;
+    const float v = bn_y(a, r, c) - ctr;
     s += v;
     q += v * v;
   }
@@ -206,7 +215,7 @@ __global__ void __launch_bounds__(256) bn_act_fwd_kernel(BnArgs a, T* __restrict
   const float mu = a.mean[c], rs = a.rstd[c], g = a.gamma[c], be = a.beta[c];
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   for (int64_t r = r0 + rl; r < r0 + 64 && r < a.M; r += nrl) {
-    float z = (a.y[r * a.ldy + c] - mu) * rs * g + be;
+    float z = (bn_y(a, r, c) - mu) * rs * g + be;
     z = fminf(fmaxf(z, a.lo), a.hi);
     DT<T>::st(out + act_index(a, r, c), z);
   }
@@ -226,7 +235,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
     float yv[4], dv[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      yv[u] = a.y[(r + u * nrl) * a.ldy + c];
+      yv[u] = bn_y(a, r + u * nrl, c);
       dv[u] = DT<T>::ld(dout + act_index(a, r + u * nrl, c));
     }
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
     }
   }
   for (; r < r1; r += nrl) {
-    const float xh = (a.y[r * a.ldy + c] - mu) * rs;
+    const float xh = (bn_y(a, r, c) - mu) * rs;
     const float z = xh * g + be;
     if (z > a.lo && z < a.hi) {
       const float d = DT<T>::ld(dout + act_index(a, r, c));
@@ -263,17 +272,17 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
 // dy = gamma * rstd * (dz - sum(dz)/M - xhat * sum(dz*xhat)/M)     (training-mode BatchNorm backward)
 template <typename T>
 __global__ void __launch_bounds__(256) bn_act_bwd_kernel(BnArgs a, const T* __restrict__ dout, const float* __restrict__ sums,
-                                                         T* __restrict__ dy, int64_t lddy) {
+                                                         T* __restrict__ dy, int64_t lddy, int dW, int dOW) {
   const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
   const float mu = a.mean[c], rs = a.rstd[c], g = a.gamma[c], be = a.beta[c];
   const float inv = 1.f / (float)a.M;
   const float m1 = sums[c] * inv, m2 = sums[C + c] * inv;
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   for (int64_t r = r0 + rl; r < r0 + 64 && r < a.M; r += nrl) {
-    const float xh = (a.y[r * a.ldy + c] - mu) * rs;
+    const float xh = (bn_y(a, r, c) - mu) * rs;
     const float z = xh * g + be;
     const float d = (z > a.lo && z < a.hi) ? DT<T>::ld(dout + act_index(a, r, c)) : 0.f;
-    DT<T>::st(dy + r * lddy + c, g * rs * (d - m1 - xh * m2));
+    DT<T>::st(dy + grid_row(r, dW, dOW) * lddy + c, g * rs * (d - m1 - xh * m2));
   }
 }
 
@@ -282,9 +291,11 @@ bool col_args_ok(const ColArgs& a) {
          a.OH == (a.H + 2 * a.PH - a.KH) / a.SH + 1 && a.OW == (a.W + 2 * a.PW - a.KW) / a.SW + 1 && a.OH > 0 && a.OW > 0;
 }
 
+bool grid_ok(int64_t M, int gw, int gow) { return gow == 0 || (gow > 0 && gw >= gow && M < ((int64_t)1 << 31) && M % gow == 0); }
+
 bool bn_args_ok(const BnArgs& a) {
   return a.y && a.M > 0 && a.C > 0 && a.C <= 256 && 256 % a.C == 0 && a.ldy >= a.C && a.mean && a.rstd && a.gamma && a.beta &&
-         (a.tH == 0 || (a.tW > 0 && a.M % ((int64_t)a.tH * a.tW) == 0));
+         (a.tH == 0 || (a.tW > 0 && a.M % ((int64_t)a.tH * a.tW) == 0)) && grid_ok(a.M, a.yW, a.yOW);
 }
 
 }  // namespace
@@ -366,10 +377,11 @@ extern "C" int asr_window_sum(const float* Z, int64_t ldz, float* y, int64_t ldy
   return ASR_OK;
 }
 
-extern "C" int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, hipStream_t stream) {
-  ASR_CHECK_ARG(y && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C);
+extern "C" int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, int y_grid_w,
+                            int y_grid_ow, hipStream_t stream) {
+  ASR_CHECK_ARG(y && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C && grid_ok(M, y_grid_w, y_grid_ow));
   BnArgs a{};
-  a.y = y; a.ldy = ldy; a.M = M; a.C = C;
+  a.y = y; a.ldy = ldy; a.M = M; a.C = C; a.yW = y_grid_w; a.yOW = y_grid_ow;
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
   bn_stats_kernel<<<(unsigned)ceil_div64(M, BN_ROWS), 256, 0, stream>>>(a, center, sums, nullptr);
   ASR_LAUNCH_CHECK();
@@ -379,10 +391,10 @@ extern "C" int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const
 extern "C" int64_t asr_bn_stats_blocks(int64_t M) { return M > 0 ? ceil_div64(M, BN_ROWS) : 0; }
 
 extern "C" int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* partial, float* sums,
-                                    hipStream_t stream) {
-  ASR_CHECK_ARG(y && partial && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C);
+                                    int y_grid_w, int y_grid_ow, hipStream_t stream) {
+  ASR_CHECK_ARG(y && partial && sums && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C && grid_ok(M, y_grid_w, y_grid_ow));
   BnArgs a{};
-  a.y = y; a.ldy = ldy; a.M = M; a.C = C;
+  a.y = y; a.ldy = ldy; a.M = M; a.C = C; a.yW = y_grid_w; a.yOW = y_grid_ow;
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
   const int64_t nblk = ceil_div64(M, BN_ROWS);
   bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, center, nullptr, partial);
@@ -393,8 +405,8 @@ extern "C" int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int 
 
 extern "C" int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
-                              int dtype, hipStream_t stream) {
-  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo};
+                              int y_grid_w, int y_grid_ow, int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow};
   ASR_CHECK_ARG(out && bn_args_ok(a) && (tH > 0 || ldo >= C));
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
@@ -409,8 +421,8 @@ extern "C" int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ld
 
 extern "C" int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C,
                                      const float* mean, const float* rstd, const float* gamma, const float* beta, float lo,
-                                     float hi, int tH, int tW, float* sums, int dtype, hipStream_t stream) {
-  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo};
+                                     float hi, int tH, int tW, int y_grid_w, int y_grid_ow, float* sums, int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow};
   ASR_CHECK_ARG(dout && sums && bn_args_ok(a) && (tH > 0 || ldo >= C));
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
@@ -425,16 +437,17 @@ extern "C" int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float*
 
 extern "C" int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
-                              int tH, int tW, const float* sums, int dtype, hipStream_t stream) {
-  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo};
-  ASR_CHECK_ARG(dout && dy && sums && bn_args_ok(a) && (tH > 0 || ldo >= C) && lddy >= C);
+                              int tH, int tW, int y_grid_w, int y_grid_ow, int dy_grid_w, int dy_grid_ow, const float* sums, int dtype,
+                              hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow};
+  ASR_CHECK_ARG(dout && dy && sums && bn_args_ok(a) && (tH > 0 || ldo >= C) && lddy >= C && grid_ok(M, dy_grid_w, dy_grid_ow));
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
   const unsigned grid = (unsigned)ceil_div64(M, 64);
   if (dtype == ASR_F32)
-    bn_act_bwd_kernel<float><<<grid, 256, 0, stream>>>(a, (const float*)dout, sums, (float*)dy, lddy);
+    bn_act_bwd_kernel<float><<<grid, 256, 0, stream>>>(a, (const float*)dout, sums, (float*)dy, lddy, dy_grid_w, dy_grid_ow);
   else
-    bn_act_bwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a, (const bf16_t*)dout, sums, (bf16_t*)dy, lddy);
+    bn_act_bwd_kernel<bf16_t><<<grid, 256, 0, stream>>>(a, (const bf16_t*)dout, sums, (bf16_t*)dy, lddy, dy_grid_w, dy_grid_ow);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -408,25 +408,31 @@ int asr_window_sum(const float* Z, int64_t ldz, float* y, int64_t ldy, const flo
                    int KW, int Cout, asr_stream_t stream);
 /* nn.BatchNorm2d statistics over the rows of the fp32 conv output y (M, ldy), channel = column:
  * sums[0:C] += sum(y - center), sums[C:2C] += sum((y - center)^2); center may be NULL (two-pass mean / variance).     */
-int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, asr_stream_t stream);
+/* y_grid_w / y_grid_ow (all asr_bn_* calls): y_grid_ow > 0 says that y is the un-compacted output of a window GEMM (section emb_cnn
+ * above): rows come in groups of y_grid_w of which the first y_grid_ow are convolution outputs, row m of the convolution is y row
+ * (m / y_grid_ow) * y_grid_w + m % y_grid_ow (M < 2^31, M % y_grid_ow == 0); 0 / 0: y is compact.  asr_bn_act_bwd's dy_grid_* place
+ * its OUTPUT rows the same way (the dense dy operand of the window data / weight gradients; the rows between groups are not written). */
+int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* sums, int y_grid_w, int y_grid_ow,
+                 asr_stream_t stream);
 /* the same sums WITHOUT atomics: per-workgroup sums into the workspace partial (asr_bn_stats_blocks(M), 2C), then added in a
  * fixed order into sums (2C, overwritten): the batch statistics, and with them the forward pass, are reproducible bit for bit  */
 int64_t asr_bn_stats_blocks(int64_t M);
 int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* partial, float* sums,
-                         asr_stream_t stream);
+                         int y_grid_w, int y_grid_ow, asr_stream_t stream);
 /* out = clamp(gamma * (y - mean) * rstd + beta, lo, hi)   (BatchNorm2d + Hardtanh, transformer.py:35-36,38-39).
  * tH > 0: rows are (b,h,w) over (B,tH,tW) and out is the encoder input (B, tW, C*tH), feature c*tH + h (:74-76).     */
 int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
                    const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
-                   int dtype, asr_stream_t stream);
+                   int y_grid_w, int y_grid_ow, int dtype, asr_stream_t stream);
 /* sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat, dz = dout where lo < z < hi (= dbeta, dgamma of the BatchNorm)      */
 int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
-                          float* sums, int dtype, asr_stream_t stream);
+                          int y_grid_w, int y_grid_ow, float* sums, int dtype, asr_stream_t stream);
 /* dy (M, lddy) = gamma * rstd * (dz - sums[c]/M - xhat * sums[C+c]/M)   (training-mode BatchNorm backward)           */
 int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
-                   int tH, int tW, const float* sums, int dtype, asr_stream_t stream);
+                   int tH, int tW, int y_grid_w, int y_grid_ow, int dy_grid_w, int dy_grid_ow, const float* sums, int dtype,
+                   asr_stream_t stream);
 
 /* ---- spectrogram front end on the device (reference: SpectrogramParser.parse_audio, utils/data_loader.py:72-89) ---------
  * frames (B*Tmax, n_fft) fp32 <- windowed, centred (reflect padded) frames of the padded waveforms wav (B, wav_stride),

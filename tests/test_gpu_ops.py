@@ -1007,14 +1007,17 @@ def test_window_convolutions_against_conv2d(ops, shift, cfg, monkeypatch):
         tag = "t_win%d" % SW
         wd, bd = torch.nn.Parameter(w.to(D)), torch.nn.Parameter(b.to(D))
         xin = nhwc(x).to(D, torch.bfloat16 if C > 1 else torch.float32).contiguous()
-        X2, A, y, M = Fn._conv_window_fwd(xin, geo, wd, bd, tag)
-        got = y[:M, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
+        X2, A, y, M, (yW, yOW) = Fn._conv_window_fwd(xin, geo, wd, bd, tag)
+        # the strided form leaves y on the GEMM's row grid (groups of yW rows, the first yOW are outputs), the unit-stride form compact
+        yc = y[:M // yOW * yW].view(M // yOW, yW, -1)[:, :yOW].reshape(M, -1) if yOW else y[:M]
+        got = yc[:, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2).cpu()
         assert (got - ref.detach()).abs().max().item() < 2e-3 * max(1.0, ref.detach().abs().max().item())
-        assert bool((y[:M, Cout:] == 0).all())
-        dyd = torch.zeros((y.shape[0], 64), device=D, dtype=torch.bfloat16)
-        dyd[:M, :Cout] = nhwc(dy).reshape(M, Cout).to(D, torch.bfloat16)
+        assert bool((yc[:, Cout:] == 0).all())
+        Dd, dview, (dW, dOW) = Fn._window_dy(geo, Cout, tag, D)
+        assert dOW == OW
+        dview.view(B * OH, dW, Cout)[:, :OW] = nhwc(dy).reshape(B * OH, OW, Cout).to(D, torch.bfloat16)
         bg = torch.zeros(Cout, device=D)
-        dw, dx = Fn._conv_window_bwd(dyd, A, wd, bg, geo, tag, SW == 1)
+        dw, dx = Fn._conv_window_bwd(Dd, A, wd, bg, geo, tag, SW == 1)
         assert tuple(dw.shape) == tuple(w.shape)
         assert (dw.cpu() - wr.grad).abs().max().item() < 3e-3 * wr.grad.abs().max().item()
         assert (bg.cpu() - br.grad).abs().max().item() < 1e-3 * br.grad.abs().max().item()

@@ -473,13 +473,14 @@ def test_window_convolution_algebra_on_cpu_stand_ins(monkeypatch, cfg, shift):
     geo = ops.conv_geom(B, H, W, C, KH, KW, SH, SW, 0, PW)
     assert Fn._window_ok(geo)
     wd, bd = torch.nn.Parameter(w.clone()), torch.nn.Parameter(b.clone())
-    X2, A, y, M = Fn._conv_window_fwd(x.permute(0, 2, 3, 1).contiguous().bfloat16(), geo, wd, bd, "cpu_win")
-    got = y[:M, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
+    X2, A, y, M, (yW, yOW) = Fn._conv_window_fwd(x.permute(0, 2, 3, 1).contiguous().bfloat16(), geo, wd, bd, "cpu_win")
+    yc = y[:M // yOW * yW].view(M // yOW, yW, -1)[:, :yOW].reshape(M, -1) if yOW else y[:M]      # strided form: y on the GEMM's row grid
+    got = yc[:, :Cout].reshape(B, OH, OW, Cout).permute(0, 3, 1, 2)
     assert (got - ref.detach()).abs().max().item() < 1e-4 * max(1.0, ref.detach().abs().max().item())
-    dyd = torch.zeros((y.shape[0], 64), dtype=torch.bfloat16)
-    dyd[:M, :Cout] = dy.permute(0, 2, 3, 1).reshape(M, Cout).bfloat16()
+    Dd, dview, (dW, dOW) = Fn._window_dy(geo, Cout, "cpu_win", torch.device("cpu"))
+    dview.view(B * OH, dW, Cout)[:, :OW] = dy.permute(0, 2, 3, 1).reshape(B * OH, OW, Cout).bfloat16()
     bg = torch.zeros(Cout)
-    dw, dx = Fn._conv_window_bwd(dyd, A, wd, bg, geo, "cpu_win", SW == 1)
+    dw, dx = Fn._conv_window_bwd(Dd, A, wd, bg, geo, "cpu_win", SW == 1)
     assert tuple(dw.shape) == tuple(w.shape)
     assert (dw - wr.grad).abs().max().item() < 1e-4 * wr.grad.abs().max().item()
     assert (bg - br.grad).abs().max().item() < 1e-4 * br.grad.abs().max().item()
