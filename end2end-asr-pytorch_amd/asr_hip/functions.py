@@ -717,12 +717,10 @@ def _conv_window_bwd(D, A, w, b_grad, g, tag, need_dx):
 def _bn_stats(bn, y, M, C, training, ygrid=(0, 0)):
     """nn.BatchNorm2d statistics (eps / momentum of the module; unbiased running variance) -> (mean, rstd)."""
     if training:
-        mean, var = ops.bn_batch_stats(y, M, C, ygrid)
-        if bn.track_running_stats:
-            mom = 0.1 if bn.momentum is None else bn.momentum
-            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
-            bn.running_var.mul_(1.0 - mom).add_(var, alpha=mom * M / max(M - 1, 1))
-            bn.num_batches_tracked.add_(1)
+        track = bn.track_running_stats and bn.running_mean.dtype == torch.float32 and bn.num_batches_tracked.dtype == torch.int64
+        mom = (0.1 if bn.momentum is None else bn.momentum) if track else -1.0
+        return ops.bn_train_stats(y, M, C, bn.eps, mom, bn.running_mean if track else None, bn.running_var if track else None,
+                                  bn.num_batches_tracked if track else None, ygrid)
     else:
         mean, var = bn.running_mean.float(), bn.running_var.float()
     return mean.contiguous(), torch.rsqrt(var + bn.eps).contiguous()

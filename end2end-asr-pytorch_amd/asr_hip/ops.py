@@ -1116,6 +1116,18 @@ def bn_batch_stats(y, M, C, ygrid=(0, 0)):
     return mean, s2[C:] / M
 
 
+def bn_train_stats(y, M, C, eps, momentum=-1.0, running_mean=None, running_var=None, num_batches=None, ygrid=(0, 0)):
+    """-> (mean, rstd) of training-mode BatchNorm over y's first M rows / C columns, the module's running buffers updated in place
+    (momentum < 0: left alone): asr_bn_batch_stats, four launches."""
+    nb = L.load().asr_bn_stats_blocks(M)
+    part = torch.empty((nb, 2 * C), device=y.device, dtype=torch.float32)
+    mean = torch.empty(C, device=y.device, dtype=torch.float32)
+    rstd = torch.empty(C, device=y.device, dtype=torch.float32)
+    L.call("asr_bn_batch_stats", L.ptr(y), y.stride(0), M, C, L.ptr(part), L.ptr(mean), L.ptr(rstd), float(eps), float(momentum),
+           L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches), ygrid[0], ygrid[1], L.stream())
+    return mean, rstd
+
+
 def bn_act_fwd(y, M, C, mean, rstd, gamma, beta, lo, hi, out, tH=0, tW=0, ygrid=(0, 0)):
     ldo = 0 if tH else out.stride(0)
     L.call("asr_bn_act_fwd", L.ptr(y), y.stride(0), L.ptr(out), ldo, M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(beta),

@@ -209,6 +209,37 @@ __global__ void __launch_bounds__(1024) bn_partial_sum_kernel(const float* __res
   }
 }
 
+// The two finishing steps of nn.BatchNorm2d's training statistics, each as the tail of the fixed-order sum above (C <= 256):
+// mode 1: mean[c] = sum(y) / M;   mode 2 (partial holds the CENTRED sums): var = sum((y - mean)^2) / M, rstd = rsqrt(var + eps) and, with
+// momentum >= 0, running_mean / running_var (unbiased: var * M / (M - 1)) / num_batches_tracked -- what cost ten small torch launches per layer.
+__global__ void __launch_bounds__(1024) bn_finish_kernel(const float* __restrict__ partial, int64_t nblk, int C, int mode, float inv_m,
+                                                         float unbias, float eps, float momentum, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var, int64_t* __restrict__ num_batches) {
+  __shared__ float red[1024];
+  const int C2 = 2 * C, G = 1024 / C2, c = threadIdx.x % C2, g = threadIdx.x / C2;
+  float s = 0.f;
+  if (g < G)
+    for (int64_t b = g; b < nblk; b += G) s += partial[b * C2 + c];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g != 0) return;
+  for (int i = 1; i < G; ++i) s += red[i * C2 + c];
+  if (mode == 1) {
+    if (c < C) mean[c] = s * inv_m;
+    return;
+  }
+  if (c < C) return;
+  const int ch = c - C;
+  const float var = s * inv_m;
+  rstd[ch] = rsqrtf(var + eps);
+  if (momentum >= 0.f && running_mean) {
+    running_mean[ch] = running_mean[ch] * (1.f - momentum) + momentum * mean[ch];
+    running_var[ch] = running_var[ch] * (1.f - momentum) + momentum * unbias * var;
+    if (ch == 0 && num_batches) num_batches[0] += 1;
+  }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) bn_act_fwd_kernel(BnArgs a, T* __restrict__ out) {
   const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
@@ -399,6 +430,25 @@ extern "C" int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int 
   const int64_t nblk = ceil_div64(M, BN_ROWS);
   bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, center, nullptr, partial);
   bn_partial_sum_kernel<<<1, 1024, 0, stream>>>(partial, nblk, 2 * C, sums);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_bn_batch_stats(const float* y, int64_t ldy, int64_t M, int C, float* partial, float* mean, float* rstd, float eps,
+                                  float momentum, float* running_mean, float* running_var, int64_t* num_batches, int y_grid_w,
+                                  int y_grid_ow, hipStream_t stream) {
+  ASR_CHECK_ARG(y && partial && mean && rstd && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C && grid_ok(M, y_grid_w, y_grid_ow));
+  ASR_CHECK_ARG(momentum < 0.f || (running_mean && running_var));
+  BnArgs a{};
+  a.y = y; a.ldy = ldy; a.M = M; a.C = C; a.yW = y_grid_w; a.yOW = y_grid_ow;
+  AsrProfScope prof(ASR_OP_ADD_LN, stream);
+  const int64_t nblk = ceil_div64(M, BN_ROWS);
+  const float inv_m = 1.f / (float)M, unbias = (float)M / (float)(M > 1 ? M - 1 : 1);
+  bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, nullptr, nullptr, partial);
+  bn_finish_kernel<<<1, 1024, 0, stream>>>(partial, nblk, C, 1, inv_m, unbias, eps, momentum, mean, rstd, nullptr, nullptr, nullptr);
+  bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, mean, nullptr, partial);
+  bn_finish_kernel<<<1, 1024, 0, stream>>>(partial, nblk, C, 2, inv_m, unbias, eps, momentum, mean, rstd, running_mean, running_var,
+                                           num_batches);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

@@ -419,6 +419,13 @@ int asr_bn_stats(const float* y, int64_t ldy, int64_t M, int C, const float* cen
 int64_t asr_bn_stats_blocks(int64_t M);
 int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int C, const float* center, float* partial, float* sums,
                          int y_grid_w, int y_grid_ow, asr_stream_t stream);
+/* nn.BatchNorm2d's training-mode statistics in one call (four launches): mean, then the centred second moment, both summed in a
+ * fixed order (partial: asr_bn_stats_blocks(M) x 2C floats), rstd = rsqrt(var + eps) and -- momentum >= 0 -- the module's buffers:
+ * running_mean = (1 - momentum) running_mean + momentum mean, running_var likewise with the UNBIASED variance var M / (M - 1),
+ * num_batches_tracked += 1 (transformer.py:35,38 = torch.nn.BatchNorm2d defaults eps 1e-5, momentum 0.1).                       */
+int asr_bn_batch_stats(const float* y, int64_t ldy, int64_t M, int C, float* partial, float* mean, float* rstd, float eps,
+                       float momentum, float* running_mean, float* running_var, int64_t* num_batches, int y_grid_w, int y_grid_ow,
+                       asr_stream_t stream);
 /* out = clamp(gamma * (y - mean) * rstd + beta, lo, hi)   (BatchNorm2d + Hardtanh, transformer.py:35-36,38-39).
  * tH > 0: rows are (b,h,w) over (B,tH,tW) and out is the encoder input (B, tW, C*tH), feature c*tH + h (:74-76).     */
 int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
