@@ -470,6 +470,11 @@ def main():
                                                              "algorithmic_gflop": v.get("algorithmic_gflop_per_launch"),
                                                              "t_hbm_us_at_6.29TBs": v.get("t_hbm_us_at_6.29TBs"), "t_mfma_us_at_2.5PF": v.get("t_mfma_us_at_2.5PF")}
                                                          for k, v in tr[2].items()} if tr and tr[2] else None),
+                                   "scope_note": "since round 4 these six launches also carry conv.0's forward and weight gradient, both max-pools "
+                                                 "and the first pool's backward (csrc/conv_level0.hip): in round 3 that work ran as five separate "
+                                                 "HBM-bound launches (0.48 ms) outside this family.  On the same scope (replayed step, family + conv1 / "
+                                                 "pooling launches) round 3 was 1513.8 GFLOP / 1.95 ms = 0.31 of the peak (profiles/r03_replayed_families.json), "
+                                                 "this tree is in families_replayed below",
                                    "launches": n_launch, "avg_launch_ms": prof[key][0] / n_launch,
                                    "algorithmic_flop_per_launch_avg": fl[key][0] / fl[key][1],
                                    "families_eager": fams,
