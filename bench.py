@@ -492,9 +492,20 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(sd_cpu, " ".join(MODEL_FLAGS), a.batch)
             except Exception as e:           # the baseline is a report, never a reason to lose the measurement
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if dist.is_initialized():
         dist.destroy_process_group()
+    if line is not None:
+        # the contract is ONE JSON line on stdout: RCCL prints a version banner through C stdio (block-buffered when stdout is a pipe,
+        # i.e. it would come out AFTER a line printed here at exit) -- flush it first, then print the line last
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
