@@ -480,9 +480,12 @@ __device__ __forceinline__ void attn_bwd_dq_body(const AttnArgs& p, const int vi
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[qi][k2][r] * c2 - lse2[qi]);       // masked: s = -inf -> 0
-            s[qi][k2][r] = pv * (dp[qi][k2][r] - dlt[qi]);
+          for (int r = 0; r < 4; r += 2) {      // two scores per packed instruction (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32)
+            const f32x2_t e = f32x2_t{s[qi][k2][r], s[qi][k2][r + 1]} * c2 - lse2[qi];       // masked: s = -inf -> exp2 = 0
+            const f32x2_t pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            const f32x2_t ds = pv * (f32x2_t{dp[qi][k2][r], dp[qi][k2][r + 1]} - dlt[qi]);
+            s[qi][k2][r] = ds[0];
+            s[qi][k2][r + 1] = ds[1];
           }
         pb[qi] = pack_p(s[qi], 0);
       }
@@ -679,12 +682,18 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
             yw[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xF5, 0xf, 0xf, true);
           }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float pv = __builtin_amdgcn_exp2f(s[ki][q2][r] * c2 - lse2[q2][r]);
+          for (int r = 0; r < 4; r += 2) {      // two scores per packed instruction
+            const f32x2_t e = f32x2_t{s[ki][q2][r], s[ki][q2][r + 1]} * c2 - f32x2_t{lse2[q2][r], lse2[q2][r + 1]};
+            const f32x2_t pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
             // field of key & 1 (v_bfe_u32).  No test of p.thr here: with dropout off thr = 0 never exceeds a field and inv_keep = 1
-            const float keepf = ((yw[r] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep;
-            s[ki][q2][r] = pv * keepf;                                   // dropped / rescaled probabilities (for dV)
-            dp[ki][q2][r] = pv * (dp[ki][q2][r] * keepf - dlt[q2][r]);   // dS (for dK)
+            const f32x2_t keepf = {((yw[r] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep,
+                                   ((yw[r + 1] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep};
+            const f32x2_t pd = pv * keepf;                                                     // dropped / rescaled probabilities (for dV)
+            const f32x2_t ds = pv * (f32x2_t{dp[ki][q2][r], dp[ki][q2][r + 1]} * keepf - f32x2_t{dlt[q2][r], dlt[q2][r + 1]});   // dS (for dK)
+            s[ki][q2][r] = pd[0];
+            s[ki][q2][r + 1] = pd[1];
+            dp[ki][q2][r] = ds[0];
+            dp[ki][q2][r + 1] = ds[1];
           }
         }
         pa[ki] = pack_p(s[ki], 0);
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
   attn_bwd_dq_body<NQ>(p, xcd_linear_id(), smem);
 }
 template <int NK>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, NK == 1 ? 4 : 2) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   __shared__ float s_stat[2][2][64];
   attn_bwd_dkv_body<NK>(p, xcd_linear_id(), smem, s_stat);
@@ -736,7 +745,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_bf16_d64_kernel(AttnArgs p) 
 // independent; both only need delta).  Two launches on two streams cost a fork and a join -- 0.16 ms of idle time per step over the
 // 12 attention blocks of the benchmark model -- for the same overlap.
 template <int N>
-__global__ __launch_bounds__(256) void attn_bwd_both_bf16_d64_kernel(AttnArgs p, int n_dq) {
+__global__ __launch_bounds__(256, N == 1 ? 4 : 2) void attn_bwd_both_bf16_d64_kernel(AttnArgs p, int n_dq) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   __shared__ float s_stat[2][2][64];
   const int bid = (int)blockIdx.x;
