@@ -537,8 +537,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   const int kend = key_end(p, b);
   const int64_t stat0 = ((int64_t)b * p.H + h) * p.Tq;
   const uint32_t field_sh = (uint32_t)(lr & 1) << 4;        // this lane's keys are kw + 16 ki + lr with kw a multiple of 16: key & 1 = lr & 1
-  const unsigned voQ[2] = {tile_voff(p.q_st, tid, 0), tile_voff(p.q_st, tid, 1)};
-  const unsigned voO[2] = {tile_voff(p.o_st, tid, 0), tile_voff(p.o_st, tid, 1)};
+  // (no hoisted DMA offsets / column-fragment addresses here, unlike the dQ half: this half has to fit 128 registers for the fourth wave per
+  //  SIMD, and its loop is bound by the dependent chain of a wave, not by the vector instruction count -- profiles/r04_attention_bwd_ablation.txt)
   FragOff fo;
   fo.init(lr, g);
 
@@ -589,8 +589,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   };
   if (t0 < ntile) {
     stage_stats(t0, t0 & 1);
-    stage_tile_h(smem, Qb, p.q_st, t0 << 6, p.Tq, voQ, tid, wave);
-    stage_tile_h(smem + TILE, dOb, p.o_st, t0 << 6, p.Tq, voO, tid, wave);
+    stage_tile(smem, Qb, p.q_st, t0 << 6, p.Tq, tid, wave);
+    stage_tile(smem + TILE, dOb, p.o_st, t0 << 6, p.Tq, tid, wave);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -638,8 +638,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
           unsigned char* nb = smem + ((t + 1 - t0) & 1) * 2 * TILE;
           if (!next_ragged) dma_stats(t + 1, (t + 1) & 1);
           else if (tid < 128) s_stat[(t + 1) & 1][tid >> 6][tid & 63] = next_stat;
-          stage_tile_h(nb, Qb, p.q_st, q0 + 64, p.Tq, voQ, tid, wave);
-          stage_tile_h(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, voO, tid, wave);
+          stage_tile(nb, Qb, p.q_st, q0 + 64, p.Tq, tid, wave);
+          stage_tile(nb + TILE, dOb, p.o_st, q0 + 64, p.Tq, tid, wave);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -701,8 +701,8 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
       }
 #pragma unroll
       for (int df = 0; df < 4; ++df) {
-        const uint4 aot = frag_cols_at(sdO, fo.cols[df], ms);
-        const uint4 aqt = frag_cols_at(sQ, fo.cols[df], ms);
+        const uint4 aot = frag_cols(sdO, df * 16, ms, lr, g);        // (addresses computed per read: this half lives at 128 registers)
+        const uint4 aqt = frag_cols(sQ, df * 16, ms, lr, g);
 #pragma unroll
         for (int ki = 0; ki < NK; ++ki) {
           mma(dv[ki][df], aot, pa[ki]);
