@@ -229,7 +229,7 @@ def _dec_pack(decoder):
         w1, w2_ = (ff.conv_1, ff.conv_2) if hasattr(ff, "conv_1") else (ff.linear_1, ff.linear_2)
         layers.append(dict(
             wqkv=fr(torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0)),
-            wqkv_rm=torch.cat([w2(sa.query_linear), w2(sa.key_linear), w2(sa.value_linear)], 0).contiguous(), wq_c_rm=w2(ca.query_linear),
+            wq_c_rm=w2(ca.query_linear),
             bqkv=torch.cat([b1(sa.query_linear), b1(sa.key_linear), b1(sa.value_linear)], 0).contiguous(),
             wo_s=fr(w2(sa.output_linear)), bo_s=b1(sa.output_linear),
             ln_s=(sa.layer_norm.weight.data.float().contiguous(), sa.layer_norm.bias.data.float().contiguous(), sa.layer_norm.eps),
@@ -271,10 +271,10 @@ class FusedGreedyDecoder:
 
     TOKENS_PER_GRAPH = 8
     # projections inside the attention launches (asr_dec_attn_fused).  Measured at B = 32, t = 300 (profiles/r02_decode_trace.txt):
-    # cross attention 11.0 us fused vs 6.7 + 8.6 us as two launches -- on; self attention 19.9 us fused vs 7.0 + 10.8 us: every
-    # (sequence, head) workgroup re-reads the head's 192 KB of Q/K/V rows, 48 MB through L2 per layer against 1.5 MB in the GEMM -- off
+    # cross attention 11.0 us fused vs 6.7 + 8.6 us as two launches -- on.  (The self attention fused the same way measured 19.9 us
+    # against 7.0 + 10.8: every (sequence, head) workgroup re-reads the head's 192 KB of Q/K/V rows, 48 MB through L2 per layer against
+    # 1.5 MB in the GEMM; that variant is not kept.)
     FUSE_CROSS = True
-    FUSE_SELF = False
 
     def __init__(self, decoder, encoder_padded_outputs, max_len):
         self.dec = decoder
@@ -289,7 +289,6 @@ class FusedGreedyDecoder:
             raise ValueError("the fused step holds at most 32 sequences (greedy_search_graphed splits larger batches)")
         # the one-launch projection + attention kernels keep every key of a (sequence, head) in registers: up to 512 of them
         self.fuse_cross = self.FUSE_CROSS and encoder_padded_outputs.shape[1] <= 512
-        self.fuse_self = self.FUSE_SELF and max_len <= 512
         self.pack = _dec_pack(decoder)
         self.state = torch.zeros(2, dtype=torch.int64, device=dev)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -319,17 +318,12 @@ class FusedGreedyDecoder:
             return ops.dec_gemm(w[0], bias, out, w_frag=w[1], **kw)
 
         for i, Lw in enumerate(P_["layers"]):
-            if self.fuse_self:
-                src = dict(embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale)) if prev is None else dict(ln=prev)
-                ops.dec_attn_fused(Lw["wqkv_rm"], Lw["bqkv"], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale, x_out=x0,
-                                   state=self.state, self_attention=True, out_frag=True, **src)
+            if prev is None:
+                gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0, embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
             else:
-                if prev is None:
-                    gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, x_out=x0, embed=(self.tok, P_["table"], self.pe, dec.x_logit_scale, self.state))
-                else:
-                    gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
-                ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
-                             k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state, out_frag=True)
+                gemm(Lw["wqkv"], Lw["bqkv"], self.qkv, ln=prev, x_out=x0)
+            ops.dec_attn(self.qkv[:, :HD], c.self_k[i], c.self_v[i], self.o, c.H, c.dk, scale,
+                         k_new=self.qkv[:, HD:2 * HD], v_new=self.qkv[:, 2 * HD:], state=self.state, out_frag=True)
             gemm(Lw["wo_s"], Lw["bo_s"], self.y, x=self.o, x_frag=True)
             if self.fuse_cross:
                 ops.dec_attn_fused(Lw["wq_c_rm"], Lw["bq_c"], c.cross[i][0], c.cross[i][1], self.o, c.H, c.dk, scale,

@@ -94,15 +94,11 @@ def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_d
     if W.shape[1] == K and ops.gemm_nn_tn_supported(dy2d, W, x2d):      # graph capture, bf16: dX and dW workgroups in ONE launch
         return ops.gemm_nn_tn(dy2d, W, x2d, P.grad_of(wparam).view(N, K), P.grad_of(bparam) if bparam is not None else None,
                               out=dx_out, accumulate=accumulate, relu_mask=relu_mask)
-    ops.join_if_pending_reads(dx_out)
     f = ops.fork()
     with f:                                   # dW / db on the second stream, next to dX on this one
         _wgrad_bias(dy2d, x2d, wparam, bparam)
     dx = _dgrad(dy2d, wparam, dx_out, accumulate, relu_mask)
-    if ops._side["defer"]:
-        f.defer(dy2d, x2d)                    # nobody reads dW before the optimiser: no join here (ops.join_deferred)
-    else:
-        f.join()
+    f.join()
     return dx
 
 
@@ -141,7 +137,6 @@ class _Fused:
             return dx
         if need_dx and ops.gemm_nn_tn_supported(dy2d, self.W, x2d):
             return ops.gemm_nn_tn(dy2d, self.W, x2d, g, self.b_grad, out=dx_out, accumulate=accumulate)
-        ops.join_if_pending_reads(dx_out)
         f = ops.fork() if need_dx else None
         if f is not None:
             f.__enter__()
@@ -160,10 +155,7 @@ class _Fused:
         else:
             wt = ops.transpose_padded(self.W)
             dx = ops.gemm_nt(_pad_cols(dy2d), wt, out=dx_out, accumulate=accumulate)
-        if ops._side["defer"]:
-            f.defer(dy2d, x2d)
-        else:
-            f.join()
+        f.join()
         return dx
 
 
@@ -456,13 +448,10 @@ class EmbedFn(Function):
 
 
 # ================================================================================================ vgg front end
-_conv_overlap = os.environ.get("ASR_CONV_OVERLAP", "0") == "1"
 _conv7_pool = os.environ.get("ASR_CONV7_POOL", "1") != "0"       # A/B switch: 0 = conv.7 stores its output, the pooling kernel reads it back
 _pool_codes = os.environ.get("ASR_POOL_CODES", "1") != "0"         # A/B switch: 0 = the pooling backward finds the arg max again from the activations
-# fold of the conv weight-gradient partial blocks on the second stream, under the next data-gradient convolution: measured SLOWER
-# (7.44 -> 7.50 / 7.59 ms per step: the data-gradient convolutions are as much HBM- as MFMA-bound), default off
-_conv_reduce_side = os.environ.get("ASR_CONV_REDUCE_SIDE", "0") == "1"      # A/B switch, default OFF: conv weight gradients on the second stream next to the
-# following data gradient measured 7.82-7.94 vs 7.70 ms/step (both kernels are MFMA bound: sharing the CUs only slows both)
+# (conv weight gradients -- or the fold of their partial blocks -- on the second stream next to the following data gradient measured
+#  slower, 7.82-7.94 / 7.50-7.59 vs 7.70 / 7.44 ms per step in round 2: both kernels are MFMA- and HBM-bound, sharing the CUs slows both)
 
 
 # The full-resolution level (conv.0, conv.2, first pool) as three launches that never store a 64-channel full-resolution tensor
@@ -524,28 +513,9 @@ class VGGFn(Function):
         src, y1, y2, p1, y3, y4, c1, c4, y4_shape = ctx.t
         w0, b0, w2, b2, w5, b5, w7, b7 = ctx.params
 
-        forks = []
-
         def wgrad(x, dy, w, b, tag):
-            # dW and db straight from the NHWC tensors (transposing LDS reads; no planar copies).  On the second stream while a
-            # graph is captured: the weight gradient of a layer runs next to the data gradient that follows it (every operand
-            # stays referenced until the joins at the end of this function)
-            f = ops.fork() if _conv_overlap else None
-            if f is not None and f.on:
-                with f:
-                    ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
-                forks.append(f)
-                return
-            f = ops.fork() if (_conv_reduce_side and ops.compute_dtype() == torch.bfloat16) else None
-            if f is not None and f.on:
-                # MFMA-bound first stage here; its HBM-bound fold (75 MB of partial blocks) on the second stream, under the data-gradient
-                # convolution that follows on this one
-                fold = ops.conv3x3_wgrad_split(x, dy, P.grad_of(w), P.grad_of(b), tag)
-                with f:
-                    fold()
-                forks.append(f)
-            else:
-                ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
+            # dW and db straight from the NHWC tensors (transposing LDS reads; no planar copies)
+            ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
 
         dy4 = ops.maxpool_bwd_code(c4, dout.contiguous(), y4_shape, tcf=True) if c4 is not None else ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
         wgrad(y3, dy4, w7, b7, "c7")
@@ -563,8 +533,6 @@ class VGGFn(Function):
             _, wd2 = P.conv_shadow(w2)
             ops.vgg_level0_dgrad(dp1, c1, src, w0.data, b0.data, wd2, P.grad_of(w0), P.grad_of(b0))
             P.grad_ready(w0, b0)
-            for f in forks:
-                f.join()
             return (None,) * 9
         dy2 = ops.maxpool_bwd_code(c1, dp1, tuple(y1.shape[:3]) + (w2.shape[0],), tcf=False) if c1 is not None else ops.maxpool_bwd(y2, dp1)
         wgrad(y1, dy2, w2, b2, "c2")
@@ -573,8 +541,6 @@ class VGGFn(Function):
         dy1 = ops.conv3x3(dy2, wd2, None, w2.shape[1], relu=False, mask_src=y1)
         ops.conv1_wgrad(src, dy1, P.grad_of(w0), P.grad_of(b0))
         P.grad_ready(w0, b0)
-        for f in forks:
-            f.join()
         return (None,) * 9
 
 

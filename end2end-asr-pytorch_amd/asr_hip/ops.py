@@ -52,8 +52,7 @@ def _pad8(n):
 
 
 # ------------------------------------------------------------------------------------------------ second stream
-_side = {"stream": None, "enabled": os.environ.get("ASR_OVERLAP", "1") != "0", "pending": [],
-         "defer": os.environ.get("ASR_DEFER_JOIN", "0") == "1"}
+_side = {"stream": None, "enabled": os.environ.get("ASR_OVERLAP", "1") != "0"}
 
 
 class fork:
@@ -88,29 +87,6 @@ class fork:
         if self.on:
             self.main.wait_stream(self.side)
 
-    def defer(self, *tensors):
-        """Instead of join(): leave the side-stream work running and keep `tensors` (its operands) referenced until the next
-        join_deferred() -- the main stream does not wait at this point.  Used for weight gradients: nothing on the main stream
-        reads dW before the optimiser, so a layer's backward need not wait for them (a join is a cross-stream graph edge and an
-        idle gap on the main stream: 44 of them per step)."""
-        if self.on:
-            _side["pending"].append(tensors)
-
-
-def join_if_pending_reads(t):
-    """A main-stream kernel is about to WRITE tensor `t` in place (accumulate epilogue): if a deferred side-stream kernel still
-    reads memory that overlaps it (dropout 0: LayerNorm's d_y IS d_res, read by a weight gradient and accumulated into by the
-    next data gradient), wait for the second stream first."""
-    if t is None or not _side["pending"]:
-        return
-    lo = t.data_ptr()
-    hi = lo + t.numel() * t.element_size()
-    for group in _side["pending"]:
-        for x in group:
-            a = x.data_ptr()
-            if a < hi and lo < a + x.numel() * x.element_size():
-                join_deferred()
-                return
 
 
 # ---- deferred, grouped weight gradients.  Only a linear layer's DATA gradient feeds the rest of backward; its weight gradient is a
@@ -120,9 +96,7 @@ def join_if_pending_reads(t):
 # data-parallel step, whose reducer only exchanges between graphs.)
 _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
-_debug_group = os.environ.get("ASR_DEBUG_GROUP") == "1"
 WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "32"))      # layers per grouped launch (<= 32: asr_gemm_tn_grouped); 16 / 24 / 32 measured: profiles/r03_grouped_wgrad_group_size_ab.txt
-_wgrad_side = int(os.environ.get("ASR_WGRAD_SIDE", "0"))
 # a group is also closed once it holds this many 64-row stages of 256 x 256 blocks (about 150 per workgroup of the scheduled kernel):
 # with 12 720 rows per layer (configs[3]) groups of 16 layers measure 0.3 - 0.5 ms per step faster than groups of 32, with 6 400 rows
 # groups of 32 are the faster ones -- both are ~38 000 stages.  profiles/r03_grouped_wgrad_group_size_ab.txt
@@ -152,21 +126,13 @@ def queue_wgrad(dy, x, dw, db, N, K):
 
 
 def flush_wgrads(final=False):
-    """Contract everything queued.  ASR_WGRAD_SIDE=1: on the second stream (a branch of the captured graph), so that the grouped
-    launch shares the chip with the data-gradient chain that follows it on the main stream -- the decoder's kernels there are
-    12 - 200 blocks each; the operands stay referenced until join_deferred().  ASR_WGRAD_SIDE=2: only the flush at the end of the
-    transformer's backward (final: what follows on the main stream is the conv front end's backward).  Both measured slower."""
+    """Contract everything queued, on the launching stream (the same launches on a second stream, next to the data-gradient chain
+    that follows, measured slower: profiles/r03_grouped_wgrad_ab.txt)."""
     _wgrad_stages[0] = 0
     while _wgrad_q:
         grp = _wgrad_q[:WGRAD_GROUP]
         del _wgrad_q[:WGRAD_GROUP]
-        if (_wgrad_side == 1 or (_wgrad_side == 2 and final)) and torch.cuda.is_current_stream_capturing():
-            f = fork()
-            with f:
-                gemm_tn_grouped(grp)
-            f.defer(*[t for e in grp for t in e[:2]])
-        else:
-            gemm_tn_grouped(grp)
+        gemm_tn_grouped(grp)
 
 
 def _tn_group_ok(e):
@@ -185,10 +151,6 @@ def gemm_tn_grouped(grp):
     import ctypes
     odd = [e for e in grp if not _tn_group_ok(e)]
     if odd:
-        if _debug_group:
-            for dy, x, dw, db, N, K in odd:
-                print("gemm_tn_grouped: per-layer launch for dy %s stride %s, x %s stride %s, N %d K %d" %
-                      (tuple(dy.shape), dy.stride(), tuple(x.shape), x.stride(), N, K), flush=True)
         for dy, x, dw, db, N, K in odd:
             gemm_tn(dy, x, dw, colsum_acc=db, N=N, K=K)
         grp = [e for e in grp if _tn_group_ok(e)]
@@ -209,12 +171,9 @@ def gemm_tn_grouped(grp):
 
 
 def join_deferred():
-    """Main stream waits for everything deferred on the second stream (called before anything reads the weight gradients
-    and at the end of every captured graph body)."""
+    """Everything deferred is launched: the queued weight gradients and the partial-sum folds (called before anything reads the
+    weight gradients and at the end of every captured graph body)."""
     flush_wgrads()
-    if _side["pending"] and _side["stream"] is not None:
-        torch.cuda.current_stream().wait_stream(_side["stream"])
-    _side["pending"] = []
     flush_ln_reduces()
     flush_tn_reduces()
 
@@ -252,11 +211,6 @@ def gemm_tn(dy, x, dw, colsum_acc=None, N=None, K=None, splits=0, use_ws=True):
     N = dy.shape[1] if N is None else N
     K = x.shape[1] if K is None else K
     assert dw.dtype == torch.float32 and dw.stride(1) == 1 and dy.dtype == x.dtype
-    if _debug_group and torch.cuda.is_current_stream_capturing():
-        import traceback
-        print("gemm_tn inside a capture: dy %s stride %s x %s stride %s N %s K %s  <- %s" %
-              (tuple(dy.shape), dy.stride(), tuple(x.shape), x.stride(), N, K,
-               " < ".join("%s:%d" % (f.name, f.lineno) for f in traceback.extract_stack()[-5:-1])), flush=True)
     n_ws = L.load().asr_gemm_tn_workspace(M, N, K, int(splits), L.dt(dy)) if use_ws else 0
     ws = torch.empty(n_ws, device=dy.device, dtype=torch.float32) if n_ws else None
     L.call("asr_gemm_tn", L.ptr(dy), dy.stride(0), L.ptr(x), x.stride(0), L.ptr(dw), dw.stride(0), L.ptr(colsum_acc), L.ptr(ws),
@@ -331,7 +285,6 @@ def reset_pending():
     """Forget second stages that were never issued (a capture that raised half way): their workspaces are gone."""
     del _tn_pending[:]
     del _ln_pending[:]
-    _side["pending"] = []
 
 
 def flush_tn_reduces():
@@ -513,15 +466,7 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
                L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), sd, parts,
                L.dt(q), L.stream())
 
-    f = fork()
-    if f.on and os.environ.get('ASR_ATTN_SPLIT', '0') == '1':   # (A/B) dK/dV on the second stream next to dQ: the default is ONE launch for both
-        launch(L.ATTN_DELTA)
-        with f:
-            launch(L.ATTN_DKV)
-        launch(L.ATTN_DQ)
-        f.join()
-    else:
-        launch(L.ATTN_ALL)
+    launch(L.ATTN_ALL)       # one launch for dQ and dK / dV (two launches on two streams cost a fork and a join: profiles/r02_ab_attn_both.txt)
     return dq, dk, dv
 
 
@@ -1033,18 +978,6 @@ def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
     L.call("asr_conv3x3_wgrad_nhwc", L.ptr(x), L.ptr(dy), L.ptr(dw), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x),
            L.stream())
 
-
-
-def conv3x3_wgrad_split(x, dy, dw, db, tag):
-    """The same in two launches: partial blocks into a workspace of this layer's own (tag), then the HBM-bound fold -- returned as a
-    closure so that the caller can run it on its second stream next to the data-gradient convolution that follows."""
-    B, H, W, Cin = x.shape
-    Cout = dy.shape[3]
-    assert x.is_contiguous() and dy.is_contiguous() and dy.shape[:3] == x.shape[:3]
-    n_ws = L.load().asr_conv3x3_wgrad_workspace(B, H, W, Cin, Cout)
-    ws = workspace("wgrad_ws_" + tag, (n_ws,), torch.float32, x.device, zero=False)
-    L.call("asr_conv3x3_wgrad_partials", L.ptr(x), L.ptr(dy), L.ptr(db), L.ptr(ws), n_ws, B, H, W, Cin, Cout, L.dt(x), L.stream())
-    return lambda: L.call("asr_conv3x3_wgrad_reduce", L.ptr(ws), L.ptr(dw), B, H, W, Cin, Cout, L.stream())
 
 
 # ------------------------------------------------------------------------------------------------ emb_cnn front end

@@ -248,11 +248,10 @@ def _model(layers=2, inner=256, V=40):
     return model
 
 
-@pytest.mark.parametrize("fuse_self,fuse_cross", [(False, True), (True, True), (False, False)])
-def test_fused_step_logits_match_kernel_per_op_step(fuse_self, fuse_cross, monkeypatch):
+@pytest.mark.parametrize("fuse_cross", [True, False])
+def test_fused_step_logits_match_kernel_per_op_step(fuse_cross, monkeypatch):
     """Teacher forcing: the same tokens through both steps -> logits within 3e-2 of the logit range at every position."""
     from asr_hip.decode import DecoderKVCache, FusedGreedyDecoder, fused_decode_supported
-    monkeypatch.setattr(FusedGreedyDecoder, "FUSE_SELF", fuse_self)
     monkeypatch.setattr(FusedGreedyDecoder, "FUSE_CROSS", fuse_cross)
     model = _model()
     dec = model.decoder
