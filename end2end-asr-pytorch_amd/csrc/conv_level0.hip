@@ -815,12 +815,21 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
         }
       }
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int off = ((2 * ms + t / 3) * 18) * 128;
-        const bf16x8_t bb = l0_read_tr(sb + xlo[t % 3] + off, sb + xhi[t % 3] + off);
+      for (int ky = 0; ky < 3; ++ky) {      // one run of 12 pixels per kernel row, the kx = 1, 2 operands by shifting (conv_wgrad_dma.hip)
+        const int off = ((2 * ms + ky) * 18) * 128;
+        const uint2 r0 = asr_lds_read_tr16(sb + xlo[0] + off), r1 = asr_lds_read_tr16(sb + xhi[0] + off);
+        const uint2 r2 = asr_lds_read_tr16(sb + xlo[0] + off + 8 * 128);
+        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
+        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, make_uint4(__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                                                                     __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)));
+        const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.y, r1.x, r1.y, r2.x));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bb, acc[t][i], 0, 0, 0);
-        if (t % 3 == 2) L0_FENCE();
+        for (int i = 0; i < 4; ++i) acc[3 * ky][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0, acc[3 * ky][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[3 * ky + 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1, acc[3 * ky + 1][i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[3 * ky + 2][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b2, acc[3 * ky + 2][i], 0, 0, 0);
+        L0_FENCE();
       }
     }
     if (j + 1 < np) expand(buf ^ 1);
