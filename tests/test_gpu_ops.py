@@ -1028,6 +1028,53 @@ def test_window_convolutions_against_conv2d(ops, shift, cfg, monkeypatch):
         ops.set_compute_dtype(prev)
 
 
+@pytest.mark.parametrize("grid", [(0, 0), (13, 9)])
+def test_batchnorm_hardtanh_on_a_row_grid(ops, grid):
+    """asr_bn_batch_stats / asr_bn_act_fwd / asr_bn_act_bwd against torch's BatchNorm2d (training mode: batch statistics, running buffers with
+    the unbiased variance, reference transformer.py:35-36) + Hardtanh(0, 20), with the convolution output y either compact or on the row
+    grid of a window GEMM (groups of 13 rows of which 9 are outputs; the rows in between hold garbage that must not be read) and the
+    gradient written through the same kind of grid into a buffer whose other rows must stay untouched."""
+    D = dev()
+    C, groups = 32, 57
+    gW, gOW = grid
+    M = groups * (gOW or 9)
+    g = torch.Generator().manual_seed(4)
+    yc = (torch.randn(M, C, generator=g) * 6 + 5)                                     # compact conv output, some of it outside (0, 20)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dz = torch.randn(M, C, generator=g)
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+        bn.running_mean.normal_(generator=g); bn.running_var.uniform_(0.5, 2.0, generator=g)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    yr = yc.clone().requires_grad_()
+    ref = F.hardtanh(bn(yr.t().reshape(1, C, M, 1)), 0.0, 20.0).reshape(C, M).t()
+    ref.backward(dz)
+    if gOW:
+        y = torch.full((groups * gW, 64), 1e30)
+        y.view(groups, gW, 64)[:, :gOW, :C] = yc.view(groups, gOW, C)
+    else:
+        y = torch.zeros(M, 64)
+        y[:, :C] = yc
+    y = y.to(D)
+    rm, rv, nb = rm0.clone().to(D), rv0.clone().to(D), torch.zeros((), dtype=torch.int64, device=D)
+    mean, rstd = ops.bn_train_stats(y, M, C, bn.eps, 0.1, rm, rv, nb, ygrid=grid)
+    assert (mean.cpu() - yc.mean(0)).abs().max().item() < 1e-4
+    assert (rstd.cpu() - torch.rsqrt(yc.var(0, unbiased=False) + bn.eps)).abs().max().item() < 1e-4
+    assert (rm.cpu() - bn.running_mean).abs().max().item() < 1e-5 and (rv.cpu() - bn.running_var).abs().max().item() < 1e-4 and int(nb) == 1
+    out = torch.empty(M, C, device=D)
+    ops.bn_act_fwd(y, M, C, mean, rstd, gamma.to(D), beta.to(D), 0.0, 20.0, out, ygrid=grid)
+    assert (out.cpu() - ref.detach()).abs().max().item() < 1e-4
+    dgrid = (17, gOW) if gOW else (0, 0)                                                # the gradient goes to yet another grid
+    dy = torch.full(((groups * 17 if gOW else M), C), 7.0, device=D)
+    sums = ops.bn_act_bwd(dz.to(D), y, M, C, mean, rstd, gamma.to(D), beta.to(D), 0.0, 20.0, dy, ygrid=grid, dygrid=dgrid)
+    assert (sums[:C].cpu() - bn.bias.grad).abs().max().item() < 2e-3 and (sums[C:].cpu() - bn.weight.grad).abs().max().item() < 2e-3
+    got = dy.view(groups, 17, C)[:, :gOW].reshape(M, C) if gOW else dy
+    assert (got.cpu() - yr.grad).abs().max().item() < 1e-4 * max(1.0, yr.grad.abs().max().item())
+    if gOW:
+        assert bool((dy.view(groups, 17, C)[:, gOW:] == 7.0).all())                  # rows between the groups: not written
+
+
 def test_ops_refuse_host_tensors(ops):
     from asr_hip.lib import AsrHipError
     with pytest.raises(AsrHipError):
