@@ -319,7 +319,7 @@ def main():
         opt.zero_grad()
         pred, gold, hyp, _ = model(src, src_len, tgt)
         loss = calculate_loss(pred, gold, smoothing=0.1, loss_type="ce")
-        loss.backward()
+        ops.backward_from(loss)
         opt.step()
         return loss
 

@@ -464,6 +464,7 @@ class VGGFn(Function):
     def forward(ctx, src, w0, b0, w2, b2, w5, b5, w7, b7):
         cd = ops.compute_dtype()
         src = src.contiguous().float()
+        P.conv_shadows((w2, w5, w7))                      # the three packed weight sets of the step in one launch
         wk2, _ = P.conv_shadow(w2)
         tap = capture_selections is not None
         # conv.0 + ReLU recomputed inside conv.2's loader, conv.2 + ReLU + MaxPool2d + selection codes from its epilogue: the log-mel
@@ -836,7 +837,7 @@ class CEFn(Function):
             # data-gradient GEMM reads), and return a stride-0 zero as the formal fp32 gradient -- saves the 56 MB fp32 tensor, its
             # cast / pad launch and half of this kernel's stores (reference: loss.backward() through utils/metrics.py:118-130)
             ctx.handover["dy"] = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count, out_dtype=torch.bfloat16, pad=64)
-            return torch.zeros((), device=logits.device, dtype=torch.float32).expand(ctx.shape), None, None, None, None
+            return ops.zero_scalar(logits.device).expand(ctx.shape), None, None, None, None
         dl = ops.ce_bwd(logits, g, lse, ctx.smoothing, ctx.pad_id, go, count)
         return dl.view(ctx.shape), None, None, None, None
 

@@ -93,7 +93,7 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         pred, gold, self.hyp_seq, self.gold_seq = self.model(self.src, self.src_len, self.tgt)
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
-        loss.backward()
+        ops.backward_from(loss)
         self._body_c(guard=sums)                 # sums[0] = the loss sum: non-finite -> the update is skipped on the device
         return loss.detach(), sums
 
@@ -138,7 +138,7 @@ class GraphedTrainStep:
         self.hyp_seq = ops.argmax_rows(pred.detach().reshape(-1, pred.shape[-1])).view(pred.shape[0], pred.shape[1])
         self.gold_seq = gold
         loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
-        loss.backward()
+        ops.backward_from(loss)
         ops.join_deferred()                     # every forked stream must have re-joined before this graph ends
         return loss.detach(), sums, {"feats": feats, "leaf": leaf, "enc_out": enc_out, "d_enc": enc_leaf.grad}
 

@@ -91,6 +91,7 @@ _SIGS = {
     "asr_conv1_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_conv1_wgrad": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "asr_conv_pack_weight": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "asr_conv_pack_weight_multi": (_I, [_I, _P, _P, _P, _P, _P, _I, _P]),
     "asr_conv3x3_igemm": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "asr_conv3x3_relu_pool": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "asr_maxpool_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -479,7 +479,8 @@ def decoder_preprocess(tgt, Td):
     seq_out = torch.empty((B, Td), device=dev, dtype=torch.int64)
     key_pad = torch.empty((B, Td), device=dev, dtype=torch.uint8)
     row_keep = torch.empty((B, Td), device=dev, dtype=torch.uint8)
-    overflow = torch.zeros(1, device=dev, dtype=torch.int32)
+    # the flag is only ever read when a target CAN be too long for Td (models/asr/transformer.py): otherwise a scratch word, no fill launch
+    overflow = torch.zeros(1, device=dev, dtype=torch.int32) if Lw + 1 > Td else _scratch_word(dev)
     L.call("asr_decoder_preprocess", L.ptr(tgt), B, Lw, Td, L.ptr(seq_in), L.ptr(seq_out), L.ptr(key_pad),
            L.ptr(row_keep), L.ptr(overflow), L.stream())
     return seq_in, seq_out, key_pad, row_keep, overflow
@@ -793,6 +794,29 @@ def ratio(num, den):
 
 
 _ones = {}
+_consts = {}
+
+
+def zero_scalar(device):
+    """A shared 0-dim fp32 zero (read-only by convention: formal gradients that nobody consumes)."""
+    t = _consts.get(("zero", str(device)))
+    if t is None:
+        t = torch.zeros((), device=device, dtype=torch.float32)
+        _consts[("zero", str(device))] = t
+    return t
+
+
+def _scratch_word(device):
+    t = _consts.get(("scratch", str(device)))
+    if t is None:
+        t = torch.zeros(1, device=device, dtype=torch.int32)
+        _consts[("scratch", str(device))] = t
+    return t
+
+
+def backward_from(loss):
+    """loss.backward() without the ones_like() fill launch autograd would seed it with: the seed is a cached device scalar."""
+    loss.backward(ones_scalar(loss.device).view(loss.shape))
 
 
 def ones_scalar(device):
@@ -827,6 +851,18 @@ def conv_pack_weight(w, wk, wd):
     Cout, Cin = w.shape[0], w.shape[1]
     t = wk if wk is not None else wd
     L.call("asr_conv_pack_weight", L.ptr(w), L.ptr(wk), L.ptr(wd), Cout, Cin, L.dt(t), L.stream())
+
+
+def conv_pack_weight_multi(items):
+    """items: up to 8 (w (Cout,Cin,3,3) fp32, wk, wd) triples of one dtype -> all packed by one launch."""
+    import ctypes
+    n = len(items)
+    if n == 0:
+        return
+    P_, I_ = ctypes.c_void_p * n, ctypes.c_int * n
+    L.call("asr_conv_pack_weight_multi", n, P_(*[w.data_ptr() for w, _, _ in items]), P_(*[wk.data_ptr() for _, wk, _ in items]),
+           P_(*[wd.data_ptr() for _, _, wd in items]), I_(*[w.shape[0] for w, _, _ in items]), I_(*[w.shape[1] for w, _, _ in items]),
+           L.dt(items[0][1]), L.stream())
 
 
 def conv3x3(x, wk, bias, Cout, relu, mask_src=None):

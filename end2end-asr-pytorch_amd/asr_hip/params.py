@@ -83,6 +83,27 @@ def conv_shadow(p, dtype=None):
     return sh["wk"], sh["wd"]
 
 
+def conv_shadows(params, dtype=None):
+    """conv_shadow() for several weights at once: the stale ones are packed by ONE launch (asr_conv_pack_weight_multi)."""
+    dtype = dtype or ops.compute_dtype()
+    stale = []
+    for p in params:
+        sh = p.__dict__.get("_asr_shadow")
+        key = _key(p, dtype)
+        if sh is not None and sh["key"] == key:
+            continue
+        Cout, Cin = p.shape[0], p.shape[1]
+        if sh is None or sh["wk"].dtype != dtype or sh["wk"].device != p.device:
+            sh = {"wk": torch.empty((Cout, 9, Cin), device=p.device, dtype=dtype),
+                  "wd": torch.empty((Cin, 9, Cout), device=p.device, dtype=dtype)}
+            p.__dict__["_asr_shadow"] = sh
+        stale.append((p, sh, key))
+    if stale:
+        ops.conv_pack_weight_multi([(p.data, sh["wk"], sh["wd"]) for p, sh, _ in stale])
+        for p, sh, key in stale:
+            sh["key"] = key
+
+
 def fused(params):
     """If the given parameters occupy CONSECUTIVE slots of one FlatParams buffer (e.g. the Q, K, V weights of an attention
     block, which FlatParams lays out back to back), return (master_flat_view, grad_flat_view, flat, offset) over all of

@@ -227,6 +227,33 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ 
   }
 }
 
+// up to 8 weight tensors in one launch (the conv stack's three packs were three 5 us launches per step)
+struct PackMulti {
+  const float* w[8]; void* wk[8]; void* wd[8];
+  int cout[8], cin[8];
+  int64_t start[9];        // element ranges of the tensors in the launch's flat index
+  int n;
+};
+template <typename T>
+__global__ void pack_weight_multi_kernel(PackMulti a) {
+  const int64_t total = a.start[a.n];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 8; ++j) k += (j < a.n && i >= a.start[j]) ? 1 : 0;
+    const int64_t e = i - a.start[k];
+    const int Cin = a.cin[k], Cout = a.cout[k];
+    const int tap = (int)(e % 9);
+    const int ci = (int)((e / 9) % Cin);
+    const int co = (int)(e / (9 * (int64_t)Cin));
+    const float v = a.w[k][e];
+    T* wk = static_cast<T*>(a.wk[k]);
+    T* wd = static_cast<T*>(a.wd[k]);
+    if (wk) DT<T>::st(wk + ((int64_t)co * 9 + tap) * Cin + ci, v);
+    if (wd) DT<T>::st(wd + ((int64_t)ci * 9 + (8 - tap)) * Cout + co, v);
+  }
+}
+
 // ================================================================================================ implicit GEMM 3x3
 __device__ const uint4 conv_zero_page = {0u, 0u, 0u, 0u};      // source of halo pixels outside the image
 
@@ -1210,6 +1237,27 @@ extern "C" int asr_conv_pack_weight(const float* w, void* wk, void* wd, int Cout
   const int64_t total = (int64_t)Cout * Cin * 9;
   if (dtype == ASR_F32) hipLaunchKernelGGL((pack_weight_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, w, (float*)wk, (float*)wd, Cout, Cin);
   else if (dtype == ASR_BF16) hipLaunchKernelGGL((pack_weight_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, w, (bf16_t*)wk, (bf16_t*)wd, Cout, Cin);
+  else return ASR_EINVAL;
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_conv_pack_weight_multi(int n, const float* const* w, void* const* wk, void* const* wd, const int* Cout, const int* Cin,
+                                          int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(n >= 0 && n <= 8 && (n == 0 || (w && wk && wd && Cout && Cin)));
+  if (n == 0) return ASR_OK;
+  PackMulti a{};
+  a.n = n;
+  int64_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    ASR_CHECK_ARG(w[k] && (wk[k] || wd[k]) && Cout[k] > 0 && Cin[k] > 0);
+    a.w[k] = w[k]; a.wk[k] = wk[k]; a.wd[k] = wd[k]; a.cout[k] = Cout[k]; a.cin[k] = Cin[k];
+    a.start[k] = total;
+    total += (int64_t)Cout[k] * Cin[k] * 9;
+  }
+  for (int k = n; k <= 8; ++k) a.start[k] = total;
+  if (dtype == ASR_F32) hipLaunchKernelGGL((pack_weight_multi_kernel<float>), dim3(stream_grid(total)), dim3(256), 0, s, a);
+  else if (dtype == ASR_BF16) hipLaunchKernelGGL((pack_weight_multi_kernel<bf16_t>), dim3(stream_grid(total)), dim3(256), 0, s, a);
   else return ASR_EINVAL;
   ASR_LAUNCH_CHECK();
   return ASR_OK;

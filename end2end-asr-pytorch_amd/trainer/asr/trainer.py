@@ -21,6 +21,7 @@ from utils import constant
 from utils.audio import gpu_front_end
 from utils.data_loader import DevicePrefetcher
 from utils.functions import save_model
+from asr_hip import ops
 from asr_hip.text import edit_distance_batch
 from utils.metrics import calculate_metrics
 
@@ -192,7 +193,7 @@ class Trainer():
             return None
         loss_value = None
         if opt is not None:
-            loss.backward()
+            ops.backward_from(loss)
             if constant.args.clip:
                 opt.optimizer.clip_grad_norm_(constant.args.max_norm)
             opt.step()

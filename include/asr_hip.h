@@ -327,6 +327,9 @@ int asr_conv1_wgrad(const float* x, const void* dy, float* dw_acc, float* db_acc
                     int dtype, asr_stream_t stream);
 /* master (Cout,Cin,3,3) fp32 -> wk (Cout,9,Cin) for forward and wd (Cin,9,Cout) tap-flipped for dgrad            */
 int asr_conv_pack_weight(const float* w, void* wk, void* wd, int Cout, int Cin, int dtype, asr_stream_t stream);
+/* the same for up to 8 weight tensors in ONE launch (arrays of n pointers / sizes in host memory): the conv stack's packs of a step */
+int asr_conv_pack_weight_multi(int n, const float* const* w, void* const* wk, void* const* wd, const int* Cout, const int* Cin,
+                               int dtype, asr_stream_t stream);
 /* y = act(conv3x3_pad1(x; wk) + bias): relu=1 -> ReLU.  If mask_src != NULL: y *= (mask_src > 0) (dgrad through
  * the ReLU that produced this conv's input).  Cin, Cout multiples of 64, Cout <= 128.  bf16 64 -> 64 runs the persistent
  * register-resident-weights kernel of conv_c64.hip, everything else the generic implicit GEMM of conv.hip.        */
