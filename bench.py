@@ -478,8 +478,8 @@ def main():
                                    "launches": n_launch, "avg_launch_ms": prof[key][0] / n_launch,
                                    "algorithmic_flop_per_launch_avg": fl[key][0] / fl[key][1],
                                    "families_eager": fams,
-                                   "families_eager_note": "MFMA families during the EAGER steps of the roofline pass: a linear layer's backward is "
-                                                          "two launches there, not the one-launch / grouped forms of the replayed step",
+                                   "families_eager_note": "MFMA families during the EAGER steps of the roofline pass (the eager backward uses the "
+                                                          "same deferred / grouped weight-gradient launches as the replayed step since round 4)",
                                    "largest_family_by_time_eager": max(fams, key=lambda k: fams[k]["ms_per_step"])}
                 rep = replayed_families(a, peak)
                 if rep is not None:

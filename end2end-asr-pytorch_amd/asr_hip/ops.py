@@ -104,15 +104,50 @@ WGRAD_STAGES = int(os.environ.get("ASR_WGRAD_STAGES", "38000"))
 _wgrad_stages = [0]
 
 
+# The deferred forms (grouped weight gradients, LayerNorm / one-launch-backward folds in one launch per step) need a point where
+# "backward is over" is known: under a hipGraph capture every graph body ends with join_deferred(); in an EAGER backward pass the
+# autograd engine calls us back when the pass has finished (queue_callback), so loss.backward() still returns complete gradients --
+# the default train.py loop then issues ~60 launches per step less (round 4).  Outside both (an op called directly) nothing is deferred.
+_defer_eager = os.environ.get("ASR_DEFER_EAGER", "1") != "0"
+_backward_flush = {"armed": False}
+
+
+def _backward_flush_cb():
+    _backward_flush["armed"] = False
+    join_deferred()
+
+
+def deferral_ok():
+    """True while a hipGraph is being captured, or inside an eager autograd backward pass whose end will flush the queues."""
+    if torch.cuda.is_current_stream_capturing():
+        return True
+    if not _defer_eager:
+        return False
+    from . import params as P_
+    r = P_._state["reducer"]
+    if r is not None and getattr(r, "active", False):
+        return False                # an eager gradient reducer exchanges a bucket the moment its parameters report ready: nothing may trail
+    if _backward_flush["armed"]:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_backward_flush_cb)
+    except RuntimeError:            # not inside a backward pass
+        return False
+    _backward_flush["armed"] = True
+    return True
+
+
 def defer_wgrad_now(dtype=None):
-    if not _defer_wgrad or not torch.cuda.is_current_stream_capturing() or (dtype or compute_dtype()) != torch.bfloat16:
+    if not _defer_wgrad or (dtype or compute_dtype()) != torch.bfloat16:
         return False
     from . import params as P_
     r = P_._state["reducer"]
     # data parallel: an eager reducer wants every layer's gradient the moment its backward ran (bucket by bucket); in graph-replay
     # mode the collectives are issued BETWEEN the graphs (hold), every graph body ends with join_deferred() -> flush_wgrads(), so the
     # gradients of a graph's layers are complete before its slice is exchanged
-    return r is None or not getattr(r, "active", False) or getattr(r, "hold", False)
+    if not (r is None or not getattr(r, "active", False) or getattr(r, "hold", False)):
+        return False
+    return deferral_ok()
 
 
 def queue_wgrad(dy, x, dw, db, N, K):
@@ -253,7 +288,7 @@ _tn_pending = []
 def gemm_nn_tn_supported(dy, w, x):
     """True when a linear layer's dX and dW can be ONE launch (asr_gemm_nn_tn): bf16, inside a graph capture (the weight
     gradient is then complete only after flush_tn_reduces(), which join_deferred() issues at the end of backward)."""
-    return (_nn_tn and dy.dtype == torch.bfloat16 and torch.cuda.is_current_stream_capturing() and gemm_nn_supported(dy, w) and
+    return (_nn_tn and dy.dtype == torch.bfloat16 and gemm_nn_supported(dy, w) and deferral_ok() and
             gemm_tn_supported(dy, x) and x.dtype == dy.dtype and w.shape[0] * w.shape[1] <= _nn_tn_max)
 
 
@@ -378,7 +413,7 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     d_y = torch.empty_like(z) if (p > 0 or defer_wgrad_now(z.dtype)) else d_res
     n_ws = L.load().asr_add_ln_bwd_workspace(M, D)
     ws = torch.empty(n_ws, device=z.device, dtype=torch.float32)       # caching allocator: no cost after the first step
-    if _ln_multi and D % 2 == 0 and torch.cuda.is_current_stream_capturing():
+    if _ln_multi and D % 2 == 0 and deferral_ok():
         # graph capture: the dgamma / dbeta sums of all layers in one launch at the end of backward (flush_ln_reduces)
         L.call("asr_add_ln_bwd_partials", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
                L.ptr(d_res), L.ptr(d_y), L.ptr(ws), n_ws, M, D, float(p), int(seed), _seed_dev(z), L.dt(z), L.stream())
