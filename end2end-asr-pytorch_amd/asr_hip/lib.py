@@ -207,9 +207,25 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
+
+
 def stream():
+    """The current HIP stream's handle.  torch's raw accessor when it exists: torch.cuda.current_stream() builds a Stream object and
+    resolves the device on every call (~3 us, once per launch on the eager path)."""
+    if _raw_stream is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
+_fn_cache = {}
+
+
 def call(name, *args):
-    check(getattr(load(), name)(*args), name)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(load(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)
