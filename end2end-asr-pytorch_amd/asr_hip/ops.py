@@ -208,6 +208,7 @@ def gemm_tn_grouped(grp):
 def join_deferred():
     """Everything deferred is launched: the queued weight gradients and the partial-sum folds (called before anything reads the
     weight gradients and at the end of every captured graph body)."""
+    _backward_flush["armed"] = False      # (a backward pass that raised never ran its callback: do not trust a stale flag)
     flush_wgrads()
     flush_ln_reduces()
     flush_tn_reduces()
