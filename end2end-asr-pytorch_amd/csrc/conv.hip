@@ -14,6 +14,7 @@
 #include "common.h"
 #include "conv1_wgrad_mfma.h"
 #include "conv_c64.h"
+#include "conv_ws.h"
 #include "conv_wgrad_dma.h"
 
 namespace {
@@ -1299,6 +1300,16 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
     }
     return ASR_OK;
   }
+  // 128 input channels in bf16 (conv.7's data gradient with conv.5's ReLU mask, conv.5's data gradient): the persistent
+  // weight-stationary kernel of conv_ws.hip; WS128 = 0 (tuning) or a shape outside its domain -> the generic implicit GEMM
+  if (dtype == ASR_BF16 && Cin == 128 && !p.ablate && asr_tuning("WS128", 1) != 0) {
+    WsArgs a{};
+    a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
+    a.mask = static_cast<const bf16_t*>(mask_src); a.y = static_cast<bf16_t*>(y);
+    a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+    const int rc = asr_conv3x3_ws128_launch(a, s);
+    if (rc != ASR_EUNSUPPORTED) return rc;
+  }
   if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
   return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);
 }
@@ -1349,10 +1360,20 @@ extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, con
                                               int W, int Cin, int Cout, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && wk && pool && code && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
-  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 16 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
-      (((uintptr_t)code) & 7) != 0 || asr_tuning("CONV_POOL", 1) == 0 || asr_tuning("IGEMM_TH", 16) != 16)
+  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 8 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
+      (((uintptr_t)code) & 7) != 0 || asr_tuning("CONV_POOL", 1) == 0)
     return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
+  if (Cin == 128 && asr_tuning("WS128", 1) != 0) {        // conv.7 forward: persistent weight-stationary kernel (conv_ws.hip)
+    WsArgs a{};
+    a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
+    a.pool = static_cast<bf16_t*>(pool); a.code = code;
+    a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 1;
+    AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+    const int rc = asr_conv3x3_ws128_launch(a, s);
+    if (rc != ASR_EUNSUPPORTED) return rc;
+  }
+  if (H % 16 != 0 || asr_tuning("IGEMM_TH", 16) != 16) return ASR_EUNSUPPORTED;
   ConvArgs p{};
   p.x = x; p.wk = wk; p.bias = bias; p.pool = pool; p.code = code;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 1;

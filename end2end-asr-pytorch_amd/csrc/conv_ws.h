@@ -1,0 +1,19 @@
+// Internal interface between conv.hip (asr_conv3x3_igemm / asr_conv3x3_relu_pool_tcf_code dispatch) and conv_ws.hip (persistent,
+// weight-stationary bf16 kernel for the 128-input-channel layers of vgg_cnn's second level).
+#pragma once
+#include "common.h"
+
+struct WsArgs {
+  const bf16_t* x;      // (B, H, W, 128) NHWC
+  const bf16_t* wk;     // (Cout, 9 taps, 128 ci) packed weights (asr_conv_pack_weight)
+  const float* bias;    // (Cout) or null
+  const bf16_t* mask;   // (B, H, W, Cout) or null: output zeroed where mask <= 0 (ReLU mask of the consumer's input, dgrad)
+  bf16_t* y;            // (B, H, W, Cout); unused by the pooled form
+  bf16_t* pool;         // pooled form: (B, W/2, Cout, H/2) = the encoder layout (B, T', C F') of max-pool(ReLU(conv))
+  uint8_t* code;        // pooled form: one selection byte per pooled element, same layout
+  int B, H, W, Cout, relu;
+  int tiles_h, tiles_w, ntiles;   // filled by the launcher
+};
+
+// ASR_EUNSUPPORTED when the shape is outside the kernel's domain (the caller falls back to the generic implicit GEMM)
+int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s);

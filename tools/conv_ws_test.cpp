@@ -1,0 +1,191 @@
+// Development harness for csrc/conv_ws.hip (no torch: starts in a second on a fresh GPU box).  Through the C ABI of libasr_hip.so:
+//   * parity: the weight-stationary kernel (tuning WS128 = 1) against the generic implicit GEMM it replaces (WS128 = 0) AND against a
+//     host loop, on exact-integer data (every partial sum is an integer below 2^24, so any summation order gives the same fp32 value
+//     and the comparison is bit for bit), odd sizes, masks, both Cout, pooled form;
+//   * timing at the benchmark shapes (B = 32, 80 x 400), both kernels, prefetch depth 1 / 2.
+// Build:  hipcc -O2 tools/conv_ws_test.cpp -o tools/bin/conv_ws_test -Iinclude -Lend2end-asr-pytorch_amd/asr_hip -lasr_hip \
+//               -Wl,-rpath,'$ORIGIN/../../end2end-asr-pytorch_amd/asr_hip'
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "asr_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+#define AK(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "asr error %d (%s) at %s:%d\n", r_, asr_strerror(r_), __FILE__, __LINE__); exit(3); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); }       // exact for the small integers used here
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2bf_rne(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static uint32_t rng_state = 12345u;
+static uint32_t rnd() { rng_state = rng_state * 1664525u + 1013904223u; return rng_state >> 8; }
+static int rint_(int lo, int hi) { return lo + (int)(rnd() % (uint32_t)(hi - lo + 1)); }
+
+template <typename T> struct Dev {
+  T* p = nullptr; size_t n = 0;
+  explicit Dev(size_t n_) : n(n_) { CK(hipMalloc(&p, (n ? n : 1) * sizeof(T))); }
+  ~Dev() { (void)hipFree(p); }
+  void up(const std::vector<T>& h) { CK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice)); }
+  std::vector<T> down() const { std::vector<T> h(n); CK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
+};
+
+struct Case { int B, H, W, Cout; bool mask, relu, pooled; };
+
+static int run_case(const Case& c, bool host_check) {
+  const int Cin = 128;
+  const size_t npx = (size_t)c.B * c.H * c.W;
+  std::vector<uint16_t> x(npx * Cin), wk((size_t)c.Cout * 9 * Cin), mk(npx * c.Cout);
+  std::vector<float> bias(c.Cout);
+  for (auto& v : x) v = f2bf((float)rint_(-3, 3));
+  for (auto& v : wk) v = f2bf((float)rint_(-2, 2));
+  for (auto& v : mk) v = f2bf((float)rint_(-1, 1));
+  for (auto& v : bias) v = (float)rint_(-8, 8) * 0.5f;
+  Dev<uint16_t> dx(x.size()), dw(wk.size()), dm(mk.size());
+  Dev<float> db(bias.size());
+  dx.up(x); dw.up(wk); dm.up(mk); db.up(bias);
+  const size_t nout = c.pooled ? (size_t)c.B * (c.W / 2) * c.Cout * (c.H / 2) : npx * c.Cout;
+  std::vector<std::vector<uint16_t>> ys;
+  std::vector<std::vector<uint8_t>> cds;
+  for (int ws = 0; ws < 2; ++ws) {
+    AK(asr_set_tuning("WS128", ws));
+    Dev<uint16_t> dy(nout);
+    Dev<uint8_t> dc(c.pooled ? nout : 1);
+    CK(hipMemset(dy.p, 0xff, nout * 2));
+    if (c.pooled) {
+      const int rc = asr_conv3x3_relu_pool_tcf_code(dx.p, dw.p, db.p, dy.p, dc.p, c.B, c.H, c.W, Cin, c.Cout, ASR_BF16, nullptr);
+      if (rc == ASR_EUNSUPPORTED && ws == 0) { ys.push_back({}); cds.push_back({}); continue; }   // the old kernel needs H % 16 == 0
+      AK(rc);
+    } else {
+      AK(asr_conv3x3_igemm(dx.p, dw.p, db.p, c.mask ? dm.p : nullptr, dy.p, c.B, c.H, c.W, Cin, c.Cout, c.relu ? 1 : 0, ASR_BF16, nullptr));
+    }
+    CK(hipDeviceSynchronize());
+    ys.push_back(dy.down());
+    cds.push_back(c.pooled ? dc.down() : std::vector<uint8_t>());
+  }
+  AK(asr_clear_tuning("WS128"));
+  size_t bad = 0;
+  if (!ys[0].empty()) {
+    for (size_t i = 0; i < nout; ++i) bad += ys[0][i] != ys[1][i];
+    if (c.pooled) for (size_t i = 0; i < nout; ++i) bad += cds[0][i] != cds[1][i];
+  }
+  size_t bad_host = 0;
+  if (host_check) {
+    std::vector<float> y(npx * c.Cout);
+    for (int b = 0; b < c.B; ++b)
+      for (int h = 0; h < c.H; ++h)
+        for (int w = 0; w < c.W; ++w)
+          for (int co = 0; co < c.Cout; ++co) {
+            float s = bias[co];
+            for (int ky = 0; ky < 3; ++ky)
+              for (int kx = 0; kx < 3; ++kx) {
+                const int yy = h + ky - 1, xx = w + kx - 1;
+                if (yy < 0 || yy >= c.H || xx < 0 || xx >= c.W) continue;
+                const uint16_t* xp = &x[(((size_t)b * c.H + yy) * c.W + xx) * Cin];
+                const uint16_t* wp = &wk[((size_t)co * 9 + ky * 3 + kx) * Cin];
+                for (int ci = 0; ci < Cin; ++ci) s += bf2f(xp[ci]) * bf2f(wp[ci]);
+              }
+            if (c.relu || c.pooled) s = s > 0.f ? s : 0.f;
+            const size_t o = (((size_t)b * c.H + h) * c.W + w) * c.Cout + co;
+            if (c.mask && !(bf2f(mk[o]) > 0.f)) s = 0.f;
+            y[o] = bf2f(f2bf_rne(s));
+          }
+    if (!c.pooled) {
+      for (size_t i = 0; i < nout; ++i) bad_host += f2bf(y[i]) != ys[1][i];
+    } else {
+      const int H2 = c.H / 2, W2 = c.W / 2;
+      for (int b = 0; b < c.B; ++b)
+        for (int ow = 0; ow < W2; ++ow)
+          for (int co = 0; co < c.Cout; ++co)
+            for (int oh = 0; oh < H2; ++oh) {
+              float m = -1.f; int arg = 0;
+              for (int k = 0; k < 4; ++k) {
+                const float v = y[(((size_t)b * c.H + 2 * oh + (k >> 1)) * c.W + 2 * ow + (k & 1)) * c.Cout + co];
+                if (v > m) { m = v; arg = k; }
+              }
+              const size_t o = (((size_t)b * W2 + ow) * c.Cout + co) * H2 + oh;
+              bad_host += f2bf(m) != ys[1][o];
+              bad_host += (uint8_t)(m > 0.f ? 1 + arg : 0) != cds[1][o];
+            }
+    }
+  }
+  printf("  case B=%d H=%d W=%d Cout=%d mask=%d relu=%d pooled=%d : %zu mismatches vs generic kernel%s, %zu vs host%s\n", c.B, c.H, c.W, c.Cout,
+         (int)c.mask, (int)c.relu, (int)c.pooled, bad, ys[0].empty() ? " (n/a)" : "", bad_host, host_check ? "" : " (skipped)");
+  return (int)(bad + bad_host != 0);
+}
+
+static void time_case(const Case& c) {
+  const int Cin = 128;
+  const size_t npx = (size_t)c.B * c.H * c.W;
+  std::vector<uint16_t> x(npx * Cin), wk((size_t)c.Cout * 9 * Cin);
+  for (auto& v : x) v = f2bf_rne((float)((int)(rnd() % 2001) - 1000) * 1e-3f);
+  for (auto& v : wk) v = f2bf_rne((float)((int)(rnd() % 2001) - 1000) * 3e-5f);
+  std::vector<float> bias(c.Cout, 0.01f);
+  Dev<uint16_t> dx(x.size()), dw(wk.size()), dm(npx * c.Cout), dy(npx * c.Cout);
+  Dev<uint8_t> dc(npx * c.Cout / 4);
+  Dev<float> db(bias.size());
+  dx.up(x); dw.up(wk); db.up(bias);
+  CK(hipMemcpy(dm.p, dx.p, (c.Cout <= Cin ? npx * c.Cout : npx * Cin) * 2, hipMemcpyDeviceToDevice));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const double fl = 2.0 * 9 * Cin * c.Cout * (double)npx;
+  for (int ws = 0; ws < 2; ++ws)
+    for (int pd = 1; pd <= (ws ? 2 : 1); ++pd) {
+      AK(asr_set_tuning("WS128", ws));
+      AK(asr_set_tuning("WS_PD", pd));
+      auto go = [&]() {
+        if (c.pooled) AK(asr_conv3x3_relu_pool_tcf_code(dx.p, dw.p, db.p, dy.p, dc.p, c.B, c.H, c.W, Cin, c.Cout, ASR_BF16, nullptr));
+        else AK(asr_conv3x3_igemm(dx.p, dw.p, db.p, c.mask ? dm.p : nullptr, dy.p, c.B, c.H, c.W, Cin, c.Cout, c.relu ? 1 : 0, ASR_BF16, nullptr));
+      };
+      for (int i = 0; i < 3; ++i) go();
+      CK(hipDeviceSynchronize());
+      const int iters = 20;
+      CK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < iters; ++i) go();
+      CK(hipEventRecord(e1, nullptr));
+      CK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      const double us = ms * 1e3 / iters;
+      printf("  time B=%d %dx%d 128->%d mask=%d pooled=%d  %-22s %8.1f us  %7.1f TF/s (%4.1f%% of 2.5 PF)\n", c.B, c.H, c.W, c.Cout, (int)c.mask,
+             (int)c.pooled, ws ? (pd == 2 ? "weight-stationary pd=2" : "weight-stationary pd=1") : "generic igemm", us, fl / us / 1e6, fl / us / 25e6);
+    }
+  AK(asr_clear_tuning("WS128"));
+  AK(asr_clear_tuning("WS_PD"));
+}
+
+int main(int argc, char** argv) {
+  const bool timing = argc < 2 || strcmp(argv[1], "parity") != 0;
+  const bool parity = argc < 2 || strcmp(argv[1], "time") != 0;
+  int fails = 0;
+  if (parity) {
+    printf("== parity (exact-integer data)\n");
+    const Case cases[] = {
+        {1, 8, 16, 128, false, true, false},  {2, 24, 48, 128, false, true, false}, {2, 19, 37, 128, true, false, false},
+        {1, 16, 32, 64, false, false, false}, {2, 21, 50, 64, true, false, false},  {3, 32, 64, 128, false, true, true},
+        {2, 24, 48, 128, false, true, true},  {1, 80, 400, 128, true, false, false}, {1, 80, 400, 64, false, false, false},
+        {1, 80, 400, 128, false, true, true},
+    };
+    for (size_t i = 0; i < sizeof(cases) / sizeof(cases[0]); ++i) fails += run_case(cases[i], (size_t)cases[i].B * cases[i].H * cases[i].W <= 40000);
+    // more workgroup-sized than the grid: persistence over many tiles, XCD walk, tail
+    fails += run_case({9, 80, 400, 128, true, false, false}, false);
+    fails += run_case({9, 80, 400, 128, false, true, true}, false);
+    fails += run_case({9, 80, 400, 64, false, false, false}, false);
+  }
+  if (timing) {
+    printf("== timing (B = 32, 80 x 400)\n");
+    time_case({32, 80, 400, 128, false, true, true});
+    time_case({32, 80, 400, 128, true, false, false});
+    time_case({32, 80, 400, 128, false, true, false});
+    time_case({32, 80, 400, 64, false, false, false});
+  }
+  printf(fails ? "FAILED (%d cases)\n" : "OK\n", fails);
+  return fails ? 1 : 0;
+}
