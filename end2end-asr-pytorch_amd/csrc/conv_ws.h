@@ -13,6 +13,7 @@ struct WsArgs {
   uint8_t* code;        // pooled form: one selection byte per pooled element, same layout
   int B, H, W, Cout, relu;
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
+  long long* dbg;                 // development only (tuning WS_DBG): per-section clock totals of workgroup 0
 };
 
 // ASR_EUNSUPPORTED when the shape is outside the kernel's domain (the caller falls back to the generic implicit GEMM)

@@ -157,8 +157,22 @@ static void time_case(const Case& c) {
       printf("  time B=%d %dx%d 128->%d mask=%d pooled=%d  %-22s %8.1f us  %7.1f TF/s (%4.1f%% of 2.5 PF)\n", c.B, c.H, c.W, c.Cout, (int)c.mask,
              (int)c.pooled, ws ? (pd == 2 ? "weight-stationary pd=2" : "weight-stationary pd=1") : "generic igemm", us, fl / us / 1e6, fl / us / 25e6);
     }
-  AK(asr_clear_tuning("WS128"));
   AK(asr_clear_tuning("WS_PD"));
+  if (c.Cout == 128 ? (c.pooled || c.mask) : !c.mask) {      // per-section clocks of workgroup 0 (timing instantiations exist for these forms)
+    Dev<long long> dbg(64);
+    CK(hipMemset(dbg.p, 0, 64 * 8));
+    AK(asr_set_tuning("WS128", 1));
+    AK(asr_set_tuning("WS_DBG", (int64_t)(uintptr_t)dbg.p));
+    if (c.pooled) AK(asr_conv3x3_relu_pool_tcf_code(dx.p, dw.p, db.p, dy.p, dc.p, c.B, c.H, c.W, Cin, c.Cout, ASR_BF16, nullptr));
+    else AK(asr_conv3x3_igemm(dx.p, dw.p, db.p, c.mask ? dm.p : nullptr, dy.p, c.B, c.H, c.W, Cin, c.Cout, c.relu ? 1 : 0, ASR_BF16, nullptr));
+    CK(hipDeviceSynchronize());
+    AK(asr_clear_tuning("WS_DBG"));
+    const std::vector<long long> h = dbg.down();
+    for (int w = 0; w < 4; ++w)
+      printf("    wave %d, %lld tiles, cycles per tile: barrier %lld  staging %lld  contraction %lld  dma wait %lld  epilogue %lld\n", w, h[w * 8 + 5],
+             h[w * 8 + 0] / h[w * 8 + 5], h[w * 8 + 1] / h[w * 8 + 5], h[w * 8 + 2] / h[w * 8 + 5], h[w * 8 + 3] / h[w * 8 + 5], h[w * 8 + 4] / h[w * 8 + 5]);
+  }
+  AK(asr_clear_tuning("WS128"));
 }
 
 int main(int argc, char** argv) {
