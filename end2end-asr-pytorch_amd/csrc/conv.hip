@@ -1302,12 +1302,12 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   }
   // 128 input channels in bf16 (conv.7's data gradient with conv.5's ReLU mask, conv.5's data gradient): the persistent
   // weight-stationary kernel of conv_ws.hip; WS128 = 0 (tuning) or a shape outside its domain -> the generic implicit GEMM
-  if (dtype == ASR_BF16 && Cin == 128 && !p.ablate && asr_tuning("WS128", 1) != 0) {
+  if (const int ws = (int)asr_tuning("WS128", 2); dtype == ASR_BF16 && Cin == 128 && !p.ablate && ws != 0) {
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
     a.mask = static_cast<const bf16_t*>(mask_src); a.y = static_cast<bf16_t*>(y);
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
-    const int rc = asr_conv3x3_ws128_launch(a, s);
+    const int rc = ws == 1 ? asr_conv3x3_ws128_launch(a, s) : asr_conv3x3_ws16_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;
   }
   if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
@@ -1360,17 +1360,19 @@ extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, con
                                               int W, int Cin, int Cout, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && wk && pool && code && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
-  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 8 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
+  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 4 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
       (((uintptr_t)code) & 7) != 0 || asr_tuning("CONV_POOL", 1) == 0)
     return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
-  if (Cin == 128 && asr_tuning("WS128", 1) != 0) {        // conv.7 forward: persistent weight-stationary kernel (conv_ws.hip)
+  // conv.7 forward: persistent weight-stationary kernels.  Default: the one-workgroup-per-CU form -- the two-workgroup form stages every
+  // patch once per half of the output channels and writes 4-byte runs (279 vs 309 us, profiles/r05_conv_ws_sections_ws16.txt)
+  if (const int ws = (int)asr_tuning("WS128", H % 8 == 0 ? 1 : 2); Cin == 128 && ws != 0) {
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
     a.pool = static_cast<bf16_t*>(pool); a.code = code;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 1;
     AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
-    const int rc = asr_conv3x3_ws128_launch(a, s);
+    const int rc = ws == 1 ? asr_conv3x3_ws128_launch(a, s) : asr_conv3x3_ws16_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;
   }
   if (H % 16 != 0 || asr_tuning("IGEMM_TH", 16) != 16) return ASR_EUNSUPPORTED;
