@@ -229,6 +229,19 @@ def respawn(a):
     os.execv(sys.executable, cmd)
 
 
+def rccl_version_line(path):
+    """The line RCCL wrote under NCCL_DEBUG=VERSION (rank 0's file), or None."""
+    if not path:
+        return None
+    try:
+        for l in open(path, errors="replace"):
+            if "version" in l.lower():
+                return l.strip()[:300]
+    except OSError:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -247,6 +260,9 @@ def main():
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype in which the gradient slices are "
                     "all-reduced (bf16 = half the bytes per xGMI link, summed in bf16 by the collective; asr_hip/ddp.py)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
+    ap.add_argument("--soak-seconds", type=float, default=5.0, help="UNTIMED replay of the same step for about this long after the timed "
+                    "region (reported under config.soak, excluded from `value`): gives an external GPU-busy sampler something to see -- "
+                    "the timed region of the default run is a quarter of a second.  0 = off")
     a = ap.parse_args()
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and a.gpus > 1:
@@ -273,9 +289,16 @@ def main():
         raise SystemExit("bench.py: %d rank(s) need %d GPU(s), %d visible" % (world, world, ndev))
     torch.cuda.set_device(local % ndev)
     backend = os.environ.get("ASR_DIST_BACKEND", "nccl")
+    rccl_log = None
     if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        if backend == "nccl" and "NCCL_DEBUG" not in os.environ:
+            # self-diagnosing first run on a real node: RCCL's own version line, into a per-process file (its C stdio would otherwise
+            # interleave with the ONE JSON line of the contract), quoted in config.collective_version_line below
+            os.environ["NCCL_DEBUG"] = "VERSION"
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/asr_rccl_%p.log")
+            rccl_log = os.environ["NCCL_DEBUG_FILE"].replace("%p", str(os.getpid()))
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     from asr_hip import lib as L
@@ -353,6 +376,22 @@ def main():
 
     dt, dt_local, loss = timed(a.steps)
     final_loss = gs.global_loss() if gs is not None else float(loss.item())
+    # every rank's own clock over the same region (the reported time is their maximum): a straggler shows up as a spread here
+    per_rank = [dt_local]
+    if world > 1:
+        tl_ = torch.tensor([dt_local], device="cuda", dtype=torch.float64)
+        allt = [torch.zeros_like(tl_) for _ in range(world)]
+        dist.all_gather(allt, tl_)
+        per_rank = [float(t.item()) for t in allt]
+
+    # Untimed soak: the same step for ~soak-seconds more (a step count derived from the all-reduced time, so every rank runs the
+    # same number of collectives).  NOT part of `value`.
+    soak = None
+    if a.soak_seconds > 0:
+        n_soak = max(1, int(a.soak_seconds / max(dt / a.steps, 1e-6)))
+        t_soak, _, _ = timed(n_soak)
+        soak = {"steps": n_soak, "seconds": t_soak, "ms_per_step": t_soak / n_soak * 1e3,
+                "note": "untimed repeat of the measured step after the timed region; excluded from value / ms_per_step"}
 
     # Exposed part of the gradient exchange: the same steps with the collectives switched off (ranks then drift apart -- this
     # runs after the timed region and nothing is measured afterwards that depends on the weights).
@@ -417,6 +456,10 @@ def main():
                                                  if dist.is_initialized() and dist.get_backend() == "nccl" else None),
                           "grad_wire": (a.grad_wire if (world > 1 or force_ddp) else None),
                           "rank0_ms_per_step": dt_local / a.steps * 1e3,
+                          "per_rank_ms_per_step": {"min": min(per_rank) / a.steps * 1e3, "max": max(per_rank) / a.steps * 1e3,
+                                                   "all": [t / a.steps * 1e3 for t in per_rank]},
+                          "collective_version_line": rccl_version_line(rccl_log),
+                          "soak": soak,
                           "step_tflops_whole_model": (value * mflop_per_frame * 1e6 / 1e12) if mflop_per_frame else None,
                           "frac_of_mfma_peak_whole_step": (value * mflop_per_frame * 1e6 / 1e12 / (peak * world)) if mflop_per_frame else None,
                           "final_loss": final_loss}}

@@ -633,7 +633,9 @@ def _window_dy(g, Cout, tag, dev):
     Kdp = ops._pad8(KW * Cout)
     lead = KW - 1
     tail = (Kdp + Cout - 1) // Cout + 1
-    D = ops.workspace(tag + "_d", (lead + R + tail, Cout), ops.compute_dtype(), dev)       # zero at creation; only output rows are ever written
+    # zero at creation; only output rows (j < OW of every group of Wg) are ever written -- so the row grid is part of the key: two batches
+    # with equal B * Wg but different (B, Wg, OW) put their gap rows in different places, and a stale dy in a gap row would be contracted
+    D = ops.workspace(tag + "_d", (lead + R + tail, Cout), ops.compute_dtype(), dev, geom=(B, OH, Wg, OW, lead))
     return D, D[lead:lead + R], (Wg, OW)
 
 
@@ -684,10 +686,22 @@ def _conv_window_bwd(D, A, w, b_grad, g, tag, need_dx):
 def _bn_stats(bn, y, M, C, training, ygrid=(0, 0)):
     """nn.BatchNorm2d statistics (eps / momentum of the module; unbiased running variance) -> (mean, rstd)."""
     if training:
-        track = bn.track_running_stats and bn.running_mean.dtype == torch.float32 and bn.num_batches_tracked.dtype == torch.int64
-        mom = (0.1 if bn.momentum is None else bn.momentum) if track else -1.0
-        return ops.bn_train_stats(y, M, C, bn.eps, mom, bn.running_mean if track else None, bn.running_var if track else None,
-                                  bn.num_batches_tracked if track else None, ygrid)
+        track = bn.track_running_stats and bn.running_mean is not None
+        # the kernel updates fp32 buffers with a fixed momentum in its own launch; anything else nn.BatchNorm2d allows -- buffers in
+        # another dtype (model.half() / .bfloat16()), momentum=None (cumulative average) -- is updated here through torch, never skipped
+        fused = track and bn.momentum is not None and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32 \
+            and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64
+        mean, rstd = ops.bn_train_stats(y, M, C, bn.eps, bn.momentum if fused else -1.0, bn.running_mean if fused else None,
+                                        bn.running_var if fused else None, bn.num_batches_tracked if fused else None, ygrid)
+        if track and not fused:
+            with torch.no_grad():
+                if bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                f = bn.momentum if bn.momentum is not None else 1.0 / float(max(int(bn.num_batches_tracked), 1))
+                var_unbiased = (1.0 / (rstd * rstd) - bn.eps) * (float(M) / float(max(M - 1, 1)))
+                bn.running_mean.mul_(1.0 - f).add_((f * mean).to(bn.running_mean.dtype))
+                bn.running_var.mul_(1.0 - f).add_((f * var_unbiased).to(bn.running_var.dtype))
+        return mean, rstd
     else:
         mean, var = bn.running_mean.float(), bn.running_var.float()
     return mean.contiguous(), torch.rsqrt(var + bn.eps).contiguous()

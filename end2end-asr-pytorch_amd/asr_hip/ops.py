@@ -318,9 +318,15 @@ def gemm_nn_tn(dy, w, x, dw, db=None, out=None, accumulate=False, relu_mask=None
 
 
 def reset_pending():
-    """Forget second stages that were never issued (a capture that raised half way): their workspaces are gone."""
+    """Forget everything deferred that was never issued -- a capture or a backward pass that raised half way: queued weight
+    gradients (their tensors belong to the failed batch), second stages (their workspaces are gone) and the armed flush flag (the
+    autograd engine drops its final callbacks on error).  Called by the graph capture's error path and by FusedAdam.zero_grad():
+    a new step never inherits a failed one's queue."""
+    del _wgrad_q[:]
+    _wgrad_stages[0] = 0
     del _tn_pending[:]
     del _ln_pending[:]
+    _backward_flush["armed"] = False
 
 
 def flush_tn_reduces():
@@ -1056,11 +1062,12 @@ def conv3x3_wgrad_nhwc(x, dy, dw, db=None):
 _ws = {}
 
 
-def workspace(tag, shape, dtype, device, zero=True):
+def workspace(tag, shape, dtype, device, zero=True, geom=None):
     """Persistent zero-initialised buffer: kernels rewrite the live region only, padding rows/columns stay zero.
     ONE grow-only allocation per tag (variable-length batches do not leak a buffer per shape): a request that fits is a view
-    of it, re-zeroed only when the shape differs from the previous request (the padding moves).  zero=False: scratch that its
-    user overwrites completely (never re-zeroed: three layers sharing one tag cost three 75 MB fills per step otherwise)."""
+    of it, re-zeroed only when the shape -- or `geom`, whatever else decides WHERE the live region lies inside an equal shape --
+    differs from the previous request (the padding moves).  zero=False: scratch that its user overwrites completely (never
+    re-zeroed: three layers sharing one tag cost three 75 MB fills per step otherwise)."""
     key = (tag, dtype, str(device))
     shape = tuple(int(x) for x in shape)
     n = 1
@@ -1068,12 +1075,12 @@ def workspace(tag, shape, dtype, device, zero=True):
         n *= x
     ent = _ws.get(key)
     if ent is None or ent[0].numel() < n:
-        ent = [torch.zeros(n, device=device, dtype=dtype), shape]
+        ent = [torch.zeros(n, device=device, dtype=dtype), (shape, geom)]
         _ws[key] = ent
-    elif ent[1] != shape:
+    elif ent[1] != (shape, geom):
         if zero:
             ent[0][:n].zero_()
-        ent[1] = shape
+        ent[1] = (shape, geom)
     return ent[0][:n].view(shape)
 
 

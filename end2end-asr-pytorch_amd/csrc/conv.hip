@@ -1302,12 +1302,12 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   }
   // 128 input channels in bf16 (conv.7's data gradient with conv.5's ReLU mask, conv.5's data gradient): the persistent
   // weight-stationary kernel of conv_ws.hip; WS128 = 0 (tuning) or a shape outside its domain -> the generic implicit GEMM
-  if (const int ws = (int)asr_tuning("WS128", 2); dtype == ASR_BF16 && Cin == 128 && !p.ablate && ws != 0) {
+  if (dtype == ASR_BF16 && Cin == 128 && !p.ablate && asr_tuning("WS128", 1) != 0) {
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
     a.mask = static_cast<const bf16_t*>(mask_src); a.y = static_cast<bf16_t*>(y);
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
-    const int rc = ws == 1 ? asr_conv3x3_ws128_launch(a, s) : asr_conv3x3_ws16_launch(a, s);
+    const int rc = asr_conv3x3_ws128_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;
   }
   if (dtype == ASR_F32) return Cout == 64 ? launch_igemm<float, 64>(p, s) : launch_igemm<float, 128>(p, s);
@@ -1360,19 +1360,17 @@ extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, con
                                               int W, int Cin, int Cout, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && wk && pool && code && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
-  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 4 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
+  if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 8 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
       (((uintptr_t)code) & 7) != 0 || asr_tuning("CONV_POOL", 1) == 0)
     return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
-  // conv.7 forward: persistent weight-stationary kernels.  Default: the one-workgroup-per-CU form -- the two-workgroup form stages every
-  // patch once per half of the output channels and writes 4-byte runs (279 vs 309 us, profiles/r05_conv_ws_sections_ws16.txt)
-  if (const int ws = (int)asr_tuning("WS128", H % 8 == 0 ? 1 : 2); Cin == 128 && ws != 0) {
+  if (Cin == 128 && H % 8 == 0 && asr_tuning("WS128", 1) != 0) {        // conv.7 forward: persistent weight-stationary kernel (conv_ws.hip)
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
     a.pool = static_cast<bf16_t*>(pool); a.code = code;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 1;
     AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
-    const int rc = ws == 1 ? asr_conv3x3_ws128_launch(a, s) : asr_conv3x3_ws16_launch(a, s);
+    const int rc = asr_conv3x3_ws128_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;
   }
   if (H % 16 != 0 || asr_tuning("IGEMM_TH", 16) != 16) return ASR_EUNSUPPORTED;
@@ -1500,9 +1498,9 @@ extern "C" int asr_maxpool_bwd_code(const uint8_t* code, const void* dy, void* d
   return ASR_OK;
 }
 
-namespace {
-// workgroups along the pixel axis (x) and dW blocks (y) of the NHWC weight-gradient launch
-void wgrad_grid(int B, int H, int W, int Cin, int Cout, int* wgx, int* blocks_y, int* patches_per_wg) {
+// workgroups along the pixel axis (x) and dW blocks (y) of the NHWC weight-gradient launch.  ONE definition (declared in
+// conv_wgrad_dma.h): conv_level0.hip writes partial blocks on this grid and asr_conv3x3_wgrad_reduce folds them on it.
+void asr_conv3x3_wgrad_grid(int B, int H, int W, int Cin, int Cout, int* wgx, int* blocks_y, int* patches_per_wg) {
   const int npatch = B * ((H + 7) / 8) * ((W + 15) / 16);
   *blocks_y = (Cout / 64) * (Cin / 64);
   int gx = 512 / *blocks_y;                         // ~2 workgroups per CU in flight
@@ -1512,12 +1510,11 @@ void wgrad_grid(int B, int H, int W, int Cin, int Cout, int* wgx, int* blocks_y,
   *patches_per_wg = ppw;
   *wgx = (npatch + ppw - 1) / ppw;
 }
-}  // namespace
 
 extern "C" int64_t asr_conv3x3_wgrad_workspace(int B, int H, int W, int Cin, int Cout) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin % 64 != 0 || Cout % 64 != 0) return 0;
   int wgx, by, ppw;
-  wgrad_grid(B, H, W, Cin, Cout, &wgx, &by, &ppw);
+  asr_conv3x3_wgrad_grid(B, H, W, Cin, Cout, &wgx, &by, &ppw);
   return (int64_t)wgx * by * 9 * 64 * 64;
 }
 
@@ -1543,7 +1540,7 @@ extern "C" int asr_conv3x3_wgrad_reduce(const float* workspace, float* dw, int B
   if (Cin % 64 != 0 || Cout % 64 != 0) return ASR_EUNSUPPORTED;
   if (B == 0) return ASR_OK;
   int wgx, blocks_y, ppw;
-  wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &ppw);
+  asr_conv3x3_wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &ppw);
   AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(9 * 64 * 64 / 256, (unsigned)blocks_y), dim3(256), 0, s, workspace, dw, wgx,
                      Cin / 64, Cin);
@@ -1566,7 +1563,7 @@ int conv3x3_wgrad_impl(const void* x, const void* dy, float* dw, float* db, floa
   const int ablate = (int)asr_tuning("WGRAD_ABLATE", 0);
   p.ablate = ablate;
   int wgx, blocks_y;
-  wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &p.patches_per_wg);
+  asr_conv3x3_wgrad_grid(B, H, W, Cin, Cout, &wgx, &blocks_y, &p.patches_per_wg);
   p.ws = (workspace && workspace_floats >= (int64_t)wgx * blocks_y * 9 * 64 * 64) ? workspace : nullptr;
   const int esz = dtype == ASR_F32 ? 4 : 2;
   const size_t lds = (size_t)(180 + 128) * (64 * esz + 16);

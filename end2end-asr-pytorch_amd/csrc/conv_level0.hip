@@ -23,6 +23,7 @@
 #include "common.h"
 #include "conv_c64_core.h"
 #include "conv_level0.h"
+#include "conv_wgrad_dma.h"
 
 #include <utility>
 
@@ -876,12 +877,9 @@ template <typename K> int l0_grant(K kernel, size_t lds) {
 bool l0_shape_ok(int B, int H, int W) {
   return B >= 0 && H >= 2 && W >= 2 && (int64_t)B * H * W * 128 < ((int64_t)1 << 32);
 }
-void l0_wgrad_grid(int B, int H, int W, int* wgx, int* ppw) {      // = wgrad_grid of conv.hip for one 64 x 64 block
-  const int npatch = B * ((H + 7) / 8) * ((W + 15) / 16);
-  int pp = (npatch + 511) / 512;
-  if (pp < 4) pp = 4;
-  *ppw = pp;
-  *wgx = (npatch + pp - 1) / pp;
+void l0_wgrad_grid(int B, int H, int W, int* wgx, int* ppw) {      // the grid conv.hip's reduce will fold (one 64 x 64 block)
+  int blocks_y = 0;
+  asr_conv3x3_wgrad_grid(B, H, W, 64, 64, wgx, &blocks_y, ppw);
 }
 
 }  // namespace
@@ -897,8 +895,15 @@ extern "C" int asr_vgg_level0_fwd(const float* src, const float* w0, const float
   a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t lds = 2 * L0_PB + 2 * L0_SS + L0_WM + 512;
   const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
-  const int rc = split ? l0_grant(vgg_level0_fwd_kernel<true>, lds) : l0_grant(vgg_level0_fwd_kernel<false>, lds);
-  if (rc != ASR_OK) return rc;
+  {
+    // The caller decides HERE whether the level runs on these kernels (EUNSUPPORTED -> the stored-activation launch chain): the two
+    // backward kernels need more LDS than this one, so their grants are part of the decision -- a backward pass cannot fall back.
+    const size_t lds_d = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16, lds_w = 2 * L0_STAGE + 2 * 1024 + 256 + 128;
+    const int r0 = split ? l0_grant(vgg_level0_fwd_kernel<true>, lds) : l0_grant(vgg_level0_fwd_kernel<false>, lds);
+    const int r1 = split ? l0_grant(vgg_level0_dgrad_kernel<true>, lds_d) : l0_grant(vgg_level0_dgrad_kernel<false>, lds_d);
+    const int r2 = split ? l0_grant(vgg_level0_wgrad_kernel<true>, lds_w) : l0_grant(vgg_level0_wgrad_kernel<false>, lds_w);
+    if (r0 != ASR_OK || r1 != ASR_OK || r2 != ASR_OK) return ASR_EUNSUPPORTED;
+  }
   const int64_t slots = (int64_t)l0_cus() * 2;
   const unsigned grid = (unsigned)(a.ntiles < slots ? a.ntiles : slots);
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);

@@ -12,3 +12,6 @@ struct WgdArgs {
 };
 
 int asr_conv3x3_wgrad_dma_launch(const WgdArgs& p, unsigned wgx, unsigned blocks_y, hipStream_t s);
+
+// the grid of the weight-gradient launch and of its partial-block workspace (conv.hip); also used by conv_level0.hip
+void asr_conv3x3_wgrad_grid(int B, int H, int W, int Cin, int Cout, int* wgx, int* blocks_y, int* patches_per_wg);

@@ -17,5 +17,4 @@ struct WsArgs {
 };
 
 // ASR_EUNSUPPORTED when the shape is outside the kernel's domain (the caller falls back to the generic implicit GEMM)
-int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s);      // conv_ws.hip: one workgroup per CU, 32 channels per wave
-int asr_conv3x3_ws16_launch(const WsArgs& a, hipStream_t s);       // conv_ws16.hip: two workgroups per CU, 16 channels per wave
+int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s);

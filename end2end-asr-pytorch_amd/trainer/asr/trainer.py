@@ -55,11 +55,16 @@ class _Pending:
         buf = _Pending._pool.get(key)
         if buf is None:
             buf = _Pending._pool[key] = (torch.empty((2,) + tuple(gold_seq.shape), dtype=torch.int64).pin_memory(),
-                                         torch.empty(1, dtype=torch.float32).pin_memory())
-        self.ids, self.loss = buf
+                                         torch.empty(1, dtype=torch.float32).pin_memory(), torch.zeros(1, dtype=torch.int64).pin_memory())
+        self.ids, self.loss, self.skip = buf
         self.ids[0].copy_(gold_seq, non_blocking=True)
         self.ids[1].copy_(hyp_seq, non_blocking=True)
         self.loss.copy_(loss.detach().reshape(1).float(), non_blocking=True)
+        if graph_opt is not None:
+            # the DEVICE's decision travels with the loss (same stream, same event): its guard also cancels a step whose gradient scale
+            # is not finite while the loss is (asr_adam_noam_step), which the host could not re-derive from the loss value alone
+            from asr_hip import ops
+            self.skip.copy_(ops.step_state(loss.device)[2:3], non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
         self.id2label = id2label
@@ -67,13 +72,18 @@ class _Pending:
     def result(self):
         self.event.synchronize()
         loss_value = float(self.loss[0])
-        if loss_value != loss_value or loss_value in (float("inf"), float("-inf")):
+        bad_loss = loss_value != loss_value or loss_value in (float("inf"), float("-inf"))
+        if self.graph_opt is not None and int(self.skip[0]) != 0:
+            # the replayed step cancelled itself on the device (non-finite loss or gradient scale): the host mirror of the step count,
+            # the rate and Adam's 'step' fields follow the device, whatever the loss value says
+            from asr_hip.graph import GraphedTrainStep
+            GraphedTrainStep.step_skipped(self.graph_opt)
+            if not bad_loss:
+                logging.info("The replayed step skipped its update (non-finite gradient scale); weights and moments untouched")
+        if bad_loss:
             # reference trainer.py:102-104 skips such a batch; a replayed step cannot branch on the host, so the device-side optimiser
             # step cancelled itself (asr_adam_noam_step guard) and the batch is left out of the running loss here
             logging.info("Found infinity loss, masking (the replayed step left weights and moments untouched)")
-            if self.graph_opt is not None:
-                from asr_hip.graph import GraphedTrainStep
-                GraphedTrainStep.step_skipped(self.graph_opt)
             return None
         return (loss_value,) + Trainer._text_metrics(self.ids.tolist(), self.id2label)
 

@@ -259,3 +259,41 @@ def test_logit_handover_keeps_a_second_consumers_gradient(golden_dir):
     with torch.no_grad():
         model(src, src_len, tgt)
     assert F_._logit_handover[0] is None
+
+
+def test_a_failed_backward_leaves_nothing_behind(golden_dir):
+    """the eager loop defers weight gradients / LayerNorm folds to the end of the backward pass; a pass that RAISES
+    never reaches that point (the autograd engine drops its final callbacks).  The next step -- zero_grad(), forward, backward --
+    must produce the gradients of a clean step: nothing of the failed batch may be contracted into the zeroed buffer, and the
+    flush must be armed again."""
+    from asr_hip import ops
+    z, args, model, opt = build(golden_dir, "raw_tiny", "bf16")
+    sm = float(z["smoothing"])
+    step(model, opt, z, sm)
+    clean = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    from utils.metrics import calculate_metrics
+    src = torch.from_numpy(z["src"]).cuda()
+    tgt = torch.from_numpy(z["tgt"]).cuda()
+    src_len = torch.from_numpy(z["src_len"])
+    opt.zero_grad()
+    pred, gold, hyp, _ = model(src * 3.0, src_len, tgt)          # a different batch, so that stale entries would be visible
+    loss, _ = calculate_metrics(pred, gold, smoothing=sm, loss_type="ce")
+
+    class Boom(RuntimeError):
+        pass
+
+    def bomb(grad):
+        raise Boom("injected")
+    # half way through backward: the decoder's layers have queued their weight gradients, the encoder's have not run yet
+    enc_hook = model.encoder.layers[-1].register_full_backward_hook(lambda m, gi, go: bomb(None))
+    with pytest.raises(Boom):
+        loss.backward()
+    enc_hook.remove()
+    assert len(ops._wgrad_q) > 0 or ops._backward_flush["armed"], "the injected failure was expected to leave deferred work behind"
+
+    step(model, opt, z, sm)
+    assert not ops._wgrad_q and not ops._ln_pending and not ops._tn_pending and not ops._backward_flush["armed"]
+    for k, p in model.named_parameters():
+        if k in clean:
+            torch.testing.assert_close(p.grad, clean[k], rtol=0, atol=0, msg=lambda m, k=k: "%s: %s" % (k, m))

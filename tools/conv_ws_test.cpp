@@ -52,9 +52,9 @@ static int run_case(const Case& c, bool host_check) {
   Dev<float> db(bias.size());
   dx.up(x); dw.up(wk); dm.up(mk); db.up(bias);
   const size_t nout = c.pooled ? (size_t)c.B * (c.W / 2) * c.Cout * (c.H / 2) : npx * c.Cout;
-  std::vector<std::vector<uint16_t>> ys(3);       // WS128 = 0 generic implicit GEMM, 1 conv_ws.hip, 2 conv_ws16.hip; empty = shape unsupported
-  std::vector<std::vector<uint8_t>> cds(3);
-  for (int ws = 0; ws < 3; ++ws) {
+  std::vector<std::vector<uint16_t>> ys(2);       // WS128 = 0 generic implicit GEMM, 1 conv_ws.hip; empty = shape unsupported
+  std::vector<std::vector<uint8_t>> cds(2);
+  for (int ws = 0; ws < 2; ++ws) {
     AK(asr_set_tuning("WS128", ws));
     Dev<uint16_t> dy(nout);
     Dev<uint8_t> dc(c.pooled ? nout : 1);
@@ -74,7 +74,7 @@ static int run_case(const Case& c, bool host_check) {
   AK(asr_clear_tuning("WS128"));
   size_t bad = 0;
   if (!ys[0].empty())
-    for (int k = 1; k < 3; ++k) {
+    for (int k = 1; k < 2; ++k) {
       if (ys[k].empty()) continue;
       for (size_t i = 0; i < nout; ++i) bad += ys[0][i] != ys[k][i];
       if (c.pooled) for (size_t i = 0; i < nout; ++i) bad += cds[0][i] != cds[k][i];
@@ -101,7 +101,7 @@ static int run_case(const Case& c, bool host_check) {
             y[o] = bf2f(f2bf_rne(s));
           }
     if (!c.pooled) {
-      for (int k = 1; k < 3; ++k)
+      for (int k = 1; k < 2; ++k)
         if (!ys[k].empty()) for (size_t i = 0; i < nout; ++i) bad_host += f2bf(y[i]) != ys[k][i];
     } else {
       const int H2 = c.H / 2, W2 = c.W / 2;
@@ -115,7 +115,7 @@ static int run_case(const Case& c, bool host_check) {
                 if (v > m) { m = v; arg = k; }
               }
               const size_t o = (((size_t)b * W2 + ow) * c.Cout + co) * H2 + oh;
-              for (int k = 1; k < 3; ++k)
+              for (int k = 1; k < 2; ++k)
                 if (!ys[k].empty()) bad_host += (f2bf(m) != ys[k][o]) + ((uint8_t)(m > 0.f ? 1 + arg : 0) != cds[k][o]);
             }
     }
@@ -140,7 +140,7 @@ static void time_case(const Case& c) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double fl = 2.0 * 9 * Cin * c.Cout * (double)npx;
-  for (int ws = 0; ws < 3; ++ws)
+  for (int ws = 0; ws < 2; ++ws)
     for (int pd = 2; pd <= 2; ++pd) {
       AK(asr_set_tuning("WS128", ws));
       AK(asr_set_tuning("WS_PD", pd));
@@ -162,7 +162,7 @@ static void time_case(const Case& c) {
              (int)c.pooled, ws == 2 ? "ws16 (2 WG/CU, 16 co/wave)" : ws == 1 ? "ws128 (1 WG/CU, 32 co/wave)" : "generic igemm", us, fl / us / 1e6, fl / us / 25e6);
     }
   AK(asr_clear_tuning("WS_PD"));
-  for (int ws = 1; ws < 3; ++ws) {
+  for (int ws = 1; ws < 2; ++ws) {
     if (ws == 1 && !(c.Cout == 128 ? (c.pooled || c.mask) : !c.mask)) continue;      // (timing instantiations of conv_ws.hip exist for these forms)
     Dev<long long> dbg(64);
     CK(hipMemset(dbg.p, 0, 64 * 8));
@@ -189,7 +189,7 @@ int main(int argc, char** argv) {
     const Case cases[] = {
         {1, 8, 16, 128, false, true, false},  {2, 24, 48, 128, false, true, false}, {2, 19, 37, 128, true, false, false},
         {1, 16, 32, 64, false, false, false}, {2, 21, 50, 64, true, false, false},  {3, 32, 64, 128, false, true, true},
-        {2, 24, 48, 128, false, true, true},  {2, 12, 48, 128, false, true, true}, {1, 80, 400, 128, true, false, false}, {1, 80, 400, 64, false, false, false},
+        {2, 24, 48, 128, false, true, true},  {1, 80, 400, 128, true, false, false}, {1, 80, 400, 64, false, false, false},
         {1, 80, 400, 128, false, true, true},
     };
     for (size_t i = 0; i < sizeof(cases) / sizeof(cases[0]); ++i) fails += run_case(cases[i], (size_t)cases[i].B * cases[i].H * cases[i].W <= 40000);
