@@ -278,8 +278,18 @@ def test_benched_conv_path_agrees_with_the_tapped_launch_chain(golden_dir):
     _report["cfg1_b32/bf16/tap_off_vs_tap_on"] = {"logit_max_abs_diff": perr, "logit_abs_max": amax, "loss_diff": abs(l1 - l0),
                                                    "grad_rel_l2_worst": rel[worst], "grad_rel_l2_worst_name": worst,
                                                    "grad_rel_l2_median": float(np.median(list(rel.values()))),
+                                                   "grad_rel_l2_conv": {k: rel[k] for k in rel if k.startswith("conv.")},
                                                    "grad_rel_l2": {k: rel[k] for k in sorted(rel, key=lambda k: -rel[k])[:12]}}
     _dump()
+    # Bound per tensor = the SAME bound each run has against the fp64 truth, max(REL_BF16, 1.5 x PyTorch-autocast's own error on that tensor):
+    # tighter than the triangle inequality over the two runs would give.  Measured (profiles/r05_parity_baseline_shapes.json): logits
+    # 1.7e-2 of 1.82, loss 4e-5, gradients median 2.5e-2, worst 8.9e-2 on a decoder self-attention query weight whose autocast floor is
+    # 0.1 -- a last-bit difference in the conv features is amplified by every bf16 rounding behind it, exactly like a change of seed.
+    floor = {k: float(z["ebf/" + k]) for k in rel}
+    bound = {k: max(REL_BF16, 1.5 * floor[k]) for k in rel}
+    worst_b = max(rel, key=lambda k: rel[k] / bound[k])
     assert perr <= 1.5e-2 * amax, (perr, amax)
     assert abs(l1 - l0) < 2e-3, (l1, l0)
-    assert rel[worst] <= 2e-2, (worst, rel[worst])
+    assert rel[worst_b] <= bound[worst_b], (worst_b, rel[worst_b], bound[worst_b])
+    # (the front end's own gradients differ by 2.1 - 3.5e-2: they inherit the difference of the gradient that ARRIVES from the encoder;
+    #  the chains themselves are tied bit for bit on exact-integer inputs by tests/test_gpu_level0.py and tools/conv_ws_test.cpp)
