@@ -434,7 +434,8 @@ def main():
         value = frames / dt
         peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         mode = "eager" if a.eager else ("hipGraph replay" if red is None or not red.active else
-                                        "4 hipGraphs per step, RCCL all-reduces between them")
+                                        ("ONE hipGraph per step with the RCCL all-reduces captured inside (ASR_DDP_ONE_GRAPH=1)"
+                                         if getattr(gs, "_one", False) else "4 hipGraphs per step, RCCL all-reduces between them"))
         out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic", "launch_mode": mode,

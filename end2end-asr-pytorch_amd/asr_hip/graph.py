@@ -24,6 +24,8 @@ slices right to left except for the conv slice, which comes last:
 The graphs share one memory pool (activations saved by A1 are read by A2 and B) and are always replayed in this order.
 Shapes are static per instance: one GraphedTrainStep per (B, T_src, L_tgt) bucket.
 """
+import os
+
 import torch
 
 from . import ops
@@ -70,6 +72,8 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.loss, self.sums = self._body_single()
             self.graphs = [self.graph]
+        elif self._capture_one_graph():
+            pass
         else:
             self.graph_a, self.graph_a2, self.graph_b, self.graph_c = (torch.cuda.CUDAGraph() for _ in range(4))
             with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
@@ -86,6 +90,27 @@ class GraphedTrainStep:
         if replay_after_capture:
             self._host_after()                           # capture does not execute; replay below does
             self._replay()
+
+    def _capture_one_graph(self):
+        """Data parallel, ASR_DDP_ONE_GRAPH=1 (experiment, VERDICT r4 #7a): the three all-reduces captured INSIDE one hipGraph with
+        the four bodies (RCCL collectives are capturable; the work handles' waits become graph edges), so that a replay is one launch
+        on the host again instead of four graph launches + three collectives.  Falls back to the four-graph form when the capture
+        raises.  Measured on one rank over nccl: profiles/r05_ddp_one_graph.txt."""
+        self._one = False
+        if os.environ.get("ASR_DDP_ONE_GRAPH", "0") != "1":
+            return False
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.loss, self.sums = self._eager_step()
+        except Exception as e:               # noqa: BLE001 -- any capture failure: the proven form below
+            import logging
+            logging.warning("one-graph data-parallel capture failed (%r): four graphs with the collectives between them", e)
+            ops.reset_pending()
+            torch.cuda.synchronize()
+            return False
+        self.graph, self.graphs, self._one = g, [g], True
+        return True
 
     # ------------------------------------------------------------------------------------------------ single GPU
     def _body_single(self):
@@ -187,7 +212,7 @@ class GraphedTrainStep:
         return loss, sums
 
     def _replay(self):
-        if self.red is None:
+        if self.red is None or getattr(self, "_one", False):
             self.graph.replay()
             return
         self.graph_a.replay()

@@ -1,6 +1,8 @@
 """The captured whole-step hipGraph must be the same training step as the eager launch sequence: same losses, same
 weights after N steps (dropout off), a learning rate computed on the device that equals Noam's host formula, and
 different dropout masks on every replay (dropout on)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -172,3 +174,32 @@ def test_trainer_graph_buckets_equal_eager_on_whole_buckets(golden_dir, monkeypa
     padded, _, o_p, trp = run(48)
     assert list(trp._graphs)[0][3] == 96 and o_p._step == 4
     assert all(r[0] == r[0] and abs(r[0]) < 1e3 for r in padded) and padded[-1][0] < padded[0][0]
+
+
+def test_collectives_captured_inside_one_graph_equal_the_plain_step():
+    """VERDICT r4 #7a: with ASR_DDP_ONE_GRAPH=1 the data-parallel step is ONE hipGraph with the three RCCL all-reduces captured inside
+    (instead of four graphs with host-issued collectives between them).  One rank over nccl (ASR_FORCE_DDP=1; an all-reduce over one
+    rank is the identity): the benchmark's loss after the same steps must equal the plain single-graph step's, and the launch mode
+    must say that the capture was used (no silent fallback to four graphs)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
+           "--soak-seconds", "0", "--no-exposure", "--batch", "8"]
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        env.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    plain = run({})
+    one = run({"ASR_FORCE_DDP": "1", "ASR_DDP_ONE_GRAPH": "1"})
+    four = run({"ASR_FORCE_DDP": "1"})
+    assert "ONE hipGraph" in one["launch_mode"], one["launch_mode"]
+    assert "4 hipGraphs" in four["launch_mode"], four["launch_mode"]
+    assert one["config"]["collective_backend"] == "nccl" and one["config"]["collective_library"].startswith("RCCL")
+    lp, lo, lf = plain["config"]["final_loss"], one["config"]["final_loss"], four["config"]["final_loss"]
+    assert abs(lp - lo) < 2e-3 and abs(lp - lf) < 2e-3, (lp, lo, lf)
