@@ -37,9 +37,9 @@ MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm
 LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0, "enc_layers": 12, "dec_layers": 6}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_F32_TFLOPS = 157.3
-TRAFFIC_FILE = os.path.join("profiles", "r04_roofline_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r05_roofline_traffic.json")
 # per-family kernel time of the REPLAYED step (tools/prof_families.py over a committed rocprofv3 trace of this command)
-REPLAYED_FAMILIES_FILE = os.path.join("profiles", "r04_replayed_families.json")
+REPLAYED_FAMILIES_FILE = os.path.join("profiles", "r05_replayed_families.json")
 
 
 # ------------------------------------------------------------------------------------------------ algorithmic work
@@ -96,7 +96,7 @@ def measured_traffic(a):
     WRITE_SIZE runs of this workload, gfx950 correction applied); None for any other batch / precision."""
     if a.batch != 32 or a.precision != "bf16":
         return None
-    for f in (TRAFFIC_FILE, os.path.join("profiles", "r03_roofline_traffic.json")):
+    for f in (TRAFFIC_FILE, os.path.join("profiles", "r04_roofline_traffic.json")):
         try:
             with open(os.path.join(ROOT, f)) as fh:
                 d = json.load(fh)
@@ -503,17 +503,20 @@ def main():
                 n_launch = prof[key][1]
                 out["roofline"] = {"bound": "mfma", "kernel": "the front end's 3 forward + 3 data-gradient convolutions: vgg_level0_fwd / "
                                    "vgg_level0_dgrad (conv.2 with conv.0, the first pool and dW0 inside), conv3x3_c64_kernel (conv.5, two passes), "
-                                   "conv3x3_igemm_kernel (conv.7 and the two 128-channel data gradients): 45 % of the step's algorithmic FLOPs",
+                                   "conv3x3_ws128_kernel (conv.7 and the two 128-channel data gradients: the weight-stationary kernel of csrc/conv_ws.hip, round 5): 45 % of the step's algorithmic FLOPs",
                                    "achieved": f["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": f["frac"],
                                    "traffic": tr[0] if tr else None,
                                    "traffic_source": ("constant read from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                                       "command, committed; NOT measured by this run)" % tr[1]) if tr else None,
                                    "timing": "HIP events around every launch on its own stream during %d EAGER steps right after the "
                                              "timed (graph-replayed) region" % prof_steps,
-                                   "bound_per_launch": ({k: {"bound": v.get("bound"), "hbm_MB": round(v["hbm_bytes_per_launch"] / 1e6, 1),
-                                                             "algorithmic_gflop": v.get("algorithmic_gflop_per_launch"),
-                                                             "t_hbm_us_at_6.29TBs": v.get("t_hbm_us_at_6.29TBs"), "t_mfma_us_at_2.5PF": v.get("t_mfma_us_at_2.5PF")}
-                                                         for k, v in tr[2].items()} if tr and tr[2] else None),
+                                   "per_launch_vs_both_roofs": ({k: {"hbm_MB": round(v["hbm_bytes_per_launch"] / 1e6, 1),
+                                                                     "algorithmic_gflop": v.get("algorithmic_gflop_per_launch"),
+                                                                     "measured_us_replayed_step": v.get("measured_us_replayed_step"),
+                                                                     "achieved_TFLOPs": v.get("achieved_TFLOPs"), "achieved_HBM_TBs": v.get("achieved_HBM_TBs"),
+                                                                     "t_hbm_us_at_6.29TBs": v.get("t_hbm_us_at_6.29TBs"), "t_mfma_us_at_2.5PF": v.get("t_mfma_us_at_2.5PF"),
+                                                                     "x_of_mfma_bound": v.get("x_of_mfma_bound"), "x_of_hbm_bound": v.get("x_of_hbm_bound")}
+                                                                 for k, v in tr[2].items()} if tr and tr[2] else None),
                                    "scope_note": "since round 4 these six launches also carry conv.0's forward and weight gradient, both max-pools "
                                                  "and the first pool's backward (csrc/conv_level0.hip): in round 3 that work ran as five separate "
                                                  "HBM-bound launches (0.48 ms) outside this family.  On the same scope (replayed step, family + conv1 / "

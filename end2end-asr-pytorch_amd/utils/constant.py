@@ -61,7 +61,10 @@ _FLAGS = [
     (("--max-norm",), dict(default=400, type=_F)), (("--dropout",), dict(default=0.1, type=_F)),
     (("--parallel",), dict(action="store_true")), (("--shuffle",), dict(action="store_true")),
     # MI355X path (additions)
-    (("--precision",), dict(default="bf16", choices=["bf16", "fp32", "fp8"])),     # fp8: bf16 storage, fp8 MFMA for the --rank projections
+    # fp8: bf16 storage, fp8 (e4m3) MFMA for the forward --rank projections -- functional, SLOWER than bf16 (22.97 vs 12.55 ms per step
+    # of configs[4]: quantisation passes around K = 64 contractions); parity unpinned (no reference code for the low-rank variant)
+    (("--precision",), dict(default="bf16", choices=["bf16", "fp32", "fp8"],
+                            help="bf16 (default) | fp32 (parity mode) | fp8 (low-rank projections only; functional, slower than bf16)")),
     (("--dist-backend",), dict(default="nccl")), (("--bucket-mb",), dict(default=32.0, type=_F)),
     (("--grad-wire",), dict(default="fp32", choices=["fp32", "bf16"])),
     (("--gpu-frontend",), dict(action="store_true")),

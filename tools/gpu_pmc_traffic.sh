@@ -14,5 +14,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   echo "# rocprofv3 --pmc $ctr -- $cmd" >> $root/gpurun_out/${tag}_traffic_pmc.txt
   if [ -n "$db" ]; then python $root/tools/pmc_summary.py "$db" "conv3x3|vgg_level0" >> $root/gpurun_out/${tag}_traffic_pmc.txt 2>&1; else echo "no database" >> $root/gpurun_out/${tag}_traffic_pmc.txt; fi
 done
-python $root/tools/make_traffic_json.py $root/gpurun_out/${tag}_traffic_pmc.txt > $root/gpurun_out/${tag}_roofline_traffic.json
+python $root/tools/make_traffic_json.py $root/gpurun_out/${tag}_traffic_pmc.txt $root/gpurun_out/${tag}_replayed_families.json > $root/gpurun_out/${tag}_roofline_traffic.json
 cat $root/gpurun_out/${tag}_roofline_traffic.json | tail -5

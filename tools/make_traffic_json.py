@@ -22,12 +22,30 @@ def algorithmic_flop(name):
         return 2 * 9 * (64 * 64 + 64) * PX1
     if "conv3x3_c64_kernel" in name:
         return 2 * 9 * 64 * 64 * (PX1 if ", true>" in name or "true, 2" in name else PX2)      # pooled / masked forms = full resolution (ASR_LEVEL0=0)
-    if "igemm_kernel<unsigned short, 128" in name:
+    if "igemm_kernel<unsigned short, 128" in name or "ws128_kernel<128" in name:
         return 2 * 9 * 128 * 128 * PX2
+    if "ws128_kernel<64" in name:
+        return 2 * 9 * 128 * 64 * PX2
     if "igemm_kernel<unsigned short, 64" in name:
         return 2 * 9 * 128 * 64 * PX2
     return None
 CALLS_PER_STEP = 6
+_DUR = {}
+if len(sys.argv) > 2:
+    try:
+        _DUR = json.load(open(sys.argv[2])).get("conv_front_end_kernels_us", {})
+    except (OSError, ValueError):
+        _DUR = {}
+
+
+def duration_us(name):
+    key = re.sub(r"\(anonymous namespace\)::", "", name)
+    for k, v in _DUR.items():
+        if k[:60] == key[:60]:
+            return v["avg_us"]
+    return None
+
+
 txt = open(sys.argv[1]).read().splitlines()
 vals = {}
 name = None
@@ -46,7 +64,7 @@ out = {"workload": "configs[1] B=32 bf16", "kernel_family": "asr_conv3x3_igemm /
        "per_kernel": {}}
 tot = 0.0
 for nm, v in sorted(vals.items()):
-    if not re.search(r"conv3x3_c64_kernel|conv3x3_igemm_kernel|vgg_level0_fwd_kernel|vgg_level0_dgrad_kernel", nm) or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
+    if not re.search(r"conv3x3_c64_kernel|conv3x3_igemm_kernel|conv3x3_ws128_kernel|vgg_level0_fwd_kernel|vgg_level0_dgrad_kernel", nm) or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
     n, f = v["FETCH_SIZE"]
     w = v["WRITE_SIZE"][1]
@@ -57,7 +75,15 @@ for nm, v in sorted(vals.items()):
         e["algorithmic_gflop_per_launch"] = fl / 1e9
         e["t_mfma_us_at_2.5PF"] = fl / 2.5e15 * 1e6
         e["t_hbm_us_at_6.29TBs"] = b / 6.29e12 * 1e6
-        e["bound"] = "mfma" if e["t_mfma_us_at_2.5PF"] >= e["t_hbm_us_at_6.29TBs"] else "hbm"
+        # which roof is NEARER says little when a launch runs at 2x either of them: the measured duration of the
+        # launch in the replayed step (second argument: tools/prof_families.py's JSON) next to both lower bounds
+        us = duration_us(nm)
+        if us:
+            e["measured_us_replayed_step"] = us
+            e["achieved_TFLOPs"] = fl / us / 1e6
+            e["achieved_HBM_TBs"] = b / us / 1e6
+            e["x_of_mfma_bound"] = us / e["t_mfma_us_at_2.5PF"]
+            e["x_of_hbm_bound"] = us / e["t_hbm_us_at_6.29TBs"]
     out["per_kernel"][nm[:90]] = e
     tot += b * n / STEPS
 out["hbm_bytes_per_step"] = tot

@@ -11,7 +11,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = [
-    ("conv3x3_igemm (3 fwd + 3 dgrad)", r"conv3x3_igemm_kernel|conv3x3_c64_kernel|vgg_level0_fwd_kernel|vgg_level0_dgrad_kernel"),
+    ("conv3x3_igemm (3 fwd + 3 dgrad)", r"conv3x3_igemm_kernel|conv3x3_ws128_kernel|conv3x3_c64_kernel|vgg_level0_fwd_kernel|vgg_level0_dgrad_kernel"),
     ("conv3x3_wgrad", r"conv3x3_wgrad|wgrad_reduce_kernel|vgg_level0_wgrad_kernel"),
     ("conv1 + pooling (HBM-bound)", r"conv1_|pool_|vgg_level0_dw0_reduce"),
     ("linear GEMMs (fwd + dgrad + wgrad)", r"gemm_|tn_reduce|tn128_reduce"),

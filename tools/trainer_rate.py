@@ -20,8 +20,13 @@ from trainer.asr.trainer import Trainer              # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 B = 32
-args = constant.parse(Bn.MODEL_FLAGS + ["--dropout", "0.1", "--precision", "bf16", "--cuda", "--batch-size", str(B),
-                                        "--graph-buckets", os.environ.get("RATE_BUCKETS", "0")])
+_flags = Bn.MODEL_FLAGS + ["--dropout", "0.1", "--precision", "bf16", "--cuda", "--batch-size", str(B)]
+if "RATE_BUCKETS" in os.environ:                      # an explicit --graph-buckets N (0 = the eager loop)
+    _flags += ["--graph-buckets", os.environ["RATE_BUCKETS"]]
+args = constant.parse(_flags)
+import train as _train                               # noqa: E402
+_train.resolve_graph_buckets(args, constant.explicit)        # unset: what `python train.py --cuda ...` resolves to (round 5: 64 for vgg_cnn)
+print("# --graph-buckets resolved to %d (%s)" % (args.graph_buckets, "typed" if "RATE_BUCKETS" in os.environ else "train.py's default"))
 l2i, i2l = Bn.labels(Bn.V)
 model = init_transformer_model(args, l2i, i2l).cuda()
 opt = init_optimizer(args, model, "noam")
