@@ -332,7 +332,8 @@ int asr_conv_pack_weight_multi(int n, const float* const* w, void* const* wk, vo
                                int dtype, asr_stream_t stream);
 /* y = act(conv3x3_pad1(x; wk) + bias): relu=1 -> ReLU.  If mask_src != NULL: y *= (mask_src > 0) (dgrad through
  * the ReLU that produced this conv's input).  Cin, Cout multiples of 64, Cout <= 128.  bf16 64 -> 64 runs the persistent
- * register-resident-weights kernel of conv_c64.hip, everything else the generic implicit GEMM of conv.hip.        */
+ * register-resident-weights kernel of conv_c64.hip, bf16 with 128 input channels the weight-stationary kernel of
+ * conv_ws.hip (round 5), everything else the generic implicit GEMM of conv.hip.                                    */
 int asr_conv3x3_igemm(const void* x, const void* wk, const float* bias, const void* mask_src, void* y, int B,
                       int H, int W, int Cin, int Cout, int relu, int dtype, asr_stream_t stream);
 /* y = ReLU(conv3x3_pad1(x; wk) + bias) AND pool = 2x2/2 floor max-pool of y (B, H/2, W/2, Cout) from the same epilogue
@@ -377,7 +378,8 @@ int asr_vgg_level0_dgrad(const void* dpool, const uint8_t* code, const float* sr
 int asr_vgg_level0_wgrad(const float* src, const float* w0, const float* b0, const void* dpool, const uint8_t* code, float* dw2,
                          float* db2, float* workspace, int64_t workspace_floats, int B, int H, int W, asr_stream_t stream);
 /* conv.7 + ReLU + MaxPool2d + the (B, T', C F') view / transpose of transformer.py:50-52,74-76 from one epilogue: pool (B, W/2, Cout, H/2)
- * and its selection bytes (same layout); the un-pooled output is never stored.  bf16, Cout = 128, H and W multiples of 16.     */
+ * and its selection bytes (same layout); the un-pooled output is never stored.  bf16, Cout = 128, W a multiple of 16, H a multiple of
+ * 8 with 128 input channels (the weight-stationary kernel of csrc/conv_ws.hip, round 5), of 16 otherwise.                          */
 int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H, int W,
                                    int Cin, int Cout, int dtype, asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed

@@ -4,7 +4,7 @@
 tag=${1:-mfma}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-cmd="python bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline"
+cmd="python bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline --soak-seconds 0"
 : > $root/gpurun_out/${tag}_mfma_pmc.txt
 i=0
 for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES"; do
@@ -14,7 +14,7 @@ for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
   echo "# rocprofv3 --pmc $set -- $cmd" >> $root/gpurun_out/${tag}_mfma_pmc.txt
   if [ -n "$db" ]; then python $root/tools/pmc_summary.py "$db" >> $root/gpurun_out/${tag}_mfma_pmc.txt 2>&1; else echo "no database" >> $root/gpurun_out/${tag}_mfma_pmc.txt; fi
 done
-python - "$root/gpurun_out/${tag}_mfma_pmc.txt" <<'PY'
+python - "$root/gpurun_out/${tag}_mfma_pmc.txt" <<'PY' | tee -a "$root/gpurun_out/${tag}_mfma_pmc.txt"
 import re, sys
 cur = None; d = {}
 for line in open(sys.argv[1]):

@@ -4,7 +4,7 @@
 tag=${1:-pmc}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
-cmd="python bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline"
+cmd="python bench.py --steps 2 --warmup 1 --eager --no-cpu-baseline --no-roofline --soak-seconds 0"
 : > $root/gpurun_out/${tag}_traffic_pmc.txt
 for ctr in FETCH_SIZE WRITE_SIZE; do
   out=/tmp/pmc_${tag}_${ctr}

@@ -62,6 +62,9 @@ out = {"workload": "configs[1] B=32 bf16", "kernel_family": "asr_conv3x3_igemm /
                  "--no-cpu-baseline --no-roofline`; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (both counters in KB, FETCH_SIZE "
                  "under-reports 16-B/lane reads by 2x on gfx950); per step = sum over the family's kernels of bytes x launches / %d steps" % STEPS,
        "per_kernel": {}}
+# steps in the profiled run = launches of a once-per-step kernel, per counter (the two passes are separate runs)
+_once = [v for nm, v in vals.items() if "vgg_level0_fwd_kernel" in nm]
+STEPS_F = _once[0]["FETCH_SIZE"][0] if _once and "FETCH_SIZE" in _once[0] else STEPS
 tot = 0.0
 for nm, v in sorted(vals.items()):
     if not re.search(r"conv3x3_c64_kernel|conv3x3_igemm_kernel|conv3x3_ws128_kernel|vgg_level0_fwd_kernel|vgg_level0_dgrad_kernel", nm) or "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
@@ -69,7 +72,7 @@ for nm, v in sorted(vals.items()):
     n, f = v["FETCH_SIZE"]
     w = v["WRITE_SIZE"][1]
     b = (2 * f + w) * 1024
-    e = {"launches_per_step": n / STEPS, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "hbm_bytes_per_launch": b}
+    e = {"launches_per_step": n / STEPS_F, "FETCH_SIZE_KB_avg": f, "WRITE_SIZE_KB_avg": w, "hbm_bytes_per_launch": b}
     fl = algorithmic_flop(nm)
     if fl:
         e["algorithmic_gflop_per_launch"] = fl / 1e9
@@ -85,7 +88,7 @@ for nm, v in sorted(vals.items()):
             e["x_of_mfma_bound"] = us / e["t_mfma_us_at_2.5PF"]
             e["x_of_hbm_bound"] = us / e["t_hbm_us_at_6.29TBs"]
     out["per_kernel"][nm[:90]] = e
-    tot += b * n / STEPS
+    tot += b * n / STEPS_F
 out["hbm_bytes_per_step"] = tot
 out["traffic_bytes_per_launch_avg"] = tot / CALLS_PER_STEP if out["per_kernel"] else None
 print(json.dumps(out, indent=1))
