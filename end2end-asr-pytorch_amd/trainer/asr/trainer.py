@@ -94,11 +94,23 @@ class Trainer():
     def __init__(self):
         logging.info("Trainer is initialized")
 
+    @staticmethod
+    def _frames_after_cnn(T, feat):
+        """Encoder positions produced by T input frames (models/asr/transformer.py: vgg_cnn = two 2x2/2 max-pools behind same-padded
+        3x3 convolutions; emb_cnn = time kernel 11 / stride 2 / padding 10, then kernel 11 / stride 1 / no padding)."""
+        if feat == "vgg_cnn":
+            return (int(T) // 2) // 2
+        if feat == "emb_cnn":
+            return ((int(T) + 20 - 11) // 2 + 1) - 10
+        return int(T)
+
     def _graph_step(self, model, opt, src, src_lengths, tgt, smoothing):
         """--graph-buckets N: the training step as a captured hipGraph per (batch, padded frames) shape.  The batch is copied
         into the graph's static buffers -- time axis zero-padded to a multiple of N frames, targets PAD-padded to --tgt-max-len - 1
-        columns (Decoder.preprocess strips PAD, so the targets are unchanged; the extra zero frames are seen by the model exactly
-        like the collate function's own padding of shorter utterances -- for vgg_cnn.  With --feat_extractor emb_cnn the BatchNorm
+        columns (Decoder.preprocess strips PAD, so the targets are unchanged; the encoder positions the extra zero frames add are masked
+        through the lengths (clamped to the positions of the batch as collated), so attention sees the un-bucketed batch; what remains
+        is the convolutions' view of the last frames of the LONGEST utterance -- followed by zero frames instead of the image border,
+        exactly what the collate padding does to every shorter utterance -- for vgg_cnn.  With --feat_extractor emb_cnn the BatchNorm
         batch statistics are taken over padded positions as well (as they are over the collate padding in the reference), so bucket
         padding changes them: results are NOT identical to --graph-buckets 0 there) -- and the graph is replayed.  At most
         GRAPH_CACHE shapes stay captured (least recently used first out: a captured step owns its activations' memory pool).  The first batch of a new
@@ -128,6 +140,12 @@ class Trainer():
             del graphs[old]                       # frees that shape's graph, static buffers and memory pool
             logging.info("graph cache: dropped the captured step of shape %s", (old,))
         lens = torch.as_tensor(src_lengths).to(torch.int32)
+        if Tb > T:
+            # The model masks encoder position j by j < length with the PRE-CNN lengths (a reference quirk kept on purpose), so on the
+            # batch as collated every one of its T' positions below an utterance's length is attended.  The bucket padding adds
+            # positions T' .. T'_b - 1 that do not exist in the un-bucketed batch: clamping the lengths to T' masks exactly those
+            # (keys and rows), whatever the utterance -- attention sees the batch it would see with --graph-buckets 0.
+            lens = torch.clamp(lens, max=self._frames_after_cnn(T, getattr(a, "feat_extractor", "")))
         if gs is None:
             src_b = torch.zeros((B, C, F, Tb), device=src.device, dtype=src.dtype)
             src_b[..., :T].copy_(src)

@@ -174,6 +174,12 @@ def test_trainer_graph_buckets_equal_eager_on_whole_buckets(golden_dir, monkeypa
     padded, _, o_p, trp = run(48)
     assert list(trp._graphs)[0][3] == 96 and o_p._step == 4
     assert all(r[0] == r[0] and abs(r[0]) < 1e3 for r in padded) and padded[-1][0] < padded[0][0]
+    # round 5: the positions the bucket padding adds are masked through the (clamped) lengths, so the padded step differs from the
+    # step on the batch as collated only by the convolutions' view of the longest utterance's last frames: a small fraction of the loss
+    # (without the clamp every utterance longer than T' positions would also attend the added positions)
+    rel = [abs(p_[0] - e_[0]) / abs(e_[0]) for p_, e_ in zip(padded, eager)]
+    print("bucket-padded vs collated batch, relative loss difference per step:", rel)
+    assert max(rel) < 5e-3, rel               # measured 8e-4 ... 1e-3
 
 
 def test_collectives_captured_inside_one_graph_equal_the_plain_step():
