@@ -1285,6 +1285,16 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
     a.B = B; a.H = H; a.W = W; a.relu = relu;
     return asr_conv3x3_c64_launch(a, s);
   }
+  // 64 -> 128 channels without a mask (conv.5 forward) in ONE pass: the weight-stationary kernel of conv_ws.hip with 64 input channels
+  // (a wave keeps 32 of the 128 output channels x 9 x 64 in 144 registers, two workgroups per CU, 4-row tiles; round 5).  WS64 = 0
+  // (tuning): the two-pass form below
+  if (dtype == ASR_BF16 && Cin == 64 && Cout == 128 && !mask_src && !p.ablate && asr_tuning("WS64", 1) != 0) {
+    WsArgs a{};
+    a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias; a.y = static_cast<bf16_t*>(y);
+    a.B = B; a.H = H; a.W = W; a.Cin = 64; a.Cout = Cout; a.relu = relu;
+    const int rc = asr_conv3x3_ws128_launch(a, s);
+    if (rc != ASR_EUNSUPPORTED) return rc;
+  }
   // 64 -> 128 channels without a mask (conv.5 forward): the same kernel once per half of the output channels -- each half's 72 KB of
   // weights sits in registers, the 64-channel input is read twice (the second time from L2 / MALL); 0 = the generic implicit GEMM
   if (c64 && dtype == ASR_BF16 && Cin == 64 && Cout == 128 && !mask_src && (int64_t)B * H * W * 256 < ((int64_t)1 << 32) && !p.ablate &&
@@ -1306,7 +1316,7 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
     a.mask = static_cast<const bf16_t*>(mask_src); a.y = static_cast<bf16_t*>(y);
-    a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = relu;
+    a.B = B; a.H = H; a.W = W; a.Cin = 128; a.Cout = Cout; a.relu = relu;
     const int rc = asr_conv3x3_ws128_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;
   }
@@ -1368,7 +1378,7 @@ extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, con
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
     a.pool = static_cast<bf16_t*>(pool); a.code = code;
-    a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.relu = 1;
+    a.B = B; a.H = H; a.W = W; a.Cin = 128; a.Cout = Cout; a.relu = 1;
     AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
     const int rc = asr_conv3x3_ws128_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;

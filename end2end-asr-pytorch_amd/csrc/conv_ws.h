@@ -4,14 +4,14 @@
 #include "common.h"
 
 struct WsArgs {
-  const bf16_t* x;      // (B, H, W, 128) NHWC
-  const bf16_t* wk;     // (Cout, 9 taps, 128 ci) packed weights (asr_conv_pack_weight)
+  const bf16_t* x;      // (B, H, W, Cin) NHWC
+  const bf16_t* wk;     // (Cout, 9 taps, Cin) packed weights (asr_conv_pack_weight)
   const float* bias;    // (Cout) or null
   const bf16_t* mask;   // (B, H, W, Cout) or null: output zeroed where mask <= 0 (ReLU mask of the consumer's input, dgrad)
   bf16_t* y;            // (B, H, W, Cout); unused by the pooled form
   bf16_t* pool;         // pooled form: (B, W/2, Cout, H/2) = the encoder layout (B, T', C F') of max-pool(ReLU(conv))
   uint8_t* code;        // pooled form: one selection byte per pooled element, same layout
-  int B, H, W, Cout, relu;
+  int B, H, W, Cin, Cout, relu;      // Cin = 128 (any form) or 64 (Cout = 128, no mask, not pooled: conv.5 forward)
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
   long long* dbg;                 // development only (tuning WS_DBG): per-section clock totals of workgroup 0
 };

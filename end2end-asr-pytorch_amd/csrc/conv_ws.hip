@@ -1,6 +1,7 @@
-// 3x3 convolution with 128 INPUT channels, bf16 NHWC, weight-stationary: the three 128-channel launches of vgg_cnn's second level
-// (reference: models/asr/transformer.py:48-52 -- conv.7 forward with its ReLU + MaxPool2d + the (B, T', C F') view / transpose of
-// :74-76, conv.7's data gradient with conv.5's ReLU mask, conv.5's data gradient).
+// 3x3 convolution, bf16 NHWC, weight-stationary: the four launches of vgg_cnn's second level that are not weight gradients
+// (reference: models/asr/transformer.py:48-52 -- conv.5 forward (64 -> 128, one pass), conv.7 forward with its ReLU + MaxPool2d + the
+// (B, T', C F') view / transpose of :74-76, conv.7's data gradient with conv.5's ReLU mask, conv.5's data gradient).  The notes below
+// describe the 128-input-channel form; WsGeo<64, 4> is the same kernel with 144 registers of weights per wave and two workgroups per CU.
 //
 // The generic implicit GEMM (conv.hip) re-reads all 9 x 128 x Cout weights (295 KB at Cout = 128) from L2 for every 16 x 16-pixel
 // workgroup tile, through registers into a single LDS buffer with two barriers per tap: its MFMA loop alone runs at 55 % of the peak,
@@ -27,40 +28,51 @@
 #include "conv_c64_core.h"
 #include "conv_ws.h"
 
+#include <stdio.h>
+
 #include <utility>
 
 namespace {
 
 #define WS_FENCE() asm volatile("" ::: "memory")
 
-constexpr int WS_TH = 8, WS_TW = 16, WS_PW = 18;
-constexpr int WS_NHALO = (WS_TH + 2) * WS_PW;     // 180 halo pixels
-constexpr int WS_PB = WS_NHALO * 256;             // bytes of one patch buffer (128 bf16 channels per pixel)
-constexpr int WS_NCH = WS_NHALO * 16;             // 16-byte chunks of a patch
-constexpr int WS_PIT = (WS_NCH + 255) / 256;      // DMA instructions per thread and patch (the last one: the first wave only)
-constexpr int WS_NBUF = 2;
-
-// unit U of a tile's contraction: 4 pixel fragments x (tap, 32-channel k step)
-template <int U, int FM> struct WsUnit {
-  static constexpr int HPS = FM / 4;              // units per k step
-  static constexpr int S = U / HPS, half = U % HPS, tap = S >> 2, ms = S & 3, dy = tap / 3, dx = tap % 3;
+constexpr int WS_TW = 16, WS_PW = 18, WS_NBUF = 2;
+// geometry of a (CI input channels, TH-row tile) instantiation: CI = 128 / TH = 8 -- the three 128-channel launches, one workgroup per
+// CU; CI = 64 / TH = 4 -- conv.5's forward (64 -> 128) in ONE pass, two workgroups per CU (144 registers of weights per wave)
+template <int CI, int TH> struct WsGeo {
+  static constexpr int KS = CI / 32;                    // k steps per tap
+  static constexpr int CPP = CI / 8;                    // 16-byte chunks per pixel
+  static constexpr int PSZ = CI * 2;                    // bytes per pixel
+  static constexpr int NHALO = (TH + 2) * WS_PW;        // halo pixels of a tile (180 / 108)
+  static constexpr int PB = NHALO * PSZ;                // bytes of one patch buffer
+  static constexpr int NCH = NHALO * CPP;               // 16-byte chunks of a patch
+  static constexpr int PIT = (NCH + 255) / 256;         // DMA instructions per thread and patch (the last one partial)
+  // swizzle key of patch column x: the slot of chunk c is c ^ key(x).  256-byte pixels: x & 15; 128-byte pixels (two per bank line):
+  // (x >> 1) & 7 -- either way the 16 lanes of a ds_read_b128 lane group touch 16 different 16-byte slots of a bank line
+  __device__ static __forceinline__ int key(int x) { return CI == 128 ? (x & 15) : ((x >> 1) & 7); }
 };
 
-template <int U, int FM>
-__device__ __forceinline__ void ws_issue(u32x4_t (&dst)[4], const unsigned (&pbd)[3][4]) {
-  using K = WsUnit<U, FM>;
+// unit U of a tile's contraction: 4 pixel fragments x (tap, 32-channel k step)
+template <int U, int FM, int KS> struct WsUnit {
+  static constexpr int HPS = FM / 4;              // units per k step
+  static constexpr int S = U / HPS, half = U % HPS, tap = S / KS, ms = S % KS, dy = tap / 3, dx = tap % 3;
+};
+
+template <int U, int FM, int KS, int PSZ>
+__device__ __forceinline__ void ws_issue(u32x4_t (&dst)[4], const unsigned (&pbd)[3][KS]) {
+  using K = WsUnit<U, FM, KS>;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[i]) : "v"(pbd[K::dx][K::ms]), "n"((K::half * 4 + i + K::dy) * WS_PW * 256));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[i]) : "v"(pbd[K::dx][K::ms]), "n"((K::half * 4 + i + K::dy) * WS_PW * PSZ));
 }
 
-template <int U, int FM, int PD>
-__device__ __forceinline__ void ws_unit(f32x4_t (&acc)[FM][2], u32x4_t (&a)[PD + 1][4], const u32x4_t (&wB)[9][4][2],
-                                        const unsigned (&pbd)[3][4], u32x4_t (&bq)[2]) {
-  using K = WsUnit<U, FM>;
-  constexpr int NU = 36 * (FM / 4);
+template <int U, int FM, int PD, int KS, int PSZ>
+__device__ __forceinline__ void ws_unit(f32x4_t (&acc)[FM][2], u32x4_t (&a)[PD + 1][4], const u32x4_t (&wB)[9][KS][2],
+                                        const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
+  using K = WsUnit<U, FM, KS>;
+  constexpr int NU = 9 * KS * (FM / 4);
   u32x4_t(&cur)[4] = a[U % (PD + 1)];
-  if constexpr (U + PD < NU) ws_issue<U + PD, FM>(a[(U + PD) % (PD + 1)], pbd);      // PD units ahead of the MFMAs
+  if constexpr (U + PD < NU) ws_issue<U + PD, FM, KS, PSZ>(a[(U + PD) % (PD + 1)], pbd);      // PD units ahead of the MFMAs
   constexpr int ahead = ((U + PD < NU) ? PD : NU - 1 - U) * 4;                        // reads that may stay in flight (they return in order)
   if constexpr (U == 0)
     asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(bq[0]), "+v"(bq[1]) : "n"(ahead));
@@ -75,21 +87,25 @@ __device__ __forceinline__ void ws_unit(f32x4_t (&acc)[FM][2], u32x4_t (&a)[PD +
                                                                         K::S == 0 ? __builtin_bit_cast(f32x4_t, bq[j]) : acc[K::half * 4 + i][j], 0, 0, 0);
 }
 
-template <int FM, int PD, int... U>
+template <int FM, int PD, int KS, int PSZ, int... U>
 __device__ __forceinline__ void ws_units(std::integer_sequence<int, U...>, f32x4_t (&acc)[FM][2], u32x4_t (&a)[PD + 1][4],
-                                         const u32x4_t (&wB)[9][4][2], const unsigned (&pbd)[3][4], u32x4_t (&bq)[2]) {
-  (ws_unit<U, FM, PD>(acc, a, wB, pbd, bq), ...);
+                                         const u32x4_t (&wB)[9][KS][2], const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
+  (ws_unit<U, FM, PD, KS, PSZ>(acc, a, wB, pbd, bq), ...);
 }
 
 // EP = 0: y (B, H, W, CO) NHWC, optional ReLU / mask.  EP = 1: ReLU + 2x2 max-pool + selection codes in the (B, W/2, CO, H/2) layout.
 // TM = true (tuning WS_DBG = device address of 64 int64): every wave of workgroup 0 stamps the shader clock at the section boundaries
 // of a tile and leaves its totals {barrier, staging issue, contraction, DMA wait, epilogue, tiles} in dbg[wave * 8 ..]
-template <int CO, bool MASK, int EP, int PD, bool TM = false>
-__global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
+template <int CI, int TH, int CO, bool MASK, int EP, int PD, bool TM = false>
+__global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(WsArgs p) {
+  using G = WsGeo<CI, TH>;
+  constexpr int KS = G::KS, CPP = G::CPP, PSZ = G::PSZ, WS_PB = G::PB, WS_NCH = G::NCH, WS_PIT = G::PIT, WS_TH = TH;
   static_assert(CO == 64 || CO == 128, "output channels");
-  static_assert(EP == 0 || (CO == 128 && !MASK), "pooled epilogue: conv.7 forward");
-  constexpr int WN = CO / 32, WM = 4 / WN, FM = 8 / WM;      // waves along channels / pixel rows, pixel fragments (tile rows) per wave
-  constexpr int NU = 36 * (FM / 4);
+  static_assert(EP == 0 || (CO == 128 && !MASK && TH == 8 && CI == 128), "pooled epilogue: conv.7 forward");
+  constexpr int WN = CO / 32, WM = 4 / WN, FM = TH / WM;     // waves along channels / pixel rows, pixel fragments (tile rows) per wave
+  static_assert(FM == 4 || FM == 8, "4 or 8 tile rows per wave");
+  constexpr int NU = 9 * KS * (FM / 4);
+  constexpr int NA = CI == 128 ? 64 : 32;                    // weight operands that live in the accumulation half of the register file
   constexpr int STASH = MASK ? 4 * FM * 1024 : 0;            // the lane's FM mask chunks of the tile
   constexpr int BIAS_OFF = WS_NBUF * WS_PB + STASH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,18 +122,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
   const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x);
 
   // ---- weights: A operand of every MFMA, resident in registers for the whole kernel
-  u32x4_t wB[9][4][2];
+  u32x4_t wB[9][KS][2];
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms)
+    for (int ms = 0; ms < KS; ++ms)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
       {
         // 64 of the 72 operands are loaded STRAIGHT into the accumulation half of the register file ("=a"): the MFMA reads its A operand
         // from there directly.  Left to itself the allocator treats that half as spill space and pays four v_accvgpr_read per use.
-        const bf16_t* src = p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * 128 + (ms * 4 + gs) * 8;
-        if ((tap * 4 + ms) * 2 + j < 64) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wB[tap][ms][j]) : "v"(src));
+        const bf16_t* src = p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * CI + (ms * 4 + gs) * 8;
+        if ((tap * KS + ms) * 2 + j < NA) asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(wB[tap][ms][j]) : "v"(src));
         else wB[tap][ms][j] = *reinterpret_cast<const u32x4_t*>(src);
       }
   if (tid < CO) reinterpret_cast<float*>(smem + BIAS_OFF)[tid] = p.bias ? p.bias[tid] : 0.f;
@@ -143,14 +159,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
   int rel[WS_PIT];
 #pragma unroll
   for (int it = 0; it < WS_PIT; ++it) {
-    const int c = tid + it * 256, hp = c >> 4, px = hp % WS_PW;
-    rel[it] = ((hp / WS_PW - 1) * p.W + px - 1) * 256 + (((c & 15) ^ (px & 15)) << 4);
+    const int c = tid + it * 256, hp = c / CPP, px = hp % WS_PW;
+    rel[it] = ((hp / WS_PW - 1) * p.W + px - 1) * PSZ + (((c % CPP) ^ G::key(px)) << 4);
   }
   const int relo = ((wm * FM) * p.W + pix) * (CO * 2) + co0 * 2;
   auto stage = [&](int n, const Org& o_, int t_) __attribute__((always_inline)) {
     const int b = o_.b, h0 = o_.h0, w0 = o_.w0;
     unsigned char* buf = smem + (n % WS_NBUF) * WS_PB;
-    const unsigned base = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * 256u;   // < 4 GB (launcher)
+    const unsigned base = (((unsigned)b * (unsigned)p.H + (unsigned)h0) * (unsigned)p.W + (unsigned)w0) * (unsigned)PSZ;   // < 4 GB (launcher)
     const bool inside = h0 >= 1 && w0 >= 1 && h0 + WS_TH + 1 <= p.H && w0 + WS_TW + 1 <= p.W;
     if (inside) {
 #pragma unroll
@@ -166,7 +182,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
       for (int it = 0; it < WS_PIT; ++it) {
         const int c = t_ + it * 256;
         if (it < WS_PIT - 1 || c < WS_NCH) {
-          const int hp = c >> 4, px = hp % WS_PW;
+          const int hp = c / CPP, px = hp % WS_PW;
           const int gy = h0 + hp / WS_PW - 1, gx = w0 + px - 1;
           const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
           const unsigned char* src = in ? X + (base + (unsigned)rel[it]) : reinterpret_cast<const unsigned char*>(&c64_zero_page);
@@ -186,12 +202,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
 
   // per-lane operand addressing: LDS byte address of the lane's chunk of (fragment 0, tap row 0) for column shift dx and k step ms
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  unsigned offk[3][4];
+  unsigned offk[3][KS];
 #pragma unroll
   for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms)
-      offk[dx][ms] = smem_base + (unsigned)(((wm * FM) * WS_PW + pix + dx) * 256) + (unsigned)(((ms * 4 + gs) ^ ((pix + dx) & 15)) << 4);
+    for (int ms = 0; ms < KS; ++ms)
+      offk[dx][ms] = smem_base + (unsigned)(((wm * FM) * WS_PW + pix + dx) * PSZ) + (unsigned)(((ms * 4 + gs) ^ G::key(pix + dx)) << 4);
   const unsigned bias_addr = smem_base + (unsigned)(BIAS_OFF + (wn * 32 + 4 * g) * 4);
   const unsigned stash_addr = smem_base + (unsigned)(WS_NBUF * WS_PB + (wave * FM * 64 + lane) * 16);
 
@@ -233,15 +249,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
     lds_read16(bq[0], bias_addr);
     lds_read16(bq[1], bias_addr + 64);
     f32x4_t acc[FM][2];
-    unsigned pbd[3][4];
+    unsigned pbd[3][KS];
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-      for (int ms = 0; ms < 4; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n % WS_NBUF) * WS_PB);
+      for (int ms = 0; ms < KS; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n % WS_NBUF) * WS_PB);
     u32x4_t a[PD + 1][4];
-    ws_issue<0, FM>(a[0], pbd);
-    if constexpr (PD == 2) ws_issue<1, FM>(a[1], pbd);
-    ws_units<FM, PD>(std::make_integer_sequence<int, NU>{}, acc, a, wB, pbd, bq);
+    ws_issue<0, FM, KS, PSZ>(a[0], pbd);
+    if constexpr (PD == 2) ws_issue<1, FM, KS, PSZ>(a[1], pbd);
+    ws_units<FM, PD, KS, PSZ>(std::make_integer_sequence<int, NU>{}, acc, a, wB, pbd, bq);
 
     // patch n + 1 (and this tile's mask chunks) must have landed before the next barrier
     WS_FENCE();
@@ -344,8 +360,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_ws128_kernel(WsArgs p) {
   }
 }
 
-template <int CO, bool MASK, int EP, int PD, bool TM = false>
+template <int CI, int TH, int CO, bool MASK, int EP, int PD, bool TM = false>
 int ws_launch_t(WsArgs p, hipStream_t s) {
+  using G = WsGeo<CI, TH>;
+  constexpr int WS_TH = TH, WS_PB = G::PB;
   p.tiles_h = (p.H + WS_TH - 1) / WS_TH;
   p.tiles_w = (p.W + WS_TW - 1) / WS_TW;
   const int64_t nt = (int64_t)p.B * p.tiles_h * p.tiles_w;
@@ -358,17 +376,19 @@ int ws_launch_t(WsArgs p, hipStream_t s) {
       n = 256;
     cus = n;
   }
-  constexpr int FM = 8 / (4 / (CO / 32));
+  constexpr int FM = TH / (4 / (CO / 32));
   const size_t lds = (size_t)WS_NBUF * WS_PB + (MASK ? 4 * FM * 1024 : 0) + CO * 4;
   static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
   if (!granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws128_kernel<CO, MASK, EP, PD, TM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws128_kernel<CI, TH, CO, MASK, EP, PD, TM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ASR_EUNSUPPORTED;
     granted = true;
   }
-  const unsigned grid = (unsigned)(nt < cus ? nt : cus);
-  hipLaunchKernelGGL((conv3x3_ws128_kernel<CO, MASK, EP, PD, TM>), dim3(grid), dim3(256), lds, s, p);
+  const int per_cu = CI == 64 ? (int)asr_tuning("WS64_PER_CU", 2) : 1;
+  const int64_t slots = (int64_t)cus * (per_cu > 0 ? per_cu : 1);         // 64 input channels: 144 registers of weights per wave, two workgroups per CU
+  const unsigned grid = (unsigned)(nt < slots ? nt : slots);
+  hipLaunchKernelGGL((conv3x3_ws128_kernel<CI, TH, CO, MASK, EP, PD, TM>), dim3(grid), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -379,22 +399,32 @@ int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s) {
   if (a.Cout != 64 && a.Cout != 128) return ASR_EUNSUPPORTED;
   // 32-bit byte offsets inside the kernel
   if ((int64_t)a.B * a.H * a.W * 256 >= ((int64_t)1 << 32)) return ASR_EUNSUPPORTED;
+  if (a.Cin == 64) {               // conv.5 forward (64 -> 128) in one pass: 4-row tiles, two workgroups per CU
+    if (a.Cout != 128 || a.mask || a.pool) return ASR_EUNSUPPORTED;
+    if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {
+      WsArgs t = a;
+      t.dbg = reinterpret_cast<long long*>(dbg);
+      return ws_launch_t<64, 4, 128, false, 0, 1, true>(t, s);
+    }
+    return asr_tuning("WS_PD", 2) == 1 ? ws_launch_t<64, 4, 128, false, 0, 1>(a, s) : ws_launch_t<64, 4, 128, false, 0, 2>(a, s);
+  }
+  if (a.Cin != 128) return ASR_EUNSUPPORTED;
   const int pd = (int)asr_tuning("WS_PD", 2);
   if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {        // development: per-section clock totals of workgroup 0 (tools/conv_ws_test.cpp)
     WsArgs t = a;
     t.dbg = reinterpret_cast<long long*>(dbg);
-    if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, false, 1, 2, true>(t, s);
-    if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, true, 0, 2, true>(t, s);
-    if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<64, false, 0, 2, true>(t, s);
+    if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, 8, 128, false, 1, 2, true>(t, s);
+    if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, 8, 128, true, 0, 2, true>(t, s);
+    if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<128, 8, 64, false, 0, 2, true>(t, s);
   }
   if (a.pool) {
     if (a.Cout != 128 || a.mask || !a.code || a.H % 8 != 0 || a.W % 16 != 0) return ASR_EUNSUPPORTED;
-    return pd == 1 ? ws_launch_t<128, false, 1, 1>(a, s) : ws_launch_t<128, false, 1, 2>(a, s);
+    return pd == 1 ? ws_launch_t<128, 8, 128, false, 1, 1>(a, s) : ws_launch_t<128, 8, 128, false, 1, 2>(a, s);
   }
   if (a.Cout == 128) {
-    if (a.mask) return pd == 1 ? ws_launch_t<128, true, 0, 1>(a, s) : ws_launch_t<128, true, 0, 2>(a, s);
-    return pd == 1 ? ws_launch_t<128, false, 0, 1>(a, s) : ws_launch_t<128, false, 0, 2>(a, s);
+    if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 128, true, 0, 1>(a, s) : ws_launch_t<128, 8, 128, true, 0, 2>(a, s);
+    return pd == 1 ? ws_launch_t<128, 8, 128, false, 0, 1>(a, s) : ws_launch_t<128, 8, 128, false, 0, 2>(a, s);
   }
-  if (a.mask) return pd == 1 ? ws_launch_t<64, true, 0, 1>(a, s) : ws_launch_t<64, true, 0, 2>(a, s);
-  return pd == 1 ? ws_launch_t<64, false, 0, 1>(a, s) : ws_launch_t<64, false, 0, 2>(a, s);
+  if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 64, true, 0, 1>(a, s) : ws_launch_t<128, 8, 64, true, 0, 2>(a, s);
+  return pd == 1 ? ws_launch_t<128, 8, 64, false, 0, 1>(a, s) : ws_launch_t<128, 8, 64, false, 0, 2>(a, s);
 }

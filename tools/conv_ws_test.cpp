@@ -37,10 +37,11 @@ template <typename T> struct Dev {
   std::vector<T> down() const { std::vector<T> h(n); CK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost)); return h; }
 };
 
-struct Case { int B, H, W, Cout; bool mask, relu, pooled; };
+struct Case { int B, H, W, Cout; bool mask, relu, pooled; int Cin = 128; };
+static const char* knob(const Case& c) { return c.Cin == 64 ? "WS64" : "WS128"; }      // the switch between the old and the new kernel for this shape
 
 static int run_case(const Case& c, bool host_check) {
-  const int Cin = 128;
+  const int Cin = c.Cin;
   const size_t npx = (size_t)c.B * c.H * c.W;
   std::vector<uint16_t> x(npx * Cin), wk((size_t)c.Cout * 9 * Cin), mk(npx * c.Cout);
   std::vector<float> bias(c.Cout);
@@ -55,7 +56,7 @@ static int run_case(const Case& c, bool host_check) {
   std::vector<std::vector<uint16_t>> ys(2);       // WS128 = 0 generic implicit GEMM, 1 conv_ws.hip; empty = shape unsupported
   std::vector<std::vector<uint8_t>> cds(2);
   for (int ws = 0; ws < 2; ++ws) {
-    AK(asr_set_tuning("WS128", ws));
+    AK(asr_set_tuning(knob(c), ws));
     Dev<uint16_t> dy(nout);
     Dev<uint8_t> dc(c.pooled ? nout : 1);
     CK(hipMemset(dy.p, 0xff, nout * 2));
@@ -71,7 +72,7 @@ static int run_case(const Case& c, bool host_check) {
     ys[ws] = dy.down();
     if (c.pooled) cds[ws] = dc.down();
   }
-  AK(asr_clear_tuning("WS128"));
+  AK(asr_clear_tuning(knob(c)));
   size_t bad = 0;
   if (!ys[0].empty())
     for (int k = 1; k < 2; ++k) {
@@ -120,13 +121,13 @@ static int run_case(const Case& c, bool host_check) {
             }
     }
   }
-  printf("  case B=%d H=%d W=%d Cout=%d mask=%d relu=%d pooled=%d : %zu mismatches vs generic kernel%s, %zu vs host%s\n", c.B, c.H, c.W, c.Cout,
+  printf("  case B=%d H=%d W=%d %d->%d mask=%d relu=%d pooled=%d : %zu mismatches vs generic kernel%s, %zu vs host%s\n", c.B, c.H, c.W, c.Cin, c.Cout,
          (int)c.mask, (int)c.relu, (int)c.pooled, bad, ys[0].empty() ? " (n/a)" : "", bad_host, host_check ? "" : " (skipped)");
   return (int)(bad + bad_host != 0);
 }
 
 static void time_case(const Case& c) {
-  const int Cin = 128;
+  const int Cin = c.Cin;
   const size_t npx = (size_t)c.B * c.H * c.W;
   std::vector<uint16_t> x(npx * Cin), wk((size_t)c.Cout * 9 * Cin);
   for (auto& v : x) v = f2bf_rne((float)((int)(rnd() % 2001) - 1000) * 1e-3f);
@@ -141,8 +142,8 @@ static void time_case(const Case& c) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double fl = 2.0 * 9 * Cin * c.Cout * (double)npx;
   for (int ws = 0; ws < 2; ++ws)
-    for (int pd = 2; pd <= 2; ++pd) {
-      AK(asr_set_tuning("WS128", ws));
+    for (int pd = (c.Cin == 64 && ws == 1) ? 1 : 2; pd <= 2; ++pd) {
+      AK(asr_set_tuning(knob(c), ws));
       AK(asr_set_tuning("WS_PD", pd));
       auto go = [&]() {
         if (c.pooled) AK(asr_conv3x3_relu_pool_tcf_code(dx.p, dw.p, db.p, dy.p, dc.p, c.B, c.H, c.W, Cin, c.Cout, ASR_BF16, nullptr));
@@ -158,15 +159,15 @@ static void time_case(const Case& c) {
       float ms = 0.f;
       CK(hipEventElapsedTime(&ms, e0, e1));
       const double us = ms * 1e3 / iters;
-      printf("  time B=%d %dx%d 128->%d mask=%d pooled=%d  %-22s %8.1f us  %7.1f TF/s (%4.1f%% of 2.5 PF)\n", c.B, c.H, c.W, c.Cout, (int)c.mask,
-             (int)c.pooled, ws == 2 ? "ws16 (2 WG/CU, 16 co/wave)" : ws == 1 ? "ws128 (1 WG/CU, 32 co/wave)" : "generic igemm", us, fl / us / 1e6, fl / us / 25e6);
+      printf("  time B=%d %dx%d %d->%d mask=%d pooled=%d  %-22s %8.1f us  %7.1f TF/s (%4.1f%% of 2.5 PF)\n", c.B, c.H, c.W, c.Cin, c.Cout, (int)c.mask,
+             (int)c.pooled, ws == 1 ? (pd == 2 ? "weight-stationary pd=2" : "weight-stationary pd=1") : (c.Cin == 64 ? "c64 kernel, two passes" : "generic igemm"), us, fl / us / 1e6, fl / us / 25e6);
     }
   AK(asr_clear_tuning("WS_PD"));
   for (int ws = 1; ws < 2; ++ws) {
-    if (ws == 1 && !(c.Cout == 128 ? (c.pooled || c.mask) : !c.mask)) continue;      // (timing instantiations of conv_ws.hip exist for these forms)
+    if (c.Cin == 128 && ws == 1 && !(c.Cout == 128 ? (c.pooled || c.mask) : !c.mask)) continue;      // (timing instantiations of conv_ws.hip exist for these forms)
     Dev<long long> dbg(64);
     CK(hipMemset(dbg.p, 0, 64 * 8));
-    AK(asr_set_tuning("WS128", ws));
+    AK(asr_set_tuning(knob(c), ws));
     AK(asr_set_tuning("WS_DBG", (int64_t)(uintptr_t)dbg.p));
     if (c.pooled) AK(asr_conv3x3_relu_pool_tcf_code(dx.p, dw.p, db.p, dy.p, dc.p, c.B, c.H, c.W, Cin, c.Cout, ASR_BF16, nullptr));
     else AK(asr_conv3x3_igemm(dx.p, dw.p, db.p, c.mask ? dm.p : nullptr, dy.p, c.B, c.H, c.W, Cin, c.Cout, c.relu ? 1 : 0, ASR_BF16, nullptr));
@@ -177,10 +178,11 @@ static void time_case(const Case& c) {
       printf("    %s wave %d, %lld tiles, cycles per tile: barrier %lld  staging %lld  contraction %lld  dma wait %lld  epilogue %lld\n", ws == 1 ? "ws128" : "ws16 ", w, h[w * 8 + 5],
              h[w * 8 + 0] / h[w * 8 + 5], h[w * 8 + 1] / h[w * 8 + 5], h[w * 8 + 2] / h[w * 8 + 5], h[w * 8 + 3] / h[w * 8 + 5], h[w * 8 + 4] / h[w * 8 + 5]);
   }
-  AK(asr_clear_tuning("WS128"));
+  AK(asr_clear_tuning(knob(c)));
 }
 
 int main(int argc, char** argv) {
+  if (const char* e = getenv("WS64_PER_CU")) AK(asr_set_tuning("WS64_PER_CU", atoi(e)));
   const bool timing = argc < 2 || strcmp(argv[1], "parity") != 0;
   const bool parity = argc < 2 || strcmp(argv[1], "time") != 0;
   int fails = 0;
@@ -197,6 +199,11 @@ int main(int argc, char** argv) {
     fails += run_case({9, 80, 400, 128, true, false, false}, false);
     fails += run_case({9, 80, 400, 128, false, true, true}, false);
     fails += run_case({9, 80, 400, 64, false, false, false}, false);
+    // 64 -> 128 in one pass (conv.5 forward) against the two-pass form and the host loop
+    fails += run_case({1, 8, 16, 128, false, true, false, 64}, true);
+    fails += run_case({2, 21, 50, 128, false, true, false, 64}, true);
+    fails += run_case({2, 24, 48, 128, false, false, false, 64}, true);
+    fails += run_case({9, 80, 400, 128, false, true, false, 64}, false);
   }
   if (timing) {
     printf("== timing (B = 32, 80 x 400)\n");
@@ -204,6 +211,7 @@ int main(int argc, char** argv) {
     time_case({32, 80, 400, 128, true, false, false});
     time_case({32, 80, 400, 128, false, true, false});
     time_case({32, 80, 400, 64, false, false, false});
+    time_case({32, 80, 400, 128, false, true, false, 64});
   }
   printf(fails ? "FAILED (%d cases)\n" : "OK\n", fails);
   return fails ? 1 : 0;
