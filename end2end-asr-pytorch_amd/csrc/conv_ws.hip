@@ -94,6 +94,9 @@ __device__ __forceinline__ void ws_units(std::integer_sequence<int, U...>, f32x4
 }
 
 // EP = 0: y (B, H, W, CO) NHWC, optional ReLU / mask.  EP = 1: ReLU + 2x2 max-pool + selection codes in the (B, W/2, CO, H/2) layout.
+// EP = 2: the same with the tiles walked in VERTICAL PAIRS (H % 16 == 0): the first tile's 4 pooled rows wait in registers for the second's, and a
+// (column, channel) run leaves as ONE 16-byte + ONE 8-byte store instead of two 8-byte + two 4-byte ones -- a store instruction costs the SIMD
+// ~150 cycles whatever its width, the pooled epilogue was 16 of them per tile.
 // TM = true (tuning WS_DBG = device address of 64 int64): every wave of workgroup 0 stamps the shader clock at the section boundaries
 // of a tile and leaves its totals {barrier, staging issue, contraction, DMA wait, epilogue, tiles} in dbg[wave * 8 ..]
 template <int CI, int TH, int CO, bool MASK, int EP, int PD, bool TM = false>
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   constexpr int KS = G::KS, CPP = G::CPP, PSZ = G::PSZ, WS_PB = G::PB, WS_NCH = G::NCH, WS_PIT = G::PIT, WS_TH = TH;
   static_assert(CO == 64 || CO == 128, "output channels");
   static_assert(EP == 0 || (CO == 128 && !MASK && TH == 8 && CI == 128), "pooled epilogue: conv.7 forward");
+  constexpr bool POOLED = EP != 0, PAIR = EP == 2;
   constexpr int WN = CO / 32, WM = 4 / WN, FM = TH / WM;     // waves along channels / pixel rows, pixel fragments (tile rows) per wave
   static_assert(FM == 4 || FM == 8, "4 or 8 tile rows per wave");
   constexpr int NU = 9 * KS * (FM / 4);
@@ -118,7 +122,9 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   const int gs = ((g & 1) << 1) | (g >> 1);
   const int nwg = gridDim.x;
   const int vid = (nwg % 8 == 0) ? (blockIdx.x % 8) * (nwg / 8) + blockIdx.x / 8 : blockIdx.x;      // consecutive tiles on one XCD
-  const int cnt = vid < p.ntiles ? (p.ntiles - vid + nwg - 1) / nwg : 0;
+  // PAIR: the unit of the walk is a pair of vertically adjacent tiles (2 q, 2 q + 1 in the row-tiles-fastest order; tiles_h is even)
+  const int nitems = PAIR ? p.ntiles / 2 : p.ntiles;
+  const int cnt = (vid < nitems ? (nitems - vid + nwg - 1) / nwg : 0) * (PAIR ? 2 : 1);
   const unsigned char* X = reinterpret_cast<const unsigned char*>(p.x);
 
   // ---- weights: A operand of every MFMA, resident in registers for the whole kernel
@@ -142,9 +148,9 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   // (column, channel) run of the transposed output then meet in one L2 before the line is written back.
   struct Org { int b, h0, w0; };
   auto origin = [&](int n) __attribute__((always_inline)) {
-    int t = vid + n * nwg;
+    int t = PAIR ? 2 * (vid + (n >> 1) * nwg) + (n & 1) : vid + n * nwg;
     Org o;
-    if (EP == 1) {
+    if (POOLED) {
       o.h0 = (t % p.tiles_h) * WS_TH; t /= p.tiles_h;
       o.w0 = (t % p.tiles_w) * WS_TW; o.b = t / p.tiles_w;
     } else {
@@ -211,6 +217,8 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   const unsigned bias_addr = smem_base + (unsigned)(BIAS_OFF + (wn * 32 + 4 * g) * 4);
   const unsigned stash_addr = smem_base + (unsigned)(WS_NBUF * WS_PB + (wave * FM * 64 + lane) * 16);
 
+  uint2 holdv[PAIR ? 8 : 1];          // PAIR: the upper tile's pooled rows and selection bytes of the lane's 8 channels
+  uint32_t holdc[PAIR ? 8 : 1];
   long long tsec[5] = {0, 0, 0, 0, 0}, tlast = TM ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #define WS_STAMP(K) if (TM) { const long long now_ = (long long)__builtin_amdgcn_s_memtime(); tsec[K] += now_ - tlast; tlast = now_; }
   for (int n = 0; n < cnt; ++n) {
@@ -346,8 +354,18 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
             const uint32_t c01 = __builtin_amdgcn_perm(cd[1][j][d], cd[0][j][d], selc);
             const uint32_t c23 = __builtin_amdgcn_perm(cd[3][j][d], cd[2][j][d], selc);
             const int64_t e = e0 + (int64_t)(j * 16 + r) * H2;
-            *reinterpret_cast<uint2*>(p.pool + e) = make_uint2(o01, o23);
-            *reinterpret_cast<uint32_t*>(p.code + e) = c01 | (c23 << 16);
+            if constexpr (PAIR) {
+              if ((n & 1) == 0) {
+                holdv[j * 4 + r] = make_uint2(o01, o23);
+                holdc[j * 4 + r] = c01 | (c23 << 16);
+              } else {            // e - 4 = the upper tile's first pooled row: 8 rows = 16 bytes of values, 8 selection bytes
+                *reinterpret_cast<uint4*>(p.pool + e - 4) = make_uint4(holdv[j * 4 + r].x, holdv[j * 4 + r].y, o01, o23);
+                *reinterpret_cast<uint2*>(p.code + e - 4) = make_uint2(holdc[j * 4 + r], c01 | (c23 << 16));
+              }
+            } else {
+              *reinterpret_cast<uint2*>(p.pool + e) = make_uint2(o01, o23);
+              *reinterpret_cast<uint32_t*>(p.code + e) = c01 | (c23 << 16);
+            }
           }
       }
     }
@@ -387,7 +405,8 @@ int ws_launch_t(WsArgs p, hipStream_t s) {
   }
   const int per_cu = CI == 64 ? (int)asr_tuning("WS64_PER_CU", 2) : 1;
   const int64_t slots = (int64_t)cus * (per_cu > 0 ? per_cu : 1);         // 64 input channels: 144 registers of weights per wave, two workgroups per CU
-  const unsigned grid = (unsigned)(nt < slots ? nt : slots);
+  const int64_t items = EP == 2 ? nt / 2 : nt;
+  const unsigned grid = (unsigned)(items < slots ? items : slots);
   hipLaunchKernelGGL((conv3x3_ws128_kernel<CI, TH, CO, MASK, EP, PD, TM>), dim3(grid), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
@@ -419,6 +438,7 @@ int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s) {
   }
   if (a.pool) {
     if (a.Cout != 128 || a.mask || !a.code || a.H % 8 != 0 || a.W % 16 != 0) return ASR_EUNSUPPORTED;
+    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, false, 2, 2>(a, s);       // vertical tile pairs: half the store instructions
     return pd == 1 ? ws_launch_t<128, 8, 128, false, 1, 1>(a, s) : ws_launch_t<128, 8, 128, false, 1, 2>(a, s);
   }
   if (a.Cout == 128) {
