@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/rNN_roofline_traffic.json from the two-pass PMC summary written by tools/gpu_pmc_traffic.sh.
-bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KB and FETCH_SIZE under-reports 16-byte-per-lane
-reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section).  The family = every conv3x3_c64_kernel / conv3x3_igemm_kernel /
+bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KB and FETCH_SIZE under-reports coalesced
+reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section; at EVERY access width from 1 to 16 bytes per lane and through the LDS-DMA:
+profiles/r05_fetch_size_calibration.txt).  The family = every conv3x3_c64_kernel / conv3x3_igemm_kernel /
 vgg_level0_fwd / vgg_level0_dgrad launch of a step; the average is over the SIX calls of a step (3 forward + 3 data-gradient
 convolutions: what bench.py's roofline leg brackets) -- conv.5's forward is two kernel launches inside one call since round 3; since
 round 4 conv.2's forward and data gradient are the full-resolution-level kernels of csrc/conv_level0.hip (conv.0, the first pool and the
