@@ -92,3 +92,31 @@ def test_attention_dropout_mask_is_packed_sixteen_bit_arithmetic(tmp_path):
     for names in steady:
         assert sum(n.startswith("v_") and not n.startswith("v_mfma") for n in names) <= 285
         assert not any(n.startswith("v_pk_sub_u16") for n in names)
+
+
+@pytest.fixture(scope="module")
+def conv_ws_asm(tmp_path_factory):
+    return _asm(str(tmp_path_factory.mktemp("isa_ws")), "conv_ws.hip")
+
+
+@pytest.mark.parametrize("kernel,mfmas,max_regs", [
+    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELb0ELi2ELi2ELb0E", 576, 512),      # conv.7 forward, pooled epilogue on tile pairs
+    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELb1ELi0ELi2ELb0E", 576, 512),      # conv.7 data gradient + mask
+    (r"conv3x3_ws128_kernelILi128ELi8ELi64ELb0ELi0ELi2ELb0E", 288, 512),       # conv.5 data gradient
+    (r"conv3x3_ws128_kernelILi64ELi4ELi128ELb0ELi0ELi2ELb0E", 144, 256),       # conv.5 forward in one pass: TWO workgroups per CU
+])
+def test_weight_stationary_conv_keeps_its_weights_where_the_mfma_reads_them(conv_ws_asm, kernel, mfmas, max_regs):
+    """csrc/conv_ws.hip (round 5) rests on three compiler-dependent facts: the weights loaded with an "=a" constraint STAY in the
+    accumulation half of the register file and the MFMAs take them from there (no v_accvgpr_read: left to itself the allocator treats that
+    half as spill space, 253 reads per tile in the first build), nothing spills to scratch, and the 64-input-channel form fits 256
+    registers (two workgroups per CU).  One tile's contraction is fully unrolled: 9 taps x k steps x fragments MFMAs."""
+    seg = _kernel(conv_ws_asm, kernel)
+    ops = _ops(seg)
+    assert sum(1 for o, _ in ops if o.startswith("v_mfma")) == mfmas
+    assert not [l for o, l in ops if o.startswith("v_accvgpr")], "accumulation-half registers are being copied instead of read by the MFMA"
+    assert not [l for o, l in ops if o.startswith("scratch_") or o.startswith("buffer_store") or o.startswith("buffer_load_dword ")]
+    assert sum(1 for o, l in ops if o.startswith("v_mfma") and re.search(r"\ba\[\d+:\d+\]", l)) >= mfmas * 3 // 4     # A operands in a[..]
+    meta = "\n".join(seg)
+    nv = re.search(r"\.amdhsa_next_free_vgpr (\d+)", meta)
+    sc = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
+    assert nv and int(nv.group(1)) <= max_regs and sc and int(sc.group(1)) == 0, (nv and nv.group(1), sc and sc.group(1))
