@@ -36,6 +36,10 @@ MFLOP_PER_FRAME = 129.9          # fwd+bwd algorithmic FLOPs (2*MAC over conv/mm
 # configs[3] (not the headline; `--workload librispeech`): enc 12 / dec 6 layers, emb_cnn, T_src=1600, B=16, V=32
 LIBRI = {"T_SRC": 1600, "T_TGT": 100, "V": 32, "B": 16, "MFLOP_PER_FRAME": 179.0, "enc_layers": 12, "dec_layers": 6}
 PEAK_BF16_TFLOPS = 2500.0        # dense MFMA bf16 peak, MI355X_MICROARCH.md
+# what a pure stream of v_mfma_f32_16x16x32_bf16 sustains on pseudo-random bf16 operands on this chip (the power budget sets the clock:
+# 2.2 - 2.46 PF on zeros / constants): tools/probes/mfma_power_probe.hip, profiles/r05_mfma_power_probe.txt.  Context only -- `frac` stays
+# against PEAK_BF16_TFLOPS.
+SUSTAINED_BF16_RANDOM_TFLOPS = 1810.0
 PEAK_F32_TFLOPS = 157.3
 TRAFFIC_FILE = os.path.join("profiles", "r05_roofline_traffic.json")
 # per-family kernel time of the REPLAYED step (tools/prof_families.py over a committed rocprofv3 trace of this command)
@@ -505,6 +509,10 @@ def main():
                                    "vgg_level0_dgrad (conv.2 with conv.0, the first pool and dW0 inside), conv3x3_c64_kernel (conv.5, two passes), "
                                    "conv3x3_ws128_kernel (conv.7 and the two 128-channel data gradients: the weight-stationary kernel of csrc/conv_ws.hip, round 5): 45 % of the step's algorithmic FLOPs",
                                    "achieved": f["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": f["frac"],
+                                   "frac_of_sustained_random_data": (f["achieved"] / SUSTAINED_BF16_RANDOM_TFLOPS) if a.precision == "bf16" else None,
+                                   "sustained_note": "a pure MFMA stream sustains %.0f TFLOP/s on pseudo-random bf16 operands on this chip (2.2 - 2.46 PF on "
+                                                     "zeros / constants: the power budget sets the clock; profiles/r05_mfma_power_probe.txt, a committed "
+                                                     "probe result, NOT measured by this run)" % SUSTAINED_BF16_RANDOM_TFLOPS,
                                    "traffic": tr[0] if tr else None,
                                    "traffic_source": ("constant read from %s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
                                                       "command, committed; NOT measured by this run)" % tr[1]) if tr else None,
