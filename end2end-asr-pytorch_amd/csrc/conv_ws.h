@@ -1,5 +1,5 @@
 // Internal interface between conv.hip (asr_conv3x3_igemm / asr_conv3x3_relu_pool_tcf_code dispatch) and conv_ws.hip (persistent,
-// weight-stationary bf16 kernel for the 128-input-channel layers of vgg_cnn's second level).
+// weight-stationary bf16 kernel for vgg_cnn's second level: the three launches with 128 input channels and conv.5's forward, 64 -> 128).
 #pragma once
 #include "common.h"
 

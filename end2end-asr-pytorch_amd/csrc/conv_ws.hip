@@ -22,8 +22,13 @@
 //   * epilogues from the accumulators: NHWC rows as in conv_c64.hip (bias / ReLU / mask on packed bf16, v_permlane16_swap -> one
 //     16-byte chunk per lane); pooled form: 2 x 2 maximum over row pairs (registers) and lane pairs (DPP), selection byte per pooled
 //     element (packed 16-bit arithmetic), and -- a wave holds all 8 rows of a tile -- the 4 pooled rows of a (column, channel) as one
-//     8-byte run of the (B, W/2, C, H/2) encoder layout straight from registers (no LDS staging, no barrier).
-// MFMA bound: 2 * 9 * 128 * Cout flop per output pixel against 2 * (128 + Cout) bytes.
+//     8-byte run of the (B, W/2, C, H/2) encoder layout straight from registers (no LDS staging, no barrier); with H % 16 == 0 the tiles
+//     are walked in vertical pairs and a run leaves as one 16-byte + one 8-byte store (EP = 2).
+// What bounds it: the contraction runs at 16.4 cycles per MFMA, the matrix pipe's own rate; the tile's 20 - 36
+// memory instructions and its epilogue are serial to it at one wave per SIMD (61 % MFMA-busy in cycles) -- and the chip's power budget: a
+// pure MFMA stream sustains 1.8 PF on activations-like operands (tools/probes/mfma_power_probe.hip), 1.69 PF with this loop's 0.5 LDS
+// operand reads per MFMA beside it (mfma_lds_power_probe.hip); the 64-channel form's two workgroups per CU double the work per cycle and
+// run at 0.73 x the clock.
 #include "common.h"
 #include "conv_c64_core.h"
 #include "conv_ws.h"
