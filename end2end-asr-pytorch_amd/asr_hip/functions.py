@@ -457,6 +457,9 @@ _pool_codes = os.environ.get("ASR_POOL_CODES", "1") != "0"         # A/B switch:
 # The full-resolution level (conv.0, conv.2, first pool) as three launches that never store a 64-channel full-resolution tensor
 # (csrc/conv_level0.hip): forward, weight side and data side of the backward.  A/B switch: 0 = the launch chain on stored activations.
 _level0 = os.environ.get("ASR_LEVEL0", "1") != "0"
+# conv.5's ReLU mask for conv.7's data gradient as one bit per element written by conv.5's own epilogue (asr_conv3x3_igemm_bits): the
+# gradient kernel reads 16 MB of mask instead of the 262 MB of conv.5's output.  A/B switch: 0 = the stored activations are the mask.
+_relu_bits = os.environ.get("ASR_RELU_BITS", "1") != "0"
 
 
 class VGGFn(Function):
@@ -487,7 +490,8 @@ class VGGFn(Function):
                 y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])
                 c1 = None
         wk5, _ = P.conv_shadow(w5)
-        y3 = ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True)
+        with_bits = ops.conv3x3_relu_bits(p1, wk5, b5.data, w5.shape[0]) if (_relu_bits and cd == torch.bfloat16 and not tap) else None
+        y3, m3 = with_bits if with_bits is not None else (ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True), None)
         wk7, _ = P.conv_shadow(w7)
         y4_shape = tuple(y3.shape[:3]) + (w7.shape[0],)
         # conv.7 + ReLU + MaxPool2d + the (B, T', C F') transpose from the convolution's epilogue: y4 is never stored (not for the tap)
@@ -505,13 +509,13 @@ class VGGFn(Function):
         if tap:
             capture_selections.append(("vgg", (y1, y2, y3, y4)))
         # what backward reads: the conv inputs (y1, p1, y3), the ReLU masks (y1, y3) and either the codes or the pre-pool activations
-        ctx.t = (src, y1, None if c1 is not None else y2, p1, y3, None if c4 is not None else y4, c1, c4, y4_shape)
+        ctx.t = (src, y1, None if c1 is not None else y2, p1, y3, None if c4 is not None else y4, c1, c4, y4_shape, m3)
         ctx.params = (w0, b0, w2, b2, w5, b5, w7, b7)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        src, y1, y2, p1, y3, y4, c1, c4, y4_shape = ctx.t
+        src, y1, y2, p1, y3, y4, c1, c4, y4_shape, m3 = ctx.t
         w0, b0, w2, b2, w5, b5, w7, b7 = ctx.params
 
         def wgrad(x, dy, w, b, tag):
@@ -522,7 +526,9 @@ class VGGFn(Function):
         wgrad(y3, dy4, w7, b7, "c7")
         P.grad_ready(w7, b7)
         _, wd7 = P.conv_shadow(w7)
-        dy3 = ops.conv3x3(dy4, wd7, None, w7.shape[1], relu=False, mask_src=y3)
+        dy3 = ops.conv3x3_masked_by_bits(dy4, wd7, None, w7.shape[1], m3) if m3 is not None else None
+        if dy3 is None:
+            dy3 = ops.conv3x3(dy4, wd7, None, w7.shape[1], relu=False, mask_src=y3)
         wgrad(p1, dy3, w5, b5, "c5")
         P.grad_ready(w5, b5)
         _, wd5 = P.conv_shadow(w5)

@@ -916,6 +916,37 @@ def conv3x3(x, wk, bias, Cout, relu, mask_src=None):
     return y
 
 
+def conv3x3_relu_bits(x, wk, bias, Cout):
+    """(y, bits): y = ReLU(conv3x3(x) + bias) and its ReLU mask at one bit per element (include/asr_hip.h: asr_relu_bits_bytes), for
+    conv3x3_masked_by_bits on the way back.  None where the library has no such form (callers keep y as the mask)."""
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    nbytes = L.load().asr_relu_bits_bytes(B, H, W, Cout)
+    if nbytes < 0:
+        return None
+    y = torch.empty((B, H, W, Cout), device=x.device, dtype=x.dtype)
+    bits = torch.empty((nbytes,), device=x.device, dtype=torch.uint8)
+    rc = L.load().asr_conv3x3_igemm_bits(L.ptr(x), L.ptr(wk), L.ptr(bias), None, L.ptr(y), L.ptr(bits), B, H, W, Cin, Cout, 1, L.dt(x),
+                                         L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_conv3x3_igemm_bits")
+    return y, bits
+
+
+def conv3x3_masked_by_bits(x, wk, bias, Cout, bits, relu=False):
+    """conv3x3(x) (+ bias) zeroed where `bits` (conv3x3_relu_bits) is 0; None where the library has no such form."""
+    B, H, W, Cin = x.shape
+    assert x.is_contiguous()
+    y = torch.empty((B, H, W, Cout), device=x.device, dtype=x.dtype)
+    rc = L.load().asr_conv3x3_igemm_bits(L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(bits), L.ptr(y), None, B, H, W, Cin, Cout, int(relu),
+                                         L.dt(x), L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_conv3x3_igemm_bits")
+    return y
+
+
 def conv3x3_relu_pool(x, wk, bias, Cout):
     """(y, pool): y = ReLU(conv3x3(x) + bias) and its 2x2/2 max-pool.  One kernel where the library has the fused epilogue
     (bf16, 64 -> 64 channels), otherwise the convolution followed by the pooling kernel -- both are HIP paths."""

@@ -1324,6 +1324,30 @@ extern "C" int asr_conv3x3_igemm(const void* x, const void* wk, const float* bia
   return Cout == 64 ? launch_igemm<bf16_t, 64>(p, s) : launch_igemm<bf16_t, 128>(p, s);
 }
 
+extern "C" int64_t asr_relu_bits_bytes(int B, int H, int W, int C) {
+  if (B < 0 || H <= 0 || W <= 0 || C != 128) return -1;
+  return (int64_t)B * (2 * ((H + 7) / 8)) * ((W + 15) / 16) * (C / 32) * 256;       // one dword per (4 x 16-pixel tile, 32 channels, lane)
+}
+
+// The convolution with a ReLU mask of ONE BIT per element on either side (conv_ws.hip): bits_out -- written for this launch's ReLU output
+// (conv.5 forward, bf16 64 -> 128); bits_in -- the output is zeroed where the bit is 0 (conv.7's data gradient, bf16 128 -> 128).
+extern "C" int asr_conv3x3_igemm_bits(const void* x, const void* wk, const float* bias, const uint8_t* bits_in, void* y, uint8_t* bits_out,
+                                      int B, int H, int W, int Cin, int Cout, int relu, int dtype, hipStream_t s) {
+  ASR_CHECK_ARG(x && wk && y && B >= 0 && H > 0 && W > 0);
+  ASR_CHECK_ARG((bits_in != nullptr) != (bits_out != nullptr));
+  if (dtype != ASR_BF16 || !aligned16(x) || !aligned16(wk) || !aligned16(y) || ((uintptr_t)bits_in & 3) || ((uintptr_t)bits_out & 3))
+    return ASR_EUNSUPPORTED;
+  if (bits_in ? (Cin != 128 || Cout != 128) : (Cin != 64 || Cout != 128 || !relu)) return ASR_EUNSUPPORTED;
+  if (asr_tuning("WS_BITS", 1) == 0) return ASR_EUNSUPPORTED;
+  if (B == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
+  WsArgs a{};
+  a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias; a.y = static_cast<bf16_t*>(y);
+  a.bits_in = bits_in; a.bits_out = bits_out;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.relu = relu;
+  return asr_conv3x3_ws128_launch(a, s);
+}
+
 extern "C" int asr_conv3x3_relu_pool(const void* x, const void* wk, const float* bias, void* y, void* pool, int B, int H, int W,
                                      int Cin, int Cout, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && wk && y && pool && B >= 0 && H > 0 && W > 0);

@@ -11,6 +11,8 @@ struct WsArgs {
   bf16_t* y;            // (B, H, W, Cout); unused by the pooled form
   bf16_t* pool;         // pooled form: (B, W/2, Cout, H/2) = the encoder layout (B, T', C F') of max-pool(ReLU(conv))
   uint8_t* code;        // pooled form: one selection byte per pooled element, same layout
+  const uint8_t* bits_in;   // or null: ReLU mask of the output as ONE BIT per element (layout: asr_relu_bits_bytes), Cin = Cout = 128
+  uint8_t* bits_out;        // or null: write such bits for this launch's ReLU output (Cin = 64, Cout = 128)
   int B, H, W, Cin, Cout, relu;      // Cin = 128 (any form) or 64 (Cout = 128, no mask, not pooled: conv.5 forward)
   int tiles_h, tiles_w, ntiles;   // filled by the launcher
   long long* dbg;                 // development only (tuning WS_DBG): per-section clock totals of workgroup 0

@@ -104,12 +104,23 @@ __device__ __forceinline__ void ws_units(std::integer_sequence<int, U...>, f32x4
 // ~150 cycles whatever its width, the pooled epilogue was 16 of them per tile.
 // TM = true (tuning WS_DBG = device address of 64 int64): every wave of workgroup 0 stamps the shader clock at the section boundaries
 // of a tile and leaves its totals {barrier, staging issue, contraction, DMA wait, epilogue, tiles} in dbg[wave * 8 ..]
-template <int CI, int TH, int CO, bool MASK, int EP, int PD, bool TM = false>
+template <int CI, int TH, int CO, int MK, int EP, int PD, bool TM = false>
 __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(WsArgs p) {
   using G = WsGeo<CI, TH>;
   constexpr int KS = G::KS, CPP = G::CPP, PSZ = G::PSZ, WS_PB = G::PB, WS_NCH = G::NCH, WS_PIT = G::PIT, WS_TH = TH;
   static_assert(CO == 64 || CO == 128, "output channels");
-  static_assert(EP == 0 || (CO == 128 && !MASK && TH == 8 && CI == 128), "pooled epilogue: conv.7 forward");
+  // MK: 0 = no mask; 1 = output zeroed where the bf16 tensor p.mask is <= 0 (the lane's 16-byte mask chunks by LDS-DMA into a private
+  // stash); 2 = the same from ONE BIT per element (p.bits_in, layout below): a single 8-byte load per lane and tile instead of 8 DMA
+  // pieces, 16 MB of mask instead of 262 MB; 3 = no mask, but the epilogue WRITES such bits for its ReLU output (p.bits_out: conv.5
+  // forward for conv.7's data gradient).  Bit layout (asr_hip.h: asr_relu_bits_bytes): one dword per (4-row x 16-column tile, wave, lane) in
+  // THIS kernel's lane order -- [b][h / 4][w / 16][co / 32][lane] with byte r = row 4 (h / 4) + r, bit k = channel co0(lane) + k of pixel
+  // column pix(lane) -- so that the producer's store and the consumer's two loads are 256 contiguous bytes per wave.  (A pixel-major
+  // layout, [b][h / 8][w][c / 8][h % 8], was measured first: its 4-byte stores at 8-byte stride cost the producer 160 us instead of 125,
+  // profiles/r05_relu_bits.txt -- partial-sector writes, not instructions: the same kernel WITHOUT the store ran in 119.)
+  constexpr bool MASK = MK == 1, BITS_IN = MK == 2, BITS_OUT = MK == 3;
+  static_assert(EP == 0 || (CO == 128 && MK == 0 && TH == 8 && CI == 128), "pooled epilogue: conv.7 forward");
+  static_assert(!BITS_IN || (TH == 8 && CO == 128), "bit mask in: 8-row tiles, a wave holds all 8 rows");
+  static_assert(!BITS_OUT || (TH == 4 && CO == 128 && EP == 0), "bit mask out: the 4-row form");
   constexpr bool POOLED = EP != 0, PAIR = EP == 2;
   constexpr int WN = CO / 32, WM = 4 / WN, FM = TH / WM;     // waves along channels / pixel rows, pixel fragments (tile rows) per wave
   static_assert(FM == 4 || FM == 8, "4 or 8 tile rows per wave");
@@ -254,6 +265,12 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
       }
     }
+    uint2 mbits = make_uint2(0u, 0u);
+    if constexpr (BITS_IN) {           // the lane's 8 mask bytes of the tile (rows 0 .. 7 of its pixel column, its 8-channel chunk)
+      const uint8_t* src = p.bits_in + ((((size_t)b * (2 * ((p.H + 7) >> 3)) + (h0 >> 2)) * p.tiles_w + (w0 >> 4)) * 256 + tl) * 4;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(mbits.x) : "v"(src));                        // rows 0 .. 3
+      asm volatile("global_load_dword %0, %1, off" : "=v"(mbits.y) : "v"(src + (size_t)p.tiles_w * 1024));     // rows 4 .. 7: the 4-row tile below
+    }
     if (more) stage(n + 1, origin(n + 1), tl);
     WS_FENCE();
     WS_STAMP(1)
@@ -276,6 +293,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
     WS_FENCE();
     WS_STAMP(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (BITS_IN) asm volatile("" : "+v"(mbits));       // valid from here on (the wait above is this load's too)
     WS_STAMP(3)
 
     if constexpr (EP == 0) {
@@ -289,6 +307,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
           asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(mk[i]), "+v"(mk[i + 1]), "+v"(mk[i + 2]), "+v"(mk[i + 3]) : "n"(FM - 4 - i));
       }
       const uint32_t floor2 = p.relu ? 0u : 0x80008000u;       // ReLU = packed signed max with 0, "no ReLU" = max with the most negative int16
+      uint32_t rowbits[BITS_OUT ? FM : 1];
       const int rows_ok = p.H - h0 - (tl >> 6) / WN * FM;
       const bool col_ok = w0 + pix < p.W;
       unsigned char* yb = reinterpret_cast<unsigned char*>(p.y) + (obase + (unsigned)relo);
@@ -310,7 +329,31 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
           o.x = c64_mask2(o.x, mk[i][0]); o.y = c64_mask2(o.y, mk[i][1]);
           o.z = c64_mask2(o.z, mk[i][2]); o.w = c64_mask2(o.w, mk[i][3]);
         }
+        if constexpr (BITS_IN) {         // byte i of the lane's 8: bit k = channel co0 + k kept; bit -> 16-bit mask by a signed bit-field extract
+          const uint32_t by = ((i < 4 ? mbits.x : mbits.y) >> (8 * (i & 3)));
+          uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const uint32_t l = (uint32_t)__builtin_amdgcn_sbfe((int)by, 2 * d, 1), h = (uint32_t)__builtin_amdgcn_sbfe((int)by, 2 * d + 1, 1);
+            ow[d] &= __builtin_amdgcn_perm(h, l, 0x07060100u);
+          }
+        }
+        if constexpr (BITS_OUT) {        // the chunk's 8 sign tests (ReLU output: > 0 <=> bits != 0) -> byte i of the lane's dword
+          const uint32_t one = 0x00010001u;
+          uint32_t t[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+          for (int d = 0; d < 4; ++d) asm("v_pk_min_u16 %0, %0, %1" : "+v"(t[d]) : "v"(one));       // 1 per non-zero half
+          uint32_t e = t[0] | (t[1] << 2);                      // channels 0, 2, 4, 6 at bits 0, 2, 4, 6; 1, 3, 5, 7 at bits 16, 18, 20, 22
+          e |= t[2] << 4;
+          e |= t[3] << 6;
+          rowbits[i] = e | (e >> 15);                           // low byte = the mask byte (the rest is dropped by the byte pick below)
+        }
         if (col_ok && i < rows_ok) *reinterpret_cast<uint4*>(yb + (size_t)i * p.W * (CO * 2)) = o;
+      }
+      if constexpr (BITS_OUT) {
+        const uint32_t obits = __builtin_amdgcn_perm(__builtin_amdgcn_perm(rowbits[3], rowbits[2], 0x0c0c0400u),
+                                                     __builtin_amdgcn_perm(rowbits[1], rowbits[0], 0x0c0c0400u), 0x05040100u);
+        *reinterpret_cast<uint32_t*>(p.bits_out + ((((size_t)b * (2 * ((p.H + 7) >> 3)) + (h0 >> 2)) * p.tiles_w + (w0 >> 4)) * 256 + tl) * 4) = obits;
       }
     } else {
       // ---- pooled epilogue (launcher: H % 8 == 0, W % 16 == 0, so every tile is whole).  Values are ReLU outputs (>= 0): the
@@ -383,7 +426,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   }
 }
 
-template <int CI, int TH, int CO, bool MASK, int EP, int PD, bool TM = false>
+template <int CI, int TH, int CO, int MK, int EP, int PD, bool TM = false>
 int ws_launch_t(WsArgs p, hipStream_t s) {
   using G = WsGeo<CI, TH>;
   constexpr int WS_TH = TH, WS_PB = G::PB;
@@ -400,10 +443,10 @@ int ws_launch_t(WsArgs p, hipStream_t s) {
     cus = n;
   }
   constexpr int FM = TH / (4 / (CO / 32));
-  const size_t lds = (size_t)WS_NBUF * WS_PB + (MASK ? 4 * FM * 1024 : 0) + CO * 4;
+  const size_t lds = (size_t)WS_NBUF * WS_PB + (MK == 1 ? 4 * FM * 1024 : 0) + CO * 4;
   static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
   if (!granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws128_kernel<CI, TH, CO, MASK, EP, PD, TM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws128_kernel<CI, TH, CO, MK, EP, PD, TM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ASR_EUNSUPPORTED;
     granted = true;
@@ -412,7 +455,7 @@ int ws_launch_t(WsArgs p, hipStream_t s) {
   const int64_t slots = (int64_t)cus * (per_cu > 0 ? per_cu : 1);         // 64 input channels: 144 registers of weights per wave, two workgroups per CU
   const int64_t items = EP == 2 ? nt / 2 : nt;
   const unsigned grid = (unsigned)(items < slots ? items : slots);
-  hipLaunchKernelGGL((conv3x3_ws128_kernel<CI, TH, CO, MASK, EP, PD, TM>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_ws128_kernel<CI, TH, CO, MK, EP, PD, TM>), dim3(grid), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -423,33 +466,37 @@ int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s) {
   if (a.Cout != 64 && a.Cout != 128) return ASR_EUNSUPPORTED;
   // 32-bit byte offsets inside the kernel
   if ((int64_t)a.B * a.H * a.W * 256 >= ((int64_t)1 << 32)) return ASR_EUNSUPPORTED;
+  if (a.bits_in && (a.Cin != 128 || a.Cout != 128 || a.mask || a.pool || a.bits_out)) return ASR_EUNSUPPORTED;
+  if (a.bits_out && (a.Cin != 64 || a.Cout != 128 || a.mask || a.pool || !a.relu)) return ASR_EUNSUPPORTED;
   if (a.Cin == 64) {               // conv.5 forward (64 -> 128) in one pass: 4-row tiles, two workgroups per CU
     if (a.Cout != 128 || a.mask || a.pool) return ASR_EUNSUPPORTED;
+    if (a.bits_out) return ws_launch_t<64, 4, 128, 3, 0, 2>(a, s);        // ... also writing the ReLU bit mask of its output
     if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {
       WsArgs t = a;
       t.dbg = reinterpret_cast<long long*>(dbg);
-      return ws_launch_t<64, 4, 128, false, 0, 1, true>(t, s);
+      return ws_launch_t<64, 4, 128, 0, 0, 1, true>(t, s);
     }
-    return asr_tuning("WS_PD", 2) == 1 ? ws_launch_t<64, 4, 128, false, 0, 1>(a, s) : ws_launch_t<64, 4, 128, false, 0, 2>(a, s);
+    return asr_tuning("WS_PD", 2) == 1 ? ws_launch_t<64, 4, 128, 0, 0, 1>(a, s) : ws_launch_t<64, 4, 128, 0, 0, 2>(a, s);
   }
   if (a.Cin != 128) return ASR_EUNSUPPORTED;
   const int pd = (int)asr_tuning("WS_PD", 2);
   if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {        // development: per-section clock totals of workgroup 0 (tools/conv_ws_test.cpp)
     WsArgs t = a;
     t.dbg = reinterpret_cast<long long*>(dbg);
-    if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, 8, 128, false, 1, 2, true>(t, s);
-    if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, 8, 128, true, 0, 2, true>(t, s);
-    if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<128, 8, 64, false, 0, 2, true>(t, s);
+    if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, 8, 128, 0, 1, 2, true>(t, s);
+    if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, 8, 128, 1, 0, 2, true>(t, s);
+    if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<128, 8, 64, 0, 0, 2, true>(t, s);
   }
   if (a.pool) {
     if (a.Cout != 128 || a.mask || !a.code || a.H % 8 != 0 || a.W % 16 != 0) return ASR_EUNSUPPORTED;
-    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, false, 2, 2>(a, s);       // vertical tile pairs: half the store instructions
-    return pd == 1 ? ws_launch_t<128, 8, 128, false, 1, 1>(a, s) : ws_launch_t<128, 8, 128, false, 1, 2>(a, s);
+    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, 0, 2, 2>(a, s);       // vertical tile pairs: half the store instructions
+    return pd == 1 ? ws_launch_t<128, 8, 128, 0, 1, 1>(a, s) : ws_launch_t<128, 8, 128, 0, 1, 2>(a, s);
   }
+  if (a.bits_in) return ws_launch_t<128, 8, 128, 2, 0, 2>(a, s);           // conv.7's data gradient with conv.5's ReLU mask as bits
   if (a.Cout == 128) {
-    if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 128, true, 0, 1>(a, s) : ws_launch_t<128, 8, 128, true, 0, 2>(a, s);
-    return pd == 1 ? ws_launch_t<128, 8, 128, false, 0, 1>(a, s) : ws_launch_t<128, 8, 128, false, 0, 2>(a, s);
+    if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 128, 1, 0, 1>(a, s) : ws_launch_t<128, 8, 128, 1, 0, 2>(a, s);
+    return pd == 1 ? ws_launch_t<128, 8, 128, 0, 0, 1>(a, s) : ws_launch_t<128, 8, 128, 0, 0, 2>(a, s);
   }
-  if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 64, true, 0, 1>(a, s) : ws_launch_t<128, 8, 64, true, 0, 2>(a, s);
-  return pd == 1 ? ws_launch_t<128, 8, 64, false, 0, 1>(a, s) : ws_launch_t<128, 8, 64, false, 0, 2>(a, s);
+  if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 64, 1, 0, 1>(a, s) : ws_launch_t<128, 8, 64, 1, 0, 2>(a, s);
+  return pd == 1 ? ws_launch_t<128, 8, 64, 0, 0, 1>(a, s) : ws_launch_t<128, 8, 64, 0, 0, 2>(a, s);
 }

@@ -336,6 +336,19 @@ int asr_conv_pack_weight_multi(int n, const float* const* w, void* const* wk, vo
  * conv_ws.hip (round 5), everything else the generic implicit GEMM of conv.hip.                                    */
 int asr_conv3x3_igemm(const void* x, const void* wk, const float* bias, const void* mask_src, void* y, int B,
                       int H, int W, int Cin, int Cout, int relu, int dtype, asr_stream_t stream);
+/* ReLU masks of ONE BIT per element (round 5; transformer.py:48-52 and the autograd of its second ReLU: conv.5 -> ReLU -> conv.7).
+ * A (B, H, W, 128) mask is an array of dwords [b][h / 4][w / 16][c / 32][lane], rows padded to a multiple of 8 and columns to a multiple
+ * of 16 (asr_relu_bits_bytes = its size; -1 unless C = 128): byte r of the dword = row 4 (h / 4) + r, bit k = channel
+ * 32 (c / 32) + 16 (g & 1) + 8 (g >> 1) + k of pixel column 16 (w / 16) + 8 (a & 1) + 2 (l & 3) + ((a >> 1 ^ a) & 1), where
+ * l = lane & 15, a = l >> 2, g = lane >> 4 -- the kernels' own fragment order, so that the writer's store and the reader's loads are
+ * 256 contiguous bytes per wave.  asr_conv3x3_igemm_bits is asr_conv3x3_igemm with exactly one of
+ *   bits_out: also writes the mask (y > 0) of this launch's ReLU output          (bf16, Cin = 64, Cout = 128, relu = 1);
+ *   bits_in : y *= bit, instead of asr_conv3x3_igemm's 16-bit mask_src tensor      (bf16, Cin = Cout = 128);
+ * ASR_EUNSUPPORTED for any other shape / dtype (callers keep the mask_src form).  Pointers 4-byte aligned.  Results are bit for bit
+ * those of asr_conv3x3_igemm with the bf16 mask.                                                                  */
+int64_t asr_relu_bits_bytes(int B, int H, int W, int C);
+int asr_conv3x3_igemm_bits(const void* x, const void* wk, const float* bias, const uint8_t* bits_in, void* y, uint8_t* bits_out,
+                           int B, int H, int W, int Cin, int Cout, int relu, int dtype, asr_stream_t stream);
 /* y = ReLU(conv3x3_pad1(x; wk) + bias) AND pool = 2x2/2 floor max-pool of y (B, H/2, W/2, Cout) from the same epilogue
  * (transformer.py:45-47: conv.2, ReLU, MaxPool2d): the pool no longer re-reads y.  ASR_EUNSUPPORTED unless bf16 and
  * Cin = Cout = 64 (the layer that has this shape in the model) -- callers then use asr_conv3x3_igemm + asr_maxpool_fwd.  */

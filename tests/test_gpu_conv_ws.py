@@ -124,3 +124,51 @@ def test_many_tiles_per_workgroup_and_both_kernels_agree():
         finally:
             L.set_tuning(knob, None)
         assert torch.equal(a, b), (Cin, Cout)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 8, 16), (2, 21, 50), (2, 24, 48), (3, 80, 400)])
+def test_relu_mask_as_bits_is_exact(B, H, W):
+    """conv.5's ReLU mask for conv.7's data gradient at ONE BIT per element (asr_conv3x3_igemm_bits; reference: the autograd of
+    transformer.py:50's ReLU): conv.5's epilogue writes the bits beside its output, the gradient kernel applies them.  The output, the
+    bits (against their definition in include/asr_hip.h) and the masked gradient are those of the 16-bit-mask forms, bit for bit."""
+    from asr_hip import lib as L
+    from asr_hip import ops
+    x, w5, b5, _ = _data(B, H, W, 64, 128, seed=H + W)
+    g, w7, _, _ = _data(B, H, W, 128, 128, seed=H + W + 1)
+    xd, wk5, bd, gd, wk7 = x.cuda().bfloat16(), _packed(w5), b5.cuda(), g.cuda().bfloat16(), _packed(w7)
+    y_ref = ops.conv3x3(xd, wk5, bd, 128, relu=True)
+    got = ops.conv3x3_relu_bits(xd, wk5, bd, 128)
+    assert got is not None
+    y, bits = got
+    H4, W16 = 2 * ((H + 7) // 8), (W + 15) // 16
+    assert bits.numel() == L.load().asr_relu_bits_bytes(B, H, W, 128) == B * H4 * W16 * 4 * 64 * 4
+    assert torch.equal(y, y_ref)
+    assert torch.equal(y.cpu(), _reference(x, w5, b5, True, None))
+    # the layout of include/asr_hip.h: dword [b][h / 4][w / 16][c / 32][lane], byte = h % 4, bit = c % 8
+    lane = torch.arange(64)
+    l, grp = lane & 15, lane >> 4
+    a = l >> 2
+    pix = 8 * (a & 1) + 2 * (l & 3) + (((a >> 1) ^ a) & 1)
+    chunk = 2 * (grp & 1) + (grp >> 1)                                     # 8-channel chunk of the wave's 32 channels
+    by = bits.cpu().view(B, H4, W16, 4, 64, 4)                         # (..., wave, lane, row)
+    unpacked = torch.zeros(B, H4 * 4, W16 * 16, 128, dtype=torch.bool)
+    cols = torch.arange(W16).view(-1, 1) * 16 + pix.view(1, -1)        # (W16, 64)
+    for wave in range(4):
+        for k in range(8):
+            ch = wave * 32 + chunk * 8 + k                                                                  # (64,)
+            v = ((by[:, :, :, wave] >> k) & 1).bool().permute(0, 1, 4, 2, 3).reshape(B, H4 * 4, W16, 64)     # (B, rows, W16, lane)
+            unpacked[:, :, cols, ch.view(1, -1).expand(W16, 64)] = v
+    assert torch.equal(unpacked[:, :H, :W], y_ref.cpu().float() > 0)
+    z_ref = ops.conv3x3(gd, wk7, None, 128, relu=False, mask_src=y_ref)
+    z = ops.conv3x3_masked_by_bits(gd, wk7, None, 128, bits)
+    assert z is not None and torch.equal(z, z_ref)
+    assert torch.equal(z.cpu(), _reference(g, w7, torch.zeros(128), False, y_ref.cpu().float()))
+
+
+def test_relu_bits_outside_their_domain_are_refused():
+    from asr_hip import ops
+    x = torch.zeros(1, 8, 16, 128, device="cuda", dtype=torch.bfloat16)
+    wk = torch.zeros(128, 9, 128, device="cuda", dtype=torch.bfloat16)
+    assert ops.conv3x3_relu_bits(x, wk, torch.zeros(128, device="cuda"), 128) is None            # bits out: 64 -> 128 only
+    x32 = torch.zeros(1, 8, 16, 64, device="cuda")
+    assert ops.conv3x3_relu_bits(x32, torch.zeros(128, 9, 64, device="cuda"), torch.zeros(128, device="cuda"), 128) is None      # fp32

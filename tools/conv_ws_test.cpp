@@ -6,6 +6,7 @@
 // Build:  hipcc -O2 tools/conv_ws_test.cpp -o tools/bin/conv_ws_test -Iinclude -Lend2end-asr-pytorch_amd/asr_hip -lasr_hip \
 //               -Wl,-rpath,'$ORIGIN/../../end2end-asr-pytorch_amd/asr_hip'
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -181,11 +182,95 @@ static void time_case(const Case& c) {
   AK(asr_clear_tuning(knob(c)));
 }
 
+// conv.5 forward writing its ReLU mask as bits, conv.7's data gradient reading it: both against the 16-bit-mask forms, the bits against
+// the definition (include/asr_hip.h: asr_relu_bits_bytes)
+static int run_bits(int B, int H, int W, bool timing) {
+  const size_t npx = (size_t)B * H * W;
+  std::vector<uint16_t> x(npx * 64), w5((size_t)128 * 9 * 64), g(npx * 128), w7((size_t)128 * 9 * 128);
+  std::vector<float> bias(128);
+  for (auto& v : x) v = f2bf((float)rint_(-3, 3));
+  for (auto& v : w5) v = f2bf((float)rint_(-2, 2));
+  for (auto& v : g) v = f2bf((float)rint_(-3, 3));
+  for (auto& v : w7) v = f2bf((float)rint_(-2, 2));
+  for (auto& v : bias) v = (float)rint_(-8, 8) * 0.5f;
+  const int64_t nb = asr_relu_bits_bytes(B, H, W, 128);
+  Dev<uint16_t> dx(x.size()), dw5(w5.size()), dg(g.size()), dw7(w7.size()), y0(npx * 128), y1(npx * 128), z0(npx * 128), z1(npx * 128);
+  Dev<uint8_t> dbits((size_t)nb);
+  Dev<float> db(128);
+  dx.up(x); dw5.up(w5); dg.up(g); dw7.up(w7); db.up(bias);
+  CK(hipMemset(dbits.p, 0xa5, (size_t)nb));
+  AK(asr_conv3x3_igemm(dx.p, dw5.p, db.p, nullptr, y0.p, B, H, W, 64, 128, 1, ASR_BF16, nullptr));
+  AK(asr_conv3x3_igemm_bits(dx.p, dw5.p, db.p, nullptr, y1.p, dbits.p, B, H, W, 64, 128, 1, ASR_BF16, nullptr));
+  AK(asr_conv3x3_igemm(dg.p, dw7.p, nullptr, y0.p, z0.p, B, H, W, 128, 128, 0, ASR_BF16, nullptr));
+  AK(asr_conv3x3_igemm_bits(dg.p, dw7.p, nullptr, dbits.p, z1.p, nullptr, B, H, W, 128, 128, 0, ASR_BF16, nullptr));
+  CK(hipDeviceSynchronize());
+  const auto hy0 = y0.down(), hy1 = y1.down(), hz0 = z0.down(), hz1 = z1.down();
+  const auto hb = dbits.down();
+  size_t bad_y = 0, bad_z = 0, bad_b = 0, kept = 0;
+  for (size_t i = 0; i < hy0.size(); ++i) bad_y += hy0[i] != hy1[i];
+  for (size_t i = 0; i < hz0.size(); ++i) bad_z += hz0[i] != hz1[i];
+  const int H4 = 2 * ((H + 7) / 8), W16 = (W + 15) / 16;
+  int lane_of[16][4];          // (pixel column in the tile, 8-channel chunk of the 32) -> lane: the layout of include/asr_hip.h
+  for (int lane = 0; lane < 64; ++lane) {
+    const int l = lane & 15, a = l >> 2, gq = lane >> 4;
+    lane_of[8 * (a & 1) + 2 * (l & 3) + (((a >> 1) ^ a) & 1)][2 * (gq & 1) + (gq >> 1)] = lane;
+  }
+  for (int b = 0; b < B; ++b)
+    for (int h = 0; h < H; ++h)
+      for (int w = 0; w < W; ++w)
+        for (int c = 0; c < 128; ++c) {
+          const bool want = bf2f(hy0[(((size_t)b * H + h) * W + w) * 128 + c]) > 0.f;
+          const size_t dw = ((((size_t)b * H4 + h / 4) * W16 + w / 16) * 4 + c / 32) * 64 + lane_of[w % 16][c % 32 / 8];
+          const bool got = (hb[dw * 4 + h % 4] >> (c % 8)) & 1;
+          bad_b += want != got;
+          kept += want;
+        }
+  printf("  bits B=%d H=%d W=%d: conv.5 output %zu mismatches, mask bits %zu wrong (%.1f%% kept), conv.7 data gradient %zu mismatches\n", B, H, W,
+         bad_y, bad_b, 100.0 * kept / (double)hy0.size(), bad_z);
+  if (timing) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    // interleaved rounds (the chip's clock follows the recent load: a form timed right after another is not comparable with one
+    // timed after a pause), median of 7
+    static const char* names[] = {"conv.5 forward", "conv.5 forward + bits out", "conv.7 dgrad, bf16 mask", "conv.7 dgrad, bit mask"};
+    std::vector<double> t[4];
+    for (int round = 0; round < 7; ++round)
+      for (int form = 0; form < 4; ++form) {
+        auto go = [&]() {
+          if (form == 0) AK(asr_conv3x3_igemm(dx.p, dw5.p, db.p, nullptr, y0.p, B, H, W, 64, 128, 1, ASR_BF16, nullptr));
+          if (form == 1) AK(asr_conv3x3_igemm_bits(dx.p, dw5.p, db.p, nullptr, y1.p, dbits.p, B, H, W, 64, 128, 1, ASR_BF16, nullptr));
+          if (form == 2) AK(asr_conv3x3_igemm(dg.p, dw7.p, nullptr, y0.p, z0.p, B, H, W, 128, 128, 0, ASR_BF16, nullptr));
+          if (form == 3) AK(asr_conv3x3_igemm_bits(dg.p, dw7.p, nullptr, dbits.p, z1.p, nullptr, B, H, W, 128, 128, 0, ASR_BF16, nullptr));
+        };
+        for (int i = 0; i < 2; ++i) go();
+        const int iters = 10;
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) go();
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        t[form].push_back(ms * 1e3 / iters);
+      }
+    for (int form = 0; form < 4; ++form) {
+      std::sort(t[form].begin(), t[form].end());
+      printf("    time %-28s median %7.1f us  (min %7.1f, max %7.1f)\n", names[form], t[form][3], t[form][0], t[form][6]);
+    }
+  }
+  return (bad_y || bad_z || bad_b) ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
   if (const char* e = getenv("WS64_PER_CU")) AK(asr_set_tuning("WS64_PER_CU", atoi(e)));
   const bool timing = argc < 2 || strcmp(argv[1], "parity") != 0;
   const bool parity = argc < 2 || strcmp(argv[1], "time") != 0;
   int fails = 0;
+  if (argc >= 2 && strcmp(argv[1], "bits") == 0) {
+    fails += run_bits(2, 21, 50, false);
+    fails += run_bits(32, 80, 400, true);
+    printf(fails ? "FAILED (%d cases)\n" : "OK\n", fails);
+    return fails ? 1 : 0;
+  }
   if (parity) {
     printf("== parity (exact-integer data)\n");
     const Case cases[] = {
@@ -204,6 +289,10 @@ int main(int argc, char** argv) {
     fails += run_case({2, 21, 50, 128, false, true, false, 64}, true);
     fails += run_case({2, 24, 48, 128, false, false, false, 64}, true);
     fails += run_case({9, 80, 400, 128, false, true, false, 64}, false);
+    fails += run_bits(1, 8, 16, false);
+    fails += run_bits(2, 21, 50, false);
+    fails += run_bits(2, 24, 48, false);
+    fails += run_bits(9, 80, 400, false);
   }
   if (timing) {
     printf("== timing (B = 32, 80 x 400)\n");
