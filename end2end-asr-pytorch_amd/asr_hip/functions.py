@@ -102,6 +102,24 @@ def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_d
     return dx
 
 
+# The output projection's data gradient IS the attention backward's dO: its epilogue also writes delta = rowsum(dO * O) per head
+# (asr_gemm_nn_rowdot), one dependent launch less per attention block.  A/B switch: 0 = asr_attn_bwd computes delta itself.
+_rowdot = os.environ.get("ASR_NN_ROWDOT", "1") != "0"
+
+
+def _out_proj_bwd(dy2d, o2d, o32, wparam, bparam, Tq, dk):
+    """(dO, delta or None) for MHAFn.backward: _linear_bwd of the output projection, with delta from the same launch where possible."""
+    N, K = wparam.shape[0], wparam.numel() // wparam.shape[0]
+    if (_rowdot and dk == 64 and ops.defer_wgrad_now(dy2d.dtype) and ops.gemm_tn_supported(dy2d, o2d) and o2d.dtype == dy2d.dtype):
+        W = P.linear_weight(wparam)
+        if W.shape[1] == K and ops.gemm_nn_supported(dy2d, W):
+            got = ops.gemm_nn_rowdot(dy2d, W, o2d, o32.view(-1, K) if o32 is not None else None, Tq)
+            if got is not None:
+                ops.queue_wgrad(dy2d, o2d, P.grad_of(wparam).view(N, K), P.grad_of(bparam) if bparam is not None else None, N, K)
+                return got[0], got[1].view(-1, K // 64, Tq)
+    return _linear_bwd(dy2d, o2d, wparam, bparam), None
+
+
 class _Fused:
     """Several projections that read the same input, run as ONE GEMM because their weights (and biases) are adjacent in
     the flat parameter buffers (FusedAdam lays Q/K/V out that way).  Duck-types the few things the helpers need."""
@@ -313,7 +331,7 @@ class MHAFn(Function):
         dout2 = dout.reshape(B * Tq, D).contiguous()
         d_res, d_y = ops.add_ln_bwd(dout2, Z, mean, rstd, gamma.data, cfg.get("row_keep"), P.grad_of(gamma),
                                     P.grad_of(beta), p=cfg["p"], seed=seed_o)
-        dO = _linear_bwd(d_y, O.view(B * Tq, HD), Wo, bo)
+        dO, delta = _out_proj_bwd(d_y, O.view(B * Tq, HD), O32, Wo, bo, Tq, dk)
         # gradient buffers mirror the forward layout so that the fused projections see one contiguous (M, 2|3*HD) operand
         if fused.ok and ctx.self_attn:
             dqkv = torch.empty((B, Tq, 3 * HD), device=dout.device, dtype=Q.dtype)
@@ -325,7 +343,7 @@ class MHAFn(Function):
         else:
             dQ, dK, dV = torch.empty_like(Q), torch.empty_like(K), torch.empty_like(V)
         ops.attn_bwd(Q, K, V, O, dO.view(B, Tq, HD), lse, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
-                     causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV), o32=O32)
+                     causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV), o32=O32, delta=delta)
         d_kv = None
         # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulated straight into d_res
         if fused.ok and ctx.self_attn:

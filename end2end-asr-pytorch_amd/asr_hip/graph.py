@@ -99,18 +99,24 @@ class GraphedTrainStep:
         self._one = False
         if os.environ.get("ASR_DDP_ONE_GRAPH", "0") != "1":
             return False
-        try:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.loss, self.sums = self._eager_step()
-        except Exception as e:               # noqa: BLE001 -- any capture failure: the proven form below
-            import logging
-            logging.warning("one-graph data-parallel capture failed (%r): four graphs with the collectives between them", e)
-            ops.reset_pending()
-            torch.cuda.synchronize()
-            return False
-        self.graph, self.graphs, self._one = g, [g], True
-        return True
+        import logging
+        for attempt in (1, 2):               # (one capture in ~20 raised on the GPU box while the collective library's watchdog was still polling the warm-up steps' work)
+            g = None
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.loss, self.sums = self._eager_step()
+            except Exception as e:           # noqa: BLE001 -- any capture failure: once more, then the proven form below
+                logging.warning("one-graph data-parallel capture failed, attempt %d (%r)", attempt, e)
+                ops.reset_pending()
+                torch.cuda.synchronize()
+                g = None
+                continue
+            self.graph, self.graphs, self._one = g, [g], True
+            return True
+        logging.warning("one-graph data-parallel capture: four graphs with the collectives between them instead")
+        return False
 
     # ------------------------------------------------------------------------------------------------ single GPU
     def _body_single(self):

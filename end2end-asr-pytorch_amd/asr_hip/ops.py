@@ -278,6 +278,23 @@ def gemm_nn(dy, w, out=None, accumulate=False, relu_mask=None, alpha=1.0):
     return out
 
 
+def gemm_nn_rowdot(dy, w, o, o32, T):
+    """(dx, rowdot): dx (M,K) = dy @ w (N,K) as gemm_nn, and rowdot (M / T, K / 64, T) fp32 = the sums of dx * o over each run of 64
+    columns (o32, the un-rounded fp32 copy of o, is used when given) -- the attention backward's delta from the epilogue of the GEMM
+    that produces dO.  None where the library has no such form (callers use gemm_nn and let attn_bwd compute delta)."""
+    M, (N, K) = dy.shape[0], w.shape
+    if dy.dtype != torch.bfloat16 or K % 64 != 0 or M % T != 0 or not o.is_contiguous() or o.numel() != M * K:
+        return None
+    dx = torch.empty((M, K), device=dy.device, dtype=dy.dtype)
+    rowdot = torch.empty((M // T, K // 64, T), device=dy.device, dtype=torch.float32)
+    rc = L.load().asr_gemm_nn_rowdot(L.ptr(dy), dy.stride(0), L.ptr(w), w.stride(0), L.ptr(dx), L.ptr(o), L.ptr(o32), L.ptr(rowdot),
+                                     M, K, N, T, L.dt(dy), L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_gemm_nn_rowdot")
+    return dx, rowdot
+
+
 _nn_tn = os.environ.get("ASR_NN_TN", "1") != "0"
 # larger weights keep the two-stream pair: their 128 x 128-tile weight-gradient kernel moves half the operand bytes per flop, which
 # is worth more than the fork / join it costs (512 x 5120 over 6400 rows: 112 us as a pair, 141 us as one launch)
@@ -484,8 +501,10 @@ def attn_fwd(q, k, v, H, d, key_len=None, key_pad=None, causal=False, scale=1.0,
     return o, lse, attn
 
 
-def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, out=None, o32=None):
-    """out: optional (dq, dk, dv) destination tensors; they must have the strides of q, k, v (the ABI reuses them)."""
+def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False, scale=1.0, p=0.0, seed=0, out=None, o32=None,
+             delta=None):
+    """out: optional (dq, dk, dv) destination tensors; they must have the strides of q, k, v (the ABI reuses them).
+    delta: rowsum(dO * O) (B, H, Tq) fp32 when the caller already has it (gemm_nn_rowdot) -- the delta launch is then skipped."""
     B, Tq, _ = q.shape
     Tk = k.shape[1]
     assert do.is_contiguous() and o.is_contiguous()
@@ -497,7 +516,11 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
     else:
         dq, dk, dv = out
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
-    delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
+    have_delta = delta is not None
+    if have_delta:
+        assert delta.shape == (B, H, Tq) and delta.dtype == torch.float32 and delta.is_contiguous()
+    else:
+        delta = torch.empty((B, H, Tq), device=q.device, dtype=torch.float32)
     msb, msq = _mask_strides(key_pad, B, Tq, Tk)
     qs, ks, vs, os_ = _bt_strides(q, H, d), _bt_strides(k, H, d), _bt_strides(v, H, d), _bt_strides(o, H, d)
     sd = _seed_dev(q)
@@ -508,7 +531,7 @@ def attn_bwd(q, k, v, o, do, lse, H, d, key_len=None, key_pad=None, causal=False
                L.ptr(key_len), L.ptr(key_pad), msb, msq, int(causal), float(scale), float(p), int(seed), sd, parts,
                L.dt(q), L.stream())
 
-    launch(L.ATTN_ALL)       # one launch for dQ and dK / dV (two launches on two streams cost a fork and a join: profiles/r02_ab_attn_both.txt)
+    launch(L.ATTN_DQ | L.ATTN_DKV if have_delta else L.ATTN_ALL)       # one launch for dQ and dK / dV (two launches on two streams cost a fork and a join: profiles/r02_ab_attn_both.txt)
     return dq, dk, dv
 
 

@@ -22,6 +22,8 @@ struct GemmArgs {
   int relu, accumulate, atomic, vecA, vecB, vecC;
   int tiles_n, ntiles;
   int ablate;          // -DASR_TUNE_ABLATE builds only (tuning "GEMM_ABLATE"): 1 = stage A once, 2 = stage B once (stale operands: timing only)
+  // NN, bf16 out (asr_gemm_nn_rowdot; gemm_big.h has the definition): the attention backward's delta from the block that is dO
+  const void* dot_o; const float* dot_o32; float* dot_out; int dot_T, dot_H;
 };
 
 constexpr int kPitch = 144;   // bytes per LDS tile row: 128 data + 16 pad (keeps 16-B alignment, breaks the 128-B stride)
@@ -1370,6 +1372,28 @@ __device__ __forceinline__ void gemm_nn_body(const GemmArgs& p, const int bid, c
               if (!(DT<T>::from(m.e[e]) > 0.f)) o.e[e] = DT<TO>::to(0.f);
           }
           *reinterpret_cast<uint4*>(C + (int64_t)gr * p.ldc + gc) = o.v;
+          if constexpr (sizeof(TO) == 2) {
+            if (p.dot_out) {
+              // the attention backward's delta = rowsum(dO * O) per head from the block that IS dO (asr_gemm_nn_rowdot; the lanes, the
+              // order of additions and therefore the bits of csrc/attention_fast.hip attn_delta_bf16_d64_kernel): 8 lanes = one head
+              const int64_t ooff = (int64_t)gr * p.N + gc;
+              float acc = 0.f;
+              if (p.dot_o32) {
+                const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(p.dot_o32 + ooff), o1 = *reinterpret_cast<const f32x4_t*>(p.dot_o32 + ooff + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc += o0[e] * bf16_to_f32(o.e[e]) + o1[e] * bf16_to_f32(o.e[4 + e]);
+              } else {
+                Chunk<bf16_t> f;
+                f.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.dot_o) + ooff);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += bf16_to_f32(f.e[e]) * bf16_to_f32(o.e[e]);
+              }
+              acc += __shfl_xor(acc, 4, 64);
+              acc += __shfl_xor(acc, 2, 64);
+              acc += __shfl_xor(acc, 1, 64);
+              if ((c % CPRO) == 0) p.dot_out[((int64_t)(gr / p.dot_T) * p.dot_H + (gc >> 6)) * p.dot_T + gr % p.dot_T] = acc;
+            }
+          }
         }
       } else {
 #pragma unroll
@@ -2009,6 +2033,29 @@ extern "C" int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ld
     return launch_nn<bf16_t, bf16_t, 64, 3>(p, stream);
   if (out_dtype == ASR_BF16) return big ? launch_nn<bf16_t, bf16_t, 128>(p, stream) : launch_nn<bf16_t, bf16_t, 64>(p, stream);
   return big ? launch_nn<bf16_t, float, 128>(p, stream) : launch_nn<bf16_t, float, 64>(p, stream);
+}
+
+// asr_gemm_nn (bf16, alpha = 1, no mask, no +=) whose epilogue also writes the attention backward's delta (include/asr_hip.h)
+extern "C" int asr_gemm_nn_rowdot(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, const void* O, const float* O32,
+                                  float* rowdot, int M, int N, int K, int T, int dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(A && B && C && (O || O32) && rowdot && M >= 0 && N >= 0 && K >= 0 && T > 0);
+  if (dtype != ASR_BF16 || N % 64 != 0 || M % T != 0 || asr_tuning("NN_ROWDOT", 1) == 0) return ASR_EUNSUPPORTED;
+  if (M == 0 || N == 0) return ASR_OK;
+  if (K <= 0 || lda % 8 != 0 || ldb % 8 != 0 || !aligned16(A) || !aligned16(B) || !aligned16(C) || (O && !aligned16(O)) ||
+      (O32 && !aligned16(O32)) || ldb < N || lda < (K + 63) / 64 * 64)
+    return ASR_EUNSUPPORTED;
+  AsrProfScope prof(ASR_OP_GEMM, stream);
+  BigGemmArgs q{};
+  q.A = A; q.B = B; q.C = C; q.lda = lda; q.ldb = ldb; q.ldc = N; q.M = M; q.N = N; q.K = K; q.alpha = 1.f;
+  q.dot_o = O; q.dot_o32 = O32; q.dot_out = rowdot; q.dot_T = T; q.dot_H = N / 64;
+  if (asr_gemm_big_nn(q, stream)) return ASR_OK;
+  GemmArgs p{};
+  p.A = A; p.B = B; p.C = C; p.lda = lda; p.ldb = ldb; p.ldc = N; p.M = M; p.N = N; p.K = K; p.alpha = 1.f;
+  p.vecC = 1;
+  p.dot_o = O; p.dot_o32 = O32; p.dot_out = rowdot; p.dot_T = T; p.dot_H = N / 64;
+  const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
+  if (t64 <= asr_tuning("NN_RING", 512) && K >= 256) return launch_nn<bf16_t, bf16_t, 64, 3>(p, stream);
+  return launch_nn<bf16_t, bf16_t, 64>(p, stream);
 }
 
 // ---- one launch for a linear layer's backward: dx (M,K) (+)= dy (M,N) . w (N,K) [ReLU mask]  AND  the partial sums of

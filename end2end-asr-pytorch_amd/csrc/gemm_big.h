@@ -11,6 +11,9 @@ struct BigGemmArgs {
   int M, N, K;
   float alpha;
   int relu, accumulate, out_f32;
+  // NN only (asr_gemm_nn_rowdot): dot_out[(b H + h) T + q] = sum_{d < 64} C[b T + q][64 h + d] * O[b T + q][64 h + d] with the ROUNDED C;
+  // O = dot_o32 (fp32, row stride N) if given, else dot_o (bf16, row stride N).  N = 64 H.
+  const void* dot_o; const float* dot_o32; float* dot_out; int dot_T, dot_H;
 };
 
 // -> true when the shape / layout is taken (launched on `stream`), false when the caller should use the four-wave kernels.

@@ -320,6 +320,26 @@ __global__ __launch_bounds__(512, 2) void gemm_big_nn_kernel(BigGemmArgs p, int 
 #pragma unroll
       for (int e = 0; e < 8; ++e) o.e[e] = f32_to_bf16(v[e]);
       *reinterpret_cast<uint4*>(C + off) = o.v;
+      if (p.dot_out) {
+        // the attention backward's delta = rowsum(dO * O) per head from the block that IS dO (csrc/attention_fast.hip
+        // attn_delta_bf16_d64_kernel, same lanes per row, same order of additions: the same bits): 8 lanes = the 64 columns of a head
+        const int64_t ooff = (int64_t)grow * p.N + gcol;
+        float acc = 0.f;
+        if (p.dot_o32) {
+          const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(p.dot_o32 + ooff), o1 = *reinterpret_cast<const f32x4_t*>(p.dot_o32 + ooff + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc += o0[e] * bf16_to_f32(o.e[e]) + o1[e] * bf16_to_f32(o.e[4 + e]);
+        } else {
+          Chunk<bf16_t> f;
+          f.v = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(p.dot_o) + ooff);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc += bf16_to_f32(f.e[e]) * bf16_to_f32(o.e[e]);
+        }
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 1, 64);
+        if ((pc & 7) == 0) p.dot_out[((int64_t)(grow / p.dot_T) * p.dot_H + (gcol >> 6)) * p.dot_T + grow % p.dot_T] = acc;
+      }
     }
   }
 }
@@ -368,6 +388,7 @@ bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
 bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream) {
   const int mode = (int)asr_tuning("GEMM_BIG_NN", 1);         // 0: off; 1: automatic; 2: always (tests)
   if (mode == 0 || p.out_f32 || p.bias != nullptr || p.relu) return false;
+  if (p.dot_out && (p.N % 64 != 0 || p.accumulate || p.mask || p.N != p.dot_H * 64)) return false;
   if (p.K <= 0 || p.K % 64 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0 || p.N % 8 != 0 || !aligned16(p.A) || !aligned16(p.B) ||
       !aligned16(p.C) || (p.mask && !aligned16(p.mask)) || p.lda < p.K || p.ldb < p.N)
     return false;

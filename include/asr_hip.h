@@ -90,6 +90,14 @@ int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, cons
  * whole stage and the caller guarantees A[:, K:] == 0 there (B's rows are clamped), else ASR_EUNSUPPORTED.              */
 int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask, int M,
                 int N, int K, float alpha, int flags, int in_dtype, int out_dtype, asr_stream_t stream);
+/* The data gradient that IS the attention backward's dO (the output projection's, models/common_layers.py:190-198 under autograd),
+ * with the softmax backward's row term from the same epilogue: C (M, N) bf16 = A (M, K) . B (K, N) as asr_gemm_nn (alpha = 1, no mask,
+ * no +=, ldc = N), and rowdot[(b H + h) T + q] = sum_{d < 64} C[b T + q][64 h + d] * O[b T + q][64 h + d] with the ROUNDED C, H = N / 64,
+ * O = O32 (fp32, the un-rounded attention output) when given, else O (bf16); both (M, N) contiguous.  This is asr_attn_bwd's `delta`
+ * (then called without ASR_ATTN_DELTA): one dependent launch less per attention block.  bf16, N % 64 == 0, M % T == 0, else
+ * ASR_EUNSUPPORTED (callers keep asr_gemm_nn + ASR_ATTN_DELTA).                                                          */
+int asr_gemm_nn_rowdot(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, const void* O, const float* O32,
+                       float* rowdot, int M, int N, int K, int T, int dtype, asr_stream_t stream);
 /* A linear layer's whole backward in ONE launch (every nn.Linear / Conv1d(k=1) of models/common_layers.py:136-142,181-197 under
  * autograd): dx (M,K) (+)= dy (M,N) . w (N,K) [flags: ASR_GEMM_ACCUMULATE; relu_mask as in asr_gemm_nt] from the data-gradient
  * workgroups of asr_gemm_nn, and next to them in the same grid the weight-gradient workgroups: the partial 64 x 64 tiles of

@@ -199,12 +199,14 @@ def test_collectives_captured_inside_one_graph_equal_the_plain_step():
         env.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        return json.loads(r.stdout.strip().splitlines()[-1])
+        out = json.loads(r.stdout.strip().splitlines()[-1])
+        out["_stderr_tail"] = r.stderr[-1500:]
+        return out
 
     plain = run({})
     one = run({"ASR_FORCE_DDP": "1", "ASR_DDP_ONE_GRAPH": "1"})
     four = run({"ASR_FORCE_DDP": "1"})
-    assert "ONE hipGraph" in one["launch_mode"], one["launch_mode"]
+    assert "ONE hipGraph" in one["launch_mode"], (one["launch_mode"], one["_stderr_tail"])
     assert "4 hipGraphs" in four["launch_mode"], four["launch_mode"]
     assert one["config"]["collective_backend"] == "nccl" and one["config"]["collective_library"].startswith("RCCL")
     lp, lo, lf = plain["config"]["final_loss"], one["config"]["final_loss"], four["config"]["final_loss"]

@@ -184,6 +184,47 @@ def test_gemm_nn_data_gradient(ops, dtype, shape):
     close("nn relu mask", out, (dy @ w) * (mask > 0), dtype)
 
 
+@pytest.mark.parametrize("M,T,N,K,big", [(6400, 200, 512, 512, 1), (3200, 100, 512, 512, 0), (12720, 795, 512, 512, 1), (1590, 795, 512, 512, 0),
+                                         (600, 100, 128, 192, 0), (600, 100, 128, 192, 2)])
+@pytest.mark.parametrize("use_o32", [True, False])
+def test_gemm_nn_rowdot_is_the_attention_delta(ops, M, T, N, K, big, use_o32):
+    """asr_gemm_nn_rowdot: the output projection's data gradient (dO of the attention backward) and, from the same epilogue, delta =
+    rowsum(dO * O) per head (reference: autograd of models/common_layers.py:211-225's softmax(QK^T)V -- the softmax backward's row
+    term).  dO must be asr_gemm_nn's bits; delta must be what asr_attn_bwd's own delta launch computes from that dO (compared through
+    the attention backward itself: the same dQ / dK / dV bits -- both GEMM kernels add in the delta kernel's lanes and order) and the
+    fp64 row sums of the ROUNDED dO within fp32 summation error."""
+    from asr_hip import lib as L
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(M + N)
+    D = dev()
+    H, B = N // 64, M // T
+    dy = torch.randn(M, K, generator=g).to(D).to(bf)
+    w = (torch.randn(K, N, generator=g) * K ** -0.5).to(D).to(bf)
+    o32 = torch.randn(M, N, generator=g).to(D)
+    o = o32.to(bf)
+    L.set_tuning("GEMM_BIG_NN", big if big != 1 else None)
+    try:
+        want_dx = ops.gemm_nn(dy, w)
+        got = ops.gemm_nn_rowdot(dy, w, o, o32 if use_o32 else None, T)
+    finally:
+        L.set_tuning("GEMM_BIG_NN", None)
+    assert got is not None
+    dx, delta = got
+    assert torch.equal(dx, want_dx)
+    ref = (dx.double() * (o32 if use_o32 else o).double()).view(B, T, H, 64).sum(-1).permute(0, 2, 1)      # (B, H, T)
+    scale = (dx.double().abs() * (o32 if use_o32 else o).double().abs()).view(B, T, H, 64).sum(-1).permute(0, 2, 1)
+    assert delta.shape == (B, H, T)
+    assert ((delta.double() - ref).abs() <= 8e-6 * scale + 1e-30).all()           # 64 products and their fp32 sum
+    # through the attention backward: delta handed in against delta computed by asr_attn_bwd's own launch
+    q_, k_, v_ = (torch.randn(B, T, N, generator=g).to(D).to(bf) for _ in range(3))
+    lse = torch.randn(B, H, T, generator=g).to(D).abs() + 6.0
+    a = ops.attn_bwd(q_, k_, v_, o.view(B, T, N), dx.view(B, T, N), lse, H, 64, scale=0.125, o32=o32.view(B, T, N) if use_o32 else None)
+    b = ops.attn_bwd(q_, k_, v_, o.view(B, T, N), dx.view(B, T, N), lse, H, 64, scale=0.125, o32=o32.view(B, T, N) if use_o32 else None,
+                     delta=delta)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 @pytest.fixture
 def four_wave_nn():
     """asr_gemm_nn on the four-wave kernel only (GEMM_BIG_NN = 0) for the duration of a test."""
