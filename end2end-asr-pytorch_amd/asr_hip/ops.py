@@ -96,11 +96,12 @@ class fork:
 # data-parallel step, whose reducer only exchanges between graphs.)
 _defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
-WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "32"))      # layers per grouped launch (<= 32: asr_gemm_tn_grouped); 16 / 24 / 32 measured: profiles/r03_grouped_wgrad_group_size_ab.txt
+WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "48"))      # layers per grouped launch (<= 48: asr_gemm_tn_grouped).  Round 5: whole-contraction blocks dispatched longest first want the LARGEST group (the headline's 46 layers are one launch of 503 blocks); round 3's equal pieces: 16 / 24 / 32 measured, profiles/r03_grouped_wgrad_group_size_ab.txt
 # a group is also closed once it holds this many 64-row stages of 256 x 256 blocks (about 150 per workgroup of the scheduled kernel):
 # with 12 720 rows per layer (configs[3]) groups of 16 layers measure 0.3 - 0.5 ms per step faster than groups of 32, with 6 400 rows
 # groups of 32 are the faster ones -- both are ~38 000 stages.  profiles/r03_grouped_wgrad_group_size_ab.txt
-WGRAD_STAGES = int(os.environ.get("ASR_WGRAD_STAGES", "38000"))
+# (round 5: off by default -- it was tuned for the equal-piece kernel; 38000 restores round 3's grouping together with ASR_TN_ROT=0)
+WGRAD_STAGES = int(os.environ.get("ASR_WGRAD_STAGES", "0"))
 _wgrad_stages = [0]
 
 
@@ -180,7 +181,7 @@ def _tn_group_ok(e):
 
 
 def gemm_tn_grouped(grp):
-    """grp: up to 32 tuples (dy (M,>=N) bf16, x (M,>=K) bf16, dw (N,K) fp32, db (N) fp32 or None, N, K): dw += dy[:, :N]^T x[:, :K] and
+    """grp: up to 48 tuples (dy (M,>=N) bf16, x (M,>=K) bf16, dw (N,K) fp32, db (N) fp32 or None, N, K): dw += dy[:, :N]^T x[:, :K] and
     db += column sums of dy for all of them in one launch (asr_gemm_tn_grouped); problems whose layout the grouped kernel does not
     take (a row stride that is not a whole number of 16-byte chunks) go through the per-layer kernel, the others stay grouped."""
     import ctypes

@@ -1142,27 +1142,249 @@ __device__ __forceinline__ void tn256_body(const Tn128Args& p, unsigned char* sm
   }
 }
 
+// ---- the same block with the operand reads of stage s + 1 issued UNDER the MFMAs of stage s (round 5).  What the loop above costs
+// per 32-MFMA stage, from its ISA and the PMC pass (profiles/r05_step_mfma_pmc.txt: 26.7 % MFMA-busy, 4.4 vector instructions per MFMA):
+// all 24 transposing reads are issued behind the barrier and the first MFMA waits for them, with BOTH waves of a SIMD in that same
+// phase (the barrier aligned them); three vector instructions of address arithmetic per read (the ring offset is recomputed per read);
+// and a scalar reload of lda / ldb from the kernel arguments with its s_waitcnt lgkmcnt(0) right behind the barrier.  Here:
+//   * a fragment's registers are reloaded for the NEXT stage as soon as their last MFMA of this stage has issued -- a[i] behind row i
+//     (MFMAs (i, 0..7)), b[j] behind MFMA (3, j) -- by hand-issued ds_read_b64_tr_b16 with counted s_waitcnt lgkmcnt in row 0 of the
+//     next stage (LDS returns in order; at most 15 reads may stay outstanding, which is what row 0's first MFMA needs anyway);
+//   * the barrier that publishes stage s + 1 (and frees stage s's buffer for the DMA of stage s + 3) sits behind row 0 of stage s,
+//     after an s_waitcnt lgkmcnt(0) that is free by then (the reads of stage s were issued a row or more ago);
+//   * twelve lane offsets (4 + 8 fragments; the second half of a fragment is offset:2048 of the same address: row + 4 has the row's
+//     swizzle key) + ONE add per fragment and stage for the ring position; every kernel argument the loop needs is in registers before
+//     it (no scalar load, hence nothing else on lgkmcnt).
+// Same LDS image, same DMA, same MFMA order per accumulator as tn256_body: the same bits.
+typedef __attribute__((ext_vector_type(2))) unsigned int tn_u32x2_t;
+__device__ __forceinline__ tn_u32x2_t tn_tr_read(unsigned addr, const int off2048) {
+  tn_u32x2_t v;
+  if (off2048) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(v) : "v"(addr));
+  else asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+#define TN_FRAG_READ(F, ADDR) { const tn_u32x2_t lo_ = tn_tr_read(ADDR, 0), hi_ = tn_tr_read(ADDR, 1); F = u32x4_t{lo_.x, lo_.y, hi_.x, hi_.y}; }
+template <int N> __device__ __forceinline__ void tn_wait_lgkm(u32x4_t& x, u32x4_t& y) {
+  asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
+}
+__device__ __forceinline__ void tn_mma(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+}
+
+template <int NST>
+__device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* smem, int tile, int m_beg, int m_end, bool single) {
+  static_assert(NST == 3, "ring of three stages");
+  constexpr int RM = 32, TILEB = RM * 512, STAGEB = 2 * TILEB;
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 1, wk = wave & 1;
+  // every argument the loop touches, in registers before it
+  const int64_t lda2 = p.lda * 2, ldb2 = p.ldb * 2;
+  const int pM = p.M, pN = p.N, pK = p.K;
+  const unsigned char* A = static_cast<const unsigned char*>(p.A);
+  const unsigned char* B = static_cast<const unsigned char*>(p.B);
+  float* const C = p.C;
+  float* const colsum = p.colsum;
+  const int64_t ldc = p.ldc;
+  const int n0 = (tile / p.tiles_k) * 256, k0 = (tile % p.tiles_k) * 256;
+  const int nstage = (m_end - m_beg + RM - 1) / RM;
+  const int a_chunks = (int)(lda2 / 16), b_chunks = (int)((p.ldb >= pK ? p.ldb : (int64_t)((pK + 7) / 8 * 8)) * 2 / 16);
+  asm volatile("" ::"s"(lda2), "s"(ldb2), "s"(pM), "s"(pN), "s"(pK), "s"(A), "s"(B), "s"(C), "s"(colsum), "s"(ldc), "s"(n0), "s"(k0), "s"(nstage));
+
+  int64_t offA[2], offB[2];
+  int rowi[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid, row = c >> 5, slot = (c & 31) ^ tn256_key(row);
+    int ca = n0 * 2 / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;
+    int cb = k0 * 2 / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
+    offA[i] = (int64_t)row * lda2 + (int64_t)ca * 16;
+    offB[i] = (int64_t)row * ldb2 + (int64_t)cb * 16;
+    rowi[i] = row;
+  }
+  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(&tn_zero_page);
+  const unsigned char* ba = A + (int64_t)m_beg * lda2;        // rows of the stage being staged next: advanced by 32 rows per call
+  const unsigned char* bb = B + (int64_t)m_beg * ldb2;
+  int staged = 0;                                              // stages handed to the DMA so far
+  unsigned ring_w = 0;                                         // ring position (bytes) of the next stage to stage
+  auto stage = [&]() __attribute__((always_inline)) {
+    const unsigned sl = wave_lds + ring_w;
+    const int valid = m_end - m_beg - staged * RM;
+    if (valid >= RM) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        tn_dma(sl + i * 8192, ba + offA[i]);
+        tn_dma(sl + TILEB + i * 8192, bb + offB[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bool in = rowi[i] < valid;
+        tn_dma(sl + i * 8192, in ? ba + offA[i] : zero);
+        tn_dma(sl + TILEB + i * 8192, in ? bb + offB[i] : zero);
+      }
+    }
+    ba += RM * lda2; bb += RM * ldb2;
+    ++staged;
+    ring_w = ring_w == 2u * STAGEB ? 0u : ring_w + STAGEB;
+  };
+
+  // fragment read offsets inside a stage: row 8 g + (lr >> 2) (+ 4: offset 2048), column c0 + 4 (lr & 3)
+  const int frow = 8 * g + (lr >> 2), fkey = tn256_key(frow);
+  unsigned fa[4], fb[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int col = wn * 64 + i * 16 + 4 * (lr & 3);
+    fa[i] = smem_base + (unsigned)(frow * 512 + (((col >> 3) ^ fkey) << 4) + ((col >> 2) & 1) * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = wk * 128 + j * 16 + 4 * (lr & 3);
+    fb[j] = smem_base + (unsigned)(TILEB + frow * 512 + (((col >> 3) ^ fkey) << 4) + ((col >> 2) & 1) * 8);
+  }
+
+  f32x4_t acc[4][8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool do_colsum = colsum != nullptr && k0 == 0 && wk == 0;
+  auto addsum = [&](int i, const u32x4_t& v) __attribute__((always_inline)) {
+    Chunk<bf16_t> c; c.v = make_uint4(v.x, v.y, v.z, v.w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
+  };
+
+  // prologue: stages 0 .. 2 on their way, stage 0 landed and published, its fragments requested
+  for (int st = 0; st < NST && st < nstage; ++st) stage();
+  if (nstage >= 3) wait_vmcnt<8>(); else if (nstage == 2) wait_vmcnt<4>(); else wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  u32x4_t a[4], b[8];
+  unsigned ring_r = 0;                                         // ring position of the stage whose fragments are requested next
+#pragma unroll
+  for (int i = 0; i < 3; ++i) TN_FRAG_READ(a[i], fa[i] + ring_r)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) TN_FRAG_READ(b[j], fb[j] + ring_r)
+  TN_FRAG_READ(a[3], fa[3] + ring_r)
+  ring_r = STAGEB;
+
+  for (int st = 0; st < nstage; ++st) {
+    // ---- row 0: the only waits of the stage.  Requests in flight, oldest first: a0 a1 a2 b0 .. b7 a3 (two reads each)
+    tn_wait_lgkm<15>(a[0], b[0]);
+    if (do_colsum) addsum(0, a[0]);
+    tn_mma(acc[0][0], b[0], a[0]);
+    tn_wait_lgkm<14>(a[0], b[1]); tn_mma(acc[0][1], b[1], a[0]);
+    tn_wait_lgkm<12>(a[0], b[2]); tn_mma(acc[0][2], b[2], a[0]);
+    tn_wait_lgkm<10>(a[0], b[3]); tn_mma(acc[0][3], b[3], a[0]);
+    tn_wait_lgkm<8>(a[0], b[4]);  tn_mma(acc[0][4], b[4], a[0]);
+    tn_wait_lgkm<6>(a[0], b[5]);  tn_mma(acc[0][5], b[5], a[0]);
+    tn_wait_lgkm<4>(a[0], b[6]);  tn_mma(acc[0][6], b[6], a[0]);
+    tn_wait_lgkm<2>(a[0], b[7]);  tn_mma(acc[0][7], b[7], a[0]);
+    // ---- stage st + 1 published (every wave's pieces landed), stage st's buffer free (every wave's reads of it returned)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    if (st + 2 < nstage) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (staged < nstage) stage();                              // stage st + 3 into the buffer of stage st
+    // (past the last stage the requests below fetch stale bytes of the ring that nobody uses)
+    TN_FRAG_READ(a[0], fa[0] + ring_r)
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+      if (do_colsum) addsum(i, a[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        tn_mma(acc[i][j], b[j], a[i]);
+        if (i == 3) TN_FRAG_READ(b[j], fb[j] + ring_r)
+      }
+      TN_FRAG_READ(a[i], fa[i] + ring_r)
+    }
+    ring_r = ring_r == 2u * STAGEB ? 0u : ring_r + STAGEB;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stale requests of the last stage: the next piece rewrites the ring
+
+  // ---- epilogue.  The MFMAs ran with the operands swapped (k rows, n columns): lane (lr, g) holds, of fragment (i, j), the FOUR
+  // consecutive k = k0 + wk 128 + 16 j + 4 g .. + 3 of row n = n0 + wn 64 + 16 i + lr -- 16 contiguous bytes of dW
+  const bool vec = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gn = n0 + wn * 64 + i * 16 + lr;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int gk = k0 + wk * 128 + j * 16 + g * 4;
+      if (gn >= pN || gk >= pK) continue;
+      float* dst = C + (int64_t)gn * ldc + gk;
+      if (single && vec && gk + 4 <= pK) {
+        f32x4_t v = *reinterpret_cast<const f32x4_t*>(dst);
+        v += acc[i][j];
+        *reinterpret_cast<f32x4_t*>(dst) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (gk + r < pK) { if (single) dst[r] += acc[i][j][r]; else atomicAdd(dst + r, acc[i][j][r]); }
+      }
+    }
+  }
+  if (do_colsum) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float v = bsum[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int gn = n0 + wn * 64 + i * 16 + lr;
+      if (g == 0 && gn < pN) atomicAdd(colsum + gn, v);
+    }
+  }
+}
+#undef TN_FRAG_READ
+
 // ---- grouped form: the weight gradients of up to TN_GROUP_MAX linear layers in ONE launch.  A weight gradient is off the
 // critical path of backward (only the data gradient feeds the next layer), and alone it is latency bound: 16 - 64 blocks of dW, each
 // a serial chain over all M rows.  Queued and launched together at the end of backward, the layers' blocks fill the chip
 // (~1900 blocks of 128 x 128 for the 4-layer model), every block contracts ALL rows of its layer (no m-split: no partial-sum
 // workspace, no fold pass, plain += into the fp32 gradient), longest layers first.
-constexpr int TN_GROUP_MAX = 32;
+constexpr int TN_GROUP_MAX = 48;
+struct TnGroupProb {                  // Tn128Args in 72 bytes: 48 problems + their prefix sums stay inside the 4 KB of kernel arguments
+  const void* A; const void* B; float* C; float* colsum;
+  int lda, ldb, ldc, M, N, K, m_per_split, tiles_k, ntiles, pad;
+};
 struct TnGroupArgs {
-  Tn128Args p[TN_GROUP_MAX];
+  TnGroupProb p[TN_GROUP_MAX];
   int first[TN_GROUP_MAX + 1];       // first[i] = number of blocks of the problems before i
   int n;
 };
-template <int NST>
+static_assert(sizeof(TnGroupArgs) + 16 <= 4096, "kernel argument segment");
+__device__ __forceinline__ Tn128Args tn_group_prob(const TnGroupArgs& ga, int i) {
+  const TnGroupProb& q = ga.p[i];
+  Tn128Args p;
+  p.A = q.A; p.B = q.B; p.C = q.C; p.colsum = q.colsum; p.ws = nullptr;
+  p.lda = q.lda; p.ldb = q.ldb; p.ldc = q.ldc;
+  p.M = q.M; p.N = q.N; p.K = q.K; p.m_per_split = q.m_per_split; p.tiles_k = q.tiles_k; p.ntiles = q.ntiles;
+  return p;
+}
+template <int NST, bool ROT = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
-  const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  // ROT (whole-contraction blocks, longest first): workgroups are dispatched in blockIdx order as CUs free up, so the list must be
+  // walked in that order -- in rounds of 256 (one per CU), and inside a round the 32 blocks of an XCD are consecutive list entries
+  // (blocks of one problem share operand columns in that XCD's L2)
+  int wid;
+  if constexpr (ROT) {
+    const int base = bid & ~255, left = min(256, nwg - base), q = left >> 3, r = left & 7, b = bid - base;
+    wid = base + ((b & 7) < r ? (b & 7) * (q + 1) : r * (q + 1) + ((b & 7) - r) * q) + (b >> 3);
+  } else {
+    wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
+  }
   int i = 0;
   while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
-  const Tn128Args& p = ga.p[i];
+  const Tn128Args p = tn_group_prob(ga, i);
   const int w = wid - ga.first[i], split = w / p.ntiles, m_beg = split * p.m_per_split;
-  tn256_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
+  if constexpr (ROT) tn256r_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
+  else tn256_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
 }
 
 // ---- the same blocks, scheduled by the host: the launch is ONE workgroup per CU and every workgroup gets the same number of 32-row
@@ -1184,7 +1406,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256s_kernel(TnGroupArgs ga, int
   bool again = false;
   while (x < x1) {
     while (i + 1 < ga.n && x >= ga.first[i + 1]) ++i;
-    const Tn128Args& p = ga.p[i];
+    const Tn128Args p = tn_group_prob(ga, i);
     const int spb = p.m_per_split;                         // stages of one block of this problem
     const int w = x - ga.first[i], tile = w / spb, st0 = w % spb;
     const int st1 = min(spb, st0 + (x1 - x));
@@ -1201,7 +1423,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128g_kernel(TnGroupArgs ga) {
   const int wid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (bid >> 3);
   int i = 0;
   while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
-  tn128p_body<NST>(ga.p[i], smem, wid - ga.first[i], true);
+  tn128p_body<NST>(tn_group_prob(ga, i), smem, wid - ga.first[i], true);
 }
 
 __global__ __launch_bounds__(256) void tn128_reduce_kernel(const float* __restrict__ ws, float* C, int64_t ldc, int N, int K,
@@ -1925,7 +2147,7 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     if (M[i] == 0 || N[i] == 0 || K[i] == 0) continue;   // an empty problem adds nothing (its pointers may be null)
     ASR_CHECK_ARG(dy[i] && x[i] && dw[i]);
     if (ld_dy[i] % 8 != 0 || ld_x[i] % 8 != 0 || !aligned16(dy[i]) || !aligned16(x[i]) || ld_dy[i] < N[i] ||
-        ld_dy[i] >= ((int64_t)1 << 22) || ld_x[i] >= ((int64_t)1 << 22))
+        ld_dy[i] >= ((int64_t)1 << 22) || ld_x[i] >= ((int64_t)1 << 22) || ld_dw[i] >= ((int64_t)1 << 31))
       return ASR_EUNSUPPORTED;
     order[cnt++] = i;
   }
@@ -1946,12 +2168,18 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
   const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 3200);
   int max_m = 0;
   for (int j = 0; j < cnt; ++j) max_m = M[order[j]] > max_m ? M[order[j]] : max_m;
-  const bool big = tmode != 128, sched = tmode == 1 || (tmode == 0 && max_m < asr_tuning("TN_GROUP_SLICE_MIN", 9600));
+  // TN_ROT (default 1, round 5): tn256r_body, and ONE workgroup per block of dW over the WHOLE contraction, dispatched longest
+  // first -- no block is shared between workgroups, so no fp32 atomics and a vector epilogue: round 3's equal pieces shared almost
+  // every block (pieces of 130 - 160 stages against blocks of 100 / 200), and the 65 536 atomics per visit were a quarter of the
+  // launch (profiles/r05_tn_grouped.txt).  0: round 3's forms below.
+  const bool nst4 = asr_tuning("TN_GROUP_STAGES", 3) == 4;
+  const bool rot = !nst4 && tmode == 0 && asr_tuning("TN_ROT", 1) != 0;
+  const bool big = tmode != 128, sched = !rot && (tmode == 1 || (tmode == 0 && max_m < asr_tuning("TN_GROUP_SLICE_MIN", 9600)));
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];
-    Tn128Args& q = ga.p[j];
-    q.A = dy[i]; q.B = x[i]; q.C = dw[i]; q.colsum = db[i]; q.ws = nullptr;
-    q.lda = ld_dy[i]; q.ldb = ld_x[i]; q.ldc = ld_dw[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
+    TnGroupProb& q = ga.p[j];
+    q.A = dy[i]; q.B = x[i]; q.C = dw[i]; q.colsum = db[i];
+    q.lda = (int)ld_dy[i]; q.ldb = (int)ld_x[i]; q.ldc = (int)ld_dw[i]; q.M = M[i]; q.N = N[i]; q.K = K[i];
     const int T = big ? 256 : 128;
     q.tiles_k = (K[i] + T - 1) / T;
     q.ntiles = ((N[i] + T - 1) / T) * q.tiles_k;
@@ -1962,7 +2190,7 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
       continue;
     }
     int splits = 1;
-    if (big && mrows > 0) splits = (M[i] + mrows - 1) / mrows;
+    if (big && mrows > 0 && !rot) splits = (M[i] + mrows - 1) / mrows;
     if (splits < 1) splits = 1;
     q.m_per_split = ((M[i] + splits - 1) / splits + 31) / 32 * 32;
     splits = (M[i] + q.m_per_split - 1) / q.m_per_split;
@@ -1978,10 +2206,10 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     granted = true;
   }
   AsrProfScope prof(ASR_OP_GEMM, stream);
-  const bool nst4 = asr_tuning("TN_GROUP_STAGES", 3) == 4;
   if (sched) {
     // one workgroup per CU (TN_GROUP_WGS), at least 16 stages each; pieces of equal length
     int nwg = (int)asr_tuning("TN_GROUP_WGS", 256);
@@ -1993,6 +2221,7 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     else hipLaunchKernelGGL(gemm_tn256s_kernel<3>, dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
   } else if (big) {
     if (nst4) hipLaunchKernelGGL(gemm_tn256g_kernel<4>, dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
+    else if (rot) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
     else hipLaunchKernelGGL(gemm_tn256g_kernel<3>, dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
   } else if (nst4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);
   else hipLaunchKernelGGL(gemm_tn128g_kernel<3>, dim3((unsigned)total), dim3(256), 3 * 16384, stream, ga);

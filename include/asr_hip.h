@@ -76,11 +76,11 @@ int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ldb, float* C
                 float* workspace, int64_t workspace_floats, int M, int N, int K, int splits, int dtype,
                 asr_stream_t stream);
 
-/* The weight (and bias) gradients of up to 32 linear layers in ONE launch: dw[i] (N[i],K[i]) fp32 += dy[i][:, :N]^T x[i][:, :K],
+/* The weight (and bias) gradients of up to 48 linear layers in ONE launch: dw[i] (N[i],K[i]) fp32 += dy[i][:, :N]^T x[i][:, :K],
  * db[i] (N[i]) += column sums of dy[i] (db[i] may be NULL), each over M[i] rows; bf16 operands with 16-byte aligned rows.  A weight
  * gradient is off the critical path of backward (models/common_layers.py:136-142,181-187 leave it to autograd's order): queued and
  * launched together the layers fill the chip where each alone is a latency-bound chain of 16 - 64 blocks.  Arrays are HOST
- * arrays of n entries (n <= 32); returns ASR_EUNSUPPORTED when a layout does not fit (the caller then uses asr_gemm_tn per layer). */
+ * arrays of n entries (n <= 48; 32 until round 4); returns ASR_EUNSUPPORTED when a layout does not fit (the caller then uses asr_gemm_tn per layer). */
 int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
                         float* const* dw, const int64_t* ld_dw, float* const* db, const int* M, const int* N, const int* K,
                         int dtype, asr_stream_t stream);
