@@ -8,6 +8,10 @@
 // register-staged global->LDS with the next tile's loads issued before the current tile's MFMAs.
 #include <stdlib.h>
 
+#include <algorithm>
+#include <queue>
+#include <utility>
+#include <vector>
 #include "common.h"
 #include "gemm_big.h"
 
@@ -1167,11 +1171,13 @@ __device__ __forceinline__ tn_u32x2_t tn_tr_read(unsigned addr, const int off204
 template <int N> __device__ __forceinline__ void tn_wait_lgkm(u32x4_t& x, u32x4_t& y) {
   asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(x), "+v"(y) : "n"(N));
 }
-__device__ __forceinline__ void tn_mma(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
+// SWAP: the fragment comes out transposed (k rows, n columns) -- a lane then holds four CONSECUTIVE k of one row of dW
+template <bool SWAP> __device__ __forceinline__ void tn_mma2(f32x4_t& acc, const u32x4_t& a, const u32x4_t& b) {
+  if constexpr (SWAP) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b), __builtin_bit_cast(bf16x8_t, a), acc, 0, 0, 0);
+  else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
-template <int NST>
+template <int NST, bool SWAP>
 __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* smem, int tile, int m_beg, int m_end, bool single) {
   static_assert(NST == 3, "ring of three stages");
   constexpr int RM = 32, TILEB = RM * 512, STAGEB = 2 * TILEB;
@@ -1276,14 +1282,14 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
     // ---- row 0: the only waits of the stage.  Requests in flight, oldest first: a0 a1 a2 b0 .. b7 a3 (two reads each)
     tn_wait_lgkm<15>(a[0], b[0]);
     if (do_colsum) addsum(0, a[0]);
-    tn_mma(acc[0][0], b[0], a[0]);
-    tn_wait_lgkm<14>(a[0], b[1]); tn_mma(acc[0][1], b[1], a[0]);
-    tn_wait_lgkm<12>(a[0], b[2]); tn_mma(acc[0][2], b[2], a[0]);
-    tn_wait_lgkm<10>(a[0], b[3]); tn_mma(acc[0][3], b[3], a[0]);
-    tn_wait_lgkm<8>(a[0], b[4]);  tn_mma(acc[0][4], b[4], a[0]);
-    tn_wait_lgkm<6>(a[0], b[5]);  tn_mma(acc[0][5], b[5], a[0]);
-    tn_wait_lgkm<4>(a[0], b[6]);  tn_mma(acc[0][6], b[6], a[0]);
-    tn_wait_lgkm<2>(a[0], b[7]);  tn_mma(acc[0][7], b[7], a[0]);
+    tn_mma2<SWAP>(acc[0][0], a[0], b[0]);
+    tn_wait_lgkm<14>(a[0], b[1]); tn_mma2<SWAP>(acc[0][1], a[0], b[1]);
+    tn_wait_lgkm<12>(a[0], b[2]); tn_mma2<SWAP>(acc[0][2], a[0], b[2]);
+    tn_wait_lgkm<10>(a[0], b[3]); tn_mma2<SWAP>(acc[0][3], a[0], b[3]);
+    tn_wait_lgkm<8>(a[0], b[4]);  tn_mma2<SWAP>(acc[0][4], a[0], b[4]);
+    tn_wait_lgkm<6>(a[0], b[5]);  tn_mma2<SWAP>(acc[0][5], a[0], b[5]);
+    tn_wait_lgkm<4>(a[0], b[6]);  tn_mma2<SWAP>(acc[0][6], a[0], b[6]);
+    tn_wait_lgkm<2>(a[0], b[7]);  tn_mma2<SWAP>(acc[0][7], a[0], b[7]);
     // ---- stage st + 1 published (every wave's pieces landed), stage st's buffer free (every wave's reads of it returned)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
     if (st + 2 < nstage) wait_vmcnt<4>(); else wait_vmcnt<0>();
@@ -1297,7 +1303,7 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
       if (do_colsum) addsum(i, a[i]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        tn_mma(acc[i][j], b[j], a[i]);
+        tn_mma2<SWAP>(acc[i][j], a[i], b[j]);
         if (i == 3) TN_FRAG_READ(b[j], fb[j] + ring_r)
       }
       TN_FRAG_READ(a[i], fa[i] + ring_r)
@@ -1306,27 +1312,68 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stale requests of the last stage: the next piece rewrites the ring
 
+  if constexpr (!SWAP) {
+    // ---- epilogue of the shared-block forms (equal pieces, slices): lane (lr, g) holds rows 4g .. 4g+3 of column lr of a fragment --
+    // an instruction's 64 lanes touch 4 runs of 64 contiguous bytes, which is what the fp32 atomics want
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int gn = n0 + wn * 64 + i * 16 + g * 4 + r;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int gk = k0 + wk * 128 + j * 16 + lr;
+          if (gn < pN && gk < pK) {
+            float* dst = C + (int64_t)gn * ldc + gk;
+            if (single) *dst += acc[i][j][r]; else atomicAdd(dst, acc[i][j][r]);
+          }
+        }
+      }
+  } else {
   // ---- epilogue.  The MFMAs ran with the operands swapped (k rows, n columns): lane (lr, g) holds, of fragment (i, j), the FOUR
   // consecutive k = k0 + wk 128 + 16 j + 4 g .. + 3 of row n = n0 + wn 64 + 16 i + lr -- 16 contiguous bytes of dW
-  const bool vec = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0;
+  // A block with one owner: plain read-modify-write, the 8 loads of a fragment row issued TOGETHER (the compiler cannot prove that
+  // dst(i, j) and dst(i', j') differ -- ldc is a run-time value -- and would otherwise wait for every load behind the previous store:
+  // 32 dependent round trips to L2 / HBM per block).  A sliced block: fp32 atomics without a return value (nothing to wait for).
+  const bool vec = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (pK & 3) == 0;
+  const bool full = n0 + 256 <= pN && k0 + 256 <= pK;          // no edge inside the block: no per-element tests (wave-uniform)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int gn = n0 + wn * 64 + i * 16 + lr;
+    const int gk0 = k0 + wk * 128 + g * 4;
+    float* const row = C + (int64_t)gn * ldc + gk0;
+    if (full && vec && single) {
+      f32x4_t old[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int gk = k0 + wk * 128 + j * 16 + g * 4;
-      if (gn >= pN || gk >= pK) continue;
-      float* dst = C + (int64_t)gn * ldc + gk;
-      if (single && vec && gk + 4 <= pK) {
-        f32x4_t v = *reinterpret_cast<const f32x4_t*>(dst);
-        v += acc[i][j];
-        *reinterpret_cast<f32x4_t*>(dst) = v;
+      for (int j = 0; j < 8; ++j) old[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(row + j * 16));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4_t*>(row + j * 16) = old[j] + acc[i][j];
+    } else if (full && !single) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(row + j * 16 + r, acc[i][j][r]);
+    } else if (gn < pN) {
+      if (single && vec) {
+        f32x4_t old[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (gk0 + j * 16 < pK) old[j] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(row + j * 16));
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (gk0 + j * 16 < pK) *reinterpret_cast<f32x4_t*>(row + j * 16) = old[j] + acc[i][j];
       } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (gk + r < pK) { if (single) dst[r] += acc[i][j][r]; else atomicAdd(dst + r, acc[i][j][r]); }
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (gk0 + j * 16 + r < pK) {
+              if (single) row[j * 16 + r] += acc[i][j][r];
+              else atomicAdd(row + j * 16 + r, acc[i][j][r]);
+            }
       }
     }
+  }
   }
   if (do_colsum) {
 #pragma unroll
@@ -1365,7 +1412,7 @@ __device__ __forceinline__ Tn128Args tn_group_prob(const TnGroupArgs& ga, int i)
   p.M = q.M; p.N = q.N; p.K = q.K; p.m_per_split = q.m_per_split; p.tiles_k = q.tiles_k; p.ntiles = q.ntiles;
   return p;
 }
-template <int NST, bool ROT = false>
+template <int NST, bool ROT = false, bool SWAP = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
@@ -1383,7 +1430,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
   while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
   const Tn128Args p = tn_group_prob(ga, i);
   const int w = wid - ga.first[i], split = w / p.ntiles, m_beg = split * p.m_per_split;
-  if constexpr (ROT) tn256r_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
+  if constexpr (ROT) tn256r_body<NST, SWAP>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
   else tn256_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
 }
 
@@ -1394,7 +1441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
 // Measured before (profiles/r03_bench_timeline.txt, launch-by-launch listing): 184 / 300 / 304 equal-length blocks on 256 CUs
 // took 185 / 340 / 266 us -- the second round of 44 blocks costs as much as the first of 256.
 // first[] holds the prefix sums of STAGES per problem here; m_per_split the stages of one block of that problem.
-template <int NST>
+template <int NST, bool ROT = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn256s_kernel(TnGroupArgs ga, int per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
@@ -1411,7 +1458,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256s_kernel(TnGroupArgs ga, int
     const int w = x - ga.first[i], tile = w / spb, st0 = w % spb;
     const int st1 = min(spb, st0 + (x1 - x));
     if (again) __syncthreads();                            // every wave is done reading the previous piece's last stages
-    tn256_body<NST>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
+    if constexpr (ROT) tn256r_body<NST, false>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
+    else tn256_body<NST>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
     x += st1 - st0;
     again = true;
   }
@@ -2134,6 +2182,80 @@ extern "C" int asr_gemm_tn(const void* A, int64_t lda, const void* B, int64_t ld
   return ASR_OK;
 }
 
+// Slices per problem for the whole-block form of asr_gemm_tn_grouped: the launch's workgroups (one per block of dW and slice of its
+// rows, longest first) are played through on 256 CUs -- each goes to the CU that is free first, as the dispatcher does -- for a few
+// upper bounds on the slice length; a workgroup costs its stages + a fixed part (pipeline fill, epilogue; more with atomics).
+// The plan of the last few distinct problem lists is kept (a training step asks for the same lists again and again).
+static bool tn_rot_plan(int cnt, const int* order, const int* M, const int* N, const int* K, int* splits_out) {
+  struct Memo { uint64_t key; int cnt; bool whole_wins; int splits[TN_GROUP_MAX]; };
+  static Memo memo[8];
+  static int memo_next = 0;
+  uint64_t key = 1469598103934665603ull;
+  for (int j = 0; j < cnt; ++j) {
+    const int i = order[j];
+    for (const int v : {M[i], N[i], K[i]}) key = (key ^ (uint64_t)(uint32_t)v) * 1099511628211ull;
+  }
+  for (const Memo& m : memo)
+    if (m.key == key && m.cnt == cnt) {
+      for (int j = 0; j < cnt; ++j) splits_out[order[j]] = m.splits[j];
+      return m.whole_wins;
+    }
+  // a visit that ends in 65 536 fp32 atomics costs about as much as 100 stages (profiles/r05_tn_grouped.txt: 123 us of a 480 us
+  // pass for ~2.3 visits per workgroup)
+  constexpr int CUS = 256, FIXED = 10, FIXED_ATOMIC = 100;
+  int64_t whole = 0;
+  int longest = 0;
+  for (int j = 0; j < cnt; ++j) {
+    const int i = order[j];
+    const int st = (M[i] + 31) / 32;
+    whole += (int64_t)((N[i] + 255) / 256) * ((K[i] + 255) / 256) * st;
+    longest = st > longest ? st : longest;
+  }
+  const int64_t share = whole / CUS > 32 ? whole / CUS : 32;
+  const double cuts[] = {1e30, 1.0, 1.0 / 1.5, 0.5, 1.0 / 3, 0.25};
+  int best_splits[TN_GROUP_MAX];
+  int64_t best = -1;
+  std::vector<std::pair<int, int>> items;          // (cost, count) runs, longest first
+  for (const double cut : cuts) {
+    const double lim = cut > 1e20 ? 1e30 : (double)share * cut;
+    if (cut < 1e20 && lim >= longest) continue;      // the same plan as "whole"
+    int sp[TN_GROUP_MAX];
+    items.clear();
+    for (int j = 0; j < cnt; ++j) {
+      const int i = order[j];
+      const int st = (M[i] + 31) / 32;
+      int s = st > lim ? (int)((st + lim - 1) / lim) : 1;
+      if (s > st) s = st;
+      sp[j] = s;
+      const int len = (st + s - 1) / s;
+      items.push_back({len + (s > 1 ? FIXED_ATOMIC : FIXED), ((N[i] + 255) / 256) * ((K[i] + 255) / 256) * s});
+    }
+    std::sort(items.begin(), items.end(), [](const std::pair<int, int>& a, const std::pair<int, int>& b) { return a.first > b.first; });
+    std::priority_queue<int64_t, std::vector<int64_t>, std::greater<int64_t>> free_at;
+    for (int c = 0; c < CUS; ++c) free_at.push(0);
+    int64_t end = 0;
+    for (const auto& it : items)
+      for (int c = 0; c < it.second; ++c) {
+        const int64_t t = free_at.top() + it.first;
+        free_at.pop();
+        free_at.push(t);
+        end = t > end ? t : end;
+      }
+    if (best < 0 || end < best) {
+      best = end;
+      for (int j = 0; j < cnt; ++j) best_splits[j] = sp[j];
+    }
+  }
+  // the alternative: equal pieces of the launch's stages on one workgroup per CU -- perfectly balanced, but nearly every block is
+  // shared between two workgroups (two atomic visits each)
+  const int64_t pieces = share + 2 * FIXED_ATOMIC + FIXED;
+  Memo& m = memo[memo_next];
+  memo_next = (memo_next + 1) % 8;
+  m.key = key; m.cnt = cnt; m.whole_wins = best <= pieces;
+  for (int j = 0; j < cnt; ++j) { m.splits[j] = best_splits[j]; splits_out[order[j]] = best_splits[j]; }
+  return m.whole_wins;
+}
+
 extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
                                    float* const* dw, const int64_t* ld_dw, float* const* db, const int* M, const int* N, const int* K,
                                    int dtype, hipStream_t stream) {
@@ -2174,7 +2296,24 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
   // launch (profiles/r05_tn_grouped.txt).  0: round 3's forms below.
   const bool nst4 = asr_tuning("TN_GROUP_STAGES", 3) == 4;
   const bool rot = !nst4 && tmode == 0 && asr_tuning("TN_ROT", 1) != 0;
-  const bool big = tmode != 128, sched = !rot && (tmode == 1 || (tmode == 0 && max_m < asr_tuning("TN_GROUP_SLICE_MIN", 9600)));
+  const bool big = tmode != 128;
+  // ... cut into slices of its rows (summed with fp32 atomics, as before) where that shortens the launch: one block longer than a CU's
+  // share (emb_cnn's window contractions: one or two blocks over several hundred thousand rows), or equal blocks whose count is an
+  // awkward multiple of the CUs (configs[3]: 576 blocks of 398 stages = 2.25 rounds).  tn_rot_plan() decides by playing the dispatch
+  // through for a few slice lengths; the list is then ordered by SLICE length.
+  int rot_splits[TN_GROUP_MAX];
+  // where the whole blocks would leave CUs idle (tn_rot_plan), round 3's forms with the new loop; TN_ROT = 2: whole blocks always
+  const bool whole = rot && (tn_rot_plan(cnt, order, M, N, K, rot_splits) || asr_tuning("TN_ROT", 1) == 2);
+  const bool sched = !whole && (tmode == 1 || (tmode == 0 && max_m < asr_tuning("TN_GROUP_SLICE_MIN", 9600)));
+  if (whole) {
+    int slice[TN_GROUP_MAX];
+    for (int j = 0; j < cnt; ++j) {
+      const int i = order[j];
+      slice[i] = ((M[i] + 31) / 32 + rot_splits[i] - 1) / rot_splits[i];
+    }
+    for (int a = 1; a < cnt; ++a)
+      for (int b = a; b > 0 && slice[order[b]] > slice[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  }
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];
     TnGroupProb& q = ga.p[j];
@@ -2189,8 +2328,8 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
       total += q.ntiles * q.m_per_split;
       continue;
     }
-    int splits = 1;
-    if (big && mrows > 0 && !rot) splits = (M[i] + mrows - 1) / mrows;
+    int splits = whole ? rot_splits[i] : 1;
+    if (big && mrows > 0 && !whole) splits = (M[i] + mrows - 1) / mrows;
     if (splits < 1) splits = 1;
     q.m_per_split = ((M[i] + splits - 1) / splits + 31) / 32 * 32;
     splits = (M[i] + q.m_per_split - 1) / q.m_per_split;
@@ -2207,6 +2346,8 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     granted = true;
   }
   AsrProfScope prof(ASR_OP_GEMM, stream);
@@ -2218,9 +2359,11 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     const int per_wg = (total + nwg - 1) / nwg;
     nwg = (total + per_wg - 1) / per_wg;
     if (nst4) hipLaunchKernelGGL(gemm_tn256s_kernel<4>, dim3((unsigned)nwg), dim3(512), 4 * 32768, stream, ga, per_wg);
+    else if (rot) hipLaunchKernelGGL((gemm_tn256s_kernel<3, true>), dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
     else hipLaunchKernelGGL(gemm_tn256s_kernel<3>, dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
   } else if (big) {
     if (nst4) hipLaunchKernelGGL(gemm_tn256g_kernel<4>, dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
+    else if (whole) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
     else if (rot) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
     else hipLaunchKernelGGL(gemm_tn256g_kernel<3>, dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
   } else if (nst4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);

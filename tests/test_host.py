@@ -362,9 +362,11 @@ def test_command_line_records_which_options_were_typed():
 
 
 def test_deferred_weight_gradients_close_their_groups_by_work(monkeypatch):
-    """Host logic of asr_hip/ops.py queue_wgrad / flush_wgrads (no kernel runs: the grouped launch is replaced by a recorder): a group
-    is closed at 32 layers or ~38 000 block-stages of 256 x 256 x 64 rows, whichever comes first -- 32 layers at the 6 400 rows of
-    configs[1], 16 at the 12 720 rows of configs[3] -- and a flush empties the queue in order."""
+    """Host logic of asr_hip/ops.py queue_wgrad / flush_wgrads (no kernel runs: the grouped launch is replaced by a recorder).  Round 5
+    default: a group is closed at 48 layers (asr_gemm_tn_grouped's limit; whole-contraction blocks dispatched longest first want the
+    largest group) and a flush empties the queue in order.  Round 3's grouping (ASR_WGRAD_GROUP=32 ASR_WGRAD_STAGES=38000, for the
+    equal-piece kernel ASR_TN_ROT=0): 32 layers or ~38 000 block-stages of 256 x 256 x 64 rows, whichever comes first -- 32 layers at the
+    6 400 rows of configs[1], 16 at the 12 720 rows of configs[3]."""
     from asr_hip import ops
     seen = []
     monkeypatch.setattr(ops, "gemm_tn_grouped", lambda grp: seen.append([(e[0].shape[0], e[4], e[5]) for e in grp]))
@@ -376,6 +378,17 @@ def test_deferred_weight_gradients_close_their_groups_by_work(monkeypatch):
             ops.queue_wgrad(torch.zeros(M, N, dtype=torch.bfloat16), torch.zeros(M, K, dtype=torch.bfloat16),
                             torch.zeros(N, K), torch.zeros(N), N, K)
 
+    assert ops.WGRAD_GROUP == 48 and ops.WGRAD_STAGES == 0
+    for M in (6400, 12720):
+        for _ in range(13):
+            layer(M)
+        assert [len(g) for g in seen] == [48]
+        ops.flush_wgrads()
+        assert [len(g) for g in seen] == [48, 4] and not ops._wgrad_q
+        assert [e[0] for g in seen for e in g] == [M] * 52
+        del seen[:]
+    monkeypatch.setattr(ops, "WGRAD_GROUP", 32)
+    monkeypatch.setattr(ops, "WGRAD_STAGES", 38000)
     for _ in range(10):
         layer(6400)
     assert [len(g) for g in seen] == [32]
