@@ -1179,7 +1179,7 @@ template <bool SWAP> __device__ __forceinline__ void tn_mma2(f32x4_t& acc, const
 
 template <int NST, bool SWAP>
 __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* smem, int tile, int m_beg, int m_end, bool single) {
-  static_assert(NST == 3, "ring of three stages");
+  static_assert(NST == 3 || NST == 4, "ring of three or four stages");
   constexpr int RM = 32, TILEB = RM * 512, STAGEB = 2 * TILEB;
   const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1234,7 +1234,7 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
     }
     ba += RM * lda2; bb += RM * ldb2;
     ++staged;
-    ring_w = ring_w == 2u * STAGEB ? 0u : ring_w + STAGEB;
+    ring_w = ring_w == (unsigned)(NST - 1) * STAGEB ? 0u : ring_w + STAGEB;
   };
 
   // fragment read offsets inside a stage: row 8 g + (lr >> 2) (+ 4: offset 2048), column c0 + 4 (lr & 3)
@@ -1266,7 +1266,7 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
 
   // prologue: stages 0 .. 2 on their way, stage 0 landed and published, its fragments requested
   for (int st = 0; st < NST && st < nstage; ++st) stage();
-  if (nstage >= 3) wait_vmcnt<8>(); else if (nstage == 2) wait_vmcnt<4>(); else wait_vmcnt<0>();
+  if (NST == 4 && nstage >= 4) wait_vmcnt<12>(); else if (nstage >= 3) wait_vmcnt<8>(); else if (nstage == 2) wait_vmcnt<4>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   u32x4_t a[4], b[8];
@@ -1292,10 +1292,10 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
     tn_wait_lgkm<2>(a[0], b[7]);  tn_mma2<SWAP>(acc[0][7], a[0], b[7]);
     // ---- stage st + 1 published (every wave's pieces landed), stage st's buffer free (every wave's reads of it returned)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
-    if (st + 2 < nstage) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if (NST == 4 && st + 3 < nstage) wait_vmcnt<8>(); else if (st + 2 < nstage) wait_vmcnt<4>(); else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    if (staged < nstage) stage();                              // stage st + 3 into the buffer of stage st
+    if (staged < nstage) stage();                              // stage st + NST into the buffer of stage st
     // (past the last stage the requests below fetch stale bytes of the ring that nobody uses)
     TN_FRAG_READ(a[0], fa[0] + ring_r)
 #pragma unroll
@@ -1308,7 +1308,7 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
       }
       TN_FRAG_READ(a[i], fa[i] + ring_r)
     }
-    ring_r = ring_r == 2u * STAGEB ? 0u : ring_r + STAGEB;
+    ring_r = ring_r == (unsigned)(NST - 1) * STAGEB ? 0u : ring_r + STAGEB;
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stale requests of the last stage: the next piece rewrites the ring
 
@@ -2347,6 +2347,7 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     granted = true;
   }
@@ -2363,6 +2364,7 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     else hipLaunchKernelGGL(gemm_tn256s_kernel<3>, dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
   } else if (big) {
     if (nst4) hipLaunchKernelGGL(gemm_tn256g_kernel<4>, dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
+    else if (whole && asr_tuning("TN_ROT_NST", 3) == 4) hipLaunchKernelGGL((gemm_tn256g_kernel<4, true, true>), dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
     else if (whole) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
     else if (rot) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
     else hipLaunchKernelGGL(gemm_tn256g_kernel<3>, dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);

@@ -24,6 +24,7 @@ struct Prob { int M, N, K; void* dy; void* x; float* dw; float* db; std::vector<
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main(int argc, char** argv) {
+  if (const char* e = getenv("TN_ROT_NST")) AK(asr_set_tuning("TN_ROT_NST", atoi(e)));
   const bool big = argc > 1 && strcmp(argv[1], "big") == 0;
   const int Me = big ? 12720 : 6400, Md = big ? 1600 : 3200, LE = big ? 12 : 4, LD = big ? 6 : 4;
   std::vector<Prob> ps;
