@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <mutex>
 #include <queue>
 #include <utility>
 #include <vector>
@@ -2190,6 +2191,8 @@ static bool tn_rot_plan(int cnt, const int* order, const int* M, const int* N, c
   struct Memo { uint64_t key; int cnt; bool whole_wins; int splits[TN_GROUP_MAX]; };
   static Memo memo[8];
   static int memo_next = 0;
+  static std::mutex memo_lock;                  // (the library is called from one thread per process; a second caller must not tear an entry)
+  std::lock_guard<std::mutex> hold(memo_lock);
   uint64_t key = 1469598103934665603ull;
   for (int j = 0; j < cnt; ++j) {
     const int i = order[j];

@@ -66,6 +66,41 @@ def test_ring_kernels_keep_their_counted_waits(gemm_asm, kernel, pieces):
     assert sum(1 for o, _ in ops[:end] if o == "global_load_lds_dwordx4") >= 2 * pieces        # prologue stage(s) + the refill inside the loop
 
 
+@pytest.mark.parametrize("kernel", [r"gemm_tn256g_kernelILi3ELb1ELb1EE", r"gemm_tn256g_kernelILi3ELb1ELb0EE", r"gemm_tn256s_kernelILi3ELb1EE"])
+def test_grouped_weight_gradient_loop_reads_under_its_mfmas(gemm_asm, kernel):
+    """csrc/gemm.hip tn256r_body (round 5): the operand reads of stage s + 1 are hand-issued under the MFMAs of stage s with counted
+    s_waitcnt lgkmcnt.  That only holds while (a) nothing else uses lgkmcnt in the loop -- round 3's loop reloaded lda / ldb from the
+    kernel arguments behind every barrier (s_load + s_waitcnt lgkmcnt(0)); (b) a fragment's registers are written by the reads and
+    consumed by the MFMAs directly -- a compiler-inserted copy of a register whose read is still in flight would copy stale bits;
+    (c) the ring position costs one add per fragment, not the three instructions per read of the old loop."""
+    ops = _ops(_kernel(gemm_asm, kernel))
+    mf = [i for i, (o, _) in enumerate(ops) if o.startswith("v_mfma")]
+    assert len(mf) == 32                                            # one 32-row stage of a 64 x 128 quadrant, not unrolled
+    # the stage loop (its basic blocks are not in source order: row 3 precedes the header): everything between the first and the last of
+    # its 32 MFMAs and 24 operand reads -- the reads are the LAST 24 of the kernel, the prologue's 24 come before the loop
+    tr = [i for i, (o, _) in enumerate(ops) if o == "ds_read_b64_tr_b16"]
+    assert len(tr) == 48
+    body = mf + tr[24:]
+    loop = ops[min(body):max(body) + 1]
+    names = [o for o, _ in loop]
+    assert names.count("ds_read_b64_tr_b16") == 24 and names.count("s_barrier") == 1
+    assert not [t for o, t in loop if o.startswith("s_load")], "a kernel argument is read inside the stage loop"
+    lg = [t for o, t in loop if o == "s_waitcnt" and "lgkmcnt" in t]
+    assert [int(re.search(r"lgkmcnt\((\d+)\)", t).group(1)) for t in lg] == [15, 14, 12, 10, 8, 6, 4, 2, 0], lg
+    frag_regs = set()
+    for o, t in loop:
+        if o == "ds_read_b64_tr_b16":
+            lo, hi = map(int, re.search(r"v\[(\d+):(\d+)\]", t).groups())
+            frag_regs.update(range(lo, hi + 1))
+    assert len(frag_regs) == 48                                     # 12 fragments x 4 registers, each read in place
+    copies = [t for o, t in loop if o.startswith("v_mov") and int(re.search(r"v(\d+)$", t.split(",")[-1].strip()).group(1) if re.search(r"v(\d+)$", t.split(",")[-1].strip()) else -1) in frag_regs]
+    assert not copies, copies
+    valu = sum(1 for o in names if o.startswith("v_") and not o.startswith("v_mfma"))
+    assert valu <= 80 + (64 if "s_kernel" in kernel or "ELb0EE" in kernel else 64), valu      # 12 adds + DMA addresses (+ the bias column sums of the waves that own them)
+    seg_txt = "\n".join(t for _, t in ops)
+    assert "scratch_" not in seg_txt and "v_accvgpr" not in seg_txt
+
+
 def test_attention_dropout_mask_is_packed_sixteen_bit_arithmetic(tmp_path):
     lines = _asm(str(tmp_path), "attention_pp.hip")
     seg = _kernel(lines, r"attn_fwd_pp_bf16_d64_kernelILb1ELi4E")
