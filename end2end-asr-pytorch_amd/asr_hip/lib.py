@@ -43,6 +43,7 @@ _SIGS = {
     "asr_gemm_tn_grouped": (_I, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "asr_gemm_nn": (_I, [_P, _L, _P, _L, _P, _L, _P, _I, _I, _I, _F, _I, _I, _I, _P]),
     "asr_gemm_nn_rowdot": (_I, [_P, _L, _P, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "asr_gemm_tn_grouped_plan": (_I, [_I, _P, _P, _P, _P]),
     "asr_gemm_nn_tn_splits": (_I, [_I, _I]),
     "asr_gemm_nn_tn_workspace": (_L, [_I, _I, _I, _I]),
     "asr_gemm_nn_tn": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _L, _I, _I, _I, _P]),

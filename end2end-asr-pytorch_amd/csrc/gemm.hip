@@ -2259,6 +2259,23 @@ static bool tn_rot_plan(int cnt, const int* order, const int* M, const int* N, c
   return m.whole_wins;
 }
 
+// The decision asr_gemm_tn_grouped takes for a list of problems, without launching anything (host only; tests, tuning): 1 = one
+// workgroup per whole block of dW (splits[i] > 1: the slices of an over-long block), 0 = round 3's shared forms.
+extern "C" int asr_gemm_tn_grouped_plan(int n, const int* M, const int* N, const int* K, int* splits) {
+  ASR_CHECK_ARG(n >= 0 && n <= TN_GROUP_MAX && (n == 0 || (M && N && K && splits)));
+  int order[TN_GROUP_MAX];
+  int cnt = 0;
+  for (int i = 0; i < n; ++i) {
+    ASR_CHECK_ARG(M[i] >= 0 && N[i] >= 0 && K[i] >= 0);
+    splits[i] = 1;
+    if (M[i] > 0 && N[i] > 0 && K[i] > 0) order[cnt++] = i;
+  }
+  if (cnt == 0) return 1;
+  for (int a = 1; a < cnt; ++a)
+    for (int b = a; b > 0 && M[order[b]] > M[order[b - 1]]; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  return tn_rot_plan(cnt, order, M, N, K, splits) ? 1 : 0;
+}
+
 extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
                                    float* const* dw, const int64_t* ld_dw, float* const* db, const int* M, const int* N, const int* K,
                                    int dtype, hipStream_t stream) {

@@ -90,6 +90,11 @@ int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, cons
  * whole stage and the caller guarantees A[:, K:] == 0 there (B's rows are clamped), else ASR_EUNSUPPORTED.              */
 int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask, int M,
                 int N, int K, float alpha, int flags, int in_dtype, int out_dtype, asr_stream_t stream);
+/* What asr_gemm_tn_grouped would do with these n problems (host only, nothing is launched): returns 1 = one workgroup per WHOLE block of
+ * dW, dispatched longest first, no atomics (splits[i] > 1: a block longer than a CU's share of the launch is cut into that many
+ * slices of its rows), 0 = the shared-block forms of round 3 (equal pieces / slices, fp32 atomics) because whole blocks would leave
+ * CUs idle; < 0 = error.  The dispatch is played through on 256 CUs for a few slice lengths (csrc/gemm.hip tn_rot_plan).        */
+int asr_gemm_tn_grouped_plan(int n, const int* M, const int* N, const int* K, int* splits);
 /* The data gradient that IS the attention backward's dO (the output projection's, models/common_layers.py:190-198 under autograd),
  * with the softmax backward's row term from the same epilogue: C (M, N) bf16 = A (M, K) . B (K, N) as asr_gemm_nn (alpha = 1, no mask,
  * no +=, ldc = N), and rowdot[(b H + h) T + q] = sum_{d < 64} C[b T + q][64 h + d] * O[b T + q][64 h + d] with the ROUNDED C, H = N / 64,

@@ -361,6 +361,34 @@ def test_command_line_records_which_options_were_typed():
         constant.explicit = old_explicit
 
 
+def test_grouped_weight_gradient_plan():
+    """asr_gemm_tn_grouped_plan (host only): the 46 linear layers of configs[1] are one launch of whole blocks, none sliced; configs[3]'s
+    48 encoder problems (576 equal blocks of 398 stages = 2.25 rounds of 256 CUs) keep the shared forms; a single block over 400 000 rows
+    (emb_cnn's window contraction) next to ordinary layers is sliced into about a CU's share each."""
+    import ctypes
+    from asr_hip import lib as L
+    h = L.load()
+
+    def plan(probs):
+        n = len(probs)
+        I = ctypes.c_int * n
+        sp = I()
+        rc = h.asr_gemm_tn_grouped_plan(n, I(*[p[0] for p in probs]), I(*[p[1] for p in probs]), I(*[p[2] for p in probs]), sp)
+        assert rc in (0, 1), rc
+        return rc, list(sp)
+
+    enc = lambda M: [(M, 512, 2048), (M, 2048, 512), (M, 512, 512), (M, 1536, 512)]
+    dec = lambda Md, Me: [(Md, 512, 2048), (Md, 2048, 512), (Md, 512, 512), (Me, 1024, 512), (Md, 512, 512), (Md, 512, 512), (Md, 1536, 512)]
+    headline = [(3200, 4416, 512)] + dec(3200, 6400) * 4 + enc(6400) * 4 + [(6400, 512, 2560)]
+    assert len(headline) == 46
+    assert plan(headline) == (1, [1] * 46)
+    assert plan(enc(12720) * 12)[0] == 0
+    whole, sp = plan([(409600, 64, 64)] + enc(6400) * 8)
+    assert whole == 1 and sp[1:] == [1] * 32 and 32 <= sp[0] <= 64          # 384 blocks x 200 stages + 12 800: a CU's share is ~350 stages
+    assert plan([(409600, 64, 64)] + enc(6400) * 2)[0] == 0                  # 96 blocks on 256 CUs: the equal pieces fill the chip
+    assert plan([]) == (1, [])
+
+
 def test_deferred_weight_gradients_close_their_groups_by_work(monkeypatch):
     """Host logic of asr_hip/ops.py queue_wgrad / flush_wgrads (no kernel runs: the grouped launch is replaced by a recorder).  Round 5
     default: a group is closed at 48 layers (asr_gemm_tn_grouped's limit; whole-contraction blocks dispatched longest first want the
