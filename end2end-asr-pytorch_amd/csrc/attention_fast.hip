@@ -162,6 +162,9 @@ __device__ __forceinline__ uint4 pack_p(const f32x4_t* v, int ms) {
 __device__ __forceinline__ void mma(f32x4_t& acc, const uint4& a, const uint4& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
+__device__ __forceinline__ f32x4_t mma_z(const uint4& a, const uint4& b) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+}
 __device__ __forceinline__ uint4 load_row16(const bf16_t* base, int64_t st, int row, int nrows, int col0) {
   const int r = row < nrows ? row : nrows - 1;
   return *reinterpret_cast<const uint4*>(base + (int64_t)r * st + col0);
@@ -730,6 +733,293 @@ __device__ __forceinline__ void attn_bwd_dkv_body(const AttnArgs& p, const int v
   }
 }
 
+// ---- short key sequences (Tk <= 256: every attention of the benchmark model, T' = 200 / 100): the WHOLE backward of one (batch, head) in
+// one workgroup and ONE pass over the scores (round 5).  The two-half form above recomputes S, the softmax, the dropout mask and dP in
+// both halves (the dQ workgroups and the dK / dV workgroups): 7 matrix products and two softmax passes per (query, key) pair, at 12.7
+// vector instructions per MFMA the launch is bound by that vector work.  Here 8 waves own 32 keys each (all 256 of the head), walk the
+// query tiles once as the dK / dV half does -- S^T, P^T, dP^T, dS^T in registers, dK / dV accumulated in registers -- and the data
+// gradient of the queries comes from the same dS: every wave writes its dS^T rows (key-major, the standard 64 x 64 tile image) to LDS,
+// and after one barrier the 8 waves contract dQ^T[d][q] = K^T[d][key] dS^T[key][q] over all 256 keys, 2 of the 16 output fragments each
+// (both operands by transposing reads: K staged once per workgroup).  5 matrix products and one softmax pass per pair; no atomics.
+template <int NK, int NW>
+__device__ __forceinline__ void attn_bwd_fused_body(const AttnArgs& p, const int bh, unsigned char* smem) {
+  // 16 NK keys per wave, NW waves: (2, 8) = 256 keys; (1, 8) = 128 keys (the decoder's self-attention: every wave has live keys);
+  // (1, 16) = 256 keys on 1024 threads (<= 128 registers: a few spills, whose reloads wait for every load in flight -- measured, not used)
+  constexpr int KT = NK * NW / 4, NQF = 16 / NW;             // key tiles of 64; dQ fragments per wave
+  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int htid = tid & 255, hwave = wave & 3, grp = wave >> 2;            // staging is done by groups of 4 waves, one tile each
+  constexpr int NGRP = NW / 4;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const int kw = wave * 16 * NK;
+  // LDS: [Q | dO] x 2 buffers, K (4 tiles), dS (4 tiles), lse / delta rows x 2 buffers
+  unsigned char* sK = smem + 4 * TILE;
+  unsigned char* sdS = smem + 8 * TILE;
+  float (*s_stat)[2][64] = reinterpret_cast<float (*)[2][64]>(smem + 12 * TILE);
+  const bf16_t* Qb = static_cast<const bf16_t*>(p.Q) + (int64_t)b * p.q_sb + (int64_t)h * HD;
+  const bf16_t* Kb = static_cast<const bf16_t*>(p.K) + (int64_t)b * p.k_sb + (int64_t)h * HD;
+  const bf16_t* Vb = static_cast<const bf16_t*>(p.V) + (int64_t)b * p.v_sb + (int64_t)h * HD;
+  const bf16_t* dOb = static_cast<const bf16_t*>(p.dO) + (int64_t)b * p.o_sb + (int64_t)h * HD;
+  const uint64_t seed = asr_mix_seed(p.seed, p.seed_dev);
+  const float c2 = p.scale * LOG2E;
+  const int kend = key_end(p, b);
+  const int64_t stat0 = ((int64_t)b * p.H + h) * p.Tq;
+  const uint32_t field_sh = (uint32_t)(lr & 1) << 4;
+  FragOff fo;
+  fo.init(lr, g);
+
+  uint4 kfr[NK][2], vfr[NK][2];
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki)
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      kfr[ki][ds] = load_row16(Kb, p.k_st, kw + ki * 16 + lr, p.Tk, ds * 32 + g * 8);
+      vfr[ki][ds] = load_row16(Vb, p.v_st, kw + ki * 16 + lr, p.Tk, ds * 32 + g * 8);
+    }
+  f32x4_t dk[NK][4], dv[NK][4];
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki)
+#pragma unroll
+    for (int df = 0; df < 4; ++df) { dk[ki][df] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[ki][df] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const int ntile = (p.Tq + 63) >> 6, nkt = (p.Tk + 63) >> 6;
+  constexpr uint32_t DROP_ROW_C = 0x9E3779B1u;
+  uint32_t ybase[NK];
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki)
+    ybase[ki] = (drop_row_key(seed, drop_row(p, b, h, g * 4 + 2 * (lr & 1))) + ((uint32_t)(kw + ki * 16 + lr) >> 1)) * DROP_C1;
+  // where this lane's dS^T values go: row = its key inside the key tile, the 4 consecutive queries 32 ms + 16 q2 + 4 g .. + 3 = 8 bytes
+  unsigned ds_row[NK];
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki) {
+    const int key = kw + ki * 16 + lr, row = key & 63;
+    ds_row[ki] = (unsigned)((key >> 6) * TILE + row * ROWB + (g & 1) * 8) | ((unsigned)(row & 7) << 28);      // swizzle key in the top bits
+  }
+
+  auto load_stat = [&](int t) __attribute__((always_inline)) -> float {
+    const int ql = tid & 63, qq = (t << 6) + ql;
+    if (tid < 64) return qq < p.Tq ? p.lse[stat0 + qq] : INFINITY;
+    return (tid < 128 && qq < p.Tq) ? p.delta[stat0 + qq] : 0.f;
+  };
+  auto stage_stats = [&](int t, int buf) __attribute__((always_inline)) {
+    const float v = load_stat(t);
+    if (tid < 128) s_stat[buf][tid >> 6][tid & 63] = v;
+  };
+  auto stage_q_do = [&](unsigned char* buf, int q0) __attribute__((always_inline)) {
+    if (grp == 0) stage_tile(buf, Qb, p.q_st, q0, p.Tq, htid, hwave);
+    else if (grp == 1) stage_tile(buf + TILE, dOb, p.o_st, q0, p.Tq, htid, hwave);
+  };
+  // K (all keys of the head; rows past Tk repeat the last key: their dS is 0) for the dQ contraction, the first query tile, its statistics
+#pragma unroll
+  for (int j = 0; j < (KT + NGRP - 1) / NGRP; ++j)
+    if ((KT + NGRP - 1) / NGRP * grp + j < KT)
+      stage_tile(sK + ((KT + NGRP - 1) / NGRP * grp + j) * TILE, Kb, p.k_st, ((KT + NGRP - 1) / NGRP * grp + j) * 64, p.Tk, htid, hwave);
+  // dS^T rows of key fragments that are dead for a whole query tile (past the key length; causal: every key after the tile's last query)
+  // are never written: zero once (a causal fragment only ever goes from dead to live as the query tiles advance)
+#pragma unroll
+  for (int i = 0; i < KT * TILE / (16 * 64 * NW); ++i)
+    *reinterpret_cast<uint4*>(sdS + (size_t)(i * 64 * NW + tid) * 16) = make_uint4(0u, 0u, 0u, 0u);
+  stage_stats(0, 0);
+  stage_q_do(smem, 0);
+  // lse / delta of the tile after next travel in a register for a whole tile: no global round trip is ever waited for inside a tile
+  float stat_next = ntile > 1 ? load_stat(1) : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int q0 = t << 6;
+    const unsigned char* sQ = smem + (t & 1) * 2 * TILE;
+    const unsigned char* sdO = sQ + TILE;
+    const float* st_lse = s_stat[t & 1][0];
+    const float* st_dlt = s_stat[t & 1][1];
+    bool live[NK], need_mask[NK];
+#pragma unroll
+    for (int ki = 0; ki < NK; ++ki) {
+      const int k0 = kw + ki * 16;
+      live[ki] = k0 < kend && !(p.causal && k0 > q0 + 63);
+      need_mask[ki] = p.key_pad != nullptr || (p.causal && k0 + 15 > q0) || (k0 + 16 > kend);
+    }
+    // the tile's key-padding bytes, both halves, requested first and packed before the next tile's DMA goes out: the waits the compiler
+    // puts in front of their use count only the loads it knows -- behind the hand-issued DMA they waited for its round trip as well
+    uint32_t mb[2][NK];
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+      for (int ki = 0; ki < NK; ++ki) {
+        mb[ms][ki] = 0u;
+        if (p.key_pad) {
+          const int key = kw + ki * 16 + lr;
+          const int col = (int)((int64_t)b * p.m_sb) + (key < p.Tk ? key : p.Tk - 1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int qq = q0 + (2 * ms + (i >> 2)) * 16 + g * 4 + (i & 3);
+            mb[ms][ki] |= (uint32_t)(__builtin_amdgcn_raw_buffer_load_b8(mask_rsrc(p), col + (qq < p.Tq ? qq : p.Tq - 1) * (int)p.m_sq, 0, 0) != 0) << i;
+          }
+        }
+      }
+    const float next_stat = stat_next;                        // tile t + 1's, requested a tile ago
+    if (t + 2 < ntile) stat_next = load_stat(t + 2);
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      f32x4_t s[NK][2], dp[NK][2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) {
+          const uint4 aq = frag_rows_at(sQ, fo.rows[ds], 2 * ms + q2);
+          const uint4 ao = frag_rows_at(sdO, fo.rows[ds], 2 * ms + q2);
+#pragma unroll
+          for (int ki = 0; ki < NK; ++ki) {
+            if (!live[ki]) continue;
+            if (ds == 0) {                                      // the first product takes a literal 0 as its addend: no zeroing moves
+              s[ki][q2] = mma_z(aq, kfr[ki][ds]);
+              dp[ki][q2] = mma_z(ao, vfr[ki][ds]);
+            } else {
+              mma(s[ki][q2], aq, kfr[ki][ds]);
+              mma(dp[ki][q2], ao, vfr[ki][ds]);
+            }
+          }
+        }
+      }
+      f32x4_t lse2[2], dlt[2];
+#pragma unroll
+      for (int q2 = 0; q2 < 2; ++q2) {
+        lse2[q2] = *reinterpret_cast<const f32x4_t*>(st_lse + (2 * ms + q2) * 16 + g * 4) * LOG2E;
+        dlt[q2] = *reinterpret_cast<const f32x4_t*>(st_dlt + (2 * ms + q2) * 16 + g * 4);
+      }
+      if (ms == 0 && t + 1 < ntile) {            // the next query tile and its statistics into the other buffers
+#pragma unroll
+        for (int ki = 0; ki < NK; ++ki) asm volatile("" : "+v"(mb[0][ki]), "+v"(mb[1][ki]));      // packed (= loaded) by here
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < 128) s_stat[(t + 1) & 1][tid >> 6][tid & 63] = next_stat;
+        stage_q_do(smem + ((t + 1) & 1) * 2 * TILE, q0 + 64);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      uint4 pa[NK], pd[NK];
+#pragma unroll
+      for (int ki = 0; ki < NK; ++ki) {
+        if (!live[ki]) continue;
+        const int key = kw + ki * 16 + lr;
+        if (need_mask[ki]) {
+          const uint32_t mbits = mb[ms][ki];
+#pragma unroll
+          for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int qq = q0 + (2 * ms + q2) * 16 + g * 4 + r;
+              const bool dead = (key >= kend) | (p.causal != 0 & key > qq) | (((mbits >> (q2 * 4 + r)) & 1u) != 0u);
+              s[ki][q2][r] = dead ? -INFINITY : s[ki][q2][r];
+            }
+        }
+#pragma unroll
+        for (int q2 = 0; q2 < 2; ++q2) {
+          uint32_t yw[4] = {0u, 0u, 0u, 0u};
+          if (p.thr) {
+            const uint32_t ya = drop_pair_mix(ybase[ki] + (uint32_t)((2 * ms + q2) * 16) * DROP_ROW_C * DROP_C1);
+            const uint32_t yb = drop_pair_mix(ybase[ki] + (uint32_t)((2 * ms + q2) * 16 + 1) * DROP_ROW_C * DROP_C1);
+            yw[0] = (uint32_t)__builtin_amdgcn_mov_dpp((int)ya, 0xA0, 0xf, 0xf, true);
+            yw[1] = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xA0, 0xf, 0xf, true);
+            yw[2] = (uint32_t)__builtin_amdgcn_mov_dpp((int)ya, 0xF5, 0xf, 0xf, true);
+            yw[3] = (uint32_t)__builtin_amdgcn_mov_dpp((int)yb, 0xF5, 0xf, 0xf, true);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2_t e = f32x2_t{s[ki][q2][r], s[ki][q2][r + 1]} * c2 - f32x2_t{lse2[q2][r], lse2[q2][r + 1]};
+            const f32x2_t pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            const f32x2_t keepf = {((yw[r] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep,
+                                   ((yw[r + 1] >> field_sh) & 0xffffu) < p.thr ? 0.f : p.inv_keep};
+            const f32x2_t pdv = pv * keepf;
+            const f32x2_t dsv = pv * (f32x2_t{dp[ki][q2][r], dp[ki][q2][r + 1]} * keepf - f32x2_t{dlt[q2][r], dlt[q2][r + 1]});
+            s[ki][q2][r] = pdv[0];
+            s[ki][q2][r + 1] = pdv[1];
+            dp[ki][q2][r] = dsv[0];
+            dp[ki][q2][r + 1] = dsv[1];
+          }
+        }
+        pa[ki] = pack_p(s[ki], 0);
+        pd[ki] = pack_p(dp[ki], 0);
+        // dS^T rows of this wave for the dQ contraction: queries 32 ms + 4 g .. + 3 (q2 = 0) and + 16 (q2 = 1) of key row `key`
+        const unsigned base = ds_row[ki] & 0x0fffffffu, rk = ds_row[ki] >> 28;
+        *reinterpret_cast<uint2*>(sdS + base + (((unsigned)(4 * ms + (g >> 1)) ^ rk) << 4)) = make_uint2(pd[ki].x, pd[ki].y);
+        *reinterpret_cast<uint2*>(sdS + base + (((unsigned)(4 * ms + 2 + (g >> 1)) ^ rk) << 4)) = make_uint2(pd[ki].z, pd[ki].w);
+      }
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const uint4 aot = frag_cols(sdO, df * 16, ms, lr, g);
+        const uint4 aqt = frag_cols(sQ, df * 16, ms, lr, g);
+#pragma unroll
+        for (int ki = 0; ki < NK; ++ki) {
+          if (!live[ki]) continue;
+          mma(dv[ki][df], aot, pa[ki]);
+          mma(dk[ki][df], aqt, pd[ki]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ki = 0; ki < NK; ++ki) ybase[ki] += 64u * DROP_ROW_C * DROP_C1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // every wave's dS^T rows of this query tile are in LDS
+    asm volatile("" ::: "memory");
+    {
+      // dQ^T[d][q] of this tile: wave -> d fragment (wave & 3) and query fragments NK (wave >> 2) ..; contraction over the key tiles
+      const int df = wave & 3, qf0 = NQF * (wave >> 2);
+      f32x4_t dq[NQF];
+#pragma unroll
+      for (int j = 0; j < NQF; ++j) dq[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      // key tiles that are dead for this whole query tile add nothing (their dS^T rows are zero): the live range ends at the key
+      // length, and under the causal mask at the tile's last query
+      const int klive = p.causal ? min(kend, q0 + 64) : kend;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        if (kt * 64 >= klive) break;
+        uint4 akt[2], bdS[2][NQF];
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms) {
+          akt[ms] = frag_cols(sK + kt * TILE, df * 16, ms, lr, g);
+#pragma unroll
+          for (int j = 0; j < NQF; ++j) bdS[ms][j] = frag_cols(sdS + kt * TILE, (qf0 + j) * 16, ms, lr, g);
+        }
+#pragma unroll
+        for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+          for (int j = 0; j < NQF; ++j) mma(dq[j], akt[ms], bdS[ms][j]);
+      }
+      // the next tile's DMA (and the statistics behind it) has landed -- awaited HERE, before this tile's stores go out: vmcnt retires
+      // in order, a wait behind the stores would wait for their round trip as well (it did: 8 us per query tile instead of 4)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < NQF; ++j) {
+        const int q = q0 + (qf0 + j) * 16 + lr;
+        if (q < p.Tq) {
+          bf16_t* oq = static_cast<bf16_t*>(p.dQ) + (int64_t)b * p.q_sb + (int64_t)q * p.q_st + (int64_t)h * HD + df * 16 + g * 4;
+          const f32x4_t a = dq[j] * p.scale;
+          *reinterpret_cast<uint2*>(oq) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                              // next tile landed (every wave waited above); everybody is done with this tile's dS^T rows
+    asm volatile("" ::: "memory");
+  }
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki) {
+    const int key = kw + ki * 16 + lr;
+    if (key >= p.Tk) continue;
+    bf16_t* ok = static_cast<bf16_t*>(p.dK) + (int64_t)b * p.k_sb + (int64_t)key * p.k_st + (int64_t)h * HD;
+    bf16_t* ov = static_cast<bf16_t*>(p.dV) + (int64_t)b * p.v_sb + (int64_t)key * p.v_st + (int64_t)h * HD;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      const f32x4_t a = dk[ki][df] * p.scale, c = dv[ki][df];
+      *reinterpret_cast<uint2*>(ok + df * 16 + g * 4) = make_uint2(pack_bf16(a[0], a[1]), pack_bf16(a[2], a[3]));
+      *reinterpret_cast<uint2*>(ov + df * 16 + g * 4) = make_uint2(pack_bf16(c[0], c[1]), pack_bf16(c[2], c[3]));
+    }
+  }
+}
+constexpr int FUSED_BWD_LDS = 12 * TILE + 2 * 2 * 64 * 4;
+template <int NK, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_fused_bf16_d64_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsmem[];
+  attn_bwd_fused_body<NK, NW>(p, xcd_linear_id(), fsmem);
+}
+
 template <int NQ>
 __global__ __launch_bounds__(256) void attn_bwd_dq_bf16_d64_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
@@ -814,6 +1104,20 @@ int attn_fast_bwd(const AttnArgs& p, int d, int dtype, hipStream_t s) {
   if (p.parts & ASR_ATTN_DELTA) {
     attn_delta_bf16_d64_kernel<<<dim3((unsigned)ceil_div64(rows, 32)), dim3(256), 0, s>>>(p);
     ASR_LAUNCH_CHECK();
+  }
+  // short key sequences: the whole backward of a (batch, head) in one workgroup, one pass over the scores (attn_bwd_fused_body)
+  if ((p.parts & ASR_ATTN_DQ) && (p.parts & ASR_ATTN_DKV) && p.Tk <= 256 && asr_tuning("ATTN_BWD_FUSED", 1) != 0) {
+    static bool granted = false;
+    if (!granted) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_bf16_d64_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_BWD_LDS);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_bf16_d64_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_BWD_LDS);
+      granted = true;
+    }
+    // 8 waves x 16 keys up to 128 keys, x 32 keys up to 256
+    if (p.Tk <= 128) attn_bwd_fused_bf16_d64_kernel<1, 8><<<dim3((unsigned)(p.B * p.H)), dim3(512), FUSED_BWD_LDS, s>>>(p);
+    else attn_bwd_fused_bf16_d64_kernel<2, 8><<<dim3((unsigned)(p.B * p.H)), dim3(512), FUSED_BWD_LDS, s>>>(p);
+    ASR_LAUNCH_CHECK();
+    return ASR_OK;
   }
   if ((p.parts & ASR_ATTN_DQ) && (p.parts & ASR_ATTN_DKV) && asr_tuning("ATTN_BOTH", 1) != 0) {
     const bool short_q = p.Tq <= asr_tuning("ATTN_SHORT_BWD", 1 << 30), short_k = p.Tk <= asr_tuning("ATTN_SHORT_BWD", 1 << 30);

@@ -667,6 +667,53 @@ def test_attention_dropout_consistency(ops, dtype, d, T):
     close("dV == attn_dropped^T @ dO", dv, (a.transpose(-1, -2) @ doh).permute(0, 2, 1, 3).reshape(B, T, H * d), dtype, scale=4)
 
 
+@pytest.mark.parametrize("B,H,Tq,Tk,causal,mask,p", [
+    (2, 8, 200, 200, False, "len", 0.1), (2, 8, 100, 200, False, "len", 0.1), (2, 8, 100, 100, True, "pad", 0.1), (3, 4, 130, 75, False, "len", 0.0),
+    (2, 2, 70, 256, False, "full", 0.25), (1, 8, 333, 131, False, None, 0.1), (2, 4, 64, 64, True, None, 0.0), (1, 2, 5, 3, False, None, 0.1)])
+def test_attention_backward_in_one_pass_equals_the_two_halves(ops, B, H, Tq, Tk, causal, mask, p):
+    """Short key sequences (Tk <= 256, bf16, d = 64): the whole backward of a (batch, head) in one workgroup and one pass over the scores
+    (csrc/attention_fast.hip attn_bwd_fused_body; reference: autograd of models/common_layers.py:211-225) against the two-half launch it
+    replaces (tuning ATTN_BWD_FUSED = 0) on the same inputs, masks, dropout seed and delta: both form P, the dropout mask and dS from
+    the same fp32 scores with the same instructions, so dK / dV (same contraction, same order) are EQUAL and dQ -- contracted over the
+    keys from the bf16 dS^T through LDS instead of from fp32-accumulated per-wave fragments -- is within bf16 rounding of it."""
+    from asr_hip import lib as L
+    d, bf = 64, torch.bfloat16
+    g = torch.Generator().manual_seed(Tq * 3 + Tk)
+    D = dev()
+    qx, kx, vx = (torch.randn(B, T, H * d, generator=g).to(D, bf) for T in (Tq, Tk, Tk))
+    do = torch.randn(B, Tq, H * d, generator=g).to(D, bf)
+    kl = kp = None
+    if mask == "len":
+        kl = torch.randint(max(1, Tk // 3), Tk + 1, (B,), generator=g).to(torch.int32).to(D)
+    elif mask == "pad":
+        kp = torch.zeros(B, Tk, dtype=torch.uint8)
+        for b in range(B):
+            kp[b, Tk - 7 * (b + 1):] = 1
+        kp = kp.to(D)
+    elif mask == "full":
+        kp = (torch.rand(B, Tq, Tk, generator=g) > 0.7).to(torch.uint8)
+        kp[:, :, 0] = 0
+        kp = kp.to(D)
+    o32 = torch.empty(B, Tq, H * d, device=D, dtype=torch.float32)
+    o, lse, _ = ops.attn_fwd(qx, kx, vx, H, d, key_len=kl, key_pad=kp, causal=causal, scale=0.125, p=p, seed=91, o32=o32)
+    got = {}
+    try:
+        for fused in (1, 0):
+            L.set_tuning("ATTN_BWD_FUSED", fused)
+            got[fused] = ops.attn_bwd(qx, kx, vx, o, do, lse, H, d, key_len=kl, key_pad=kp, causal=causal, scale=0.125, p=p, seed=91, o32=o32)
+    finally:
+        L.set_tuning("ATTN_BWD_FUSED", None)
+    torch.cuda.synchronize()
+    assert torch.equal(got[1][1], got[0][1]), "dK"
+    assert torch.equal(got[1][2], got[0][2]), "dV"
+    a, b_ = got[1][0].float(), got[0][0].float()
+    assert torch.isfinite(a).all()
+    # both contract bf16-rounded dS (2^-9 relative per term) over the keys, in different orders and with the dropout rescale on different
+    # sides of the rounding: a few 2^-9 of the LARGEST terms, i.e. of the tensor's scale, and a small relative L2 error
+    assert (a - b_).abs().max() <= 2.0 ** -7 * b_.abs().max(), ((a - b_).abs().max().item(), b_.abs().max().item())
+    assert (a - b_).norm() <= 4e-3 * b_.norm(), ((a - b_).norm().item(), b_.norm().item())
+
+
 # ------------------------------------------------------------------------------------------------ decoder input side
 def test_decoder_preprocess_matches_oracle(ops):
     from oracle import asr_oracle as O
