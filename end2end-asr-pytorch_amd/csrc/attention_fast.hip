@@ -795,6 +795,16 @@ __device__ __forceinline__ void attn_bwd_fused_body(const AttnArgs& p, const int
     ds_row[ki] = (unsigned)((key >> 6) * TILE + row * ROWB + (g & 1) * 8) | ((unsigned)(row & 7) << 28);      // swizzle key in the top bits
   }
 
+  // a key that is dead for EVERY query (past the key length, or padded in a (B, Tk) mask: m_sq == 0) is known once per kernel; what is
+  // left per element is the causal comparison in the tiles on the diagonal, and the bytes of a (B, Tq, Tk) mask
+  const bool mask3d = p.key_pad != nullptr && p.m_sq != 0;
+  bool kd[NK];
+#pragma unroll
+  for (int ki = 0; ki < NK; ++ki) {
+    const int key = kw + ki * 16 + lr;
+    kd[ki] = key >= kend;
+    if (p.key_pad != nullptr && p.m_sq == 0) kd[ki] |= key < p.Tk && p.key_pad[(int64_t)b * p.m_sb + key] != 0;
+  }
   auto load_stat = [&](int t) __attribute__((always_inline)) -> float {
     const int ql = tid & 63, qq = (t << 6) + ql;
     if (tid < 64) return qq < p.Tq ? p.lse[stat0 + qq] : INFINITY;
@@ -835,7 +845,7 @@ __device__ __forceinline__ void attn_bwd_fused_body(const AttnArgs& p, const int
     for (int ki = 0; ki < NK; ++ki) {
       const int k0 = kw + ki * 16;
       live[ki] = k0 < kend && !(p.causal && k0 > q0 + 63);
-      need_mask[ki] = p.key_pad != nullptr || (p.causal && k0 + 15 > q0) || (k0 + 16 > kend);
+      need_mask[ki] = p.key_pad != nullptr || (p.causal && k0 + 15 > q0) || (k0 + 16 > kend);     // (a 2-D pad mask: any lane may be dead)
     }
     // the tile's key-padding bytes, both halves, requested first and packed before the next tile's DMA goes out: the waits the compiler
     // puts in front of their use count only the loads it knows -- behind the hand-issued DMA they waited for its round trip as well
@@ -845,7 +855,7 @@ __device__ __forceinline__ void attn_bwd_fused_body(const AttnArgs& p, const int
 #pragma unroll
       for (int ki = 0; ki < NK; ++ki) {
         mb[ms][ki] = 0u;
-        if (p.key_pad) {
+        if (mask3d) {
           const int key = kw + ki * 16 + lr;
           const int col = (int)((int64_t)b * p.m_sb) + (key < p.Tk ? key : p.Tk - 1);
 #pragma unroll
@@ -899,15 +909,22 @@ __device__ __forceinline__ void attn_bwd_fused_body(const AttnArgs& p, const int
         if (!live[ki]) continue;
         const int key = kw + ki * 16 + lr;
         if (need_mask[ki]) {
-          const uint32_t mbits = mb[ms][ki];
+          if (mask3d || (p.causal && kw + ki * 16 + 15 > q0)) {
+            const uint32_t mbits = mb[ms][ki];
 #pragma unroll
-          for (int q2 = 0; q2 < 2; ++q2)
+            for (int q2 = 0; q2 < 2; ++q2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int qq = q0 + (2 * ms + q2) * 16 + g * 4 + r;
-              const bool dead = (key >= kend) | (p.causal != 0 & key > qq) | (((mbits >> (q2 * 4 + r)) & 1u) != 0u);
-              s[ki][q2][r] = dead ? -INFINITY : s[ki][q2][r];
-            }
+              for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + (2 * ms + q2) * 16 + g * 4 + r;
+                const bool dead = kd[ki] | (p.causal != 0 & key > qq) | (((mbits >> (q2 * 4 + r)) & 1u) != 0u);
+                s[ki][q2][r] = dead ? -INFINITY : s[ki][q2][r];
+              }
+          } else {                                              // the lane's key is dead for all 8 queries or for none
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) s[ki][q2][r] = kd[ki] ? -INFINITY : s[ki][q2][r];
+          }
         }
 #pragma unroll
         for (int q2 = 0; q2 < 2; ++q2) {
