@@ -19,12 +19,6 @@ for name, Tq, Tk, causal, pad in (("encoder self 200 x 200", 200, 200, False, Fa
         kp = kp.to(D)
     o32 = torch.empty(B, Tq, H * d, device=D)
     o, lse, _ = ops.attn_fwd(q, k, v, H, d, key_len=kl, key_pad=kp, causal=causal, scale=0.125, p=0.1, seed=3, o32=o32)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(50):
-        ops.attn_fwd(q, k, v, H, d, key_len=kl, key_pad=kp, causal=causal, scale=0.125, p=0.1, seed=3, o32=o32)
-    e1.record(); torch.cuda.synchronize()
-    print("%-38s forward %.1f us" % (name, e0.elapsed_time(e1) * 1e3 / 50))
     delta = torch.zeros(B, H, Tq, device=D)
     res = {}
     for fused in (0, 1, 0, 1):
