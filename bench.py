@@ -506,8 +506,9 @@ def main():
                 tr = measured_traffic(a)
                 n_launch = prof[key][1]
                 out["roofline"] = {"bound": "mfma", "kernel": "the front end's 3 forward + 3 data-gradient convolutions: vgg_level0_fwd / "
-                                   "vgg_level0_dgrad (conv.2 with conv.0, the first pool and dW0 inside), conv3x3_c64_kernel (conv.5, two passes), "
-                                   "conv3x3_ws128_kernel (conv.7 and the two 128-channel data gradients: the weight-stationary kernel of csrc/conv_ws.hip, round 5): 45 % of the step's algorithmic FLOPs",
+                                   "vgg_level0_dgrad (conv.2 with conv.0, the first pool and dW0 inside), conv3x3_ws128_kernel (conv.5 in one pass writing its ReLU mask as bits, "
+                                   "conv.7 with its pooled epilogue, conv.7's data gradient reading the bit mask, conv.5's data gradient: the weight-stationary kernel of "
+                                   "csrc/conv_ws.hip, round 5): 45 % of the step's algorithmic FLOPs",
                                    "achieved": f["achieved"], "peak": peak, "unit": "TFLOP/s", "frac": f["frac"],
                                    "frac_of_sustained_random_data": (f["achieved"] / SUSTAINED_BF16_RANDOM_TFLOPS) if a.precision == "bf16" else None,
                                    "sustained_note": "a pure MFMA stream sustains %.0f TFLOP/s on pseudo-random bf16 operands on this chip (2.2 - 2.46 PF on "
