@@ -866,10 +866,15 @@ int l0_cus() {
   }
   return cus;
 }
-template <typename K> int l0_grant(K kernel, size_t lds) {
-  static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
+// One flag per KERNEL (the six kernels share the type void (*)(L0Args): a template over the type would share one flag between them,
+// ADVICE r5); the first (eager / warm-up) launch does the grant, never a captured one.
+template <void (*Kern)(L0Args)> int l0_grant(size_t lds) {
+  static bool granted = false;
   if (!granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ASR_ELAUNCH;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      (void)hipGetLastError();          // a refused grant is reported by the return value, not left behind for the next launch check
+      return ASR_ELAUNCH;
+    }
     granted = true;
   }
   return ASR_OK;
@@ -899,9 +904,9 @@ extern "C" int asr_vgg_level0_fwd(const float* src, const float* w0, const float
     // The caller decides HERE whether the level runs on these kernels (EUNSUPPORTED -> the stored-activation launch chain): the two
     // backward kernels need more LDS than this one, so their grants are part of the decision -- a backward pass cannot fall back.
     const size_t lds_d = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16, lds_w = 2 * L0_STAGE + 2 * 1024 + 256 + 128;
-    const int r0 = split ? l0_grant(vgg_level0_fwd_kernel<true>, lds) : l0_grant(vgg_level0_fwd_kernel<false>, lds);
-    const int r1 = split ? l0_grant(vgg_level0_dgrad_kernel<true>, lds_d) : l0_grant(vgg_level0_dgrad_kernel<false>, lds_d);
-    const int r2 = split ? l0_grant(vgg_level0_wgrad_kernel<true>, lds_w) : l0_grant(vgg_level0_wgrad_kernel<false>, lds_w);
+    const int r0 = split ? l0_grant<vgg_level0_fwd_kernel<true>>(lds) : l0_grant<vgg_level0_fwd_kernel<false>>(lds);
+    const int r1 = split ? l0_grant<vgg_level0_dgrad_kernel<true>>(lds_d) : l0_grant<vgg_level0_dgrad_kernel<false>>(lds_d);
+    const int r2 = split ? l0_grant<vgg_level0_wgrad_kernel<true>>(lds_w) : l0_grant<vgg_level0_wgrad_kernel<false>>(lds_w);
     if (r0 != ASR_OK || r1 != ASR_OK || r2 != ASR_OK) return ASR_EUNSUPPORTED;
   }
   const int64_t slots = (int64_t)l0_cus() * 2;
@@ -933,7 +938,7 @@ extern "C" int asr_vgg_level0_dgrad(const void* dpool, const uint8_t* code, cons
   a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t lds = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16;
   const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
-  const int rc = split ? l0_grant(vgg_level0_dgrad_kernel<true>, lds) : l0_grant(vgg_level0_dgrad_kernel<false>, lds);
+  const int rc = split ? l0_grant<vgg_level0_dgrad_kernel<true>>(lds) : l0_grant<vgg_level0_dgrad_kernel<false>>(lds);
   if (rc != ASR_OK) return rc;
   const int64_t slots = (int64_t)l0_cus() * 2;
   const unsigned grid = (unsigned)(a.ntiles < slots ? a.ntiles : slots);
@@ -961,7 +966,7 @@ extern "C" int asr_vgg_level0_wgrad(const float* src, const float* w0, const flo
   if (workspace_floats < (int64_t)wgx * 9 * 64 * 64) return ASR_EINVAL;
   const size_t lds = 2 * L0_STAGE + 2 * 1024 + 256 + 128;
   const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
-  const int rc = split ? l0_grant(vgg_level0_wgrad_kernel<true>, lds) : l0_grant(vgg_level0_wgrad_kernel<false>, lds);
+  const int rc = split ? l0_grant<vgg_level0_wgrad_kernel<true>>(lds) : l0_grant<vgg_level0_wgrad_kernel<false>>(lds);
   if (rc != ASR_OK) return rc;
   {
     AsrProfScope prof(ASR_OP_CONV_WGRAD, s);

@@ -471,32 +471,38 @@ int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s) {
   if (a.Cin == 64) {               // conv.5 forward (64 -> 128) in one pass: 4-row tiles, two workgroups per CU
     if (a.Cout != 128 || a.mask || a.pool) return ASR_EUNSUPPORTED;
     if (a.bits_out) return ws_launch_t<64, 4, 128, 3, 0, 2>(a, s);        // ... also writing the ReLU bit mask of its output
+#ifdef ASR_TUNE_ABLATE
     if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {
       WsArgs t = a;
       t.dbg = reinterpret_cast<long long*>(dbg);
       return ws_launch_t<64, 4, 128, 0, 0, 1, true>(t, s);
     }
-    return asr_tuning("WS_PD", 2) == 1 ? ws_launch_t<64, 4, 128, 0, 0, 1>(a, s) : ws_launch_t<64, 4, 128, 0, 0, 2>(a, s);
+#endif
+    return ws_launch_t<64, 4, 128, 0, 0, 2>(a, s);
   }
   if (a.Cin != 128) return ASR_EUNSUPPORTED;
-  const int pd = (int)asr_tuning("WS_PD", 2);
-  if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {        // development: per-section clock totals of workgroup 0 (tools/conv_ws_test.cpp)
+#ifdef ASR_TUNE_ABLATE
+  // development builds only (ASR_HIPCC_EXTRA=-DASR_TUNE_ABLATE): per-section clock totals of workgroup 0 written through a device address
+  // handed in as tuning value WS_DBG (tools/conv_ws_test.cpp).  Never in the shipped library: asr_hip/lib.py forwards ASR_* environment
+  // variables to asr_set_tuning, and a stray value must not become a pointer the production kernel writes through.
+  if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {
     WsArgs t = a;
     t.dbg = reinterpret_cast<long long*>(dbg);
     if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, 8, 128, 0, 1, 2, true>(t, s);
     if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, 8, 128, 1, 0, 2, true>(t, s);
     if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<128, 8, 64, 0, 0, 2, true>(t, s);
   }
+#endif
+  // (operand prefetch depth 2 everywhere: depth 1 lost by 3 - 6 % in every form, profiles/r05_conv_ws_sections_v1.txt; its instantiations
+  //  and the WS_PD switch were removed in round 6)
   if (a.pool) {
     if (a.Cout != 128 || a.mask || !a.code || a.H % 8 != 0 || a.W % 16 != 0) return ASR_EUNSUPPORTED;
-    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, 0, 2, 2>(a, s);       // vertical tile pairs: half the store instructions
-    return pd == 1 ? ws_launch_t<128, 8, 128, 0, 1, 1>(a, s) : ws_launch_t<128, 8, 128, 0, 1, 2>(a, s);
+    // vertical tile pairs: half the store instructions.  Single tiles where H % 16 == 8 -- and under tuning WS_PAIR = 0, the arm
+    // tests/test_gpu_conv_ws.py holds the paired epilogue against
+    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, 0, 2, 2>(a, s);
+    return ws_launch_t<128, 8, 128, 0, 1, 2>(a, s);
   }
   if (a.bits_in) return ws_launch_t<128, 8, 128, 2, 0, 2>(a, s);           // conv.7's data gradient with conv.5's ReLU mask as bits
-  if (a.Cout == 128) {
-    if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 128, 1, 0, 1>(a, s) : ws_launch_t<128, 8, 128, 1, 0, 2>(a, s);
-    return pd == 1 ? ws_launch_t<128, 8, 128, 0, 0, 1>(a, s) : ws_launch_t<128, 8, 128, 0, 0, 2>(a, s);
-  }
-  if (a.mask) return pd == 1 ? ws_launch_t<128, 8, 64, 1, 0, 1>(a, s) : ws_launch_t<128, 8, 64, 1, 0, 2>(a, s);
-  return pd == 1 ? ws_launch_t<128, 8, 64, 0, 0, 1>(a, s) : ws_launch_t<128, 8, 64, 0, 0, 2>(a, s);
+  if (a.Cout == 128) return a.mask ? ws_launch_t<128, 8, 128, 1, 0, 2>(a, s) : ws_launch_t<128, 8, 128, 0, 0, 2>(a, s);
+  return a.mask ? ws_launch_t<128, 8, 64, 1, 0, 2>(a, s) : ws_launch_t<128, 8, 64, 0, 0, 2>(a, s);
 }

@@ -33,15 +33,24 @@ def build_labels(path):
 DEFAULT_GRAPH_BUCKET = 64
 
 
-def resolve_graph_buckets(args, explicit):
+def resolve_graph_buckets(args, explicit, model=None):
     """The fast path is the default path: `train.py --cuda` with the vgg_cnn front end and the cross-entropy loss replays one captured
     hipGraph per (batch, frames padded to a multiple of 64) shape -- 5.75 against 7.86 ms per step of the eager loop at configs[1]
     (profiles/r04_trainer_rate.txt).  `--graph-buckets 0` opts out; an explicit value always wins.  NOT the default for emb_cnn: its
     BatchNorm takes batch statistics over every time step it is given (the reference's does too, over the collate padding), so the
-    extra bucket padding would change the numbers; there the user opts in (trainer.py warns)."""
+    extra bucket padding would change the numbers; there the user opts in (trainer.py warns).
+    `model`: the front end is read from the model that will train (main() calls this AFTER init / load_model: a --continue-from
+    checkpoint carries its own --feat_extractor, the command line's default must not decide for it).
+    Parity caveat of the default (README, --help): for the LONGEST utterance of a batch the convolutions see bias + ReLU'd zero frames
+    where --graph-buckets 0 (and the reference) see the image border -- 1e-3 of the loss on vgg_tiny padded 64 -> 96 frames
+    (tests/test_gpu_graph.py); every other utterance already sees exactly that through the collate padding."""
     if "graph_buckets" in explicit:
         return args.graph_buckets
-    if getattr(args, "cuda", False) and getattr(args, "feat_extractor", "") == "vgg_cnn" and getattr(args, "loss", "ce") == "ce":
+    core = model.module if hasattr(model, "module") else model
+    feat = getattr(core, "feat_extractor", None) if core is not None else None
+    if feat is None:
+        feat = getattr(args, "feat_extractor", "")
+    if getattr(args, "cuda", False) and feat == "vgg_cnn" and getattr(args, "loss", "ce") == "ce":
         args.graph_buckets = DEFAULT_GRAPH_BUCKET
     return args.graph_buckets
 
@@ -52,7 +61,6 @@ def main():
     from utils.functions import init_optimizer, init_transformer_model, load_model
 
     args = constant.args
-    resolve_graph_buckets(args, constant.explicit)
     if "OMP_NUM_THREADS" not in os.environ:
         # the training process only issues kernel launches and small host tensor ops (collation runs in the loader's worker
         # processes): with torch's default of one intra-op thread per core, every host-side tensor op wakes a pool whose workers
@@ -79,8 +87,6 @@ def main():
                       window=args.window, noise_dir=args.noise_dir, noise_prob=args.noise_prob,
                       noise_levels=(args.noise_min, args.noise_max))
     logging.info(audio_conf)
-    logging.info("training step: %s", ("hipGraph replay per (batch, frames padded to a multiple of %d) shape (--graph-buckets 0: eager launches)"
-                                       % args.graph_buckets) if args.graph_buckets > 0 else "eager launches (--graph-buckets N: captured hipGraphs)")
     label2id, id2label = build_labels(args.labels_path)
 
     train_data = SpectrogramDataset(audio_conf, manifest_filepath_list=args.train_manifest_list, label2id=label2id,
@@ -103,6 +109,9 @@ def main():
         raise SystemExit("The model is not supported, check args --h")
     if constant.USE_CUDA:
         model = model.cuda()
+    resolve_graph_buckets(args, constant.explicit, model)          # after the model exists: its front end decides, not the command line's default
+    logging.info("training step: %s", ("hipGraph replay per (batch, frames padded to a multiple of %d) shape (--graph-buckets 0: eager launches)"
+                                       % args.graph_buckets) if args.graph_buckets > 0 else "eager launches (--graph-buckets N: captured hipGraphs)")
     logging.info(model)
     Trainer().train(model, train_loader, train_sampler, valid_loader_list, opt, args.loss, start_epoch, args.epochs, label2id,
                     id2label, metrics)

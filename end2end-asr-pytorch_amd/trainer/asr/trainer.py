@@ -124,7 +124,11 @@ class Trainer():
         if tgt.shape[1] > L or src.dim() != 4:
             return None
         N = int(a.graph_buckets)
-        if getattr(a, "feat_extractor", "") == "emb_cnn" and not self.__dict__.get("_warned_bn_buckets"):
+        # the front end is the MODEL's (a --continue-from checkpoint brings its own: load_model builds the model from the checkpoint's
+        # args, and the command line's --feat_extractor default would clamp an emb_cnn model's lengths to T // 4)
+        core = model.module if hasattr(model, "module") else model
+        feat = getattr(core, "feat_extractor", getattr(a, "feat_extractor", ""))
+        if feat == "emb_cnn" and not self.__dict__.get("_warned_bn_buckets"):
             self._warned_bn_buckets = True
             logging.warning("--graph-buckets with --feat_extractor emb_cnn: BatchNorm batch statistics include the bucket padding "
                             "(as they include the collate padding in the reference); results differ from --graph-buckets 0")
@@ -145,7 +149,7 @@ class Trainer():
             # batch as collated every one of its T' positions below an utterance's length is attended.  The bucket padding adds
             # positions T' .. T'_b - 1 that do not exist in the un-bucketed batch: clamping the lengths to T' masks exactly those
             # (keys and rows), whatever the utterance -- attention sees the batch it would see with --graph-buckets 0.
-            lens = torch.clamp(lens, max=self._frames_after_cnn(T, getattr(a, "feat_extractor", "")))
+            lens = torch.clamp(lens, max=self._frames_after_cnn(T, feat))
         if gs is None:
             src_b = torch.zeros((B, C, F, Tb), device=src.device, dtype=src.dtype)
             src_b[..., :T].copy_(src)

@@ -71,7 +71,15 @@ _FLAGS = [
     # 0: eager launches on the batch exactly as collated.  N > 0: training batches are zero-padded along time to a multiple of N
     # frames (the way the collate function pads shorter utterances) and to --tgt-max-len - 1 target columns, and the step is a
     # captured hipGraph per (batch, frames) shape, replayed (trainer/asr/trainer.py)
-    (("--graph-buckets",), dict(default=0, type=_I)),
+    (("--graph-buckets",), dict(default=0, type=_I,
+                                help="0: eager launches; N > 0: hipGraph replay per (batch, frames padded to a multiple of N) shape. Default: 64 for a "
+                                     "vgg_cnn model with --cuda and the CE loss (decided from the MODEL, after --continue-from is resolved), else 0. "
+                                     "Parity caveat: the longest utterance of a batch sees zero frames instead of the image border behind its "
+                                     "last frame (as every shorter one already does through the collate padding)")),
+    # data parallel under graph replay: `four` = four hipGraphs with the RCCL all-reduces between them (ordering proven under two ranks);
+    # `one` = the collectives captured inside ONE hipGraph; `auto` = try one, verify its first replayed step against the four-graph
+    # step's loss and gradient checksum on the same batch, fall back LOUDLY (asr_hip/graph.py)
+    (("--ddp-graph",), dict(default="auto", choices=["one", "four", "auto"])),
     # Low-Rank Transformer (arXiv:1910.13923, BASELINE configs[4]): rank of every attention / feed-forward projection, 0 = full rank
     (("--rank",), dict(default=0, type=_I)),
 ]

@@ -79,7 +79,8 @@ class FusedAdam(torch.optim.Adam):
     def zero_grad(self, set_to_none=False):
         """Gradients are accumulation targets of the kernels: zero them, never drop them."""
         self._ensure_flat()
-        if not torch.cuda.is_current_stream_capturing():
+        # (a host without a device: is_current_stream_capturing() raises hipErrorNoDevice there, and nothing can be capturing; ADVICE r5)
+        if self.flat is None or not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
             # nothing of a previous (failed) backward pass may trail into the gradients zeroed here; a completed pass left the queues empty.
             # (Inside a capture the queues belong to the graph body being recorded: graph.py flushes them itself.)
             ops.reset_pending()

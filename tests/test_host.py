@@ -656,3 +656,22 @@ def test_train_cli_replays_graphs_by_default_for_vgg_cnn():
     assert resolved(base) == 0
     assert resolved(["--feat_extractor", "emb_cnn", "--cuda"]) == 0
     assert resolved(base + ["--cuda", "--loss", "ctc"]) == 0
+
+    # the MODEL's front end decides, not the command line's default -- `train.py --cuda --continue-from <emb_cnn checkpoint>`
+    # without retyping --feat_extractor must NOT take the bucketed-graph default (it would clamp the lengths to T // 4)
+    class _M:
+        def __init__(self, feat):
+            self.feat_extractor = feat
+
+    class _Wrapped:
+        def __init__(self, feat):
+            self.module = _M(feat)
+
+    def resolved_for(argv, model):
+        a = constant.parser.parse_args(argv)
+        return train.resolve_graph_buckets(a, constant._given(argv), model)
+
+    assert resolved_for(["--cuda"], _M("emb_cnn")) == 0                       # command line says vgg_cnn (default), the checkpoint's model says emb_cnn
+    assert resolved_for(["--cuda"], _Wrapped("emb_cnn")) == 0
+    assert resolved_for(["--feat_extractor", "emb_cnn", "--cuda"], _M("vgg_cnn")) == 64
+    assert resolved_for(["--cuda", "--graph-buckets", "32"], _M("emb_cnn")) == 32

@@ -143,9 +143,8 @@ static void time_case(const Case& c) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const double fl = 2.0 * 9 * Cin * c.Cout * (double)npx;
   for (int ws = 0; ws < 2; ++ws)
-    for (int pd = (c.Cin == 64 && ws == 1) ? 1 : 2; pd <= 2; ++pd) {
+    for (int pd = 2; pd <= 2; ++pd) {        // (operand prefetch depth 1 and its WS_PD switch were removed in round 6: it lost everywhere)
       AK(asr_set_tuning(knob(c), ws));
-      AK(asr_set_tuning("WS_PD", pd));
       auto go = [&]() {
         if (c.pooled) AK(asr_conv3x3_relu_pool_tcf_code(dx.p, dw.p, db.p, dy.p, dc.p, c.B, c.H, c.W, Cin, c.Cout, ASR_BF16, nullptr));
         else AK(asr_conv3x3_igemm(dx.p, dw.p, db.p, c.mask ? dm.p : nullptr, dy.p, c.B, c.H, c.W, Cin, c.Cout, c.relu ? 1 : 0, ASR_BF16, nullptr));
@@ -163,7 +162,7 @@ static void time_case(const Case& c) {
       printf("  time B=%d %dx%d %d->%d mask=%d pooled=%d  %-22s %8.1f us  %7.1f TF/s (%4.1f%% of 2.5 PF)\n", c.B, c.H, c.W, c.Cin, c.Cout, (int)c.mask,
              (int)c.pooled, ws == 1 ? (pd == 2 ? "weight-stationary pd=2" : "weight-stationary pd=1") : (c.Cin == 64 ? "c64 kernel, two passes" : "generic igemm"), us, fl / us / 1e6, fl / us / 25e6);
     }
-  AK(asr_clear_tuning("WS_PD"));
+#ifdef ASR_TUNE_ABLATE        // section clocks: only a library built with ASR_HIPCC_EXTRA=-DASR_TUNE_ABLATE has the timing instantiations
   for (int ws = 1; ws < 2; ++ws) {
     if (c.Cin == 128 && ws == 1 && !(c.Cout == 128 ? (c.pooled || c.mask) : !c.mask)) continue;      // (timing instantiations of conv_ws.hip exist for these forms)
     Dev<long long> dbg(64);
@@ -179,6 +178,7 @@ static void time_case(const Case& c) {
       printf("    %s wave %d, %lld tiles, cycles per tile: barrier %lld  staging %lld  contraction %lld  dma wait %lld  epilogue %lld\n", ws == 1 ? "ws128" : "ws16 ", w, h[w * 8 + 5],
              h[w * 8 + 0] / h[w * 8 + 5], h[w * 8 + 1] / h[w * 8 + 5], h[w * 8 + 2] / h[w * 8 + 5], h[w * 8 + 3] / h[w * 8 + 5], h[w * 8 + 4] / h[w * 8 + 5]);
   }
+#endif
   AK(asr_clear_tuning(knob(c)));
 }
 

@@ -9,9 +9,15 @@ title = sys.argv[3] if len(sys.argv) > 3 else ""
 c = sqlite3.connect(db)
 rows = c.execute("select name, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name order by 3 desc").fetchall()
 tot = sum(r[2] for r in rows)
+# the number of steps in the trace is what a ONCE-PER-STEP kernel says it is, not what the command line promised (VERDICT r5 #4b: the
+# r05 header divided by 11 where every once-per-step kernel had 10 calls)
+once = [r[1] for r in rows if re.search(r"adam_noam_kernel|adam_kernel|step_advance_kernel", r[0])]
+if once and min(once) > 0 and min(once) != steps:
+    print("# (step count %d from the command line replaced by %d = calls of the once-per-step optimiser kernel)" % (steps, min(once)))
+    steps = min(once)
 if title:
     print("# " + title)
-print("# total kernel time %.1f ms over %d steps = %.2f ms/step" % (tot, steps, tot / steps))
+print("# total kernel time %.1f ms over %d steps = %.2f ms/step (sum of kernel durations: exceeds the wall clock where two streams overlap)" % (tot, steps, tot / steps))
 print("%10s %6s %8s %7s %11s  %s" % ("total_ms", "pct", "ms/step", "calls", "avg_us", "kernel"))
 for n, cnt, ms, avg in rows:
     n = re.sub(r'\(anonymous namespace\)::', '', n)
