@@ -307,6 +307,11 @@ def main():
                     "of the gradient all-reduce is exposed")
     ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"], help="N > 1: dtype in which the gradient slices are "
                     "all-reduced (bf16 = half the bytes per xGMI link, summed in bf16 by the collective; asr_hip/ddp.py)")
+    ap.add_argument("--ddp-graph", default="four", choices=["one", "four", "auto"],
+                    help="N > 1 (or ASR_FORCE_DDP=1): four = four hipGraphs with the RCCL all-reduces between them (default here: the ordering "
+                         "proven under two ranks, and an unattended multi-GPU run must not be the first to try a captured collective); one = the "
+                         "collectives captured inside ONE hipGraph; auto = one, verified against the four-body step on the capture batch, "
+                         "falling back loudly (train.py's default).  Recorded in config.ddp_graph")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying hipGraphs")
     ap.add_argument("--soak-seconds", type=float, default=5.0, help="UNTIMED replay of the same step for about this long after the timed "
                     "region (reported under config.soak, excluded from `value`): gives an external GPU-busy sampler something to see -- "
@@ -399,7 +404,7 @@ def main():
     gs = None
     if not a.eager:
         from asr_hip.graph import GraphedTrainStep
-        gs = GraphedTrainStep(model, opt, 0.1, src, src_len, tgt, warmup_steps=max(1, a.warmup))
+        gs = GraphedTrainStep(model, opt, 0.1, src, src_len, tgt, warmup_steps=max(1, a.warmup), ddp_graph=a.ddp_graph)
         step = lambda: gs()[0]
     else:
         step = eager_step
@@ -482,7 +487,7 @@ def main():
         value = frames / dt
         peak = PEAK_F32_TFLOPS if a.precision == "fp32" else PEAK_BF16_TFLOPS
         mode = "eager" if a.eager else ("hipGraph replay" if red is None or not red.active else
-                                        ("ONE hipGraph per step with the RCCL all-reduces captured inside (ASR_DDP_ONE_GRAPH=1)"
+                                        ("ONE hipGraph per step with the RCCL all-reduces captured inside (--ddp-graph %s)" % a.ddp_graph
                                          if getattr(gs, "_one", False) else "4 hipGraphs per step, RCCL all-reduces between them"))
         out = {"metric": "input spectrogram frames/sec (training step)", "value": value, "unit": "frames/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
@@ -504,6 +509,7 @@ def main():
                           "collective_library": (("RCCL %s" % ".".join(str(x) for x in torch.cuda.nccl.version()))
                                                  if dist.is_initialized() and dist.get_backend() == "nccl" else None),
                           "grad_wire": (a.grad_wire if (world > 1 or force_ddp) else None),
+                          "ddp_graph": ({"requested": a.ddp_graph, "ran": getattr(gs, "ddp_graph_mode", None)} if (gs is not None and (world > 1 or force_ddp)) else None),
                           "rank0_ms_per_step": dt_local / a.steps * 1e3,
                           "per_rank_ms_per_step": {"min": min(per_rank) / a.steps * 1e3, "max": max(per_rank) / a.steps * 1e3,
                                                    "all": [t / a.steps * 1e3 for t in per_rank]},

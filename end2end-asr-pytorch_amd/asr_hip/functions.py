@@ -916,16 +916,20 @@ class SDPAFn(Function):
         H, dk = cfg["H"], cfg["dk"]
         B, Tq, HD = Q.shape
         seed = P.next_seed()
-        scale = 1.0 / (dk ** 0.5)
+        scale = cfg.get("scale") or 1.0 / (dk ** 0.5)          # (heads zero-padded to a common width keep the reference's sqrt(dim_key))
         O32 = torch.empty((B, Tq, HD), device=Q.device, dtype=torch.float32) if (Q.dtype != torch.float32 and any(ctx.needs_input_grad)) else None
-        O, lse, _ = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
-                                 causal=cfg.get("causal", False), scale=scale, p=cfg["p"], seed=seed, o32=O32)
+        O, lse, attn = ops.attn_fwd(Q, K, V, H, dk, key_len=cfg.get("key_len"), key_pad=cfg.get("key_pad"),
+                                    causal=cfg.get("causal", False), scale=scale, p=cfg["p"], seed=seed, o32=O32,
+                                    want_attn=cfg.get("want_attn", False))
         ctx.t = (Q, K, V, O, lse, O32)
         ctx.cfg, ctx.seed, ctx.scale = cfg, seed, scale
+        if attn is not None:                                   # the reference's returned attention matrices, (H*B, Tq, Tk)
+            ctx.mark_non_differentiable(attn)
+            return O, attn
         return O
 
     @staticmethod
-    def backward(ctx, dO):
+    def backward(ctx, dO, *unused):
         Q, K, V, O, lse, O32 = ctx.t
         cfg = ctx.cfg
         dQ, dK, dV = ops.attn_bwd(Q, K, V, O, dO.contiguous(), lse, cfg["H"], cfg["dk"], key_len=cfg.get("key_len"),

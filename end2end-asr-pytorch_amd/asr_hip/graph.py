@@ -33,9 +33,19 @@ from . import params as P
 
 
 class GraphedTrainStep:
-    def __init__(self, model, opt, smoothing, src, src_len, tgt, clip_max_norm=None, warmup_steps=2, replay_after_capture=True):
+    def __init__(self, model, opt, smoothing, src, src_len, tgt, clip_max_norm=None, warmup_steps=2, replay_after_capture=True,
+                 ddp_graph=None):
         """Runs `warmup_steps` REAL steps eagerly on the given batch, captures, and (replay_after_capture) one more by replay.
-        A trainer that must apply each batch exactly once passes warmup_steps=1, replay_after_capture=False."""
+        A trainer that must apply each batch exactly once passes warmup_steps=1, replay_after_capture=False.
+        ddp_graph (data parallel only; train.py / bench.py --ddp-graph): "four" = four hipGraphs with the RCCL all-reduces between them
+        (the ordering proven under two ranks); "one" = the collectives captured inside ONE hipGraph (falls back to four when the
+        capture raises); "auto" = "one", then VERIFIED: the captured step is replayed on the capture batch from a snapshot of the
+        weights / moments / step state and must reproduce the loss sum and the gradient checksum of the four-body eager step from the
+        same snapshot -- else the four-graph form, loudly.  None: $ASR_DDP_GRAPH, else "four".  `self.ddp_graph_mode` tells what runs."""
+        self.ddp_graph = ddp_graph or os.environ.get("ASR_DDP_GRAPH") or ("one" if os.environ.get("ASR_DDP_ONE_GRAPH") == "1" else "four")
+        if self.ddp_graph not in ("one", "four", "auto"):
+            raise ValueError("ddp_graph must be one | four | auto, not %r" % (self.ddp_graph,))
+        self.ddp_graph_mode = None
         from utils.metrics import calculate_metrics
         self._metrics = calculate_metrics
         self.model, self.opt, self.smoothing, self.clip = model, opt, float(smoothing), clip_max_norm
@@ -73,8 +83,9 @@ class GraphedTrainStep:
                 self.loss, self.sums = self._body_single()
             self.graphs = [self.graph]
         elif self._capture_one_graph():
-            pass
+            self.ddp_graph_mode = "one (verified against the four-body step)" if self.ddp_graph == "auto" else "one"
         else:
+            self.ddp_graph_mode = "four" if self.ddp_graph == "four" else "four (fallback from %s)" % self.ddp_graph
             self.graph_a, self.graph_a2, self.graph_b, self.graph_c = (torch.cuda.CUDAGraph() for _ in range(4))
             with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
                 self.loss, self.sums, st = self._body_a()
@@ -92,12 +103,12 @@ class GraphedTrainStep:
             self._replay()
 
     def _capture_one_graph(self):
-        """Data parallel, ASR_DDP_ONE_GRAPH=1 (experiment, VERDICT r4 #7a): the three all-reduces captured INSIDE one hipGraph with
-        the four bodies (RCCL collectives are capturable; the work handles' waits become graph edges), so that a replay is one launch
-        on the host again instead of four graph launches + three collectives.  Falls back to the four-graph form when the capture
-        raises.  Measured on one rank over nccl: profiles/r05_ddp_one_graph.txt."""
+        """Data parallel, ddp_graph "one" / "auto" (VERDICT r4 #7a, r5 #8): the three all-reduces captured INSIDE one hipGraph with the
+        four bodies (RCCL collectives are capturable; the work handles' waits become graph edges), so that a replay is one launch on
+        the host again instead of four graph launches + three collectives.  Falls back to the four-graph form when the capture raises
+        or ("auto") when the verification replay disagrees.  Measured on one rank over nccl: profiles/r05_ddp_one_graph.txt."""
         self._one = False
-        if os.environ.get("ASR_DDP_ONE_GRAPH", "0") != "1":
+        if self.ddp_graph == "four":
             return False
         import logging
         for attempt in (1, 2):               # (one capture in ~20 raised on the GPU box while the collective library's watchdog was still polling the warm-up steps' work)
@@ -105,6 +116,7 @@ class GraphedTrainStep:
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
+                self._seed_ctr_at_capture = P._state["seed_ctr"]      # the dropout-site seeds this capture bakes in are drawn from here on
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.loss, self.sums = self._eager_step()
             except Exception as e:           # noqa: BLE001 -- any capture failure: once more, then the proven form below
@@ -114,19 +126,69 @@ class GraphedTrainStep:
                 g = None
                 continue
             self.graph, self.graphs, self._one = g, [g], True
+            if self.ddp_graph == "auto" and not self._verify_one_graph():
+                self.graph = self.graphs = None
+                self._one = False
+                break
             return True
-        logging.warning("one-graph data-parallel capture: four graphs with the collectives between them instead")
+        logging.warning("one-graph data-parallel step not used: FOUR graphs with the collectives between them instead")
         return False
+
+    def _verify_one_graph(self):
+        """"auto": from one snapshot of (weights, moments, bf16 shadow, device step state) run (a) the four bodies eagerly with the
+        collectives issued between them -- the ordering the four-graph form replays -- and (b) the captured one-graph step; both on the
+        capture batch with the same dropout seeds.  (b) must reproduce (a)'s reduced statistics slot [loss sum, token count,
+        num_correct] and the checksum (sum of squares) of the reduced flat gradient buffer.  The snapshot is restored afterwards: the
+        verification applies no step.  Every rank takes the same decision (the compared numbers are all-reduced quantities)."""
+        import logging
+        adam = self.opt.optimizer
+        flat = adam.flat
+        st = ops.step_state(self.src.device)
+        shadow = flat.shadow_for_step(torch.bfloat16) if ops.compute_dtype() == torch.bfloat16 else None
+        snap = [t.clone() for t in (flat.data, adam._m, adam._v, st)] + ([shadow.clone()] if shadow is not None else [])
+        seed_after = P._state["seed_ctr"]
+
+        def restore():
+            for dst, src_ in zip((flat.data, adam._m, adam._v, st) + ((shadow,) if shadow is not None else ()), snap):
+                dst.copy_(src_)
+            P._state["seed_ctr"] = self._seed_ctr_at_capture      # an eager step re-draws exactly the seeds the capture baked in
+
+        def probe(run):
+            restore()
+            run()
+            torch.cuda.synchronize()
+            return flat.stats[:3].detach().double().cpu(), float(flat.grad.detach().double().pow(2).sum().item())
+
+        try:
+            ref_stats, ref_sq = probe(lambda: self._eager_step())
+            one_stats, one_sq = probe(lambda: self.graph.replay())
+        finally:
+            restore()
+            P._state["seed_ctr"] = seed_after
+            torch.cuda.synchronize()
+        ok = bool(torch.allclose(ref_stats, one_stats, rtol=1e-6, atol=0.0)) and abs(ref_sq - one_sq) <= 1e-5 * max(abs(ref_sq), 1e-30)
+        if not ok:
+            logging.warning("one-graph data-parallel step DISAGREES with the four-body step on the capture batch: stats %s vs %s, gradient "
+                            "checksum %.9g vs %.9g", one_stats.tolist(), ref_stats.tolist(), one_sq, ref_sq)
+        return ok
 
     # ------------------------------------------------------------------------------------------------ single GPU
     def _body_single(self):
         ops.step_advance()
         self.opt.zero_grad()
-        pred, gold, self.hyp_seq, self.gold_seq = self.model(self.src, self.src_len, self.tgt)
-        loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
+        # (Transformer.forward's pieces: its hyp_seq -- a second arg-max pass over the 56 MB of logits -- comes from the loss kernel here)
+        core = self.core
+        enc_out, _ = core.encoder(core._features(self.src), self.src_len)
+        pred, gold, *_ = core.decoder(self.tgt, enc_out, self.src_len)
+        self.gold_seq = gold
+        loss, sums, self.hyp_seq = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False, with_argmax=True)
         ops.backward_from(loss)
         self._body_c(guard=sums)                 # sums[0] = the loss sum: non-finite -> the update is skipped on the device
         return loss.detach(), sums
+
+    # (The optimiser's transformer slice on a second graph branch under the conv backward -- legal without clipping -- was measured a
+    #  third time in round 6 and removed again: +0.11 ms whether it meets the HBM-bound pooling backward or the conv weight gradient,
+    #  whose LDS-DMA pipeline doubles its time next to a launch that saturates HBM.  profiles/r06_side_tail.txt)
 
     # ------------------------------------------------------------------------------------------------ data parallel
     @staticmethod
@@ -166,9 +228,8 @@ class GraphedTrainStep:
         enc_out, _ = core.encoder(leaf, self.src_len)
         enc_leaf = enc_out.detach().requires_grad_(True)          # second cut: the decoder's backward ends here
         pred, gold, *_ = core.decoder(self.tgt, enc_leaf, self.src_len)
-        self.hyp_seq = ops.argmax_rows(pred.detach().reshape(-1, pred.shape[-1])).view(pred.shape[0], pred.shape[1])
         self.gold_seq = gold
-        loss, sums = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False)
+        loss, sums, self.hyp_seq = self._metrics(pred, gold, smoothing=self.smoothing, loss_type="ce", sync=False, with_argmax=True)
         ops.backward_from(loss)
         ops.join_deferred()                     # every forked stream must have re-joined before this graph ends
         return loss.detach(), sums, {"feats": feats, "leaf": leaf, "enc_out": enc_out, "d_enc": enc_leaf.grad}

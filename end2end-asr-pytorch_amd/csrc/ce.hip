@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * CE_ROWS) void ce_fwd_kernel(const float* __res
     if (lane == 0) {
       const float lse = mi.v + logf(e);
       row_lse[row] = lse;
-      argmax[row] = mi.i;
+      argmax[row] = mi.i == 0x7fffffff ? 0 : mi.i;        // (a row without a finite value: index 0, like argmax_rows_kernel)
       const int64_t g = gold[row];
       if (g != pad_id) {
         const float lpg = l[g] - lse;

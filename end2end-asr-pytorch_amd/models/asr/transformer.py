@@ -228,8 +228,10 @@ class Decoder(nn.Module):
     def _kv_cache_supported(self):
         """The incremental decoders (asr_hip/decode.py) read the full-rank projection weights of every layer; the Low-Rank
         Transformer (--rank > 0: LowRankLinear holds .u / .v, no .weight) decodes by re-running the layer modules over the
-        prefix instead, like the reference's own loop."""
-        return all(isinstance(l.self_attn, MultiHeadAttention) and isinstance(l.encoder_attn, MultiHeadAttention) for l in self.layers)
+        prefix instead, like the reference's own loop.  So does a model with dim_key != dim_value (the caches hold H * dim_key columns for
+        keys and values alike)."""
+        return (self.dim_key == self.dim_value and
+                all(isinstance(l.self_attn, MultiHeadAttention) and isinstance(l.encoder_attn, MultiHeadAttention) for l in self.layers))
 
     @torch.no_grad()
     def greedy_search(self, encoder_padded_outputs, beam_width=2, lm_rescoring=False, lm=None, lm_weight=0.1, c_weight=1,

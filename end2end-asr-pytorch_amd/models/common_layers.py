@@ -81,6 +81,9 @@ def _mask_to_u8(mask):
     return mask.to(torch.uint8).contiguous()
 
 
+_HEAD_WIDTHS = (16, 32, 64)          # head widths the attention kernels contract (csrc/attention.hip dispatch)
+
+
 class MultiHeadAttention(nn.Module):
     """forward(query, key, value, mask=None) -> (output, attn)   (reference: common_layers.py:144-200).
 
@@ -90,8 +93,10 @@ class MultiHeadAttention(nn.Module):
 
     def __init__(self, num_heads, dim_model, dim_key, dim_value, dropout=0.1):
         super().__init__()
-        if dim_key != dim_value:
-            raise NotImplementedError("the fused attention kernel needs dim_key == dim_value")
+        # dim_key != dim_value is a signature the reference accepts (common_layers.py:144-168; no BASELINE config uses it): the
+        # attention kernels contract ONE head width (16, 32 or 64), so such a block runs them at the next width >= both on zero-padded heads
+        # (forward()'s _forward_padded) -- zero query / key columns add nothing to a score, zero value columns give output columns
+        # that are dropped again.
         self.num_heads, self.dim_model, self.dim_key, self.dim_value = num_heads, dim_model, dim_key, dim_value
         self.query_linear = nn.Linear(dim_model, num_heads * dim_key)
         self.key_linear = nn.Linear(dim_model, num_heads * dim_key)
@@ -110,6 +115,8 @@ class MultiHeadAttention(nn.Module):
                 need_attn=True, kv_grad_box=None):
         if key is not value:
             raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
+        if self.dim_key != self.dim_value or self.dim_key not in _HEAD_WIDTHS:
+            return self._forward_padded(query, key, mask, key_len, key_pad, causal, row_keep, need_attn)
         cfg = dict(H=self.num_heads, dk=self.dim_key, p=self.dropout.p if self.training else 0.0, key_len=key_len,
                    key_pad=key_pad if key_pad is not None else _mask_to_u8(mask), causal=causal, row_keep=row_keep,
                    want_attn=need_attn, kv_grad_box=kv_grad_box)
@@ -122,6 +129,36 @@ class MultiHeadAttention(nn.Module):
         if need_attn:
             return res[0], res[1]
         return res, None
+
+
+    def _forward_padded(self, query, key, mask, key_len, key_pad, causal, row_keep, need_attn):
+        """dim_key != dim_value (reference: common_layers.py:170-200 with separate widths): projections by LinearFn, heads zero-padded to
+        the kernels' next head width (16 / 32 / 64) >= both, SDPAFn on the padded heads with the reference's temperature sqrt(dim_key), the first dim_value
+        columns of every output head into the output projection, AddLNFn.  The pads and slices are torch views / copies on the device
+        (autograd differentiates them): the compatibility path of a boundary footnote, not the tuned one."""
+        import torch.nn.functional as TF
+        H, dk, dv = self.num_heads, self.dim_key, self.dim_value
+        fit = [w for w in _HEAD_WIDTHS if w >= max(dk, dv)]
+        if not fit:
+            raise NotImplementedError("attention heads wider than %d (dim_key %d, dim_value %d): the attention kernels contract 16, 32 or "
+                                      "64 columns per head" % (_HEAD_WIDTHS[-1], dk, dv))
+        d = fit[0]
+        p = self.dropout.p if self.training else 0.0
+        q_in, kv_in = _to_compute(query), _to_compute(key)
+        B, Tq, _ = q_in.shape
+        Tk = kv_in.shape[1]
+        Q = F_.linear(q_in, self.query_linear.weight, self.query_linear.bias).view(B, Tq, H, dk)
+        K = F_.linear(kv_in, self.key_linear.weight, self.key_linear.bias).view(B, Tk, H, dk)
+        V = F_.linear(kv_in, self.value_linear.weight, self.value_linear.bias).view(B, Tk, H, dv)
+        pad = lambda t, w: (TF.pad(t, (0, d - w)) if w < d else t).reshape(t.shape[0], t.shape[1], H * d).contiguous()
+        cfg = dict(H=H, dk=d, scale=1.0 / float(dk) ** 0.5, p=p, key_len=key_len,
+                   key_pad=key_pad if key_pad is not None else _mask_to_u8(mask), causal=causal, want_attn=need_attn)
+        res = F_.SDPAFn.apply(pad(Q, dk), pad(K, dk), pad(V, dv), cfg)
+        O, attn = (res if isinstance(res, tuple) else (res, None))
+        O = O.view(B, Tq, H, d)[..., :dv].reshape(B, Tq, H * dv)
+        y = F_.linear(O, self.output_linear.weight, self.output_linear.bias)
+        out = F_.AddLNFn.apply(y, q_in, self.layer_norm.weight, self.layer_norm.bias, dict(p=p, row_keep=row_keep))
+        return out, attn
 
 
 class ScaledDotProductAttention(nn.Module):

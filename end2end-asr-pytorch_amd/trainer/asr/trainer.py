@@ -157,7 +157,10 @@ class Trainer():
             tgt_b[:, :tgt.shape[1]].copy_(tgt)
             gs = graphs[key] = GraphedTrainStep(model, opt, smoothing, src_b, lens, tgt_b,
                                                 clip_max_norm=a.max_norm if a.clip else None, warmup_steps=1,
-                                                replay_after_capture=False)
+                                                replay_after_capture=False, ddp_graph=getattr(a, "ddp_graph", None))
+            if gs.ddp_graph_mode is not None and not self.__dict__.get("_logged_ddp_graph"):
+                self._logged_ddp_graph = True
+                logging.info("data-parallel graph replay: %s (--ddp-graph %s)", gs.ddp_graph_mode, gs.ddp_graph)
             loss, gold_seq, hyp_seq = gs.warm           # the eager step the constructor ran IS this batch's training step
             return self._global_loss(opt, loss), gold_seq, hyp_seq
         else:

@@ -55,14 +55,18 @@ def calculate_loss(pred, gold, input_lengths=None, target_lengths=None, smoothin
 
 
 def calculate_metrics(pred, gold, input_lengths=None, target_lengths=None, smoothing=0.0, loss_type="ce", sync=True,
-                      global_count=None):
+                      global_count=None, with_argmax=False):
     """-> (loss, num_correct)  (reference: metrics.py:78-100).  num_correct is a Python int as in the reference
-    (one device sync); pass sync=False to get the fp32 device tensor [loss_sum, count, num_correct] instead."""
+    (one device sync); pass sync=False to get the fp32 device tensor [loss_sum, count, num_correct] instead.
+    with_argmax (ce, sync=False): -> (loss, sums, argmax (B, T) int64): the row arg-max the loss kernel finds anyway (lowest index on
+    ties, like asr_argmax_rows) -- the captured training step takes its hyp_seq from here instead of a second pass over the logits."""
     if loss_type == "ctc":              # the reference returns (loss, None) (metrics.py:96-97)
         return calculate_loss(pred, gold, input_lengths, target_lengths, smoothing, "ctc"), None
     if loss_type != "ce":
         raise NotImplementedError("loss_type must be 'ce' or 'ctc'")
-    loss, sums, _ = F_.CEFn.apply(pred, gold, float(smoothing), constant.PAD_TOKEN, global_count)
+    loss, sums, am = F_.CEFn.apply(pred, gold, float(smoothing), constant.PAD_TOKEN, global_count)
     if sync:
         return loss, int(sums[2].item())
+    if with_argmax:
+        return loss, sums, am.view(pred.shape[0], pred.shape[1])
     return loss, sums

@@ -47,6 +47,11 @@ CASES = {
                "--dim-inner", "128", "--dim-emb", "64", "--feat_extractor", "", "--tgt-max-len", "16",
                "--src-max-len", "50", "--label-smoothing", "0.1", "--dropout", "0.0", "--emb_trg_sharing"],
         B=4, T=50, src_len=[50, 37, 20, 5], tgt_len=[15, 9, 4, 1], smoothing=0.1),
+    "dkdv_tiny": dict(  # dim_key != dim_value (reference: common_layers.py:144-168 takes them separately; round 6: the product accepts it)
+        flags=["--num-layers", "1", "--num-heads", "2", "--dim-model", "32", "--dim-key", "16", "--dim-value", "24",
+               "--dim-inner", "64", "--dim-emb", "32", "--feat_extractor", "", "--tgt-max-len", "12",
+               "--src-max-len", "40", "--label-smoothing", "0.1", "--dropout", "0.0"],
+        B=3, T=40, src_len=[40, 26, 7], tgt_len=[11, 6, 2], smoothing=0.1),
 }
 
 

@@ -39,7 +39,7 @@ multiples of those floors:
              arg-max: checked on EVERY row -- a row may differ from the oracle's arg-max only if the oracle's top-2 margin on that
              row is <= 2 x the measured max logit error of this run (north_star: "token-index argmax bit-exact"; a tie within the
              arithmetic's own error is the only admissible difference); the number of such rows is reported.
-Measured values (every tensor) are written to gpurun_out/parity_r05.json and quoted in DESIGN.md section 2.
+Measured values (every tensor) are written to gpurun_out/parity_r06.json and quoted in DESIGN.md section 2.
 """
 import json
 import os
@@ -53,10 +53,15 @@ import big_cases as BC
 pytestmark = pytest.mark.gpu
 
 REL_BF16 = 5e-2        # floor of the per-tensor bound ||g - g_64|| / ||g_64|| in bf16 mode (the bound is max(this, BF16_FLOOR_FACTOR * ebf[name]))
-# ebf[name] is ONE sample of PyTorch-autocast's error on that tensor and the product's error is another sample of the same kind of noise:
-# over ~150 tensors x 5 cases the largest ratio of two such samples is not bounded by 1.5 (rounds 3 - 4 used 1.5; round 5: a kernel change
-# that is bit-exact on integer inputs -- conv.5's forward in one pass, another summation order -- moved one decoder query bias of cfg0 from
-# 1.4 x to 1.55 x its floor, 0.0567 against 0.0551).  2 x is the factor DESIGN.md stated in round 2; the measured ratios are in the parity json.
+# ebf[name] is ONE sample of PyTorch-autocast's error on that tensor and the product's error is another sample of the same kind of noise.
+# The factor is DERIVED, once (round 6, VERDICT r5 #6b), from a measurement of how far two such samples lie apart on the reference itself
+# (oracle/bf16_floor_study.py -> profiles/r06_bf16_floor_study.json: the reference under torch.autocast(cpu, bf16) against its fp64 self,
+# three summation orders, cfg0 / cfg1_b2 / cfg3_shape, 984 tensor x pair ratios): median 1.02, 90 % below 1.17, the largest ratio on an
+# ordinary weight tensor 1.52 (an encoder key projection; the input LayerNorm's two parameters move 3 - 30 x when the intra-op thread
+# count changes -- another reduction kernel inside PyTorch -- and are the whole tail above 1.75).  So the SAME implementation, re-ordered,
+# already needs 1.52; another implementation of the same arithmetic gets the next quarter step of headroom on top: 2.0.  It is not to be
+# moved when a test fails: a tensor above 2 x its floor is a defect to be explained.  (History: rounds 3 - 4 used 1.5 and round 5 met a
+# decoder query bias at 1.55 x -- inside what the reference does to itself.)  The product's own ratios are histogrammed in the parity json.
 BF16_FLOOR_FACTOR = 2.0
 _oracle_cache = {}
 _report = {}
@@ -112,7 +117,20 @@ def _oracle_under_selections(z, model, taps, src, src_len, tgt, ref):
 def _dump():
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out, exist_ok=True)
-    with open(os.path.join(out, "parity_r05.json"), "w") as f:
+    # the product's rel / floor ratios over every (case, tensor) of the bf16 runs so far, as a histogram (same bin edges as the
+    # reference-against-itself study in profiles/r06_bf16_floor_study.json)
+    ratios = [r / max(fl, 1e-30) for key, e in _report.items() if key.endswith("/bf16") and "grad_rel_l2" in e for r, fl in e["grad_rel_l2"].values()]
+    if ratios:
+        edges = [0.0, 0.5, 0.75, 1.0, 1.05, 1.1, 1.2, 1.3, 1.5, 1.75, 2.0, 2.5, 3.0, 1e9]
+        ra = np.array(ratios)
+        _report["bf16_rel_over_floor"] = {
+            "n": int(ra.size), "max": float(ra.max()), "p50": float(np.quantile(ra, 0.5)), "p90": float(np.quantile(ra, 0.9)), "p99": float(np.quantile(ra, 0.99)),
+            "histogram": {"[%.2f, %s)" % (edges[i], ("%.2f" % edges[i + 1]) if edges[i + 1] < 1e8 else "inf"): int(((ra >= edges[i]) & (ra < edges[i + 1])).sum())
+                          for i in range(len(edges) - 1)},
+            "factor": BF16_FLOOR_FACTOR, "floor_absolute": REL_BF16,
+            "note": "rel = ||g - g64|| / ||g64|| of the product's bf16 gradient per parameter tensor, floor = the same for the reference under "
+                    "torch.autocast(cpu, bf16) (tests/golden/<case>.npz ebf/*); the per-tensor bound is max(floor_absolute, factor x floor)"}
+    with open(os.path.join(out, "parity_r06.json"), "w") as f:
         json.dump(_report, f, indent=1, sort_keys=True)
 
 

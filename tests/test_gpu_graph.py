@@ -183,7 +183,7 @@ def test_trainer_graph_buckets_equal_eager_on_whole_buckets(golden_dir, monkeypa
 
 
 def test_collectives_captured_inside_one_graph_equal_the_plain_step():
-    """VERDICT r4 #7a: with ASR_DDP_ONE_GRAPH=1 the data-parallel step is ONE hipGraph with the three RCCL all-reduces captured inside
+    """VERDICT r4 #7a: with --ddp-graph one | auto the data-parallel step is ONE hipGraph with the three RCCL all-reduces captured inside
     (instead of four graphs with host-issued collectives between them).  One rank over nccl (ASR_FORCE_DDP=1; an all-reduce over one
     rank is the identity): the benchmark's loss after the same steps must equal the plain single-graph step's, and the launch mode
     must say that the capture was used (no silent fallback to four graphs)."""
@@ -194,20 +194,24 @@ def test_collectives_captured_inside_one_graph_equal_the_plain_step():
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-roofline",
            "--soak-seconds", "0", "--no-exposure", "--batch", "8"]
 
-    def run(extra):
+    def run(extra, flags=()):
         env = dict(os.environ, **extra)
         env.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd + list(flags), env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out = json.loads(r.stdout.strip().splitlines()[-1])
         out["_stderr_tail"] = r.stderr[-1500:]
         return out
 
     plain = run({})
-    one = run({"ASR_FORCE_DDP": "1", "ASR_DDP_ONE_GRAPH": "1"})
+    # --ddp-graph auto: one graph, and only after its replay reproduced the four-body step's reduced loss sum / token
+    # count / gradient checksum on the capture batch (dropout 0.1 on: the same seeds are re-drawn); the mode that ran is in the line
+    one = run({"ASR_FORCE_DDP": "1"}, ["--ddp-graph", "auto"])
     four = run({"ASR_FORCE_DDP": "1"})
     assert "ONE hipGraph" in one["launch_mode"], (one["launch_mode"], one["_stderr_tail"])
+    assert one["config"]["ddp_graph"] == {"requested": "auto", "ran": "one (verified against the four-body step)"}, one["config"]["ddp_graph"]
     assert "4 hipGraphs" in four["launch_mode"], four["launch_mode"]
+    assert four["config"]["ddp_graph"] == {"requested": "four", "ran": "four"}, four["config"]["ddp_graph"]
     assert one["config"]["collective_backend"] == "nccl" and one["config"]["collective_library"].startswith("RCCL")
     lp, lo, lf = plain["config"]["final_loss"], one["config"]["final_loss"], four["config"]["final_loss"]
     assert abs(lp - lo) < 2e-3 and abs(lp - lf) < 2e-3, (lp, lo, lf)

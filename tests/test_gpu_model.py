@@ -68,7 +68,7 @@ def _noise_driven(k, name):
     return k.endswith("key_linear.bias") or (name == "emb_tiny" and k in ("conv.0.bias", "conv.3.bias"))
 
 
-@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny", "emb_tiny"])
+@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny", "emb_tiny", "dkdv_tiny"])
 def test_fp32_mode_matches_reference(golden_dir, name):
     z, args, model, opt = build(golden_dir, name, "fp32")
     sm = float(z["smoothing"])
@@ -108,7 +108,7 @@ def test_fp32_mode_matches_reference(golden_dir, name):
         np.testing.assert_allclose(v.cpu().numpy(), z["w2/" + k], rtol=0, atol=atol, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny", "emb_tiny"])
+@pytest.mark.parametrize("name", ["vgg_tiny", "raw_tiny", "emb_tiny", "dkdv_tiny"])
 def test_bf16_mode_within_tolerance(golden_dir, name):
     z, args, model, opt = build(golden_dir, name, "bf16")
     sm = float(z["smoothing"])

@@ -8,7 +8,7 @@ import torch
 
 from oracle import asr_oracle as O
 
-CASES = ["vgg_tiny", "emb_tiny", "raw_tiny"]
+CASES = ["vgg_tiny", "emb_tiny", "raw_tiny", "dkdv_tiny"]       # dkdv_tiny: dim_key 16 != dim_value 24 (round 6)
 
 
 def noise_driven(k, cfg):
