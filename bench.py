@@ -509,7 +509,7 @@ def main():
                           "collective_library": (("RCCL %s" % ".".join(str(x) for x in torch.cuda.nccl.version()))
                                                  if dist.is_initialized() and dist.get_backend() == "nccl" else None),
                           "grad_wire": (a.grad_wire if (world > 1 or force_ddp) else None),
-                          "ddp_graph": ({"requested": a.ddp_graph, "ran": getattr(gs, "ddp_graph_mode", None)} if (gs is not None and (world > 1 or force_ddp)) else None),
+                          "ddp_graph": ({"requested": a.ddp_graph, "ran": getattr(gs, "ddp_graph_mode", None), "verification": getattr(gs, "ddp_verify", None)} if (gs is not None and (world > 1 or force_ddp)) else None),
                           "rank0_ms_per_step": dt_local / a.steps * 1e3,
                           "per_rank_ms_per_step": {"min": min(per_rank) / a.steps * 1e3, "max": max(per_rank) / a.steps * 1e3,
                                                    "all": [t / a.steps * 1e3 for t in per_rank]},

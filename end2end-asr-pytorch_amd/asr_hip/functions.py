@@ -103,14 +103,14 @@ def _linear_bwd(dy2d, x2d, wparam, bparam, dx_out=None, accumulate=False, need_d
 
 
 # The output projection's data gradient IS the attention backward's dO: its epilogue also writes delta = rowsum(dO * O) per head
-# (asr_gemm_nn_rowdot), one dependent launch less per attention block.  A/B switch: 0 = asr_attn_bwd computes delta itself.
-_rowdot = os.environ.get("ASR_NN_ROWDOT", "1") != "0"
+# (asr_gemm_nn_rowdot), one dependent launch less per attention block (tuning NN_ROWDOT = 0 in the library = asr_attn_bwd computes delta
+# itself: the arm tests/test_gpu_ops.py holds the epilogue against).
 
 
 def _out_proj_bwd(dy2d, o2d, o32, wparam, bparam, Tq, dk):
     """(dO, delta or None) for MHAFn.backward: _linear_bwd of the output projection, with delta from the same launch where possible."""
     N, K = wparam.shape[0], wparam.numel() // wparam.shape[0]
-    if (_rowdot and dk == 64 and ops.defer_wgrad_now(dy2d.dtype) and ops.gemm_tn_supported(dy2d, o2d) and o2d.dtype == dy2d.dtype):
+    if (dk == 64 and ops.defer_wgrad_now(dy2d.dtype) and ops.gemm_tn_supported(dy2d, o2d) and o2d.dtype == dy2d.dtype):
         W = P.linear_weight(wparam)
         if W.shape[1] == K and ops.gemm_nn_supported(dy2d, W):
             got = ops.gemm_nn_rowdot(dy2d, W, o2d, o32.view(-1, K) if o32 is not None else None, Tq)
@@ -413,6 +413,23 @@ class FFNFn(Function):
 
 
 # ================================================================================================ encoder input
+# Hand-over between the conv front end and the encoder input projection (round 6).  The second max-pool's backward used to be a launch of
+# its own between the projection's data gradient and conv.7's backward (asr_maxpool_bwd_code: 58 us, 65 MB written by the GEMM, read
+# back with 33 MB of selection bytes, 262 MB written).  When VGGFn.forward produced its selection bytes channel last it leaves a slot
+# here; EncInFn.forward claims it if the features it is given ARE that output (live weak reference + address + size, never an address
+# alone; the claim empties the slot), and then its backward runs asr_gemm_nn_poolbwd -- the pooling backward in the data-gradient GEMM's
+# epilogue -- and leaves the un-pooled gradient in the box for VGGFn.backward, returning a stride-0 zero as the formal gradient.
+_pool_handover = [None]
+_pool_handover_on = os.environ.get("ASR_POOL_HANDOVER", "1") != "0"
+
+
+def _claim_pool_handover(x):
+    slot, _pool_handover[0] = _pool_handover[0], None
+    if slot is None or slot[0]() is None:
+        return None
+    return slot[3] if (slot[1] == x.data_ptr() and slot[2] == x.numel()) else None
+
+
 class EncInFn(Function):
     @staticmethod
     def forward(ctx, x, Win, bin_, gamma, beta, pe):
@@ -429,6 +446,9 @@ class EncInFn(Function):
         ctx.shape = (B, T, Din)
         ctx.need_dx = x.requires_grad
         ctx.in_dtype = x.dtype
+        ctx.pool_box = _claim_pool_handover(x) if (x.requires_grad and x.dtype == cd and x.is_contiguous()) else None
+        if ctx.pool_box is not None:
+            ctx.pool_box["claimed"] = True
         return out.view(B, T, -1)
 
     @staticmethod
@@ -438,11 +458,22 @@ class EncInFn(Function):
         Win, bin_, gamma, beta = ctx.params
         dout2 = dout.reshape(B * T, -1).contiguous()
         dz, _ = ops.add_ln_bwd(dout2, z, mean, rstd, gamma.data, None, P.grad_of(gamma), P.grad_of(beta))
-        dx = _linear_bwd(dz, x2, Win, bin_, need_dx=ctx.need_dx)
+        box = ctx.pool_box
+        dx = None
+        if box is not None and ctx.need_dx:
+            # the data gradient straight into the gradient of conv.7's un-pooled output (the pooling backward in the GEMM's epilogue)
+            Bc, Hc, Wc, Cc = box["x_shape"]
+            dy4 = ops.gemm_nn_poolbwd(dz, P.tcf_perm_shadow(Win, Cc, Hc // 2), box["code"], box["x_shape"])
+            if dy4 is not None:
+                box["dy4"] = dy4
+                _linear_bwd(dz, x2, Win, bin_, need_dx=False)                       # weight / bias gradient as ever
+                dx = ops.zero_scalar(dz.device, ctx.in_dtype).expand(B, T, Din)   # formal gradient: VGGFn.backward reads the box
+        if dx is None:
+            dx = _linear_bwd(dz, x2, Win, bin_, need_dx=ctx.need_dx)
+            if dx is not None:
+                dx = dx.view(B, T, Din).to(ctx.in_dtype)
         ops.flush_wgrads(final=True)                      # the transformer's backward ends here: every queued weight gradient in grouped launches
         P.grad_ready(*ctx.params)
-        if dx is not None:
-            dx = dx.view(B, T, Din).to(ctx.in_dtype)
         return dx, None, None, None, None, None
 
 
@@ -466,18 +497,15 @@ class EmbedFn(Function):
 
 
 # ================================================================================================ vgg front end
-_conv7_pool = os.environ.get("ASR_CONV7_POOL", "1") != "0"       # A/B switch: 0 = conv.7 stores its output, the pooling kernel reads it back
-_pool_codes = os.environ.get("ASR_POOL_CODES", "1") != "0"         # A/B switch: 0 = the pooling backward finds the arg max again from the activations
+# Round 6 removed the A/B switches of this front end (ASR_CONV7_POOL, ASR_POOL_CODES, ASR_LEVEL0, ASR_RELU_BITS: every one measured, the
+# fused forms won -- DESIGN.md section 4): each fused form is taken where the library has it (its wrapper returns None otherwise: fp32
+# parity mode, odd shapes) and when the parity tests' activation tap does not need the stored tensors.
+#   * pools from their convolution's epilogue with one selection byte per pooled element (the un-pooled outputs are never stored);
+#   * the full-resolution level (conv.0, conv.2, first pool) as three launches that never store a 64-channel full-resolution tensor
+#     (csrc/conv_level0.hip): forward, weight side and data side of the backward;
+#   * conv.5's ReLU mask for conv.7's data gradient as one bit per element written by conv.5's own epilogue (asr_conv3x3_igemm_bits).
 # (conv weight gradients -- or the fold of their partial blocks -- on the second stream next to the following data gradient measured
 #  slower, 7.82-7.94 / 7.50-7.59 vs 7.70 / 7.44 ms per step in round 2: both kernels are MFMA- and HBM-bound, sharing the CUs slows both)
-
-
-# The full-resolution level (conv.0, conv.2, first pool) as three launches that never store a 64-channel full-resolution tensor
-# (csrc/conv_level0.hip): forward, weight side and data side of the backward.  A/B switch: 0 = the launch chain on stored activations.
-_level0 = os.environ.get("ASR_LEVEL0", "1") != "0"
-# conv.5's ReLU mask for conv.7's data gradient as one bit per element written by conv.5's own epilogue (asr_conv3x3_igemm_bits): the
-# gradient kernel reads 16 MB of mask instead of the 262 MB of conv.5's output.  A/B switch: 0 = the stored activations are the mask.
-_relu_bits = os.environ.get("ASR_RELU_BITS", "1") != "0"
 
 
 class VGGFn(Function):
@@ -491,7 +519,7 @@ class VGGFn(Function):
         # conv.0 + ReLU recomputed inside conv.2's loader, conv.2 + ReLU + MaxPool2d + selection codes from its epilogue: the log-mel
         # frames in, the pooled tensor out (bf16 compute; the parity tests' tap needs the stored activations)
         lvl0 = None
-        if _level0 and _pool_codes and cd == torch.bfloat16 and not tap and w0.shape[0] == 64 and tuple(w2.shape[:2]) == (64, 64):
+        if cd == torch.bfloat16 and not tap and w0.shape[0] == 64 and tuple(w2.shape[:2]) == (64, 64):
             lvl0 = ops.vgg_level0_fwd(src, w0.data, b0.data, wk2, b2.data)
         if lvl0 is not None:
             y1 = y2 = None
@@ -501,25 +529,33 @@ class VGGFn(Function):
             # conv.2 + ReLU + MaxPool2d in one epilogue.  With selection codes (one byte per pooled element) the backward never reads the
             # un-pooled activations again, so y2 (527 MB at the benchmark shape) is not even stored -- unless the parity tests' tap
             # (capture_selections) or a no-code fallback needs it.
-            fused = ops.conv3x3_relu_pool_code(y1, wk2, b2.data, w2.shape[0], keep_y=tap) if _pool_codes else None
+            fused = ops.conv3x3_relu_pool_code(y1, wk2, b2.data, w2.shape[0], keep_y=tap)
             if fused is not None:
                 y2, p1, c1 = fused
             else:
                 y2, p1 = ops.conv3x3_relu_pool(y1, wk2, b2.data, w2.shape[0])
                 c1 = None
         wk5, _ = P.conv_shadow(w5)
-        with_bits = ops.conv3x3_relu_bits(p1, wk5, b5.data, w5.shape[0]) if (_relu_bits and cd == torch.bfloat16 and not tap) else None
+        with_bits = ops.conv3x3_relu_bits(p1, wk5, b5.data, w5.shape[0]) if (cd == torch.bfloat16 and not tap) else None
         y3, m3 = with_bits if with_bits is not None else (ops.conv3x3(p1, wk5, b5.data, w5.shape[0], relu=True), None)
         wk7, _ = P.conv_shadow(w7)
         y4_shape = tuple(y3.shape[:3]) + (w7.shape[0],)
         # conv.7 + ReLU + MaxPool2d + the (B, T', C F') transpose from the convolution's epilogue: y4 is never stored (not for the tap)
-        fused7 = ops.conv3x3_relu_pool_tcf_code(y3, wk7, b7.data, w7.shape[0]) if (_pool_codes and _conv7_pool and not tap) else None
+        fused7, box = None, None
+        if not tap:
+            # selection bytes channel last when a consumer may take the pooling backward into its own epilogue (EncInFn, see _pool_handover)
+            if _pool_handover_on and cd == torch.bfloat16 and any(ctx.needs_input_grad):
+                fused7 = ops.conv3x3_relu_pool_tcf_code(y3, wk7, b7.data, w7.shape[0], code_cl=True)
+                if fused7 is not None:
+                    box = {"code": fused7[1], "x_shape": y4_shape, "claimed": False, "dy4": None}
+            if fused7 is None:
+                fused7 = ops.conv3x3_relu_pool_tcf_code(y3, wk7, b7.data, w7.shape[0])
         if fused7 is not None:
             y4 = None
             out, c4 = fused7
         else:
             y4 = ops.conv3x3(y3, wk7, b7.data, w7.shape[0], relu=True)
-            pooled = ops.maxpool_fwd_code(y4, tcf=True) if _pool_codes else None
+            pooled = ops.maxpool_fwd_code(y4, tcf=True)
             if pooled is not None:
                 out, c4 = pooled
             else:
@@ -529,6 +565,8 @@ class VGGFn(Function):
         # what backward reads: the conv inputs (y1, p1, y3), the ReLU masks (y1, y3) and either the codes or the pre-pool activations
         ctx.t = (src, y1, None if c1 is not None else y2, p1, y3, None if c4 is not None else y4, c1, c4, y4_shape, m3)
         ctx.params = (w0, b0, w2, b2, w5, b5, w7, b7)
+        ctx.pool_box = box
+        _pool_handover[0] = (weakref.ref(out), out.data_ptr(), out.numel(), box) if box is not None else None
         return out
 
     @staticmethod
@@ -540,7 +578,15 @@ class VGGFn(Function):
             # dW and db straight from the NHWC tensors (transposing LDS reads; no planar copies)
             ops.conv3x3_wgrad_nhwc(x, dy, P.grad_of(w), P.grad_of(b))
 
-        dy4 = ops.maxpool_bwd_code(c4, dout.contiguous(), y4_shape, tcf=True) if c4 is not None else ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
+        box = ctx.pool_box
+        dy4 = box.pop("dy4", None) if box is not None else None
+        if dy4 is None:
+            if box is not None:
+                # channel-last selection bytes, but nobody took the pooling backward (the features went somewhere else than EncInFn):
+                # back to the pooled tensor's own layout for the stand-alone kernel (a copy on the device; not the training path)
+                Bq, Hq, Wq, Cq = y4_shape
+                c4 = c4.permute(0, 1, 3, 2).reshape(Bq, Wq // 2, Cq * (Hq // 2)).contiguous()
+            dy4 = ops.maxpool_bwd_code(c4, dout.contiguous(), y4_shape, tcf=True) if c4 is not None else ops.maxpool_bwd(y4, dout.contiguous(), tcf=True)
         wgrad(y3, dy4, w7, b7, "c7")
         P.grad_ready(w7, b7)
         _, wd7 = P.conv_shadow(w7)
@@ -586,9 +632,11 @@ def _conv_gemm_fwd(x_nhwc, g, w, b, tag):
     return col, Ws, y, M, K
 
 
-_emb_window = os.environ.get("ASR_EMB_WINDOW", "1") != "0"
-_emb_shift_wgrad = os.environ.get("ASR_EMB_SHIFT_WGRAD", "1") != "0"
-_emb_shift_fwd = os.environ.get("ASR_EMB_SHIFT_FWD", "1") != "0"
+# (Round 6 removed ASR_EMB_WINDOW / ASR_EMB_SHIFT_FWD / ASR_EMB_SHIFT_WGRAD: the time-window and packet formulations below won every
+#  measurement of rounds 2 - 3; the full im2col path stays as the fallback for geometries they do not cover.  The two attributes below
+#  are not switches but test arms: tests/test_host.py checks the index algebra of BOTH forms of each contraction on CPU stand-ins.)
+_emb_shift_fwd = True          # unit time stride: one dense product over single-step patches + asr_window_sum (else the window-view GEMM)
+_emb_shift_wgrad = True        # weight gradient as ONE packet-of-rows contraction against the shifted dy view (else per window view)
 
 
 def _window_ok(g):
@@ -596,7 +644,7 @@ def _window_ok(g):
     extent is a whole number of strides (both emb_cnn layers: 1 -> 32, 41 x 11, stride (2,2), time padding 10, and 32 -> 32,
     21 x 11, stride (2,1)); bf16 operands."""
     B, H, W, C, KH, KW, SH, SW, PH, PW, OH, OW = g
-    return _emb_window and PH == 0 and KW > 1 and (W + 2 * PW) % SW == 0 and ops.compute_dtype() == torch.bfloat16
+    return PH == 0 and KW > 1 and (W + 2 * PW) % SW == 0 and ops.compute_dtype() == torch.bfloat16
 
 
 def _window_geom(g):

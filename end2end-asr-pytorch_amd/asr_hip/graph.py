@@ -46,6 +46,7 @@ class GraphedTrainStep:
         if self.ddp_graph not in ("one", "four", "auto"):
             raise ValueError("ddp_graph must be one | four | auto, not %r" % (self.ddp_graph,))
         self.ddp_graph_mode = None
+        self.ddp_verify = None                    # "auto": the numbers of the verification replay (bench.py prints them)
         from utils.metrics import calculate_metrics
         self._metrics = calculate_metrics
         self.model, self.opt, self.smoothing, self.clip = model, opt, float(smoothing), clip_max_norm
@@ -77,6 +78,16 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.reset_pending()
+        self._capture()
+        # A capture RECORDS the refresh launches of the lazily refreshed weight shadows (conv packs, the channel-last copy of the input
+        # projection) and marks those caches fresh -- without running them.  A replay refreshes them itself; an EAGER step that follows a
+        # capture directly (the trainer's first batch of another bucket shape) would read copies one optimiser step old (round 6).
+        P.bump_generation()
+        if replay_after_capture:
+            self._host_after()                           # capture does not execute; replay below does
+            self._replay()
+
+    def _capture(self):
         if self.red is None:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
@@ -98,9 +109,6 @@ class GraphedTrainStep:
                 self._body_c()
             del st
             self.graphs = [self.graph_a, self.graph_a2, self.graph_b, self.graph_c]
-        if replay_after_capture:
-            self._host_after()                           # capture does not execute; replay below does
-            self._replay()
 
     def _capture_one_graph(self):
         """Data parallel, ddp_graph "one" / "auto" (VERDICT r4 #7a, r5 #8): the three all-reduces captured INSIDE one hipGraph with the
@@ -155,6 +163,7 @@ class GraphedTrainStep:
 
         def probe(run):
             restore()
+            P.bump_generation()          # (as after every step: the lazily refreshed weight shadows are re-derived from the restored masters)
             run()
             torch.cuda.synchronize()
             return flat.stats[:3].detach().double().cpu(), float(flat.grad.detach().double().pow(2).sum().item())
@@ -166,10 +175,15 @@ class GraphedTrainStep:
             restore()
             P._state["seed_ctr"] = seed_after
             torch.cuda.synchronize()
-        ok = bool(torch.allclose(ref_stats, one_stats, rtol=1e-6, atol=0.0)) and abs(ref_sq - one_sq) <= 1e-5 * max(abs(ref_sq), 1e-30)
+        # What the check must catch is an ORDERING defect of the captured collectives (a slice reduced before its gradients are complete,
+        # a body running ahead of a collective): whole tensors missing or stale, i.e. errors of tens of percent.  What it must tolerate:
+        # the eager bodies contract the linear layers' weight gradients per layer where the capture groups them (another summation
+        # order), and fp32 atomics in the bias / statistics sums: 1e-6-level noise.  Hence 1e-4 on the statistics, 1e-3 on the checksum.
+        ok = bool(torch.allclose(ref_stats, one_stats, rtol=1e-4, atol=0.0)) and abs(ref_sq - one_sq) <= 1e-3 * max(abs(ref_sq), 1e-30)
+        self.ddp_verify = {"stats_four_body": ref_stats.tolist(), "stats_one_graph": one_stats.tolist(), "grad_sumsq_four_body": ref_sq,
+                           "grad_sumsq_one_graph": one_sq, "agree": ok}
         if not ok:
-            logging.warning("one-graph data-parallel step DISAGREES with the four-body step on the capture batch: stats %s vs %s, gradient "
-                            "checksum %.9g vs %.9g", one_stats.tolist(), ref_stats.tolist(), one_sq, ref_sq)
+            logging.warning("one-graph data-parallel step DISAGREES with the four-body step on the capture batch: %s", self.ddp_verify)
         return ok
 
     # ------------------------------------------------------------------------------------------------ single GPU

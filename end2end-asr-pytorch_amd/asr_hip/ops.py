@@ -92,16 +92,15 @@ class fork:
 # ---- deferred, grouped weight gradients.  Only a linear layer's DATA gradient feeds the rest of backward; its weight gradient is a
 # latency-bound chain of 16 - 64 blocks when launched alone.  While a hipGraph is being captured (bf16, no data-parallel reducer
 # waiting for per-layer gradients) the layers' (dy, x) pairs are queued and contracted by ONE launch per 16 layers at the end of the
-# transformer's backward (asr_gemm_tn_grouped).  ASR_DEFER_WGRAD=0 restores the per-layer launches.  (Round 3: also under the multi-graph
+# transformer's backward (asr_gemm_tn_grouped; per-layer launches everywhere else).  (Round 3: also under the multi-graph
 # data-parallel step, whose reducer only exchanges between graphs.)
-_defer_wgrad = os.environ.get("ASR_DEFER_WGRAD", "1") != "0"
 _wgrad_q = []
-WGRAD_GROUP = int(os.environ.get("ASR_WGRAD_GROUP", "48"))      # layers per grouped launch (<= 48: asr_gemm_tn_grouped).  Round 5: whole-contraction blocks dispatched longest first want the LARGEST group (the headline's 46 layers are one launch of 503 blocks); round 3's equal pieces: 16 / 24 / 32 measured, profiles/r03_grouped_wgrad_group_size_ab.txt
+WGRAD_GROUP = 48      # layers per grouped launch (<= 48: asr_gemm_tn_grouped).  Round 5: whole-contraction blocks dispatched longest first want the LARGEST group (the headline's 46 layers are one launch of 503 blocks); round 3's equal pieces: 16 / 24 / 32 measured, profiles/r03_grouped_wgrad_group_size_ab.txt
 # a group is also closed once it holds this many 64-row stages of 256 x 256 blocks (about 150 per workgroup of the scheduled kernel):
 # with 12 720 rows per layer (configs[3]) groups of 16 layers measure 0.3 - 0.5 ms per step faster than groups of 32, with 6 400 rows
 # groups of 32 are the faster ones -- both are ~38 000 stages.  profiles/r03_grouped_wgrad_group_size_ab.txt
-# (round 5: off by default -- it was tuned for the equal-piece kernel; 38000 restores round 3's grouping together with ASR_TN_ROT=0)
-WGRAD_STAGES = int(os.environ.get("ASR_WGRAD_STAGES", "0"))
+# (round 5: off -- it was tuned for the equal-piece kernel; a module attribute, like WGRAD_GROUP, for tests/test_host.py -- no environment switch since round 6)
+WGRAD_STAGES = 0
 _wgrad_stages = [0]
 
 
@@ -109,7 +108,6 @@ _wgrad_stages = [0]
 # "backward is over" is known: under a hipGraph capture every graph body ends with join_deferred(); in an EAGER backward pass the
 # autograd engine calls us back when the pass has finished (queue_callback), so loss.backward() still returns complete gradients --
 # the default train.py loop then issues ~60 launches per step less (round 4).  Outside both (an op called directly) nothing is deferred.
-_defer_eager = os.environ.get("ASR_DEFER_EAGER", "1") != "0"
 _backward_flush = {"armed": False}
 
 
@@ -122,8 +120,6 @@ def deferral_ok():
     """True while a hipGraph is being captured, or inside an eager autograd backward pass whose end will flush the queues."""
     if torch.cuda.is_current_stream_capturing():
         return True
-    if not _defer_eager:
-        return False
     from . import params as P_
     r = P_._state["reducer"]
     if r is not None and getattr(r, "active", False):
@@ -139,7 +135,7 @@ def deferral_ok():
 
 
 def defer_wgrad_now(dtype=None):
-    if not _defer_wgrad or (dtype or compute_dtype()) != torch.bfloat16:
+    if (dtype or compute_dtype()) != torch.bfloat16:
         return False
     from . import params as P_
     r = P_._state["reducer"]
@@ -296,11 +292,11 @@ def gemm_nn_rowdot(dy, w, o, o32, T):
     return dx, rowdot
 
 
-_nn_tn = os.environ.get("ASR_NN_TN", "1") != "0"
+_nn_tn = True
 # larger weights keep the two-stream pair: their 128 x 128-tile weight-gradient kernel moves half the operand bytes per flop, which
 # is worth more than the fork / join it costs (512 x 5120 over 6400 rows: 112 us as a pair, 141 us as one launch)
-_nn_tn_max = int(os.environ.get("ASR_NN_TN_MAX", str(1 << 21)))
-_tn_fold_next = os.environ.get("ASR_TN_FOLD_NEXT", "1") != "0"
+_nn_tn_max = 1 << 21
+_tn_fold_next = True
 _tn_pending = []
 
 
@@ -438,7 +434,7 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     d_y = torch.empty_like(z) if (p > 0 or defer_wgrad_now(z.dtype)) else d_res
     n_ws = L.load().asr_add_ln_bwd_workspace(M, D)
     ws = torch.empty(n_ws, device=z.device, dtype=torch.float32)       # caching allocator: no cost after the first step
-    if _ln_multi and D % 2 == 0 and deferral_ok():
+    if D % 2 == 0 and deferral_ok():
         # graph capture: the dgamma / dbeta sums of all layers in one launch at the end of backward (flush_ln_reduces)
         L.call("asr_add_ln_bwd_partials", L.ptr(dout), L.ptr(z), L.ptr(mean), L.ptr(rstd), L.ptr(gamma), L.ptr(row_keep),
                L.ptr(d_res), L.ptr(d_y), L.ptr(ws), n_ws, M, D, float(p), int(seed), _seed_dev(z), L.dt(z), L.stream())
@@ -450,7 +446,6 @@ def add_ln_bwd(dout, z, mean, rstd, gamma, row_keep, dgamma, dbeta, p=0.0, seed=
     return d_res, d_y
 
 
-_ln_multi = os.environ.get("ASR_LN_MULTI", "1") != "0"
 _ln_pending = []
 
 
@@ -863,12 +858,12 @@ _ones = {}
 _consts = {}
 
 
-def zero_scalar(device):
-    """A shared 0-dim fp32 zero (read-only by convention: formal gradients that nobody consumes)."""
-    t = _consts.get(("zero", str(device)))
+def zero_scalar(device, dtype=torch.float32):
+    """A shared 0-dim zero (read-only by convention: formal gradients that nobody consumes)."""
+    t = _consts.get(("zero", str(device), dtype))
     if t is None:
-        t = torch.zeros((), device=device, dtype=torch.float32)
-        _consts[("zero", str(device))] = t
+        t = torch.zeros((), device=device, dtype=dtype)
+        _consts[("zero", str(device), dtype)] = t
     return t
 
 
@@ -1046,19 +1041,47 @@ def vgg_level0_wgrad(src, w0, b0, dpool, code, dw2, db2):
            B, H, W, L.stream())
 
 
-def conv3x3_relu_pool_tcf_code(x, wk, bias, Cout):
+def conv3x3_relu_pool_tcf_code(x, wk, bias, Cout, code_cl=False):
     """(pool (B, W/2, Cout * H/2), code): the encoder-layout max-pool of ReLU(conv3x3(x) + bias) and its selection bytes from the
-    convolution's own epilogue (the un-pooled output is never stored); None when the library has no fused form for this shape."""
+    convolution's own epilogue (the un-pooled output is never stored); None when the library has no fused form for this shape.
+    code_cl: the selection bytes CHANNEL LAST, (B, W/2, H/2, Cout) -- what gemm_nn_poolbwd reads -- instead of pool's own layout
+    (B, W/2, Cout, H/2); None when only the other layout is available."""
     B, H, W, Cin = x.shape
     assert x.is_contiguous()
     pool = torch.empty((B, W // 2, Cout * (H // 2)), device=x.device, dtype=x.dtype)
-    code = torch.empty((B, W // 2, Cout * (H // 2)), device=x.device, dtype=torch.uint8)
-    rc = L.load().asr_conv3x3_relu_pool_tcf_code(L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(pool), L.ptr(code), B, H, W, Cin, Cout,
-                                                 L.dt(x), L.stream())
+    code = torch.empty((B, W // 2, H // 2, Cout) if code_cl else (B, W // 2, Cout * (H // 2)), device=x.device, dtype=torch.uint8)
+    fn = L.load().asr_conv3x3_relu_pool_tcf_codecl if code_cl else L.load().asr_conv3x3_relu_pool_tcf_code
+    rc = fn(L.ptr(x), L.ptr(wk), L.ptr(bias), L.ptr(pool), L.ptr(code), B, H, W, Cin, Cout, L.dt(x), L.stream())
     if rc == L.EUNSUPPORTED:
         return None
     L.check(rc, "asr_conv3x3_relu_pool_tcf_code")
     return pool, code
+
+
+def permute_cols_tcf(src, dst, C, H2):
+    """dst[r][h2 * C + c] = src[r][c * H2 + h2] (2-D, same shape): model feature order -> channel last (asr_permute_cols_tcf)."""
+    assert src.dim() == 2 and dst.shape == src.shape and src.shape[1] >= C * H2 and src.dtype == dst.dtype
+    L.call("asr_permute_cols_tcf", L.ptr(src), src.stride(0), L.ptr(dst), dst.stride(0), src.shape[0], C, H2, L.dt(src), L.stream())
+    return dst
+
+
+def gemm_nn_poolbwd(dy2d, w_perm, code_cl, x_shape):
+    """The encoder input projection's data gradient with the second max-pool's backward in its epilogue: dy2d (B * W2, N) . w_perm
+    (N, H2 * C; columns channel last) routed through the selection bytes code_cl (B, W2, H2, C) into the gradient of the un-pooled conv
+    output, (B, 2 H2, 2 W2, C) NHWC = x_shape.  None when the library has no such form for the shape (callers: gemm_nn + maxpool_bwd_code)."""
+    B, H, W, C = x_shape
+    H2, W2 = H // 2, W // 2
+    M, K = dy2d.shape[0], w_perm.shape[0]
+    if (H % 2 or W % 2 or M != B * W2 or w_perm.shape[1] != H2 * C or dy2d.dtype != torch.bfloat16 or dy2d.stride(1) != 1 or
+            w_perm.stride(1) != 1 or tuple(code_cl.shape) != (B, W2, H2, C) or not code_cl.is_contiguous()):
+        return None
+    dx = torch.empty(x_shape, device=dy2d.device, dtype=dy2d.dtype)
+    rc = L.load().asr_gemm_nn_poolbwd(L.ptr(dy2d), dy2d.stride(0), L.ptr(w_perm), w_perm.stride(0), L.ptr(code_cl), L.ptr(dx), M, K, H2, W2,
+                                      C, L.dt(dy2d), L.stream())
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc, "asr_gemm_nn_poolbwd")
+    return dx
 
 
 def maxpool_fwd_code(x, tcf=False):

@@ -83,6 +83,24 @@ def conv_shadow(p, dtype=None):
     return sh["wk"], sh["wd"]
 
 
+def tcf_perm_shadow(p, C, H2, dtype=None):
+    """p: the encoder input projection's (N, C * H2) master (columns in the model's feature order c * H2 + h2, reference
+    transformer.py:74-76) -> its compute-dtype shadow with the columns in CHANNEL-LAST order h2 * C + c: the B operand of
+    ops.gemm_nn_poolbwd.  Refreshed like the conv packs: one launch whenever the master changed (every optimiser step)."""
+    dtype = dtype or ops.compute_dtype()
+    sh = p.__dict__.get("_asr_tcf_perm")
+    key = _key(p, dtype) + (C, H2)
+    if sh is not None and sh["key"] == key:
+        return sh["w"]
+    W = linear_weight(p, dtype)
+    if sh is None or sh["w"].dtype != dtype or sh["w"].device != p.device or sh["w"].shape != W.shape:
+        sh = {"w": torch.empty_like(W)}
+        p.__dict__["_asr_tcf_perm"] = sh
+    ops.permute_cols_tcf(W, sh["w"], C, H2)
+    sh["key"] = key
+    return sh["w"]
+
+
 def conv_shadows(params, dtype=None):
     """conv_shadow() for several weights at once: the stale ones are packed by ONE launch (asr_conv_pack_weight_multi)."""
     dtype = dtype or ops.compute_dtype()

@@ -1390,8 +1390,9 @@ extern "C" int asr_conv3x3_relu_pool_code(const void* x, const void* wk, const f
  * one selection byte per pooled element in the same layout (conv.7 + ReLU + MaxPool2d + view / transpose, transformer.py:50-52,74-76).
  * ASR_EUNSUPPORTED unless bf16, Cout = 128, Cin a multiple of 64, H and W multiples of 16 (callers use asr_conv3x3_igemm +
  * asr_maxpool_fwd_code). */
-extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H,
-                                              int W, int Cin, int Cout, int dtype, hipStream_t s) {
+namespace {
+int conv3x3_relu_pool_tcf_code_impl(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int code_cl, int B, int H,
+                                    int W, int Cin, int Cout, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(x && wk && pool && code && B >= 0 && H > 0 && W > 0);
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   if (dtype != ASR_BF16 || Cout != 128 || Cin % 64 != 0 || H % 8 != 0 || W % 16 != 0 || !aligned16(x) || !aligned16(wk) || !aligned16(pool) ||
@@ -1401,18 +1402,28 @@ extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, con
   if (Cin == 128 && H % 8 == 0 && asr_tuning("WS128", 1) != 0) {        // conv.7 forward: persistent weight-stationary kernel (conv_ws.hip)
     WsArgs a{};
     a.x = static_cast<const bf16_t*>(x); a.wk = static_cast<const bf16_t*>(wk); a.bias = bias;
-    a.pool = static_cast<bf16_t*>(pool); a.code = code;
+    a.pool = static_cast<bf16_t*>(pool); a.code = code; a.code_cl = code_cl;
     a.B = B; a.H = H; a.W = W; a.Cin = 128; a.Cout = Cout; a.relu = 1;
     AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
     const int rc = asr_conv3x3_ws128_launch(a, s);
     if (rc != ASR_EUNSUPPORTED) return rc;
   }
+  if (code_cl) return ASR_EUNSUPPORTED;        // channel-last selection bytes: the weight-stationary kernel only
   if (H % 16 != 0 || asr_tuning("IGEMM_TH", 16) != 16) return ASR_EUNSUPPORTED;
   ConvArgs p{};
   p.x = x; p.wk = wk; p.bias = bias; p.pool = pool; p.code = code;
   p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
   return launch_igemm_t<bf16_t, 128, 16, 1, 1, true>(p, s);
+}
+}  // namespace
+extern "C" int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H,
+                                              int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  return conv3x3_relu_pool_tcf_code_impl(x, wk, bias, pool, code, 0, B, H, W, Cin, Cout, dtype, s);
+}
+extern "C" int asr_conv3x3_relu_pool_tcf_codecl(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code_cl, int B, int H,
+                                                int W, int Cin, int Cout, int dtype, hipStream_t s) {
+  return conv3x3_relu_pool_tcf_code_impl(x, wk, bias, pool, code_cl, 1, B, H, W, Cin, Cout, dtype, s);
 }
 
 extern "C" int asr_maxpool_fwd(const void* x, void* y, int B, int H, int W, int C, int out_tcf, int dtype, hipStream_t s) {

@@ -10,7 +10,9 @@ struct WsArgs {
   const bf16_t* mask;   // (B, H, W, Cout) or null: output zeroed where mask <= 0 (ReLU mask of the consumer's input, dgrad)
   bf16_t* y;            // (B, H, W, Cout); unused by the pooled form
   bf16_t* pool;         // pooled form: (B, W/2, Cout, H/2) = the encoder layout (B, T', C F') of max-pool(ReLU(conv))
-  uint8_t* code;        // pooled form: one selection byte per pooled element, same layout
+  uint8_t* code;        // pooled form: one selection byte per pooled element, same layout -- or, with code_cl != 0, CHANNEL LAST
+                        // (B, W/2, H/2, Cout): the 128 bytes of a pooled pixel contiguous, what asr_gemm_nn_poolbwd's epilogue reads
+  int code_cl;
   const uint8_t* bits_in;   // or null: ReLU mask of the output as ONE BIT per element (layout: asr_relu_bits_bytes), Cin = Cout = 128
   uint8_t* bits_out;        // or null: write such bits for this launch's ReLU output (Cin = 64, Cout = 128)
   int B, H, W, Cin, Cout, relu;      // Cin = 128 (any form) or 64 (Cout = 128, no mask, not pooled: conv.5 forward)

@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // every kernel argument the tile loop uses is consumed once HERE: the compiler otherwise waits for its scalar loads (lgkmcnt(0) --
   // the counter our hand-issued operand reads use) at their first use inside the loop, draining the read pipeline once per tile
-  asm volatile("" ::"s"(p.y), "s"(p.pool), "s"(p.code), "s"(p.mask), "s"(p.H), "s"(p.W), "s"(p.relu), "s"(p.tiles_h), "s"(p.tiles_w));
+  asm volatile("" ::"s"(p.y), "s"(p.pool), "s"(p.code), "s"(p.mask), "s"(p.H), "s"(p.W), "s"(p.relu), "s"(p.tiles_h), "s"(p.tiles_w), "s"(p.code_cl));
 
   // per-lane operand addressing: LDS byte address of the lane's chunk of (fragment 0, tap row 0) for column shift dx and k step ms
   const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -387,8 +387,26 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
             asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(c) : "v"(nz));
             mx[pr][j][d] = m; cd[pr][j][d] = c;
           }
+      // selection bytes channel last (p.code_cl; B, W/2, H/2, 128): the lane's 4 + 4 bytes of a pooled row are exchanged between the
+      // lane groups like the NHWC epilogue's values -- 8 consecutive channels, one 8-byte store per pooled row, the four lane groups of
+      // a pixel one whole 32-byte sector.  (All lanes take part in the exchange; the even pixel's lanes store.)
+      uint2 ccl[4];
+      if (p.code_cl) {
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const uint32_t ca = __builtin_amdgcn_perm(cd[pr][0][1], cd[pr][0][0], 0x06040200u);
+          const uint32_t cb = __builtin_amdgcn_perm(cd[pr][1][1], cd[pr][1][0], 0x06040200u);
+          auto sw = __builtin_amdgcn_permlane16_swap(ca, cb, false, false);
+          ccl[pr] = make_uint2(sw[0], sw[1]);
+        }
+      }
       if ((pix & 1) == 0) {
         const int H2 = p.H >> 1, W2 = p.W >> 1;
+        if (p.code_cl) {
+          uint8_t* cq = p.code + ((((int64_t)b * W2 + ((w0 + pix) >> 1)) * H2 + (h0 >> 1)) * 128 + co0);
+#pragma unroll
+          for (int pr = 0; pr < 4; ++pr) *reinterpret_cast<uint2*>(cq + pr * 128) = ccl[pr];
+        }
         const int64_t e0 = (((int64_t)b * W2 + ((w0 + pix) >> 1)) * 128 + wn * 32 + 4 * g) * H2 + (h0 >> 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -408,11 +426,11 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
                 holdc[j * 4 + r] = c01 | (c23 << 16);
               } else {            // e - 4 = the upper tile's first pooled row: 8 rows = 16 bytes of values, 8 selection bytes
                 *reinterpret_cast<uint4*>(p.pool + e - 4) = make_uint4(holdv[j * 4 + r].x, holdv[j * 4 + r].y, o01, o23);
-                *reinterpret_cast<uint2*>(p.code + e - 4) = make_uint2(holdc[j * 4 + r], c01 | (c23 << 16));
+                if (!p.code_cl) *reinterpret_cast<uint2*>(p.code + e - 4) = make_uint2(holdc[j * 4 + r], c01 | (c23 << 16));
               }
             } else {
               *reinterpret_cast<uint2*>(p.pool + e) = make_uint2(o01, o23);
-              *reinterpret_cast<uint32_t*>(p.code + e) = c01 | (c23 << 16);
+              if (!p.code_cl) *reinterpret_cast<uint32_t*>(p.code + e) = c01 | (c23 << 16);
             }
           }
       }

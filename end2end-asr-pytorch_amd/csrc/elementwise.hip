@@ -494,6 +494,37 @@ extern "C" int asr_widen_flat(const void* src_bf16, float* dst, int64_t n, hipSt
   return ASR_OK;
 }
 
+// dst[r][h2 * C + c] = src[r][c * H2 + h2]: the model's feature order (c * F' + f, transformer.py:74-76) -> channel last.  One thread =
+// one 16-byte piece of dst (EPC consecutive channels of one h2), gathered from EPC elements H2 apart (5 MB at the benchmark's
+// 512 x 5120 weight: L2 resident, one launch per step).
+template <typename T>
+__global__ __launch_bounds__(256) void permute_cols_tcf_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst, int64_t ld_dst,
+                                                               int rows, int C, int H2) {
+  constexpr int EPC = DT<T>::EPC;
+  const int pieces = H2 * (C / EPC);
+  const int64_t total = (int64_t)rows * pieces, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const int r = (int)(i / pieces), q = (int)(i - (int64_t)r * pieces), h2 = q / (C / EPC), c0 = (q - h2 * (C / EPC)) * EPC;
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) o.e[e] = src[(int64_t)r * ld_src + (int64_t)(c0 + e) * H2 + h2];
+    *reinterpret_cast<uint4*>(dst + (int64_t)r * ld_dst + (int64_t)h2 * C + c0) = o.v;
+  }
+}
+extern "C" int asr_permute_cols_tcf(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int C, int H2, int dtype,
+                                    hipStream_t s) {
+  ASR_CHECK_ARG(src && dst && rows >= 0 && C > 0 && H2 > 0 && (dtype == ASR_F32 || dtype == ASR_BF16));
+  const int epc = dtype == ASR_F32 ? 4 : 8;
+  if (C % epc != 0 || ld_dst % epc != 0 || !aligned16(dst) || ld_src < (int64_t)C * H2 || ld_dst < (int64_t)C * H2) return ASR_EUNSUPPORTED;
+  if (rows == 0) return ASR_OK;
+  int64_t blocks = ceil_div64((int64_t)rows * H2 * (C / epc), 256);
+  if (blocks > 4096) blocks = 4096;
+  if (dtype == ASR_F32) hipLaunchKernelGGL((permute_cols_tcf_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float*)src, ld_src, (float*)dst, ld_dst, rows, C, H2);
+  else hipLaunchKernelGGL((permute_cols_tcf_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, rows, C, H2);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
 extern "C" int asr_cast_flat(const float* src, void* dst, int64_t n, int dtype, hipStream_t s) {
   ASR_CHECK_ARG(src && dst && n >= 0 && aligned16(src));
   if (n == 0) return ASR_OK;

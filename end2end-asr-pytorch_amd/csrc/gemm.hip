@@ -1022,145 +1022,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn128p_kernel(Tn128Args p) {
 // & 1) << 2) << 1: the 8 rows one transposing read touches (r0 .. r0+3 and r0+8 .. r0+11, 32 bytes each) land on 8 different
 // 32-byte bank groups.
 __device__ __forceinline__ int tn256_key(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
-__device__ __forceinline__ uint4 tn256_pack(const unsigned char* tile, int lr, int g, int c0) {
-  const int row = 8 * g + (lr >> 2), col = c0 + 4 * (lr & 3);
-  const int chunk = col >> 3, half = (col >> 2) & 1;
-  const uint2 lo = asr_lds_read_tr16(tile + row * 512 + ((chunk ^ tn256_key(row)) << 4) + half * 8);
-  const uint2 hi = asr_lds_read_tr16(tile + (row + 4) * 512 + ((chunk ^ tn256_key(row + 4)) << 4) + half * 8);
-  return make_uint4(lo.x, lo.y, hi.x, hi.y);
-}
-
-template <int NST>
-__device__ __forceinline__ void tn256_body(const Tn128Args& p, unsigned char* smem, int tile, int m_beg, int m_end, bool single) {
-  constexpr int RM = 32, TILEB = RM * 512, STAGEB = 2 * TILEB;       // 16 KB per operand, 32 KB per stage
-  const int tid = threadIdx.x, lane = tid & 63, lr = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 1, wk = wave & 1;
-  const int n0 = (tile / p.tiles_k) * 256, k0 = (tile % p.tiles_k) * 256;
-  const int nstage = (m_end - m_beg + RM - 1) / RM;
-  const unsigned char* A = static_cast<const unsigned char*>(p.A);
-  const unsigned char* B = static_cast<const unsigned char*>(p.B);
-  const int a_chunks = (int)(p.lda * 2 / 16), b_chunks = (int)((p.ldb >= p.K ? p.ldb : (int64_t)((p.K + 7) / 8 * 8)) * 2 / 16);
-
-  // per-thread DMA pieces: 1024 chunks per operand tile = 2 per thread; chunk c = (row, slot), source chunk slot ^ key(row)
-  int64_t offA[2], offB[2];
-  int rowi[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = i * 512 + tid, row = c >> 5, slot = (c & 31) ^ tn256_key(row);
-    int ca = n0 * 2 / 16 + slot; ca = ca < a_chunks ? ca : a_chunks - 1;       // columns past N / K are never stored
-    int cb = k0 * 2 / 16 + slot; cb = cb < b_chunks ? cb : b_chunks - 1;
-    offA[i] = (int64_t)row * p.lda * 2 + (int64_t)ca * 16;
-    offB[i] = (int64_t)row * p.ldb * 2 + (int64_t)cb * 16;
-    rowi[i] = row;
-  }
-  const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-  const unsigned wave_lds = smem_base + (unsigned)wave * 1024u;
-  const unsigned char* zero = reinterpret_cast<const unsigned char*>(&tn_zero_page);
-  auto stage = [&](int st) __attribute__((always_inline)) {
-    const unsigned sl = wave_lds + (unsigned)((st % NST) * STAGEB);
-    const int64_t mrow = m_beg + (int64_t)st * RM;
-    const unsigned char* ba = A + mrow * p.lda * 2;
-    const unsigned char* bb = B + mrow * p.ldb * 2;
-    const int valid = m_end - (int)mrow;                  // rows of this stage that exist (uniform)
-    if (valid >= RM) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        tn_dma(sl + i * 8192, ba + offA[i]);
-        tn_dma(sl + TILEB + i * 8192, bb + offB[i]);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const bool in = rowi[i] < valid;
-        tn_dma(sl + i * 8192, in ? ba + offA[i] : zero);
-        tn_dma(sl + TILEB + i * 8192, in ? bb + offB[i] : zero);
-      }
-    }
-  };
-
-  f32x4_t acc[4][8];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = p.colsum != nullptr && k0 == 0 && wk == 0;
-
-#pragma unroll
-  for (int st = 0; st < NST - 1; ++st)
-    if (st < nstage) stage(st);
-  for (int st = 0; st < nstage; ++st) {
-    // stage st has landed once at most the DMA pieces of the later stages are outstanding (4 pieces per stage and thread, in order)
-    const int ahead = min(NST - 2, nstage - 1 - st);
-    if (ahead >= 2) wait_vmcnt<8>();
-    else if (ahead == 1) wait_vmcnt<4>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();              // stage st visible to every wave; every wave is done reading stage st - 1
-    asm volatile("" ::: "memory");
-    if (st + NST - 1 < nstage) stage(st + NST - 1);
-    const unsigned char* sA = smem + (st % NST) * STAGEB;
-    const unsigned char* sB = sA + TILEB;
-    uint4 a[4], b[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = tn256_pack(sA, lr, g, wn * 64 + i * 16);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) b[j] = tn256_pack(sB, lr, g, wk * 128 + j * 16);
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        Chunk<bf16_t> c; c.v = a[i];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) mma16<bf16_t>(acc[i][j], a[i], b[j]);
-  }
-
-  // ---- the wave's 64 x 128 quadrant: lane (lr, g) holds rows 4g..4g+3 of column lr of every fragment
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int gn = n0 + wn * 64 + i * 16 + g * 4 + r;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int gk = k0 + wk * 128 + j * 16 + lr;
-        if (gn < p.N && gk < p.K) {
-          float* dst = p.C + (int64_t)gn * p.ldc + gk;
-          if (single) *dst += acc[i][j][r]; else atomicAdd(dst, acc[i][j][r]);
-        }
-      }
-    }
-  if (do_colsum) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      const int gn = n0 + wn * 64 + i * 16 + lr;
-      if (g == 0 && gn < p.N) atomicAdd(p.colsum + gn, v);
-    }
-  }
-}
-
-// ---- the same block with the operand reads of stage s + 1 issued UNDER the MFMAs of stage s (round 5).  What the loop above costs
-// per 32-MFMA stage, from its ISA and the PMC pass (profiles/r05_step_mfma_pmc.txt: 26.7 % MFMA-busy, 4.4 vector instructions per MFMA):
-// all 24 transposing reads are issued behind the barrier and the first MFMA waits for them, with BOTH waves of a SIMD in that same
-// phase (the barrier aligned them); three vector instructions of address arithmetic per read (the ring offset is recomputed per read);
-// and a scalar reload of lda / ldb from the kernel arguments with its s_waitcnt lgkmcnt(0) right behind the barrier.  Here:
-//   * a fragment's registers are reloaded for the NEXT stage as soon as their last MFMA of this stage has issued -- a[i] behind row i
-//     (MFMAs (i, 0..7)), b[j] behind MFMA (3, j) -- by hand-issued ds_read_b64_tr_b16 with counted s_waitcnt lgkmcnt in row 0 of the
-//     next stage (LDS returns in order; at most 15 reads may stay outstanding, which is what row 0's first MFMA needs anyway);
-//   * the barrier that publishes stage s + 1 (and frees stage s's buffer for the DMA of stage s + 3) sits behind row 0 of stage s,
-//     after an s_waitcnt lgkmcnt(0) that is free by then (the reads of stage s were issued a row or more ago);
-//   * twelve lane offsets (4 + 8 fragments; the second half of a fragment is offset:2048 of the same address: row + 4 has the row's
-//     swizzle key) + ONE add per fragment and stage for the ring position; every kernel argument the loop needs is in registers before
-//     it (no scalar load, hence nothing else on lgkmcnt).
-// Same LDS image, same DMA, same MFMA order per accumulator as tn256_body: the same bits.
+// (Round 3's loop over the same LDS image, tn256_body, was removed in round 6 with its switches TN_ROT / TN_GROUP_STAGES / TN_ROT_NST:
+// this loop gives the same bits -- same DMA, same MFMA order per accumulator -- and won every measurement, profiles/r05_tn_grouped.txt.)
 typedef __attribute__((ext_vector_type(2))) unsigned int tn_u32x2_t;
 __device__ __forceinline__ tn_u32x2_t tn_tr_read(unsigned addr, const int off2048) {
   tn_u32x2_t v;
@@ -1413,7 +1276,7 @@ __device__ __forceinline__ Tn128Args tn_group_prob(const TnGroupArgs& ga, int i)
   p.M = q.M; p.N = q.N; p.K = q.K; p.m_per_split = q.m_per_split; p.tiles_k = q.tiles_k; p.ntiles = q.ntiles;
   return p;
 }
-template <int NST, bool ROT = false, bool SWAP = false>
+template <int NST, bool ROT, bool SWAP = false>        // ROT: the launch is a list of whole-contraction blocks, longest first (walk order below)
 __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
@@ -1431,8 +1294,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
   while (i + 1 < ga.n && wid >= ga.first[i + 1]) ++i;
   const Tn128Args p = tn_group_prob(ga, i);
   const int w = wid - ga.first[i], split = w / p.ntiles, m_beg = split * p.m_per_split;
-  if constexpr (ROT) tn256r_body<NST, SWAP>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
-  else tn256_body<NST>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
+  tn256r_body<NST, SWAP>(p, smem, w % p.ntiles, m_beg, min(p.M, m_beg + p.m_per_split), p.m_per_split >= p.M);
 }
 
 // ---- the same blocks, scheduled by the host: the launch is ONE workgroup per CU and every workgroup gets the same number of 32-row
@@ -1442,7 +1304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256g_kernel(TnGroupArgs ga) {
 // Measured before (profiles/r03_bench_timeline.txt, launch-by-launch listing): 184 / 300 / 304 equal-length blocks on 256 CUs
 // took 185 / 340 / 266 us -- the second round of 44 blocks costs as much as the first of 256.
 // first[] holds the prefix sums of STAGES per problem here; m_per_split the stages of one block of that problem.
-template <int NST, bool ROT = false>
+template <int NST>
 __global__ __launch_bounds__(512, 2) void gemm_tn256s_kernel(TnGroupArgs ga, int per_wg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, qn = nwg >> 3, rn = nwg & 7;
@@ -1459,8 +1321,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn256s_kernel(TnGroupArgs ga, int
     const int w = x - ga.first[i], tile = w / spb, st0 = w % spb;
     const int st1 = min(spb, st0 + (x1 - x));
     if (again) __syncthreads();                            // every wave is done reading the previous piece's last stages
-    if constexpr (ROT) tn256r_body<NST, false>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
-    else tn256_body<NST>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
+    tn256r_body<NST, false>(p, smem, tile, st0 * 32, min(p.M, st1 * 32), st0 == 0 && st1 == spb);
     x += st1 - st0;
     again = true;
   }
@@ -2310,20 +2171,20 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
   const int mrows = (int)asr_tuning("TN_GROUP_MROWS", 3200);
   int max_m = 0;
   for (int j = 0; j < cnt; ++j) max_m = M[order[j]] > max_m ? M[order[j]] : max_m;
-  // TN_ROT (default 1, round 5): tn256r_body, and ONE workgroup per block of dW over the WHOLE contraction, dispatched longest
+  // Round 5: tn256r_body, and ONE workgroup per block of dW over the WHOLE contraction, dispatched longest
   // first -- no block is shared between workgroups, so no fp32 atomics and a vector epilogue: round 3's equal pieces shared almost
   // every block (pieces of 130 - 160 stages against blocks of 100 / 200), and the 65 536 atomics per visit were a quarter of the
-  // launch (profiles/r05_tn_grouped.txt).  0: round 3's forms below.
-  const bool nst4 = asr_tuning("TN_GROUP_STAGES", 3) == 4;
-  const bool rot = !nst4 && tmode == 0 && asr_tuning("TN_ROT", 1) != 0;
+  // launch (profiles/r05_tn_grouped.txt).
+  // (every 256 x 256 form runs tn256r_body since round 6; tmode != 0 forces a form for the tests)
+  const bool rot = tmode == 0;
   const bool big = tmode != 128;
   // ... cut into slices of its rows (summed with fp32 atomics, as before) where that shortens the launch: one block longer than a CU's
   // share (emb_cnn's window contractions: one or two blocks over several hundred thousand rows), or equal blocks whose count is an
   // awkward multiple of the CUs (configs[3]: 576 blocks of 398 stages = 2.25 rounds).  tn_rot_plan() decides by playing the dispatch
   // through for a few slice lengths; the list is then ordered by SLICE length.
   int rot_splits[TN_GROUP_MAX];
-  // where the whole blocks would leave CUs idle (tn_rot_plan), round 3's forms with the new loop; TN_ROT = 2: whole blocks always
-  const bool whole = rot && (tn_rot_plan(cnt, order, M, N, K, rot_splits) || asr_tuning("TN_ROT", 1) == 2);
+  // where the whole blocks would leave CUs idle (tn_rot_plan), round 3's shared forms (equal pieces / slices) with the new loop
+  const bool whole = rot && tn_rot_plan(cnt, order, M, N, K, rot_splits);
   const bool sched = !whole && (tmode == 1 || (tmode == 0 && max_m < asr_tuning("TN_GROUP_SLICE_MIN", 9600)));
   if (whole) {
     int slice[TN_GROUP_MAX];
@@ -2359,16 +2220,10 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
   ga.n = cnt;
   static bool granted = false;
   if (!granted) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 16384);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<3, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256g_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn256s_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 32768);
     granted = true;
   }
   AsrProfScope prof(ASR_OP_GEMM, stream);
@@ -2379,17 +2234,11 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     if (nwg < 1) nwg = 1;
     const int per_wg = (total + nwg - 1) / nwg;
     nwg = (total + per_wg - 1) / per_wg;
-    if (nst4) hipLaunchKernelGGL(gemm_tn256s_kernel<4>, dim3((unsigned)nwg), dim3(512), 4 * 32768, stream, ga, per_wg);
-    else if (rot) hipLaunchKernelGGL((gemm_tn256s_kernel<3, true>), dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
-    else hipLaunchKernelGGL(gemm_tn256s_kernel<3>, dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
+    hipLaunchKernelGGL(gemm_tn256s_kernel<3>, dim3((unsigned)nwg), dim3(512), 3 * 32768, stream, ga, per_wg);
   } else if (big) {
-    if (nst4) hipLaunchKernelGGL(gemm_tn256g_kernel<4>, dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
-    else if (whole && asr_tuning("TN_ROT_NST", 3) == 4) hipLaunchKernelGGL((gemm_tn256g_kernel<4, true, true>), dim3((unsigned)total), dim3(512), 4 * 32768, stream, ga);
-    else if (whole) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
-    else if (rot) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
-    else hipLaunchKernelGGL(gemm_tn256g_kernel<3>, dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
-  } else if (nst4) hipLaunchKernelGGL(gemm_tn128g_kernel<4>, dim3((unsigned)total), dim3(256), 4 * 16384, stream, ga);
-  else hipLaunchKernelGGL(gemm_tn128g_kernel<3>, dim3((unsigned)total), dim3(256), 3 * 16384, stream, ga);
+    if (whole) hipLaunchKernelGGL((gemm_tn256g_kernel<3, true, true>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
+    else hipLaunchKernelGGL((gemm_tn256g_kernel<3, true, false>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
+  } else hipLaunchKernelGGL(gemm_tn128g_kernel<3>, dim3((unsigned)total), dim3(256), 3 * 16384, stream, ga);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -2450,6 +2299,24 @@ extern "C" int asr_gemm_nn_rowdot(const void* A, int64_t lda, const void* B, int
   const int64_t t64 = ceil_div64(M, 64) * ceil_div64(N, 64);
   if (t64 <= asr_tuning("NN_RING", 512) && K >= 256) return launch_nn<bf16_t, bf16_t, 64, 3>(p, stream);
   return launch_nn<bf16_t, bf16_t, 64>(p, stream);
+}
+
+// asr_gemm_nn whose epilogue is the second max-pool's backward (include/asr_hip.h): the encoder input projection's data gradient lands
+// directly in the un-pooled NHWC gradient of conv.7's output.  Eight-wave 128 x 128 blocks only (csrc/gemm_big.hip).
+extern "C" int asr_gemm_nn_poolbwd(const void* A, int64_t lda, const void* Bp, int64_t ldb, const uint8_t* code_cl, void* dy, int M, int K,
+                                   int H2, int W2, int C, int dtype, hipStream_t stream) {
+  ASR_CHECK_ARG(A && Bp && code_cl && dy && M >= 0 && K >= 0 && H2 > 0 && W2 > 0 && C > 0);
+  const int64_t N = (int64_t)H2 * C;
+  if (dtype != ASR_BF16 || C % 8 != 0 || M % W2 != 0 || N >= ((int64_t)1 << 30)) return ASR_EUNSUPPORTED;
+  if (M == 0) return ASR_OK;
+  if (K <= 0 || K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || !aligned16(A) || !aligned16(Bp) || !aligned16(dy) || (((uintptr_t)code_cl) & 7) != 0 ||
+      ldb < N || lda < K)
+    return ASR_EUNSUPPORTED;
+  AsrProfScope prof(ASR_OP_GEMM, stream);
+  BigGemmArgs q{};
+  q.A = A; q.B = Bp; q.C = dy; q.lda = lda; q.ldb = ldb; q.ldc = N; q.M = M; q.N = (int)N; q.K = K; q.alpha = 1.f;
+  q.pool_code = code_cl; q.pool_H2 = H2; q.pool_W2 = W2; q.pool_C = C;
+  return asr_gemm_big_nn(q, stream) ? ASR_OK : ASR_EUNSUPPORTED;
 }
 
 // ---- one launch for a linear layer's backward: dx (M,K) (+)= dy (M,N) . w (N,K) [ReLU mask]  AND  the partial sums of

@@ -14,6 +14,9 @@ struct BigGemmArgs {
   // NN only (asr_gemm_nn_rowdot): dot_out[(b H + h) T + q] = sum_{d < 64} C[b T + q][64 h + d] * O[b T + q][64 h + d] with the ROUNDED C;
   // O = dot_o32 (fp32, row stride N) if given, else dot_o (bf16, row stride N).  N = 64 H.
   const void* dot_o; const float* dot_o32; float* dot_out; int dot_T, dot_H;
+  // NN only (asr_gemm_nn_poolbwd): C is NOT (M, N) but the un-pooled NHWC gradient (M / W2, 2 H2, 2 W2, pool_C); row m = (b, w2), column
+  // n = (h2, c); every 16-byte piece goes through its 8 selection bytes pool_code[(m H2 + h2) pool_C + c] to the four window positions
+  const uint8_t* pool_code; int pool_H2, pool_W2, pool_C;
 };
 
 // -> true when the shape / layout is taken (launched on `stream`), false when the caller should use the four-wave kernels.

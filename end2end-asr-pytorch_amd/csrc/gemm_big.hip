@@ -297,6 +297,52 @@ __global__ __launch_bounds__(512, 2) void gemm_big_nn_kernel(BigGemmArgs p, int 
   bf16_t* C = static_cast<bf16_t*>(p.C);
   const bf16_t* Msk = static_cast<const bf16_t*>(p.mask);
   constexpr int CPR = BN / 8;
+  if (p.pool_code) {
+    // The second max-pool's backward (asr_gemm_nn_poolbwd).  A piece = 8 channels of pooled pixel (h2, w2) of image b (row m = (b, w2),
+    // column n = (h2, c)); it is routed by its 8 selection bytes to the 2 x 2 window, and all four positions are written.  The loop
+    // runs over OUTPUT pixels, not pooled pieces: piece fastest, then the window column, then the pooled row -- a wave's 64 stores are
+    // the 4 consecutive pixels (2 w2, 2 w2 + 1, 2 w2 + 2, 2 w2 + 3) of one image row = 1 KB of consecutive bytes (a first version
+    // stored the four positions of a piece from one thread: 256-byte segments with 256-byte holes per instruction, 2.6 TB/s).
+    // thread <-> (piece column pc, window column dxk, pooled rows r0 + 16 j): its 8 pieces' selection bytes are loaded up front (8
+    // independent loads in flight: one round trip, not one per store -- a first version loaded inside the store loop and the launch
+    // became a chain of 16 L2 latencies per workgroup, 114 us), then the two image rows of the window are written
+    static_assert(CPR == 16, "the pooled-gradient epilogue maps 16 pieces per row");
+    const int pc = tid & 15, dxk = (tid >> 4) & 1, r0 = tid >> 5;
+    const int gcol = n0 + pc * 8;
+    const int h2 = gcol / p.pool_C, cc = gcol - h2 * p.pool_C;
+    uint2 kk[8];
+    bf16_t* dst[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int grow = m0 + r0 + 16 * j;
+      const bool ok = grow < p.M && gcol < p.N;
+      const int gr = ok ? grow : 0;
+      const int bb = gr / p.pool_W2, w2 = gr - bb * p.pool_W2;
+      kk[j] = ok ? *reinterpret_cast<const uint2*>(p.pool_code + ((int64_t)gr * p.pool_H2 + h2) * p.pool_C + cc) : make_uint2(0xffffffffu, 0xffffffffu);
+      dst[j] = ok ? C + (((int64_t)bb * 2 * p.pool_H2 + 2 * h2) * (2 * p.pool_W2) + 2 * w2 + dxk) * p.pool_C + cc : nullptr;
+    }
+    const int64_t rowp = (int64_t)2 * p.pool_W2 * p.pool_C;
+#pragma unroll
+    for (int dyk = 0; dyk < 2; ++dyk) {
+      const uint32_t want = (uint32_t)(dyk * 2 + dxk + 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (dst[j] == nullptr) continue;
+        const int row = r0 + 16 * j;
+        const float4 v0 = *reinterpret_cast<const float4*>(smem + row * OP + pc * 32);
+        const float4 v1 = *reinterpret_cast<const float4*>(smem + row * OP + pc * 32 + 16);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        Chunk<bf16_t> q;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t code = ((e < 4 ? kk[j].x : kk[j].y) >> (8 * (e & 3))) & 0xffu;
+          q.e[e] = code == want ? f32_to_bf16(v[e]) : (bf16_t)0;
+        }
+        *reinterpret_cast<uint4*>(dst[j] + dyk * rowp) = q.v;
+      }
+    }
+    return;
+  }
   for (int c = tid; c < BM * CPR; c += 512) {
     const int row = c / CPR, pc = c % CPR;
     const int grow = m0 + row, gcol = n0 + pc * 8;
@@ -388,6 +434,7 @@ bool asr_gemm_big_nt(const BigGemmArgs& p, hipStream_t stream) {
 bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream) {
   const int mode = (int)asr_tuning("GEMM_BIG_NN", 1);         // 0: off; 1: automatic; 2: always (tests)
   if (mode == 0 || p.out_f32 || p.bias != nullptr || p.relu) return false;
+  if (p.pool_code && (p.accumulate || p.mask || p.dot_out || p.pool_C % 8 != 0 || p.N != p.pool_H2 * p.pool_C || p.M % p.pool_W2 != 0)) return false;
   if (p.dot_out && (p.N % 64 != 0 || p.accumulate || p.mask || p.N != p.dot_H * 64)) return false;
   if (p.K <= 0 || p.K % 64 != 0 || p.lda % 8 != 0 || p.ldb % 8 != 0 || p.ldc % 8 != 0 || p.N % 8 != 0 || !aligned16(p.A) || !aligned16(p.B) ||
       !aligned16(p.C) || (p.mask && !aligned16(p.mask)) || p.lda < p.K || p.ldb < p.N)
@@ -395,7 +442,7 @@ bool asr_gemm_big_nn(const BigGemmArgs& p, hipStream_t stream) {
   const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
   // (profiles/r03_gemm_big_nn_shapes.txt: below ~150 blocks the four-wave 64 x 64 kernel fills the chip better -- 3200 x 512 over K = 1536:
   // 13.8 vs 19.0 us)
-  if (mode == 1 && t128 < 150) return false;
+  if (mode == 1 && t128 < 150 && !p.pool_code) return false;      // (the pooled-gradient epilogue exists in this kernel only)
   const int ns = (int)asr_tuning("GEMM_BIG_NS", (t128 > 256 || p.K < 2048) ? 2 : 4);
   if (ns == 2) launch_nn<2>(p, stream); else if (ns == 4) launch_nn<4>(p, stream); else launch_nn<3>(p, stream);
   return hipGetLastError() == hipSuccess;

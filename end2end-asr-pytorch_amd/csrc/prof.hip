@@ -84,8 +84,8 @@ const char* const kTuningNames[] = {
     "ATTN_GENERIC", "IGEMM_TH", "IGEMM_TPS", "IGEMM_WBUF", "CONV1_WGRAD_MFMA", "IGEMM_ABLATE", "C64", "CONV_POOL", "WGRAD_ABLATE",
     "WGRAD_DMA", "CONV1_WGRAD_WGS", "C64_PER_CU", "C64_ABLATE", "C64_SHAPE", "GEMM_NS", "GEMM_TILE", "GEMM_GENERIC", "TN_WGS",
     "TN_128", "TN_128_MIN", "TN_128_RM", "TN_NBUF", "NN_BIG", "NN_RING", "TN_GROUP_SLICE_MIN", "GEMM_BIG_MIN", "NT_RING", "TN_PIPE", "TN_PIPE_MIN", "GEMM_ABLATE", "ATTN_SHORT", "ATTN_SHORT_BWD", "ATTN_BOTH", "NNTN_STAGES",
-    "ATTN_PP", "ATTN_PP_MIN", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_STAGGER", "ATTN_PP_STAGGER_SEL", "TN_GROUP_STAGES", "TN_GROUP_TILE", "TN_GROUP_MROWS",
-    "TN_GROUP_WGS", "WGRAD_XCD", "IGEMM_XCD", "C64_SPLIT", "GEMM_BIG", "GEMM_BIG_NS", "GEMM_BIG_NN", "L0_WSPLIT", "WS128", "WS64", "WS64_PER_CU", "WS_PAIR", "WS_BITS", "NN_ROWDOT", "TN_ROT", "TN_ROT_NST", "ATTN_BWD_FUSED",
+    "ATTN_PP", "ATTN_PP_MIN", "ATTN_PP_TAIL", "ATTN_PP_PRIO", "ATTN_PP_STAGGER", "ATTN_PP_STAGGER_SEL", "TN_GROUP_TILE", "TN_GROUP_MROWS",
+    "TN_GROUP_WGS", "WGRAD_XCD", "IGEMM_XCD", "C64_SPLIT", "GEMM_BIG", "GEMM_BIG_NS", "GEMM_BIG_NN", "L0_WSPLIT", "WS128", "WS64", "WS64_PER_CU", "WS_PAIR", "WS_BITS", "NN_ROWDOT", "ATTN_BWD_FUSED",
 #ifdef ASR_TUNE_ABLATE
     "WS_DBG",          // development builds only: a device ADDRESS the timing instantiations of conv_ws.hip write through
 #endif

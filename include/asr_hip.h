@@ -90,6 +90,22 @@ int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* ld_dy, cons
  * whole stage and the caller guarantees A[:, K:] == 0 there (B's rows are clamped), else ASR_EUNSUPPORTED.              */
 int asr_gemm_nn(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc, const void* relu_mask, int M,
                 int N, int K, float alpha, int flags, int in_dtype, int out_dtype, asr_stream_t stream);
+/* The encoder input projection's data gradient WITH the second max-pool's backward in its epilogue (reference: the autograd of
+ * models/asr/transformer.py:50-52, 74-76, 172 -- MaxPool2d, view / transpose, encoder.input_linear): the product
+ * G (M, N) = A (M, K) . Bp (K, N), M = Bt * W2 rows (b, w2), N = H2 * C columns in (h2, c) order -- Bp is the projection weight with its
+ * input columns PERMUTED from the model's (c, h2) order (asr_permute_cols_tcf) -- is never stored: every 16-byte piece (8 channels of
+ * pooled pixel (h2, w2)) is rounded to bf16 and routed through its 8 selection bytes code_cl[((b W2 + w2) H2 + h2) C + c] (1 + k = window
+ * position k in scan order (0, 0), (0, 1), (1, 0), (1, 1); 0 = none) into dy (Bt, 2 H2, 2 W2, C) NHWC, the gradient of the un-pooled
+ * conv output: all four window positions are written (zeros where not selected), so dy needs no clearing.  Equals asr_gemm_nn into the
+ * (b, w2, c, h2) layout followed by asr_maxpool_bwd_code bit for bit (same products, same rounding, then a selection).
+ * bf16, K % 64 == 0, C % 8 == 0, 16-byte aligned rows, else ASR_EUNSUPPORTED.                                              */
+int asr_gemm_nn_poolbwd(const void* A, int64_t lda, const void* Bp, int64_t ldb, const uint8_t* code_cl, void* dy, int M, int K, int H2,
+                        int W2, int C, int dtype, asr_stream_t stream);
+/* dst (rows, H2 * C) <- src (rows, C * H2): dst[r][h2 * C + c] = src[r][c * H2 + h2] (row strides ld_src / ld_dst elements): the
+ * column permutation between the model's feature order c * F' + f (transformer.py:74-76) and the channel-last order of
+ * asr_gemm_nn_poolbwd.  bf16 or fp32; C % 8 == 0 (bf16) / C % 4 == 0 (fp32); dst rows 16-byte aligned.                    */
+int asr_permute_cols_tcf(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int rows, int C, int H2, int dtype,
+                         asr_stream_t stream);
 /* What asr_gemm_tn_grouped would do with these n problems (host only, nothing is launched): returns 1 = one workgroup per WHOLE block of
  * dW, dispatched longest first, no atomics (splits[i] > 1: a block longer than a CU's share of the launch is cut into that many
  * slices of its rows), 0 = the shared-block forms of round 3 (equal pieces / slices, fp32 atomics) because whole blocks would leave
@@ -408,6 +424,11 @@ int asr_vgg_level0_wgrad(const float* src, const float* w0, const float* b0, con
  * 8 with 128 input channels (the weight-stationary kernel of csrc/conv_ws.hip, round 5), of 16 otherwise.                          */
 int asr_conv3x3_relu_pool_tcf_code(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code, int B, int H, int W,
                                    int Cin, int Cout, int dtype, asr_stream_t stream);
+/* The same with the selection bytes CHANNEL LAST, code_cl (B, W/2, H/2, Cout): the 128 bytes of a pooled pixel contiguous -- the form
+ * asr_gemm_nn_poolbwd reads (round 6).  Served by the weight-stationary kernel only (bf16, 128 -> 128, H % 8 == 0, W % 16 == 0),
+ * else ASR_EUNSUPPORTED (callers keep asr_conv3x3_relu_pool_tcf_code + asr_maxpool_bwd_code).                                       */
+int asr_conv3x3_relu_pool_tcf_codecl(const void* x, const void* wk, const float* bias, void* pool, uint8_t* code_cl, int B, int H, int W,
+                                     int Cin, int Cout, int dtype, asr_stream_t stream);
 /* dW (Cout,Cin,3,3) += and db (Cout, optional) += straight from NHWC x (B,H,W,Cin) and dy (B,H,W,Cout): the transposed
  * MFMA operands are built in LDS with ds_read_b64_tr_b16, no planar copies (conv.hip; bf16 with a workspace: the LDS-DMA
  * pipelined kernel of conv_wgrad_dma.hip).                                                                      */

@@ -208,10 +208,11 @@ def test_collectives_captured_inside_one_graph_equal_the_plain_step():
     # count / gradient checksum on the capture batch (dropout 0.1 on: the same seeds are re-drawn); the mode that ran is in the line
     one = run({"ASR_FORCE_DDP": "1"}, ["--ddp-graph", "auto"])
     four = run({"ASR_FORCE_DDP": "1"})
-    assert "ONE hipGraph" in one["launch_mode"], (one["launch_mode"], one["_stderr_tail"])
-    assert one["config"]["ddp_graph"] == {"requested": "auto", "ran": "one (verified against the four-body step)"}, one["config"]["ddp_graph"]
+    assert "ONE hipGraph" in one["launch_mode"], (one["launch_mode"], one["config"]["ddp_graph"], one["_stderr_tail"])
+    dg = one["config"]["ddp_graph"]
+    assert dg["requested"] == "auto" and dg["ran"] == "one (verified against the four-body step)" and dg["verification"]["agree"], dg
     assert "4 hipGraphs" in four["launch_mode"], four["launch_mode"]
-    assert four["config"]["ddp_graph"] == {"requested": "four", "ran": "four"}, four["config"]["ddp_graph"]
+    assert four["config"]["ddp_graph"]["requested"] == "four" and four["config"]["ddp_graph"]["ran"] == "four", four["config"]["ddp_graph"]
     assert one["config"]["collective_backend"] == "nccl" and one["config"]["collective_library"].startswith("RCCL")
     lp, lo, lf = plain["config"]["final_loss"], one["config"]["final_loss"], four["config"]["final_loss"]
     assert abs(lp - lo) < 2e-3 and abs(lp - lf) < 2e-3, (lp, lo, lf)

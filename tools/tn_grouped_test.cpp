@@ -1,6 +1,6 @@
 // Development harness for the grouped weight-gradient contraction (asr_gemm_tn_grouped; csrc/gemm.hip tn256_body / tn256r_body): the linear
 // layers of configs[1] (4 + 4 layers, d_model 512, inner 2048, 6400 encoder / 3200 decoder rows) in the two launches the training step
-// issues, round 3's loop (tuning TN_ROT = 0) against round 5's (operand reads of the next stage under the MFMAs): the same bits (the
+// issues, the equal-piece form (tuning TN_GROUP_TILE = 1; until round 6 also round 3's loop, removed since) against round 5's (operand reads of the next stage under the MFMAs): the same bits (the
 // accumulation order per element is the same), interleaved timing.  `big` adds configs[3]'s row counts (12 720 / 1600).
 // Build:  hipcc -O2 tools/tn_grouped_test.cpp -o tools/bin/tn_grouped_test -Iinclude -Lend2end-asr-pytorch_amd/asr_hip -lasr_hip \
 //               -Wl,-rpath,'$ORIGIN/../../end2end-asr-pytorch_amd/asr_hip'
@@ -24,7 +24,6 @@ struct Prob { int M, N, K; void* dy; void* x; float* dw; float* db; std::vector<
 static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 int main(int argc, char** argv) {
-  if (const char* e = getenv("TN_ROT_NST")) AK(asr_set_tuning("TN_ROT_NST", atoi(e)));
   const bool big = argc > 1 && strcmp(argv[1], "big") == 0;
   const int Me = big ? 12720 : 6400, Md = big ? 1600 : 3200, LE = big ? 12 : 4, LD = big ? 6 : 4;
   std::vector<Prob> ps;
@@ -63,7 +62,7 @@ int main(int argc, char** argv) {
   // ---- the same bits
   std::vector<std::vector<float>> out[2];
   for (int rot = 0; rot < 2; ++rot) {
-    AK(asr_set_tuning("TN_ROT", rot));
+    AK(asr_set_tuning("TN_GROUP_TILE", rot ? 0 : 1));      // 0: the planner (whole blocks for the headline's list); 1: equal pieces, shared blocks meet in atomics
     group = rot ? 48 : 32;
     for (auto& p : ps) { CK(hipMemset(p.dw, 0, (size_t)p.N * p.K * 4)); CK(hipMemset(p.db, 0, (size_t)p.N * 4)); }
     pass();
@@ -115,7 +114,7 @@ int main(int argc, char** argv) {
   std::vector<double> t[2];
   for (int round = 0; round < 7; ++round)
     for (int rot = 0; rot < 2; ++rot) {
-      AK(asr_set_tuning("TN_ROT", rot));
+      AK(asr_set_tuning("TN_GROUP_TILE", rot ? 0 : 1));      // 0: the planner (whole blocks for the headline's list); 1: equal pieces, shared blocks meet in atomics
     group = rot ? 48 : 32;
       pass();
       const int iters = 6;
@@ -132,7 +131,7 @@ int main(int argc, char** argv) {
     printf("  %-40s median %7.1f us per pass (min %7.1f, max %7.1f) = %6.1f TF/s\n", rot ? "whole blocks, reads under MFMAs (r5)" : "equal pieces, atomics (round 3)",
            t[rot][3], t[rot][0], t[rot][6], flops / t[rot][3] * 1e-6);
   }
-  AK(asr_clear_tuning("TN_ROT"));
+  AK(asr_clear_tuning("TN_GROUP_TILE"));
   const bool fail = bad_ref[0] || bad_ref[1];
   printf(fail ? "FAILED\n" : "OK\n");
   return fail ? 1 : 0;
