@@ -119,6 +119,13 @@ class GraphedTrainStep:
         if self.ddp_graph == "four":
             return False
         import logging
+        import torch.distributed as dist
+        if not (dist.is_initialized() and dist.get_backend() == "nccl"):
+            # only RCCL's collectives can be recorded into a hipGraph; a gloo all-reduce inside a capture does not raise, it aborts the
+            # process (the two-rank parity tests run over gloo on one GPU)
+            logging.warning("--ddp-graph %s: the %s backend cannot be captured -- four graphs", self.ddp_graph,
+                            dist.get_backend() if dist.is_initialized() else "missing")
+            return False
         for attempt in (1, 2):               # (one capture in ~20 raised on the GPU box while the collective library's watchdog was still polling the warm-up steps' work)
             g = None
             try:

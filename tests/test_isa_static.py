@@ -66,7 +66,7 @@ def test_ring_kernels_keep_their_counted_waits(gemm_asm, kernel, pieces):
     assert sum(1 for o, _ in ops[:end] if o == "global_load_lds_dwordx4") >= 2 * pieces        # prologue stage(s) + the refill inside the loop
 
 
-@pytest.mark.parametrize("kernel", [r"gemm_tn256g_kernelILi3ELb1ELb1EE", r"gemm_tn256g_kernelILi3ELb1ELb0EE", r"gemm_tn256s_kernelILi3ELb1EE"])
+@pytest.mark.parametrize("kernel", [r"gemm_tn256g_kernelILi3ELb1ELb1EE", r"gemm_tn256g_kernelILi3ELb1ELb0EE", r"gemm_tn256s_kernelILi3EE"])
 def test_grouped_weight_gradient_loop_reads_under_its_mfmas(gemm_asm, kernel):
     """csrc/gemm.hip tn256r_body (round 5): the operand reads of stage s + 1 are hand-issued under the MFMAs of stage s with counted
     s_waitcnt lgkmcnt.  That only holds while (a) nothing else uses lgkmcnt in the loop -- round 3's loop reloaded lda / ldb from the
