@@ -755,7 +755,13 @@ def _conv_window_bwd(D, A, w, b_grad, g, tag, need_dx):
     return dw, ops.col2im(dX2, g1)
 
 
-def _bn_stats(bn, y, M, C, training, ygrid=(0, 0)):
+# Length mask of emb_cnn's BatchNorm statistics (round 6): a device int32[2] = valid time steps of the first / second convolution's
+# output, set by whoever pads the batch BEYOND its collated length (asr_hip/graph.py under trainer --graph-buckets); None = every row
+# counts, as in the reference (whose BatchNorm does run over the collate padding -- that part is kept).
+emb_valid = None
+
+
+def _bn_stats(bn, y, M, C, training, ygrid=(0, 0), valid=None):
     """nn.BatchNorm2d statistics (eps / momentum of the module; unbiased running variance) -> (mean, rstd)."""
     if training:
         track = bn.track_running_stats and bn.running_mean is not None
@@ -763,8 +769,11 @@ def _bn_stats(bn, y, M, C, training, ygrid=(0, 0)):
         # another dtype (model.half() / .bfloat16()), momentum=None (cumulative average) -- is updated here through torch, never skipped
         fused = track and bn.momentum is not None and bn.running_mean.dtype == torch.float32 and bn.running_var.dtype == torch.float32 \
             and bn.num_batches_tracked is not None and bn.num_batches_tracked.dtype == torch.int64
+        if valid is not None and track and not fused:
+            raise NotImplementedError("length-masked BatchNorm statistics need fp32 running buffers and a fixed momentum (the count is "
+                                      "known on the device only); run this model with --graph-buckets 0")
         mean, rstd = ops.bn_train_stats(y, M, C, bn.eps, bn.momentum if fused else -1.0, bn.running_mean if fused else None,
-                                        bn.running_var if fused else None, bn.num_batches_tracked if fused else None, ygrid)
+                                        bn.running_var if fused else None, bn.num_batches_tracked if fused else None, ygrid, valid)
         if track and not fused:
             with torch.no_grad():
                 if bn.num_batches_tracked is not None:
@@ -800,7 +809,10 @@ class EmbCNNFn(Function):
         else:
             colA, WsA, yA, MA, KA = _conv_gemm_fwd(src.view(B, Fq, T, 1), gA, w0, b0, "embA")
             ygA = (0, 0)
-        meanA, rstdA = _bn_stats(bn1, yA, MA, C1, training, ygA)
+        # bucket padding behind the collated batch stays out of the batch statistics (emb_valid: device int32[2], see above)
+        ev = emb_valid if (training and emb_valid is not None) else None
+        vA = (ev[0:1], gA[11]) if ev is not None else None
+        meanA, rstdA = _bn_stats(bn1, yA, MA, C1, training, ygA, vA)
         a1 = torch.empty((B, gA[10], gA[11], C1), device=src.device, dtype=cd)
         ops.bn_act_fwd(yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, a1.view(MA, C1), ygrid=ygA)
         gB = ops.conv_geom(B, gA[10], gA[11], C1, w3.shape[2], w3.shape[3], 2, 1, 0, 0)
@@ -811,7 +823,8 @@ class EmbCNNFn(Function):
         else:
             colB, WsB, yB, MB, KB = _conv_gemm_fwd(a1, gB, w3, b3, "embB")
             ygB = (0, 0)
-        meanB, rstdB = _bn_stats(bn4, yB, MB, C2, training, ygB)
+        vB = (ev[1:2], gB[11]) if ev is not None else None
+        meanB, rstdB = _bn_stats(bn4, yB, MB, C2, training, ygB, vB)
         out = torch.empty((B, gB[11], C2 * gB[10]), device=src.device, dtype=cd)
         ops.bn_act_fwd(yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, out, tH=gB[10], tW=gB[11], ygrid=ygB)
         ctx.t = (colA, WsA, yA, meanA, rstdA, colB, WsB, yB, meanB, rstdB)
@@ -820,6 +833,7 @@ class EmbCNNFn(Function):
         ctx.generation = _emb_generation[0]
         ctx.geo = (gA, gB, MA, KA, MB, KB)
         ctx.ygrid = (ygA, ygB)
+        ctx.valid = (vA, vB)
         ctx.win, ctx.winA = win, winA
         ctx.params = (w0, b0, g1, be1, w3, b3, g4, be4)
         return out
@@ -840,11 +854,13 @@ class EmbCNNFn(Function):
             dout = dout.to(cd)
         # ---- second conv block
         ygA, ygB = ctx.ygrid
+        vA, vB = ctx.valid
         if ctx.win:
             DB, dyB, dgB = _window_dy(gB, C2, "embW", dev)
         else:
             dyB, dgB = ops.workspace("embB_dy", (yB.shape[0], 64), cd, dev), (0, 0)
-        sB = ops.bn_act_bwd(dout, yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, dyB, tH=gB[10], tW=gB[11], ygrid=ygB, dygrid=dgB)
+        sB = ops.bn_act_bwd(dout, yB, MB, C2, meanB, rstdB, g4.data, be4.data, 0.0, 20.0, dyB, tH=gB[10], tW=gB[11], ygrid=ygB, dygrid=dgB,
+                            valid=vB)
         P.grad_of(be4).add_(sB[:C2])
         P.grad_of(g4).add_(sB[C2:])
         if ctx.win:
@@ -863,7 +879,7 @@ class EmbCNNFn(Function):
             DA, dyA, dgA = _window_dy(gA, C1, "embV", dev)
         else:
             dyA, dgA = ops.workspace("embA_dy", (yA.shape[0], 64), cd, dev), (0, 0)
-        sA = ops.bn_act_bwd(da1.view(MA, C1), yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, dyA, ygrid=ygA, dygrid=dgA)
+        sA = ops.bn_act_bwd(da1.view(MA, C1), yA, MA, C1, meanA, rstdA, g1.data, be1.data, 0.0, 20.0, dyA, ygrid=ygA, dygrid=dgA, valid=vA)
         P.grad_of(be1).add_(sA[:C1])
         P.grad_of(g1).add_(sA[C1:])
         if ctx.winA:

@@ -34,7 +34,7 @@ from . import params as P
 
 class GraphedTrainStep:
     def __init__(self, model, opt, smoothing, src, src_len, tgt, clip_max_norm=None, warmup_steps=2, replay_after_capture=True,
-                 ddp_graph=None):
+                 ddp_graph=None, emb_valid=None):
         """Runs `warmup_steps` REAL steps eagerly on the given batch, captures, and (replay_after_capture) one more by replay.
         A trainer that must apply each batch exactly once passes warmup_steps=1, replay_after_capture=False.
         ddp_graph (data parallel only; train.py / bench.py --ddp-graph): "four" = four hipGraphs with the RCCL all-reduces between them
@@ -55,6 +55,11 @@ class GraphedTrainStep:
         self.src = src.clone()
         self.tgt = tgt.clone()
         self.src_len = torch.as_tensor(src_len).to(device=dev, dtype=torch.int32).clone()
+        # emb_cnn: valid time steps of the two convolutions' outputs for the BatchNorm statistics ([T1, T2] of the batch AS COLLATED; the
+        # static buffers may be padded further to a shape bucket).  None = no mask (the batch fills its buffers).
+        self.emb_valid = None
+        if emb_valid is not None:
+            self.emb_valid = torch.as_tensor(emb_valid).to(device=dev, dtype=torch.int32).clone()
         self.lr_dev = torch.zeros(1, device=dev, dtype=torch.float32)
         adam = opt.optimizer
         adam._ensure_flat()
@@ -78,7 +83,12 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.reset_pending()
-        self._capture()
+        from . import functions as F_
+        prev, F_.emb_valid = F_.emb_valid, self.emb_valid          # the captured launches take the mask's device address
+        try:
+            self._capture()
+        finally:
+            F_.emb_valid = prev
         # A capture RECORDS the refresh launches of the lazily refreshed weight shadows (conv packs, the channel-last copy of the input
         # projection) and marks those caches fresh -- without running them.  A replay refreshes them itself; an EAGER step that follows a
         # capture directly (the trainer's first batch of another bucket shape) would read copies one optimiser step old (round 6).
@@ -288,6 +298,14 @@ class GraphedTrainStep:
                 w.wait()
 
     def _eager_step(self):
+        from . import functions as F_
+        prev, F_.emb_valid = F_.emb_valid, self.emb_valid          # (read by EmbCNNFn at call time: eager steps and captures alike)
+        try:
+            return self._eager_step_inner()
+        finally:
+            F_.emb_valid = prev
+
+    def _eager_step_inner(self):
         if self.red is None:
             return self._body_single()
         loss, sums, st = self._body_a()
@@ -346,7 +364,7 @@ class GraphedTrainStep:
             opt._dev_step -= 1
         opt.optimizer.after_replay(-1)
 
-    def __call__(self, src=None, src_len=None, tgt=None):
+    def __call__(self, src=None, src_len=None, tgt=None, emb_valid=None):
         """Copy the batch into the static buffers (skip arguments that are already there) and replay.
         Returns (loss, sums) device tensors: sums = [loss_sum, non-PAD count, num_correct] (data parallel: `loss` is this
         rank's local mean and `sums` holds the GLOBAL sums once the step has run)."""
@@ -358,6 +376,10 @@ class GraphedTrainStep:
             sl = torch.as_tensor(src_len)
             if not (sl.is_cuda and sl.data_ptr() == self.src_len.data_ptr()):
                 self.src_len.copy_(sl.to(torch.int32), non_blocking=True)
+        if emb_valid is not None:
+            if self.emb_valid is None:
+                raise ValueError("this step was captured without a BatchNorm length mask")
+            self.emb_valid.copy_(torch.as_tensor(emb_valid).to(torch.int32), non_blocking=True)
         flat = self.opt.optimizer.flat
         if getattr(self.opt.optimizer, "_shadow_by_step", False) and flat.shadow_is_stale(torch.bfloat16):
             # a master was rewritten through torch between replays (checkpoint load, a test's poke): the captured forward reads the

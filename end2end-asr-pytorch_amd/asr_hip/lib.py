@@ -124,6 +124,9 @@ _SIGS = {
     "asr_bn_stats_blocks": (_L, [_L]),
     "asr_bn_stats_partial": (_I, [_P, _L, _L, _I, _P, _P, _P, _I, _I, _P]),
     "asr_bn_batch_stats": (_I, [_P, _L, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P]),
+    "asr_bn_batch_stats_v": (_I, [_P, _L, _L, _I, _P, _P, _P, _F, _F, _P, _P, _P, _I, _I, _P, _I, _P]),
+    "asr_bn_act_bwd_reduce_v": (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _P, _I, _I, _P]),
+    "asr_bn_act_bwd_v": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _I, _P, _P, _I, _I, _P]),
     "asr_bn_act_fwd": (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P]),
     "asr_bn_act_bwd_reduce": (_I, [_P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _I, _P]),
     "asr_bn_act_bwd": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -1206,15 +1206,17 @@ def bn_batch_stats(y, M, C, ygrid=(0, 0)):
     return mean, s2[C:] / M
 
 
-def bn_train_stats(y, M, C, eps, momentum=-1.0, running_mean=None, running_var=None, num_batches=None, ygrid=(0, 0)):
+def bn_train_stats(y, M, C, eps, momentum=-1.0, running_mean=None, running_var=None, num_batches=None, ygrid=(0, 0), valid=None):
     """-> (mean, rstd) of training-mode BatchNorm over y's first M rows / C columns, the module's running buffers updated in place
-    (momentum < 0: left alone): asr_bn_batch_stats, four launches."""
+    (momentum < 0: left alone): asr_bn_batch_stats, four launches.  valid = (device int32[1], row_w): only rows with
+    m % row_w < valid[0] count (the padding a shape bucket adds behind the collated batch stays out of the statistics)."""
     nb = L.load().asr_bn_stats_blocks(M)
     part = torch.empty((nb, 2 * C), device=y.device, dtype=torch.float32)
     mean = torch.empty(C, device=y.device, dtype=torch.float32)
     rstd = torch.empty(C, device=y.device, dtype=torch.float32)
-    L.call("asr_bn_batch_stats", L.ptr(y), y.stride(0), M, C, L.ptr(part), L.ptr(mean), L.ptr(rstd), float(eps), float(momentum),
-           L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches), ygrid[0], ygrid[1], L.stream())
+    L.call("asr_bn_batch_stats_v", L.ptr(y), y.stride(0), M, C, L.ptr(part), L.ptr(mean), L.ptr(rstd), float(eps), float(momentum),
+           L.ptr(running_mean), L.ptr(running_var), L.ptr(num_batches), ygrid[0], ygrid[1], L.ptr(valid[0]) if valid else None,
+           int(valid[1]) if valid else 0, L.stream())
     return mean, rstd
 
 
@@ -1225,16 +1227,17 @@ def bn_act_fwd(y, M, C, mean, rstd, gamma, beta, lo, hi, out, tH=0, tW=0, ygrid=
     return out
 
 
-def bn_act_bwd(dout, y, M, C, mean, rstd, gamma, beta, lo, hi, dy, tH=0, tW=0, ygrid=(0, 0), dygrid=(0, 0)):
+def bn_act_bwd(dout, y, M, C, mean, rstd, gamma, beta, lo, hi, dy, tH=0, tW=0, ygrid=(0, 0), dygrid=(0, 0), valid=None):
     """-> sums (2C): [dbeta, dgamma]; writes dy[:M, :C] (the gradient w.r.t. the conv output) in dy's dtype.  dygrid = (Wg, OW): row m
     goes to dy row (m // OW) * Wg + m % OW (dy is the dense operand of the window gradients; the rows in between are left alone)."""
     assert dout.dtype == dy.dtype and dout.is_contiguous()
     ldo = 0 if tH else dout.stride(0)
     sums = torch.zeros(2 * C, device=y.device, dtype=torch.float32)
-    L.call("asr_bn_act_bwd_reduce", L.ptr(dout), ldo, L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
-           L.ptr(beta), float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], L.ptr(sums), L.dt(dout), L.stream())
-    L.call("asr_bn_act_bwd", L.ptr(dout), ldo, L.ptr(y), y.stride(0), L.ptr(dy), dy.stride(0), M, C, L.ptr(mean), L.ptr(rstd),
-           L.ptr(gamma), L.ptr(beta), float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], dygrid[0], dygrid[1], L.ptr(sums),
+    vp, vw = (L.ptr(valid[0]), int(valid[1])) if valid else (None, 0)
+    L.call("asr_bn_act_bwd_reduce_v", L.ptr(dout), ldo, L.ptr(y), y.stride(0), M, C, L.ptr(mean), L.ptr(rstd), L.ptr(gamma),
+           L.ptr(beta), float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], L.ptr(sums), vp, vw, L.dt(dout), L.stream())
+    L.call("asr_bn_act_bwd_v", L.ptr(dout), ldo, L.ptr(y), y.stride(0), L.ptr(dy), dy.stride(0), M, C, L.ptr(mean), L.ptr(rstd),
+           L.ptr(gamma), L.ptr(beta), float(lo), float(hi), tH, tW, ygrid[0], ygrid[1], dygrid[0], dygrid[1], L.ptr(sums), vp, vw,
            L.dt(dout), L.stream())
     return sums
 

@@ -128,7 +128,15 @@ struct BnArgs {
   int tH, tW;          // > 0: rows are (b, h, w) over (B, tH, tW) and the activation side uses (B, tW, C*tH), feature c*tH + h
   int64_t ldo;
   int yW, yOW;         // yOW > 0: y lives on the row grid of a window GEMM -- groups of yW rows of which the first yOW are outputs
-};                     // (row m of the convolution = y row (m / yOW) * yW + m % yOW); 0: y is compact
+                       // (row m of the convolution = y row (m / yOW) * yW + m % yOW); 0: y is compact
+  // Length-masked statistics (round 6; the *_v entry points): rows are (group, t) with t = m % vW the time step; only t < *valid take
+  // part in the batch statistics and receive a gradient -- the rest is padding that a shape BUCKET added behind the batch as collated
+  // (trainer --graph-buckets), which the reference's BatchNorm never sees.  *valid lives in device memory: one captured graph serves
+  // every batch of its bucket.  valid == nullptr: every row counts.
+  const int* valid;
+  int vW;
+};
+__device__ __forceinline__ bool bn_row_ok(const BnArgs& a, int64_t m, int nv) { return a.valid == nullptr || (int)((unsigned)m % (unsigned)a.vW) < nv; }
 
 // row m of the convolution output -> row of a buffer laid out in groups of gw rows with gow outputs each (gow == 0: identity)
 __device__ __forceinline__ int64_t grid_row(int64_t m, int gw, int gow) {
@@ -160,18 +168,23 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, const float* __
   __shared__ float red[2][256];
   const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
   const float ctr = center ? center[c] : 0.f;
+  const int nv = a.valid ? *a.valid : 0;
   const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
   const int64_t r1 = r0 + BN_ROWS < a.M ? r0 + BN_ROWS : a.M;
   float s = 0.f, q = 0.f;
   int64_t r = r0 + rl;
   for (; r + 3 * nrl < r1; r += 4 * nrl) {
-    const float v0 = bn_y(a, r, c) - ctr, v1 = bn_y(a, r + nrl, c) - ctr;
-    const float v2 = bn_y(a, r + 2 * nrl, c) - ctr, v3 = bn_y(a, r + 3 * nrl, c) - ctr;
+    float v0 = bn_y(a, r, c) - ctr, v1 = bn_y(a, r + nrl, c) - ctr;
+    float v2 = bn_y(a, r + 2 * nrl, c) - ctr, v3 = bn_y(a, r + 3 * nrl, c) - ctr;
+    if (a.valid) {          // (the loads stay unconditional: four in flight; padding rows hold finite numbers)
+      v0 = bn_row_ok(a, r, nv) ? v0 : 0.f; v1 = bn_row_ok(a, r + nrl, nv) ? v1 : 0.f;
+      v2 = bn_row_ok(a, r + 2 * nrl, nv) ? v2 : 0.f; v3 = bn_row_ok(a, r + 3 * nrl, nv) ? v3 : 0.f;
+    }
     s += (v0 + v1) + (v2 + v3);
     q += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
   }
   for (; r < r1; r += nrl) {
-    const float v = bn_y(a, r, c) - ctr;
+    const float v = bn_row_ok(a, r, nv) ? bn_y(a, r, c) - ctr : 0.f;
     s += v;
     q += v * v;
   }
@@ -215,8 +228,14 @@ __global__ void __launch_bounds__(1024) bn_partial_sum_kernel(const float* __res
 __global__ void __launch_bounds__(1024) bn_finish_kernel(const float* __restrict__ partial, int64_t nblk, int C, int mode, float inv_m,
                                                          float unbias, float eps, float momentum, float* __restrict__ mean,
                                                          float* __restrict__ rstd, float* __restrict__ running_mean,
-                                                         float* __restrict__ running_var, int64_t* __restrict__ num_batches) {
+                                                         float* __restrict__ running_var, int64_t* __restrict__ num_batches,
+                                                         const int* __restrict__ valid, int64_t groups) {
   __shared__ float red[1024];
+  if (valid) {              // length-masked statistics: the count is groups x *valid, known on the device only
+    const float m = (float)(groups * (int64_t)valid[0]);
+    inv_m = 1.f / fmaxf(m, 1.f);
+    unbias = m / fmaxf(m - 1.f, 1.f);
+  }
   const int C2 = 2 * C, G = 1024 / C2, c = threadIdx.x % C2, g = threadIdx.x / C2;
   float s = 0.f;
   if (g < G)
@@ -261,6 +280,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
   const int64_t r0 = (int64_t)blockIdx.x * BN_ROWS;
   const int64_t r1 = r0 + BN_ROWS < a.M ? r0 + BN_ROWS : a.M;
   float s = 0.f, q = 0.f;
+  const int nv = a.valid ? *a.valid : 0;
   int64_t r = r0 + rl;
   for (; r + 3 * nrl < r1; r += 4 * nrl) {          // all 8 loads of four rows first; rows outside the Hardtanh window contribute 0
     float yv[4], dv[4];
@@ -273,7 +293,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
     for (int u = 0; u < 4; ++u) {
       const float xh = (yv[u] - mu) * rs;
       const float z = xh * g + be;
-      const float d = (z > a.lo && z < a.hi) ? dv[u] : 0.f;
+      const float d = (z > a.lo && z < a.hi && bn_row_ok(a, r + u * nrl, nv)) ? dv[u] : 0.f;
       s += d;
       q += d * xh;
     }
@@ -281,7 +301,7 @@ __global__ void __launch_bounds__(256) bn_act_bwd_reduce_kernel(BnArgs a, const 
   for (; r < r1; r += nrl) {
     const float xh = (bn_y(a, r, c) - mu) * rs;
     const float z = xh * g + be;
-    if (z > a.lo && z < a.hi) {
+    if (z > a.lo && z < a.hi && bn_row_ok(a, r, nv)) {
       const float d = DT<T>::ld(dout + act_index(a, r, c));
       s += d;
       q += d * xh;
@@ -306,14 +326,16 @@ __global__ void __launch_bounds__(256) bn_act_bwd_kernel(BnArgs a, const T* __re
                                                          T* __restrict__ dy, int64_t lddy, int dW, int dOW) {
   const int C = a.C, c = threadIdx.x % C, rl = threadIdx.x / C, nrl = 256 / C;
   const float mu = a.mean[c], rs = a.rstd[c], g = a.gamma[c], be = a.beta[c];
-  const float inv = 1.f / (float)a.M;
+  const int nv = a.valid ? *a.valid : 0;
+  const float inv = a.valid ? 1.f / fmaxf((float)((a.M / a.vW) * (int64_t)nv), 1.f) : 1.f / (float)a.M;
   const float m1 = sums[c] * inv, m2 = sums[C + c] * inv;
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   for (int64_t r = r0 + rl; r < r0 + 64 && r < a.M; r += nrl) {
     const float xh = (bn_y(a, r, c) - mu) * rs;
     const float z = xh * g + be;
     const float d = (z > a.lo && z < a.hi) ? DT<T>::ld(dout + act_index(a, r, c)) : 0.f;
-    DT<T>::st(dy + grid_row(r, dW, dOW) * lddy + c, g * rs * (d - m1 - xh * m2));
+    // a padding row took no part in the statistics: it gets no gradient (its dout is zero already: the encoder masks it)
+    DT<T>::st(dy + grid_row(r, dW, dOW) * lddy + c, bn_row_ok(a, r, nv) ? g * rs * (d - m1 - xh * m2) : 0.f);
   }
 }
 
@@ -437,18 +459,27 @@ extern "C" int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int 
 extern "C" int asr_bn_batch_stats(const float* y, int64_t ldy, int64_t M, int C, float* partial, float* mean, float* rstd, float eps,
                                   float momentum, float* running_mean, float* running_var, int64_t* num_batches, int y_grid_w,
                                   int y_grid_ow, hipStream_t stream) {
+  return asr_bn_batch_stats_v(y, ldy, M, C, partial, mean, rstd, eps, momentum, running_mean, running_var, num_batches, y_grid_w, y_grid_ow,
+                              nullptr, 0, stream);
+}
+extern "C" int asr_bn_batch_stats_v(const float* y, int64_t ldy, int64_t M, int C, float* partial, float* mean, float* rstd, float eps,
+                                    float momentum, float* running_mean, float* running_var, int64_t* num_batches, int y_grid_w,
+                                    int y_grid_ow, const int* valid_w, int row_w, hipStream_t stream) {
   ASR_CHECK_ARG(y && partial && mean && rstd && M > 0 && C > 0 && C <= 256 && 256 % C == 0 && ldy >= C && grid_ok(M, y_grid_w, y_grid_ow));
   ASR_CHECK_ARG(momentum < 0.f || (running_mean && running_var));
+  ASR_CHECK_ARG(valid_w == nullptr || (row_w > 0 && M % row_w == 0 && M < ((int64_t)1 << 31)));
   BnArgs a{};
-  a.y = y; a.ldy = ldy; a.M = M; a.C = C; a.yW = y_grid_w; a.yOW = y_grid_ow;
+  a.y = y; a.ldy = ldy; a.M = M; a.C = C; a.yW = y_grid_w; a.yOW = y_grid_ow; a.valid = valid_w; a.vW = row_w;
+  const int64_t groups = valid_w ? M / row_w : 0;
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
   const int64_t nblk = ceil_div64(M, BN_ROWS);
   const float inv_m = 1.f / (float)M, unbias = (float)M / (float)(M > 1 ? M - 1 : 1);
   bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, nullptr, nullptr, partial);
-  bn_finish_kernel<<<1, 1024, 0, stream>>>(partial, nblk, C, 1, inv_m, unbias, eps, momentum, mean, rstd, nullptr, nullptr, nullptr);
+  bn_finish_kernel<<<1, 1024, 0, stream>>>(partial, nblk, C, 1, inv_m, unbias, eps, momentum, mean, rstd, nullptr, nullptr, nullptr, valid_w,
+                                           groups);
   bn_stats_kernel<<<(unsigned)nblk, 256, 0, stream>>>(a, mean, nullptr, partial);
   bn_finish_kernel<<<1, 1024, 0, stream>>>(partial, nblk, C, 2, inv_m, unbias, eps, momentum, mean, rstd, running_mean, running_var,
-                                           num_batches);
+                                           num_batches, valid_w, groups);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -456,7 +487,7 @@ extern "C" int asr_bn_batch_stats(const float* y, int64_t ldy, int64_t M, int C,
 extern "C" int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
                               const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
                               int y_grid_w, int y_grid_ow, int dtype, hipStream_t stream) {
-  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow};
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow, nullptr, 0};
   ASR_CHECK_ARG(out && bn_args_ok(a) && (tH > 0 || ldo >= C));
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
@@ -472,7 +503,15 @@ extern "C" int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ld
 extern "C" int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C,
                                      const float* mean, const float* rstd, const float* gamma, const float* beta, float lo,
                                      float hi, int tH, int tW, int y_grid_w, int y_grid_ow, float* sums, int dtype, hipStream_t stream) {
-  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow};
+  return asr_bn_act_bwd_reduce_v(dout, ldo, y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, y_grid_w, y_grid_ow, sums, nullptr, 0,
+                                 dtype, stream);
+}
+extern "C" int asr_bn_act_bwd_reduce_v(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C,
+                                       const float* mean, const float* rstd, const float* gamma, const float* beta, float lo,
+                                       float hi, int tH, int tW, int y_grid_w, int y_grid_ow, float* sums, const int* valid_w, int row_w,
+                                       int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow, valid_w, row_w};
+  ASR_CHECK_ARG(valid_w == nullptr || (row_w > 0 && M % row_w == 0));
   ASR_CHECK_ARG(dout && sums && bn_args_ok(a) && (tH > 0 || ldo >= C));
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   AsrProfScope prof(ASR_OP_ADD_LN, stream);
@@ -489,7 +528,15 @@ extern "C" int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int
                               const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
                               int tH, int tW, int y_grid_w, int y_grid_ow, int dy_grid_w, int dy_grid_ow, const float* sums, int dtype,
                               hipStream_t stream) {
-  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow};
+  return asr_bn_act_bwd_v(dout, ldo, y, ldy, dy, lddy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, y_grid_w, y_grid_ow, dy_grid_w,
+                          dy_grid_ow, sums, nullptr, 0, dtype, stream);
+}
+extern "C" int asr_bn_act_bwd_v(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
+                                const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
+                                int tH, int tW, int y_grid_w, int y_grid_ow, int dy_grid_w, int dy_grid_ow, const float* sums,
+                                const int* valid_w, int row_w, int dtype, hipStream_t stream) {
+  BnArgs a{y, ldy, M, C, mean, rstd, gamma, beta, lo, hi, tH, tW, ldo, y_grid_w, y_grid_ow, valid_w, row_w};
+  ASR_CHECK_ARG(valid_w == nullptr || (row_w > 0 && M % row_w == 0));
   ASR_CHECK_ARG(dout && dy && sums && bn_args_ok(a) && (tH > 0 || ldo >= C) && lddy >= C && grid_ok(M, dy_grid_w, dy_grid_ow));
   ASR_CHECK_ARG(dtype == ASR_F32 || dtype == ASR_BF16);
   AsrProfScope prof(ASR_OP_ADD_LN, stream);

@@ -36,9 +36,9 @@ DEFAULT_GRAPH_BUCKET = 64
 def resolve_graph_buckets(args, explicit, model=None):
     """The fast path is the default path: `train.py --cuda` with the vgg_cnn front end and the cross-entropy loss replays one captured
     hipGraph per (batch, frames padded to a multiple of 64) shape -- 5.75 against 7.86 ms per step of the eager loop at configs[1]
-    (profiles/r04_trainer_rate.txt).  `--graph-buckets 0` opts out; an explicit value always wins.  NOT the default for emb_cnn: its
-    BatchNorm takes batch statistics over every time step it is given (the reference's does too, over the collate padding), so the
-    extra bucket padding would change the numbers; there the user opts in (trainer.py warns).
+    (profiles/r04_trainer_rate.txt).  `--graph-buckets 0` opts out; an explicit value always wins.  Since round 6 also for emb_cnn: its
+    BatchNorm statistics are length-masked on the device to the batch as collated (what the reference's BatchNorm sees), so the bucket
+    padding no longer enters them (asr_bn_batch_stats_v; tests/test_gpu_graph.py).
     `model`: the front end is read from the model that will train (main() calls this AFTER init / load_model: a --continue-from
     checkpoint carries its own --feat_extractor, the command line's default must not decide for it).
     Parity caveat of the default (README, --help): for the LONGEST utterance of a batch the convolutions see bias + ReLU'd zero frames
@@ -50,7 +50,7 @@ def resolve_graph_buckets(args, explicit, model=None):
     feat = getattr(core, "feat_extractor", None) if core is not None else None
     if feat is None:
         feat = getattr(args, "feat_extractor", "")
-    if getattr(args, "cuda", False) and feat == "vgg_cnn" and getattr(args, "loss", "ce") == "ce":
+    if getattr(args, "cuda", False) and feat in ("vgg_cnn", "emb_cnn") and getattr(args, "loss", "ce") == "ce":
         args.graph_buckets = DEFAULT_GRAPH_BUCKET
     return args.graph_buckets
 

@@ -110,9 +110,9 @@ class Trainer():
         columns (Decoder.preprocess strips PAD, so the targets are unchanged; the encoder positions the extra zero frames add are masked
         through the lengths (clamped to the positions of the batch as collated), so attention sees the un-bucketed batch; what remains
         is the convolutions' view of the last frames of the LONGEST utterance -- followed by zero frames instead of the image border,
-        exactly what the collate padding does to every shorter utterance -- for vgg_cnn.  With --feat_extractor emb_cnn the BatchNorm
-        batch statistics are taken over padded positions as well (as they are over the collate padding in the reference), so bucket
-        padding changes them: results are NOT identical to --graph-buckets 0 there) -- and the graph is replayed.  At most
+        exactly what the collate padding does to every shorter utterance.  With --feat_extractor emb_cnn the BatchNorm batch statistics
+        are taken over the batch as collated, collate padding included as in the reference; the frames the bucket adds are masked out
+        of them on the device: tests/test_gpu_graph.py) -- and the graph is replayed.  At most
         GRAPH_CACHE shapes stay captured (least recently used first out: a captured step owns its activations' memory pool).  The first batch of a new
         shape runs eagerly (that IS its training step) and captures.  Returns (loss value, gold_seq, hyp_seq) or None when the
         shapes do not fit (falls back to eager launches).  Under --parallel (an active gradient reducer) the step is the four-graph
@@ -128,10 +128,12 @@ class Trainer():
         # args, and the command line's --feat_extractor default would clamp an emb_cnn model's lengths to T // 4)
         core = model.module if hasattr(model, "module") else model
         feat = getattr(core, "feat_extractor", getattr(a, "feat_extractor", ""))
-        if feat == "emb_cnn" and not self.__dict__.get("_warned_bn_buckets"):
-            self._warned_bn_buckets = True
-            logging.warning("--graph-buckets with --feat_extractor emb_cnn: BatchNorm batch statistics include the bucket padding "
-                            "(as they include the collate padding in the reference); results differ from --graph-buckets 0")
+        # emb_cnn: the BatchNorm batch statistics run over the batch AS COLLATED (like the reference's, collate padding included); the
+        # frames a bucket adds behind it are masked out of them by a device-side length (round 6: asr_bn_batch_stats_v)
+        emb_valid = None
+        if feat == "emb_cnn":
+            t1 = (int(src.shape[3]) + 20 - 11) // 2 + 1
+            emb_valid = [t1, t1 - 10]
         B, C, F, T = src.shape
         Tb = (T + N - 1) // N * N
         key = (B, C, F, Tb, L, src.dtype)
@@ -157,7 +159,7 @@ class Trainer():
             tgt_b[:, :tgt.shape[1]].copy_(tgt)
             gs = graphs[key] = GraphedTrainStep(model, opt, smoothing, src_b, lens, tgt_b,
                                                 clip_max_norm=a.max_norm if a.clip else None, warmup_steps=1,
-                                                replay_after_capture=False, ddp_graph=getattr(a, "ddp_graph", None))
+                                                replay_after_capture=False, ddp_graph=getattr(a, "ddp_graph", None), emb_valid=emb_valid)
             if gs.ddp_graph_mode is not None and not self.__dict__.get("_logged_ddp_graph"):
                 self._logged_ddp_graph = True
                 logging.info("data-parallel graph replay: %s (--ddp-graph %s)", gs.ddp_graph_mode, gs.ddp_graph)
@@ -170,7 +172,7 @@ class Trainer():
             gs.tgt.zero_()
             gs.tgt[:, :tgt.shape[1]].copy_(tgt, non_blocking=True)
             gs.sync_step_counter()
-            gs(src_len=lens)
+            gs(src_len=lens, emb_valid=emb_valid)
         return self._global_loss(opt, gs.loss), gs.gold_seq, gs.hyp_seq
 
     @staticmethod

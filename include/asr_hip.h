@@ -478,6 +478,14 @@ int asr_bn_stats_partial(const float* y, int64_t ldy, int64_t M, int C, const fl
 int asr_bn_batch_stats(const float* y, int64_t ldy, int64_t M, int C, float* partial, float* mean, float* rstd, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* num_batches, int y_grid_w, int y_grid_ow,
                        asr_stream_t stream);
+/* Length-masked forms (round 6).  Rows are (group, t), t = m % row_w the time step of the convolution output; only rows with
+ * t < valid_w[0] (a DEVICE int, so that one captured graph serves every batch of its shape bucket) take part in the statistics
+ * (count = (M / row_w) * valid_w[0]) and receive a gradient from asr_bn_act_bwd_v (the others get 0).  What is masked is the padding a
+ * shape bucket adds BEHIND the batch as collated (trainer --graph-buckets): the reference's BatchNorm (transformer.py:35,38) runs over
+ * the collate padding but never sees a bucket.  valid_w == NULL: the unmasked functions above.                                    */
+int asr_bn_batch_stats_v(const float* y, int64_t ldy, int64_t M, int C, float* partial, float* mean, float* rstd, float eps,
+                         float momentum, float* running_mean, float* running_var, int64_t* num_batches, int y_grid_w, int y_grid_ow,
+                         const int* valid_w, int row_w, asr_stream_t stream);
 /* out = clamp(gamma * (y - mean) * rstd + beta, lo, hi)   (BatchNorm2d + Hardtanh, transformer.py:35-36,38-39).
  * tH > 0: rows are (b,h,w) over (B,tH,tW) and out is the encoder input (B, tW, C*tH), feature c*tH + h (:74-76).     */
 int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t M, int C, const float* mean,
@@ -487,11 +495,18 @@ int asr_bn_act_fwd(const float* y, int64_t ldy, void* out, int64_t ldo, int64_t 
 int asr_bn_act_bwd_reduce(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C, const float* mean,
                           const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
                           int y_grid_w, int y_grid_ow, float* sums, int dtype, asr_stream_t stream);
+int asr_bn_act_bwd_reduce_v(const void* dout, int64_t ldo, const float* y, int64_t ldy, int64_t M, int C, const float* mean,
+                            const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
+                            int y_grid_w, int y_grid_ow, float* sums, const int* valid_w, int row_w, int dtype, asr_stream_t stream);
 /* dy (M, lddy) = gamma * rstd * (dz - sums[c]/M - xhat * sums[C+c]/M)   (training-mode BatchNorm backward)           */
 int asr_bn_act_bwd(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
                    const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi,
                    int tH, int tW, int y_grid_w, int y_grid_ow, int dy_grid_w, int dy_grid_ow, const float* sums, int dtype,
                    asr_stream_t stream);
+int asr_bn_act_bwd_v(const void* dout, int64_t ldo, const float* y, int64_t ldy, void* dy, int64_t lddy, int64_t M, int C,
+                     const float* mean, const float* rstd, const float* gamma, const float* beta, float lo, float hi, int tH, int tW,
+                     int y_grid_w, int y_grid_ow, int dy_grid_w, int dy_grid_ow, const float* sums, const int* valid_w, int row_w,
+                     int dtype, asr_stream_t stream);
 
 /* ---- spectrogram front end on the device (reference: SpectrogramParser.parse_audio, utils/data_loader.py:72-89) ---------
  * frames (B*Tmax, n_fft) fp32 <- windowed, centred (reflect padded) frames of the padded waveforms wav (B, wav_stride),

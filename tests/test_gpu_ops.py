@@ -1163,6 +1163,52 @@ def test_batchnorm_hardtanh_on_a_row_grid(ops, grid):
         assert bool((dy.view(groups, 17, C)[:, gOW:] == 7.0).all())                  # rows between the groups: not written
 
 
+@pytest.mark.parametrize("grid", [(0, 0), (13, 9)])
+@pytest.mark.parametrize("nv", [9, 6, 1])
+def test_batchnorm_length_masked_statistics(ops, grid, nv):
+    """The *_v forms (round 6): rows are (group, t) with t = m % 9; only t < valid[0] -- a DEVICE int -- take part in the statistics and get
+    a gradient.  Truth: torch's BatchNorm2d (training) + Hardtanh on the COMPACTED valid rows -- what the reference's BatchNorm sees when
+    the batch is not padded to a shape bucket -- and zeros in the gradient of the masked rows.  nv = 9: everything valid = the unmasked
+    result."""
+    D = dev()
+    C, groups, Wt = 32, 41, 9
+    gW, gOW = grid
+    M = groups * Wt
+    g = torch.Generator().manual_seed(40 + nv)
+    yc = (torch.randn(M, C, generator=g) * 6 + 5)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dz = torch.randn(M, C, generator=g)
+    keep = (torch.arange(M) % Wt) < nv
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(gamma); bn.bias.copy_(beta)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    yv = yc[keep].clone().requires_grad_()
+    Mv = int(keep.sum())
+    ref = F.hardtanh(bn(yv.t().reshape(1, C, Mv, 1)), 0.0, 20.0).reshape(C, Mv).t()
+    ref.backward(dz[keep])
+    if gOW:
+        y = torch.full((groups * gW, 64), 1e30)
+        y.view(groups, gW, 64)[:, :gOW, :C] = yc.view(groups, gOW, C)
+    else:
+        y = torch.zeros(M, 64)
+        y[:, :C] = yc
+    y = y.to(D)
+    valid = (torch.tensor([nv], dtype=torch.int32, device=D), Wt)
+    rm, rv, nb = rm0.clone().to(D), rv0.clone().to(D), torch.zeros((), dtype=torch.int64, device=D)
+    mean, rstd = ops.bn_train_stats(y, M, C, bn.eps, 0.1, rm, rv, nb, ygrid=grid, valid=valid)
+    assert (mean.cpu() - yc[keep].mean(0)).abs().max().item() < 1e-4
+    assert (rstd.cpu() - torch.rsqrt(yc[keep].var(0, unbiased=False) + bn.eps)).abs().max().item() < 1e-4
+    assert (rm.cpu() - bn.running_mean).abs().max().item() < 1e-5 and (rv.cpu() - bn.running_var).abs().max().item() < 1e-4 and int(nb) == 1
+    dgrid = (17, gOW) if gOW else (0, 0)
+    dy = torch.full(((groups * 17 if gOW else M), C), 7.0, device=D)
+    sums = ops.bn_act_bwd(dz.to(D), y, M, C, mean, rstd, gamma.to(D), beta.to(D), 0.0, 20.0, dy, ygrid=grid, dygrid=dgrid, valid=valid)
+    assert (sums[:C].cpu() - bn.bias.grad).abs().max().item() < 2e-3 and (sums[C:].cpu() - bn.weight.grad).abs().max().item() < 2e-3
+    got = (dy.view(groups, 17, C)[:, :gOW].reshape(M, C) if gOW else dy).cpu()
+    assert (got[keep] - yv.grad).abs().max().item() < 1e-4 * max(1.0, yv.grad.abs().max().item())
+    assert bool((got[~keep] == 0).all())                                              # masked rows: no gradient
+
+
 def test_ops_refuse_host_tensors(ops):
     from asr_hip.lib import AsrHipError
     with pytest.raises(AsrHipError):

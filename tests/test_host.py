@@ -639,8 +639,8 @@ def test_grad_reducer_world8_gloo_at_the_benchmark_models_offsets(tmp_path):
 
 def test_train_cli_replays_graphs_by_default_for_vgg_cnn():
     """VERDICT r4 #6a: the README command line gets the benched path.  `train.py --cuda` with vgg_cnn and the CE loss resolves
-    --graph-buckets to 64 unless the user typed a value (0 = opt out); emb_cnn (BatchNorm statistics over padded frames), the CTC
-    loss and CPU runs keep the eager loop."""
+    --graph-buckets to 64 unless the user typed a value (0 = opt out); so does emb_cnn since round 6 (its BatchNorm statistics are
+    length-masked to the batch as collated); a model without a CNN front end, the CTC loss and CPU runs keep the eager loop."""
     import importlib
     from utils import constant
     train = importlib.import_module("train")
@@ -654,11 +654,13 @@ def test_train_cli_replays_graphs_by_default_for_vgg_cnn():
     assert resolved(base + ["--cuda", "--graph-buckets", "0"]) == 0
     assert resolved(base + ["--cuda", "--graph-buckets", "128"]) == 128
     assert resolved(base) == 0
-    assert resolved(["--feat_extractor", "emb_cnn", "--cuda"]) == 0
+    assert resolved(["--feat_extractor", "emb_cnn", "--cuda"]) == 64
+    assert resolved(["--feat_extractor", "", "--cuda"]) == 0
     assert resolved(base + ["--cuda", "--loss", "ctc"]) == 0
 
     # the MODEL's front end decides, not the command line's default -- `train.py --cuda --continue-from <emb_cnn checkpoint>`
-    # without retyping --feat_extractor must NOT take the bucketed-graph default (it would clamp the lengths to T // 4)
+    # without retyping --feat_extractor must be decided by the checkpoint's model (the trainer clamps the lengths by the MODEL's front end:
+    # an emb_cnn model under the command line's vgg_cnn default would have had half its positions masked)
     class _M:
         def __init__(self, feat):
             self.feat_extractor = feat
@@ -671,7 +673,8 @@ def test_train_cli_replays_graphs_by_default_for_vgg_cnn():
         a = constant.parser.parse_args(argv)
         return train.resolve_graph_buckets(a, constant._given(argv), model)
 
-    assert resolved_for(["--cuda"], _M("emb_cnn")) == 0                       # command line says vgg_cnn (default), the checkpoint's model says emb_cnn
-    assert resolved_for(["--cuda"], _Wrapped("emb_cnn")) == 0
-    assert resolved_for(["--feat_extractor", "emb_cnn", "--cuda"], _M("vgg_cnn")) == 64
-    assert resolved_for(["--cuda", "--graph-buckets", "32"], _M("emb_cnn")) == 32
+    assert resolved_for(["--cuda"], _M("")) == 0                              # command line says vgg_cnn (default), the checkpoint's model has no CNN
+    assert resolved_for(["--cuda"], _Wrapped("")) == 0
+    assert resolved_for(["--feat_extractor", "", "--cuda"], _M("vgg_cnn")) == 64
+    assert resolved_for(["--feat_extractor", "", "--cuda"], _Wrapped("emb_cnn")) == 64
+    assert resolved_for(["--cuda", "--graph-buckets", "32"], _M("")) == 32
