@@ -217,7 +217,9 @@ def test_emb_cnn_bucket_padding_stays_out_of_the_batchnorm_statistics(golden_dir
     for a, b in zip(eager, graph):
         assert abs(a - b) <= 1e-4 * max(1.0, abs(a)), (eager, graph)
     for k in w_e:
-        if k.endswith("key_linear.bias") or k.endswith("num_batches_tracked"):
+        # (skipped: parameters whose exact gradient is zero -- key biases, conv biases in front of a BatchNorm -- Adam turns their rounding
+        #  noise into +- lr moves in either run)
+        if k.endswith("key_linear.bias") or k.endswith("num_batches_tracked") or k in ("conv.0.bias", "conv.3.bias"):
             continue
         assert torch.allclose(w_e[k].float(), w_g[k].float(), rtol=1e-4, atol=2e-5), (k, float((w_e[k].float() - w_g[k].float()).abs().max()))
     assert int(w_g["conv.1.num_batches_tracked"]) == int(w_e["conv.1.num_batches_tracked"]) == 4
