@@ -182,6 +182,32 @@ def test_trainer_graph_buckets_equal_eager_on_whole_buckets(golden_dir, monkeypa
     assert max(rel) < 5e-3, rel               # measured 8e-4 ... 1e-3
 
 
+def test_weight_shadows_are_not_left_stale_by_a_capture(golden_dir):
+    """Round 6 (found by the --ddp-graph auto verification).  A capture RECORDS the refresh launches of the lazily refreshed weight shadows
+    (the conv packs, the channel-last copy of the input projection) and marks those caches fresh -- without running them.  A replay
+    refreshes them itself, but an EAGER step right after a capture (the trainer's first batch of another bucket shape) used to read
+    copies one optimiser step old.  After constructing a captured step WITHOUT replaying it, what the next eager forward would fetch must
+    be derived from the CURRENT masters."""
+    from asr_hip.graph import GraphedTrainStep
+    from asr_hip import params as P
+    z, args, m, o = build(golden_dir, "vgg_tiny", "bf16")
+    src, tgt = torch.from_numpy(z["src"]).cuda(), torch.from_numpy(z["tgt"]).cuda()
+    src_len = torch.from_numpy(z["src_len"])
+    GraphedTrainStep(m, o, float(z["smoothing"]), src, src_len, tgt, warmup_steps=1, replay_after_capture=False)
+    torch.cuda.synchronize()
+    core = m.module if hasattr(m, "module") else m
+    for idx in (2, 5, 7):
+        w = core.conv[idx].weight
+        wk, wd = P.conv_shadow(w)                      # what VGGFn.forward of an eager step would use now
+        want = w.data.permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]).to(torch.bfloat16)
+        assert torch.equal(wk, want), ("conv.%d packed weights are not the current masters'" % idx, float((wk.float() - want.float()).abs().max()))
+    Win = core.encoder.input_linear.weight
+    C, H2 = 128, Win.shape[1] // 128
+    wp = P.tcf_perm_shadow(Win, C, H2)
+    want = Win.data.to(torch.bfloat16).view(Win.shape[0], C, H2).permute(0, 2, 1).reshape(Win.shape[0], H2 * C)
+    assert torch.equal(wp, want)
+
+
 def test_emb_cnn_bucket_padding_stays_out_of_the_batchnorm_statistics(golden_dir, monkeypatch):
     """emb_cnn's BatchNorm takes batch statistics over every time step it is given -- in the reference over the batch as
     collated.  --graph-buckets pads further (emb_tiny: 96 -> 128 frames); since round 6 those frames are masked out of the statistics by
