@@ -25,6 +25,7 @@
 #include "conv_level0.h"
 #include "conv_wgrad_dma.h"
 
+#include <type_traits>
 #include <utility>
 
 extern "C" int asr_conv3x3_wgrad_reduce(const float* workspace, float* dw, int B, int H, int W, int Cin, int Cout, hipStream_t s);
@@ -163,75 +164,93 @@ __device__ __forceinline__ void l0_gen_store(unsigned char* ypatch, int wa, cons
   asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb));
   *reinterpret_cast<uint2*>(ypatch + (wa ^ (cf << 5))) = make_uint2(pa & vmask, pb & vmask);
 }
+__device__ __forceinline__ void l0_gen_store_inside(unsigned char* ypatch, int wa, const f32x4_t& a, int cf) {
+  uint32_t pa = pack_bf16(a[0], a[1]), pb = pack_bf16(a[2], a[3]);
+  asm("v_pk_max_i16 %0, %0, 0" : "+v"(pa));
+  asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb));
+  *reinterpret_cast<uint2*>(ypatch + (wa ^ (cf << 5))) = make_uint2(pa, pb);
+}
 __device__ __forceinline__ uint32_t l0_halo_valid(const L0Args& p, const L0Org& o, int prc) {
   const int gy = o.h0 + (prc & 0xff) - 1, gx = o.w0 + ((prc >> 8) & 0xff) - 1;
   return ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
 }
 
-// pooled 2 x 2 max + selection codes from the accumulators of an 8 x 16 tile (the POOL epilogue of conv3x3_c64_kernel, y never stored)
-__device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)[4][2], int tl, int b, int h0, int w0, int co0) {
-  uint32_t keep[4][2][2];
+// pooled 2 x 2 max + selection codes from the accumulators of an 8 x 16 tile (the POOL epilogue of conv3x3_c64_kernel, y never stored).
+// A lane holds 4 channels x 2 channel fragments of ONE pixel per tile row; the two pixels of a pooling window sit in a lane pair.  The
+// pair first trades fragments -- the even lane keeps fragment 0 of both pixels, the odd lane fragment 1 (one v_cndmask with a DPP source
+// per dword) -- so that every lane then owns WHOLE windows of half the channels: maxima and codes are computed once per window instead
+// of twice per lane pair (round 6: 217 -> ~130 vector instructions per wave and tile).  ReLU comes after the maximum: the int16 order of
+// bf16 bit patterns is the value order wherever a positive value exists, and a window without one pools to 0 / code 0 either way.
+// (k0[d], k1[d]: this lane's pixel, fragments 0 / 1.  L = fragment 0 of the even lane's pixel on the even lane, fragment 1 of it on the odd
+// lane; R = the odd lane's pixel likewise.  v_cndmask_b32_dpp takes VCC implicitly, so the four selects of a tile row share one asm block;
+// the leading s_nop covers the VALU-write -> DPP-read wait states the compiler cannot see inside an asm.)
+__device__ __forceinline__ void l0_pair_trade(const uint32_t (&k0)[2], const uint32_t (&k1)[2], uint64_t even_lanes, uint32_t (&L)[2], uint32_t (&R)[2]) {
+  asm("s_nop 1\n\ts_mov_b64 vcc, %8\n\t"
+      "v_cndmask_b32_dpp %0, %5, %4, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %1, %7, %6, vcc quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_not_b64 vcc, vcc\n\t"
+      "v_cndmask_b32_dpp %2, %4, %5, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf\n\t"
+      "v_cndmask_b32_dpp %3, %6, %7, vcc quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf"
+      : "=&v"(L[0]), "=&v"(L[1]), "=&v"(R[0]), "=&v"(R[1]) : "v"(k0[0]), "v"(k1[0]), "v"(k0[1]), "v"(k1[1]), "s"(even_lanes) : "vcc", "scc");
+}
+// lane_poff: the lane's element offset inside the tile's pooled block -- ((2 wm + (g & 1)) W/2 + lr / 2) 64 + its 8 channels -- fixed for
+// the kernel; the tile's own offset is wave-uniform (scalar registers, folded into the store's base address).
+__device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)[4][2], int tl, int b, int h0, int w0, unsigned lane_poff) {
+  const uint64_t even_lanes = 0x5555555555555555ull;
+  uint32_t L[4][2], R[4][2];      // [tile row][channel pair]: left / right pixel of the window column, this lane's fragment
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 4; ++i) {
+    uint32_t k0[2], k1[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      uint32_t pa = pack_bf16(acc[i][0][2 * d], acc[i][0][2 * d + 1]);
-      uint32_t pb2 = pack_bf16(acc[i][1][2 * d], acc[i][1][2 * d + 1]);
-      asm("v_pk_max_i16 %0, %0, 0" : "+v"(pa));
-      asm("v_pk_max_i16 %0, %0, 0" : "+v"(pb2));
-      keep[i][0][d] = pa; keep[i][1][d] = pb2;
+      k0[d] = pack_bf16(acc[i][0][2 * d], acc[i][0][2 * d + 1]);
+      k1[d] = pack_bf16(acc[i][1][2 * d], acc[i][1][2 * d + 1]);
     }
-  const int H2 = p.H >> 1, W2 = p.W >> 1;
+    l0_pair_trade(k0, k1, even_lanes, L[i], R[i]);
+  }
+  const uint32_t one = 0x00010001u;
+  uint32_t pm[2][2], cb[2];
 #pragma unroll
   for (int pr = 0; pr < 2; ++pr) {
-    uint32_t lo[2], hi[2], pmax[2][2];
+    uint32_t cw[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
-      uint32_t va = keep[2 * pr][0][d], vb = keep[2 * pr][1][d];
-      asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(keep[2 * pr + 1][0][d]));
-      asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(keep[2 * pr + 1][1][d]));
-      const uint32_t na = (uint32_t)__builtin_amdgcn_mov_dpp((int)va, 0xB1, 0xf, 0xf, true);      // quad_perm [1,0,3,2]: lane ^ 1
-      const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)vb, 0xB1, 0xf, 0xf, true);
-      asm("v_pk_max_i16 %0, %0, %1" : "+v"(va) : "v"(na));
-      asm("v_pk_max_i16 %0, %0, %1" : "+v"(vb) : "v"(nb));
-      pmax[0][d] = va; pmax[1][d] = vb;
-      auto sw = __builtin_amdgcn_permlane16_swap(va, vb, false, false);
-      lo[d] = sw[0]; hi[d] = sw[1];
+      const uint32_t v0 = L[2 * pr][d], v1 = R[2 * pr][d], v2 = L[2 * pr + 1][d], v3 = R[2 * pr + 1][d];
+      uint32_t ma, mb, m;
+      asm("v_pk_max_i16 %0, %1, %2" : "=v"(ma) : "v"(v0), "v"(v1));
+      asm("v_pk_max_i16 %0, %1, %2" : "=v"(mb) : "v"(v2), "v"(v3));
+      asm("v_pk_max_i16 %0, %0, %1" : "+v"(ma) : "v"(mb));
+      asm("v_pk_max_i16 %0, %1, 0" : "=v"(m) : "v"(ma));          // ReLU (conv_c64.hip): the pooled value
+      // code = 0 where the maximum is 0, else 1 + the first window position (row-major) that holds it
+      uint32_t n0 = v0 ^ m, n1 = v1 ^ m, n2 = v2 ^ m, nz;
+      asm("v_pk_min_u16 %0, %0, %1" : "+v"(n0) : "v"(one));
+      asm("v_pk_min_u16 %0, %0, %1" : "+v"(n1) : "v"(one));
+      asm("v_pk_min_u16 %0, %0, %1" : "+v"(n2) : "v"(one));
+      asm("v_pk_min_u16 %0, %1, %2" : "=v"(nz) : "v"(m), "v"(one));
+      const uint32_t n01 = n0 & n1;
+      uint32_t t1, t2, c;
+      asm("v_pk_mad_u16 %0, %1, %2, %1" : "=v"(t1) : "v"(n0), "v"(n1));            // n0 + n0 n1
+      asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(t2) : "v"(n01), "v"(n2), "v"(t1));   // + n0 n1 n2
+      asm("v_pk_mad_u16 %0, %1, %2, %2" : "=v"(c) : "v"(t2), "v"(nz));              // (1 + ...) where the maximum is not 0
+      pm[pr][d] = m;
+      cw[d] = c;
     }
-    const int prow = (h0 >> 1) + (tl >> 7) * 2 + pr, pcol = (w0 >> 1) + ((tl & 15) >> 1);
-    const int64_t pidx = (((int64_t)b * H2 + prow) * W2 + pcol) * 64 + co0;
-    const bool st = !(tl & 1) && prow < H2 && pcol < W2;
-    if (st) *reinterpret_cast<uint4*>(p.pool + pidx) = make_uint4(lo[0], lo[1], hi[0], hi[1]);
-    uint32_t clo[2], chi[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-      uint32_t cw[2];
-#pragma unroll
-      for (int cf = 0; cf < 2; ++cf) {
-        // Only the EVEN lane of a pixel pair stores (st): the window order (this lane's pixel, its neighbour's) is the even lane's, the
-        // odd lane computes a word nobody reads.  The window maximum is the pooled value of above (non-negative bf16: signed = unsigned order).
-        const uint32_t v0 = keep[2 * pr][cf][d], v2 = keep[2 * pr + 1][cf][d];
-        const uint32_t v1 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v0, 0xB1, 0xf, 0xf, true);
-        const uint32_t v3 = (uint32_t)__builtin_amdgcn_mov_dpp((int)v2, 0xB1, 0xf, 0xf, true);
-        const uint32_t m = pmax[cf][d];
-        const uint32_t one = 0x00010001u;
-        uint32_t n0 = v0 ^ m, n1 = v1 ^ m, n2 = v2 ^ m, nz = m;
-        asm("v_pk_min_u16 %0, %0, %1" : "+v"(n0) : "v"(one));
-        asm("v_pk_min_u16 %0, %0, %1" : "+v"(n1) : "v"(one));
-        asm("v_pk_min_u16 %0, %0, %1" : "+v"(n2) : "v"(one));
-        asm("v_pk_min_u16 %0, %0, %1" : "+v"(nz) : "v"(one));
-        const uint32_t n01 = n0 & n1, n012 = n01 & n2;
-        uint32_t c = one + n0 + n01 + n012;
-        asm("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(c) : "v"(nz));
-        cw[cf] = c;
-      }
-      auto sw = __builtin_amdgcn_permlane16_swap(cw[0], cw[1], false, false);
-      clo[d] = sw[0]; chi[d] = sw[1];
-    }
-    if (st) {
-      const uint32_t b0 = __builtin_amdgcn_perm(clo[1], clo[0], 0x06040200u), b1 = __builtin_amdgcn_perm(chi[1], chi[0], 0x06040200u);
-      *reinterpret_cast<uint2*>(p.code + pidx) = make_uint2(b0, b1);
-    }
+    cb[pr] = __builtin_amdgcn_perm(cw[1], cw[0], 0x06040200u);      // 4 selection bytes of channels 4 g .. 4 g + 3
+  }
+  // lane rows g, g ^ 1 trade pooled rows: the even row keeps pooled row 0 of 8 consecutive channels, the odd row pooled row 1
+  const auto s0 = __builtin_amdgcn_permlane16_swap(pm[0][0], pm[1][0], false, false);
+  const auto s1 = __builtin_amdgcn_permlane16_swap(pm[0][1], pm[1][1], false, false);
+  const auto sc = __builtin_amdgcn_permlane16_swap(cb[0], cb[1], false, false);
+  const int H2 = p.H >> 1, W2 = p.W >> 1;
+  const int64_t tile_off = (((int64_t)b * H2 + (h0 >> 1)) * W2 + (w0 >> 1)) * 64;
+  bool st = true;
+  if (h0 + 8 > 2 * H2 || w0 + 16 > 2 * W2) {       // (wave-uniform: a tile on the lower / right edge)
+    const int g = (tl >> 4) & 3;
+    st = (h0 >> 1) + (tl >> 7) * 2 + (g & 1) < H2 && (w0 >> 1) + ((tl & 15) >> 1) < W2;
+  }
+  if (st) {
+    *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(p.pool + tile_off) + lane_poff * 2u) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+    *reinterpret_cast<uint2*>(p.code + tile_off + lane_poff) = make_uint2(sc[0], sc[1]);
   }
 }
 
@@ -275,29 +294,33 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
   org[1] = org[0]; walk.advance(org[1]);
   org[2] = org[1]; walk.advance(org[2]);
 
-  const int co0 = wn * 32 + (g & 1) * 16 + (g & 2) * 4;
+  const unsigned lane_poff = (unsigned)(((wm * 2 + (g & 1)) * (p.W >> 1) + (lr >> 1)) * 64 + wn * 32 + (lr & 1) * 16 + (g & 2) * 4);
 
+  // the wave's three pixel fragments: frame-patch and halo-patch offsets of the lane, fixed for the kernel (round 6: held in registers --
+  // recomputing them per tile was 60 of the generation's 180 vector instructions)
+  int g_addr[3], w_addr[3], g_prc[3];
+#pragma unroll
+  for (int fi = 0; fi < 3; ++fi) {
+    L0GenLane gl;
+    gl.init(wave * 3 + fi, lr, g);
+    g_addr[fi] = gl.gaddr;
+    w_addr[fi] = (gl.prc & 0x10000) ? gl.waddr : -1;      // -1: a lane of the last fragment past the patch (dump area)
+    g_prc[fi] = gl.prc;
+  }
   auto generate = [&](int yb, int sb, const L0Org& o) __attribute__((always_inline)) {
     unsigned char* yp = smem + yb * L0_PB;
     const unsigned char* sp = smem + S_OFF + sb * L0_SS;
     const bool inside = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 9 <= p.H && o.w0 + 17 <= p.W;
-    int lrl = lr;
-    asm volatile("" : "+v"(lrl));       // (recomputed per tile on purpose: see L0GenLane)
     u32x4_t bop[3];
-    uint32_t vm[3];
     int wa[3];
 #pragma unroll
     for (int fi = 0; fi < 3; ++fi) {
-      L0GenLane gl;
-      gl.init(wave * 3 + fi, lrl, g);
-      bop[fi] = l0_frame_operand(sp + gl.gaddr);
-      vm[fi] = inside ? 0xffffffffu : l0_halo_valid(p, o, gl.prc);
-      wa[fi] = (gl.prc & 0x10000) ? gl.waddr : (S_OFF + 1024 - yb * L0_PB);      // dump area: the unused tail of frame buffer 0
+      bop[fi] = l0_frame_operand(sp + g_addr[fi]);
+      wa[fi] = w_addr[fi] >= 0 ? w_addr[fi] : (S_OFF + 1024 - yb * L0_PB);      // dump area: the unused tail of frame buffer 0
     }
     // two halves of two channel fragments: every LDS read of a half first, then its 6 + 6 MFMAs back to back (six independent
     // accumulator chains: the second MFMA of a chain issues 96 cycles after the first), then the six convert / store tails
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    auto half = [&](int h, auto masked) __attribute__((always_inline)) {
       u32x4_t wh[2], wl[2];
       f32x4_t acc6[2][3];
 #pragma unroll
@@ -324,7 +347,17 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int fi = 0; fi < 3; ++fi) l0_gen_store(yp, wa[fi], acc6[c][fi], 2 * h + c, vm[fi]);
+        for (int fi = 0; fi < 3; ++fi) {
+          if constexpr (decltype(masked)::value) l0_gen_store(yp, wa[fi], acc6[c][fi], 2 * h + c, l0_halo_valid(p, o, g_prc[fi]));
+          else l0_gen_store_inside(yp, wa[fi], acc6[c][fi], 2 * h + c);
+        }
+    };
+    if (inside) {       // (wave-uniform) no halo pixel of the tile lies outside the image: nothing to mask
+      half(0, std::false_type{});
+      half(1, std::false_type{});
+    } else {
+      half(0, std::true_type{});
+      half(1, std::true_type{});
     }
   };
 
@@ -366,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
     L0_FENCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // frame patch n + 2 (issued a whole tile ago) -- and last tile's stores
     if (n + 2 < cnt) l0_split_frames(smem + S_OFF + (n & 1) * L0_SS, tl);
-    l0_pool_epilogue(p, acc, tl, org[0].b, org[0].h0, org[0].w0, ((tl >> 6) & 1) * 32 + ((tl >> 4) & 1) * 16 + ((tl >> 4) & 2) * 4);
+    l0_pool_epilogue(p, acc, tl, org[0].b, org[0].h0, org[0].w0, lane_poff);
     org[0] = org[1]; org[1] = org[2];
     walk.advance(org[2]);
     const unsigned flip = (n & 1) ? (unsigned)(-L0_PB) : (unsigned)L0_PB;
@@ -577,6 +610,21 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
     float bj[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) bj[j] = *reinterpret_cast<const float*>(smem + B0_OFF + (wn * 32 + j * 16 + lr) * 4);
+    // (a tile on the lower / right edge -- wave-uniform, 1 in 10 at the benchmark shape -- first clears the gradient of its pixels outside the
+    // image; the mask itself is then conv.0's sign alone: one compare and one select per element.  Folded into ONE condition the row /
+    // column tests cost the compiler six vector instructions per element, round 6.)
+    if (!whole) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool rowok = wm * 4 + i < p.H - h0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rowok && 4 * g + r < p.W - w0;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j][r] = ok ? acc[i][j][r] : 0.f;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const u32x4_t am = l0_frame_operand(sp + mbase + i * 80);
@@ -584,7 +632,6 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
                      d2 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 8), d3 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 12);
       const uint2 fhi = make_uint2(__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u));
       const uint2 flo = make_uint2(__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u));
-      const bool rowok = whole || (wm * 4 + i < p.H - h0);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // (the conv.0 operands are re-read per use: 16 registers held across the epilogue would not fit beside the 144 of the weights)
@@ -597,10 +644,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
         }
         float dy[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const bool ok = y[r] > 0.f && rowok && (whole || 4 * g + r < p.W - w0);
-          dy[r] = ok ? acc[i][j][r] : 0.f;
-        }
+        for (int r = 0; r < 4; ++r) dy[r] = y[r] > 0.f ? acc[i][j][r] : 0.f;
         const uint2 bd = make_uint2(pack_bf16(dy[0], dy[1]), pack_bf16(dy[2], dy[3]));
         dw0[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(l0_s16x4_t, fhi), __builtin_bit_cast(l0_s16x4_t, bd), dw0[j], 0, 0, 0);
         dw0[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(l0_s16x4_t, flo), __builtin_bit_cast(l0_s16x4_t, bd), dw0[j], 0, 0, 0);
@@ -657,7 +701,7 @@ __device__ __forceinline__ bf16x8_t l0_read_tr(const unsigned char* lo, const un
 
 template <bool WSPLIT>
 __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
-  constexpr int S_OFF = 2 * L0_STAGE, B0_OFF = S_OFF + 2 * 1024, DUMP_OFF = B0_OFF + 256;      // 128-byte dump area behind the bias
+  constexpr int S_OFF = 2 * L0_STAGE, B0_OFF = S_OFF + 2 * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, g = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -725,38 +769,56 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
     *reinterpret_cast<u32x4_t*>(dp + a0 + 16 * 128) = o3;
     *reinterpret_cast<u32x4_t*>(dp + a1 + 16 * 128) = o4;
   };
+  // conv.0 for the 10 x 18 halo patch, this wave's 16 channels.  Pixel fragments by PATCH ROW (round 6): fragment f < 10 = columns 0 .. 15 of
+  // row f, so its frame-patch and halo-patch addresses are one lane constant each plus a compile-time offset (instruction immediates);
+  // fragments 10 / 11 = columns 16, 17 of rows 0 .. 7 / 8, 9 (lane lr <-> row lr / 2, column 16 + (lr & 1)); the 12 lanes of fragment 11
+  // that have no pixel repeat fragment 10's (same value to the same place).  The linear numbering it replaces (pixel = 16 f + lr) cost two
+  // divisions by 18 per fragment and lane: ~300 of the ~530 vector instructions of a wave and patch.
+  const int gq = g < 3 ? g : 2;
+  const int swz = ((g >> 1) ^ (wave << 1)) << 4, sub8 = (g & 1) * 8;
+  const int ga1 = (gq * 20 + lr) * 4, wa1 = lr * 128 + (swz ^ ((lr & 7) << 4)) + sub8;
+  const int pr2 = lr >> 1, pc2 = 16 + (lr & 1);
+  const int ga2 = ((pr2 + gq) * 20 + pc2) * 4, wa2 = (pr2 * 18 + pc2) * 128 + (swz ^ ((pc2 & 7) << 4)) + sub8;
+  const int ga3 = lr < 4 ? ga2 + 8 * 80 : ga2, wa3 = lr < 4 ? wa2 + 8 * 18 * 128 : wa2, pr3 = lr < 4 ? pr2 + 8 : pr2;
   auto generate = [&](int st, int sb, const L0Org& o) __attribute__((always_inline)) {
     unsigned char* xp = smem + st * L0_STAGE;
     const unsigned char* sp = smem + S_OFF + sb * 1024;
     const bool inside = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 9 <= p.H && o.w0 + 17 <= p.W;
-    int lrl = lr;
-    asm volatile("" : "+v"(lrl));
-    // software pipeline over groups of 3 pixel fragments: the 6 MFMAs of group k issued, then group k - 1 converted / stored (its
-    // addressing recomputed there: a dozen vector instructions against 6 registers held across the MFMAs)
-    f32x4_t acc3[2][3];
-    auto finish = [&](int k) __attribute__((always_inline)) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        const int f = k * 3 + u;
-        L0GenLane gl;
-        gl.init(f, lrl, g);
-        const uint32_t vm = inside ? 0xffffffffu : l0_halo_valid(p, o, gl.prc);
-        const int wa = (f < 11 || (gl.prc & 0x10000)) ? gl.waddr : (DUMP_OFF - st * L0_STAGE);
-        l0_gen_store(xp, wa, acc3[k & 1][u], wave, vm);
+    auto frag_ga = [&](int f) __attribute__((always_inline)) { return f < 10 ? ga1 + f * 80 : (f == 10 ? ga2 : ga3); };
+    auto frag_wa = [&](int f) __attribute__((always_inline)) { return f < 10 ? wa1 + f * (18 * 128) : (f == 10 ? wa2 : wa3); };
+    // software pipeline over groups of 3 pixel fragments: the 6 MFMAs of group k issued, then group k - 1 converted / stored
+    auto run = [&](auto masked) __attribute__((always_inline)) {
+      uint32_t colm = 0xffffffffu, colm2 = 0xffffffffu;
+      if constexpr (decltype(masked)::value) {       // halo pixels outside the image are conv.2's zero padding
+        colm = (unsigned)(o.w0 + lr - 1) < (unsigned)p.W ? 0xffffffffu : 0u;
+        colm2 = (unsigned)(o.w0 + pc2 - 1) < (unsigned)p.W ? 0xffffffffu : 0u;
       }
+      f32x4_t acc3[2][3];
+      auto finish = [&](int k) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int f = k * 3 + u;
+          if constexpr (decltype(masked)::value) {
+            uint32_t vm;
+            if (f < 10) vm = (unsigned)(o.h0 + f - 1) < (unsigned)p.H ? colm : 0u;
+            else vm = (unsigned)(o.h0 + (f == 10 ? pr2 : pr3) - 1) < (unsigned)p.H ? colm2 : 0u;
+            l0_gen_store(xp, frag_wa(f), acc3[k & 1][u], 0, vm);
+          } else {
+            l0_gen_store_inside(xp, frag_wa(f), acc3[k & 1][u], 0);
+          }
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) acc3[k & 1][u] = l0_gen_mfma<WSPLIT>(l0_frame_operand(sp + frag_ga(k * 3 + u)), whi, wlo, bias0);
+        if (k > 0) finish(k - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      finish(3);
     };
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-        L0GenLane gl;
-        gl.init(k * 3 + u, lrl, g);
-        acc3[k & 1][u] = l0_gen_mfma<WSPLIT>(l0_frame_operand(sp + gl.gaddr), whi, wlo, bias0);
-      }
-      if (k > 0) finish(k - 1);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    finish(3);
+    if (inside) run(std::false_type{});       // (wave-uniform)
+    else run(std::true_type{});
   };
 
   // ---- per-lane operand offsets inside a stage (conv_wgrad_dma.hip)
@@ -779,8 +841,11 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.db != nullptr && wave == 0;
+  // db2: every wave sums ONE channel fragment of the dY operands it reads anyway (fragment = wave; v_dot2c_f32_bf16 against (1, 1): one
+  // instruction per two values).  Round 5 had wave 0 sum all four with shift / mask / add: 192 vector instructions on one wave of a
+  // barrier-synchronised four.
+  float bsum = 0.f;
+  const bool do_bias = p.db != nullptr;
 
   // ---- prologue: frame patches 0 and 1, stage 0 complete
   if (np > 0) { l0_stage_frames(p, org[0], smem_base + S_OFF, tid, wave_u); load_pooled(org[0]); }
@@ -808,11 +873,19 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = l0_read_tr(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
       if (do_bias) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const u32x4_t u = __builtin_bit_cast(u32x4_t, a[i]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
+        auto sum8 = [&](const bf16x8_t& v) __attribute__((always_inline)) {
+          const u32x4_t u = __builtin_bit_cast(u32x4_t, v);
+          // (one asm block: the accumulating chain is hazard-free, but a DOT result needs 3 wait states before any OTHER vector instruction
+          // reads it, and the compiler cannot see the opcode inside an asm -- hence the trailing s_nop.  The builtin picked one dword of
+          // `u` four times, hipcc 7.0.)
+          asm("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5\n\ts_nop 2"
+              : "+v"(bsum) : "s"(0x3F803F80u), "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
+        };
+        switch (wave_u) {       // (wave-uniform: scalar branches)
+          case 0: sum8(a[0]); break;
+          case 1: sum8(a[1]); break;
+          case 2: sum8(a[2]); break;
+          default: sum8(a[3]); break;
         }
       }
 #pragma unroll
@@ -847,13 +920,10 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[(t * 64 + i * 16 + g * 4 + r) * 64 + wave * 16 + lr] = acc[t][i][r];
   if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (g == 0) atomicAdd(p.db + i * 16 + lr, v);
-    }
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) atomicAdd(p.db + wave * 16 + lr, v);
   }
 }
 
@@ -903,7 +973,7 @@ extern "C" int asr_vgg_level0_fwd(const float* src, const float* w0, const float
   {
     // The caller decides HERE whether the level runs on these kernels (EUNSUPPORTED -> the stored-activation launch chain): the two
     // backward kernels need more LDS than this one, so their grants are part of the decision -- a backward pass cannot fall back.
-    const size_t lds_d = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16, lds_w = 2 * L0_STAGE + 2 * 1024 + 256 + 128;
+    const size_t lds_d = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16, lds_w = 2 * L0_STAGE + 2 * 1024 + 256;
     const int r0 = split ? l0_grant<vgg_level0_fwd_kernel<true>>(lds) : l0_grant<vgg_level0_fwd_kernel<false>>(lds);
     const int r1 = split ? l0_grant<vgg_level0_dgrad_kernel<true>>(lds_d) : l0_grant<vgg_level0_dgrad_kernel<false>>(lds_d);
     const int r2 = split ? l0_grant<vgg_level0_wgrad_kernel<true>>(lds_w) : l0_grant<vgg_level0_wgrad_kernel<false>>(lds_w);
@@ -964,7 +1034,7 @@ extern "C" int asr_vgg_level0_wgrad(const float* src, const float* w0, const flo
   int wgx;
   l0_wgrad_grid(B, H, W, &wgx, &a.patches_per_wg);
   if (workspace_floats < (int64_t)wgx * 9 * 64 * 64) return ASR_EINVAL;
-  const size_t lds = 2 * L0_STAGE + 2 * 1024 + 256 + 128;
+  const size_t lds = 2 * L0_STAGE + 2 * 1024 + 256;
   const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
   const int rc = split ? l0_grant<vgg_level0_wgrad_kernel<true>>(lds) : l0_grant<vgg_level0_wgrad_kernel<false>>(lds);
   if (rc != ASR_OK) return rc;
