@@ -215,10 +215,14 @@ __global__ __launch_bounds__(TW * TH * 2, 2) void conv3x3_c64_kernel(C64Args p) 
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n % NBUF) * PBYTES);
-    u32x4_t a[2][4];
     if (!C64_ABL(p, 2)) {
-      c64_issue<0, PW, CB>(a[0], pbd);
-      c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);
+      if constexpr (CB == 1) {        // one column block per tile row: the row-ordered form (half the operand reads; conv_c64_core.h)
+        c64_rows<PW>(acc, wB, pbd, bq);
+      } else {
+        u32x4_t a[2][4];
+        c64_issue<0, PW, CB>(a[0], pbd);
+        c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);
+      }
     } else {
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bq[0]), "+v"(bq[1]));
 #pragma unroll

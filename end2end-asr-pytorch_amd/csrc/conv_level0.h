@@ -18,4 +18,6 @@ struct L0Args {
   float* db;            // weight-gradient kernel: (64) bias gradient of conv.2, accumulated with atomics (as conv3x3_wgrad_dma does)
   int B, H, W;
   int tiles_h, tiles_w, ntiles, patches_per_wg;   // filled by the launchers
+  int wsplit;           // 1: conv.0's weights as whi + wlo (default); 0: bf16-rounded weights alone (tuning L0_WSPLIT)
+  long long* dbg;       // tuning only (-DL0_TIMING builds): per-section clock totals of workgroup 0 of the forward kernel
 };

@@ -15,16 +15,20 @@
 //   wgrad    (vgg_level0_wgrad_kernel)  src -> [conv.0 + ReLU into the LDS patch], pooled gradient + codes -> [expanded dY tile]
 //                                           -> the 64 x 64 x 9 weight-gradient block of conv_wgrad_dma.hip
 //
-// conv.0 as an MFMA: per output pixel the contraction index is (tap row ky = lane group, slot): slots {hi(x[ky][0..2]), 0, lo(x[ky][0..2]), 0}
-// of the fp32 frame value split x = hi + lo into two bf16 (hi = truncation, lo = round(x - hi): 16 mantissa bits), against the weight
-// rounded to bf16 twice (w = whi + wlo: the second MFMA adds hi(x) * wlo), bias as the accumulator's initial value: products exact
-// to 2^-16, fp32 accumulation -- the fp32 vector-ALU kernel it replaces (conv1_fwd) agrees to rounding of the bf16 result.
+// conv.0 as ONE MFMA per 16 pixels x 16 channels (K = 32 = lane group x 8 slots): the fp32 frame value is split x = hi + lo into two bf16
+// (hi = truncation, lo = round(x - hi): 16 mantissa bits), the weight is rounded to bf16 twice (w = whi + wlo), and the 27 products
+// hi.whi + lo.whi + hi.wlo of a pixel's 3 x 3 window sit in the 32 slots -- lane group ky < 3 holds tap row ky as
+// {hi0, hi1, hi2, hi0 | lo0, lo1, lo2, hi1} against {whi0, whi1, whi2, wlo0 | whi0, whi1, whi2, wlo1}, lane group 3 holds the third
+// column {hi2 of rows 0, 1, 2} against {wlo2 of rows 0, 1, 2} (round 6; rounds 4 - 5 spent a second MFMA on the wlo terms and left
+// group 3 empty).  Bias = the accumulator's initial value: products exact to 2^-16, fp32 accumulation -- the fp32 vector-ALU kernel it
+// replaces (conv1_fwd) agrees to rounding of the bf16 result.  L0_WSPLIT = 0 (tuning) drops the wlo terms.
 // The frame patch (12 x 20 values per 8 x 16 tile) arrives by 4-byte LDS-DMA and is split in place by the thread that fetched it.
 #include "common.h"
 #include "conv_c64_core.h"
 #include "conv_level0.h"
 #include "conv_wgrad_dma.h"
 
+#include <cstdio>
 #include <type_traits>
 #include <utility>
 
@@ -34,11 +38,16 @@ namespace {
 
 constexpr int L0_PB = 180 * 128;        // halo patch of 64 bf16 channels: 10 x 18 pixels, 16-B chunk c of the pixel in patch column x in slot c ^ (x & 7)
 constexpr int L0_SS = 1536;             // frame patch buffer: 12 x 20 packed (hi << 16 | lo) dwords (960 B, padded to 1024), 256 B of (1.0 | 0), 256 B of zeros
-constexpr int L0_WM = 8192;             // conv.0 weights as MFMA operands: [channel fragment 4][whi, wlo][64 lanes][16 B]
+constexpr int L0_WM = 4096;             // conv.0 weights as MFMA operands: [channel fragment 4][64 lanes][16 B]
 
 typedef __attribute__((ext_vector_type(4))) short l0_s16x4_t;
 
 #define L0_FENCE() asm volatile("" ::: "memory")
+#ifdef L0_TIMING       // tuning builds only (ASR_HIPCC_EXTRA=-DL0_TIMING): s_memtime stamps at the forward kernel's section boundaries
+#define L0_STAMP(K) { const long long now_ = clock64(); tsec[K] += now_ - tlast; tlast = now_; }
+#else
+#define L0_STAMP(K)
+#endif
 
 // LDS-DMA issued by hand (M0 saved / restored; the compiler neither counts these loads nor drains them before its own LDS reads)
 __device__ __forceinline__ void l0_dma4(unsigned lds_wave_base, const void* src) {
@@ -58,33 +67,37 @@ __device__ __forceinline__ uint32_t l0_split(float x) {
   return hb | (uint32_t)f32_to_bf16(x - __uint_as_float(hb));
 }
 
-// One conv.0 operand of a pixel: the lane's tap row (3 packed frame values at p, p + 4, p + 8) -> slots {hi0, hi1, hi2, 0, lo0, lo1, lo2, 0}
-__device__ __forceinline__ u32x4_t l0_frame_operand(const unsigned char* p) {
-  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(p), d1 = *reinterpret_cast<const uint32_t*>(p + 4),
-                 d2 = *reinterpret_cast<const uint32_t*>(p + 8);
+// One conv.0 operand of a pixel: three packed frame values at p, p + stride, p + 2 stride -- lane groups 0 .. 2: the tap row's three
+// columns (stride 4), lane group 3: the third column of the three tap rows (stride 80 = one frame-patch row) -- as the slots
+// {hi0, hi1, hi2, hi0 | lo0, lo1, lo2, hi1}
+__device__ __forceinline__ u32x4_t l0_frame_operand(const unsigned char* p, int stride) {
+  const uint32_t d0 = *reinterpret_cast<const uint32_t*>(p), d1 = *reinterpret_cast<const uint32_t*>(p + stride),
+                 d2 = *reinterpret_cast<const uint32_t*>(p + 2 * stride);
   u32x4_t r;
   r[0] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
-  r[1] = __builtin_amdgcn_perm(0u, d2, 0x0C0C0302u);
+  r[1] = __builtin_amdgcn_perm(d0, d2, 0x07060302u);
   r[2] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
-  r[3] = __builtin_amdgcn_perm(0u, d2, 0x0C0C0100u);
+  r[3] = __builtin_amdgcn_perm(d1, d2, 0x07060100u);
   return r;
 }
+// the lane's part of a frame-patch address: tap row g of the pixel for g < 3, row 0 / third column for lane group 3; and its stride
+__device__ __forceinline__ int l0_frame_lane_off(int g) { return g < 3 ? g * 80 : 8; }
+__device__ __forceinline__ int l0_frame_lane_stride(int g) { return g < 3 ? 4 : 80; }
 
-// conv.0 weights of output channel `co`, tap row g (0..2; lane group 3 contributes nothing) as the matching operand pair
-__device__ __forceinline__ void l0_weight_operands(const float* w0, int co, int g, u32x4_t& hi, u32x4_t& lo) {
-  hi = u32x4_t{0u, 0u, 0u, 0u};
-  lo = hi;
-  if (g < 3) {
-    uint32_t h[3], l[3];
+// conv.0 weights of output channel `co` as the matching operand of lane group g
+__device__ __forceinline__ u32x4_t l0_weight_operand(const float* w0, int co, int g, bool split) {
+  uint32_t h[9], l[9];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float w = w0[co * 9 + g * 3 + j];
-      h[j] = f32_to_bf16(w);
-      l[j] = f32_to_bf16(w - bf16_to_f32((bf16_t)h[j]));
-    }
-    hi[0] = h[0] | (h[1] << 16); hi[1] = h[2]; hi[2] = hi[0]; hi[3] = hi[1];
-    lo[0] = l[0] | (l[1] << 16); lo[1] = l[2];
+  for (int t = 0; t < 9; ++t) {
+    const float w = w0[co * 9 + t];
+    h[t] = f32_to_bf16(w);
+    l[t] = split ? (uint32_t)f32_to_bf16(w - bf16_to_f32((bf16_t)h[t])) : 0u;
   }
+  u32x4_t r = u32x4_t{l[2] | (l[5] << 16), l[8], 0u, 0u};
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (g == q) r = u32x4_t{h[3 * q] | (h[3 * q + 1] << 16), h[3 * q + 2] | (l[3 * q] << 16), h[3 * q] | (h[3 * q + 1] << 16), h[3 * q + 2] | (l[3 * q + 1] << 16)};
+  return r;
 }
 
 // tile walk of the persistent kernels: origins advance by a fixed (images, tile rows, tile columns) step with carries (conv_c64.hip)
@@ -140,7 +153,7 @@ struct L0GenLane {          // per (lane, fragment) addressing, recomputed per t
   __device__ __forceinline__ void init(int f, int lr, int g) {
     const int hp = f * 16 + lr, hpc = hp < 180 ? hp : 179;
     const int pr = (hpc * 3641) >> 16, pc = hpc - pr * 18;          // hpc / 18 for hpc < 192
-    gaddr = (hpc + 2 * pr + 20 * (g < 3 ? g : 2)) * 4;              // ((pr + tap row) * 20 + pc) * 4
+    gaddr = (hpc + 2 * pr) * 4 + l0_frame_lane_off(g);              // (pr * 20 + pc) * 4 + the lane group's tap row / column
     waddr = hpc * 128 + ((((g >> 1) ^ (pc & 7))) << 4) + (g & 1) * 8;
     prc = pr | (pc << 8) | ((hp < 180 ? 1 : 0) << 16);
   }
@@ -149,11 +162,8 @@ struct L0GenLane {          // per (lane, fragment) addressing, recomputed per t
 // One unit = (16 halo pixels) x (16 channels), in two stages so that a caller can run the MFMAs of several units back to back and
 // convert / store behind them (a unit alone is a chain MFMA -> MFMA -> convert -> ReLU -> store of ~190 cycles; twelve of them in
 // sequence cost as much as the tile's 144 main MFMAs -- in-kernel section timing, profiles/r04_level0_structure_ab.txt).
-template <bool WSPLIT>
-__device__ __forceinline__ f32x4_t l0_gen_mfma(const u32x4_t& bop, const u32x4_t& whi, const u32x4_t& wlo, const f32x4_t& bias) {
-  f32x4_t a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, whi), __builtin_bit_cast(bf16x8_t, bop), bias, 0, 0, 0);
-  if (WSPLIT) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wlo), __builtin_bit_cast(bf16x8_t, bop), a, 0, 0, 0);
-  return a;
+__device__ __forceinline__ f32x4_t l0_gen_mfma(const u32x4_t& bop, const u32x4_t& w, const f32x4_t& bias) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, bop), bias, 0, 0, 0);
 }
 // `wa`: the lane's output offset for channel fragment 0 -- L0GenLane::waddr, or the offset of a 128-byte dump area for the lanes of the
 // last fragment that lie past the patch (an address select instead of a branch keeps the units in ONE basic block)
@@ -255,7 +265,6 @@ __device__ __forceinline__ void l0_pool_epilogue(const L0Args& p, f32x4_t (&acc)
 }
 
 // ================================================================================================ forward
-template <bool WSPLIT>
 __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
   constexpr int PW = 18, CB = 1;
   constexpr int S_OFF = 2 * L0_PB, WM_OFF = S_OFF + 2 * L0_SS, B0_OFF = WM_OFF + L0_WM, B2_OFF = B0_OFF + 256;
@@ -278,10 +287,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
       for (int j = 0; j < 2; ++j)
         wB[tap][ms][j] = *reinterpret_cast<const u32x4_t*>(p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * 64 + ms * 32 + g * 8);
   {   // conv.0 operands (wave = channel fragment) and both biases into LDS
-    u32x4_t hi, lo;
-    l0_weight_operands(p.w0, wave * 16 + lr, g, hi, lo);
-    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 0) * 64 + lane) * 16) = hi;
-    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 1) * 64 + lane) * 16) = lo;
+    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + (wave * 64 + lane) * 16) = l0_weight_operand(p.w0, wave * 16 + lr, g, p.wsplit != 0);
     if (tid < 64) {
       reinterpret_cast<float*>(smem + B0_OFF)[tid] = p.b0 ? p.b0[tid] : 0.f;
       reinterpret_cast<float*>(smem + B2_OFF)[tid] = p.b2 ? p.b2[tid] : 0.f;
@@ -299,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
   // the wave's three pixel fragments: frame-patch and halo-patch offsets of the lane, fixed for the kernel (round 6: held in registers --
   // recomputing them per tile was 60 of the generation's 180 vector instructions)
   int g_addr[3], w_addr[3], g_prc[3];
+  const int gstride = l0_frame_lane_stride(g);
 #pragma unroll
   for (int fi = 0; fi < 3; ++fi) {
     L0GenLane gl;
@@ -315,34 +322,24 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
     int wa[3];
 #pragma unroll
     for (int fi = 0; fi < 3; ++fi) {
-      bop[fi] = l0_frame_operand(sp + g_addr[fi]);
+      bop[fi] = l0_frame_operand(sp + g_addr[fi], gstride);
       wa[fi] = w_addr[fi] >= 0 ? w_addr[fi] : (S_OFF + 1024 - yb * L0_PB);      // dump area: the unused tail of frame buffer 0
     }
-    // two halves of two channel fragments: every LDS read of a half first, then its 6 + 6 MFMAs back to back (six independent
-    // accumulator chains: the second MFMA of a chain issues 96 cycles after the first), then the six convert / store tails
+    // two halves of two channel fragments: every LDS read of a half first, then its 6 MFMAs back to back, then the six convert / store tails
     auto half = [&](int h, auto masked) __attribute__((always_inline)) {
-      u32x4_t wh[2], wl[2];
+      u32x4_t wh[2];
       f32x4_t acc6[2][3];
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         const int cf = 2 * h + c;
-        wh[c] = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + ((cf * 2 + 0) * 64 + lane) * 16);
-        wl[c] = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + ((cf * 2 + 1) * 64 + lane) * 16);
+        wh[c] = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + (cf * 64 + lane) * 16);
         acc6[c][0] = acc6[c][1] = acc6[c][2] = *reinterpret_cast<const f32x4_t*>(smem + B0_OFF + (cf * 16 + 4 * g) * 4);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 2; ++c)
 #pragma unroll
-        for (int fi = 0; fi < 3; ++fi)
-          acc6[c][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wh[c]), __builtin_bit_cast(bf16x8_t, bop[fi]), acc6[c][fi], 0, 0, 0);
-      if (WSPLIT) {
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int fi = 0; fi < 3; ++fi)
-            acc6[c][fi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wl[c]), __builtin_bit_cast(bf16x8_t, bop[fi]), acc6[c][fi], 0, 0, 0);
-      }
+        for (int fi = 0; fi < 3; ++fi) acc6[c][fi] = l0_gen_mfma(bop[fi], wh[c], acc6[c][fi]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 2; ++c)
@@ -377,29 +374,36 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
       pbd[dx][ms] = smem_base + (unsigned)((((wm * 4) / CB) * PW + ((wm * 4) % CB) * 16 + lr) * 128) +
                     (unsigned)(((ms * 4 + g) ^ ((lr + dx) & 7)) << 4);
 
+#ifdef L0_TIMING
+  long long tsec[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
   for (int n = 0; n < cnt; ++n) {
+    L0_STAMP(5)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's patch / frame-split writes are in LDS
     __builtin_amdgcn_s_barrier();       // patch n complete, frame patch n + 1 split; everybody is done with tile n - 1
     L0_FENCE();
+    L0_STAMP(0)
     int tl = tid;
     asm volatile("" : "+v"(tl));
     if (n + 2 < cnt) l0_stage_frames(p, org[2], smem_base + S_OFF + (unsigned)((n & 1) * L0_SS), tl, wave_u);
     if (n + 1 < cnt) generate((n + 1) & 1, (n + 1) & 1, org[1]);
     L0_FENCE();
+    L0_STAMP(1)
 
     u32x4_t bq[2];
     const unsigned bias_addr = smem_base + (unsigned)(B2_OFF + (((tl >> 6) & 1) * 32 + 4 * ((tl >> 4) & 3)) * 4);
     lds_read16(bq[0], bias_addr);
     lds_read16(bq[1], bias_addr + 64);
     f32x4_t acc[4][2];
-    u32x4_t a[2][4];
-    c64_issue<0, PW, CB>(a[0], pbd);
-    c64_steps<PW, CB>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);
+    c64_rows<PW>(acc, wB, pbd, bq);
 
     L0_FENCE();
+    L0_STAMP(2)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // frame patch n + 2 (issued a whole tile ago) -- and last tile's stores
+    L0_STAMP(3)
     if (n + 2 < cnt) l0_split_frames(smem + S_OFF + (n & 1) * L0_SS, tl);
     l0_pool_epilogue(p, acc, tl, org[0].b, org[0].h0, org[0].w0, lane_poff);
+    L0_STAMP(4)
     org[0] = org[1]; org[1] = org[2];
     walk.advance(org[2]);
     const unsigned flip = (n & 1) ? (unsigned)(-L0_PB) : (unsigned)L0_PB;
@@ -408,6 +412,12 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_fwd_kernel(L0Args p) {
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] += flip;
   }
+#ifdef L0_TIMING
+  if (p.dbg && blockIdx.x == 0 && lane == 0) {
+    for (int k = 0; k < 6; ++k) p.dbg[wave * 8 + k] = tsec[k];
+    p.dbg[wave * 8 + 7] = cnt;
+  }
+#endif
 }
 
 // ================================================================================================ data gradient + dW0 / db0
@@ -461,7 +471,6 @@ struct L0CodeMasks {
   }
 };
 
-template <bool WSPLIT>
 __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
   constexpr int PW = 18, CB = 1;
   constexpr int PST_OFF = 2 * L0_PB, S_OFF = PST_OFF + 2 * L0_PST, WM_OFF = S_OFF + 2 * L0_SS, B0_OFF = WM_OFF + L0_WM, DUMP_OFF = B0_OFF + 256;
@@ -484,10 +493,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
       for (int j = 0; j < 2; ++j)
         wB[tap][ms][j] = *reinterpret_cast<const u32x4_t*>(p.wk + ((int64_t)(wn * 32 + j * 16 + lr) * 9 + tap) * 64 + ms * 32 + g * 8);
   {
-    u32x4_t hi, lo;
-    l0_weight_operands(p.w0, wave * 16 + lr, g, hi, lo);
-    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 0) * 64 + lane) * 16) = hi;
-    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + ((wave * 2 + 1) * 64 + lane) * 16) = lo;
+    *reinterpret_cast<u32x4_t*>(smem + WM_OFF + (wave * 64 + lane) * 16) = l0_weight_operand(p.w0, wave * 16 + lr, g, p.wsplit != 0);
     if (tid < 64) {
       reinterpret_cast<float*>(smem + B0_OFF)[tid] = p.b0 ? p.b0[tid] : 0.f;
 #pragma unroll
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
                      (unsigned)(((ms * 4 + g) ^ ((lr + dx) & 7)) << 4);
   // epilogue addressing (frame patch, packed dwords): conv.0 recomputed for the tile pixels of this wave (pixel column lr, tap row g),
   // and the frame values under every tap for 4 consecutive pixels 4 g .. 4 g + 3 (tap = lr; 9 = the row of ones, above = zeros)
-  const int mbase = ((wm * 4 + 1 + (g < 3 ? g : 2)) * 20 + lr + 1) * 4;
+  const int mbase = ((wm * 4 + 1) * 20 + lr + 1) * 4 + l0_frame_lane_off(g), mstride = l0_frame_lane_stride(g);
   const int tbase = lr < 9 ? ((wm * 4 + 1 + lr / 3) * 20 + 4 * g + 1 + lr % 3) * 4 : (lr == 9 ? 1024 : 1280);
   f32x4_t dw0[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};      // [tap rows 4 g + r][channel lr of fragment j]
 
@@ -595,9 +601,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int ms = 0; ms < 2; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n & 1) * L0_PB);
-    u32x4_t a[2][4];
-    c64_issue<0, PW, CB>(a[0], pbd);
-    c64_steps<PW, CB, true>(std::make_integer_sequence<int, 18>{}, acc, a, wB, pbd, bq);   // acc[i][j]: rows = pixels 4 g + r of tile row 4 wm + i, column = channel
+    c64_rows<PW, true>(acc, wB, pbd, bq);   // acc[i][j]: rows = pixels 4 g + r of tile row 4 wm + i, column = channel
 
     L0_FENCE();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // pooled patch n + 2 and frame patch n + 1
@@ -627,7 +631,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const u32x4_t am = l0_frame_operand(sp + mbase + i * 80);
+      const u32x4_t am = l0_frame_operand(sp + mbase + i * 80, mstride);
       const uint32_t d0 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80), d1 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 4),
                      d2 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 8), d3 = *reinterpret_cast<const uint32_t*>(sp + tbase + i * 80 + 12);
       const uint2 fhi = make_uint2(__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u));
@@ -635,19 +639,16 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_dgrad_kernel(L0Args p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         // (the conv.0 operands are re-read per use: 16 registers held across the epilogue would not fit beside the 144 of the weights)
-        const u32x4_t wh = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + (((wn * 2 + j) * 2 + 0) * 64 + lane) * 16);
-        f32x4_t y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, am), __builtin_bit_cast(bf16x8_t, wh),
-                                                           f32x4_t{bj[j], bj[j], bj[j], bj[j]}, 0, 0, 0);
-        if (WSPLIT) {
-          const u32x4_t wl = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + (((wn * 2 + j) * 2 + 1) * 64 + lane) * 16);
-          y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, am), __builtin_bit_cast(bf16x8_t, wl), y, 0, 0, 0);
-        }
+        const u32x4_t wh = *reinterpret_cast<const u32x4_t*>(smem + WM_OFF + ((wn * 2 + j) * 64 + lane) * 16);
+        const f32x4_t y = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, am), __builtin_bit_cast(bf16x8_t, wh),
+                                                                 f32x4_t{bj[j], bj[j], bj[j], bj[j]}, 0, 0, 0);
         float dy[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) dy[r] = y[r] > 0.f ? acc[i][j][r] : 0.f;
         const uint2 bd = make_uint2(pack_bf16(dy[0], dy[1]), pack_bf16(dy[2], dy[3]));
-        dw0[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(l0_s16x4_t, fhi), __builtin_bit_cast(l0_s16x4_t, bd), dw0[j], 0, 0, 0);
-        dw0[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(l0_s16x4_t, flo), __builtin_bit_cast(l0_s16x4_t, bd), dw0[j], 0, 0, 0);
+        // K = 32 = (4 pixels of the lane group) x (hi, lo): the masked gradient twice against the two halves of the frame values
+        dw0[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, u32x4_t{fhi.x, fhi.y, flo.x, flo.y}),
+                                                         __builtin_bit_cast(bf16x8_t, u32x4_t{bd.x, bd.y, bd.x, bd.y}), dw0[j], 0, 0, 0);
       }
     }
     org[0] = org[1]; org[1] = org[2];
@@ -699,7 +700,6 @@ __device__ __forceinline__ bf16x8_t l0_read_tr(const unsigned char* lo, const un
   return __builtin_bit_cast(bf16x8_t, make_uint4(a.x, a.y, b.x, b.y));
 }
 
-template <bool WSPLIT>
 __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
   constexpr int S_OFF = 2 * L0_STAGE, B0_OFF = S_OFF + 2 * 1024;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -717,8 +717,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
   const int H2 = p.H >> 1, W2 = p.W >> 1;
 
   // conv.0 operands of this wave's channel fragment (registers) and its bias
-  u32x4_t whi, wlo;
-  l0_weight_operands(p.w0, wave * 16 + lr, g, whi, wlo);
+  const u32x4_t wop = l0_weight_operand(p.w0, wave * 16 + lr, g, p.wsplit != 0);
   if (tid < 64) reinterpret_cast<float*>(smem + B0_OFF)[tid] = p.b0 ? p.b0[tid] : 0.f;
   __syncthreads();
   const f32x4_t bias0 = *reinterpret_cast<const f32x4_t*>(smem + B0_OFF + (wave * 16 + 4 * g) * 4);
@@ -774,11 +773,11 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
   // fragments 10 / 11 = columns 16, 17 of rows 0 .. 7 / 8, 9 (lane lr <-> row lr / 2, column 16 + (lr & 1)); the 12 lanes of fragment 11
   // that have no pixel repeat fragment 10's (same value to the same place).  The linear numbering it replaces (pixel = 16 f + lr) cost two
   // divisions by 18 per fragment and lane: ~300 of the ~530 vector instructions of a wave and patch.
-  const int gq = g < 3 ? g : 2;
+  const int gstride = l0_frame_lane_stride(g);
   const int swz = ((g >> 1) ^ (wave << 1)) << 4, sub8 = (g & 1) * 8;
-  const int ga1 = (gq * 20 + lr) * 4, wa1 = lr * 128 + (swz ^ ((lr & 7) << 4)) + sub8;
+  const int ga1 = lr * 4 + l0_frame_lane_off(g), wa1 = lr * 128 + (swz ^ ((lr & 7) << 4)) + sub8;
   const int pr2 = lr >> 1, pc2 = 16 + (lr & 1);
-  const int ga2 = ((pr2 + gq) * 20 + pc2) * 4, wa2 = (pr2 * 18 + pc2) * 128 + (swz ^ ((pc2 & 7) << 4)) + sub8;
+  const int ga2 = (pr2 * 20 + pc2) * 4 + l0_frame_lane_off(g), wa2 = (pr2 * 18 + pc2) * 128 + (swz ^ ((pc2 & 7) << 4)) + sub8;
   const int ga3 = lr < 4 ? ga2 + 8 * 80 : ga2, wa3 = lr < 4 ? wa2 + 8 * 18 * 128 : wa2, pr3 = lr < 4 ? pr2 + 8 : pr2;
   auto generate = [&](int st, int sb, const L0Org& o) __attribute__((always_inline)) {
     unsigned char* xp = smem + st * L0_STAGE;
@@ -811,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) acc3[k & 1][u] = l0_gen_mfma<WSPLIT>(l0_frame_operand(sp + frag_ga(k * 3 + u)), whi, wlo, bias0);
+        for (int u = 0; u < 3; ++u) acc3[k & 1][u] = l0_gen_mfma(l0_frame_operand(sp + frag_ga(k * 3 + u), gstride), wop, bias0);
         if (k > 0) finish(k - 1);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -969,22 +968,37 @@ extern "C" int asr_vgg_level0_fwd(const float* src, const float* w0, const float
   a.pool = static_cast<bf16_t*>(pool); a.code = code; a.B = B; a.H = H; a.W = W;
   a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t lds = 2 * L0_PB + 2 * L0_SS + L0_WM + 512;
-  const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
+  a.wsplit = asr_tuning("L0_WSPLIT", 1) != 0 ? 1 : 0;
   {
     // The caller decides HERE whether the level runs on these kernels (EUNSUPPORTED -> the stored-activation launch chain): the two
     // backward kernels need more LDS than this one, so their grants are part of the decision -- a backward pass cannot fall back.
     const size_t lds_d = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16, lds_w = 2 * L0_STAGE + 2 * 1024 + 256;
-    const int r0 = split ? l0_grant<vgg_level0_fwd_kernel<true>>(lds) : l0_grant<vgg_level0_fwd_kernel<false>>(lds);
-    const int r1 = split ? l0_grant<vgg_level0_dgrad_kernel<true>>(lds_d) : l0_grant<vgg_level0_dgrad_kernel<false>>(lds_d);
-    const int r2 = split ? l0_grant<vgg_level0_wgrad_kernel<true>>(lds_w) : l0_grant<vgg_level0_wgrad_kernel<false>>(lds_w);
+    const int r0 = l0_grant<vgg_level0_fwd_kernel>(lds), r1 = l0_grant<vgg_level0_dgrad_kernel>(lds_d), r2 = l0_grant<vgg_level0_wgrad_kernel>(lds_w);
     if (r0 != ASR_OK || r1 != ASR_OK || r2 != ASR_OK) return ASR_EUNSUPPORTED;
   }
   const int64_t slots = (int64_t)l0_cus() * 2;
   const unsigned grid = (unsigned)(a.ntiles < slots ? a.ntiles : slots);
+#ifdef L0_TIMING
+  static long long* dbg = nullptr;
+  if (!dbg) (void)hipMalloc(&dbg, 64 * 8);
+  (void)hipMemsetAsync(dbg, 0, 64 * 8, s);
+  a.dbg = dbg;
+#endif
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
-  if (split) hipLaunchKernelGGL(vgg_level0_fwd_kernel<true>, dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(vgg_level0_fwd_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(vgg_level0_fwd_kernel, dim3(grid), dim3(256), lds, s, a);
   ASR_LAUNCH_CHECK();
+#ifdef L0_TIMING
+  {
+    long long h[64];
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+    static int shown = 0;
+    if (shown++ == 8)       // a warm launch
+      for (int w = 0; w < 4; ++w)
+        fprintf(stderr, "level0 fwd timing wave %d tiles %lld: barrier %lld generation %lld main %lld dmawait %lld epilogue %lld looptop %lld (s_memtime ticks)\n",
+                w, h[w * 8 + 7], h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+  }
+#endif
   return ASR_OK;
 }
 
@@ -1007,15 +1021,14 @@ extern "C" int asr_vgg_level0_dgrad(const void* dpool, const uint8_t* code, cons
   a.dpool = static_cast<const bf16_t*>(dpool); a.code = const_cast<uint8_t*>(code); a.ws = workspace; a.B = B; a.H = H; a.W = W;
   a.tiles_h = (H + 7) / 8; a.tiles_w = (W + 15) / 16; a.ntiles = B * a.tiles_h * a.tiles_w;
   const size_t lds = 2 * L0_PB + 2 * L0_PST + 2 * L0_SS + L0_WM + 256 + 16;
-  const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
-  const int rc = split ? l0_grant<vgg_level0_dgrad_kernel<true>>(lds) : l0_grant<vgg_level0_dgrad_kernel<false>>(lds);
+  a.wsplit = asr_tuning("L0_WSPLIT", 1) != 0 ? 1 : 0;
+  const int rc = l0_grant<vgg_level0_dgrad_kernel>(lds);
   if (rc != ASR_OK) return rc;
   const int64_t slots = (int64_t)l0_cus() * 2;
   const unsigned grid = (unsigned)(a.ntiles < slots ? a.ntiles : slots);
   if (workspace_floats < (int64_t)grid * 640) return ASR_EINVAL;
   AsrProfScope prof(ASR_OP_CONV_IGEMM, s);
-  if (split) hipLaunchKernelGGL(vgg_level0_dgrad_kernel<true>, dim3(grid), dim3(256), lds, s, a);
-  else hipLaunchKernelGGL(vgg_level0_dgrad_kernel<false>, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(vgg_level0_dgrad_kernel, dim3(grid), dim3(256), lds, s, a);
   ASR_LAUNCH_CHECK();
   hipLaunchKernelGGL(vgg_level0_dw0_reduce_kernel, dim3(10), dim3(1024), 0, s, workspace, (int)grid, dw0, db0);
   ASR_LAUNCH_CHECK();
@@ -1035,13 +1048,12 @@ extern "C" int asr_vgg_level0_wgrad(const float* src, const float* w0, const flo
   l0_wgrad_grid(B, H, W, &wgx, &a.patches_per_wg);
   if (workspace_floats < (int64_t)wgx * 9 * 64 * 64) return ASR_EINVAL;
   const size_t lds = 2 * L0_STAGE + 2 * 1024 + 256;
-  const bool split = asr_tuning("L0_WSPLIT", 1) != 0;
-  const int rc = split ? l0_grant<vgg_level0_wgrad_kernel<true>>(lds) : l0_grant<vgg_level0_wgrad_kernel<false>>(lds);
+  a.wsplit = asr_tuning("L0_WSPLIT", 1) != 0 ? 1 : 0;
+  const int rc = l0_grant<vgg_level0_wgrad_kernel>(lds);
   if (rc != ASR_OK) return rc;
   {
     AsrProfScope prof(ASR_OP_CONV_WGRAD, s);
-    if (split) hipLaunchKernelGGL(vgg_level0_wgrad_kernel<true>, dim3((unsigned)wgx), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(vgg_level0_wgrad_kernel<false>, dim3((unsigned)wgx), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(vgg_level0_wgrad_kernel, dim3((unsigned)wgx), dim3(256), lds, s, a);
     ASR_LAUNCH_CHECK();
   }
   return asr_conv3x3_wgrad_reduce(workspace, dw2, B, H, W, 64, 64, s);

@@ -4,7 +4,7 @@
 tag=${1:-l0}; reps=${2:-3}
 cd ${GRAFT_REPO_ROOT:-$(pwd)}; mkdir -p gpurun_out; export TMPDIR=/tmp
 L=end2end-asr-pytorch_amd/asr_hip
-timeout 600 python -m pytest tests/test_gpu_level0.py -x -q 2>&1 | tail -15 > gpurun_out/${tag}_tests.log
+timeout 900 python -m pytest tests/test_gpu_level0.py tests/test_gpu_ops.py -x -q -k "level0 or conv" 2>&1 | tail -15 > gpurun_out/${tag}_tests.log
 {
   echo "== new"; timeout 300 python tools/mb_level0.py $reps 2>&1 | grep -v amdgpu.ids
   if [ -f $L/libasr_hip_prev.so ]; then
