@@ -57,45 +57,50 @@ template <int CI, int TH> struct WsGeo {
   __device__ static __forceinline__ int key(int x) { return CI == 128 ? (x & 15) : ((x >> 1) & 7); }
 };
 
-// unit U of a tile's contraction: 4 pixel fragments x (tap, 32-channel k step)
-template <int U, int FM, int KS> struct WsUnit {
-  static constexpr int HPS = FM / 4;              // units per k step
-  static constexpr int S = U / HPS, half = U % HPS, tap = S / KS, ms = S % KS, dy = tap / 3, dx = tap % 3;
-};
-
-template <int U, int FM, int KS, int PSZ>
-__device__ __forceinline__ void ws_issue(u32x4_t (&dst)[4], const unsigned (&pbd)[3][KS]) {
-  using K = WsUnit<U, FM, KS>;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[i]) : "v"(pbd[K::dx][K::ms]), "n"((K::half * 4 + i + K::dy) * WS_PW * PSZ));
+// The contraction of a tile, ordered by PATCH ROW (round 6; conv_c64_core.h has the 64-channel twin).  For a fixed (tap column dx, k step)
+// the operand of patch row r -- 16 pixels x 32 channels, one ds_read_b128 -- serves every (tap row dy, tile row i) with i + dy = r and both
+// channel fragments of the wave: FM + 2 reads for 6 FM MFMAs instead of the 3 FM reads of the (tap, k step, 4 rows) units this replaces
+// (0.21 reads per MFMA at FM = 8, 0.25 at FM = 4, against 0.5).  The kernels are bound by the chip's power budget, and LDS operand reads
+// beside the MFMAs are energy: mfma_lds_power_probe.hip prices 0.5 reads per MFMA at 10 % of the sustained rate and 0.19 at 5 %.
+// Item K = (group G = K / (FM + 2): dx = G / KS, k step = G % KS; row r = K % (FM + 2)); reads run D items ahead in a ring of D + 1 quads.
+template <int K, int FM, int KS, int PSZ>
+__device__ __forceinline__ void ws_row_issue(u32x4_t& dst, const unsigned (&pbd)[3][KS]) {
+  constexpr int R = FM + 2, G = K / R, r = K % R, dx = G / KS, ms = G % KS;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(pbd[dx][ms]), "n"(r * WS_PW * PSZ));
 }
-
-template <int U, int FM, int PD, int KS, int PSZ>
-__device__ __forceinline__ void ws_unit(f32x4_t (&acc)[FM][2], u32x4_t (&a)[PD + 1][4], const u32x4_t (&wB)[9][KS][2],
-                                        const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
-  using K = WsUnit<U, FM, KS>;
-  constexpr int NU = 9 * KS * (FM / 4);
-  u32x4_t(&cur)[4] = a[U % (PD + 1)];
-  if constexpr (U + PD < NU) ws_issue<U + PD, FM, KS, PSZ>(a[(U + PD) % (PD + 1)], pbd);      // PD units ahead of the MFMAs
-  constexpr int ahead = ((U + PD < NU) ? PD : NU - 1 - U) * 4;                        // reads that may stay in flight (they return in order)
-  if constexpr (U == 0)
-    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]), "+v"(bq[0]), "+v"(bq[1]) : "n"(ahead));
-  else
-    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]) : "n"(ahead));
+template <int K, int FM, int D, int KS, int PSZ>
+__device__ __forceinline__ void ws_row_item(f32x4_t (&acc)[FM][2], u32x4_t (&ring)[D + 1], const u32x4_t (&wB)[9][KS][2],
+                                            const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
+  constexpr int R = FM + 2, NI = 3 * KS * R, G = K / R, r = K % R, dx = G / KS, ms = G % KS;
+  if constexpr (K + D < NI) ws_row_issue<K + D, FM, KS, PSZ>(ring[(K + D) % (D + 1)], pbd);
+  constexpr int pending = (K + D < NI) ? D : (NI - 1 - K);      // reads issued after read K (they return in order)
+  u32x4_t& cur = ring[K % (D + 1)];
+  if constexpr (K == 0) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(cur), "+v"(bq[0]), "+v"(bq[1]) : "n"(pending));
+  else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(cur) : "n"(pending));
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int dy = 0; dy < 3; ++dy) {
+    const int i = r - dy;
+    if (i < 0 || i >= FM) continue;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)       // the first k step starts every accumulator from the bias of its 4 output channels
-      acc[K::half * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wB[K::tap][K::ms][j]),
-                                                                        __builtin_bit_cast(bf16x8_t, cur[i]),
-                                                                        K::S == 0 ? __builtin_bit_cast(f32x4_t, bq[j]) : acc[K::half * 4 + i][j], 0, 0, 0);
+    for (int j = 0; j < 2; ++j)       // the first touch of an accumulator (group 0, tap row 0) starts it from the bias of its 4 output channels
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wB[dy * 3 + dx][ms][j]), __builtin_bit_cast(bf16x8_t, cur),
+                                                          (G == 0 && dy == 0) ? __builtin_bit_cast(f32x4_t, bq[j]) : acc[i][j], 0, 0, 0);
+  }
 }
-
-template <int FM, int PD, int KS, int PSZ, int... U>
-__device__ __forceinline__ void ws_units(std::integer_sequence<int, U...>, f32x4_t (&acc)[FM][2], u32x4_t (&a)[PD + 1][4],
-                                         const u32x4_t (&wB)[9][KS][2], const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
-  (ws_unit<U, FM, PD, KS, PSZ>(acc, a, wB, pbd, bq), ...);
+template <int FM, int D, int KS, int PSZ, int... K>
+__device__ __forceinline__ void ws_rows_seq(std::integer_sequence<int, K...>, f32x4_t (&acc)[FM][2], u32x4_t (&ring)[D + 1],
+                                            const u32x4_t (&wB)[9][KS][2], const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
+  (ws_row_item<K, FM, D, KS, PSZ>(acc, ring, wB, pbd, bq), ...);
+}
+template <int FM, int D, int KS, int PSZ, int... P>
+__device__ __forceinline__ void ws_rows_prologue(std::integer_sequence<int, P...>, u32x4_t (&ring)[D + 1], const unsigned (&pbd)[3][KS]) {
+  (ws_row_issue<P, FM, KS, PSZ>(ring[P], pbd), ...);
+}
+template <int FM, int KS, int PSZ, int D = 3>
+__device__ __forceinline__ void ws_rows(f32x4_t (&acc)[FM][2], const u32x4_t (&wB)[9][KS][2], const unsigned (&pbd)[3][KS], u32x4_t (&bq)[2]) {
+  u32x4_t ring[D + 1];
+  ws_rows_prologue<FM, D, KS, PSZ>(std::make_integer_sequence<int, D>{}, ring, pbd);
+  ws_rows_seq<FM, D, KS, PSZ>(std::make_integer_sequence<int, 3 * KS * (FM + 2)>{}, acc, ring, wB, pbd, bq);
 }
 
 // EP = 0: y (B, H, W, CO) NHWC, optional ReLU / mask.  EP = 1: ReLU + 2x2 max-pool + selection codes in the (B, W/2, CO, H/2) layout.
@@ -104,7 +109,7 @@ __device__ __forceinline__ void ws_units(std::integer_sequence<int, U...>, f32x4
 // ~150 cycles whatever its width, the pooled epilogue was 16 of them per tile.
 // TM = true (tuning WS_DBG = device address of 64 int64): every wave of workgroup 0 stamps the shader clock at the section boundaries
 // of a tile and leaves its totals {barrier, staging issue, contraction, DMA wait, epilogue, tiles} in dbg[wave * 8 ..]
-template <int CI, int TH, int CO, int MK, int EP, int PD, bool TM = false>
+template <int CI, int TH, int CO, int MK, int EP, bool TM = false>
 __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(WsArgs p) {
   using G = WsGeo<CI, TH>;
   constexpr int KS = G::KS, CPP = G::CPP, PSZ = G::PSZ, WS_PB = G::PB, WS_NCH = G::NCH, WS_PIT = G::PIT, WS_TH = TH;
@@ -124,7 +129,6 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   constexpr bool POOLED = EP != 0, PAIR = EP == 2;
   constexpr int WN = CO / 32, WM = 4 / WN, FM = TH / WM;     // waves along channels / pixel rows, pixel fragments (tile rows) per wave
   static_assert(FM == 4 || FM == 8, "4 or 8 tile rows per wave");
-  constexpr int NU = 9 * KS * (FM / 4);
   constexpr int NA = CI == 128 ? 64 : 32;                    // weight operands that live in the accumulation half of the register file
   constexpr int STASH = MASK ? 4 * FM * 1024 : 0;            // the lane's FM mask chunks of the tile
   constexpr int BIAS_OFF = WS_NBUF * WS_PB + STASH;
@@ -284,10 +288,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
     for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
       for (int ms = 0; ms < KS; ++ms) pbd[dx][ms] = offk[dx][ms] + (unsigned)((n % WS_NBUF) * WS_PB);
-    u32x4_t a[PD + 1][4];
-    ws_issue<0, FM, KS, PSZ>(a[0], pbd);
-    if constexpr (PD == 2) ws_issue<1, FM, KS, PSZ>(a[1], pbd);
-    ws_units<FM, PD, KS, PSZ>(std::make_integer_sequence<int, NU>{}, acc, a, wB, pbd, bq);
+    ws_rows<FM, KS, PSZ>(acc, wB, pbd, bq);
 
     // patch n + 1 (and this tile's mask chunks) must have landed before the next barrier
     WS_FENCE();
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256, CI == 64 ? 2 : 1) void conv3x3_ws128_kernel(Ws
   }
 }
 
-template <int CI, int TH, int CO, int MK, int EP, int PD, bool TM = false>
+template <int CI, int TH, int CO, int MK, int EP, bool TM = false>
 int ws_launch_t(WsArgs p, hipStream_t s) {
   using G = WsGeo<CI, TH>;
   constexpr int WS_TH = TH, WS_PB = G::PB;
@@ -464,7 +465,7 @@ int ws_launch_t(WsArgs p, hipStream_t s) {
   const size_t lds = (size_t)WS_NBUF * WS_PB + (MK == 1 ? 4 * FM * 1024 : 0) + CO * 4;
   static bool granted = false;          // per instantiation; the first (eager / warm-up) launch does it, never a captured one
   if (!granted) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws128_kernel<CI, TH, CO, MK, EP, PD, TM>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_ws128_kernel<CI, TH, CO, MK, EP, TM>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return ASR_EUNSUPPORTED;
     granted = true;
@@ -473,7 +474,7 @@ int ws_launch_t(WsArgs p, hipStream_t s) {
   const int64_t slots = (int64_t)cus * (per_cu > 0 ? per_cu : 1);         // 64 input channels: 144 registers of weights per wave, two workgroups per CU
   const int64_t items = EP == 2 ? nt / 2 : nt;
   const unsigned grid = (unsigned)(items < slots ? items : slots);
-  hipLaunchKernelGGL((conv3x3_ws128_kernel<CI, TH, CO, MK, EP, PD, TM>), dim3(grid), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((conv3x3_ws128_kernel<CI, TH, CO, MK, EP, TM>), dim3(grid), dim3(256), lds, s, p);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }
@@ -488,15 +489,15 @@ int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s) {
   if (a.bits_out && (a.Cin != 64 || a.Cout != 128 || a.mask || a.pool || !a.relu)) return ASR_EUNSUPPORTED;
   if (a.Cin == 64) {               // conv.5 forward (64 -> 128) in one pass: 4-row tiles, two workgroups per CU
     if (a.Cout != 128 || a.mask || a.pool) return ASR_EUNSUPPORTED;
-    if (a.bits_out) return ws_launch_t<64, 4, 128, 3, 0, 2>(a, s);        // ... also writing the ReLU bit mask of its output
+    if (a.bits_out) return ws_launch_t<64, 4, 128, 3, 0>(a, s);        // ... also writing the ReLU bit mask of its output
 #ifdef ASR_TUNE_ABLATE
     if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {
       WsArgs t = a;
       t.dbg = reinterpret_cast<long long*>(dbg);
-      return ws_launch_t<64, 4, 128, 0, 0, 1, true>(t, s);
+      return ws_launch_t<64, 4, 128, 0, 0, true>(t, s);
     }
 #endif
-    return ws_launch_t<64, 4, 128, 0, 0, 2>(a, s);
+    return ws_launch_t<64, 4, 128, 0, 0>(a, s);
   }
   if (a.Cin != 128) return ASR_EUNSUPPORTED;
 #ifdef ASR_TUNE_ABLATE
@@ -506,21 +507,19 @@ int asr_conv3x3_ws128_launch(const WsArgs& a, hipStream_t s) {
   if (const int64_t dbg = asr_tuning("WS_DBG", 0)) {
     WsArgs t = a;
     t.dbg = reinterpret_cast<long long*>(dbg);
-    if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, 8, 128, 0, 1, 2, true>(t, s);
-    if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, 8, 128, 1, 0, 2, true>(t, s);
-    if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<128, 8, 64, 0, 0, 2, true>(t, s);
+    if (a.pool && a.Cout == 128 && !a.mask && a.code && a.H % 8 == 0 && a.W % 16 == 0) return ws_launch_t<128, 8, 128, 0, 1, true>(t, s);
+    if (!a.pool && a.Cout == 128 && a.mask) return ws_launch_t<128, 8, 128, 1, 0, true>(t, s);
+    if (!a.pool && a.Cout == 64 && !a.mask) return ws_launch_t<128, 8, 64, 0, 0, true>(t, s);
   }
 #endif
-  // (operand prefetch depth 2 everywhere: depth 1 lost by 3 - 6 % in every form, profiles/r05_conv_ws_sections_v1.txt; its instantiations
-  //  and the WS_PD switch were removed in round 6)
   if (a.pool) {
     if (a.Cout != 128 || a.mask || !a.code || a.H % 8 != 0 || a.W % 16 != 0) return ASR_EUNSUPPORTED;
     // vertical tile pairs: half the store instructions.  Single tiles where H % 16 == 8 -- and under tuning WS_PAIR = 0, the arm
     // tests/test_gpu_conv_ws.py holds the paired epilogue against
-    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, 0, 2, 2>(a, s);
-    return ws_launch_t<128, 8, 128, 0, 1, 2>(a, s);
+    if (a.H % 16 == 0 && asr_tuning("WS_PAIR", 1) != 0) return ws_launch_t<128, 8, 128, 0, 2>(a, s);
+    return ws_launch_t<128, 8, 128, 0, 1>(a, s);
   }
-  if (a.bits_in) return ws_launch_t<128, 8, 128, 2, 0, 2>(a, s);           // conv.7's data gradient with conv.5's ReLU mask as bits
-  if (a.Cout == 128) return a.mask ? ws_launch_t<128, 8, 128, 1, 0, 2>(a, s) : ws_launch_t<128, 8, 128, 0, 0, 2>(a, s);
-  return a.mask ? ws_launch_t<128, 8, 64, 1, 0, 2>(a, s) : ws_launch_t<128, 8, 64, 0, 0, 2>(a, s);
+  if (a.bits_in) return ws_launch_t<128, 8, 128, 2, 0>(a, s);           // conv.7's data gradient with conv.5's ReLU mask as bits
+  if (a.Cout == 128) return a.mask ? ws_launch_t<128, 8, 128, 1, 0>(a, s) : ws_launch_t<128, 8, 128, 0, 0>(a, s);
+  return a.mask ? ws_launch_t<128, 8, 64, 1, 0>(a, s) : ws_launch_t<128, 8, 64, 0, 0>(a, s);
 }

@@ -135,12 +135,12 @@ def conv_ws_asm(tmp_path_factory):
 
 
 @pytest.mark.parametrize("kernel,mfmas,max_regs", [
-    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELi0ELi2ELi2ELb0E", 576, 512),      # conv.7 forward, pooled epilogue on tile pairs
-    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELi1ELi0ELi2ELb0E", 576, 512),      # conv.7 data gradient + mask
-    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELi2ELi0ELi2ELb0E", 576, 512),      # ... with the mask as one bit per element
-    (r"conv3x3_ws128_kernelILi128ELi8ELi64ELi0ELi0ELi2ELb0E", 288, 512),       # conv.5 data gradient
-    (r"conv3x3_ws128_kernelILi64ELi4ELi128ELi0ELi0ELi2ELb0E", 144, 256),       # conv.5 forward in one pass: TWO workgroups per CU
-    (r"conv3x3_ws128_kernelILi64ELi4ELi128ELi3ELi0ELi2ELb0E", 144, 256),       # ... writing its ReLU mask as bits
+    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELi0ELi2ELb0E", 576, 512),      # conv.7 forward, pooled epilogue on tile pairs
+    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELi1ELi0ELb0E", 576, 512),      # conv.7 data gradient + mask
+    (r"conv3x3_ws128_kernelILi128ELi8ELi128ELi2ELi0ELb0E", 576, 512),      # ... with the mask as one bit per element
+    (r"conv3x3_ws128_kernelILi128ELi8ELi64ELi0ELi0ELb0E", 288, 512),       # conv.5 data gradient
+    (r"conv3x3_ws128_kernelILi64ELi4ELi128ELi0ELi0ELb0E", 144, 256),       # conv.5 forward in one pass: TWO workgroups per CU
+    (r"conv3x3_ws128_kernelILi64ELi4ELi128ELi3ELi0ELb0E", 144, 256),       # ... writing its ReLU mask as bits
 ])
 def test_weight_stationary_conv_keeps_its_weights_where_the_mfma_reads_them(conv_ws_asm, kernel, mfmas, max_regs):
     """csrc/conv_ws.hip (round 5) rests on three compiler-dependent facts: the weights loaded with an "=a" constraint STAY in the
