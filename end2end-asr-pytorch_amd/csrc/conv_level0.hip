@@ -840,8 +840,8 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  // db2: every wave sums ONE channel fragment of the dY operands it reads anyway (fragment = wave; v_dot2c_f32_bf16 against (1, 1): one
-  // instruction per two values).  Round 5 had wave 0 sum all four with shift / mask / add: 192 vector instructions on one wave of a
+  // db2: every wave sums ONE channel fragment of the dY operands it reads anyway (fragment = wave; asr_sum8_bf16: one instruction per two
+  // values).  Round 5 had wave 0 sum all four with shift / mask / add: 192 vector instructions on one wave of a
   // barrier-synchronised four.
   float bsum = 0.f;
   const bool do_bias = p.db != nullptr;
@@ -872,19 +872,11 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = l0_read_tr(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
       if (do_bias) {
-        auto sum8 = [&](const bf16x8_t& v) __attribute__((always_inline)) {
-          const u32x4_t u = __builtin_bit_cast(u32x4_t, v);
-          // (one asm block: the accumulating chain is hazard-free, but a DOT result needs 3 wait states before any OTHER vector instruction
-          // reads it, and the compiler cannot see the opcode inside an asm -- hence the trailing s_nop.  The builtin picked one dword of
-          // `u` four times, hipcc 7.0.)
-          asm("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5\n\ts_nop 2"
-              : "+v"(bsum) : "s"(0x3F803F80u), "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
-        };
         switch (wave_u) {       // (wave-uniform: scalar branches)
-          case 0: sum8(a[0]); break;
-          case 1: sum8(a[1]); break;
-          case 2: sum8(a[2]); break;
-          default: sum8(a[3]); break;
+          case 0: asr_sum8_bf16(bsum, a[0]); break;
+          case 1: asr_sum8_bf16(bsum, a[1]); break;
+          case 2: asr_sum8_bf16(bsum, a[2]); break;
+          default: asr_sum8_bf16(bsum, a[3]); break;
         }
       }
 #pragma unroll

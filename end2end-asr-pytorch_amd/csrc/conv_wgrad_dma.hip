@@ -155,8 +155,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_bias = p.db != nullptr && ci0 == 0 && wave == 0;
+  // db: sum of dY over the pixels, in the ci block 0 workgroups.  Every wave sums ONE channel fragment of the dY operands it reads anyway
+  // (fragment = wave, one v_dot2c per two values); until round 6 wave 0 summed all four with shift / mask / add -- 192 vector
+  // instructions per patch on one wave of a barrier-synchronised four.
+  float bsum = 0.f;
+  const bool do_bias = p.db != nullptr && ci0 == 0;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   if (p_beg < p_end) stage(0, tid);
   for (int patch = p_beg; patch < p_end; ++patch) {
@@ -173,12 +177,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
       bf16x8_t a[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = wgd_read(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
-      if (do_bias) {          // db: sum of dY over the pixels (wave 0 of the ci block 0 workgroups)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const u32x4_t u = __builtin_bit_cast(u32x4_t, a[i]);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bsum[i] += __uint_as_float(u[e] << 16) + __uint_as_float(u[e] & 0xffff0000u);
+      if (do_bias) {
+        switch (wave_u) {       // (wave-uniform: scalar branches)
+          case 0: asr_sum8_bf16(bsum, a[0]); break;
+          case 1: asr_sum8_bf16(bsum, a[1]); break;
+          case 2: asr_sum8_bf16(bsum, a[2]); break;
+          default: asr_sum8_bf16(bsum, a[3]); break;
         }
       }
       // The three taps of a kernel row read the same patch row at columns c .. c + 7, c + 1 .. c + 8, c + 2 .. c + 9: ONE run of 12
@@ -214,13 +218,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) part[(t * 64 + i * 16 + g * 4 + r) * 64 + wave * 16 + lr] = acc[t][i][r];
   if (do_bias) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float v = bsum[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
-      if (g == 0) atomicAdd(p.db + co0 + i * 16 + lr, v);
-    }
+    float v = bsum;
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) atomicAdd(p.db + co0 + wave * 16 + lr, v);
   }
 }
 
