@@ -74,6 +74,16 @@ __device__ __forceinline__ uint2 asr_lds_read_tr16(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
+// Pixels 2 .. 9 of a run of 12 bf16 (r0 = 0 .. 3, r1 = 4 .. 7, r2 = 8 .. 11) as one MFMA operand: (r0.y, r1.x | r1.y, r2.x).  An operand must start
+// on an even register and r0.y never does, so the compiler spends four v_mov on it; v_pk_mov_b32 moves two dwords at once and picks a half of
+// each 64-bit source (low result = src0's half by op_sel[0], high result = src1's half by op_sel_hi[1]).
+__device__ __forceinline__ bf16x8_t asr_shift2_of12(const uint2& r0, const uint2& r1, const uint2& r2) {
+  uint2 lo, hi;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(lo) : "v"(r0), "v"(r1));
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0]" : "=v"(hi) : "v"(r1), "v"(r2));
+  return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
 // acc += the 8 bf16 of v (fp32 accumulation): v_dot2c_f32_bf16 against (1, 1), one instruction per two values.  One asm block: the
 // accumulating chain is hazard-free, but a DOT result needs 3 wait states before any OTHER vector instruction reads it and the compiler
 // cannot see the opcode inside an asm -- hence the trailing s_nop.  (__builtin_amdgcn_fdot2_f32_bf16 picked one dword of the operand four

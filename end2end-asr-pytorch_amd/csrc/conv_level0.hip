@@ -739,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
 
   // the thread's expansion item: pooled pixel (qr, qc) of the tile's 4 x 8, chunk c
   const int iq = tid >> 3, ic = tid & 7, iqr = iq >> 3, iqc = iq & 7;
-  const int da0 = L0_XB + ((2 * iqr) * 16 + 2 * iqc) * 128 + ((ic ^ ((2 * iqc) & 7)) << 4);        // window (0, 0); (0, 1) = (da0 + 128) ^ 16; row 1: + 16 * 128
+  const int da0 = L0_XB + ((2 * iqr) * 16 + 2 * iqc) * 128 + ((ic ^ wgd_key(2 * iqc)) << 4);        // window (0, 0); (0, 1) = (da0 + 128) ^ 16; row 1: + 16 * 128
   u32x4_t pv = u32x4_t{0u, 0u, 0u, 0u};
   uint2 pk = make_uint2(0u, 0u);
   auto load_pooled = [&](const L0Org& o) __attribute__((always_inline)) {
@@ -775,9 +775,9 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
   // divisions by 18 per fragment and lane: ~300 of the ~530 vector instructions of a wave and patch.
   const int gstride = l0_frame_lane_stride(g);
   const int swz = ((g >> 1) ^ (wave << 1)) << 4, sub8 = (g & 1) * 8;
-  const int ga1 = lr * 4 + l0_frame_lane_off(g), wa1 = lr * 128 + (swz ^ ((lr & 7) << 4)) + sub8;
+  const int ga1 = lr * 4 + l0_frame_lane_off(g), wa1 = lr * 128 + (swz ^ (wgd_key(lr) << 4)) + sub8;
   const int pr2 = lr >> 1, pc2 = 16 + (lr & 1);
-  const int ga2 = (pr2 * 20 + pc2) * 4 + l0_frame_lane_off(g), wa2 = (pr2 * 18 + pc2) * 128 + (swz ^ ((pc2 & 7) << 4)) + sub8;
+  const int ga2 = (pr2 * 20 + pc2) * 4 + l0_frame_lane_off(g), wa2 = (pr2 * 18 + pc2) * 128 + (swz ^ (wgd_key(pc2) << 4)) + sub8;
   const int ga3 = lr < 4 ? ga2 + 8 * 80 : ga2, wa3 = lr < 4 ? wa2 + 8 * 18 * 128 : wa2, pr3 = lr < 4 ? pr2 + 8 : pr2;
   auto generate = [&](int st, int sb, const L0Org& o) __attribute__((always_inline)) {
     unsigned char* xp = smem + st * L0_STAGE;
@@ -822,18 +822,17 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
 
   // ---- per-lane operand offsets inside a stage (conv_wgrad_dma.hip)
   const int colb = 8 * (g & 1) + (lr >> 2), rowb = g >> 1, sub = 8 * (lr & 1), cpair = (lr & 3) >> 1;
-  int xlo[3], xhi[3], dlo[4], dhi[4];
+  int xrun[3], dlo[4], dhi[4];          // (the stage's swizzle key: wgd_key, conv_wgrad_dma.h)
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int c = colb + dx, ch = wave * 2 + cpair;
-    xlo[dx] = (rowb * 18 + c) * 128 + ((ch ^ (c & 7)) << 4) + sub;
-    xhi[dx] = (rowb * 18 + c + 4) * 128 + ((ch ^ ((c + 4) & 7)) << 4) + sub;
+  for (int q = 0; q < 3; ++q) {
+    const int c = colb + 4 * q, ch = wave * 2 + cpair;
+    xrun[q] = (rowb * 18 + c) * 128 + ((ch ^ wgd_key(c)) << 4) + sub;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ch = 2 * i + cpair;
-    dlo[i] = L0_XB + (rowb * 16 + colb) * 128 + ((ch ^ (colb & 7)) << 4) + sub;
-    dhi[i] = L0_XB + (rowb * 16 + colb + 4) * 128 + ((ch ^ ((colb + 4) & 7)) << 4) + sub;
+    dlo[i] = L0_XB + (rowb * 16 + colb) * 128 + ((ch ^ wgd_key(colb)) << 4) + sub;
+    dhi[i] = L0_XB + (rowb * 16 + colb + 4) * 128 + ((ch ^ wgd_key(colb + 4)) << 4) + sub;
   }
   f32x4_t acc[9][4];
 #pragma unroll
@@ -866,36 +865,45 @@ __global__ __launch_bounds__(256, 2) void vgg_level0_wgrad_kernel(L0Args p) {
       generate(buf ^ 1, buf ^ 1, org[1]);
     }
     const unsigned char* sb = smem + buf * L0_STAGE;
+    // 12 steps = (macro step ms: two patch rows of dY) x (kernel row ky); the X run of a step is read ONE STEP AHEAD of its MFMAs (round 6: read
+    // and consumed inside one step, every step began with the LDS latency -- 12 exposed round trips per patch and wave)
+    uint2 xr[2][3];
+    auto xread = [&](uint2 (&r)[3], int st) __attribute__((always_inline)) {
+      const int off = ((2 * (st / 3) + st % 3) * 18) * 128;
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      bf16x8_t a[4];
+      for (int q = 0; q < 3; ++q) r[q] = asr_lds_read_tr16(sb + xrun[q] + off);
+    };
+    xread(xr[0], 0);
+    bf16x8_t a[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = l0_read_tr(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
-      if (do_bias) {
-        switch (wave_u) {       // (wave-uniform: scalar branches)
-          case 0: asr_sum8_bf16(bsum, a[0]); break;
-          case 1: asr_sum8_bf16(bsum, a[1]); break;
-          case 2: asr_sum8_bf16(bsum, a[2]); break;
-          default: asr_sum8_bf16(bsum, a[3]); break;
+    for (int st = 0; st < 12; ++st) {
+      const int ms = st / 3, ky = st % 3;
+      if (ky == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = l0_read_tr(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
+        if (do_bias) {
+          switch (wave_u) {       // (wave-uniform: scalar branches)
+            case 0: asr_sum8_bf16(bsum, a[0]); break;
+            case 1: asr_sum8_bf16(bsum, a[1]); break;
+            case 2: asr_sum8_bf16(bsum, a[2]); break;
+            default: asr_sum8_bf16(bsum, a[3]); break;
+          }
         }
       }
+      if (st + 1 < 12) xread(xr[(st + 1) & 1], st + 1);
+      // one run of 12 pixels per kernel row, the kx = 1, 2 operands by shifting (conv_wgrad_dma.hip)
+      const uint2 r0 = xr[st & 1][0], r1 = xr[st & 1][1], r2 = xr[st & 1][2];
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, make_uint4(__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                                                                   __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)));
+      const bf16x8_t b2 = asr_shift2_of12(r0, r1, r2);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {      // one run of 12 pixels per kernel row, the kx = 1, 2 operands by shifting (conv_wgrad_dma.hip)
-        const int off = ((2 * ms + ky) * 18) * 128;
-        const uint2 r0 = asr_lds_read_tr16(sb + xlo[0] + off), r1 = asr_lds_read_tr16(sb + xhi[0] + off);
-        const uint2 r2 = asr_lds_read_tr16(sb + xlo[0] + off + 8 * 128);
-        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
-        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, make_uint4(__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
-                                                                     __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)));
-        const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.y, r1.x, r1.y, r2.x));
+      for (int i = 0; i < 4; ++i) acc[3 * ky][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0, acc[3 * ky][i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[3 * ky][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0, acc[3 * ky][i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[3 * ky + 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1, acc[3 * ky + 1][i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[3 * ky + 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1, acc[3 * ky + 1][i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[3 * ky + 2][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b2, acc[3 * ky + 2][i], 0, 0, 0);
-        L0_FENCE();
-      }
+      for (int i = 0; i < 4; ++i) acc[3 * ky + 2][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b2, acc[3 * ky + 2][i], 0, 0, 0);
+      L0_FENCE();
     }
     if (j + 1 < np) expand(buf ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

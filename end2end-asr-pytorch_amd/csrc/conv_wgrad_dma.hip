@@ -5,7 +5,7 @@
 //   * halo patch of X (10 x 18 px x 64 ci) and dY tile (8 x 16 px x 64 co) of patch n+1 travel HBM -> LDS by the LDS-DMA (two
 //     stages) while patch n is contracted; per-thread source offsets are computed once, a patch costs one scalar base update
 //     (patches on the image border take a slower path: per-chunk bounds test, outside pixels from a 16-byte zero page);
-//   * LDS image = unpadded 128-byte pixel rows, 16-B chunk c of the pixel in patch column x in slot c ^ (x & 7); the MFMA operands
+//   * LDS image = unpadded 128-byte pixel rows, 16-B chunk c of the pixel in patch column x in slot c ^ wgd_key(x) (conv_wgrad_dma.h); the MFMA operands
 //     (8 CONSECUTIVE PIXELS per lane) are built by ds_read_b64_tr_b16 (see common.h), issued by hand two k steps ahead -- the
 //     compiler would drain the DMA counter before every LDS read it can see -- with the (macro step, tap) part of the address in
 //     the instruction's immediate offset;
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
 #pragma unroll
   for (int i = 0; i < RX; ++i) {
     const int c = tid + i * 256, hp = c >> 3, col = hp % 18;
-    relx[i] = ((hp / 18 - 1) * p.W + col - 1) * xrow + (((c & 7) ^ (col & 7)) << 4);
+    relx[i] = ((hp / 18 - 1) * p.W + col - 1) * xrow + (((c & 7) ^ wgd_key(col)) << 4);
   }
 #pragma unroll
   for (int i = 0; i < RD; ++i) {
     const int c = tid + i * 256, px = c >> 3, col = px & 15;
-    reld[i] = ((px >> 4) * p.W + col) * drow + (((c & 7) ^ (col & 7)) << 4);
+    reld[i] = ((px >> 4) * p.W + col) * drow + (((c & 7) ^ wgd_key(col)) << 4);
   }
   // patch origin, advanced without divisions
   int b, h0, w0;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
           const int hp = c >> 3, col = hp % 18, gy = h0 + hp / 18 - 1, gx = w0 + col - 1;
           const bool in = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
           const unsigned off = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * (unsigned)xrow +
-                               (unsigned)(((c & 7) ^ (col & 7)) << 4);
+                               (unsigned)(((c & 7) ^ wgd_key(col)) << 4);
           wgd_dma(sx + i * 4096, in ? X + off : zero);
         }
       }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
         const int c = t_ + i * 256, px = c >> 3, col = px & 15, gy = h0 + (px >> 4), gx = w0 + col;
         const bool in = gy < p.H && gx < p.W;
         const unsigned off = (((unsigned)b * (unsigned)p.H + (unsigned)gy) * (unsigned)p.W + (unsigned)gx) * (unsigned)drow +
-                             (unsigned)(((c & 7) ^ (col & 7)) << 4);
+                             (unsigned)(((c & 7) ^ wgd_key(col)) << 4);
         wgd_dma(sx + XB + i * 4096, in ? DY + off : zero);
       }
     }
@@ -136,18 +136,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
   // ---- per-lane operand offsets inside a stage (k = 8 g + j <-> patch row 2 ms + (g >> 1), column 8 (g & 1) + j); the
   // (macro step, tap) part of an address is a compile-time constant that lands in the read's immediate offset
   const int colb = 8 * (g & 1) + (lr >> 2), rowb = g >> 1, sub = 8 * (lr & 1), cpair = (lr & 3) >> 1;
-  int xlo[3], xhi[3], dlo[4], dhi[4];
+  int xrun[3], dlo[4], dhi[4];          // xrun: pixels colb .. + 3, + 4 .. + 7, + 8 .. + 11 of the lane's patch row (the kx = 1, 2 operands are shifts of the run)
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int c = colb + dx, ch = wave * 2 + cpair;
-    xlo[dx] = (rowb * 18 + c) * 128 + ((ch ^ (c & 7)) << 4) + sub;
-    xhi[dx] = (rowb * 18 + c + 4) * 128 + ((ch ^ ((c + 4) & 7)) << 4) + sub;
+  for (int q = 0; q < 3; ++q) {
+    const int c = colb + 4 * q, ch = wave * 2 + cpair;
+    xrun[q] = (rowb * 18 + c) * 128 + ((ch ^ wgd_key(c)) << 4) + sub;
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int ch = 2 * i + cpair;
-    dlo[i] = XB + (rowb * 16 + colb) * 128 + ((ch ^ (colb & 7)) << 4) + sub;
-    dhi[i] = XB + (rowb * 16 + colb + 4) * 128 + ((ch ^ ((colb + 4) & 7)) << 4) + sub;
+    dlo[i] = XB + (rowb * 16 + colb) * 128 + ((ch ^ wgd_key(colb)) << 4) + sub;
+    dhi[i] = XB + (rowb * 16 + colb + 4) * 128 + ((ch ^ wgd_key(colb + 4)) << 4) + sub;
   }
 
   f32x4_t acc[9][4];
@@ -172,40 +171,47 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_dma_kernel(WgdArgs p) {
     advance();
     if (patch + 1 < p_end) stage(buf ^ 1, tl);
     const unsigned char* sb = smem + buf * STAGE;
+    // 12 steps = (macro step ms: two patch rows of dY) x (kernel row ky).  The three taps of a kernel row read the same patch row at columns
+    // c .. c + 7, c + 1 .. c + 8, c + 2 .. c + 9: ONE run of 12 pixels (three transposing reads instead of six) and the kx = 1, 2 operands by
+    // shifting -- kx = 2 two v_pk_mov, kx = 1 four v_alignbit.  (Pixels 10, 11 of the run are not used: for the right half they lie in the
+    // next patch row / behind the patch, inside the stage.)  The run of a step is read ONE STEP AHEAD of its MFMAs (round 6: read and
+    // consumed inside one step, every step began with the LDS latency -- 12 exposed round trips per patch and wave).
+    uint2 xr[2][3];
+    auto xread = [&](uint2 (&r)[3], int st) __attribute__((always_inline)) {
+      const int off = ((2 * (st / 3) + st % 3) * 18) * 128;
 #pragma unroll
-    for (int ms = 0; ms < 4; ++ms) {
-      bf16x8_t a[4];
+      for (int q = 0; q < 3; ++q) r[q] = asr_lds_read_tr16(sb + xrun[q] + off);
+    };
+    xread(xr[0], 0);
+    bf16x8_t a[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = wgd_read(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
-      if (do_bias) {
-        switch (wave_u) {       // (wave-uniform: scalar branches)
-          case 0: asr_sum8_bf16(bsum, a[0]); break;
-          case 1: asr_sum8_bf16(bsum, a[1]); break;
-          case 2: asr_sum8_bf16(bsum, a[2]); break;
-          default: asr_sum8_bf16(bsum, a[3]); break;
+    for (int st = 0; st < 12; ++st) {
+      const int ms = st / 3, ky = st % 3;
+      if (ky == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = wgd_read(sb + dlo[i] + ms * 4096, sb + dhi[i] + ms * 4096);
+        if (do_bias) {
+          switch (wave_u) {       // (wave-uniform: scalar branches)
+            case 0: asr_sum8_bf16(bsum, a[0]); break;
+            case 1: asr_sum8_bf16(bsum, a[1]); break;
+            case 2: asr_sum8_bf16(bsum, a[2]); break;
+            default: asr_sum8_bf16(bsum, a[3]); break;
+          }
         }
       }
-      // The three taps of a kernel row read the same patch row at columns c .. c + 7, c + 1 .. c + 8, c + 2 .. c + 9: ONE run of 12
-      // pixels (three transposing reads instead of six; the loop is bound by them: 26 per 36 MFMAs before, 17 now) and the kx = 1, 2
-      // operands by shifting -- kx = 2 is a renaming of registers, kx = 1 four v_alignbit.  (Pixels 10, 11 of the run are not used:
-      // for the right half they lie in the next patch row / behind the patch, inside the stage.)
+      if (st + 1 < 12) xread(xr[(st + 1) & 1], st + 1);
+      const uint2 r0 = xr[st & 1][0], r1 = xr[st & 1][1], r2 = xr[st & 1][2];
+      const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
+      const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, make_uint4(__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
+                                                                   __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)));
+      const bf16x8_t b2 = asr_shift2_of12(r0, r1, r2);
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int off = ((2 * ms + ky) * 18) * 128;
-        const uint2 r0 = asr_lds_read_tr16(sb + xlo[0] + off), r1 = asr_lds_read_tr16(sb + xhi[0] + off);
-        const uint2 r2 = asr_lds_read_tr16(sb + xlo[0] + off + 8 * 128);
-        const bf16x8_t b0 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.x, r0.y, r1.x, r1.y));
-        const bf16x8_t b1 = __builtin_bit_cast(bf16x8_t, make_uint4(__builtin_amdgcn_alignbit(r0.y, r0.x, 16), __builtin_amdgcn_alignbit(r1.x, r0.y, 16),
-                                                                     __builtin_amdgcn_alignbit(r1.y, r1.x, 16), __builtin_amdgcn_alignbit(r2.x, r1.y, 16)));
-        const bf16x8_t b2 = __builtin_bit_cast(bf16x8_t, make_uint4(r0.y, r1.x, r1.y, r2.x));
+      for (int i = 0; i < 4; ++i) acc[3 * ky][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0, acc[3 * ky][i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[3 * ky][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0, acc[3 * ky][i], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) acc[3 * ky + 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1, acc[3 * ky + 1][i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[3 * ky + 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1, acc[3 * ky + 1][i], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[3 * ky + 2][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b2, acc[3 * ky + 2][i], 0, 0, 0);
-        WGD_FENCE();      // bounds how far ahead the scheduler hoists operand reads (and their registers): one tap row
-      }
+      for (int i = 0; i < 4; ++i) acc[3 * ky + 2][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b2, acc[3 * ky + 2][i], 0, 0, 0);
+      WGD_FENCE();      // bounds how far ahead the scheduler hoists operand reads (and their registers): one step
     }
   }
 
