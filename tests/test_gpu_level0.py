@@ -101,7 +101,7 @@ def test_level0_equals_the_launch_chain_it_replaces(ops, shape):
 @pytest.mark.parametrize("wsplit", ["1", "0"])
 def test_level0_against_torch_convolutions(ops, shape, wsplit):
     """Random inputs: the whole level against F.conv2d / max_pool2d in fp32 on the bf16-rounded conv.2 operands.  wsplit = 0 runs
-    conv.0 on its bf16-rounded weights alone (one MFMA less per unit): conv.0's pre-activations then move by 2^-9 relative, ~0.3 % of
+    conv.0 on its bf16-rounded weights alone (the wlo slots of the one MFMA left zero): conv.0's pre-activations then move by 2^-9 relative, ~0.3 % of
     its ReLU decisions differ from the fp32 reference's and the gradients -- compared under the REFERENCE's selections here -- by ~5 %
     (measured 4.5 - 6.7 %); the split weights (default) keep the decisions and stay at the bf16 floor of 3 %."""
     from asr_hip import lib as L
