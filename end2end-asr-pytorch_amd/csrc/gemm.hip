@@ -1041,6 +1041,12 @@ template <bool SWAP> __device__ __forceinline__ void tn_mma2(f32x4_t& acc, const
   else acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), acc, 0, 0, 0);
 }
 
+#ifdef TN_TIMING        // tuning builds only (ASR_HIPCC_EXTRA=-DTN_TIMING): s_memtime stamps at the section boundaries of a stage, workgroup 0
+__device__ long long tn_dbg[64];
+#define TN_STAMP(K) { const long long now_ = clock64(); tsec[K] += now_ - tlast; tlast = now_; }
+#else
+#define TN_STAMP(K)
+#endif
 template <int NST, bool SWAP>
 __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* smem, int tile, int m_beg, int m_end, bool single) {
   static_assert(NST == 3 || NST == 4, "ring of three or four stages");
@@ -1120,12 +1126,14 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // column sums of dY (the bias gradient) from the A fragments of the k0 = 0 blocks.  Round 6: four v_dot2c per fragment (asr_sum8_bf16)
+  // instead of a chain of 16 dependent shift / mask / add, and the four fragments of a row band split between the two waves that read them
+  // (wk = 0: fragments 0, 1; wk = 1: 2, 3).  In-kernel section timing (-DTN_TIMING) had the summing wave as the straggler of every stage of
+  // such a block: 1 745 cycles between the barriers against 1 050 for a wave that only multiplies.
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool do_colsum = colsum != nullptr && k0 == 0 && wk == 0;
+  const bool do_colsum = colsum != nullptr && k0 == 0;
   auto addsum = [&](int i, const u32x4_t& v) __attribute__((always_inline)) {
-    Chunk<bf16_t> c; c.v = make_uint4(v.x, v.y, v.z, v.w);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bsum[i] += bf16_to_f32(c.e[e]);
+    if ((i >> 1) == wk) asr_sum8_bf16(bsum[i], __builtin_bit_cast(bf16x8_t, v));
   };
 
   // prologue: stages 0 .. 2 on their way, stage 0 landed and published, its fragments requested
@@ -1142,7 +1150,11 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
   TN_FRAG_READ(a[3], fa[3] + ring_r)
   ring_r = STAGEB;
 
+#ifdef TN_TIMING
+  long long tsec[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
   for (int st = 0; st < nstage; ++st) {
+    TN_STAMP(5)
     // ---- row 0: the only waits of the stage.  Requests in flight, oldest first: a0 a1 a2 b0 .. b7 a3 (two reads each)
     tn_wait_lgkm<15>(a[0], b[0]);
     if (do_colsum) addsum(0, a[0]);
@@ -1155,10 +1167,14 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
     tn_wait_lgkm<4>(a[0], b[6]);  tn_mma2<SWAP>(acc[0][6], a[0], b[6]);
     tn_wait_lgkm<2>(a[0], b[7]);  tn_mma2<SWAP>(acc[0][7], a[0], b[7]);
     // ---- stage st + 1 published (every wave's pieces landed), stage st's buffer free (every wave's reads of it returned)
+    TN_STAMP(0)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+    TN_STAMP(1)
     if (NST == 4 && st + 3 < nstage) wait_vmcnt<8>(); else if (st + 2 < nstage) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    TN_STAMP(2)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    TN_STAMP(3)
     if (staged < nstage) stage();                              // stage st + NST into the buffer of stage st
     // (past the last stage the requests below fetch stale bytes of the ring that nobody uses)
     TN_FRAG_READ(a[0], fa[0] + ring_r)
@@ -1173,8 +1189,15 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
       TN_FRAG_READ(a[i], fa[i] + ring_r)
     }
     ring_r = ring_r == (unsigned)(NST - 1) * STAGEB ? 0u : ring_r + STAGEB;
+    TN_STAMP(4)
   }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the stale requests of the last stage: the next piece rewrites the ring
+#ifdef TN_TIMING
+  if (blockIdx.x == 0 && lane == 0) {
+    for (int k = 0; k < 6; ++k) tn_dbg[wave * 8 + k] = tsec[k];
+    tn_dbg[wave * 8 + 7] = nstage;
+  }
+#endif
 
   if constexpr (!SWAP) {
     // ---- epilogue of the shared-block forms (equal pieces, slices): lane (lr, g) holds rows 4g .. 4g+3 of column lr of a fragment --
@@ -1242,6 +1265,7 @@ __device__ __forceinline__ void tn256r_body(const Tn128Args& p, unsigned char* s
   if (do_colsum) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      if ((i >> 1) != wk) continue;
       float v = bsum[i];
       v += __shfl_xor(v, 16, 64);
       v += __shfl_xor(v, 32, 64);
@@ -2240,6 +2264,18 @@ extern "C" int asr_gemm_tn_grouped(int n, const void* const* dy, const int64_t* 
     else hipLaunchKernelGGL((gemm_tn256g_kernel<3, true, false>), dim3((unsigned)total), dim3(512), 3 * 32768, stream, ga);
   } else hipLaunchKernelGGL(gemm_tn128g_kernel<3>, dim3((unsigned)total), dim3(256), 3 * 16384, stream, ga);
   ASR_LAUNCH_CHECK();
+#ifdef TN_TIMING
+  if (big && !sched) {
+    long long h[64];
+    (void)hipStreamSynchronize(stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(tn_dbg), sizeof(h));
+    static int shown = 0;
+    if (shown++ % 8 == 3)
+      for (int w = 0; w < 8; w += 3)
+        fprintf(stderr, "tn256g timing wave %d stages %lld: row0 %lld lgkm %lld vmcnt %lld barrier %lld rest %lld looptop %lld (s_memtime ticks)\n", w, h[w * 8 + 7],
+                h[w * 8 + 0], h[w * 8 + 1], h[w * 8 + 2], h[w * 8 + 3], h[w * 8 + 4], h[w * 8 + 5]);
+  }
+#endif
   return ASR_OK;
 }
 
