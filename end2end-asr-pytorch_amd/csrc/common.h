@@ -85,12 +85,12 @@ __device__ __forceinline__ bf16x8_t asr_shift2_of12(const uint2& r0, const uint2
 }
 
 // acc += the 8 bf16 of v (fp32 accumulation): v_dot2c_f32_bf16 against (1, 1), one instruction per two values.  One asm block: the
-// accumulating chain is hazard-free, but a DOT result needs 3 wait states before any OTHER vector instruction reads it and the compiler
-// cannot see the opcode inside an asm -- hence the trailing s_nop.  (__builtin_amdgcn_fdot2_f32_bf16 picked one dword of the operand four
+// accumulating chain is hazard-free, but a DOT result needs 3 wait states before any OTHER vector instruction reads it (4 before one
+// overwrites it) and the compiler cannot see the opcode inside an asm -- hence the trailing s_nop.  (__builtin_amdgcn_fdot2_f32_bf16 picked one dword of the operand four
 // times when it was tried here, hipcc 7.0.)
 __device__ __forceinline__ void asr_sum8_bf16(float& acc, const bf16x8_t& v) {
   const u32x4_t u = __builtin_bit_cast(u32x4_t, v);
-  asm("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5\n\ts_nop 2"
+  asm("v_dot2c_f32_bf16 %0, %1, %2\n\tv_dot2c_f32_bf16 %0, %1, %3\n\tv_dot2c_f32_bf16 %0, %1, %4\n\tv_dot2c_f32_bf16 %0, %1, %5\n\ts_nop 3"
       : "+v"(acc) : "s"(0x3F803F80u), "v"(u[0]), "v"(u[1]), "v"(u[2]), "v"(u[3]));
 }
 
