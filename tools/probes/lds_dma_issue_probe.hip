@@ -15,11 +15,12 @@
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 constexpr int N_PIECES = 8192;
 
-__global__ __launch_bounds__(256, 1) void rate(int mode, const u32x4_t* __restrict__ src, long long* out) {
+template <int INFLIGHT>
+__global__ __launch_bounds__(1024, 1) void rate(int mode, const u32x4_t* __restrict__ src, long long* out) {
   __shared__ u32x4_t lds[4096];       // 64 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const u32x4_t* p = src + (size_t)blockIdx.x * 4096 * 64 + lane;          // 4 MB per workgroup, walked in 1 KB steps
-  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(__attribute__((address_space(3))) u32x4_t*)lds + (unsigned)wave * 16384u));
+  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(__attribute__((address_space(3))) u32x4_t*)lds + (unsigned)(wave & 3) * 16384u));
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0" : "=s"(keep));
   if (mode == 1) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" ::"s"(base));
@@ -46,13 +47,15 @@ __global__ __launch_bounds__(256, 1) void rate(int mode, const u32x4_t* __restri
         if ((u & 3) == 3) asm volatile("global_load_lds_dwordx4 %0, off offset:3072" ::"v"(ac - 3072) : "memory");
       }
     }
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (INFLIGHT == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (INFLIGHT == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   const long long t1 = (long long)__builtin_amdgcn_s_memtime();
   asm volatile("s_mov_b32 m0, %0" ::"s"(keep));
   if (lds[tid].x == 0xdeadbeefu) out[15] = 1;
-  if (lane == 0 && blockIdx.x == 0) out[wave] = t1 - t0;
+  if (lane == 0 && blockIdx.x == 0 && wave < 8) out[wave] = t1 - t0;
 }
 
 __global__ __launch_bounds__(64) void semantics(const unsigned* __restrict__ src, unsigned* out) {
@@ -91,7 +94,7 @@ int main() {
   for (int mode = 0; mode < 4; ++mode) {
     for (int rep = 0; rep < 2; ++rep) {
       (void)hipMemset(out, 0, 16 * 8);
-      hipLaunchKernelGGL(rate, dim3(256), dim3(256), 0, 0, mode, src, out);
+      hipLaunchKernelGGL(rate<8>, dim3(256), dim3(256), 0, 0, mode, src, out);
       if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "mode %d failed\n", mode); return 2; }
     }
     long long h[16];
@@ -99,5 +102,20 @@ int main() {
     printf("mode %d (%s): cycles per piece, waves 0-3: %.1f %.1f %.1f %.1f\n", mode, names[mode], h[0] / (double)N_PIECES, h[1] / (double)N_PIECES,
            h[2] / (double)N_PIECES, h[3] / (double)N_PIECES);
   }
+  // is that the path or the latency?  mode 1 (no M0 traffic) with more waves per CU and more pieces in flight per wave
+  for (int waves = 4; waves <= 16; waves *= 2)
+    for (int depth = 8; depth <= 48; depth = depth == 8 ? 24 : (depth == 24 ? 48 : 99)) {
+      for (int rep = 0; rep < 2; ++rep) {
+        (void)hipMemset(out, 0, 16 * 8);
+        if (depth == 8) hipLaunchKernelGGL(rate<8>, dim3(256), dim3(64 * waves), 0, 0, 1, src, out);
+        else if (depth == 24) hipLaunchKernelGGL(rate<24>, dim3(256), dim3(64 * waves), 0, 0, 1, src, out);
+        else hipLaunchKernelGGL(rate<48>, dim3(256), dim3(64 * waves), 0, 0, 1, src, out);
+        if (hipDeviceSynchronize() != hipSuccess) { fprintf(stderr, "sweep failed\n"); return 2; }
+      }
+      long long h[16];
+      (void)hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost);
+      const double cyc = h[0] / (double)N_PIECES;
+      printf("%2d waves per CU, <= %2d pieces in flight per wave: %.1f cycles per piece and wave = %.1f bytes per clock and CU\n", waves, depth, cyc, waves * 1024.0 / cyc);
+    }
   return 0;
 }
