@@ -915,16 +915,19 @@ class CEFn(Function):
         # (grad mode is always off inside Function.forward: "will backward run" is ctx.needs_input_grad)
         deferred = (global_count is None and red is not None and red.active and ctx.needs_input_grad[0]
                     and red.flat.stats.device == logits.device)
-        lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id, sums=red.flat.stats if deferred else None)
         if deferred:
+            lse, am, sums = ops.ce_fwd(logits, g, smoothing, pad_id, sums=red.flat.stats)      # (summed over ranks with the gradients: atomics into the zeroed tail)
             count = None                                               # backward: un-normalised sum
             sums = sums[:3]
+            loss = ops.ratio(sums[0:1], sums[1:2]).reshape(())
         else:
+            # per-block partial sums added in a fixed order: the same bits run to run, no zero fill, the mean from the same finish launch
+            lse, am, sums, loss = ops.ce_fwd_det(logits, g, smoothing, pad_id, den=global_count)
+            loss = loss.reshape(())
             count = global_count if global_count is not None else sums[1:2]
         ctx.t = (logits, g, lse, count)
         ctx.smoothing, ctx.pad_id, ctx.shape = smoothing, pad_id, pred.shape
         ctx.handover = _claim_logit_handover(logits) if ctx.needs_input_grad[0] else None
-        loss = ops.ratio(sums[0:1], global_count if global_count is not None else sums[1:2]).reshape(())
         ctx.mark_non_differentiable(sums, am)
         return loss, sums, am
 

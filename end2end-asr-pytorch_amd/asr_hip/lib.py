@@ -73,6 +73,9 @@ _SIGS = {
     "asr_decode_prepare": (_I, [_P, _I, _P, _P, _I, _P, _I, _P]),
     "asr_kv_append": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _P, _I, _P]),
     "asr_ce_fwd": (_I, [_P, _L, _P, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "asr_ce_partial_blocks": (_I, [_I]),
+    "asr_ce_fwd_partials": (_I, [_P, _L, _P, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "asr_ce_finish": (_I, [_P, _I, _P, _P, _P, _P]),
     "asr_argmax_rows": (_I, [_P, _L, _I, _I, _P, _P]),
     "asr_edit_distance_batch": (_I, [_P, _P, _P, _P, _I, _P]),
     "asr_logsoftmax_topk": (_I, [_P, _L, _I, _I, _I, _P, _P, _P]),

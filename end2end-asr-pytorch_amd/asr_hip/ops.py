@@ -580,6 +580,25 @@ def ce_fwd(logits, gold, smoothing, pad_id, sums=None):
     return lse, am, sums
 
 
+def ce_fwd_det(logits, gold, smoothing, pad_id, den=None):
+    """ce_fwd with reproducible statistics: per-block partial sums added in a fixed order, no zeroed destination, the loss
+    (= sums[0] / den, den = the non-PAD count unless a device scalar is given) from the same finish launch.
+    -> (row_lse, argmax, sums (3), loss (1))."""
+    M, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.stride(1) == 1 and gold.is_contiguous()
+    dev = logits.device
+    lse = torch.empty(M, device=dev, dtype=torch.float32)
+    am = torch.empty(M, device=dev, dtype=torch.int64)
+    nb = int(L.load().asr_ce_partial_blocks(M))
+    part = torch.empty(max(nb, 1) * 3, device=dev, dtype=torch.float32)
+    sums = torch.empty(3, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    L.call("asr_ce_fwd_partials", L.ptr(logits), logits.stride(0), L.ptr(gold), M, V, float(smoothing), int(pad_id), L.ptr(lse),
+           L.ptr(am), L.ptr(part), L.stream())
+    L.call("asr_ce_finish", L.ptr(part), nb, L.ptr(den), L.ptr(sums), L.ptr(loss), L.stream())
+    return lse, am, sums, loss
+
+
 # ------------------------------------------------------------------------------------------------ fp8 projections
 _fp8 = {"on": False}
 

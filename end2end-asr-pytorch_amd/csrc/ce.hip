@@ -18,7 +18,8 @@ constexpr int CE_ROWS = 8;
 
 __global__ __launch_bounds__(64 * CE_ROWS) void ce_fwd_kernel(const float* __restrict__ logits, int64_t ld,
                                                               const int64_t* __restrict__ gold, int M, int V, float eps, int pad_id,
-                                                              float* __restrict__ row_lse, int64_t* __restrict__ argmax, float* sums) {
+                                                              float* __restrict__ row_lse, int64_t* __restrict__ argmax, float* sums,
+                                                              float* __restrict__ partials) {
   __shared__ float s_part[CE_ROWS][3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.x * CE_ROWS + wave;
@@ -83,8 +84,34 @@ __global__ __launch_bounds__(64 * CE_ROWS) void ce_fwd_kernel(const float* __res
     float t = 0.f;
 #pragma unroll
     for (int w = 0; w < CE_ROWS; ++w) t += s_part[w][threadIdx.x];
-    if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
+    // partials (asr_ce_fwd_partials): the block's three sums go to their own slot and asr_ce_finish adds the slots in a fixed order -- the
+    // statistics (and the loss) are then the same bits run to run, and nobody has to zero a destination first
+    if (partials) partials[(int64_t)blockIdx.x * 3 + threadIdx.x] = t;
+    else if (t != 0.f) atomicAdd(sums + threadIdx.x, t);
   }
+}
+
+// sums[k] = the blocks' partial sums added in a fixed order (thread t takes blocks t, t + 256, ...; then a tree over the threads);
+// loss = sums[0] / (den ? den[0] : sums[1])
+__global__ __launch_bounds__(256) void ce_finish_kernel(const float* __restrict__ partials, int nblocks, const float* __restrict__ den,
+                                                        float* __restrict__ sums, float* __restrict__ loss) {
+  __shared__ float red[3][256];
+  const int tid = threadIdx.x;
+  float a[3] = {0.f, 0.f, 0.f};
+  for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) a[k] += partials[(int64_t)b * 3 + k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[k][tid] = a[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) red[k][tid] += red[k][tid + o];
+    __syncthreads();
+  }
+  if (tid < 3) sums[tid] = red[tid][0];
+  if (tid == 0) loss[0] = red[0][0] / (den ? den[0] : red[1][0]);
 }
 
 __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ logits, int64_t ld, int V,
@@ -205,7 +232,27 @@ extern "C" int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, 
   if (M == 0) return ASR_OK;
   AsrProfScope prof(ASR_OP_CE, s);
   hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + CE_ROWS - 1) / CE_ROWS), dim3(64 * CE_ROWS), 0, s, logits, ld, gold, M, V, smoothing, pad_id,
-                     row_lse, argmax, sums);
+                     row_lse, argmax, sums, (float*)nullptr);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_ce_partial_blocks(int M) { return M > 0 ? (M + CE_ROWS - 1) / CE_ROWS : 0; }
+
+extern "C" int asr_ce_fwd_partials(const float* logits, int64_t ld, const int64_t* gold, int M, int V, float smoothing, int pad_id,
+                                   float* row_lse, int64_t* argmax, float* partials, hipStream_t s) {
+  ASR_CHECK_ARG(logits && gold && row_lse && argmax && partials && M >= 0 && V > 0 && ld >= V && smoothing >= 0.f);
+  if (M == 0) return ASR_OK;
+  AsrProfScope prof(ASR_OP_CE, s);
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3((M + CE_ROWS - 1) / CE_ROWS), dim3(64 * CE_ROWS), 0, s, logits, ld, gold, M, V, smoothing, pad_id,
+                     row_lse, argmax, (float*)nullptr, partials);
+  ASR_LAUNCH_CHECK();
+  return ASR_OK;
+}
+
+extern "C" int asr_ce_finish(const float* partials, int nblocks, const float* den, float* sums, float* loss, hipStream_t s) {
+  ASR_CHECK_ARG(sums && loss && nblocks >= 0 && (partials || nblocks == 0));
+  hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(256), 0, s, partials, nblocks, den, sums, loss);
   ASR_LAUNCH_CHECK();
   return ASR_OK;
 }

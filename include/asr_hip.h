@@ -295,6 +295,14 @@ int asr_dec_finish(const float* logits, int64_t ld, int V, int64_t* tok, uint8_t
  * sums[2] += #(argmax == gold) over non-PAD rows.  argmax = lowest index among maxima.                        */
 int asr_ce_fwd(const float* logits, int64_t ld, const int64_t* gold, int M, int V, float smoothing, int pad_id,
                float* row_lse, int64_t* argmax, float* sums, asr_stream_t stream);
+/* The same with the statistics reproducible run to run and no zeroed destination (round 6): asr_ce_fwd_partials leaves the three sums of
+ * every block of rows in partials (asr_ce_partial_blocks(M) x 3 floats, every slot written), asr_ce_finish adds them in a fixed order into
+ * sums[0..2] (overwritten) and writes loss[0] = sums[0] / (den ? den[0] : sums[1]) -- utils/metrics.py:127-130's mean, asr_ratio included.
+ * (asr_ce_fwd adds with fp32 atomics: equal up to their order; it stays for destinations that are summed over ranks.)                  */
+int asr_ce_partial_blocks(int M);
+int asr_ce_fwd_partials(const float* logits, int64_t ld, const int64_t* gold, int M, int V, float smoothing, int pad_id,
+                        float* row_lse, int64_t* argmax, float* partials, asr_stream_t stream);
+int asr_ce_finish(const float* partials, int nblocks, const float* den, float* sums, float* loss, asr_stream_t stream);
 /* out[m] = lowest index of the row maximum (torch.topk(pred,1) at transformer.py:80, metrics.py:89)            */
 int asr_argmax_rows(const float* logits, int64_t ld, int M, int V, int64_t* out, asr_stream_t stream);
 /* HOST function (no device work): Levenshtein distances of n sequence pairs of int32 symbols (UTF-32 code points for CER, word

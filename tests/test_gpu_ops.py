@@ -777,6 +777,29 @@ def test_ce_matches_oracle(ops, smoothing, V):
     assert dl.stride(0) % 8 == 0
 
 
+@pytest.mark.parametrize("M,V", [(60, 35), (3200, 4364), (7, 4364)])
+def test_ce_statistics_in_a_fixed_order(ops, M, V):
+    """asr_ce_fwd_partials + asr_ce_finish (round 6): the three statistics and the mean loss are the SAME BITS run to run (per-block partial
+    sums added in a fixed order; asr_ce_fwd's fp32 atomics are equal only up to their order), equal to the atomics' to rounding, exact in
+    the two counts, and the loss is sums[0] / sums[1] -- or / den when a device scalar is given."""
+    g = torch.Generator().manual_seed(M + V)
+    logits = (torch.randn(M, V, generator=g) * 3).to(dev())
+    gold = torch.randint(1, V, (M,), generator=g)
+    gold[::5] = 0
+    gold = gold.to(dev())
+    runs = [ops.ce_fwd_det(logits, gold, 0.1, 0) for _ in range(4)]
+    lse0, am0, s0, l0 = runs[0]
+    for lse, am, s, l in runs[1:]:
+        assert torch.equal(s, s0) and torch.equal(l, l0) and torch.equal(lse, lse0) and torch.equal(am, am0)
+    lse_a, am_a, s_a = ops.ce_fwd(logits, gold, 0.1, 0)
+    assert torch.equal(lse_a, lse0) and torch.equal(am_a, am0)
+    assert s0[1].item() == s_a[1].item() == float((gold != 0).sum()) and s0[2].item() == s_a[2].item()
+    assert abs(s0[0].item() - s_a[0].item()) <= 1e-5 * abs(s_a[0].item())
+    assert l0.item() == (s0[0] / s0[1]).item()
+    den = torch.tensor([123.0], device=dev())
+    assert ops.ce_fwd_det(logits, gold, 0.1, 0, den=den)[3].item() == (s0[0] / den[0]).item()
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def test_adam_matches_oracle(ops):
     from oracle import asr_oracle as O
