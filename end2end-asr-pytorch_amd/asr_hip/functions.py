@@ -267,10 +267,62 @@ class FanOutFn(Function):
         return g, None, None
 
 
+# ================================================================================================ cross-attention K | V of all layers
+_cross_kv_on = os.environ.get("ASR_CROSS_KV", "1") != "0"        # (test arm: tests/test_gpu_model.py holds the one-GEMM form against the per-layer one)
+
+
+class CrossKVFn(Function):
+    """K | V projections of the encoder output for EVERY decoder layer as one GEMM (reference: transformer.py:296-299 calls each layer's
+    encoder_attn on the same encoder output; common_layers.py:181-187 projects it per layer).  The layers' weights (k0 v0 k1 v1 ...) and
+    biases are adjacent in the flat parameter buffers (FusedAdam._slot_order), so the stacked (L 2 H dk, D) weight is a view.
+    forward -> L views (B, Tk, 2 H dk) of one (B, Tk, L 2 H dk) tensor.  backward: the layers' attention backward kernels have written
+    dK | dV into box['dkv'] (the same layout) and returned no gradient for their views; here ONE data-gradient GEMM (contraction over all
+    layers: a single rounding of the sum the per-layer form rounded L times) and ONE weight-gradient problem."""
+
+    @staticmethod
+    def forward(ctx, enc, box, n_layers, *params):
+        ws, bs = list(params[:2 * n_layers]), list(params[2 * n_layers:])
+        fused = _Fused(ws, bs)
+        assert fused.ok
+        B, Tk, D = enc.shape
+        kv2 = enc.reshape(B * Tk, D).contiguous()
+        kv_all = fused.fwd(kv2).view(B, Tk, fused.N)
+        w = fused.N // n_layers
+        ctx.fused, ctx.box, ctx.kv2, ctx.shape, ctx.params = fused, box, kv2, (B, Tk, D), tuple(params)
+        ctx.set_materialize_grads(False)
+        return tuple(kv_all[:, :, l * w:(l + 1) * w] for l in range(n_layers))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, Tk, D = ctx.shape
+        assert all(g is None for g in grads), "a consumer of the stacked K | V returned a gradient instead of writing box['dkv']"
+        dkv = ctx.box.pop("dkv", None)
+        assert dkv is not None and ctx.box.pop("written", 0) == len(grads), "not every decoder layer wrote its dK | dV"
+        d_enc = ctx.fused.bwd(dkv.view(B * Tk, ctx.fused.N), ctx.kv2, need_dx=ctx.needs_input_grad[0])
+        P.grad_ready(*ctx.params)
+        return (None if d_enc is None else d_enc.view(B, Tk, D), None, None) + (None,) * len(ctx.params)
+
+
+def cross_kv_all(enc_out, layers):
+    """-> (per-layer K | V views, gradient box) when every layer's cross-attention block can take them, else None (per-layer projections)."""
+    if not _cross_kv_on or not enc_out.is_cuda or not all(hasattr(l, "encoder_attn") and hasattr(l.encoder_attn, "key_linear") for l in layers):
+        return None
+    eas = [l.encoder_attn for l in layers]
+    if any(ea.dim_key != ea.dim_value or ea.dim_key not in (16, 32, 64) for ea in eas):
+        return None
+    ws = [w for ea in eas for w in (ea.key_linear.weight, ea.value_linear.weight)]
+    bs = [b for ea in eas for b in (ea.key_linear.bias, ea.value_linear.bias)]
+    if not _Fused(ws, bs).ok:
+        return None
+    x = enc_out if enc_out.dtype == ops.compute_dtype() else enc_out.to(ops.compute_dtype())
+    box = {"n_layers": len(layers)}
+    return CrossKVFn.apply(x, box, len(layers), *ws, *bs), box
+
+
 # ================================================================================================ attention sub-layer
 class MHAFn(Function):
     @staticmethod
-    def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta, cfg):
+    def forward(ctx, q_in, kv_in, Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta, cfg, kv_pre=None):
         H, dk = cfg["H"], cfg["dk"]
         HD = H * dk
         B, Tq, D = q_in.shape
@@ -278,10 +330,13 @@ class MHAFn(Function):
         kv = q_in if self_attn else kv_in
         Tk = kv.shape[1]
         q2 = q_in.reshape(B * Tq, D).contiguous()
-        kv2 = kv.reshape(B * Tk, D).contiguous()
+        kv2 = None if kv_pre is not None else kv.reshape(B * Tk, D).contiguous()
         # one GEMM for Q|K|V (self attention) or K|V (cross attention) when the flat layout allows it
-        fused = _Fused([Wq, Wk, Wv], [bq, bk, bv]) if self_attn else _Fused([Wk, Wv], [bk, bv])
-        if fused.ok and self_attn:
+        fused = None if kv_pre is not None else (_Fused([Wq, Wk, Wv], [bq, bk, bv]) if self_attn else _Fused([Wk, Wv], [bk, bv]))
+        if kv_pre is not None:             # cross attention, K | V projected for all layers at once (CrossKVFn)
+            Q = _linear_fwd(q2, Wq, bq).view(B, Tq, HD)
+            K, V = kv_pre[:, :, :HD], kv_pre[:, :, HD:]
+        elif fused.ok and self_attn:
             qkv = fused.fwd(q2).view(B, Tq, 3 * HD)
             Q, K, V = qkv[:, :, :HD], qkv[:, :, HD:2 * HD], qkv[:, :, 2 * HD:]
         elif fused.ok:
@@ -312,7 +367,9 @@ class MHAFn(Function):
         ctx.t = (q2, kv2, Q, K, V, O, lse, Y, mean, rstd, O32)      # Y now holds z
         ctx.params = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, gamma, beta)
         ctx.shape = (B, Tq, Tk, D)
-        ctx.need_dkv = (not self_attn) and kv_in.requires_grad
+        ctx.kv_pre = kv_pre is not None
+        ctx.kv_pre_width = kv_pre.shape[2] if kv_pre is not None else 0
+        ctx.need_dkv = (not self_attn) and kv_pre is None and kv_in.requires_grad
         out = out.view(B, Tq, D)
         if attn is not None:
             ctx.mark_non_differentiable(attn)
@@ -333,7 +390,17 @@ class MHAFn(Function):
                                     P.grad_of(beta), p=cfg["p"], seed=seed_o)
         dO, delta = _out_proj_bwd(d_y, O.view(B * Tq, HD), O32, Wo, bo, Tq, dk)
         # gradient buffers mirror the forward layout so that the fused projections see one contiguous (M, 2|3*HD) operand
-        if fused.ok and ctx.self_attn:
+        if ctx.kv_pre:
+            # this layer's dK | dV go straight into the stacked (B, Tk, L 2 HD) buffer CrossKVFn.backward contracts (the first layer to run
+            # -- the last of the decoder -- allocates it; every layer writes its whole slice)
+            box, li = cfg["kv_pre_box"], cfg["kv_pre_layer"]
+            buf = box.get("dkv")
+            if buf is None:
+                buf = torch.empty((B, Tk, box["n_layers"] * 2 * HD), device=dout.device, dtype=Q.dtype)
+                box["dkv"] = buf
+            dQ = torch.empty((B, Tq, HD), device=dout.device, dtype=Q.dtype)
+            dK, dV = buf[:, :, li * 2 * HD:li * 2 * HD + HD], buf[:, :, li * 2 * HD + HD:(li + 1) * 2 * HD]
+        elif fused.ok and ctx.self_attn:
             dqkv = torch.empty((B, Tq, 3 * HD), device=dout.device, dtype=Q.dtype)
             dQ, dK, dV = dqkv[:, :, :HD], dqkv[:, :, HD:2 * HD], dqkv[:, :, 2 * HD:]
         elif fused.ok:
@@ -346,6 +413,11 @@ class MHAFn(Function):
                      causal=cfg.get("causal", False), scale=ctx.scale, p=cfg["p"], seed=seed_a, out=(dQ, dK, dV), o32=O32, delta=delta)
         d_kv = None
         # dq_in = d_res + dQ.Wq (+ dK.Wk + dV.Wv for self attention): accumulated straight into d_res
+        if ctx.kv_pre:
+            _linear_bwd(dQ.view(B * Tq, HD), q2, Wq, bq, dx_out=d_res, accumulate=True)
+            cfg["kv_pre_box"]["written"] = cfg["kv_pre_box"].get("written", 0) + 1
+            P.grad_ready(Wq, bq, Wo, bo, gamma, beta)           # (Wk, bk, Wv, bv: CrossKVFn.backward, after the last layer)
+            return (d_res.view(B, Tq, D), None) + (None,) * 12
         if fused.ok and ctx.self_attn:
             fused.bwd(dqkv.view(B * Tq, 3 * HD), q2, dx_out=d_res, accumulate=True)
         elif fused.ok:
@@ -370,7 +442,7 @@ class MHAFn(Function):
         if d_kv is not None:
             d_kv = d_kv.view(B, Tk, D)
         P.grad_ready(*ctx.params)
-        return (d_res.view(B, Tq, D), d_kv) + (None,) * 11
+        return (d_res.view(B, Tq, D), d_kv) + (None,) * 12
 
 
 # ================================================================================================ feed-forward sub-layer

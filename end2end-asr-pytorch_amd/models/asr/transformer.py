@@ -168,6 +168,15 @@ class Decoder(nn.Module):
                                      for _ in range(num_layers)])
         self.output_linear = nn.Linear(dim_model, num_trg_vocab, bias=False)
         nn.init.xavier_normal_(self.output_linear.weight)
+        # hint for the flat-parameter layout (utils/optimizer.py:_slot_order): every layer's cross-attention K / V projection reads the
+        # SAME encoder output (reference: transformer.py:296-299, 533-537), so adjacent weights make them one GEMM (forward below)
+        if rank == 0:
+            for li, layer in enumerate(self.layers):
+                ea = layer.encoder_attn
+                ea.key_linear.weight._asr_cross_kv = ("w", 2 * li)
+                ea.value_linear.weight._asr_cross_kv = ("w", 2 * li + 1)
+                ea.key_linear.bias._asr_cross_kv = ("b", 2 * li)
+                ea.value_linear.bias._asr_cross_kv = ("b", 2 * li + 1)
         if emb_trg_sharing:
             self.output_linear.weight = self.trg_embedding.weight
             self.x_logit_scale = dim_model ** -0.5
@@ -196,15 +205,18 @@ class Decoder(nn.Module):
         x = F_.EmbedFn.apply(seq_in, self.trg_embedding.weight, self.positional_encoding.pe[0], self.x_logit_scale, p,
                              constant.PAD_TOKEN, True)
         self_attns, enc_attns = [], []
-        # one gradient buffer for the encoder output: the layers' cross-attention backward GEMMs accumulate into it
+        # the cross-attention K | V projections of every layer as ONE GEMM on the encoder output (and one data-gradient GEMM, one weight-gradient
+        # problem in backward) where the flat parameter layout has their weights adjacent; else one gradient buffer for the encoder output
+        # that the layers' cross-attention backward GEMMs accumulate into
         box = None
+        kv_pre = F_.cross_kv_all(encoder_padded_outputs, self.layers) if len(self.layers) > 1 else None
         enc_views = [encoder_padded_outputs] * len(self.layers)
-        if torch.is_grad_enabled() and encoder_padded_outputs.requires_grad and len(self.layers) > 1:
+        if kv_pre is None and torch.is_grad_enabled() and encoder_padded_outputs.requires_grad and len(self.layers) > 1:
             box = {}
             enc_views = F_.FanOutFn.apply(encoder_padded_outputs, len(self.layers), box)
         for li, layer in enumerate(self.layers):
             x, sa, ea = layer(x, enc_views[li], row_keep=row_keep, self_key_pad=key_pad, enc_key_len=enc_len,
-                              need_attn=need_attn, kv_grad_box=box)
+                              need_attn=need_attn, kv_grad_box=box, kv_pre=None if kv_pre is None else (kv_pre[0][li], kv_pre[1], li))
             self_attns.append(sa)
             enc_attns.append(ea)
         # with --emb_trg_sharing the embedding backward (which runs last) reports the shared weight as ready
@@ -416,7 +428,7 @@ class DecoderLayer(nn.Module):
         self.pos_ffn = PositionwiseFeedForwardWithConv(dim_model, dim_inner, dropout=dropout)
 
     def forward(self, decoder_input, encoder_output, non_pad_mask=None, self_attn_mask=None, dec_enc_attn_mask=None,
-                row_keep=None, self_key_pad=None, enc_key_len=None, causal_only=False, need_attn=False, kv_grad_box=None):
+                row_keep=None, self_key_pad=None, enc_key_len=None, causal_only=False, need_attn=False, kv_grad_box=None, kv_pre=None):
         if causal_only:
             x, sa = self.self_attn(decoder_input, decoder_input, decoder_input, causal=True, need_attn=need_attn)
             x, ea = self.encoder_attn(x, encoder_output, encoder_output, need_attn=need_attn)
@@ -426,7 +438,11 @@ class DecoderLayer(nn.Module):
         generic = self_key_pad is None and self_attn_mask is not None
         x, sa = self.self_attn(decoder_input, decoder_input, decoder_input, mask=self_attn_mask if generic else None,
                                key_pad=self_key_pad, causal=not generic, row_keep=row_keep, need_attn=need_attn)
-        x, ea = self.encoder_attn(x, encoder_output, encoder_output, mask=dec_enc_attn_mask, key_len=enc_key_len,
-                                  row_keep=row_keep, need_attn=need_attn, kv_grad_box=kv_grad_box)
+        if kv_pre is not None:
+            x, ea = self.encoder_attn(x, encoder_output, encoder_output, mask=dec_enc_attn_mask, key_len=enc_key_len,
+                                      row_keep=row_keep, need_attn=need_attn, kv_pre=kv_pre)
+        else:
+            x, ea = self.encoder_attn(x, encoder_output, encoder_output, mask=dec_enc_attn_mask, key_len=enc_key_len,
+                                      row_keep=row_keep, need_attn=need_attn, kv_grad_box=kv_grad_box)
         x = self.pos_ffn(x, row_keep=row_keep)
         return x, sa, ea

@@ -112,7 +112,9 @@ class MultiHeadAttention(nn.Module):
         self.query_linear.weight._asr_qkv = True      # hint for the flat-parameter layout: q/k/v weights adjacent
 
     def forward(self, query, key, value, mask=None, key_len=None, key_pad=None, causal=False, row_keep=None,
-                need_attn=True, kv_grad_box=None):
+                need_attn=True, kv_grad_box=None, kv_pre=None):
+        """kv_pre: (projections (B, Tk, 2 H dk) of `key` by this block's K | V weights, their shared gradient box, layer index) when the
+        decoder ran all its layers' cross-attention projections as one GEMM (asr_hip.functions.cross_kv_all); `key` is then only a shape."""
         if key is not value:
             raise NotImplementedError("key and value must be the same tensor (as everywhere in the reference model)")
         if self.dim_key != self.dim_value or self.dim_key not in _HEAD_WIDTHS:
@@ -122,10 +124,14 @@ class MultiHeadAttention(nn.Module):
                    want_attn=need_attn, kv_grad_box=kv_grad_box)
         q = _to_compute(query)
         kv = None if key is query else _to_compute(key)
+        pre = None
+        if kv_pre is not None:
+            pre, cfg["kv_pre_box"], cfg["kv_pre_layer"] = kv_pre
+            kv = kv.detach()              # a shape only: the encoder output's gradient leaves through CrossKVFn
         res = F_.MHAFn.apply(q, kv, self.query_linear.weight, self.query_linear.bias, self.key_linear.weight,
                              self.key_linear.bias, self.value_linear.weight, self.value_linear.bias,
                              self.output_linear.weight, self.output_linear.bias, self.layer_norm.weight,
-                             self.layer_norm.bias, cfg)
+                             self.layer_norm.bias, cfg, pre)
         if need_attn:
             return res[0], res[1]
         return res, None

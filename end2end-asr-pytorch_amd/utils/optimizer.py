@@ -66,6 +66,18 @@ class FusedAdam(torch.optim.Adam):
             else:
                 out.append(plist[i])
                 i += 1
+        # the decoder's cross-attention K / V projections of ALL layers read the same encoder output: their weights (k0 v0 k1 v1 ...) and
+        # then their biases are made adjacent across the layers, so the K | V of every layer is ONE GEMM (round 6: models/asr/transformer.py
+        # Decoder tags them with `_asr_cross_kv = (kind, index)`; the per-layer K | V pair stays adjacent inside the group)
+        cross = [q for q in out if getattr(q, "_asr_cross_kv", None) is not None]
+        if cross:
+            ids = [id(q) for q in out]
+            first = min(ids.index(id(q)) for q in cross)
+            rest = [q for q in out if getattr(q, "_asr_cross_kv", None) is None]
+            grp = sorted([q for q in cross if q._asr_cross_kv[0] == "w"], key=lambda q: q._asr_cross_kv[1]) + \
+                  sorted([q for q in cross if q._asr_cross_kv[0] == "b"], key=lambda q: q._asr_cross_kv[1])
+            first = min(first, len(rest))
+            out = rest[:first] + grp + rest[first:]
         return out
 
     def _bind_state(self):

@@ -134,6 +134,61 @@ def test_bf16_mode_within_tolerance(golden_dir, name):
     assert loss2.item() < loss.item() + 1e-3          # one Adam step at Noam's first lr must not increase the loss
 
 
+def _build_random(golden_dir, precision, extra):
+    """vgg_tiny's data with a randomly initialised model of other widths (the golden models' H dk = 32 is below the flat buffers' 64-element
+    slot alignment: their projections never fuse)."""
+    from utils import constant
+    from utils.functions import init_optimizer, init_transformer_model
+    z = np.load(os.path.join(golden_dir, "vgg_tiny.npz"))
+    flags = str(z["flags"]).split()
+    for k, v in extra.items():
+        flags[flags.index(k) + 1] = v
+    args = constant.parse(flags + ["--precision", precision, "--cuda"])
+    l2i, i2l = _labels(int(z["V"]))
+    torch.manual_seed(1234)
+    model = init_transformer_model(args, l2i, i2l).cuda()
+    model.train()
+    return z, args, model, init_optimizer(args, model, "noam")
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_cross_attention_projections_of_all_layers_as_one_gemm(golden_dir, precision):
+    """asr_hip.functions.CrossKVFn (round 6): the K | V projections of the encoder output for every decoder layer as ONE GEMM, one
+    data-gradient GEMM and one weight-gradient problem -- against the per-layer form (ASR_CROSS_KV = 0's arm).  Forward values are the same
+    products in the same order (fp32: equal logits); the encoder output's gradient is summed over the layers inside one contraction
+    instead of layer by layer (bf16: rounded once instead of L times), so gradients agree to rounding, not to the bit."""
+    from asr_hip import functions as F_
+    wide = {"--num-layers": "3", "--dim-model": "64", "--dim-key": "32", "--dim-value": "32", "--dim-inner": "128", "--dim-emb": "64"}
+    res, ran = {}, {}
+    for on in (True, False):
+        z, args, model, opt = _build_random(golden_dir, precision, wide)
+        old = F_._cross_kv_on
+        F_._cross_kv_on = on
+        calls = []
+        fwd = F_.CrossKVFn.forward
+        F_.CrossKVFn.forward = staticmethod(lambda *a, **k: (calls.append(1), fwd(*a, **k))[1])
+        try:
+            pred, gold, hyp, loss, _ = step(model, opt, z, float(z["smoothing"]))
+            torch.cuda.synchronize()
+        finally:
+            F_._cross_kv_on = old
+            F_.CrossKVFn.forward = fwd
+        ran[on] = len(calls)
+        res[on] = (pred.detach().float().cpu(), float(loss.item()), {k: p.grad.detach().float().cpu().clone() for k, p in model.named_parameters()})
+    assert ran[True] == 1 and ran[False] == 0, ran          # the one-GEMM form ran in its arm (stacked weights adjacent in the flat buffers)
+    (p1, l1, g1), (p0, l0, g0) = res[True], res[False]
+    if precision == "fp32":
+        assert torch.equal(p1, p0) and l1 == l0
+    else:
+        assert float((p1 - p0).abs().max()) <= 1e-6 + 2e-2 * float(p0.abs().max())
+    tol = 2e-5 if precision == "fp32" else 3e-2
+    for k in g1:
+        if k.endswith("key_linear.bias"):
+            continue
+        den = float(g0[k].norm()) + 1e-30
+        assert float((g1[k] - g0[k]).norm()) / den <= tol, (k, float((g1[k] - g0[k]).norm()) / den)
+
+
 def test_module_api_standalone_mha_returns_reference_attn(golden_dir):
     """MultiHeadAttention called directly with a reference-style boolean mask returns (out, attn) with attn in the
     reference's (H*B, Tq, Tk) layout (common_layers.py:185-200)."""
