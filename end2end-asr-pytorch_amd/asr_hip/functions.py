@@ -305,9 +305,13 @@ class CrossKVFn(Function):
 
 def cross_kv_all(enc_out, layers):
     """-> (per-layer K | V views, gradient box) when every layer's cross-attention block can take them, else None (per-layer projections)."""
-    if not _cross_kv_on or not enc_out.is_cuda or not all(hasattr(l, "encoder_attn") and hasattr(l.encoder_attn, "key_linear") for l in layers):
+    if not _cross_kv_on or not enc_out.is_cuda or not all(hasattr(l, "encoder_attn") for l in layers):
         return None
     eas = [l.encoder_attn for l in layers]
+    # plain projections only (the low-rank blocks' key_linear / value_linear are factor pairs)
+    if not all(isinstance(getattr(ea, "key_linear", None), torch.nn.Linear) and isinstance(getattr(ea, "value_linear", None), torch.nn.Linear)
+               and hasattr(ea, "dim_key") for ea in eas):
+        return None
     if any(ea.dim_key != ea.dim_value or ea.dim_key not in (16, 32, 64) for ea in eas):
         return None
     ws = [w for ea in eas for w in (ea.key_linear.weight, ea.value_linear.weight)]
